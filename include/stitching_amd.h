@@ -1,0 +1,158 @@
+/* stitching_amd.h — C ABI of the MI355X (gfx950) warp + blend back end.
+ *
+ * Drop-in boundary for ONE hot path of OpenStitching/stitching: what
+ * stitching/warper.py and stitching/blender.py reach through cv2.  Each entry point
+ * below names the reference call site it replaces (file:line in /root/reference) and the
+ * OpenCV routine behind it.  Plain C types only: the library is loaded with ctypes
+ * (stitching_amd/_lib.py); INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions
+ *   - every function returns STX_OK (0) or a negative STX_ERR_* code; stx_last_error()
+ *     gives the thread-local message.  The Python shim raises StitchingError
+ *     (reference: stitching/stitching_error.py:1-2).
+ *   - one stx_ctx per (process, GPU); it owns one HIP stream and a caching device
+ *     allocator.  Calls on one ctx must be serialised by the caller (the reference is
+ *     single threaded: stitching/stitcher.py:247-254).  All work is enqueued on the ctx
+ *     stream; only stx_buf_to_host, stx_warp_roi(s), stx_ctx_sync and stx_prof_* wait.
+ *   - inputs are borrowed for the duration of the call; outputs are library-owned
+ *     opaque handles released with stx_buf_free / stx_blend_destroy / stx_ctx_destroy.
+ *   - images are row-major HWC exactly as numpy/cv2 hand them over: u8x3 BGR images,
+ *     u8x1 masks, optionally s16x3 (what stitching/blender.py:41 produces with astype).
+ *   - K and R are 3x3 row-major fp32 (the reference casts: stitching/warper.py:86,
+ *     stitching/camera_estimator.py:25-26).
+ */
+#ifndef STITCHING_AMD_H
+#define STITCHING_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STX_VERSION 100 /* 0.1.0 */
+
+/* status codes */
+#define STX_OK 0
+#define STX_ERR_INVALID (-1)     /* bad argument (mirrors CV_Assert failures)        */
+#define STX_ERR_HIP (-2)         /* HIP runtime error                                 */
+#define STX_ERR_OOM (-3)         /* device allocation failed                          */
+#define STX_ERR_STATE (-4)       /* call order violated (e.g. feed after finish)      */
+#define STX_ERR_UNSUPPORTED (-5) /* valid in the reference, not implemented here      */
+
+/* warper types: index into Warper.WARP_TYPE_CHOICES (stitching/warper.py:10-27) that this
+ * back end implements; cv.PyRotationWarper(type, scale) string -> id in the Python shim */
+#define STX_WARP_PLANE 0
+#define STX_WARP_AFFINE 1
+#define STX_WARP_CYLINDRICAL 2
+#define STX_WARP_SPHERICAL 3
+
+/* cv.INTER_* / cv.BORDER_* values used by stitching/warper.py:49-50,65-66 */
+#define STX_INTER_NEAREST 0
+#define STX_INTER_LINEAR 1
+#define STX_BORDER_CONSTANT 0
+#define STX_BORDER_REFLECT 2
+
+/* blender kinds (stitching/blender.py:8-12) */
+#define STX_BLEND_NO 0
+#define STX_BLEND_FEATHER 1
+#define STX_BLEND_MULTIBAND 2
+
+/* element types of stx_buf */
+#define STX_U8 0
+#define STX_S16 1
+#define STX_F32 2
+
+typedef struct stx_ctx stx_ctx;
+typedef struct stx_buf stx_buf;
+typedef struct stx_blender stx_blender;
+
+/* ---- library / context ------------------------------------------------------------ */
+int stx_version(void);
+const char* stx_last_error(void);
+int stx_device_count(int* out_n);
+int stx_ctx_create(int device, stx_ctx** out);
+int stx_ctx_destroy(stx_ctx* ctx);
+int stx_ctx_sync(stx_ctx* ctx);
+
+/* ---- device images ------------------------------------------------------------------
+ * Replaces the numpy.ndarray / cv.UMat values that cross the reference's cv2 boundary
+ * (stitching/blender.py:41 cv.UMat(img.astype(np.int16))). */
+int stx_buf_from_host(stx_ctx* ctx, const void* host, size_t host_stride_bytes, int w, int h, int channels, int elem,
+                      stx_buf** out);
+int stx_buf_alloc(stx_ctx* ctx, int w, int h, int channels, int elem, stx_buf** out);
+int stx_buf_to_host(const stx_buf* buf, void* host, size_t host_stride_bytes);
+/* rectangular sub-view sharing the parent's memory (numpy slicing in stitching/cropper.py:150-151) */
+int stx_buf_view(const stx_buf* buf, int x, int y, int w, int h, stx_buf** out);
+/* info = {w, h, channels, elem, stride_bytes, device} */
+int stx_buf_info(const stx_buf* buf, int64_t info[6]);
+/* device address of the first pixel (for zero-copy consumers, e.g. RCCL strip exchange) */
+int stx_buf_device_ptr(const stx_buf* buf, void** out);
+int stx_buf_free(stx_buf* buf);
+
+/* ---- Warper -------------------------------------------------------------------------
+ * stx_warp_roi  <- stitching/warper.py:79-82  cv.PyRotationWarper(type, scale).warpRoi(size, K, R)
+ *                  (RotationWarperBase::warpRoi / detectResultRoi[ByBorder],
+ *                   SphericalWarper::detectResultRoi, PlaneWarper/AffineWarper::warpRoi)
+ * out_xywh = (tl.x, tl.y, br.x-tl.x+1, br.y-tl.y+1). */
+int stx_warp_roi(stx_ctx* ctx, int type, float scale, const float K[9], const float R[9], int w, int h,
+                 int out_xywh[4]);
+/* batched form of the loop in stitching/warper.py:70-77 (one device pass, one sync) */
+int stx_warp_rois(stx_ctx* ctx, int type, float scale, int n, const float* K9s, const float* R9s, const int* sizes_wh,
+                  int* out_xywh);
+/* stx_warp <- stitching/warper.py:43-52 (interp=LINEAR, border=REFLECT, src u8x3) and
+ *             stitching/warper.py:58-68 (interp=NEAREST, border=CONSTANT, src u8x1):
+ *             cv.PyRotationWarper(type, scale).warp(src, K, R, interp, border)
+ *             = RotationWarperBase::buildMaps + cv::remap, fused: maps are never stored.
+ * out_tl receives the corner the reference discards (stitching/warper.py:45 `_`). */
+int stx_warp(stx_ctx* ctx, int type, float scale, const float K[9], const float R[9], const stx_buf* src, int interp,
+             int border, stx_buf** out, int out_tl[2]);
+/* fused form of warper.py:43-52 + 58-68 for one camera: one pass computes the backward map
+ * once and writes both the bilinear image and the nearest-neighbour 255-mask.
+ * out_img / out_mask may each be NULL. */
+int stx_warp_image_and_mask(stx_ctx* ctx, int type, float scale, const float K[9], const float R[9],
+                            const stx_buf* src, stx_buf** out_img, stx_buf** out_mask, int out_xywh[4]);
+/* stitching/warper.py:58-68 without allocating the 255-filled source (size only) */
+int stx_warp_mask(stx_ctx* ctx, int type, float scale, const float K[9], const float R[9], int w, int h,
+                  stx_buf** out_mask, int out_xywh[4]);
+
+/* ---- Blender ------------------------------------------------------------------------
+ * stx_result_roi    <- stitching/blender.py:24    cv.detail.resultRoi(corners, sizes)
+ * stx_blend_create  <- stitching/blender.py:27-38 Blender_createDefault(NO) | detail_MultiBandBlender()
+ *                      + setNumBands | detail_FeatherBlender() + setSharpness, then .prepare(dst_sz)
+ *                      (Blender/FeatherBlender/MultiBandBlender::prepare)
+ * stx_blend_feed    <- stitching/blender.py:40-41 blender.feed(UMat(int16 img), mask, corner)
+ *                      img: u8x3 (converted on load) or s16x3; mask u8x1
+ * stx_blend_finish  <- stitching/blender.py:43-48 blender.blend() + cv.convertScaleAbs(result)
+ *                      returns the u8x3 panorama and the u8 mask; consumes the blender
+ *                      (a second finish is STX_ERR_STATE; OpenCV releases dst_ in blend). */
+int stx_result_roi(int n, const int* corners_xy, const int* sizes_wh, int out_xywh[4]);
+int stx_blend_create(stx_ctx* ctx, int kind, int num_bands, float sharpness, const int roi_xywh[4],
+                     stx_blender** out);
+/* band count after MultiBandBlender::prepare's clamp (0 for the other kinds) */
+int stx_blend_num_bands(const stx_blender* b, int* out_num_bands);
+int stx_blend_feed(stx_blender* b, const stx_buf* img, const stx_buf* mask, int tlx, int tly);
+int stx_blend_finish(stx_blender* b, stx_buf** out_pano_u8, stx_buf** out_mask_u8);
+/* as stx_blend_finish, but also hands out the int16 result that blender.blend() returns
+ * before convertScaleAbs (stitching/blender.py:46); any out pointer may be NULL */
+int stx_blend_finish_ex(stx_blender* b, stx_buf** out_pano_u8, stx_buf** out_mask_u8, stx_buf** out_pano_s16);
+int stx_blend_destroy(stx_blender* b);
+
+/* ---- measurement hooks (bench.py) -----------------------------------------------------
+ * When enabled, every kernel launch on the ctx stream is bracketed by HIP events recorded
+ * on that stream; stx_prof_get reports per-kernel call count, summed duration and the
+ * algorithmic bytes the launch sites declared. */
+int stx_prof_enable(stx_ctx* ctx, int on);
+int stx_prof_reset(stx_ctx* ctx);
+int stx_prof_count(stx_ctx* ctx, int* out_n);
+int stx_prof_get(stx_ctx* ctx, int index, char* name, int name_cap, int64_t* calls, double* total_ms,
+                 double* algo_bytes);
+/* elapsed device time between two marks recorded on the ctx stream */
+int stx_mark(stx_ctx* ctx, int slot);
+int stx_mark_elapsed_ms(stx_ctx* ctx, int slot_begin, int slot_end, double* out_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STITCHING_AMD_H */

@@ -1,0 +1,16 @@
+"""stitching_amd — MI355X (gfx950) back end for the warp + blend hot path of
+OpenStitching/stitching: `Warper` and `Blender` with the reference's class surface, executed by
+hand-written HIP kernels behind the C ABI in include/stitching_amd.h (loaded with ctypes; no
+PyTorch, no OpenCV, no CPU fallback)."""
+from .blender import Blender
+from .camera import CameraParams
+from .config import device_resident, set_device_resident
+from .device import Context, DeviceImage, as_device, device_count, get_context, set_default_device
+from .stitching_error import StitchingError, StitchingWarning
+from .warper import Warper
+
+__all__ = [
+    "Blender", "CameraParams", "Context", "DeviceImage", "StitchingError", "StitchingWarning", "Warper",
+    "as_device", "device_count", "device_resident", "get_context", "set_default_device", "set_device_resident",
+]
+__version__ = "0.1.0"

@@ -1,0 +1,91 @@
+"""ctypes loader for libstitching_amd.so (C ABI: include/stitching_amd.h).
+
+There is NO CPU fallback: if the HIP library is missing or cannot be loaded the import of
+the hot path fails loudly.  Nothing here (or anywhere in stitching_amd) touches oracle/.
+"""
+import ctypes as C
+import os
+
+from .stitching_error import StitchingError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstitching_amd.so")
+
+# constants of include/stitching_amd.h
+STX_OK = 0
+WARP_PLANE, WARP_AFFINE, WARP_CYLINDRICAL, WARP_SPHERICAL = 0, 1, 2, 3
+INTER_NEAREST, INTER_LINEAR = 0, 1
+BORDER_CONSTANT, BORDER_REFLECT = 0, 2
+BLEND_NO, BLEND_FEATHER, BLEND_MULTIBAND = 0, 1, 2
+U8, S16, F32 = 0, 1, 2
+
+EXPORTS = (
+    "stx_version stx_last_error stx_device_count stx_ctx_create stx_ctx_destroy stx_ctx_sync "
+    "stx_buf_from_host stx_buf_alloc stx_buf_to_host stx_buf_view stx_buf_info stx_buf_device_ptr stx_buf_free "
+    "stx_warp_roi stx_warp_rois stx_warp stx_warp_image_and_mask stx_warp_mask "
+    "stx_result_roi stx_blend_create stx_blend_num_bands stx_blend_feed stx_blend_finish stx_blend_finish_ex "
+    "stx_blend_destroy stx_prof_enable stx_prof_reset stx_prof_count stx_prof_get stx_mark stx_mark_elapsed_ms"
+).split()
+
+_lib = None
+
+
+def build_hint():
+    return "build it with `make -C stitching_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`"
+
+
+def lib():
+    """Load the shared library once and declare every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: the HIP back end is not built ({build_hint()}). "
+                          "stitching_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, vpp = C.c_void_p, C.POINTER(C.c_void_p)
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+    L.stx_version.restype = C.c_int
+    L.stx_last_error.restype = C.c_char_p
+    L.stx_device_count.argtypes = [ip]
+    L.stx_ctx_create.argtypes = [C.c_int, vpp]
+    L.stx_ctx_destroy.argtypes = [vp]
+    L.stx_ctx_sync.argtypes = [vp]
+    L.stx_buf_from_host.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, vpp]
+    L.stx_buf_alloc.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vpp]
+    L.stx_buf_to_host.argtypes = [vp, vp, C.c_size_t]
+    L.stx_buf_view.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vpp]
+    L.stx_buf_info.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.stx_buf_device_ptr.argtypes = [vp, vpp]
+    L.stx_buf_free.argtypes = [vp]
+    L.stx_warp_roi.argtypes = [vp, C.c_int, C.c_float, fp, fp, C.c_int, C.c_int, ip]
+    L.stx_warp_rois.argtypes = [vp, C.c_int, C.c_float, C.c_int, fp, fp, ip, ip]
+    L.stx_warp.argtypes = [vp, C.c_int, C.c_float, fp, fp, vp, C.c_int, C.c_int, vpp, ip]
+    L.stx_warp_image_and_mask.argtypes = [vp, C.c_int, C.c_float, fp, fp, vp, vpp, vpp, ip]
+    L.stx_warp_mask.argtypes = [vp, C.c_int, C.c_float, fp, fp, C.c_int, C.c_int, vpp, ip]
+    L.stx_result_roi.argtypes = [C.c_int, ip, ip, ip]
+    L.stx_blend_create.argtypes = [vp, C.c_int, C.c_int, C.c_float, ip, vpp]
+    L.stx_blend_num_bands.argtypes = [vp, ip]
+    L.stx_blend_feed.argtypes = [vp, vp, vp, C.c_int, C.c_int]
+    L.stx_blend_finish.argtypes = [vp, vpp, vpp]
+    L.stx_blend_finish_ex.argtypes = [vp, vpp, vpp, vpp]
+    L.stx_blend_destroy.argtypes = [vp]
+    L.stx_prof_enable.argtypes = [vp, C.c_int]
+    L.stx_prof_reset.argtypes = [vp]
+    L.stx_prof_count.argtypes = [vp, ip]
+    L.stx_prof_get.argtypes = [vp, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                               C.POINTER(C.c_double)]
+    L.stx_mark.argtypes = [vp, C.c_int]
+    L.stx_mark_elapsed_ms.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    for name in EXPORTS:
+        if name not in ("stx_version", "stx_last_error"):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc):
+    """C status -> reference error convention (StitchingError; stitching/stitching_error.py:1-2)."""
+    if rc != STX_OK:
+        msg = lib().stx_last_error()
+        raise StitchingError(f"stitching_amd [{rc}]: {msg.decode(errors='replace') if msg else 'unknown error'}")

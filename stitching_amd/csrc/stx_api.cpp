@@ -1,0 +1,979 @@
+// stx_api.cpp — host side of the C ABI declared in include/stitching_amd.h.
+// Context / stream / caching allocator / profiler, device images, the Warper entry points
+// (ProjectorBase::setCameraParams, ROI finalisation) and the Blender state machines.
+// Compiled with -ffp-contract=off: the fp32 host arithmetic below restates OpenCV's baseline
+// (non-FMA) evaluation order.
+#include <algorithm>
+#include <array>
+#include <limits>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "stx_internal.h"
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void stx_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int stx_fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+STX_EXPORT const char* stx_last_error(void) { return g_err; }
+STX_EXPORT int stx_version(void) { return STX_VERSION; }
+
+STX_EXPORT int stx_device_count(int* out_n)
+{
+    if (!out_n) return stx_fail(STX_ERR_INVALID, "out_n is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *out_n = 0;
+        return stx_fail(STX_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *out_n = n;
+    return STX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// context, allocator
+// ---------------------------------------------------------------------------------------------
+int stx_set_device(stx_ctx* ctx)
+{
+    STX_HIP(hipSetDevice(ctx->device));
+    return STX_OK;
+}
+
+STX_EXPORT int stx_ctx_create(int device, stx_ctx** out)
+{
+    if (!out) return stx_fail(STX_ERR_INVALID, "out is null");
+    *out = nullptr;
+    int n = 0;
+    STX_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return stx_fail(STX_ERR_INVALID, "device %d out of range (have %d)", device, n);
+    STX_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    STX_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return stx_fail(STX_ERR_UNSUPPORTED, "device %d is %s; this library is built for gfx950 (MI355X) only", device,
+                        prop.gcnArchName);
+    std::unique_ptr<stx_ctx> ctx(new stx_ctx());
+    ctx->device = device;
+    STX_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->pinned_bytes = 1 << 16;
+    STX_HIP(hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault));
+    *out = ctx.release();
+    return STX_OK;
+}
+
+STX_EXPORT int stx_ctx_sync(stx_ctx* ctx)
+{
+    if (!ctx) return stx_fail(STX_ERR_INVALID, "ctx is null");
+    STX_TRY(stx_set_device(ctx));
+    STX_HIP(hipStreamSynchronize(ctx->stream));
+    return STX_OK;
+}
+
+STX_EXPORT int stx_ctx_destroy(stx_ctx* ctx)
+{
+    if (!ctx) return STX_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->block_size) hipFree(kv.first);
+    for (auto& p : ctx->prof_pending) { hipEventDestroy(p.start); hipEventDestroy(p.stop); }
+    for (auto e : ctx->event_pool) hipEventDestroy(e);
+    for (auto e : ctx->marks) if (e) hipEventDestroy(e);
+    if (ctx->pinned) hipHostFree(ctx->pinned);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return STX_OK;
+}
+
+static size_t bucket_of(size_t bytes)
+{
+    if (bytes < 256) return 256;
+    if (bytes >= (1u << 20)) return (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+    size_t b = 256;
+    while (b < bytes) b <<= 1;
+    return b;
+}
+
+// Stream-ordered caching allocator: every kernel of a ctx runs on ctx->stream, so a block
+// returned here can be handed out again immediately — its next user is enqueued after its last.
+int stx_dev_alloc(stx_ctx* ctx, size_t bytes, void** out)
+{
+    size_t b = bucket_of(bytes + 64);  // +64: kernels may over-read up to 12 bytes past a row
+    auto it = ctx->free_blocks.find(b);
+    if (it != ctx->free_blocks.end() && !it->second.empty()) {
+        *out = it->second.back();
+        it->second.pop_back();
+        return STX_OK;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, b);
+    if (e != hipSuccess) {
+        // release the cache and retry once
+        hipStreamSynchronize(ctx->stream);
+        for (auto& kv : ctx->free_blocks) {
+            for (void* q : kv.second) { ctx->bytes_allocated -= ctx->block_size[q]; ctx->block_size.erase(q); hipFree(q); }
+            kv.second.clear();
+        }
+        e = hipMalloc(&p, b);
+        if (e != hipSuccess) return stx_fail(STX_ERR_OOM, "hipMalloc(%zu) failed: %s", b, hipGetErrorString(e));
+    }
+    ctx->block_size[p] = b;
+    ctx->bytes_allocated += b;
+    *out = p;
+    return STX_OK;
+}
+
+void stx_dev_free(stx_ctx* ctx, void* p)
+{
+    if (!p) return;
+    auto it = ctx->block_size.find(p);
+    if (it == ctx->block_size.end()) return;
+    ctx->free_blocks[it->second].push_back(p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiler: HIP events around each launch, on the stream the kernel is launched on
+// ---------------------------------------------------------------------------------------------
+static hipEvent_t take_event(stx_ctx* ctx)
+{
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
+StxProfScope::StxProfScope(stx_ctx* c, const char* name, double algo_bytes) : ctx(c)
+{
+    if (!ctx->prof_on) return;
+    auto it = ctx->prof_index.find(name);
+    int idx;
+    if (it == ctx->prof_index.end()) {
+        idx = (int)ctx->prof.size();
+        ctx->prof.push_back(StxProfEntry());
+        ctx->prof.back().name = name;
+        ctx->prof_index[name] = idx;
+    } else {
+        idx = it->second;
+    }
+    ctx->prof[idx].calls += 1;
+    ctx->prof[idx].algo_bytes += algo_bytes;
+    StxPendingEvent pe;
+    pe.start = take_event(ctx);
+    pe.stop = take_event(ctx);
+    pe.entry = idx;
+    hipEventRecord(pe.start, ctx->stream);
+    ctx->prof_pending.push_back(pe);
+    pending = (int)ctx->prof_pending.size() - 1;
+}
+
+StxProfScope::~StxProfScope()
+{
+    if (pending >= 0) hipEventRecord(ctx->prof_pending[pending].stop, ctx->stream);
+}
+
+static void prof_collect(stx_ctx* ctx)
+{
+    if (ctx->prof_pending.empty()) return;
+    hipStreamSynchronize(ctx->stream);
+    for (auto& pe : ctx->prof_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) ctx->prof[pe.entry].total_ms += ms;
+        ctx->event_pool.push_back(pe.start);
+        ctx->event_pool.push_back(pe.stop);
+    }
+    ctx->prof_pending.clear();
+}
+
+STX_EXPORT int stx_prof_enable(stx_ctx* ctx, int on)
+{
+    if (!ctx) return stx_fail(STX_ERR_INVALID, "ctx is null");
+    STX_TRY(stx_set_device(ctx));
+    if (!on) prof_collect(ctx);
+    ctx->prof_on = on != 0;
+    return STX_OK;
+}
+
+STX_EXPORT int stx_prof_reset(stx_ctx* ctx)
+{
+    if (!ctx) return stx_fail(STX_ERR_INVALID, "ctx is null");
+    STX_TRY(stx_set_device(ctx));
+    prof_collect(ctx);
+    ctx->prof.clear();
+    ctx->prof_index.clear();
+    return STX_OK;
+}
+
+STX_EXPORT int stx_prof_count(stx_ctx* ctx, int* out_n)
+{
+    if (!ctx || !out_n) return stx_fail(STX_ERR_INVALID, "null argument");
+    STX_TRY(stx_set_device(ctx));
+    prof_collect(ctx);
+    *out_n = (int)ctx->prof.size();
+    return STX_OK;
+}
+
+STX_EXPORT int stx_prof_get(stx_ctx* ctx, int index, char* name, int name_cap, int64_t* calls, double* total_ms,
+                            double* algo_bytes)
+{
+    if (!ctx) return stx_fail(STX_ERR_INVALID, "ctx is null");
+    if (index < 0 || index >= (int)ctx->prof.size()) return stx_fail(STX_ERR_INVALID, "profile index out of range");
+    const StxProfEntry& e = ctx->prof[index];
+    if (name && name_cap > 0) {
+        strncpy(name, e.name.c_str(), name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (calls) *calls = e.calls;
+    if (total_ms) *total_ms = e.total_ms;
+    if (algo_bytes) *algo_bytes = e.algo_bytes;
+    return STX_OK;
+}
+
+STX_EXPORT int stx_mark(stx_ctx* ctx, int slot)
+{
+    if (!ctx || slot < 0 || slot >= 16) return stx_fail(STX_ERR_INVALID, "bad mark slot");
+    STX_TRY(stx_set_device(ctx));
+    if (!ctx->marks[slot]) STX_HIP(hipEventCreate(&ctx->marks[slot]));
+    STX_HIP(hipEventRecord(ctx->marks[slot], ctx->stream));
+    return STX_OK;
+}
+
+STX_EXPORT int stx_mark_elapsed_ms(stx_ctx* ctx, int a, int b, double* out_ms)
+{
+    if (!ctx || a < 0 || a >= 16 || b < 0 || b >= 16 || !out_ms || !ctx->marks[a] || !ctx->marks[b])
+        return stx_fail(STX_ERR_INVALID, "bad mark slots");
+    STX_TRY(stx_set_device(ctx));
+    STX_HIP(hipEventSynchronize(ctx->marks[b]));
+    float ms = 0.f;
+    STX_HIP(hipEventElapsedTime(&ms, ctx->marks[a], ctx->marks[b]));
+    *out_ms = ms;
+    return STX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device images
+// ---------------------------------------------------------------------------------------------
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int stx_buf_new(stx_ctx* ctx, int w, int h, int c, int elem, stx_buf** out)
+{
+    if (w <= 0 || h <= 0 || c <= 0 || c > 4 || elem < STX_U8 || elem > STX_F32)
+        return stx_fail(STX_ERR_INVALID, "bad image geometry %dx%dx%d elem %d", w, h, c, elem);
+    std::unique_ptr<stx_buf> b(new stx_buf());
+    b->ctx = ctx;
+    b->w = w; b->h = h; b->c = c; b->elem = elem;
+    // rows are 64-byte aligned and hold a whole number of 4-pixel groups (kernels store 4 px per lane)
+    b->stride = align_up(align_up((size_t)w, 4) * c * stx_elem_bytes(elem), 64);
+    STX_TRY(stx_dev_alloc(ctx, b->stride * h, &b->base));
+    b->ptr = (uint8_t*)b->base;
+    *out = b.release();
+    return STX_OK;
+}
+
+void stx_buf_retain(stx_buf* b) { b->refs.fetch_add(1); }
+
+void stx_buf_release(stx_buf* b)
+{
+    if (!b) return;
+    if (b->refs.fetch_sub(1) != 1) return;
+    if (b->parent) stx_buf_release(b->parent);
+    else stx_dev_free(b->ctx, b->base);
+    delete b;
+}
+
+STX_EXPORT int stx_buf_alloc(stx_ctx* ctx, int w, int h, int channels, int elem, stx_buf** out)
+{
+    if (!ctx || !out) return stx_fail(STX_ERR_INVALID, "null argument");
+    STX_TRY(stx_set_device(ctx));
+    return stx_buf_new(ctx, w, h, channels, elem, out);
+}
+
+STX_EXPORT int stx_buf_from_host(stx_ctx* ctx, const void* host, size_t host_stride, int w, int h, int channels,
+                                 int elem, stx_buf** out)
+{
+    if (!ctx || !host || !out) return stx_fail(STX_ERR_INVALID, "null argument");
+    STX_TRY(stx_set_device(ctx));
+    size_t row = (size_t)w * channels * stx_elem_bytes(elem);
+    if (host_stride < row) return stx_fail(STX_ERR_INVALID, "host stride %zu < row bytes %zu", host_stride, row);
+    stx_buf* b = nullptr;
+    STX_TRY(stx_buf_new(ctx, w, h, channels, elem, &b));
+    hipError_t e = hipMemcpy2DAsync(b->ptr, b->stride, host, host_stride, row, h, hipMemcpyHostToDevice, ctx->stream);
+    // the host buffer is only borrowed for this call
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        stx_buf_release(b);
+        return stx_fail(STX_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
+    }
+    *out = b;
+    return STX_OK;
+}
+
+STX_EXPORT int stx_buf_to_host(const stx_buf* buf, void* host, size_t host_stride)
+{
+    if (!buf || !host) return stx_fail(STX_ERR_INVALID, "null argument");
+    STX_TRY(stx_set_device(buf->ctx));
+    size_t row = (size_t)buf->w * buf->c * stx_elem_bytes(buf->elem);
+    if (host_stride < row) return stx_fail(STX_ERR_INVALID, "host stride %zu < row bytes %zu", host_stride, row);
+    STX_HIP(hipMemcpy2DAsync(host, host_stride, buf->ptr, buf->stride, row, buf->h, hipMemcpyDeviceToHost,
+                             buf->ctx->stream));
+    STX_HIP(hipStreamSynchronize(buf->ctx->stream));
+    return STX_OK;
+}
+
+STX_EXPORT int stx_buf_view(const stx_buf* buf, int x, int y, int w, int h, stx_buf** out)
+{
+    if (!buf || !out) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (x < 0 || y < 0 || w <= 0 || h <= 0 || x + w > buf->w || y + h > buf->h)
+        return stx_fail(STX_ERR_INVALID, "view (%d,%d,%d,%d) outside %dx%d", x, y, w, h, buf->w, buf->h);
+    stx_buf* root = const_cast<stx_buf*>(buf);
+    stx_buf* v = new stx_buf();
+    v->ctx = buf->ctx;
+    v->base = buf->base;
+    v->ptr = buf->ptr + (size_t)y * buf->stride + (size_t)x * buf->c * stx_elem_bytes(buf->elem);
+    v->w = w; v->h = h; v->c = buf->c; v->elem = buf->elem;
+    v->stride = buf->stride;
+    v->parent = root;
+    stx_buf_retain(root);
+    *out = v;
+    return STX_OK;
+}
+
+STX_EXPORT int stx_buf_info(const stx_buf* buf, int64_t info[6])
+{
+    if (!buf || !info) return stx_fail(STX_ERR_INVALID, "null argument");
+    info[0] = buf->w; info[1] = buf->h; info[2] = buf->c; info[3] = buf->elem;
+    info[4] = (int64_t)buf->stride; info[5] = buf->ctx->device;
+    return STX_OK;
+}
+
+STX_EXPORT int stx_buf_device_ptr(const stx_buf* buf, void** out)
+{
+    if (!buf || !out) return stx_fail(STX_ERR_INVALID, "null argument");
+    *out = buf->ptr;
+    return STX_OK;
+}
+
+STX_EXPORT int stx_buf_free(stx_buf* buf)
+{
+    stx_buf_release(buf);
+    return STX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// projector: ProjectorBase::setCameraParams, AffineWarper::getRTfromHomogeneous
+// ---------------------------------------------------------------------------------------------
+static void inv3x3_f32(const float* m, float* o)
+{
+    // cv::invert for a 3x3 CV_32F matrix: cofactors and determinant in double, cast to float
+    auto M = [&](int i, int j) { return (double)m[i * 3 + j]; };
+    double d = m[0] * (M(1, 1) * M(2, 2) - M(1, 2) * M(2, 1)) - m[1] * (M(1, 0) * M(2, 2) - M(1, 2) * M(2, 0)) +
+               m[2] * (M(1, 0) * M(2, 1) - M(1, 1) * M(2, 0));
+    if (d == 0.) {
+        for (int i = 0; i < 9; i++) o[i] = 0.f;
+        return;
+    }
+    d = 1. / d;
+    o[0] = (float)((M(1, 1) * M(2, 2) - M(1, 2) * M(2, 1)) * d);
+    o[1] = (float)((M(0, 2) * M(2, 1) - M(0, 1) * M(2, 2)) * d);
+    o[2] = (float)((M(0, 1) * M(1, 2) - M(0, 2) * M(1, 1)) * d);
+    o[3] = (float)((M(1, 2) * M(2, 0) - M(1, 0) * M(2, 2)) * d);
+    o[4] = (float)((M(0, 0) * M(2, 2) - M(0, 2) * M(2, 0)) * d);
+    o[5] = (float)((M(0, 2) * M(1, 0) - M(0, 0) * M(1, 2)) * d);
+    o[6] = (float)((M(1, 0) * M(2, 1) - M(1, 1) * M(2, 0)) * d);
+    o[7] = (float)((M(0, 1) * M(2, 0) - M(0, 0) * M(2, 1)) * d);
+    o[8] = (float)((M(0, 0) * M(1, 1) - M(0, 1) * M(1, 0)) * d);
+}
+
+static void mul3x3_f32(const float* a, const float* b, float* d)
+{
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            float t = a[i * 3] * b[j];
+            t = t + a[i * 3 + 1] * b[3 + j];
+            t = t + a[i * 3 + 2] * b[6 + j];
+            d[i * 3 + j] = t;
+        }
+}
+
+int stx_make_projector(int type, float scale, const float* K, const float* R, StxProjector* p)
+{
+    if (type < STX_WARP_PLANE || type > STX_WARP_SPHERICAL)
+        return stx_fail(STX_ERR_UNSUPPORTED, "warper type id %d is not implemented by this back end", type);
+    if (!K || !R) return stx_fail(STX_ERR_INVALID, "K and R must be 3x3 fp32");
+    for (int i = 0; i < 9; i++)
+        if (!std::isfinite(K[i]) || !std::isfinite(R[i])) return stx_fail(STX_ERR_INVALID, "K/R contain non-finite values");
+    p->type = type;
+    p->scale = scale;
+    float Rm[9], T[3] = {0.f, 0.f, 0.f};
+    if (type == STX_WARP_AFFINE) {
+        // R' = (H with H[0,2] = H[1,2] = 0)^T ; T' = -(R' * (H[0,2], H[1,2], 0)); scale is ignored (1.0)
+        float H[9];
+        memcpy(H, R, sizeof(H));
+        const float t0 = H[2], t1 = H[5];
+        H[2] = 0.f;
+        H[5] = 0.f;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) Rm[i * 3 + j] = H[j * 3 + i];
+        for (int i = 0; i < 3; i++) {
+            float v = Rm[i * 3] * t0;
+            v = v + Rm[i * 3 + 1] * t1;
+            v = v + Rm[i * 3 + 2] * 0.f;
+            T[i] = v * -1.f;
+        }
+        p->scale = 1.f;
+    } else {
+        memcpy(Rm, R, sizeof(Rm));
+    }
+    memcpy(p->k, K, sizeof(p->k));
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) p->rinv[i * 3 + j] = Rm[j * 3 + i];
+    float kinv[9];
+    inv3x3_f32(K, kinv);
+    mul3x3_f32(Rm, kinv, p->r_kinv);
+    mul3x3_f32(K, p->rinv, p->k_rinv);
+    p->t[0] = T[0]; p->t[1] = T[1]; p->t[2] = T[2];
+    return STX_OK;
+}
+
+// (int)float as x86 cvttss2si
+static int trunc_i32(float v)
+{
+    if (!(v >= -2147483648.f && v < 2147483648.f)) return INT_MIN;
+    return (int)v;
+}
+
+// PlaneProjector::mapForward for the 4 corners (PlaneWarper::detectResultRoi)
+static void plane_forward(const StxProjector& p, float x, float y, float& u, float& v)
+{
+    const float* rk = p.r_kinv;
+    float x_ = rk[0] * x;
+    x_ = x_ + rk[1] * y;
+    x_ = x_ + rk[2];
+    float y_ = rk[3] * x;
+    y_ = y_ + rk[4] * y;
+    y_ = y_ + rk[5];
+    float z_ = rk[6] * x;
+    z_ = z_ + rk[7] * y;
+    z_ = z_ + rk[8];
+    float q = x_ / z_;
+    q = q * (1 - p.t[2]);
+    x_ = p.t[0] + q;
+    q = y_ / z_;
+    q = q * (1 - p.t[2]);
+    y_ = p.t[1] + q;
+    u = p.scale * x_;
+    v = p.scale * y_;
+}
+
+static void finish_roi(const StxProjector& p, int w, int h, const float* mm, int* out_xywh)
+{
+    int tlx = trunc_i32(mm[0]), tly = trunc_i32(mm[1]), brx = trunc_i32(mm[2]), bry = trunc_i32(mm[3]);
+    if (p.type == STX_WARP_SPHERICAL) {
+        // SphericalWarper::detectResultRoi: include the poles when they project inside the image
+        float tl_uf = (float)tlx, tl_vf = (float)tly, br_uf = (float)brx, br_vf = (float)bry;
+        float x = p.rinv[1], y = p.rinv[4], z = p.rinv[7];
+        if (y > 0.f) {
+            float a = p.k[0] * x;
+            a = a + p.k[1] * y;
+            float x_ = a / z + p.k[2];
+            float y_ = p.k[4] * y / z + p.k[5];
+            if (x_ > 0.f && x_ < w && y_ > 0.f && y_ < h) {
+                float pv = static_cast<float>(3.14159265358979323846 * p.scale);
+                tl_uf = std::min(tl_uf, 0.f); tl_vf = std::min(tl_vf, pv);
+                br_uf = std::max(br_uf, 0.f); br_vf = std::max(br_vf, pv);
+            }
+        }
+        y = -p.rinv[4];
+        if (y > 0.f) {
+            float a = p.k[0] * x;
+            a = a + p.k[1] * y;
+            float x_ = a / z + p.k[2];
+            float y_ = p.k[4] * y / z + p.k[5];
+            if (x_ > 0.f && x_ < w && y_ > 0.f && y_ < h) {
+                tl_uf = std::min(tl_uf, 0.f); tl_vf = std::min(tl_vf, 0.f);
+                br_uf = std::max(br_uf, 0.f); br_vf = std::max(br_vf, 0.f);
+            }
+        }
+        tlx = trunc_i32(tl_uf); tly = trunc_i32(tl_vf); brx = trunc_i32(br_uf); bry = trunc_i32(br_vf);
+    }
+    out_xywh[0] = tlx; out_xywh[1] = tly;
+    out_xywh[2] = brx - tlx + 1; out_xywh[3] = bry - tly + 1;
+}
+
+static int rois_impl(stx_ctx* ctx, int n, const StxProjector* projs, const int* sizes_wh, int* out_xywh)
+{
+    std::vector<float> mm(4 * (size_t)n);
+    std::vector<int> dev_idx;
+    for (int i = 0; i < n; i++) {
+        const int w = sizes_wh[2 * i], h = sizes_wh[2 * i + 1];
+        if (w <= 0 || h <= 0) return stx_fail(STX_ERR_INVALID, "image size %dx%d", w, h);
+        if (projs[i].type == STX_WARP_PLANE || projs[i].type == STX_WARP_AFFINE) {
+            float mn_u = std::numeric_limits<float>::max(), mn_v = mn_u, mx_u = -mn_u, mx_v = -mn_u, u, v;
+            const float xs[2] = {0.f, (float)(w - 1)}, ys[2] = {0.f, (float)(h - 1)};
+            for (int a = 0; a < 2; a++)
+                for (int b = 0; b < 2; b++) {
+                    plane_forward(projs[i], xs[a], ys[b], u, v);
+                    mn_u = std::min(mn_u, u); mn_v = std::min(mn_v, v);
+                    mx_u = std::max(mx_u, u); mx_v = std::max(mx_v, v);
+                }
+            mm[4 * i] = mn_u; mm[4 * i + 1] = mn_v; mm[4 * i + 2] = mx_u; mm[4 * i + 3] = mx_v;
+        } else {
+            dev_idx.push_back(i);
+        }
+    }
+    if (!dev_idx.empty()) {
+        const int m = (int)dev_idx.size();
+        std::vector<StxProjector> dp(m);
+        std::vector<int> dsz(2 * (size_t)m);
+        std::vector<float> dmm(4 * (size_t)m);
+        for (int j = 0; j < m; j++) {
+            dp[j] = projs[dev_idx[j]];
+            dsz[2 * j] = sizes_wh[2 * dev_idx[j]];
+            dsz[2 * j + 1] = sizes_wh[2 * dev_idx[j] + 1];
+        }
+        STX_TRY(stx_launch_roi_minmax(ctx, m, dp.data(), dsz.data(), dmm.data()));
+        for (int j = 0; j < m; j++) memcpy(&mm[4 * dev_idx[j]], &dmm[4 * j], 16);
+    }
+    for (int i = 0; i < n; i++) finish_roi(projs[i], sizes_wh[2 * i], sizes_wh[2 * i + 1], &mm[4 * i], out_xywh + 4 * i);
+    return STX_OK;
+}
+
+// ROI cache: the reference recomputes detectResultRoi inside every warp()/warpRoi() call
+// (stitching/warper.py:44,59,80 build three warpers per image); we compute it once per camera.
+struct RoiKey {
+    int type, w, h;
+    float scale, K[9], R[9];
+    bool operator<(const RoiKey& o) const { return memcmp(this, &o, sizeof(RoiKey)) < 0; }
+};
+static thread_local std::map<RoiKey, std::array<int, 4>>* g_roi_cache = nullptr;
+
+static RoiKey make_key(int type, float scale, const float* K, const float* R, int w, int h)
+{
+    RoiKey k;
+    memset(&k, 0, sizeof(k));
+    k.type = type; k.w = w; k.h = h; k.scale = scale;
+    memcpy(k.K, K, 36);
+    memcpy(k.R, R, 36);
+    return k;
+}
+
+static int roi_cached(stx_ctx* ctx, int type, float scale, const float* K, const float* R, int w, int h,
+                      const StxProjector& proj, int* out)
+{
+    if (!g_roi_cache) g_roi_cache = new std::map<RoiKey, std::array<int, 4>>();
+    RoiKey key = make_key(type, scale, K, R, w, h);
+    auto it = g_roi_cache->find(key);
+    if (it != g_roi_cache->end()) {
+        memcpy(out, it->second.data(), 16);
+        return STX_OK;
+    }
+    int sz[2] = {w, h};
+    STX_TRY(rois_impl(ctx, 1, &proj, sz, out));
+    if (g_roi_cache->size() > 8192) g_roi_cache->clear();
+    (*g_roi_cache)[key] = {out[0], out[1], out[2], out[3]};
+    return STX_OK;
+}
+
+STX_EXPORT int stx_warp_roi(stx_ctx* ctx, int type, float scale, const float K[9], const float R[9], int w, int h,
+                            int out_xywh[4])
+{
+    if (!ctx || !out_xywh) return stx_fail(STX_ERR_INVALID, "null argument");
+    STX_TRY(stx_set_device(ctx));
+    StxProjector p;
+    STX_TRY(stx_make_projector(type, scale, K, R, &p));
+    if (w <= 0 || h <= 0) return stx_fail(STX_ERR_INVALID, "image size %dx%d", w, h);
+    return roi_cached(ctx, type, scale, K, R, w, h, p, out_xywh);
+}
+
+STX_EXPORT int stx_warp_rois(stx_ctx* ctx, int type, float scale, int n, const float* K9s, const float* R9s,
+                             const int* sizes_wh, int* out_xywh)
+{
+    if (!ctx || !K9s || !R9s || !sizes_wh || !out_xywh || n < 0) return stx_fail(STX_ERR_INVALID, "bad argument");
+    if (n == 0) return STX_OK;
+    STX_TRY(stx_set_device(ctx));
+    std::vector<StxProjector> ps(n);
+    for (int i = 0; i < n; i++) STX_TRY(stx_make_projector(type, scale, K9s + 9 * i, R9s + 9 * i, &ps[i]));
+    STX_TRY(rois_impl(ctx, n, ps.data(), sizes_wh, out_xywh));
+    if (!g_roi_cache) g_roi_cache = new std::map<RoiKey, std::array<int, 4>>();
+    if (g_roi_cache->size() > 8192) g_roi_cache->clear();
+    for (int i = 0; i < n; i++)
+        (*g_roi_cache)[make_key(type, scale, K9s + 9 * i, R9s + 9 * i, sizes_wh[2 * i], sizes_wh[2 * i + 1])] = {
+            out_xywh[4 * i], out_xywh[4 * i + 1], out_xywh[4 * i + 2], out_xywh[4 * i + 3]};
+    return STX_OK;
+}
+
+static int warp_impl(stx_ctx* ctx, int type, float scale, const float* K, const float* R, const stx_buf* src, int sw,
+                     int sh, bool want_img, bool want_mask, bool nearest_src, stx_buf** out_img, stx_buf** out_mask,
+                     int* out_xywh)
+{
+    StxProjector p;
+    STX_TRY(stx_make_projector(type, scale, K, R, &p));
+    int roi[4];
+    STX_TRY(roi_cached(ctx, type, scale, K, R, sw, sh, p, roi));
+    if (roi[2] <= 0 || roi[3] <= 0 || (long long)roi[2] * roi[3] > (1ll << 33))
+        return stx_fail(STX_ERR_INVALID, "degenerate warp roi %dx%d (camera parameters?)", roi[2], roi[3]);
+    stx_buf *bi = nullptr, *bm = nullptr;
+    if (want_img) STX_TRY(stx_buf_new(ctx, roi[2], roi[3], nearest_src ? 1 : 3, STX_U8, &bi));
+    if (want_mask) {
+        int rc = stx_buf_new(ctx, roi[2], roi[3], 1, STX_U8, &bm);
+        if (rc != STX_OK) { stx_buf_release(bi); return rc; }
+    }
+    StxWarpLaunch L;
+    L.proj = p;
+    L.tlx = roi[0]; L.tly = roi[1]; L.dw = roi[2]; L.dh = roi[3];
+    L.src = src ? src->ptr : nullptr;
+    L.sw = sw; L.sh = sh;
+    L.sstride = src ? src->stride : 0;
+    L.src_channels = src ? src->c : 0;
+    L.nearest_src = nearest_src ? 1 : 0;
+    if (nearest_src) {  // generic INTER_NEAREST warp of a u8x1 source: the "mask" path writes the image
+        L.dimg = nullptr; L.dimg_stride = 0;
+        L.dmask = bi->ptr; L.dmask_stride = bi->stride;
+    } else {
+        L.dimg = bi ? bi->ptr : nullptr; L.dimg_stride = bi ? bi->stride : 0;
+        L.dmask = bm ? bm->ptr : nullptr; L.dmask_stride = bm ? bm->stride : 0;
+    }
+    int rc = stx_launch_warp(ctx, L);
+    if (rc != STX_OK) { stx_buf_release(bi); stx_buf_release(bm); return rc; }
+    if (out_img) *out_img = bi;
+    if (out_mask) *out_mask = bm;
+    if (out_xywh) memcpy(out_xywh, roi, 16);
+    return STX_OK;
+}
+
+STX_EXPORT int stx_warp(stx_ctx* ctx, int type, float scale, const float K[9], const float R[9], const stx_buf* src,
+                        int interp, int border, stx_buf** out, int out_tl[2])
+{
+    if (!ctx || !src || !out) return stx_fail(STX_ERR_INVALID, "null argument");
+    STX_TRY(stx_set_device(ctx));
+    if (src->elem != STX_U8) return stx_fail(STX_ERR_INVALID, "warp source must be 8-bit");
+    int roi[4];
+    if (interp == STX_INTER_LINEAR && border == STX_BORDER_REFLECT) {
+        if (src->c != 3) return stx_fail(STX_ERR_UNSUPPORTED, "INTER_LINEAR warp needs a 3-channel u8 image");
+        STX_TRY(warp_impl(ctx, type, scale, K, R, src, src->w, src->h, true, false, false, out, nullptr, roi));
+    } else if (interp == STX_INTER_NEAREST && border == STX_BORDER_CONSTANT) {
+        if (src->c != 1) return stx_fail(STX_ERR_UNSUPPORTED, "INTER_NEAREST warp needs a 1-channel u8 mask");
+        STX_TRY(warp_impl(ctx, type, scale, K, R, src, src->w, src->h, true, false, true, out, nullptr, roi));
+    } else {
+        return stx_fail(STX_ERR_UNSUPPORTED,
+                        "only (INTER_LINEAR, BORDER_REFLECT) and (INTER_NEAREST, BORDER_CONSTANT) are on the path "
+                        "(stitching/warper.py:49-50,65-66)");
+    }
+    if (out_tl) { out_tl[0] = roi[0]; out_tl[1] = roi[1]; }
+    return STX_OK;
+}
+
+STX_EXPORT int stx_warp_image_and_mask(stx_ctx* ctx, int type, float scale, const float K[9], const float R[9],
+                                       const stx_buf* src, stx_buf** out_img, stx_buf** out_mask, int out_xywh[4])
+{
+    if (!ctx || !src) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (!out_img && !out_mask) return stx_fail(STX_ERR_INVALID, "nothing requested");
+    STX_TRY(stx_set_device(ctx));
+    if (src->elem != STX_U8 || src->c != 3) return stx_fail(STX_ERR_INVALID, "warp source must be u8x3");
+    return warp_impl(ctx, type, scale, K, R, src, src->w, src->h, out_img != nullptr, out_mask != nullptr, false,
+                     out_img, out_mask, out_xywh);
+}
+
+STX_EXPORT int stx_warp_mask(stx_ctx* ctx, int type, float scale, const float K[9], const float R[9], int w, int h,
+                             stx_buf** out_mask, int out_xywh[4])
+{
+    if (!ctx || !out_mask) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (w <= 0 || h <= 0) return stx_fail(STX_ERR_INVALID, "image size %dx%d", w, h);
+    STX_TRY(stx_set_device(ctx));
+    return warp_impl(ctx, type, scale, K, R, nullptr, w, h, false, true, false, nullptr, out_mask, out_xywh);
+}
+
+// ---------------------------------------------------------------------------------------------
+// blenders
+// ---------------------------------------------------------------------------------------------
+STX_EXPORT int stx_result_roi(int n, const int* corners_xy, const int* sizes_wh, int out_xywh[4])
+{
+    if (n <= 0 || !corners_xy || !sizes_wh || !out_xywh) return stx_fail(STX_ERR_INVALID, "bad argument");
+    int tlx = INT_MAX, tly = INT_MAX, brx = INT_MIN, bry = INT_MIN;
+    for (int i = 0; i < n; i++) {
+        tlx = std::min(tlx, corners_xy[2 * i]);
+        tly = std::min(tly, corners_xy[2 * i + 1]);
+        brx = std::max(brx, corners_xy[2 * i] + sizes_wh[2 * i]);
+        bry = std::max(bry, corners_xy[2 * i + 1] + sizes_wh[2 * i + 1]);
+    }
+    out_xywh[0] = tlx; out_xywh[1] = tly; out_xywh[2] = brx - tlx; out_xywh[3] = bry - tly;
+    return STX_OK;
+}
+
+struct stx_blender {
+    stx_ctx* ctx = nullptr;
+    int kind = 0, num_bands = 0;
+    float sharpness = 0.02f;
+    int rx = 0, ry = 0, rw = 0, rh = 0;  // dst_roi_ (padded for multiband)
+    int fw = 0, fh = 0;                  // dst_roi_final_ size
+    bool finished = false;
+    // multiband (deferred gather)
+    std::vector<StxMbImage> images;
+    std::vector<stx_buf*> held;
+    std::vector<void*> pyr_allocs;
+    // no / feather (accumulate per feed, as OpenCV)
+    void* dst = nullptr; long long dst_stride = 0;      // s16 HWC
+    void* dmask = nullptr; long long dmask_stride = 0;  // u8
+    void* dw = nullptr; long long dw_stride = 0;        // f32
+};
+
+static void blender_release(stx_blender* b)
+{
+    for (stx_buf* h : b->held) stx_buf_release(h);
+    b->held.clear();
+    for (void* p : b->pyr_allocs) stx_dev_free(b->ctx, p);
+    b->pyr_allocs.clear();
+    stx_dev_free(b->ctx, b->dst); b->dst = nullptr;
+    stx_dev_free(b->ctx, b->dmask); b->dmask = nullptr;
+    stx_dev_free(b->ctx, b->dw); b->dw = nullptr;
+    b->images.clear();
+}
+
+STX_EXPORT int stx_blend_create(stx_ctx* ctx, int kind, int num_bands, float sharpness, const int roi_xywh[4],
+                                stx_blender** out)
+{
+    if (!ctx || !roi_xywh || !out) return stx_fail(STX_ERR_INVALID, "null argument");
+    STX_TRY(stx_set_device(ctx));
+    if (kind < STX_BLEND_NO || kind > STX_BLEND_MULTIBAND) return stx_fail(STX_ERR_INVALID, "unknown blender kind %d", kind);
+    int w = roi_xywh[2], h = roi_xywh[3];
+    if (w <= 0 || h <= 0) return stx_fail(STX_ERR_INVALID, "empty destination roi %dx%d", w, h);
+    std::unique_ptr<stx_blender> b(new stx_blender());
+    b->ctx = ctx;
+    b->kind = kind;
+    b->sharpness = sharpness;
+    b->fw = w; b->fh = h;
+    if (kind == STX_BLEND_MULTIBAND) {
+        if (num_bands < 0) return stx_fail(STX_ERR_INVALID, "num_bands %d", num_bands);  // CV_Assert(val >= 0)
+        // MultiBandBlender::prepare: crop unnecessary bands, pad to a multiple of 2^bands
+        double max_len = (double)std::max(w, h);
+        int nb = std::min(num_bands, (int)std::ceil(std::log(max_len) / std::log(2.0)));
+        if (nb > STX_MAX_BANDS) nb = STX_MAX_BANDS;
+        b->num_bands = nb;
+        w += ((1 << nb) - w % (1 << nb)) % (1 << nb);
+        h += ((1 << nb) - h % (1 << nb)) % (1 << nb);
+    }
+    b->rx = roi_xywh[0]; b->ry = roi_xywh[1]; b->rw = w; b->rh = h;
+    if (kind != STX_BLEND_MULTIBAND) {
+        b->dst_stride = (long long)align_up((size_t)w * 6, 64);
+        b->dmask_stride = (long long)align_up((size_t)w, 64);
+        STX_TRY(stx_dev_alloc(ctx, (size_t)b->dst_stride * h, &b->dst));
+        int rc = stx_dev_alloc(ctx, (size_t)b->dmask_stride * h, &b->dmask);
+        if (rc == STX_OK && kind == STX_BLEND_FEATHER) {
+            b->dw_stride = (long long)align_up((size_t)w * 4, 64);
+            rc = stx_dev_alloc(ctx, (size_t)b->dw_stride * h, &b->dw);
+        }
+        if (rc != STX_OK) { blender_release(b.get()); return rc; }
+        hipError_t e = hipMemsetAsync(b->dst, 0, (size_t)b->dst_stride * h, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(b->dmask, 0, (size_t)b->dmask_stride * h, ctx->stream);
+        if (e == hipSuccess && b->dw) e = hipMemsetAsync(b->dw, 0, (size_t)b->dw_stride * h, ctx->stream);
+        if (e != hipSuccess) { blender_release(b.get()); return stx_fail(STX_ERR_HIP, "memset: %s", hipGetErrorString(e)); }
+    }
+    *out = b.release();
+    return STX_OK;
+}
+
+STX_EXPORT int stx_blend_num_bands(const stx_blender* b, int* out_num_bands)
+{
+    if (!b || !out_num_bands) return stx_fail(STX_ERR_INVALID, "null argument");
+    *out_num_bands = b->num_bands;
+    return STX_OK;
+}
+
+static int mb_feed(stx_blender* b, const stx_buf* img, const stx_buf* mask, int tlx, int tly)
+{
+    stx_ctx* ctx = b->ctx;
+    const int nb = b->num_bands, w = img->w, h = img->h;
+    // MultiBandBlender::feed: keep the image with a gap, snap to the 2^bands grid, stay inside dst_roi_
+    const int gap = 3 * (1 << nb);
+    int tlnx = std::max(b->rx, tlx - gap), tlny = std::max(b->ry, tly - gap);
+    int brnx = std::min(b->rx + b->rw, tlx + w + gap), brny = std::min(b->ry + b->rh, tly + h + gap);
+    tlnx = b->rx + (((tlnx - b->rx) >> nb) << nb);
+    tlny = b->ry + (((tlny - b->ry) >> nb) << nb);
+    int width = brnx - tlnx, height = brny - tlny;
+    width += ((1 << nb) - width % (1 << nb)) % (1 << nb);
+    height += ((1 << nb) - height % (1 << nb)) % (1 << nb);
+    brnx = tlnx + width;
+    brny = tlny + height;
+    const int dy = std::max(brny - (b->ry + b->rh), 0), dx = std::max(brnx - (b->rx + b->rw), 0);
+    tlnx -= dx; brnx -= dx; tlny -= dy; brny -= dy;
+
+    StxMbImage im;
+    memset(&im, 0, sizeof(im));
+    im.img0 = img->ptr; im.img0_stride = (long long)img->stride; im.img0_is_s16 = img->elem == STX_S16;
+    im.mask0 = mask->ptr; im.mask0_stride = (long long)mask->stride;
+    im.iw = w; im.ih = h;
+    im.ix = tlx - b->rx; im.iy = tly - b->ry;
+    im.fx = tlnx - b->rx; im.fy = tlny - b->ry; im.fw = width; im.fh = height;
+    im.left = tlx - tlnx; im.top = tly - tlny;
+    for (int i = 1; i <= nb; i++) {
+        const int lw = width >> i, lh = height >> i;
+        const long long gs = (long long)align_up((size_t)lw, 32), ws = (long long)align_up((size_t)lw, 16);
+        void *g = nullptr, *wt = nullptr;
+        STX_TRY(stx_dev_alloc(ctx, (size_t)gs * lh * 3 * sizeof(short), &g));
+        b->pyr_allocs.push_back(g);
+        STX_TRY(stx_dev_alloc(ctx, (size_t)ws * lh * sizeof(float), &wt));
+        b->pyr_allocs.push_back(wt);
+        im.g[i] = (short*)g; im.g_stride[i] = gs; im.g_plane[i] = gs * lh;
+        im.wt[i] = (float*)wt; im.wt_stride[i] = ws;
+    }
+    if (nb >= 1) STX_TRY(stx_launch_mb_down0(ctx, im));
+    for (int i = 1; i < nb; i++) STX_TRY(stx_launch_mb_down(ctx, im, i));
+    b->images.push_back(im);
+    stx_buf_retain(const_cast<stx_buf*>(img));
+    stx_buf_retain(const_cast<stx_buf*>(mask));
+    b->held.push_back(const_cast<stx_buf*>(img));
+    b->held.push_back(const_cast<stx_buf*>(mask));
+    return STX_OK;
+}
+
+STX_EXPORT int stx_blend_feed(stx_blender* b, const stx_buf* img, const stx_buf* mask, int tlx, int tly)
+{
+    if (!b || !img || !mask) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (b->finished) return stx_fail(STX_ERR_STATE, "feed after blend()");
+    STX_TRY(stx_set_device(b->ctx));
+    // CV_Assert(img.type() == CV_16SC3 [|| CV_8UC3]); CV_Assert(mask.type() == CV_8U)
+    if (img->c != 3 || (img->elem != STX_U8 && img->elem != STX_S16))
+        return stx_fail(STX_ERR_INVALID, "feed: image must be u8x3 or s16x3");
+    if (mask->c != 1 || mask->elem != STX_U8) return stx_fail(STX_ERR_INVALID, "feed: mask must be u8x1");
+    if (mask->w != img->w || mask->h != img->h)
+        return stx_fail(STX_ERR_INVALID, "feed: mask %dx%d does not match image %dx%d", mask->w, mask->h, img->w, img->h);
+    if (img->ctx != b->ctx || mask->ctx != b->ctx) return stx_fail(STX_ERR_INVALID, "feed: buffers belong to another context");
+    // the image must lie inside the roi given to prepare() (OpenCV would write out of bounds)
+    const int ux = b->kind == STX_BLEND_MULTIBAND ? b->rx + b->fw : b->rx + b->rw;
+    const int uy = b->kind == STX_BLEND_MULTIBAND ? b->ry + b->fh : b->ry + b->rh;
+    if (tlx < b->rx || tly < b->ry || tlx + img->w > ux || tly + img->h > uy)
+        return stx_fail(STX_ERR_INVALID, "feed: image at (%d,%d) size %dx%d leaves the prepared roi (%d,%d,%d,%d)", tlx, tly,
+                        img->w, img->h, b->rx, b->ry, ux - b->rx, uy - b->ry);
+    if (b->kind == STX_BLEND_MULTIBAND) return mb_feed(b, img, mask, tlx, tly);
+    if (b->kind == STX_BLEND_NO)
+        return stx_launch_no_feed(b->ctx, img, mask, (short*)b->dst, b->dst_stride, (uint8_t*)b->dmask, b->dmask_stride,
+                                  tlx - b->rx, tly - b->ry);
+    return stx_launch_feather_feed(b->ctx, img, mask, b->sharpness, (short*)b->dst, b->dst_stride, (float*)b->dw,
+                                   b->dw_stride, tlx - b->rx, tly - b->ry);
+}
+
+static int mb_finish(stx_blender* b, stx_buf* pano, stx_buf* pmask, stx_buf* pano16)
+{
+    stx_ctx* ctx = b->ctx;
+    const int nb = b->num_bands, n = (int)b->images.size();
+    void* d_images = nullptr;
+    STX_TRY(stx_dev_alloc(ctx, sizeof(StxMbImage) * std::max(n, 1), &d_images));
+    b->pyr_allocs.push_back(d_images);
+    if (n > 0) {
+        STX_HIP(hipMemcpyAsync(d_images, b->images.data(), sizeof(StxMbImage) * n, hipMemcpyHostToDevice, ctx->stream));
+        STX_HIP(hipStreamSynchronize(ctx->stream));  // images vector is pageable host memory
+    }
+    std::vector<short*> out(nb + 2, nullptr);
+    std::vector<long long> ostride(nb + 2, 0), oplane(nb + 2, 0);
+    for (int lv = nb; lv >= 0; lv--) {
+        const int pw = b->rw >> lv, ph = b->rh >> lv;
+        StxMbLevelLaunch L;
+        memset(&L, 0, sizeof(L));
+        L.d_images = (const StxMbImage*)d_images;
+        L.n_images = n; L.level = lv; L.num_bands = nb; L.pw = pw; L.ph = ph;
+        if (lv < nb) { L.up = out[lv + 1]; L.up_stride = ostride[lv + 1]; L.up_plane = oplane[lv + 1]; }
+        // algorithmic bytes: every input element once, every output element once
+        double bytes = 0.0;
+        for (const StxMbImage& im : b->images) {
+            if (lv == 0) {
+                bytes += (double)im.iw * im.ih * ((im.img0_is_s16 ? 6 : 3) + 1);
+                if (nb > 0) bytes += 6.0 * (im.iw / 2.0) * (im.ih / 2.0);
+            } else {
+                double lp = (double)(im.fw >> lv) * (im.fh >> lv);
+                bytes += lp * 10.0 + (lv < nb ? lp * 6.0 / 4.0 : 0.0);
+            }
+        }
+        if (lv < nb) bytes += 6.0 * (pw / 2.0) * (ph / 2.0);
+        if (lv == 0) {
+            L.pano = pano->ptr; L.pano_stride = (long long)pano->stride;
+            L.pmask = pmask->ptr; L.pmask_stride = (long long)pmask->stride;
+            if (pano16) { L.pano16 = (short*)pano16->ptr; L.pano16_stride = (long long)pano16->stride; }
+            L.final_w = b->fw; L.final_h = b->fh;
+            bytes += (double)b->fw * b->fh * (4 + (pano16 ? 6 : 0));
+        } else {
+            const long long s = (long long)align_up((size_t)pw, 32);
+            void* p = nullptr;
+            STX_TRY(stx_dev_alloc(ctx, (size_t)s * ph * 3 * sizeof(short), &p));
+            b->pyr_allocs.push_back(p);
+            out[lv] = (short*)p; ostride[lv] = s; oplane[lv] = s * ph;
+            L.out = out[lv]; L.out_stride = s; L.out_plane = s * ph;
+            bytes += 6.0 * pw * ph;
+        }
+        L.algo_bytes = bytes;
+        STX_TRY(stx_launch_mb_level(ctx, L));
+    }
+    return STX_OK;
+}
+
+STX_EXPORT int stx_blend_finish_ex(stx_blender* b, stx_buf** out_pano_u8, stx_buf** out_mask_u8, stx_buf** out_pano_s16)
+{
+    if (!b) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (b->finished) return stx_fail(STX_ERR_STATE, "blend() was already called on this blender");
+    STX_TRY(stx_set_device(b->ctx));
+    stx_ctx* ctx = b->ctx;
+    const int ow = b->kind == STX_BLEND_MULTIBAND ? b->fw : b->rw, oh = b->kind == STX_BLEND_MULTIBAND ? b->fh : b->rh;
+    stx_buf *pano = nullptr, *pmask = nullptr, *p16 = nullptr;
+    int rc = stx_buf_new(ctx, ow, oh, 3, STX_U8, &pano);
+    if (rc == STX_OK) rc = stx_buf_new(ctx, ow, oh, 1, STX_U8, &pmask);
+    if (rc == STX_OK && out_pano_s16) rc = stx_buf_new(ctx, ow, oh, 3, STX_S16, &p16);
+    if (rc == STX_OK) {
+        if (b->kind == STX_BLEND_MULTIBAND) rc = mb_finish(b, pano, pmask, p16);
+        else
+            rc = stx_launch_simple_finish(ctx, b->kind, (short*)b->dst, b->dst_stride, (const float*)b->dw, b->dw_stride,
+                                          (uint8_t*)b->dmask, b->dmask_stride, ow, oh, pano->ptr, (long long)pano->stride,
+                                          p16 ? (short*)p16->ptr : nullptr, p16 ? (long long)p16->stride : 0);
+    }
+    if (rc == STX_OK && b->kind != STX_BLEND_MULTIBAND) {
+        // hand out dst_mask_ (Blender::blend: dst_mask.assign(dst_mask_))
+        hipError_t e = hipMemcpy2DAsync(pmask->ptr, pmask->stride, b->dmask, b->dmask_stride, ow, oh,
+                                        hipMemcpyDeviceToDevice, ctx->stream);
+        if (e != hipSuccess) rc = stx_fail(STX_ERR_HIP, "mask copy: %s", hipGetErrorString(e));
+    }
+    b->finished = true;
+    blender_release(b);  // stream-ordered: the kernels above were enqueued before any reuse
+    if (rc != STX_OK) {
+        stx_buf_release(pano); stx_buf_release(pmask); stx_buf_release(p16);
+        return rc;
+    }
+    if (out_pano_u8) *out_pano_u8 = pano; else stx_buf_release(pano);
+    if (out_mask_u8) *out_mask_u8 = pmask; else stx_buf_release(pmask);
+    if (out_pano_s16) *out_pano_s16 = p16;
+    return STX_OK;
+}
+
+STX_EXPORT int stx_blend_finish(stx_blender* b, stx_buf** out_pano_u8, stx_buf** out_mask_u8)
+{
+    return stx_blend_finish_ex(b, out_pano_u8, out_mask_u8, nullptr);
+}
+
+STX_EXPORT int stx_blend_destroy(stx_blender* b)
+{
+    if (!b) return STX_OK;
+    hipSetDevice(b->ctx->device);
+    blender_release(b);
+    delete b;
+    return STX_OK;
+}

@@ -1,0 +1,525 @@
+// stx_blend.hip — multi-band (Laplacian pyramid), feather and "no" blenders for gfx950.
+//
+// Replaces, for stitching/blender.py:23-48, OpenCV's MultiBandBlender::{prepare,feed,blend},
+// createLaplacePyr, restoreImageFromLaplacePyr, normalizeUsingWeightMap, pyrDown/pyrUp,
+// copyMakeBorder, FeatherBlender (+createWeightMap/distanceTransform) and the base Blender.
+//
+// Multi-band is restructured for a 288 GB HBM part as a DEFERRED GATHER:
+//   feed()   builds, per image, only the int16 Gaussian pyramid G_1..G_B (planar) and the fp32
+//            weight pyramid W_1..W_B.  copyMakeBorder is an index map on load, the int16
+//            conversion happens in registers, no Laplacian level is ever stored.
+//   finish() runs ONE kernel per level, coarse to fine.  Each panorama pixel loops over the
+//            images whose (2^B-aligned) feed rectangle covers it, forms
+//            L = sat(G_i - pyrUp(G_{i+1})) on the fly, accumulates (short)(L*W) and W in
+//            registers in feed order, normalises, adds pyrUp of the already finished coarser
+//            level (saturating) and writes the level once.  Level 0 writes the u8 panorama,
+//            the mask and (optionally) the int16 result directly.
+// The accumulator pyramids dst_pyr_laplace_/dst_band_weights_ of OpenCV (13.3 B per panorama
+// pixel, read-modify-written once per image) never exist in HBM.  Integer sums are exact in
+// any order (int16 wrap-around adds); fp32 weight sums are taken in ascending feed order, the
+// order OpenCV's += sees.
+#include "stx_device_math.h"
+#include "stx_internal.h"
+
+using namespace stxd;
+
+namespace {
+
+constexpr float WEIGHT_EPS = 1e-5f;
+constexpr float INV255 = 0.0039215688593685627f;  // (float)(1./255.)
+constexpr float INV256 = 0.00390625f;
+
+// ---------------------------------------------------------------------------------------------
+// level-0 accessors: bordered image (copyMakeBorder REFLECT) and bordered weight (CONSTANT 0)
+// ---------------------------------------------------------------------------------------------
+template <bool S16>
+STX_DEV void load_px0(const StxMbImage& im, int sx, int sy, int& b, int& g, int& r)
+{
+    if (S16) {
+        const short* p = reinterpret_cast<const short*>(im.img0 + (long long)sy * im.img0_stride) + sx * 3;
+        b = p[0]; g = p[1]; r = p[2];
+    } else {
+        const uint8_t* p = im.img0 + (long long)sy * im.img0_stride + sx * 3;
+        b = p[0]; g = p[1]; r = p[2];
+    }
+}
+
+// horizontal 1-4-6-4-1 of the fp32 weights in pyrDown_'s scalar evaluation order
+STX_DEV float h5f(float s0, float s1, float s2, float s3, float s4)
+{
+    return fadd(fadd(fadd(fmul(s2, 6.f), fmul(fadd(s1, s3), 4.f)), s0), s4);
+}
+
+// pyrDown of (bordered level 0) -> level 1: G_1 planar int16, W_1 fp32
+template <bool S16>
+__global__ __launch_bounds__(256) void mb_down0_kernel(StxMbImage im)
+{
+    const int ow = im.fw >> 1, oh = im.fh >> 1;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= ow || y >= oh) return;
+    int cx[5], mx[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        int bx = reflect101(2 * x - 2 + j, im.fw) - im.left;  // bordered -> image coords
+        mx[j] = ((unsigned)bx < (unsigned)im.iw) ? bx : -1;
+        cx[j] = reflect(bx, im.iw);
+    }
+    int vb[5], vg[5], vr[5];
+    float vw[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        int by = reflect101(2 * y - 2 + k, im.fh) - im.top;
+        bool yin = (unsigned)by < (unsigned)im.ih;
+        int sy = reflect(by, im.ih);
+        int b[5], g[5], r[5];
+        float w[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            load_px0<S16>(im, cx[j], sy, b[j], g[j], r[j]);
+            w[j] = (yin && mx[j] >= 0) ? fmul((float)im.mask0[(long long)by * im.mask0_stride + mx[j]], INV255) : 0.f;
+        }
+        vb[k] = b[2] * 6 + (b[1] + b[3]) * 4 + b[0] + b[4];
+        vg[k] = g[2] * 6 + (g[1] + g[3]) * 4 + g[0] + g[4];
+        vr[k] = r[2] * 6 + (r[1] + r[3]) * 4 + r[0] + r[4];
+        vw[k] = h5f(w[0], w[1], w[2], w[3], w[4]);
+    }
+    short* G = im.g[1] + (long long)y * im.g_stride[1] + x;
+    G[0] = (short)((vb[2] * 6 + (vb[1] + vb[3]) * 4 + vb[0] + vb[4] + 128) >> 8);
+    G[im.g_plane[1]] = (short)((vg[2] * 6 + (vg[1] + vg[3]) * 4 + vg[0] + vg[4] + 128) >> 8);
+    G[2 * im.g_plane[1]] = (short)((vr[2] * 6 + (vr[1] + vr[3]) * 4 + vr[0] + vr[4] + 128) >> 8);
+    im.wt[1][(long long)y * im.wt_stride[1] + x] = fmul(h5f(vw[0], vw[1], vw[2], vw[3], vw[4]), INV256);
+}
+
+// pyrDown level i -> i+1 (i >= 1), planar int16 x3 + fp32
+__global__ __launch_bounds__(256) void mb_down_kernel(StxMbImage im, int lv)
+{
+    const int iw = im.fw >> lv, ih = im.fh >> lv;
+    const int ow = iw >> 1, oh = ih >> 1;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= ow || y >= oh) return;
+    int cx[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) cx[j] = reflect101(2 * x - 2 + j, iw);
+    const short* G = im.g[lv];
+    const long long gs = im.g_stride[lv], gp = im.g_plane[lv];
+    const float* W = im.wt[lv];
+    const long long ws = im.wt_stride[lv];
+    int v[3][5];
+    float vw[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        int sy = reflect101(2 * y - 2 + k, ih);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const short* row = G + c * gp + (long long)sy * gs;
+            v[c][k] = row[cx[2]] * 6 + (row[cx[1]] + row[cx[3]]) * 4 + row[cx[0]] + row[cx[4]];
+        }
+        const float* wr = W + (long long)sy * ws;
+        vw[k] = h5f(wr[cx[0]], wr[cx[1]], wr[cx[2]], wr[cx[3]], wr[cx[4]]);
+    }
+    short* O = im.g[lv + 1] + (long long)y * im.g_stride[lv + 1] + x;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+        O[c * im.g_plane[lv + 1]] = (short)((v[c][2] * 6 + (v[c][1] + v[c][3]) * 4 + v[c][0] + v[c][4] + 128) >> 8);
+    im.wt[lv + 1][(long long)y * im.wt_stride[lv + 1] + x] = fmul(h5f(vw[0], vw[1], vw[2], vw[3], vw[4]), INV256);
+}
+
+// pyrUp_<FixPtCast<short,6>> sampled at one destination pixel (X, Y) of a planar int16 image
+STX_DEV int pyr_up_at(const short* __restrict__ plane, long long stride, int cw, int ch, int X, int Y)
+{
+    const int px = X >> 1, py = Y >> 1;
+    const int xl = up_idx(px - 1, cw), xr = up_idx(px + 1, cw);
+    const int yt = up_idx(py - 1, ch), yb = up_idx(py + 1, ch);
+    const short* rc = plane + (long long)py * stride;
+    const short* rb = plane + (long long)yb * stride;
+    int hc, hb, v;
+    if (X & 1) {
+        hc = (rc[px] + rc[xr]) * 4;
+        hb = (rb[px] + rb[xr]) * 4;
+    } else {
+        hc = rc[xl] + rc[px] * 6 + rc[xr];
+        hb = rb[xl] + rb[px] * 6 + rb[xr];
+    }
+    if (Y & 1) {
+        v = (hc + hb) * 4;
+    } else {
+        const short* rt = plane + (long long)yt * stride;
+        int ht = (X & 1) ? (rt[px] + rt[xr]) * 4 : rt[xl] + rt[px] * 6 + rt[xr];
+        v = ht + hc * 6 + hb;
+    }
+    return (int)(short)((v + 32) >> 6);
+}
+
+struct MbLevelK {
+    const StxMbImage* images;
+    int n_images, level, num_bands, pw, ph;
+    short* out; long long out_stride, out_plane;
+    const short* up; long long up_stride, up_plane;
+    uint8_t* pano; long long pano_stride;
+    uint8_t* pmask; long long pmask_stride;
+    short* pano16; long long pano16_stride;
+    int final_w, final_h;
+};
+
+// levels >= 1: gather + normalise + collapse
+__global__ __launch_bounds__(256) void mb_level_kernel(MbLevelK P)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.pw || y >= P.ph) return;
+    const int lv = P.level;
+    int acc0 = 0, acc1 = 0, acc2 = 0;
+    float ws = 0.f;
+    for (int k = 0; k < P.n_images; k++) {
+        const StxMbImage& im = P.images[k];
+        const int lx = x - (im.fx >> lv), ly = y - (im.fy >> lv);
+        const int lw = im.fw >> lv, lh = im.fh >> lv;
+        if ((unsigned)lx >= (unsigned)lw || (unsigned)ly >= (unsigned)lh) continue;
+        const float w = im.wt[lv][(long long)ly * im.wt_stride[lv] + lx];
+        const short* G = im.g[lv] + (long long)ly * im.g_stride[lv] + lx;
+        int L[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            int gval = G[c * im.g_plane[lv]];
+            if (lv < P.num_bands) {
+                int u = pyr_up_at(im.g[lv + 1] + c * im.g_plane[lv + 1], im.g_stride[lv + 1], lw >> 1, lh >> 1, lx, ly);
+                gval = sat_s16(gval - u);
+            }
+            L[c] = gval;
+        }
+        acc0 += trunc_s16(fmul((float)L[0], w));
+        acc1 += trunc_s16(fmul((float)L[1], w));
+        acc2 += trunc_s16(fmul((float)L[2], w));
+        ws = fadd(ws, w);
+    }
+    const float den = fadd(ws, WEIGHT_EPS);
+    int n[3];
+    n[0] = trunc_s16(fdiv((float)(short)acc0, den));
+    n[1] = trunc_s16(fdiv((float)(short)acc1, den));
+    n[2] = trunc_s16(fdiv((float)(short)acc2, den));
+    short* O = P.out + (long long)y * P.out_stride + x;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        int v = n[c];
+        if (P.up) v = sat_s16(pyr_up_at(P.up + c * P.up_plane, P.up_stride, P.pw >> 1, P.ph >> 1, x, y) + v);
+        O[c * P.out_plane] = (short)v;
+    }
+}
+
+// level 0: as above, reading the fed images directly; writes u8 panorama + mask (+ int16 result)
+__global__ __launch_bounds__(256) void mb_level0_kernel(MbLevelK P)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.final_w || y >= P.final_h) return;
+    int acc0 = 0, acc1 = 0, acc2 = 0;
+    float ws = 0.f;
+    for (int k = 0; k < P.n_images; k++) {
+        const StxMbImage& im = P.images[k];
+        // outside the image itself the bordered weight is the constant 0: (short)(L*0) = 0, w += 0
+        const int lx = x - im.ix, ly = y - im.iy;
+        if ((unsigned)lx >= (unsigned)im.iw || (unsigned)ly >= (unsigned)im.ih) continue;
+        const float w = fmul((float)im.mask0[(long long)ly * im.mask0_stride + lx], INV255);
+        int L[3];
+        if (im.img0_is_s16) load_px0<true>(im, lx, ly, L[0], L[1], L[2]);
+        else load_px0<false>(im, lx, ly, L[0], L[1], L[2]);
+        if (P.num_bands > 0) {
+            const int bx = x - im.fx, by = y - im.fy;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                int u = pyr_up_at(im.g[1] + c * im.g_plane[1], im.g_stride[1], im.fw >> 1, im.fh >> 1, bx, by);
+                L[c] = sat_s16(L[c] - u);
+            }
+        }
+        acc0 += trunc_s16(fmul((float)L[0], w));
+        acc1 += trunc_s16(fmul((float)L[1], w));
+        acc2 += trunc_s16(fmul((float)L[2], w));
+        ws = fadd(ws, w);
+    }
+    const float den = fadd(ws, WEIGHT_EPS);
+    int v[3];
+    v[0] = trunc_s16(fdiv((float)(short)acc0, den));
+    v[1] = trunc_s16(fdiv((float)(short)acc1, den));
+    v[2] = trunc_s16(fdiv((float)(short)acc2, den));
+    if (P.up) {
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            v[c] = sat_s16(pyr_up_at(P.up + c * P.up_plane, P.up_stride, P.pw >> 1, P.ph >> 1, x, y) + v[c]);
+    }
+    const bool keep = ws > WEIGHT_EPS;  // compare(dst_band_weights_0, WEIGHT_EPS, CMP_GT); setTo(0, !mask)
+    if (!keep) v[0] = v[1] = v[2] = 0;
+    uint8_t* o = P.pano + (long long)y * P.pano_stride + x * 3;
+    // convertScaleAbs: saturate_cast<uchar>(|x|)
+    o[0] = (uint8_t)min(abs(v[0]), 255);
+    o[1] = (uint8_t)min(abs(v[1]), 255);
+    o[2] = (uint8_t)min(abs(v[2]), 255);
+    P.pmask[(long long)y * P.pmask_stride + x] = keep ? 255 : 0;
+    if (P.pano16) {
+        short* o16 = reinterpret_cast<short*>(reinterpret_cast<uint8_t*>(P.pano16) + (long long)y * P.pano16_stride) + x * 3;
+        o16[0] = (short)v[0]; o16[1] = (short)v[1]; o16[2] = (short)v[2];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// "no" blender (base cv::detail::Blender) and feather blender
+// ---------------------------------------------------------------------------------------------
+struct SimpleFeedK {
+    const uint8_t* img; long long img_stride; int img_is_s16;
+    const uint8_t* mask; long long mask_stride;
+    int w, h, dx, dy;
+    short* dst; long long dst_stride;       // int16 HWC accumulator (bytes stride)
+    uint8_t* dmask; long long dmask_stride;
+    float* dw; long long dw_stride;         // fp32 weight accumulator (feather), bytes stride
+    const float* wmap; long long wmap_stride;  // feather weight map of this image (elements stride)
+};
+
+STX_DEV void load_src(const SimpleFeedK& P, int x, int y, int& b, int& g, int& r)
+{
+    if (P.img_is_s16) {
+        const short* p = reinterpret_cast<const short*>(P.img + (long long)y * P.img_stride) + x * 3;
+        b = p[0]; g = p[1]; r = p[2];
+    } else {
+        const uint8_t* p = P.img + (long long)y * P.img_stride + x * 3;
+        b = p[0]; g = p[1]; r = p[2];
+    }
+}
+
+// Blender::feed: dst = src where mask; dst_mask |= mask
+__global__ __launch_bounds__(256) void no_feed_kernel(SimpleFeedK P)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.w || y >= P.h) return;
+    uint8_t m = P.mask[(long long)y * P.mask_stride + x];
+    if (!m) return;
+    int b, g, r;
+    load_src(P, x, y, b, g, r);
+    short* d = reinterpret_cast<short*>(reinterpret_cast<uint8_t*>(P.dst) + (long long)(y + P.dy) * P.dst_stride) + (x + P.dx) * 3;
+    d[0] = (short)b; d[1] = (short)g; d[2] = (short)r;
+    P.dmask[(long long)(y + P.dy) * P.dmask_stride + x + P.dx] |= m;
+}
+
+// distanceTransform(mask, DIST_L1, 3): exact city-block distance to the nearest zero pixel.
+// Pass 1 (one thread per column): vertical distance, down then up.  INF when the column has no zero.
+constexpr int DT_INF = 1 << 28;
+__global__ __launch_bounds__(64) void dt_cols_kernel(const uint8_t* __restrict__ mask, long long mstride, int w, int h,
+                                                    int* __restrict__ d, long long dstride)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    if (x >= w) return;
+    int cur = DT_INF;
+    for (int y = 0; y < h; y++) {
+        cur = mask[(long long)y * mstride + x] ? min(cur + 1, DT_INF) : 0;
+        d[(long long)y * dstride + x] = cur;
+    }
+    cur = DT_INF;
+    for (int y = h - 1; y >= 0; y--) {
+        int v = d[(long long)y * dstride + x];
+        cur = v == 0 ? 0 : min(cur + 1, DT_INF);
+        d[(long long)y * dstride + x] = min(v, cur);
+    }
+}
+// Pass 2 (one thread per row): f(x) = min_x' (|x - x'| + g(x')), then the weight map
+//   weight = min(dist * sharpness, 1), dist = (L1 >= 8192 or no zero) ? 8192.f : (float)L1
+// (distanceTransform_3x3's 16.16 fixed point saturates at INT_MAX>>2, i.e. 8192.0f).
+__global__ __launch_bounds__(64) void dt_rows_kernel(int* __restrict__ d, long long dstride, int w, int h, float sharpness,
+                                                    float* __restrict__ wmap, long long wstride)
+{
+    const int y = blockIdx.x * 64 + threadIdx.x;
+    if (y >= h) return;
+    int* row = d + (long long)y * dstride;
+    int cur = DT_INF;
+    for (int x = 0; x < w; x++) {
+        cur = min(row[x], min(cur + 1, DT_INF));
+        row[x] = cur;
+    }
+    cur = DT_INF;
+    float* wr = wmap + (long long)y * wstride;
+    for (int x = w - 1; x >= 0; x--) {
+        cur = min(row[x], min(cur + 1, DT_INF));
+        float dist = cur >= 8192 ? 8192.f : (float)cur;
+        float t = fmul(dist, sharpness);
+        wr[x] = t > 1.f ? 1.f : t;
+    }
+}
+
+// FeatherBlender::feed: dst += (short)(src * w); dst_weight += w
+__global__ __launch_bounds__(256) void feather_feed_kernel(SimpleFeedK P)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.w || y >= P.h) return;
+    const float w = P.wmap[(long long)y * P.wmap_stride + x];
+    int b, g, r;
+    load_src(P, x, y, b, g, r);
+    short* d = reinterpret_cast<short*>(reinterpret_cast<uint8_t*>(P.dst) + (long long)(y + P.dy) * P.dst_stride) + (x + P.dx) * 3;
+    d[0] = (short)(d[0] + trunc_s16(fmul((float)b, w)));
+    d[1] = (short)(d[1] + trunc_s16(fmul((float)g, w)));
+    d[2] = (short)(d[2] + trunc_s16(fmul((float)r, w)));
+    float* dw = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(P.dw) + (long long)(y + P.dy) * P.dw_stride) + x + P.dx;
+    *dw = fadd(*dw, w);
+}
+
+struct SimpleFinishK {
+    int kind, w, h;
+    short* dst; long long dst_stride;
+    const float* dw; long long dw_stride;
+    uint8_t* dmask; long long dmask_stride;
+    uint8_t* pano; long long pano_stride;
+    short* pano16; long long pano16_stride;
+};
+// FeatherBlender::blend (normalizeUsingWeightMap, compare GT) / Blender::blend (zero outside mask),
+// then convertScaleAbs
+__global__ __launch_bounds__(256) void simple_finish_kernel(SimpleFinishK P)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.w || y >= P.h) return;
+    short* d = reinterpret_cast<short*>(reinterpret_cast<uint8_t*>(P.dst) + (long long)y * P.dst_stride) + x * 3;
+    int v[3] = {d[0], d[1], d[2]};
+    uint8_t m;
+    if (P.kind == STX_BLEND_FEATHER) {
+        const float ws = *(reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(P.dw) + (long long)y * P.dw_stride) + x);
+        const float den = fadd(ws, WEIGHT_EPS);
+        v[0] = trunc_s16(fdiv((float)v[0], den));
+        v[1] = trunc_s16(fdiv((float)v[1], den));
+        v[2] = trunc_s16(fdiv((float)v[2], den));
+        m = ws > WEIGHT_EPS ? 255 : 0;
+        P.dmask[(long long)y * P.dmask_stride + x] = m;
+    } else {
+        m = P.dmask[(long long)y * P.dmask_stride + x];
+    }
+    if (!m) v[0] = v[1] = v[2] = 0;
+    uint8_t* o = P.pano + (long long)y * P.pano_stride + x * 3;
+    o[0] = (uint8_t)min(abs(v[0]), 255);
+    o[1] = (uint8_t)min(abs(v[1]), 255);
+    o[2] = (uint8_t)min(abs(v[2]), 255);
+    if (P.pano16) {
+        short* o16 = reinterpret_cast<short*>(reinterpret_cast<uint8_t*>(P.pano16) + (long long)y * P.pano16_stride) + x * 3;
+        o16[0] = (short)v[0]; o16[1] = (short)v[1]; o16[2] = (short)v[2];
+    }
+}
+
+int check_launch(const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return stx_fail(STX_ERR_HIP, "%s launch failed: %s", what, hipGetErrorString(e));
+    return STX_OK;
+}
+
+inline dim3 grid64x4(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
+
+}  // namespace
+
+int stx_launch_mb_down0(stx_ctx* ctx, const StxMbImage& im)
+{
+    const int ow = im.fw >> 1, oh = im.fh >> 1;
+    double bytes = (im.img0_is_s16 ? 6.0 : 3.0) * im.iw * im.ih + 1.0 * im.iw * im.ih + 10.0 * ow * oh;
+    StxProfScope prof(ctx, "mb_down0", bytes);
+    if (im.img0_is_s16) hipLaunchKernelGGL(mb_down0_kernel<true>, grid64x4(ow, oh), dim3(256), 0, ctx->stream, im);
+    else hipLaunchKernelGGL(mb_down0_kernel<false>, grid64x4(ow, oh), dim3(256), 0, ctx->stream, im);
+    return check_launch("mb_down0");
+}
+
+int stx_launch_mb_down(stx_ctx* ctx, const StxMbImage& im, int level)
+{
+    const int iw = im.fw >> level, ih = im.fh >> level;
+    const int ow = iw >> 1, oh = ih >> 1;
+    double bytes = 10.0 * iw * ih + 10.0 * ow * oh;
+    StxProfScope prof(ctx, "mb_down", bytes);
+    hipLaunchKernelGGL(mb_down_kernel, grid64x4(ow, oh), dim3(256), 0, ctx->stream, im, level);
+    return check_launch("mb_down");
+}
+
+int stx_launch_mb_level(stx_ctx* ctx, const StxMbLevelLaunch& L)
+{
+    MbLevelK K;
+    K.images = L.d_images; K.n_images = L.n_images; K.level = L.level; K.num_bands = L.num_bands;
+    K.pw = L.pw; K.ph = L.ph;
+    K.out = L.out; K.out_stride = L.out_stride; K.out_plane = L.out_plane;
+    K.up = L.up; K.up_stride = L.up_stride; K.up_plane = L.up_plane;
+    K.pano = L.pano; K.pano_stride = L.pano_stride; K.pmask = L.pmask; K.pmask_stride = L.pmask_stride;
+    K.pano16 = L.pano16; K.pano16_stride = L.pano16_stride;
+    K.final_w = L.final_w; K.final_h = L.final_h;
+    if (L.level == 0) {
+        StxProfScope prof(ctx, "mb_level0", L.algo_bytes);
+        hipLaunchKernelGGL(mb_level0_kernel, grid64x4(L.final_w, L.final_h), dim3(256), 0, ctx->stream, K);
+        return check_launch("mb_level0");
+    }
+    StxProfScope prof(ctx, "mb_level", L.algo_bytes);
+    hipLaunchKernelGGL(mb_level_kernel, grid64x4(L.pw, L.ph), dim3(256), 0, ctx->stream, K);
+    return check_launch("mb_level");
+}
+
+static void fill_feed(SimpleFeedK& K, const stx_buf* img, const stx_buf* mask, int dx, int dy)
+{
+    K.img = img->ptr; K.img_stride = (long long)img->stride; K.img_is_s16 = img->elem == STX_S16;
+    K.mask = mask->ptr; K.mask_stride = (long long)mask->stride;
+    K.w = img->w; K.h = img->h; K.dx = dx; K.dy = dy;
+    K.dst = nullptr; K.dst_stride = 0; K.dmask = nullptr; K.dmask_stride = 0;
+    K.dw = nullptr; K.dw_stride = 0; K.wmap = nullptr; K.wmap_stride = 0;
+}
+
+int stx_launch_no_feed(stx_ctx* ctx, const stx_buf* img, const stx_buf* mask, short* dst, long long dst_stride,
+                       uint8_t* dmask, long long dmask_stride, int dx, int dy)
+{
+    SimpleFeedK K;
+    fill_feed(K, img, mask, dx, dy);
+    K.dst = dst; K.dst_stride = dst_stride; K.dmask = dmask; K.dmask_stride = dmask_stride;
+    double px = (double)img->w * img->h;
+    StxProfScope prof(ctx, "no_feed", px * ((K.img_is_s16 ? 6 : 3) + 1 + 6 + 2));
+    hipLaunchKernelGGL(no_feed_kernel, grid64x4(img->w, img->h), dim3(256), 0, ctx->stream, K);
+    return check_launch("no_feed");
+}
+
+int stx_launch_feather_feed(stx_ctx* ctx, const stx_buf* img, const stx_buf* mask, float sharpness, short* dst,
+                            long long dst_stride, float* dw, long long dw_stride, int dx, int dy)
+{
+    const int w = img->w, h = img->h;
+    const long long dstride = (w + 15) & ~15;
+    void* dist = nullptr;
+    void* wmap = nullptr;
+    STX_TRY(stx_dev_alloc(ctx, sizeof(int) * dstride * h, &dist));
+    int rc = stx_dev_alloc(ctx, sizeof(float) * dstride * h, &wmap);
+    if (rc != STX_OK) { stx_dev_free(ctx, dist); return rc; }
+    double px = (double)w * h;
+    {
+        StxProfScope prof(ctx, "feather_dt_cols", px * (1 + 4));
+        hipLaunchKernelGGL(dt_cols_kernel, dim3((w + 63) / 64), dim3(64), 0, ctx->stream, mask->ptr,
+                           (long long)mask->stride, w, h, (int*)dist, dstride);
+    }
+    {
+        StxProfScope prof(ctx, "feather_dt_rows", px * (4 + 4));
+        hipLaunchKernelGGL(dt_rows_kernel, dim3((h + 63) / 64), dim3(64), 0, ctx->stream, (int*)dist, dstride, w, h,
+                           sharpness, (float*)wmap, dstride);
+    }
+    SimpleFeedK K;
+    fill_feed(K, img, mask, dx, dy);
+    K.dst = dst; K.dst_stride = dst_stride; K.dw = dw; K.dw_stride = dw_stride;
+    K.wmap = (const float*)wmap; K.wmap_stride = dstride;
+    {
+        StxProfScope prof(ctx, "feather_feed", px * ((K.img_is_s16 ? 6 : 3) + 4 + 12 + 8));
+        hipLaunchKernelGGL(feather_feed_kernel, grid64x4(w, h), dim3(256), 0, ctx->stream, K);
+    }
+    rc = check_launch("feather_feed");
+    stx_dev_free(ctx, dist);  // stream-ordered reuse: later kernels on this stream run after the ones above
+    stx_dev_free(ctx, wmap);
+    return rc;
+}
+
+int stx_launch_simple_finish(stx_ctx* ctx, int kind, short* dst, long long dst_stride, const float* dw,
+                             long long dw_stride, uint8_t* dmask, long long dmask_stride, int w, int h, uint8_t* pano,
+                             long long pano_stride, short* pano16, long long pano16_stride)
+{
+    SimpleFinishK K;
+    K.kind = kind; K.w = w; K.h = h;
+    K.dst = dst; K.dst_stride = dst_stride; K.dw = dw; K.dw_stride = dw_stride;
+    K.dmask = dmask; K.dmask_stride = dmask_stride; K.pano = pano; K.pano_stride = pano_stride;
+    K.pano16 = pano16; K.pano16_stride = pano16_stride;
+    double px = (double)w * h;
+    StxProfScope prof(ctx, "simple_finish", px * (6 + (kind == STX_BLEND_FEATHER ? 4 : 1) + 3 + 1));
+    hipLaunchKernelGGL(simple_finish_kernel, grid64x4(w, h), dim3(256), 0, ctx->stream, K);
+    return check_launch("simple_finish");
+}

@@ -1,0 +1,178 @@
+// stx_device_math.h — device-side scalar helpers for the gfx950 kernels.
+//
+// Exact-trig contract: sin/cos/atan2/acos are evaluated in fp64 with a fixed
+// sequence of IEEE fma/mul/add/div/sqrt operations (fdlibm minimax coefficients), then rounded
+// once to fp32.  The same sequence on any IEEE machine gives the same bits, so the oracle's
+// trig=exact mode and these routines agree bit-for-bit; versus libm sinf/cosf/atan2f/acosf
+// (what OpenCV calls) the result differs by at most 1 ULP fp32, and only when libm itself is
+// not correctly rounded.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define STX_DEV __device__ __forceinline__
+
+namespace stxd {
+
+STX_DEV void sincos_d(double x, double* s, double* c)
+{
+    const double INV_PIO2 = 6.36619772367581382433e-01;
+    const double PIO2_1 = 1.57079632673412561417e+00;
+    const double PIO2_1T = 6.07710050650619224932e-11;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    if (!(fabs(x) < 1.0e6)) {  // outside the contract's domain (no panorama gets here)
+        *s = sin(x);
+        *c = cos(x);
+        return;
+    }
+    double kd = rint(__dmul_rn(x, INV_PIO2));
+    double r = fma(-kd, PIO2_1, x);
+    r = fma(-kd, PIO2_1T, r);
+    double z = __dmul_rn(r, r);
+    double ps = fma(z, S6, S5);
+    ps = fma(z, ps, S4);
+    ps = fma(z, ps, S3);
+    ps = fma(z, ps, S2);
+    ps = fma(z, ps, S1);
+    double sr = fma(__dmul_rn(r, z), ps, r);
+    double pc = fma(z, C6, C5);
+    pc = fma(z, pc, C4);
+    pc = fma(z, pc, C3);
+    pc = fma(z, pc, C2);
+    pc = fma(z, pc, C1);
+    double cr = fma(__dmul_rn(z, z), pc, fma(-0.5, z, 1.0));
+    long long k = (long long)kd;
+    switch (k & 3) {
+    case 0: *s = sr; *c = cr; break;
+    case 1: *s = cr; *c = -sr; break;
+    case 2: *s = -sr; *c = -cr; break;
+    default: *s = -cr; *c = sr; break;
+    }
+}
+
+STX_DEV double atan_d(double x)
+{
+    const double atanhi[4] = {4.63647609000806093515e-01, 7.85398163397448278999e-01,
+                              9.82793723247329054082e-01, 1.57079632679489655800e+00};
+    const double atanlo[4] = {2.26987774529616870924e-17, 3.06161699786838301793e-17,
+                              1.39033110312309984516e-17, 6.12323399573676603587e-17};
+    const double aT0 = 3.33333333333329318027e-01, aT1 = -1.99999999998764832476e-01,
+                 aT2 = 1.42857142725034663711e-01, aT3 = -1.11111104054623557880e-01,
+                 aT4 = 9.09088713343650656196e-02, aT5 = -7.69187620504482999495e-02,
+                 aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02,
+                 aT8 = 4.97687799461593236017e-02, aT9 = -3.65315727442169155270e-02,
+                 aT10 = 1.62858201153657823623e-02;
+    if (x != x) return x;
+    bool neg = signbit(x);
+    double a = fabs(x);
+    int id;
+    if (a < 0.4375) {
+        id = -1;
+    } else if (a < 1.1875) {
+        if (a < 0.6875) { id = 0; a = __ddiv_rn(__dsub_rn(__dmul_rn(2.0, a), 1.0), __dadd_rn(2.0, a)); }
+        else { id = 1; a = __ddiv_rn(__dsub_rn(a, 1.0), __dadd_rn(a, 1.0)); }
+    } else if (a < 2.4375) {
+        id = 2; a = __ddiv_rn(__dsub_rn(a, 1.5), __dadd_rn(1.0, __dmul_rn(1.5, a)));
+    } else {
+        id = 3; a = __ddiv_rn(-1.0, a);
+    }
+    double z = __dmul_rn(a, a);
+    double w = __dmul_rn(z, z);
+    double s1 = __dmul_rn(z, fma(w, fma(w, fma(w, fma(w, fma(w, aT10, aT8), aT6), aT4), aT2), aT0));
+    double s2 = __dmul_rn(w, fma(w, fma(w, fma(w, fma(w, aT9, aT7), aT5), aT3), aT1));
+    double r;
+    if (id < 0) r = __dsub_rn(a, __dmul_rn(a, __dadd_rn(s1, s2)));
+    else r = __dsub_rn(atanhi[id], __dsub_rn(__dsub_rn(__dmul_rn(a, __dadd_rn(s1, s2)), atanlo[id]), a));
+    return neg ? -r : r;
+}
+
+STX_DEV double atan2_d(double y, double x)
+{
+    const double PI = 3.1415926535897931160E+00, PI_LO = 1.2246467991473531772E-16;
+    if (x != x || y != y) return x + y;
+    int m = (signbit(y) ? 1 : 0) | (signbit(x) ? 2 : 0);
+    if (y == 0.0) {
+        switch (m) {
+        case 0: case 1: return y;
+        case 2: return PI;
+        default: return -PI;
+        }
+    }
+    if (x == 0.0) return (m & 1) ? -PI / 2 : PI / 2;
+    double z = atan_d(fabs(__ddiv_rn(y, x)));
+    switch (m) {
+    case 0: return z;
+    case 1: return -z;
+    case 2: return __dsub_rn(PI, __dsub_rn(z, PI_LO));
+    default: return __dsub_rn(__dsub_rn(z, PI_LO), PI);
+    }
+}
+
+STX_DEV double acos_d(double w)
+{
+    double t = __dmul_rn(__dsub_rn(1.0, w), __dadd_rn(1.0, w));
+    return atan2_d(__dsqrt_rn(t), w);
+}
+
+STX_DEV float sinf_x(float x) { double s, c; sincos_d((double)x, &s, &c); return (float)s; }
+STX_DEV float cosf_x(float x) { double s, c; sincos_d((double)x, &s, &c); return (float)c; }
+STX_DEV void sincosf_x(float x, float* s, float* c) { double sd, cd; sincos_d((double)x, &sd, &cd); *s = (float)sd; *c = (float)cd; }
+STX_DEV float atan2f_x(float y, float x) { return (float)atan2_d((double)y, (double)x); }
+STX_DEV float acosf_x(float w) { return (float)acos_d((double)w); }
+
+// fp32 arithmetic that must not be contracted or reassociated (OpenCV's baseline build has no FMA)
+STX_DEV float fmul(float a, float b) { return __fmul_rn(a, b); }
+STX_DEV float fadd(float a, float b) { return __fadd_rn(a, b); }
+STX_DEV float fsub(float a, float b) { return __fsub_rn(a, b); }
+STX_DEV float fdiv(float a, float b) { return __fdiv_rn(a, b); }
+// a0*b0 + a1*b1 + a2*b2, left to right
+STX_DEV float dot3(float a0, float b0, float a1, float b1, float a2, float b2)
+{
+    return fadd(fadd(fmul(a0, b0), fmul(a1, b1)), fmul(a2, b2));
+}
+
+// cvRound(float) as x86-64 _mm_cvtss_si32: round-half-even, INT_MIN when out of range / NaN
+STX_DEV int cv_round(float v)
+{
+    if (!(v >= -2147483648.f && v < 2147483648.f)) return (int)0x80000000;
+    return (int)rintf(v);
+}
+STX_DEV int sat_s16(int v) { return min(max(v, -32768), 32767); }
+// static_cast<short>(float) as x86 compiles it (cvttss2si, low 16 bits)
+STX_DEV int trunc_s16(float v)
+{
+    int i;
+    if (!(v >= -2147483648.f && v < 2147483648.f)) i = (int)0x80000000;
+    else i = (int)v;
+    return (int)(short)(unsigned short)(unsigned)i;
+}
+
+// cv::borderInterpolate BORDER_REFLECT (fedcba|abcdefgh|hgfedcb), any distance
+STX_DEV int reflect(int p, int len)
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    int period = 2 * len;
+    int m = p % period;
+    if (m < 0) m += period;
+    return m < len ? m : period - 1 - m;
+}
+// cv::borderInterpolate BORDER_REFLECT_101 (gfedcb|abcdefgh|gfedcba), any distance
+STX_DEV int reflect101(int p, int len)
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    int period = 2 * len - 2;
+    int m = p % period;
+    if (m < 0) m += period;
+    return m < len ? m : period - m;
+}
+// pyrUp_ index rule on both axes: -1 -> 1 (0 when n == 1), n -> n-1
+STX_DEV int up_idx(int i, int n) { return i < 0 ? (n > 1 ? 1 : 0) : (i >= n ? n - 1 : i); }
+
+}  // namespace stxd

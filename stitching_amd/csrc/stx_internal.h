@@ -1,0 +1,159 @@
+// stx_internal.h — host-side structures shared by the C-ABI translation units.
+// gfx950 only; no CUDA compatibility layer.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/stitching_amd.h"
+
+#define STX_EXPORT extern "C" __attribute__((visibility("default")))
+#define STX_MAX_BANDS 16
+
+// ---------------------------------------------------------------------------------------------
+// error reporting
+// ---------------------------------------------------------------------------------------------
+void stx_set_error(const char* fmt, ...);
+int stx_fail(int code, const char* fmt, ...);
+
+#define STX_HIP(call)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return stx_fail(e_ == hipErrorOutOfMemory ? STX_ERR_OOM : STX_ERR_HIP, "%s failed: %s (%s:%d)", \
+                            #call, hipGetErrorString(e_), __FILE__, __LINE__);                             \
+    } while (0)
+
+#define STX_TRY(call)           \
+    do {                        \
+        int rc_ = (call);       \
+        if (rc_ != STX_OK) return rc_; \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// context: stream, caching allocator, profiler
+// ---------------------------------------------------------------------------------------------
+struct StxProfEntry {
+    std::string name;
+    int64_t calls = 0;
+    double total_ms = 0.0;
+    double algo_bytes = 0.0;
+};
+
+struct StxPendingEvent {
+    hipEvent_t start, stop;
+    int entry;
+};
+
+struct stx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // caching allocator: bucket size -> free blocks
+    std::map<size_t, std::vector<void*>> free_blocks;
+    std::map<void*, size_t> block_size;
+    size_t bytes_allocated = 0;
+    // pinned scratch for small device->host results (ROI min/max)
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+    // profiler
+    bool prof_on = false;
+    std::vector<StxProfEntry> prof;
+    std::map<std::string, int> prof_index;
+    std::vector<StxPendingEvent> prof_pending;
+    std::vector<hipEvent_t> event_pool;
+    hipEvent_t marks[16] = {};
+};
+
+int stx_dev_alloc(stx_ctx* ctx, size_t bytes, void** out);
+void stx_dev_free(stx_ctx* ctx, void* p);
+int stx_set_device(stx_ctx* ctx);
+
+// profiling bracket around one kernel launch
+struct StxProfScope {
+    stx_ctx* ctx;
+    int pending = -1;
+    StxProfScope(stx_ctx* c, const char* name, double algo_bytes);
+    ~StxProfScope();
+};
+
+// ---------------------------------------------------------------------------------------------
+// device image
+// ---------------------------------------------------------------------------------------------
+struct stx_buf {
+    stx_ctx* ctx = nullptr;
+    void* base = nullptr;  // allocation (owned when parent == nullptr)
+    uint8_t* ptr = nullptr;
+    int w = 0, h = 0, c = 0, elem = 0;
+    size_t stride = 0;  // bytes
+    stx_buf* parent = nullptr;
+    std::atomic<int> refs{1};
+};
+
+inline int stx_elem_bytes(int elem) { return elem == STX_U8 ? 1 : (elem == STX_S16 ? 2 : 4); }
+int stx_buf_new(stx_ctx* ctx, int w, int h, int c, int elem, stx_buf** out);
+void stx_buf_retain(stx_buf* b);
+void stx_buf_release(stx_buf* b);
+
+// ---------------------------------------------------------------------------------------------
+// projector (host side of ProjectorBase::setCameraParams)
+// ---------------------------------------------------------------------------------------------
+struct StxProjector {
+    int type;
+    float scale;
+    float k[9], rinv[9], r_kinv[9], k_rinv[9], t[3];
+};
+int stx_make_projector(int type, float scale, const float* K, const float* R, StxProjector* out);
+
+// kernels' host launchers (defined in the .hip files) --------------------------------------------
+struct StxWarpLaunch {
+    StxProjector proj;
+    int tlx, tly, dw, dh;          // destination roi
+    const uint8_t* src; int sw, sh; size_t sstride; int src_channels;  // src may be null (mask only)
+    uint8_t* dimg; size_t dimg_stride;    // u8x3 or null
+    uint8_t* dmask; size_t dmask_stride;  // u8x1 or null
+    int nearest_src;               // 1: out image = nearest sample of a u8x1 source (generic mask warp)
+};
+int stx_launch_warp(stx_ctx* ctx, const StxWarpLaunch& L);
+int stx_launch_roi_minmax(stx_ctx* ctx, int n, const StxProjector* projs, const int* sizes_wh, float* out_minmax4);
+
+// multi-band -------------------------------------------------------------------------------------
+struct StxMbImage {  // device-visible descriptor of one fed image (all levels)
+    const uint8_t* img0; long long img0_stride; int img0_is_s16;
+    const uint8_t* mask0; long long mask0_stride;
+    int iw, ih;            // image size
+    int ix, iy;            // image corner relative to the (padded) panorama roi
+    int fx, fy, fw, fh;    // feed rect (tl_new .. br_new) relative to the panorama roi, level 0
+    int left, top;         // copyMakeBorder offsets: bordered(x,y) = img(reflect(x-left), reflect(y-top))
+    // levels 1..B: planar int16 Gaussian pyramid (3 planes) and fp32 weight pyramid
+    short* g[STX_MAX_BANDS + 1]; long long g_stride[STX_MAX_BANDS + 1]; long long g_plane[STX_MAX_BANDS + 1];
+    float* wt[STX_MAX_BANDS + 1]; long long wt_stride[STX_MAX_BANDS + 1];
+};
+int stx_launch_mb_down0(stx_ctx* ctx, const StxMbImage& im);
+int stx_launch_mb_down(stx_ctx* ctx, const StxMbImage& im, int level /* produces level+1 */);
+struct StxMbLevelLaunch {
+    const StxMbImage* d_images; int n_images; int level; int num_bands;
+    int pw, ph;                       // padded panorama size at this level
+    short* out; long long out_stride, out_plane;            // normalised+collapsed level (planar s16), levels >= 1
+    const short* up; long long up_stride, up_plane;         // finished level+1 (null at level == num_bands)
+    // level 0 outputs
+    uint8_t* pano; long long pano_stride; uint8_t* pmask; long long pmask_stride;
+    short* pano16; long long pano16_stride;                 // optional int16 HWC result
+    int final_w, final_h;
+    double algo_bytes;
+};
+int stx_launch_mb_level(stx_ctx* ctx, const StxMbLevelLaunch& L);
+
+// simple blenders --------------------------------------------------------------------------------
+int stx_launch_no_feed(stx_ctx* ctx, const stx_buf* img, const stx_buf* mask, short* dst, long long dst_stride,
+                       uint8_t* dmask, long long dmask_stride, int dx, int dy);
+int stx_launch_feather_feed(stx_ctx* ctx, const stx_buf* img, const stx_buf* mask, float sharpness, short* dst,
+                            long long dst_stride, float* dw, long long dw_stride, int dx, int dy);
+int stx_launch_simple_finish(stx_ctx* ctx, int kind, short* dst, long long dst_stride, const float* dw,
+                             long long dw_stride, uint8_t* dmask, long long dmask_stride, int w, int h, uint8_t* pano,
+                             long long pano_stride, short* pano16, long long pano16_stride);

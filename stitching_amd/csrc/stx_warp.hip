@@ -1,0 +1,337 @@
+// stx_warp.hip — fused backward-projector + remap kernels and the ROI border reduction (gfx950).
+//
+// Replaces, for stitching/warper.py:43-52,58-68,79-82, OpenCV's
+//   RotationWarperBase<P>::buildMaps  (serial trig loop, 2 fp32 maps materialised)
+//   cv::remap INTER_LINEAR/BORDER_REFLECT (u8x3) and INTER_NEAREST/BORDER_CONSTANT (u8x1)
+//   RotationWarperBase<P>::detectResultRoiByBorder
+// with ONE pass that never stores the maps: every thread evaluates mapBackward for 4 adjacent
+// destination pixels per row, quantises to 1/32 px exactly as remap does, and samples the source
+// through the vector L1/L2 (aligned 12-byte loads + v_alignbyte for the unaligned BGR pairs).
+//
+// Trig is separable for the spherical / cylindrical projectors: sin/cos(u) depend on the column
+// only and sin/cos(pi - v) on the row only, so a 256x16 tile needs 4 sincos per thread (kept in
+// registers) + 16 per block (LDS) instead of 4 per pixel.
+#include <algorithm>
+#include <cstring>
+
+#include "stx_device_math.h"
+#include "stx_internal.h"
+
+using namespace stxd;
+
+namespace {
+
+constexpr int WARP_TW = 256;  // tile width  (64 lanes x 4 px)
+constexpr int WARP_TH = 16;   // tile height (4 waves x 4 rows)
+constexpr float PI_F = 3.14159274101257324f;  // static_cast<float>(CV_PI)
+
+struct WarpK {
+    float kr[9];
+    float t[3];
+    float scale;
+    int tlx, tly, dw, dh, sw, sh;
+    long long sstride;
+    const uint8_t* src;   // u8x3 source of the bilinear image (IMG)
+    const uint8_t* msrc;  // optional u8x1 source of the nearest image; null -> constant 255
+    long long msstride;
+    uint8_t* dimg;
+    long long dimg_stride;
+    uint8_t* dmask;
+    long long dmask_stride;
+};
+
+STX_DEV uint32_t ldg32(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
+
+// 6 consecutive bytes starting at byte address `a` (any alignment) -> lo = bytes 0..3, hi = bytes 4..7
+STX_DEV void load6(const uint8_t* base, long long a, uint32_t& lo, uint32_t& hi)
+{
+    const uint8_t* q = base + (a & ~3ll);
+    uint32_t d0 = ldg32(q), d1 = ldg32(q + 4), d2 = ldg32(q + 8);
+    uint32_t s = (uint32_t)a & 3u;
+    lo = __builtin_amdgcn_alignbyte(d1, d0, s);
+    hi = __builtin_amdgcn_alignbyte(d2, d1, s);
+}
+
+// remapBilinear, u8x3: weights (32-fx)(32-fy)*32 etc. are Q15 and exact, so
+//   (sum_w p*w + 2^14) >> 15  ==  ((p00*(32-fx) + p01*fx)*(32-fy) + (p10*(32-fx) + p11*fx)*fy + 512) >> 10
+// (the saturate_cast<short>(32768)->32767,+1 quirk of initInterTab2D at fx=fy=0 cannot change a u8 result:
+//  |p11 - p00| <= 255 < 2^14).
+STX_DEV uint32_t bil(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, uint32_t fx, uint32_t fy)
+{
+    uint32_t h0 = p00 * (32u - fx) + p01 * fx;
+    uint32_t h1 = p10 * (32u - fx) + p11 * fx;
+    return (h0 * (32u - fy) + h1 * fy + 512u) >> 10;
+}
+
+template <int TYPE, bool IMG, bool MASK>
+__global__ __launch_bounds__(256) void warp_kernel(WarpK P)
+{
+    __shared__ float s_rowa[WARP_TH];  // sph: sin(pi - v')      cyl/plane: v'
+    __shared__ float s_rowb[WARP_TH];  // sph: cos(pi - v')
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int x0 = blockIdx.x * WARP_TW + lane * 4;
+    const int y0 = blockIdx.y * WARP_TH;
+
+    if (tid < WARP_TH) {
+        float vv = (float)(P.tly + y0 + tid);
+        if (TYPE == STX_WARP_SPHERICAL) {
+            float a = fsub(PI_F, fdiv(vv, P.scale));
+            float s, c;
+            sincosf_x(a, &s, &c);
+            s_rowa[tid] = s;
+            s_rowb[tid] = c;
+        } else if (TYPE == STX_WARP_CYLINDRICAL) {
+            s_rowa[tid] = fdiv(vv, P.scale);
+        } else {
+            s_rowa[tid] = fsub(fdiv(vv, P.scale), P.t[1]);
+        }
+    }
+    float ca[4], cb[4];  // sph/cyl: sin(u'), cos(u')   plane: u'
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float uu = (float)(P.tlx + x0 + j);
+        if (TYPE == STX_WARP_SPHERICAL || TYPE == STX_WARP_CYLINDRICAL) {
+            sincosf_x(fdiv(uu, P.scale), &ca[j], &cb[j]);
+        } else {
+            ca[j] = fsub(fdiv(uu, P.scale), P.t[0]);
+            cb[j] = 0.f;
+        }
+    }
+    __syncthreads();
+    if (x0 >= P.dw) return;
+    const float omt = fsub(1.f, P.t[2]);
+
+#pragma unroll 1
+    for (int r = 0; r < WARP_TH / 4; r++) {
+        const int ry = wv + 4 * r;
+        const int y = y0 + ry;
+        if (y >= P.dh) break;
+        const float ra = s_rowa[ry], rb = (TYPE == STX_WARP_SPHERICAL) ? s_rowb[ry] : 0.f;
+        uint32_t out[3] = {0, 0, 0};
+        uint32_t mout = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float x, yy;
+            if (TYPE == STX_WARP_PLANE || TYPE == STX_WARP_AFFINE) {
+                float z;
+                x = fadd(fadd(fmul(P.kr[0], ca[j]), fmul(P.kr[1], ra)), fmul(P.kr[2], omt));
+                yy = fadd(fadd(fmul(P.kr[3], ca[j]), fmul(P.kr[4], ra)), fmul(P.kr[5], omt));
+                z = fadd(fadd(fmul(P.kr[6], ca[j]), fmul(P.kr[7], ra)), fmul(P.kr[8], omt));
+                x = fdiv(x, z);
+                yy = fdiv(yy, z);
+            } else {
+                float x_, y_, z_;
+                if (TYPE == STX_WARP_SPHERICAL) {
+                    x_ = fmul(ra, ca[j]);
+                    y_ = rb;
+                    z_ = fmul(ra, cb[j]);
+                } else {
+                    x_ = ca[j];
+                    y_ = ra;
+                    z_ = cb[j];
+                }
+                x = dot3(P.kr[0], x_, P.kr[1], y_, P.kr[2], z_);
+                yy = dot3(P.kr[3], x_, P.kr[4], y_, P.kr[5], z_);
+                float z = dot3(P.kr[6], x_, P.kr[7], y_, P.kr[8], z_);
+                if (z > 0) {
+                    x = fdiv(x, z);
+                    yy = fdiv(yy, z);
+                } else {
+                    x = yy = -1.f;
+                }
+            }
+            if (IMG) {
+                // remap(): sx = cvRound(x*32); (ix, fx) = (sx >> 5 saturated to short, sx & 31)
+                int sx = cv_round(fmul(x, 32.f)), sy = cv_round(fmul(yy, 32.f));
+                uint32_t fx = (uint32_t)sx & 31u, fy = (uint32_t)sy & 31u;
+                int ix = sat_s16(sx >> 5), iy = sat_s16(sy >> 5);
+                uint32_t b, g, rr;
+                if ((unsigned)ix < (unsigned)(P.sw - 1) && (unsigned)iy < (unsigned)(P.sh - 1)) {
+                    long long a = (long long)iy * P.sstride + (long long)ix * 3;
+                    uint32_t l0, h0, l1, h1;
+                    load6(P.src, a, l0, h0);
+                    load6(P.src, a + P.sstride, l1, h1);
+                    b = bil(l0 & 255u, l0 >> 24, l1 & 255u, l1 >> 24, fx, fy);
+                    g = bil((l0 >> 8) & 255u, h0 & 255u, (l1 >> 8) & 255u, h1 & 255u, fx, fy);
+                    rr = bil((l0 >> 16) & 255u, (h0 >> 8) & 255u, (l1 >> 16) & 255u, (h1 >> 8) & 255u, fx, fy);
+                } else {
+                    // BORDER_REFLECT taps (borderInterpolate on each of the 4 taps)
+                    int sx0 = reflect(ix, P.sw), sx1 = reflect(ix + 1, P.sw);
+                    int sy0 = reflect(iy, P.sh), sy1 = reflect(iy + 1, P.sh);
+                    const uint8_t* r0 = P.src + (long long)sy0 * P.sstride;
+                    const uint8_t* r1 = P.src + (long long)sy1 * P.sstride;
+                    b = bil(r0[sx0 * 3], r0[sx1 * 3], r1[sx0 * 3], r1[sx1 * 3], fx, fy);
+                    g = bil(r0[sx0 * 3 + 1], r0[sx1 * 3 + 1], r1[sx0 * 3 + 1], r1[sx1 * 3 + 1], fx, fy);
+                    rr = bil(r0[sx0 * 3 + 2], r0[sx1 * 3 + 2], r1[sx0 * 3 + 2], r1[sx1 * 3 + 2], fx, fy);
+                }
+                // pack the 4 BGR pixels of this thread into 3 dwords
+                uint32_t px = b | (g << 8) | (rr << 16);  // 24 bits
+                if (j == 0) out[0] = px;
+                else if (j == 1) { out[0] |= px << 24; out[1] = px >> 8; }
+                else if (j == 2) { out[1] |= px << 16; out[2] = px >> 16; }
+                else out[2] |= px << 8;
+            }
+            if (MASK) {
+                // remapNearest: saturate_cast<short>(cvRound(x)); inside -> source (255), else 0
+                int nx = sat_s16(cv_round(x)), ny = sat_s16(cv_round(yy));
+                uint32_t m = 0;
+                if ((unsigned)nx < (unsigned)P.sw && (unsigned)ny < (unsigned)P.sh)
+                    m = P.msrc ? (uint32_t)P.msrc[(long long)ny * P.msstride + nx] : 255u;
+                mout |= m << (8 * j);
+            }
+        }
+        if (IMG) {
+            uint32_t* d = reinterpret_cast<uint32_t*>(P.dimg + (long long)y * P.dimg_stride + (long long)x0 * 3);
+            d[0] = out[0];
+            d[1] = out[1];
+            d[2] = out[2];
+        }
+        if (MASK) *reinterpret_cast<uint32_t*>(P.dmask + (long long)y * P.dmask_stride + x0) = mout;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ROI: forward-project the source border, NaN-ignoring float min/max
+// ---------------------------------------------------------------------------------------------
+struct RoiK {
+    float rk[9];
+    float scale;
+    int type, w, h;
+};
+
+STX_DEV uint32_t f2ord(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void roi_kernel(const RoiK* __restrict__ Ps, uint32_t* __restrict__ out)
+{
+    const RoiK P = Ps[blockIdx.y];
+    const int npts = 2 * P.w + 2 * P.h;
+    float mnu = 3.402823466e+38f, mnv = 3.402823466e+38f, mxu = -3.402823466e+38f, mxv = -3.402823466e+38f;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npts; p += gridDim.x * blockDim.x) {
+        float x, y;
+        if (p < P.w) { x = (float)p; y = 0.f; }
+        else if (p < 2 * P.w) { x = (float)(p - P.w); y = (float)(P.h - 1); }
+        else if (p < 2 * P.w + P.h) { x = 0.f; y = (float)(p - 2 * P.w); }
+        else { x = (float)(P.w - 1); y = (float)(p - 2 * P.w - P.h); }
+        // mapForward: r_kinv * (x, y, 1)
+        float x_ = fadd(fadd(fmul(P.rk[0], x), fmul(P.rk[1], y)), P.rk[2]);
+        float y_ = fadd(fadd(fmul(P.rk[3], x), fmul(P.rk[4], y)), P.rk[5]);
+        float z_ = fadd(fadd(fmul(P.rk[6], x), fmul(P.rk[7], y)), P.rk[8]);
+        float u = fmul(P.scale, atan2f_x(x_, z_)), v;
+        if (P.type == STX_WARP_SPHERICAL) {
+            float n = __fsqrt_rn(fadd(fadd(fmul(x_, x_), fmul(y_, y_)), fmul(z_, z_)));
+            float w = fdiv(y_, n);
+            v = fmul(P.scale, fsub(PI_F, acosf_x(w == w ? w : 0.f)));
+        } else {  // cylindrical
+            v = fdiv(fmul(P.scale, y_), __fsqrt_rn(fadd(fmul(x_, x_), fmul(z_, z_))));
+        }
+        if (u < mnu) mnu = u;
+        if (v < mnv) mnv = v;
+        if (u > mxu) mxu = u;
+        if (v > mxv) mxv = v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float a = __shfl_xor(mnu, o), b = __shfl_xor(mnv, o), c = __shfl_xor(mxu, o), d = __shfl_xor(mxv, o);
+        if (a < mnu) mnu = a;
+        if (b < mnv) mnv = b;
+        if (c > mxu) mxu = c;
+        if (d > mxv) mxv = d;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        uint32_t* o = out + 4 * blockIdx.y;
+        atomicMin(o + 0, f2ord(mnu));
+        atomicMin(o + 1, f2ord(mnv));
+        atomicMax(o + 2, f2ord(mxu));
+        atomicMax(o + 3, f2ord(mxv));
+    }
+}
+
+template <int TYPE>
+int launch_typed(stx_ctx* ctx, const WarpK& K, bool img, bool mask, dim3 grid)
+{
+    hipStream_t s = ctx->stream;
+    if (img && mask) hipLaunchKernelGGL((warp_kernel<TYPE, true, true>), grid, dim3(256), 0, s, K);
+    else if (img) hipLaunchKernelGGL((warp_kernel<TYPE, true, false>), grid, dim3(256), 0, s, K);
+    else hipLaunchKernelGGL((warp_kernel<TYPE, false, true>), grid, dim3(256), 0, s, K);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return stx_fail(STX_ERR_HIP, "warp kernel launch failed: %s", hipGetErrorString(e));
+    return STX_OK;
+}
+
+}  // namespace
+
+int stx_launch_warp(stx_ctx* ctx, const StxWarpLaunch& L)
+{
+    WarpK K;
+    for (int i = 0; i < 9; i++) K.kr[i] = L.proj.k_rinv[i];
+    for (int i = 0; i < 3; i++) K.t[i] = L.proj.t[i];
+    K.scale = L.proj.scale;
+    K.tlx = L.tlx; K.tly = L.tly; K.dw = L.dw; K.dh = L.dh;
+    K.sw = L.sw; K.sh = L.sh;
+    const bool img = L.dimg != nullptr, mask = L.dmask != nullptr;
+    K.src = img ? L.src : nullptr;
+    K.sstride = (long long)L.sstride;
+    K.msrc = L.nearest_src ? L.src : nullptr;
+    K.msstride = (long long)L.sstride;
+    K.dimg = L.dimg; K.dimg_stride = (long long)L.dimg_stride;
+    K.dmask = L.dmask; K.dmask_stride = (long long)L.dmask_stride;
+    dim3 grid((L.dw + WARP_TW - 1) / WARP_TW, (L.dh + WARP_TH - 1) / WARP_TH);
+    // algorithmic bytes: read the source once, write the warped image + mask once
+    double bytes = (img ? 3.0 * L.sw * L.sh + 3.0 * L.dw * L.dh : 0.0) + (mask ? 1.0 * L.dw * L.dh : 0.0);
+    StxProfScope prof(ctx, img ? (mask ? "warp_img_mask" : "warp_img") : "warp_mask", bytes);
+    switch (L.proj.type) {
+    case STX_WARP_PLANE:
+    case STX_WARP_AFFINE: return launch_typed<STX_WARP_PLANE>(ctx, K, img, mask, grid);
+    case STX_WARP_CYLINDRICAL: return launch_typed<STX_WARP_CYLINDRICAL>(ctx, K, img, mask, grid);
+    case STX_WARP_SPHERICAL: return launch_typed<STX_WARP_SPHERICAL>(ctx, K, img, mask, grid);
+    }
+    return stx_fail(STX_ERR_UNSUPPORTED, "warp type %d not implemented", L.proj.type);
+}
+
+// out_minmax4[i] = {min u, min v, max u, max v} over the border of image i (cyl / spherical)
+int stx_launch_roi_minmax(stx_ctx* ctx, int n, const StxProjector* projs, const int* sizes_wh, float* out_minmax4)
+{
+    std::vector<RoiK> hk(n);
+    int maxpts = 0;
+    for (int i = 0; i < n; i++) {
+        for (int k = 0; k < 9; k++) hk[i].rk[k] = projs[i].r_kinv[k];
+        hk[i].scale = projs[i].scale;
+        hk[i].type = projs[i].type;
+        hk[i].w = sizes_wh[2 * i];
+        hk[i].h = sizes_wh[2 * i + 1];
+        maxpts = std::max(maxpts, 2 * hk[i].w + 2 * hk[i].h);
+    }
+    void* dk = nullptr;
+    void* dout = nullptr;
+    STX_TRY(stx_dev_alloc(ctx, sizeof(RoiK) * n, &dk));
+    STX_TRY(stx_dev_alloc(ctx, 16 * n, &dout));
+    std::vector<uint32_t> init(4 * n);
+    for (int i = 0; i < n; i++) {
+        // ordered encodings of +FLT_MAX (for the minima) and -FLT_MAX (for the maxima)
+        init[4 * i + 0] = init[4 * i + 1] = 0x7f7fffffu | 0x80000000u;
+        init[4 * i + 2] = init[4 * i + 3] = ~0xff7fffffu;
+    }
+    STX_HIP(hipMemcpyAsync(dk, hk.data(), sizeof(RoiK) * n, hipMemcpyHostToDevice, ctx->stream));
+    STX_HIP(hipMemcpyAsync(dout, init.data(), 16 * n, hipMemcpyHostToDevice, ctx->stream));
+    {
+        StxProfScope prof(ctx, "roi_border_minmax", 0.0);
+        int bx = std::min(64, (maxpts + 255) / 256);
+        hipLaunchKernelGGL(roi_kernel, dim3(bx, n), dim3(256), 0, ctx->stream, (const RoiK*)dk, (uint32_t*)dout);
+    }
+    std::vector<uint32_t> res(4 * n);
+    STX_HIP(hipMemcpyAsync(res.data(), dout, 16 * n, hipMemcpyDeviceToHost, ctx->stream));
+    STX_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 4 * n; i++) {
+        uint32_t u = res[i];
+        u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+        memcpy(&out_minmax4[i], &u, 4);
+    }
+    stx_dev_free(ctx, dk);
+    stx_dev_free(ctx, dout);
+    return STX_OK;
+}

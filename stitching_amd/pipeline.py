@@ -1,0 +1,75 @@
+"""Device-resident warp -> blend driver (the hot loop of stitching/stitcher.py:117-128 with the
+stages outside the path — exposure compensation, seam masks, cropping — switched off, as in
+BASELINE.json's synthetic configurations).
+
+One image is in flight on the host side exactly as in the reference
+(stitching/stitcher.py:247-254), but nothing waits for the GPU between images: warps, pyramid
+builds and the final gather are enqueued on one HIP stream; the only host syncs are the batched
+ROI read-back at the start and whatever the caller does with the result.
+"""
+import numpy as np
+
+from . import config
+from .blender import Blender
+from .device import DeviceImage, as_device, get_context
+from .stitching_error import StitchingError
+from .synthetic import blend_strength_for_bands
+from .warper import Warper
+
+
+class StitchJob:
+    """Pre-staged inputs of one panorama: device-resident source frames + cameras."""
+
+    def __init__(self, frames, cameras, warper_type="spherical", blender_type="multiband", num_bands=None,
+                 blend_strength=Blender.DEFAULT_BLEND_STRENGTH, ctx=None):
+        if len(frames) != len(cameras) or not frames:
+            raise StitchingError("need one camera per frame and at least one frame")
+        self.ctx = ctx or get_context()
+        self.frames = [as_device(f, self.ctx) for f in frames]
+        self.cameras = list(cameras)
+        self.sizes = [(f.width, f.height) for f in self.frames]
+        self.warper = Warper(warper_type)
+        self.warper.set_scale(self.cameras)
+        self.blender_type = blender_type
+        self.num_bands = num_bands
+        self.blend_strength = blend_strength
+        self.corners = self.warped_sizes = None
+
+    @property
+    def source_pixels(self):
+        return sum(w * h for w, h in self.sizes)
+
+    def plan(self):
+        """Eager ROI pass (stitching/stitcher.py:188 warp_rois is eager too); one device sync."""
+        self.corners, self.warped_sizes = self.warper.warp_rois(self.sizes, self.cameras)
+        if self.num_bands is not None:
+            roi = Blender.result_roi(self.corners, self.warped_sizes)
+            self.blend_strength = blend_strength_for_bands(self.num_bands, roi[2], roi[3])
+        return self.corners, self.warped_sizes
+
+    def run(self):
+        """warp every frame, feed it, blend.  Returns device-resident (panorama u8x3, mask u8)."""
+        if self.corners is None:
+            self.plan()
+        prev = config.device_resident()
+        config.set_device_resident(True)
+        try:
+            blender = Blender(self.blender_type, self.blend_strength)
+            blender.prepare(self.corners, self.warped_sizes)
+            for frame, cam, corner in zip(self.frames, self.cameras, self.corners):
+                img, mask, roi = self.warper.warp_image_and_mask(frame, cam)
+                if roi[0:2] != tuple(corner):
+                    raise StitchingError("warp roi changed between plan() and run()")
+                blender.feed(img, mask, corner)
+            self.last_num_bands = blender.blender.num_bands()
+            pano, pmask = blender.blend()
+        finally:
+            config.set_device_resident(prev)
+        return pano, pmask
+
+
+def stitch(frames, cameras, **kw):
+    """Convenience: numpy frames in, numpy panorama out (PCIe-inclusive path)."""
+    job = StitchJob(frames, cameras, **kw)
+    pano, mask = job.run()
+    return np.asarray(pano), np.asarray(mask)

@@ -1,0 +1,169 @@
+"""Warper — drop-in for stitching.warper.Warper (stitching/warper.py:7-94) on MI355X.
+
+Same class surface, constants and generator behaviour; every cv.PyRotationWarper call is
+replaced by the C ABI of include/stitching_amd.h:
+    warper.warp(img, K, R, INTER_LINEAR, BORDER_REFLECT)    -> stx_warp            (warper.py:44-51)
+    warper.warp(mask, K, R, INTER_NEAREST, BORDER_CONSTANT) -> stx_warp_mask       (warper.py:59-67)
+    warper.warpRoi(size, K, R)                              -> stx_warp_roi(s)     (warper.py:79-82)
+"""
+import ctypes as C
+from statistics import median
+
+import numpy as np
+
+from . import _lib, config
+from .device import DeviceImage, as_device, get_context
+from .stitching_error import StitchingError
+
+_TYPE_IDS = {"plane": _lib.WARP_PLANE, "affine": _lib.WARP_AFFINE, "cylindrical": _lib.WARP_CYLINDRICAL,
+             "spherical": _lib.WARP_SPHERICAL}
+
+
+def _mat33(m, what):
+    """The projector asserts K, R are 3x3 CV_32F (ProjectorBase::setCameraParams); mirror that."""
+    a = np.asarray(m)
+    if a.shape != (3, 3) or a.dtype != np.float32:
+        raise StitchingError(f"{what} must be a 3x3 float32 matrix, got shape {a.shape} dtype {a.dtype}")
+    return np.ascontiguousarray(a)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Warper:
+    """https://docs.opencv.org/4.x/da/db8/classcv_1_1detail_1_1RotationWarper.html"""
+
+    WARP_TYPE_CHOICES = (
+        "spherical",
+        "plane",
+        "affine",
+        "cylindrical",
+        "fisheye",
+        "stereographic",
+        "compressedPlaneA2B1",
+        "compressedPlaneA1.5B1",
+        "compressedPlanePortraitA2B1",
+        "compressedPlanePortraitA1.5B1",
+        "paniniA2B1",
+        "paniniA1.5B1",
+        "paniniPortraitA2B1",
+        "paniniPortraitA1.5B1",
+        "mercator",
+        "transverseMercator",
+    )
+    # implemented by the HIP back end (BASELINE.json configs use spherical, cylindrical, affine)
+    SUPPORTED_WARP_TYPES = tuple(_TYPE_IDS)
+
+    DEFAULT_WARP_TYPE = "spherical"
+
+    def __init__(self, warper_type=DEFAULT_WARP_TYPE):
+        self.warper_type = warper_type
+        self.scale = None
+
+    # ------------------------------------------------------------------ reference surface
+    def set_scale(self, cameras):
+        focals = [cam.focal for cam in cameras]
+        self.scale = median(focals)
+
+    def warp_images(self, imgs, cameras, aspect=1):
+        for img, camera in zip(imgs, cameras):
+            yield self.warp_image(img, camera, aspect)
+
+    def warp_image(self, img, camera, aspect=1):
+        ctx = get_context()
+        src = as_device(img, ctx)
+        if src.channels != 3 or src.dtype != np.uint8:
+            raise StitchingError(f"warp_image expects a HxWx3 uint8 image, got {src.shape} {src.dtype}")
+        K, R = self._K_R(camera, aspect)
+        out, tl = C.c_void_p(), (C.c_int * 2)()
+        _lib.check(ctx._lib.stx_warp(ctx.handle, self._type_id(), self._scale(aspect), _fp(K), _fp(R), src._h,
+                                     _lib.INTER_LINEAR, _lib.BORDER_REFLECT, C.byref(out), tl))
+        return self._result(DeviceImage(ctx, out))
+
+    def create_and_warp_masks(self, sizes, cameras, aspect=1):
+        for size, camera in zip(sizes, cameras):
+            yield self.create_and_warp_mask(size, camera, aspect)
+
+    def create_and_warp_mask(self, size, camera, aspect=1):
+        ctx = get_context()
+        K, R = self._K_R(camera, aspect)
+        out, roi = C.c_void_p(), (C.c_int * 4)()
+        _lib.check(ctx._lib.stx_warp_mask(ctx.handle, self._type_id(), self._scale(aspect), _fp(K), _fp(R),
+                                          int(size[0]), int(size[1]), C.byref(out), roi))
+        return self._result(DeviceImage(ctx, out))
+
+    def warp_rois(self, sizes, cameras, aspect=1):
+        sizes, cameras = list(sizes), list(cameras)
+        n = min(len(sizes), len(cameras))
+        roi_corners, roi_sizes = [], []
+        if n == 0:
+            return roi_corners, roi_sizes
+        ctx = get_context()
+        Ks = np.empty((n, 3, 3), np.float32)
+        Rs = np.empty((n, 3, 3), np.float32)
+        for i in range(n):
+            Ks[i], Rs[i] = self._K_R(cameras[i], aspect)
+        wh = np.ascontiguousarray([[int(s[0]), int(s[1])] for s in sizes[:n]], np.int32)
+        out = np.zeros((n, 4), np.int32)
+        _lib.check(ctx._lib.stx_warp_rois(ctx.handle, self._type_id(), self._scale(aspect), n, _fp(Ks), _fp(Rs),
+                                          wh.ctypes.data_as(C.POINTER(C.c_int)),
+                                          out.ctypes.data_as(C.POINTER(C.c_int))))
+        for roi in out:
+            roi = tuple(int(v) for v in roi)
+            roi_corners.append(roi[0:2])
+            roi_sizes.append(roi[2:4])
+        return roi_corners, roi_sizes
+
+    def warp_roi(self, size, camera, aspect=1):
+        ctx = get_context()
+        K, R = self._K_R(camera, aspect)
+        roi = (C.c_int * 4)()
+        _lib.check(ctx._lib.stx_warp_roi(ctx.handle, self._type_id(), self._scale(aspect), _fp(K), _fp(R),
+                                         int(size[0]), int(size[1]), roi))
+        return tuple(int(v) for v in roi)
+
+    @staticmethod
+    def get_K(camera, aspect=1):
+        K = camera.K().astype(np.float32)
+        """ Modification of intrinsic parameters needed if cameras were
+        obtained on different scale than the scale of the Images which should
+        be warped """
+        K[0, 0] *= aspect
+        K[0, 2] *= aspect
+        K[1, 1] *= aspect
+        K[1, 2] *= aspect
+        return K
+
+    # ------------------------------------------------------------------ back-end extras
+    def warp_image_and_mask(self, img, camera, aspect=1):
+        """Fused form of warp_image + create_and_warp_mask for one camera: the backward map is
+        evaluated once.  Returns (warped_image, warped_mask, (x, y, w, h))."""
+        ctx = get_context()
+        src = as_device(img, ctx)
+        K, R = self._K_R(camera, aspect)
+        oi, om, roi = C.c_void_p(), C.c_void_p(), (C.c_int * 4)()
+        _lib.check(ctx._lib.stx_warp_image_and_mask(ctx.handle, self._type_id(), self._scale(aspect), _fp(K), _fp(R),
+                                                    src._h, C.byref(oi), C.byref(om), roi))
+        return (self._result(DeviceImage(ctx, oi)), self._result(DeviceImage(ctx, om)), tuple(int(v) for v in roi))
+
+    # ------------------------------------------------------------------ helpers
+    def _type_id(self):
+        if self.warper_type not in Warper.WARP_TYPE_CHOICES:
+            raise StitchingError(f"unknown warper type {self.warper_type!r}")
+        if self.warper_type not in _TYPE_IDS:
+            raise StitchingError(f"warper type {self.warper_type!r} is not implemented by the MI355X back end "
+                                 f"(implemented: {', '.join(_TYPE_IDS)})")
+        return _TYPE_IDS[self.warper_type]
+
+    def _scale(self, aspect):
+        if self.scale is None:
+            raise StitchingError("Warper.set_scale(cameras) must be called before warping")
+        return float(self.scale * aspect)
+
+    def _K_R(self, camera, aspect):
+        return _mat33(Warper.get_K(camera, aspect), "K"), _mat33(camera.R, "camera.R")
+
+    @staticmethod
+    def _result(dev):
+        return dev if config.device_resident() else dev.numpy()
