@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""bench.py — warp + multi-band blend throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic input: every source frame
+(already resident in HBM) is warped (spherical, fused image + mask), fed to the 5-band blender
+and the panorama is produced in HBM.  N = 1 runs BASELINE.json configs[1]
+(8 synthetic 4000x3000 frames).  N > 1 is weak scaling: 8 frames per GPU, 8N frames in one ring
+panorama (stitching_amd/synthetic.py: ring_cameras), sharded as contiguous yaw runs.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
+HIP events on the stream the kernel runs on) and `cpu_baseline` (the oracle, timed on the host
+cores, N = 1 only).  torch is imported only for N > 1 (rendezvous / barrier); the product path is
+ctypes -> libstitching_amd.so.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--frames-per-gpu", type=int, default=8)
+    p.add_argument("--width", type=int, default=4000)
+    p.add_argument("--height", type=int, default=3000)
+    p.add_argument("--bands", type=int, default=5)
+    p.add_argument("--warper", default="spherical")
+    p.add_argument("--blender", default="multiband")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-frames", type=int, default=8, help="frames in the CPU-baseline sample")
+    p.add_argument("--profile-steps", type=int, default=3)
+    p.add_argument("--traffic-json", default=None, help="optional JSON with PMC-derived HBM bytes per launch")
+    return p.parse_args()
+
+
+def cpu_baseline(args, frames, cams, all_cams):
+    """The oracle (CPU restatement of OpenCV's algorithm — NOT OpenCV; see oracle/stx_oracle.cpp)
+    on the same workload, all host cores (OpenMP)."""
+    import numpy as np
+
+    from oracle import oracle as O
+    from stitching_amd.synthetic import blend_strength_for_bands
+
+    O.build()
+    cores = O.max_threads()
+    O.set_num_threads(cores)
+    n = min(args.cpu_frames, len(frames))
+    frames, cams = frames[:n], cams[:n]
+    sizes = [(f.shape[1], f.shape[0]) for f in frames]
+    w = O.Warper(args.warper)
+    w.set_scale(all_cams)
+    t0 = time.perf_counter()
+    corners, wsizes = w.warp_rois(sizes, cams)
+    roi = O.result_roi(corners, wsizes)
+    b = O.Blender(args.blender, blend_strength_for_bands(args.bands, roi[2], roi[3]))
+    b.prepare(corners, wsizes)
+    for f, c, corner in zip(frames, cams, corners):
+        b.feed(w.warp_image(f, c), w.create_and_warp_mask((f.shape[1], f.shape[0]), c), corner)
+    pano, _ = b.blend()
+    dt = time.perf_counter() - t0
+    mpix = sum(f.shape[0] * f.shape[1] for f in frames) / 1e6
+    return {"value": round(mpix / dt, 3), "unit": "Mpix/s", "cores": cores, "kind": "port",
+            "sample": f"{n} frames {args.width}x{args.height}, {args.warper} warp + {b.blender.num_bands()}-band "
+                      f"blend, {dt:.2f} s wall; CPU restatement of OpenCV's algorithm (oracle/), not OpenCV"}, np.asarray(pano)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+            sys.exit(2)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    import stitching_amd as S
+    from stitching_amd import synthetic
+    from stitching_amd.pipeline import StitchJob
+
+    S.set_default_device(local_rank)
+    ctx = S.get_context()
+
+    fpg = args.frames_per_gpu
+    n_total = fpg * world
+    all_cams = synthetic.ring_cameras(n_total, args.width, args.height, focal_factor=0.75 * world)
+    my = range(rank * fpg, (rank + 1) * fpg)
+    frames = [synthetic.make_frame(i, args.width, args.height) for i in my]
+    cams = [all_cams[i] for i in my]
+
+    if world > 1:
+        from stitching_amd.distributed import ShardedStitchJob
+
+        job = ShardedStitchJob(frames, cams, all_cams, rank, world, warper_type=args.warper,
+                               blender_type=args.blender, num_bands=args.bands, ctx=ctx, dist=dist)
+    else:
+        job = StitchJob(frames, cams, warper_type=args.warper, blender_type=args.blender, num_bands=args.bands, ctx=ctx)
+        job.warper.set_scale(all_cams)
+    job.plan()
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        out = job.run()
+        del out
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = job.run()
+        del out
+    ctx.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel durations: HIP events on the ctx stream, separate pass over the same steps
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    for _ in range(max(1, args.profile_steps)):
+        out = job.run()
+        del out
+    ctx.prof_enable(False)
+    kernels = ctx.prof_results()
+    ctx.prof_reset()
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    src_mpix = n_total * args.width * args.height / 1e6
+    ms_per_step = dt / args.steps * 1e3
+    value = src_mpix / (ms_per_step / 1e3)
+    kernels.sort(key=lambda k: -k["total_ms"])
+    dom = kernels[0]
+    avg_ms = dom["total_ms"] / dom["calls"]
+    bytes_per_launch = dom["algo_bytes"] / dom["calls"]
+    achieved = bytes_per_launch / (avg_ms / 1e3) / 1e9
+    traffic = None
+    if args.traffic_json and os.path.exists(args.traffic_json):
+        traffic = json.load(open(args.traffic_json)).get(dom["kernel"])
+    roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "avg_launch_us": round(avg_ms * 1e3, 2), "algo_bytes_per_launch": round(bytes_per_launch),
+                "launches_per_step": dom["calls"] / max(1, args.profile_steps)}
+    ksum = sum(k["total_ms"] for k in kernels)
+    kbytes = sum(k["algo_bytes"] for k in kernels)
+    result = {
+        "metric": "warped+blended Mpix/s", "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8/int16 (fixed-point remap, int32 pyramid sums, fp32 weights)",
+        "data": "synthetic",
+        "config": {"workload": f"{n_total} synthetic {args.width}x{args.height} frames, {args.warper} warp + "
+                               f"{getattr(job, 'last_num_bands', args.bands)}-band {args.blender} blend, inputs resident in HBM",
+                   "frames_per_gpu": fpg, "sharding": "contiguous yaw runs" if world > 1 else "single GPU",
+                   "source_mpix_per_step": round(src_mpix, 2)},
+        "roofline": roofline,
+        "kernels": [{"kernel": k["kernel"], "calls_per_step": k["calls"] / max(1, args.profile_steps),
+                     "avg_us": round(k["total_ms"] / k["calls"] * 1e3, 2),
+                     "algo_GBps": round(k["algo_bytes"] / max(k["total_ms"], 1e-9) / 1e6, 1)} for k in kernels],
+        "all_kernels": {"sum_ms_per_step": round(ksum / max(1, args.profile_steps), 4),
+                        "algo_GBps": round(kbytes / max(ksum, 1e-9) / 1e6, 1),
+                        "frac_of_hbm_peak": round(kbytes / max(ksum, 1e-9) / 1e6 / HBM_PEAK_GBS, 4)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        cb, _ = cpu_baseline(args, frames, cams, all_cams)
+        result["cpu_baseline"] = cb
+    print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -22,11 +22,15 @@ def make_frame(index, width, height, seed=1234):
     x0 = np.minimum(gx.astype(np.int32), 14)
     fy = (gy - y0)[:, None, None]
     fx = (gx - x0)[None, :, None]
-    top = grid[y0][:, x0] * (1 - fx) + grid[y0][:, x0 + 1] * fx
-    bot = grid[y0 + 1][:, x0] * (1 - fx) + grid[y0 + 1][:, x0 + 1] * fx
-    img = top * (1 - fy) + bot * fy
-    img += rng.integers(-24, 25, size=(height, width, 3)).astype(np.float32)
-    return np.clip(img, 0, 255).astype(np.uint8)
+    cols = grid[:, x0] * (1 - fx) + grid[:, x0 + 1] * fx  # (12, W, 3): interpolate along x first
+    noise = rng.integers(-24, 25, size=(height, width, 3), dtype=np.int16)
+    out = np.empty((height, width, 3), np.uint8)
+    for r0 in range(0, height, 256):  # row blocks keep the fp32 temporaries cache-sized
+        r1 = min(r0 + 256, height)
+        blk = cols[y0[r0:r1]] * (1 - fy[r0:r1]) + cols[y0[r0:r1] + 1] * fy[r0:r1]
+        blk += noise[r0:r1]
+        out[r0:r1] = np.clip(blk, 0, 255).astype(np.uint8)
+    return out
 
 
 def rot_y(a):

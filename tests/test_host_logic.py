@@ -1,0 +1,102 @@
+"""Host-side logic of the drop-in classes that needs no GPU."""
+import math
+
+import numpy as np
+import pytest
+
+import stitching_amd as S
+from stitching_amd import synthetic
+from stitching_amd.warper import _mat33
+
+
+def test_class_surface_matches_reference():
+    # stitching/warper.py:10-29, stitching/blender.py:8-13
+    assert S.Warper.DEFAULT_WARP_TYPE == "spherical"
+    assert len(S.Warper.WARP_TYPE_CHOICES) == 16 and S.Warper.WARP_TYPE_CHOICES[:4] == ("spherical", "plane", "affine", "cylindrical")
+    assert S.Blender.BLENDER_CHOICES == ("multiband", "feather", "no")
+    assert S.Blender.DEFAULT_BLENDER == "multiband" and S.Blender.DEFAULT_BLEND_STRENGTH == 5
+    w = S.Warper()
+    assert w.warper_type == "spherical" and w.scale is None
+    b = S.Blender()
+    assert b.blender_type == "multiband" and b.blend_strength == 5 and b.blender is None
+    for name in ["set_scale", "warp_images", "warp_image", "create_and_warp_masks", "create_and_warp_mask", "warp_rois",
+                 "warp_roi", "get_K"]:
+        assert hasattr(S.Warper, name)
+    for name in ["prepare", "feed", "blend", "create_panorama"]:
+        assert hasattr(S.Blender, name)
+
+
+def test_set_scale_is_median_focal():
+    cams = [S.CameraParams(focal=f) for f in (100.0, 300.0, 200.0, 400.0)]
+    w = S.Warper()
+    w.set_scale(cams)
+    assert w.scale == 250.0
+
+
+def test_get_K_scales_intrinsics_and_casts():
+    cam = S.CameraParams(focal=1000.0, aspect=1.5, ppx=320.0, ppy=240.0)
+    K = S.Warper.get_K(cam, 0.5)
+    assert K.dtype == np.float32
+    assert np.allclose(K, [[500, 0, 160], [0, 750, 120], [0, 0, 1]])
+
+
+def test_generators_are_lazy():
+    w = S.Warper()
+    g = w.warp_images([object()], [object()])
+    assert hasattr(g, "__next__")  # nothing executed yet
+    g2 = w.create_and_warp_masks([(1, 1)], [object()])
+    assert hasattr(g2, "__next__")
+
+
+def test_matrix_validation_mirrors_cv_assert():
+    with pytest.raises(S.StitchingError):
+        _mat33(np.eye(3, dtype=np.float64), "R")
+    with pytest.raises(S.StitchingError):
+        _mat33(np.eye(4, dtype=np.float32), "R")
+    assert _mat33(np.eye(3, dtype=np.float32), "R").flags["C_CONTIGUOUS"]
+
+
+def test_unsupported_and_unknown_types_raise():
+    w = S.Warper("fisheye")
+    w.scale = 1.0
+    with pytest.raises(S.StitchingError, match="not implemented"):
+        w._type_id()
+    with pytest.raises(S.StitchingError, match="unknown"):
+        S.Warper("bogus")._type_id()
+    with pytest.raises(S.StitchingError):
+        S.Warper()._scale(1)  # set_scale not called
+
+
+def test_blender_requires_prepare():
+    b = S.Blender()
+    with pytest.raises(S.StitchingError):
+        b.feed(np.zeros((2, 2, 3), np.uint8), np.zeros((2, 2), np.uint8), (0, 0))
+    with pytest.raises(S.StitchingError):
+        b.blend()
+
+
+def test_blend_strength_for_bands_inverts_reference_formula():
+    for bands in range(0, 9):
+        for (w, h) in [(2636, 673), (21000, 2800), (142000, 3000)]:
+            s = synthetic.blend_strength_for_bands(bands, w, h)
+            bw = np.sqrt(w * h) * s / 100
+            assert int((np.log(bw) / np.log(2.0) - 1.0)) == bands  # stitching/blender.py:32
+
+
+def test_ring_cameras_do_not_cross_the_seam():
+    for n, ff in [(8, 0.75), (16, 1.5), (64, 6.0)]:
+        cams = synthetic.ring_cameras(n, 4000, 3000, focal_factor=ff)
+        hfov = 2 * math.degrees(math.atan(4000 / (2 * ff * 4000)))
+        yaws = [math.degrees(math.atan2(c.R[0, 2], c.R[2, 2])) for c in cams]
+        assert max(abs(y) for y in yaws) + hfov / 2 < 175
+        assert all(c.R.dtype == np.float32 for c in cams)
+        assert all(abs(np.linalg.det(c.R.astype(np.float64)) - 1) < 1e-5 for c in cams)
+
+
+def test_make_frame_is_seeded_and_textured():
+    a = synthetic.make_frame(3, 64, 48)
+    b = synthetic.make_frame(3, 64, 48)
+    c = synthetic.make_frame(4, 64, 48)
+    assert a.dtype == np.uint8 and a.shape == (48, 64, 3)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    assert a.std() > 10

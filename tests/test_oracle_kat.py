@@ -1,0 +1,275 @@
+"""Known-answer tests that pin the CPU oracle (parity vs real OpenCV is UNPINNED — the
+reference's tests hold no golden vectors on this path and no OpenCV binary exists here; SURVEY.md
+§8c).  Closed forms and hand-derived vectors only."""
+import math
+
+import numpy as np
+import pytest
+
+from stitching_amd import synthetic
+
+
+def cam0(o, f=3000.0, w=4000, h=3000, R=None):
+    return o.CameraParams(focal=f, ppx=w / 2, ppy=h / 2, R=np.eye(3, dtype=np.float32) if R is None else R)
+
+
+# ------------------------------------------------------------------------------- trig
+def test_exact_trig_matches_double_libm(oracle):
+    rng = np.random.default_rng(0)
+    for x in rng.uniform(-20, 20, 4000):
+        s, c = oracle.sincos_d(x)
+        assert abs(s - math.sin(x)) < 3e-16 and abs(c - math.cos(x)) < 3e-16
+    for y, x in zip(rng.normal(size=4000), rng.normal(size=4000)):
+        assert abs(oracle.atan2_d(y, x) - math.atan2(y, x)) < 9e-16
+    for w in rng.uniform(-1, 1, 4000):
+        assert abs(oracle.acos_d(w) - math.acos(w)) < 9e-16
+    assert oracle.atan2_d(0.0, -1.0) == math.pi and oracle.atan2_d(-0.0, -1.0) == -math.pi
+    assert oracle.atan2_d(1.0, 0.0) == math.pi / 2 and oracle.atan2_d(0.0, 1.0) == 0.0
+    assert math.isnan(oracle.acos_d(1.0000001))
+
+
+def test_exact_vs_libm_maps_within_one_ulp(oracle):
+    """trig=exact (what the GPU reproduces) vs trig=libm (what OpenCV calls): fp32 warp
+    coordinates agree within 1 ULP of the intermediate trig values; after the projector the
+    coordinates differ by < 1/32 px quantum almost everywhere."""
+    cam = synthetic.ring_cameras(3, 640, 480, span_deg=100.0)[2]
+    K = oracle.Warper.get_K(cam)
+    for wt in ("spherical", "cylindrical"):
+        roi = oracle.warp_roi(wt, 480.0, K, cam.R, (640, 480), oracle.TRIG_EXACT)
+        assert roi == oracle.warp_roi(wt, 480.0, K, cam.R, (640, 480), oracle.TRIG_LIBM)
+        xe, ye = oracle.build_maps(wt, 480.0, K, cam.R, roi, oracle.TRIG_EXACT)
+        xl, yl = oracle.build_maps(wt, 480.0, K, cam.R, roi, oracle.TRIG_LIBM)
+        ok = np.isfinite(xe) & (np.abs(xe) < 2000) & (np.abs(ye) < 2000)
+        assert np.abs(xe - xl)[ok].max() < 2e-3 and np.abs(ye - yl)[ok].max() < 2e-3
+        frac_same = np.mean((xe == xl)[ok] & (ye == yl)[ok])
+        assert frac_same > 0.97
+
+
+def test_exact_vs_libm_pixels_within_one_lsb(oracle):
+    imgs = [synthetic.make_frame(0, 320, 240)]
+    cam = synthetic.ring_cameras(3, 320, 240, span_deg=100.0)[0]
+    we, wl = oracle.Warper("spherical", oracle.TRIG_EXACT), oracle.Warper("spherical", oracle.TRIG_LIBM)
+    we.set_scale([cam])
+    wl.set_scale([cam])
+    a, b = we.warp_image(imgs[0], cam), wl.warp_image(imgs[0], cam)
+    m = we.create_and_warp_mask((320, 240), cam)
+    d = np.abs(a.astype(int) - b.astype(int))[m > 0]
+    assert np.mean(d > 0) < 2e-3  # a handful of pixels sit on a 1/32-px rounding tie
+
+
+# ------------------------------------------------------------------------------- projector / ROI
+def test_roi_of_unrotated_frame_spherical(oracle):
+    # 4000x3000, f = scale = 3000, R = I  ->  3528 x 2782
+    w = oracle.Warper("spherical")
+    w.set_scale([cam0(oracle)])
+    x, y, ww, hh = w.warp_roi((4000, 3000), cam0(oracle))
+    assert (ww, hh) == (3528, 2782)
+    # u extent = +-scale*atan(2000/3000)
+    assert x == int(-3000 * math.atan2(2000, 3000))
+    # principal ray: (u, v) = (0, pi/2 * scale) lies inside
+    assert x < 0 < x + ww and y < math.pi / 2 * 3000 < y + hh
+
+
+def test_principal_ray_backward_map(oracle):
+    K = oracle.Warper.get_K(cam0(oracle))
+    v0 = int(round(math.pi / 2 * 3000))
+    xm, ym = oracle.build_maps("spherical", 3000.0, K, np.eye(3, dtype=np.float32), (0, v0, 1, 1))
+    assert abs(xm[0, 0] - 2000) < 0.5 and abs(ym[0, 0] - 1500) < 0.5
+
+
+def test_plane_warper_identity_map(oracle):
+    # R = I, scale = f: the plane warper is a pure translation by the principal point
+    cam = cam0(oracle, f=500.0, w=64, h=48)
+    K = oracle.Warper.get_K(cam)
+    roi = oracle.warp_roi("plane", 500.0, K, cam.R, (64, 48))
+    assert roi == (-32, -24, 64, 48)
+    xm, ym = oracle.build_maps("plane", 500.0, K, cam.R, roi)
+    assert np.allclose(xm, np.arange(64)[None, :].repeat(48, 0), atol=1e-3)
+    assert np.allclose(ym, np.arange(48)[:, None].repeat(64, 1), atol=1e-3)
+    img = synthetic.make_frame(1, 64, 48)
+    w = oracle.Warper("plane")
+    w.set_scale([cam])
+    out = w.warp_image(img, cam)
+    assert np.abs(out.astype(int) - img.astype(int)).max() <= 1
+    assert np.all(w.create_and_warp_mask((64, 48), cam) == 255)
+
+
+def test_affine_warper_translation_and_scale_ignored(oracle):
+    H = np.array([[1, 0, 10], [0, 1, -7], [0, 0, 1]], np.float32)
+    cam = oracle.CameraParams(focal=1.0, R=H)
+    w = oracle.Warper("affine")
+    w.scale = 123.0  # AffineWarperCreator ignores the scale
+    # getRTfromHomogeneous: R' = H_rot^T, T' = -R' t  =>  mapForward(p) = H^-1 p  (H maps panorama -> image)
+    assert w.warp_roi((50, 40), cam) == (-10, 7, 50, 40)
+    img = synthetic.make_frame(2, 50, 40)
+    assert np.abs(w.warp_image(img, cam).astype(int) - img.astype(int)).max() <= 1
+
+
+def test_spherical_pole_inclusion(oracle):
+    # camera looking straight up: the pole (0, pi*scale) or (0, 0) must be inside the roi
+    R = synthetic.rot_x(math.radians(90)).astype(np.float32)
+    cam = cam0(oracle, f=300.0, w=400, h=300, R=R)
+    w = oracle.Warper("spherical")
+    w.set_scale([cam])
+    x, y, ww, hh = w.warp_roi((400, 300), cam)
+    pole_v = [0, int(math.pi * 300)]
+    assert x <= 0 < x + ww and any(y <= pv <= y + hh for pv in pole_v)
+    assert ww >= int(2 * math.pi * 300) - 2  # all longitudes meet at the pole
+
+
+# ------------------------------------------------------------------------------- remap
+def test_border_interpolate(oracle):
+    bi = oracle.border_interpolate
+    R, R101 = oracle.BORDER_REFLECT, oracle.BORDER_REFLECT_101
+    assert [bi(p, 4, R) for p in range(-5, 9)] == [3, 3, 2, 1, 0, 0, 1, 2, 3, 3, 2, 1, 0, 0]
+    assert [bi(p, 4, R101) for p in range(-4, 8)] == [2, 3, 2, 1, 0, 1, 2, 3, 2, 1, 0, 1]
+    assert bi(-7, 1, R) == 0 and bi(9, 1, R101) == 0
+    assert bi(-1, 5, oracle.BORDER_CONSTANT) == -1 and bi(5, 5, oracle.BORDER_REPLICATE) == 4
+
+
+def test_bilinear_table_is_exact_q15(oracle):
+    t = oracle.bilinear_tab().astype(int)
+    assert np.all(t.sum(1) == 32768)
+    for fy in (0, 7, 31):
+        for fx in (0, 1, 16, 31):
+            w = t[fy * 32 + fx]
+            exp = [(32 - fx) * (32 - fy) * 32, fx * (32 - fy) * 32, (32 - fx) * fy * 32, fx * fy * 32]
+            if fx == 0 and fy == 0:
+                exp = [32767, 0, 0, 1]  # saturate_cast<short>(32768) + the sum fix-up of initInterTab2D
+            assert list(w) == exp
+
+
+def test_remap_integer_and_half_pixel(oracle):
+    src = np.arange(5 * 6 * 3, dtype=np.uint8).reshape(5, 6, 3) * 2
+    xm = np.array([[1.0, 2.5, -1.0, 5.0]], np.float32)
+    ym = np.array([[2.0, 1.0, -1.0, 4.0]], np.float32)
+    out = oracle.remap_linear(src, xm, ym)
+    assert list(out[0, 0]) == list(src[2, 1])
+    assert list(out[0, 1]) == [int((int(a) + int(b) + 1) // 2) for a, b in zip(src[1, 2], src[1, 3])]
+    assert list(out[0, 2]) == list(src[0, 0])      # (-1,-1) marker reflects onto pixel (0,0)
+    assert list(out[0, 3]) == list(src[4, 5])      # x=5 (last col), x+1 reflects onto itself
+    near = oracle.remap_nearest(np.full((5, 6), 255, np.uint8), np.array([[0.5, 1.5, 5.49, 5.5, -0.5, -0.51]], np.float32),
+                                np.zeros((1, 6), np.float32))
+    # cvRound: half-to-even  0.5->0  1.5->2  5.49->5  5.5->6(out)  -0.5->-0(in)  -0.51->-1(out)
+    assert list(near[0]) == [255, 255, 255, 0, 255, 0]
+
+
+# ------------------------------------------------------------------------------- pyramids
+def test_pyramids_preserve_constants(oracle):
+    c = np.full((12, 20, 3), -1234, np.int16)
+    d = oracle.pyr_down_16s(c)
+    assert d.shape == (6, 10, 3) and np.all(d == -1234)
+    assert np.all(oracle.pyr_up_16s(d) == -1234)
+    f = np.full((9, 7), 0.625, np.float32)
+    assert np.all(oracle.pyr_down_32f(f) == np.float32(0.625))
+
+
+def test_pyr_down_impulse_is_the_kernel(oracle):
+    a = np.zeros((16, 16), np.int16)
+    a[8, 8] = 256
+    d = oracle.pyr_down_16s(a)
+    k = np.array([1, 4, 6, 4, 1])
+    # output (y,x) sees input rows 2y-2..2y+2: impulse at 8 -> outputs 3,4,5 with taps k[4],k[2],k[0]
+    exp = np.zeros((8, 8), int)
+    for oy, ky in ((3, 4), (4, 2), (5, 0)):
+        for ox, kx in ((3, 4), (4, 2), (5, 0)):
+            exp[oy, ox] = (256 * k[ky] * k[kx] + 128) >> 8
+    assert np.array_equal(d, exp)
+
+
+def test_pyr_down_reflect101_border(oracle):
+    a = np.arange(8, dtype=np.int16)[None, :].repeat(8, 0) * 100
+    d = oracle.pyr_down_16s(a)
+    # column 0: taps at -2,-1,0,1,2 -> reflect101 -> 2,1,0,1,2 : (2*1 + 1*4 + 0*6 + 1*4 + 2*1)*100*16
+    assert d.shape == (4, 4)
+    assert d[2, 0] == ((200 + 400 + 0 + 400 + 200) * 16 + 128) >> 8
+    # last column (x=3): taps 4,5,6,7,8->6
+    assert d[2, 3] == ((400 * 1 + 500 * 4 + 600 * 6 + 700 * 4 + 600 * 1) * 16 + 128) >> 8
+
+
+def test_pyr_up_edges(oracle):
+    s = np.array([[10, 20, 40]], np.int16).repeat(3, 0)
+    u = oracle.pyr_up_16s(s)
+    row = u[2]  # interior rows: vertical weights 8 (1+6+1 / 4+4) on identical rows
+    # even cols: s[x-1] + 6 s[x] + s[x+1] (left: reflect101, right: replicate); odd: 4 (s[x] + s[x+1])
+    exp_h = [6 * 10 + 2 * 20, 4 * (10 + 20), 10 + 6 * 20 + 40, 4 * (20 + 40), 20 + 7 * 40, 8 * 40]
+    assert list(row) == [(h * 8 + 32) >> 6 for h in exp_h]
+    one = oracle.pyr_up_16s(np.array([[7]], np.int16))
+    assert one.shape == (2, 2) and np.all(one == 7)
+
+
+def test_distance_transform_l1(oracle):
+    m = np.full((7, 9), 255, np.uint8)
+    m[3, 4] = 0
+    d = oracle.distance_transform_l1(m)
+    yy, xx = np.mgrid[0:7, 0:9]
+    assert np.array_equal(d, (np.abs(yy - 3) + np.abs(xx - 4)).astype(np.float32))
+    full = oracle.distance_transform_l1(np.full((5, 5), 255, np.uint8))
+    assert np.all(full == np.float32(8192.0))  # no zero pixel: saturates at (INT_MAX>>2) * 2^-16
+
+
+# ------------------------------------------------------------------------------- blenders
+def test_convert_scale_abs(oracle):
+    a = np.array([-32768, -300, -255, -1, 0, 1, 254, 255, 256, 32767], np.int16)
+    assert list(oracle.convert_scale_abs(a)) == [255, 255, 255, 1, 0, 1, 254, 255, 255, 255]
+
+
+def test_result_roi(oracle):
+    assert oracle.result_roi([(0, 0), (-5, 7)], [(10, 10), (3, 4)]) == (-5, 0, 15, 11)
+
+
+@pytest.mark.parametrize("btype", ["multiband", "feather", "no"])
+def test_single_full_mask_image_is_reproduced(oracle, btype):
+    img = synthetic.make_frame(5, 160, 128)
+    mask = np.full((128, 160), 255, np.uint8)
+    b = oracle.Blender(btype, 20)
+    b.prepare([(7, -3)], [(160, 128)])
+    b.feed(img, mask, (7, -3))
+    pano, pmask = b.blend()
+    assert pano.shape == img.shape and np.all(pmask == 255)
+    # normalizeUsingWeightMap divides by (w + 1e-5) and truncates toward zero: with w == 1 every
+    # non-zero coefficient loses 1 in magnitude, once per level (OpenCV's known slight fading)
+    tol = {"no": 0, "feather": 1, "multiband": b.blender.num_bands() + 1}[btype]
+    assert np.abs(pano.astype(int) - img.astype(int)).max() <= tol
+
+
+def test_multiband_band_count_and_padding(oracle):
+    b = oracle.Blender("multiband", 5)
+    b.prepare([(0, 0)], [(2636, 673)])  # weir panorama size: 5 bands
+    assert b.blender.num_bands() == 5
+    b = oracle.Blender("multiband", 5)
+    b.prepare([(0, 0)], [(33, 17)])      # blend_width 1.18 -> int(log2(1.18) - 1) = 0 bands
+    assert b.blender.num_bands() == 0
+    b = oracle.Blender("multiband", 0.5)
+    b.prepare([(0, 0)], [(33, 17)])      # blend_width < 1 -> "no" blender
+    assert b.blender.num_bands() == 0
+
+
+def test_two_image_blend_is_between_inputs(oracle):
+    a = np.full((64, 96, 3), 40, np.uint8)
+    c = np.full((64, 96, 3), 200, np.uint8)
+    m = np.full((64, 96), 255, np.uint8)
+    for btype in ("multiband", "feather"):
+        b = oracle.Blender(btype, 30)
+        b.prepare([(0, 0), (48, 0)], [(96, 64), (96, 64)])
+        b.feed(a, m, (0, 0))
+        b.feed(c, m, (48, 0))
+        pano, pmask = b.blend()
+        assert pano.shape == (64, 144, 3) and np.all(pmask == 255)
+        assert np.all(np.abs(pano[:, :8].astype(int) - 40) <= 4) and np.all(np.abs(pano[:, 136:].astype(int) - 200) <= 4)
+        prof = pano[32, :, 0].astype(int)
+        assert prof.min() >= 35 and prof.max() <= 205
+        assert np.all(np.diff(prof) >= -2)  # a smooth left-to-right ramp across the overlap
+    b = oracle.Blender("no")
+    b.prepare([(0, 0), (48, 0)], [(96, 64), (96, 64)])
+    b.feed(a, m, (0, 0))
+    b.feed(c, m, (48, 0))
+    pano, _ = b.blend()
+    assert np.all(pano[:, :48] == 40) and np.all(pano[:, 48:] == 200)  # last fed wins
+
+
+def test_feed_outside_roi_is_rejected(oracle):
+    b = oracle.Blender("no")
+    b.prepare([(0, 0)], [(10, 10)])
+    with pytest.raises(ValueError):
+        b.feed(np.zeros((10, 10, 3), np.uint8), np.zeros((10, 10), np.uint8), (5, 5))
