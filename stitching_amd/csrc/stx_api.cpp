@@ -285,8 +285,8 @@ int stx_buf_new(stx_ctx* ctx, int w, int h, int c, int elem, stx_buf** out)
     std::unique_ptr<stx_buf> b(new stx_buf());
     b->ctx = ctx;
     b->w = w; b->h = h; b->c = c; b->elem = elem;
-    // rows are 64-byte aligned and hold a whole number of 4-pixel groups (kernels store 4 px per lane)
-    b->stride = align_up(align_up((size_t)w, 4) * c * stx_elem_bytes(elem), 64);
+    // rows are 64-byte aligned and hold a whole number of 8-pixel groups (kernels store 4 or 8 px per lane)
+    b->stride = align_up(align_up((size_t)w, 8) * c * stx_elem_bytes(elem), 64);
     STX_TRY(stx_dev_alloc(ctx, b->stride * h, &b->base));
     b->ptr = (uint8_t*)b->base;
     *out = b.release();
@@ -894,6 +894,8 @@ static int mb_finish(stx_blender* b, stx_buf* pano, stx_buf* pmask, stx_buf* pan
         memset(&L, 0, sizeof(L));
         L.d_images = (const StxMbImage*)d_images;
         L.n_images = n; L.level = lv; L.num_bands = nb; L.pw = pw; L.ph = ph;
+        L.all_u8 = 1;
+        for (const StxMbImage& im : b->images) if (im.img0_is_s16) L.all_u8 = 0;
         if (lv < nb) { L.up = out[lv + 1]; L.up_stride = ostride[lv + 1]; L.up_plane = oplane[lv + 1]; }
         // algorithmic bytes: every input element once, every output element once
         double bytes = 0.0;

@@ -18,6 +18,7 @@
 // pixel, read-modify-written once per image) never exist in HBM.  Integer sums are exact in
 // any order (int16 wrap-around adds); fp32 weight sums are taken in ascending feed order, the
 // order OpenCV's += sees.
+#include "stx_blend_kernels.h"
 #include "stx_device_math.h"
 #include "stx_internal.h"
 
@@ -152,16 +153,6 @@ STX_DEV int pyr_up_at(const short* __restrict__ plane, long long stride, int cw,
     return (int)(short)((v + 32) >> 6);
 }
 
-struct MbLevelK {
-    const StxMbImage* images;
-    int n_images, level, num_bands, pw, ph;
-    short* out; long long out_stride, out_plane;
-    const short* up; long long up_stride, up_plane;
-    uint8_t* pano; long long pano_stride;
-    uint8_t* pmask; long long pmask_stride;
-    short* pano16; long long pano16_stride;
-    int final_w, final_h;
-};
 
 // levels >= 1: gather + normalise + collapse
 __global__ __launch_bounds__(256) void mb_level_kernel(MbLevelK P)
@@ -418,6 +409,7 @@ int stx_launch_mb_down0(stx_ctx* ctx, const StxMbImage& im)
     const int ow = im.fw >> 1, oh = im.fh >> 1;
     double bytes = (im.img0_is_s16 ? 6.0 : 3.0) * im.iw * im.ih + 1.0 * im.iw * im.ih + 10.0 * ow * oh;
     StxProfScope prof(ctx, "mb_down0", bytes);
+    if (stx_fast_mb_down0(ctx, im)) return STX_OK;
     if (im.img0_is_s16) hipLaunchKernelGGL(mb_down0_kernel<true>, grid64x4(ow, oh), dim3(256), 0, ctx->stream, im);
     else hipLaunchKernelGGL(mb_down0_kernel<false>, grid64x4(ow, oh), dim3(256), 0, ctx->stream, im);
     return check_launch("mb_down0");
@@ -429,6 +421,7 @@ int stx_launch_mb_down(stx_ctx* ctx, const StxMbImage& im, int level)
     const int ow = iw >> 1, oh = ih >> 1;
     double bytes = 10.0 * iw * ih + 10.0 * ow * oh;
     StxProfScope prof(ctx, "mb_down", bytes);
+    if (stx_fast_mb_down(ctx, im, level)) return STX_OK;
     hipLaunchKernelGGL(mb_down_kernel, grid64x4(ow, oh), dim3(256), 0, ctx->stream, im, level);
     return check_launch("mb_down");
 }
@@ -443,12 +436,15 @@ int stx_launch_mb_level(stx_ctx* ctx, const StxMbLevelLaunch& L)
     K.pano = L.pano; K.pano_stride = L.pano_stride; K.pmask = L.pmask; K.pmask_stride = L.pmask_stride;
     K.pano16 = L.pano16; K.pano16_stride = L.pano16_stride;
     K.final_w = L.final_w; K.final_h = L.final_h;
+    K.all_u8 = L.all_u8;
     if (L.level == 0) {
         StxProfScope prof(ctx, "mb_level0", L.algo_bytes);
+        if (K.all_u8 && stx_fast_mb_level(ctx, K)) return STX_OK;
         hipLaunchKernelGGL(mb_level0_kernel, grid64x4(L.final_w, L.final_h), dim3(256), 0, ctx->stream, K);
         return check_launch("mb_level0");
     }
     StxProfScope prof(ctx, "mb_level", L.algo_bytes);
+    if (stx_fast_mb_level(ctx, K)) return STX_OK;
     hipLaunchKernelGGL(mb_level_kernel, grid64x4(L.pw, L.ph), dim3(256), 0, ctx->stream, K);
     return check_launch("mb_level");
 }

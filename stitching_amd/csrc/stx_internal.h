@@ -145,6 +145,7 @@ struct StxMbLevelLaunch {
     uint8_t* pano; long long pano_stride; uint8_t* pmask; long long pmask_stride;
     short* pano16; long long pano16_stride;                 // optional int16 HWC result
     int final_w, final_h;
+    int all_u8;
     double algo_bytes;
 };
 int stx_launch_mb_level(stx_ctx* ctx, const StxMbLevelLaunch& L);

@@ -74,3 +74,91 @@ def test_blend_voronoi_masks_bit_exact(oracle, gpu_ctx):
                              masks_fn=synthetic.voronoi_seam_masks)
     assert np.array_equal(g["pmask"], o["pmask"])
     assert np.array_equal(g["pano"], o["pano"])
+
+
+def test_blend_int16_input_and_int16_result(oracle, gpu_ctx):
+    """stitching/blender.py:41 feeds int16; values outside 0..255 (e.g. after exposure gain) must
+    follow the int16 path bit-exactly; stx_blend_finish_ex also returns blender.blend()'s int16."""
+    import ctypes as C
+
+    from stitching_amd import _lib
+    from stitching_amd.device import DeviceImage
+
+    imgs, cams = helpers.small_ring(3, 333, 251, span=110.0)
+    ow, gw = oracle.Warper("spherical"), S.Warper("spherical")
+    ow.set_scale(cams)
+    gw.set_scale(cams)
+    sizes = [(333, 251)] * 3
+    wi = [ow.warp_image(i, c).astype(np.int16) * 3 - 200 for i, c in zip(imgs, cams)]
+    wm = [ow.create_and_warp_mask(s, c) for s, c in zip(sizes, cams)]
+    corners, wsz = ow.warp_rois(sizes, cams)
+    ob, gb = oracle.Blender("multiband", 15), S.Blender("multiband", 15)
+    ob.prepare(corners, wsz)
+    gb.prepare(corners, wsz)
+    for a, m, c in zip(wi, wm, corners):
+        ob.blender.feed(a, m, c)
+        gb.feed(a, m, c)
+    o16, omask = ob.blender.blend()
+    pano, mask, p16 = gb.blender.blend(want_s16=True)
+    assert np.array_equal(np.asarray(mask), omask)
+    assert np.array_equal(np.asarray(p16), o16)
+    assert np.array_equal(np.asarray(pano), oracle.convert_scale_abs(o16))
+
+
+@pytest.mark.parametrize("wtype,strength", [("spherical", 30), ("cylindrical", 12)])
+def test_blend_larger_odd_sizes(oracle, gpu_ctx, wtype, strength):
+    """Sizes that are not multiples of anything, 5-6 bands: exercises the register-blocked kernels
+    (levels <= B-3), the generic coarse-level kernels and every border path."""
+    imgs, cams = helpers.small_ring(3, 1203, 907, span=120.0)
+    g = helpers.run_pipeline(S.Warper, S.Blender, imgs, cams, warper_type=wtype, blend_strength=strength)
+    o = helpers.run_pipeline(oracle.Warper, oracle.Blender, imgs, cams, warper_type=wtype, blend_strength=strength)
+    assert g["blender"].blender.num_bands() == o["blender"].blender.num_bands() >= 5
+    assert np.array_equal(g["pmask"], o["pmask"])
+    d = g["pano"].astype(int) - o["pano"].astype(int)
+    assert not d.any(), f"{np.count_nonzero(d)} bytes differ, max {np.abs(d).max()}"
+
+
+def test_device_resident_views_and_feed(oracle, gpu_ctx):
+    """DeviceImage slicing (stitching/cropper.py:150-151 on device) and device-resident feed."""
+    imgs, cams = helpers.small_ring(2, 400, 300, span=60.0)
+    S.set_device_resident(True)
+    try:
+        w = S.Warper()
+        w.set_scale(cams)
+        d = w.warp_image(imgs[0], cams[0])
+        assert isinstance(d, S.DeviceImage) and d.dtype == np.uint8
+        host = d.numpy()
+        v = d[10:200, 33:301]
+        assert isinstance(v, S.DeviceImage) and v.shape == (190, 268, 3)
+        assert np.array_equal(np.asarray(v), host[10:200, 33:301])
+        m = w.create_and_warp_mask((400, 300), cams[0])
+        b = S.Blender("multiband", 10)
+        b.prepare([(0, 0)], [(268, 190)])
+        b.feed(v, m[10:200, 33:301], (0, 0))
+        pano, pm = b.blend()
+        ob = oracle.Blender("multiband", 10)
+        ob.prepare([(0, 0)], [(268, 190)])
+        ob.feed(host[10:200, 33:301], np.asarray(m)[10:200, 33:301], (0, 0))
+        op, om = ob.blend()
+        assert np.array_equal(np.asarray(pano), op) and np.array_equal(np.asarray(pm), om)
+    finally:
+        S.set_device_resident(False)
+
+
+def test_error_paths(gpu_ctx):
+    b = S.Blender("multiband")
+    b.prepare([(0, 0)], [(64, 64)])
+    with pytest.raises(S.StitchingError):  # image leaves the prepared roi
+        b.feed(np.zeros((64, 64, 3), np.uint8), np.zeros((64, 64), np.uint8), (10, 0))
+    with pytest.raises(S.StitchingError):  # mask / image size mismatch
+        b.feed(np.zeros((64, 64, 3), np.uint8), np.zeros((32, 64), np.uint8), (0, 0))
+    b.feed(np.zeros((64, 64, 3), np.uint8), np.full((64, 64), 255, np.uint8), (0, 0))
+    b.blend()
+    with pytest.raises(S.StitchingError):  # blend() consumes the blender
+        b.blend()
+    w = S.Warper()
+    w.set_scale([S.CameraParams(focal=100.0)])
+    with pytest.raises(S.StitchingError):  # float64 R (the reference needs camera_estimator.py:25-26)
+        w.warp_roi((10, 10), S.CameraParams(focal=100.0, R=np.eye(3)))
+    with pytest.raises(S.StitchingError):
+        w.warp_image(np.zeros((10, 10), np.uint8), S.CameraParams(focal=100.0))
