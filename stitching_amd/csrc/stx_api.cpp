@@ -839,8 +839,7 @@ static int mb_feed(stx_blender* b, const stx_buf* img, const stx_buf* mask, int 
         im.g[i] = (short*)g; im.g_stride[i] = gs; im.g_plane[i] = gs * lh;
         im.wt[i] = (float*)wt; im.wt_stride[i] = ws;
     }
-    if (nb >= 1) STX_TRY(stx_launch_mb_down0(ctx, im));
-    for (int i = 1; i < nb; i++) STX_TRY(stx_launch_mb_down(ctx, im, i));
+    // deferred: the pyramids of all images are built at blend() time, one launch per level
     b->images.push_back(im);
     stx_buf_retain(const_cast<stx_buf*>(img));
     stx_buf_retain(const_cast<stx_buf*>(mask));
@@ -885,6 +884,7 @@ static int mb_finish(stx_blender* b, stx_buf* pano, stx_buf* pmask, stx_buf* pan
     if (n > 0) {
         STX_HIP(hipMemcpyAsync(d_images, b->images.data(), sizeof(StxMbImage) * n, hipMemcpyHostToDevice, ctx->stream));
         STX_HIP(hipStreamSynchronize(ctx->stream));  // images vector is pageable host memory
+        STX_TRY(stx_launch_mb_pyramids(ctx, (const StxMbImage*)d_images, b->images.data(), n, nb));
     }
     std::vector<short*> out(nb + 2, nullptr);
     std::vector<long long> ostride(nb + 2, 0), oplane(nb + 2, 0);

@@ -404,26 +404,36 @@ inline dim3 grid64x4(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
 
 }  // namespace
 
-int stx_launch_mb_down0(stx_ctx* ctx, const StxMbImage& im)
+// Builds G_1..G_B / W_1..W_B of every fed image: one launch per level for all images
+// (grid.z = image) on the LDS kernels; int16 sources and degenerate sizes use the generic kernels.
+int stx_launch_mb_pyramids(stx_ctx* ctx, const StxMbImage* d_images, const StxMbImage* h_images, int n, int num_bands)
 {
-    const int ow = im.fw >> 1, oh = im.fh >> 1;
-    double bytes = (im.img0_is_s16 ? 6.0 : 3.0) * im.iw * im.ih + 1.0 * im.iw * im.ih + 10.0 * ow * oh;
-    StxProfScope prof(ctx, "mb_down0", bytes);
-    if (stx_fast_mb_down0(ctx, im)) return STX_OK;
-    if (im.img0_is_s16) hipLaunchKernelGGL(mb_down0_kernel<true>, grid64x4(ow, oh), dim3(256), 0, ctx->stream, im);
-    else hipLaunchKernelGGL(mb_down0_kernel<false>, grid64x4(ow, oh), dim3(256), 0, ctx->stream, im);
-    return check_launch("mb_down0");
-}
-
-int stx_launch_mb_down(stx_ctx* ctx, const StxMbImage& im, int level)
-{
-    const int iw = im.fw >> level, ih = im.fh >> level;
-    const int ow = iw >> 1, oh = ih >> 1;
-    double bytes = 10.0 * iw * ih + 10.0 * ow * oh;
-    StxProfScope prof(ctx, "mb_down", bytes);
-    if (stx_fast_mb_down(ctx, im, level)) return STX_OK;
-    hipLaunchKernelGGL(mb_down_kernel, grid64x4(ow, oh), dim3(256), 0, ctx->stream, im, level);
-    return check_launch("mb_down");
+    for (int lv = 0; lv < num_bands; lv++) {
+        double bytes = 0.0;
+        bool any_s16 = false;
+        for (int i = 0; i < n; i++) {
+            const StxMbImage& im = h_images[i];
+            const double ip = (double)(im.fw >> lv) * (im.fh >> lv), op = ip / 4.0;
+            if (lv == 0) bytes += ((im.img0_is_s16 ? 6.0 : 3.0) + 1.0) * im.iw * im.ih + 10.0 * op;
+            else bytes += 10.0 * ip + 10.0 * op;
+            any_s16 = any_s16 || im.img0_is_s16;
+        }
+        StxProfScope prof(ctx, lv == 0 ? "mb_down0" : "mb_down", bytes);
+        const bool batched = stx_fast_mb_down_batch(ctx, d_images, h_images, n, lv);
+        for (int i = 0; i < n; i++) {
+            const StxMbImage& im = h_images[i];
+            if (batched && !(lv == 0 && im.img0_is_s16)) continue;
+            const int ow = (im.fw >> lv) >> 1, oh = (im.fh >> lv) >> 1;
+            if (lv == 0) {
+                if (im.img0_is_s16) hipLaunchKernelGGL(mb_down0_kernel<true>, grid64x4(ow, oh), dim3(256), 0, ctx->stream, im);
+                else hipLaunchKernelGGL(mb_down0_kernel<false>, grid64x4(ow, oh), dim3(256), 0, ctx->stream, im);
+            } else {
+                hipLaunchKernelGGL(mb_down_kernel, grid64x4(ow, oh), dim3(256), 0, ctx->stream, im, lv);
+            }
+        }
+        STX_TRY(check_launch("mb_down"));
+    }
+    return STX_OK;
 }
 
 int stx_launch_mb_level(stx_ctx* ctx, const StxMbLevelLaunch& L)

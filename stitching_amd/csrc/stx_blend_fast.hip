@@ -12,6 +12,8 @@
 //   mb_level_fast : gather + normalise + collapse for levels <= B-3 (2^(B-level) >= 8, so an
 //                   8-pixel strip never straddles a feed-rectangle edge); level 0 writes the
 //                   u8 panorama + mask (+ int16 result)
+#include <algorithm>
+
 #include "stx_blend_kernels.h"
 #include "stx_device_math.h"
 
@@ -38,180 +40,253 @@ STX_DEV float h5f(float s0, float s1, float s2, float s3, float s4)
 STX_DEV int h5i(int s0, int s1, int s2, int s3, int s4) { return s2 * 6 + (s1 + s3) * 4 + s0 + s4; }
 
 // ---------------------------------------------------------------------------------------------
-// pyrDown, sliding window.  One lane = 2 adjacent outputs x R output rows.
+// pyrDown through LDS.  Workgroup = 64 x 16 outputs.
+//   phase 1: the 35 input rows the tile needs are streamed from HBM with 16-byte loads; each lane
+//            filters horizontally (1-4-6-4-1, stride 2) as it loads and parks the row sums in LDS
+//            (the 5-tap stencil is staged in LDS, never re-read from memory);
+//   phase 2: vertical 1-4-6-4-1 from LDS, (v + 128) >> 8, packed stores.
+// copyMakeBorder (REFLECT image / CONSTANT weight) and pyrDown's REFLECT_101 are index maps that
+// only the lanes at a border evaluate (per-wavefront slow path); interior lanes take vector loads.
 // ---------------------------------------------------------------------------------------------
-struct HRow {  // horizontal 1-4-6-4-1 sums of one input row for the lane's 2 outputs
-    int v[3][2];
-    float w[2];
-};
+constexpr int DN_TOW = 64, DN_TOH = 16, DN_ROWS = 2 * DN_TOH + 3;
 
-// level >= 1 source: planar int16 x3 + fp32
-STX_DEV void hrow_planar(const short* __restrict__ G, long long gs, long long gp, const float* __restrict__ W,
-                         long long ws, int iw, int ih, int row, int c0, bool fastx, HRow& o)
-{
-    const int sy = reflect101(row, ih);
-    int idx[7];
-    if (!fastx) {
-#pragma unroll
-        for (int j = 0; j < 7; j++) idx[j] = reflect101(c0 + j, iw);
-    }
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const short* p = G + c * gp + (long long)sy * gs;
-        int s[7];
-        if (fastx) {
-            uint32_t a = *reinterpret_cast<const uint32_t*>(p + c0);
-            uint2 b = *reinterpret_cast<const uint2*>(p + c0 + 2);
-            s[0] = s16lo(a); s[1] = s16hi(a);
-            s[2] = s16lo(b.x); s[3] = s16hi(b.x); s[4] = s16lo(b.y); s[5] = s16hi(b.y);
-            s[6] = p[c0 + 6];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 7; j++) s[j] = p[idx[j]];
-        }
-        o.v[c][0] = h5i(s[0], s[1], s[2], s[3], s[4]);
-        o.v[c][1] = h5i(s[2], s[3], s[4], s[5], s[6]);
-    }
-    const float* q = W + (long long)sy * ws;
-    float f[7];
-    if (fastx) {
-        float2 a = *reinterpret_cast<const float2*>(q + c0);
-        float4 b = *reinterpret_cast<const float4*>(q + c0 + 2);
-        f[0] = a.x; f[1] = a.y; f[2] = b.x; f[3] = b.y; f[4] = b.z; f[5] = b.w;
-        f[6] = q[c0 + 6];
-    } else {
-#pragma unroll
-        for (int j = 0; j < 7; j++) f[j] = q[idx[j]];
-    }
-    o.w[0] = h5f(f[0], f[1], f[2], f[3], f[4]);
-    o.w[1] = h5f(f[2], f[3], f[4], f[5], f[6]);
-}
-
-// level 0 source: u8 BGR interleaved image seen through copyMakeBorder(REFLECT), u8 mask through
-// copyMakeBorder(CONSTANT 0) and convertTo(32F, 1/255)
-STX_DEV void hrow_level0(const StxMbImage& im, int row, int c0, bool fastx, HRow& o)
+// level 0 (u8 BGR + u8 mask): 4 outputs from 11 input pixels
+STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, short* hs1, short* hs2, float* hw)
 {
     const int by = reflect101(row, im.fh) - im.top;  // bordered row -> image row
     const bool yin = (unsigned)by < (unsigned)im.ih;
     const int sy = reflect(by, im.ih);
     const uint8_t* irow = im.img0 + (long long)sy * im.img0_stride;
-    int px[7][3];
-    float f[7];
-    if (fastx) {
-        const int a0 = c0 - im.left;  // 7 contiguous image columns a0 .. a0+6, all inside
-        {
-            const long long off = (long long)a0 * 3;
-            const uint8_t* q = irow + (off & ~3ll);
-            const uint32_t s = (uint32_t)off & 3u;
-            U4a4 d0 = *reinterpret_cast<const U4a4*>(q);
-            U2a4 d1 = *reinterpret_cast<const U2a4*>(q + 16);
-            uint32_t w[6];
-            w[0] = __builtin_amdgcn_alignbyte(d0.v[1], d0.v[0], s);
-            w[1] = __builtin_amdgcn_alignbyte(d0.v[2], d0.v[1], s);
-            w[2] = __builtin_amdgcn_alignbyte(d0.v[3], d0.v[2], s);
-            w[3] = __builtin_amdgcn_alignbyte(d1.v[0], d0.v[3], s);
-            w[4] = __builtin_amdgcn_alignbyte(d1.v[1], d1.v[0], s);
-            w[5] = __builtin_amdgcn_alignbyte(0u, d1.v[1], s);
+    const int c0 = 2 * xo - 2;     // first bordered column of the 11 this task reads
+    const int a0 = c0 - im.left;   // ... as an image column
+    int px[11][3];
+    float f[11];
+    if (c0 >= 0 && c0 + 10 < im.fw && a0 >= 0 && a0 + 10 < im.iw) {
+        const long long off = (long long)a0 * 3;  // 33 bytes
+        const uint8_t* q = irow + (off & ~3ll);
+        const uint32_t s = (uint32_t)off & 3u;
+        U4a4 d0 = *reinterpret_cast<const U4a4*>(q);
+        U4a4 d1 = *reinterpret_cast<const U4a4*>(q + 16);
+        U2a4 d2 = *reinterpret_cast<const U2a4*>(q + 32);
+        uint32_t w[9];
+        w[0] = __builtin_amdgcn_alignbyte(d0.v[1], d0.v[0], s);
+        w[1] = __builtin_amdgcn_alignbyte(d0.v[2], d0.v[1], s);
+        w[2] = __builtin_amdgcn_alignbyte(d0.v[3], d0.v[2], s);
+        w[3] = __builtin_amdgcn_alignbyte(d1.v[0], d0.v[3], s);
+        w[4] = __builtin_amdgcn_alignbyte(d1.v[1], d1.v[0], s);
+        w[5] = __builtin_amdgcn_alignbyte(d1.v[2], d1.v[1], s);
+        w[6] = __builtin_amdgcn_alignbyte(d1.v[3], d1.v[2], s);
+        w[7] = __builtin_amdgcn_alignbyte(d2.v[0], d1.v[3], s);
+        w[8] = __builtin_amdgcn_alignbyte(d2.v[1], d2.v[0], s);
 #pragma unroll
-            for (int j = 0; j < 7; j++) {
-                px[j][0] = (int)byte_of(w, 3 * j);
-                px[j][1] = (int)byte_of(w, 3 * j + 1);
-                px[j][2] = (int)byte_of(w, 3 * j + 2);
-            }
+        for (int j = 0; j < 11; j++) {
+            px[j][0] = (int)byte_of(w, 3 * j);
+            px[j][1] = (int)byte_of(w, 3 * j + 1);
+            px[j][2] = (int)byte_of(w, 3 * j + 2);
         }
         if (yin) {
-            const long long off = (long long)by * im.mask0_stride + a0;
-            const uint8_t* q = im.mask0 + (off & ~3ll);
-            const uint32_t s = (uint32_t)off & 3u;
-            uint32_t d0 = *reinterpret_cast<const uint32_t*>(q), d1 = *reinterpret_cast<const uint32_t*>(q + 4),
-                     d2 = *reinterpret_cast<const uint32_t*>(q + 8);
-            uint32_t w[2];
-            w[0] = __builtin_amdgcn_alignbyte(d1, d0, s);
-            w[1] = __builtin_amdgcn_alignbyte(d2, d1, s);
+            const long long moff = (long long)by * im.mask0_stride + a0;  // 11 bytes
+            const uint8_t* mq = im.mask0 + (moff & ~3ll);
+            const uint32_t ms = (uint32_t)moff & 3u;
+            U4a4 m = *reinterpret_cast<const U4a4*>(mq);
+            uint32_t mw[3];
+            mw[0] = __builtin_amdgcn_alignbyte(m.v[1], m.v[0], ms);
+            mw[1] = __builtin_amdgcn_alignbyte(m.v[2], m.v[1], ms);
+            mw[2] = __builtin_amdgcn_alignbyte(m.v[3], m.v[2], ms);
 #pragma unroll
-            for (int j = 0; j < 7; j++) f[j] = fmul((float)byte_of(w, j), INV255);
+            for (int j = 0; j < 11; j++) f[j] = fmul((float)byte_of(mw, j), INV255);
         } else {
 #pragma unroll
-            for (int j = 0; j < 7; j++) f[j] = 0.f;
+            for (int j = 0; j < 11; j++) f[j] = 0.f;
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 7; j++) {
+        for (int j = 0; j < 11; j++) {
             const int bx = reflect101(c0 + j, im.fw) - im.left;
-            const int sx = reflect(bx, im.iw);
-            const uint8_t* p = irow + sx * 3;
+            const uint8_t* p = irow + reflect(bx, im.iw) * 3;
             px[j][0] = p[0]; px[j][1] = p[1]; px[j][2] = p[2];
             f[j] = (yin && (unsigned)bx < (unsigned)im.iw)
                        ? fmul((float)im.mask0[(long long)by * im.mask0_stride + bx], INV255) : 0.f;
         }
     }
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        o.v[c][0] = h5i(px[0][c], px[1][c], px[2][c], px[3][c], px[4][c]);
-        o.v[c][1] = h5i(px[2][c], px[3][c], px[4][c], px[5][c], px[6][c]);
+    for (int o = 0; o < 4; o++) {
+        hs0[o] = (short)h5i(px[2 * o][0], px[2 * o + 1][0], px[2 * o + 2][0], px[2 * o + 3][0], px[2 * o + 4][0]);
+        hs1[o] = (short)h5i(px[2 * o][1], px[2 * o + 1][1], px[2 * o + 2][1], px[2 * o + 3][1], px[2 * o + 4][1]);
+        hs2[o] = (short)h5i(px[2 * o][2], px[2 * o + 1][2], px[2 * o + 2][2], px[2 * o + 3][2], px[2 * o + 4][2]);
+        hw[o] = h5f(f[2 * o], f[2 * o + 1], f[2 * o + 2], f[2 * o + 3], f[2 * o + 4]);
     }
-    o.w[0] = h5f(f[0], f[1], f[2], f[3], f[4]);
-    o.w[1] = h5f(f[2], f[3], f[4], f[5], f[6]);
 }
 
-template <bool L0, int R>
-__global__ __launch_bounds__(256) void mb_down_fast_kernel(StxMbImage im, int lv)
+// blockIdx.z = image: all fed images are processed by one launch (deferred pyramid build)
+__global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __restrict__ images)
 {
-    const int iw = im.fw >> lv, ih = im.fh >> lv;
-    const int ow = iw >> 1, oh = ih >> 1;
-    const int t = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int xo = 2 * t;
-    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * R;
-    if (xo >= ow || y0 >= oh) return;
-    const int c0 = 4 * t - 2;
-    bool fastx = c0 >= 0 && c0 + 6 < iw;
-    if (L0) fastx = fastx && (c0 - im.left) >= 0 && (c0 - im.left) + 6 < im.iw;
-
-    const short* G = L0 ? nullptr : im.g[lv];
-    const long long gs = L0 ? 0 : im.g_stride[lv], gp = L0 ? 0 : im.g_plane[lv];
-    const float* W = L0 ? nullptr : im.wt[lv];
-    const long long ws = L0 ? 0 : im.wt_stride[lv];
-    short* O = im.g[lv + 1];
-    const long long os = im.g_stride[lv + 1], op = im.g_plane[lv + 1];
-    float* OW = im.wt[lv + 1];
-    const long long ows = im.wt_stride[lv + 1];
-
-    HRow h0, h1, h2, h3, h4;
-    if (L0) {
-        hrow_level0(im, 2 * y0 - 2, c0, fastx, h0);
-        hrow_level0(im, 2 * y0 - 1, c0, fastx, h1);
-        hrow_level0(im, 2 * y0, c0, fastx, h2);
-    } else {
-        hrow_planar(G, gs, gp, W, ws, iw, ih, 2 * y0 - 2, c0, fastx, h0);
-        hrow_planar(G, gs, gp, W, ws, iw, ih, 2 * y0 - 1, c0, fastx, h1);
-        hrow_planar(G, gs, gp, W, ws, iw, ih, 2 * y0, c0, fastx, h2);
+    __shared__ short s_h[3][DN_ROWS][DN_TOW];  // horizontal sums, <= 255*16
+    __shared__ float s_w[DN_ROWS][DN_TOW];
+    const StxMbImage& im = images[blockIdx.z];
+    const int tid = threadIdx.x;
+    const int ow = im.fw >> 1, oh = im.fh >> 1;
+    const int X0 = blockIdx.x * DN_TOW, Y0 = blockIdx.y * DN_TOH;
+    if (im.img0_is_s16 || X0 >= ow || Y0 >= oh) return;  // int16 sources take the generic kernel
+    for (int task = tid; task < DN_ROWS * (DN_TOW / 4); task += 256) {
+        const int r = task / (DN_TOW / 4), q = task % (DN_TOW / 4);
+        dn_task_level0(im, 2 * Y0 - 2 + r, X0 + 4 * q, &s_h[0][r][4 * q], &s_h[1][r][4 * q], &s_h[2][r][4 * q],
+                       &s_w[r][4 * q]);
     }
+    __syncthreads();
+    const int p = tid & 31, rg = tid >> 5;  // output pair, row group (2 rows)
+    const int xo = X0 + 2 * p;
+    if (xo >= ow) return;
+    const bool two = xo + 1 < ow;
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-        const int y = y0 + r;
+    for (int rr = 0; rr < 2; rr++) {
+        const int yl = 2 * rg + rr, y = Y0 + yl;
         if (y >= oh) break;
-        if (L0) {
-            hrow_level0(im, 2 * y + 1, c0, fastx, h3);
-            hrow_level0(im, 2 * y + 2, c0, fastx, h4);
-        } else {
-            hrow_planar(G, gs, gp, W, ws, iw, ih, 2 * y + 1, c0, fastx, h3);
-            hrow_planar(G, gs, gp, W, ws, iw, ih, 2 * y + 2, c0, fastx, h4);
-        }
-        const bool two = xo + 1 < ow;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            int a = (h5i(h0.v[c][0], h1.v[c][0], h2.v[c][0], h3.v[c][0], h4.v[c][0]) + 128) >> 8;
-            int b = (h5i(h0.v[c][1], h1.v[c][1], h2.v[c][1], h3.v[c][1], h4.v[c][1]) + 128) >> 8;
-            short* o = O + c * op + (long long)y * os + xo;
-            if (two) *reinterpret_cast<uint32_t*>(o) = pack16(a, b);
-            else o[0] = (short)a;
+            int a[5], b[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                uint32_t v = *reinterpret_cast<const uint32_t*>(&s_h[c][2 * yl + k][2 * p]);
+                a[k] = s16lo(v);
+                b[k] = s16hi(v);
+            }
+            const int va = (h5i(a[0], a[1], a[2], a[3], a[4]) + 128) >> 8;
+            const int vb = (h5i(b[0], b[1], b[2], b[3], b[4]) + 128) >> 8;
+            short* o = im.g[1] + c * im.g_plane[1] + (long long)y * im.g_stride[1] + xo;
+            if (two) *reinterpret_cast<uint32_t*>(o) = pack16(va, vb);
+            else o[0] = (short)va;
         }
-        float wa = fmul(h5f(h0.w[0], h1.w[0], h2.w[0], h3.w[0], h4.w[0]), INV256);
-        float wb = fmul(h5f(h0.w[1], h1.w[1], h2.w[1], h3.w[1], h4.w[1]), INV256);
-        float* ow_ = OW + (long long)y * ows + xo;
-        if (two) *reinterpret_cast<float2*>(ow_) = make_float2(wa, wb);
-        else ow_[0] = wa;
-        h0 = h2; h1 = h3; h2 = h4;
+        float fa[5], fb[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            float2 v = *reinterpret_cast<const float2*>(&s_w[2 * yl + k][2 * p]);
+            fa[k] = v.x;
+            fb[k] = v.y;
+        }
+        const float wa = fmul(h5f(fa[0], fa[1], fa[2], fa[3], fa[4]), INV256);
+        const float wb = fmul(h5f(fb[0], fb[1], fb[2], fb[3], fb[4]), INV256);
+        float* o = im.wt[1] + (long long)y * im.wt_stride[1] + xo;
+        if (two) *reinterpret_cast<float2*>(o) = make_float2(wa, wb);
+        else o[0] = wa;
+    }
+}
+
+// level >= 1 (planar int16 x3 + fp32): 8 outputs from 19 input elements per plane
+STX_DEV void dn_load19_s16(const short* __restrict__ p, int c0, int iw, bool fast, int s[19])
+{
+    if (fast) {  // c0 = 16t - 2: dword, 2 x 16-byte, short
+        uint32_t a = *reinterpret_cast<const uint32_t*>(p + c0);
+        uint4 b = *reinterpret_cast<const uint4*>(p + c0 + 2);
+        uint4 c = *reinterpret_cast<const uint4*>(p + c0 + 10);
+        s[0] = s16lo(a); s[1] = s16hi(a);
+        s[2] = s16lo(b.x); s[3] = s16hi(b.x); s[4] = s16lo(b.y); s[5] = s16hi(b.y);
+        s[6] = s16lo(b.z); s[7] = s16hi(b.z); s[8] = s16lo(b.w); s[9] = s16hi(b.w);
+        s[10] = s16lo(c.x); s[11] = s16hi(c.x); s[12] = s16lo(c.y); s[13] = s16hi(c.y);
+        s[14] = s16lo(c.z); s[15] = s16hi(c.z); s[16] = s16lo(c.w); s[17] = s16hi(c.w);
+        s[18] = p[c0 + 18];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 19; j++) s[j] = p[reflect101(c0 + j, iw)];
+    }
+}
+
+__global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __restrict__ images, int lv)
+{
+    __shared__ int s_h[3][DN_ROWS][DN_TOW];
+    __shared__ float s_w[DN_ROWS][DN_TOW];
+    const StxMbImage& im = images[blockIdx.z];
+    const int tid = threadIdx.x;
+    const int iw = im.fw >> lv, ih = im.fh >> lv;
+    const int ow = iw >> 1, oh = ih >> 1;
+    const int X0 = blockIdx.x * DN_TOW, Y0 = blockIdx.y * DN_TOH;
+    if (X0 >= ow || Y0 >= oh) return;
+    const short* G = im.g[lv];
+    const long long gs = im.g_stride[lv], gp = im.g_plane[lv];
+    for (int task = tid; task < DN_ROWS * (DN_TOW / 8); task += 256) {
+        const int r = task / (DN_TOW / 8), q = task % (DN_TOW / 8);
+        const int sy = reflect101(2 * Y0 - 2 + r, ih);
+        const int c0 = 2 * (X0 + 8 * q) - 2;
+        const bool fast = c0 >= 0 && c0 + 18 < iw;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            int s[19];
+            dn_load19_s16(G + c * gp + (long long)sy * gs, c0, iw, fast, s);
+            int4 lo, hi;
+            lo.x = h5i(s[0], s[1], s[2], s[3], s[4]);
+            lo.y = h5i(s[2], s[3], s[4], s[5], s[6]);
+            lo.z = h5i(s[4], s[5], s[6], s[7], s[8]);
+            lo.w = h5i(s[6], s[7], s[8], s[9], s[10]);
+            hi.x = h5i(s[8], s[9], s[10], s[11], s[12]);
+            hi.y = h5i(s[10], s[11], s[12], s[13], s[14]);
+            hi.z = h5i(s[12], s[13], s[14], s[15], s[16]);
+            hi.w = h5i(s[14], s[15], s[16], s[17], s[18]);
+            *reinterpret_cast<int4*>(&s_h[c][r][8 * q]) = lo;
+            *reinterpret_cast<int4*>(&s_h[c][r][8 * q + 4]) = hi;
+        }
+        const float* wq = im.wt[lv] + (long long)sy * im.wt_stride[lv];
+        float f[19];
+        if (fast) {
+            float2 a = *reinterpret_cast<const float2*>(wq + c0);
+            f[0] = a.x; f[1] = a.y;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float4 b = *reinterpret_cast<const float4*>(wq + c0 + 2 + 4 * k);
+                f[2 + 4 * k] = b.x; f[3 + 4 * k] = b.y; f[4 + 4 * k] = b.z; f[5 + 4 * k] = b.w;
+            }
+            f[18] = wq[c0 + 18];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 19; j++) f[j] = wq[reflect101(c0 + j, iw)];
+        }
+        float4 lo, hi;
+        lo.x = h5f(f[0], f[1], f[2], f[3], f[4]);
+        lo.y = h5f(f[2], f[3], f[4], f[5], f[6]);
+        lo.z = h5f(f[4], f[5], f[6], f[7], f[8]);
+        lo.w = h5f(f[6], f[7], f[8], f[9], f[10]);
+        hi.x = h5f(f[8], f[9], f[10], f[11], f[12]);
+        hi.y = h5f(f[10], f[11], f[12], f[13], f[14]);
+        hi.z = h5f(f[12], f[13], f[14], f[15], f[16]);
+        hi.w = h5f(f[14], f[15], f[16], f[17], f[18]);
+        *reinterpret_cast<float4*>(&s_w[r][8 * q]) = lo;
+        *reinterpret_cast<float4*>(&s_w[r][8 * q + 4]) = hi;
+    }
+    __syncthreads();
+    const int p = tid & 31, rg = tid >> 5;
+    const int xo = X0 + 2 * p;
+    if (xo >= ow) return;
+    const bool two = xo + 1 < ow;
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int yl = 2 * rg + rr, y = Y0 + yl;
+        if (y >= oh) break;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            int a[5], b[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                int2 v = *reinterpret_cast<const int2*>(&s_h[c][2 * yl + k][2 * p]);
+                a[k] = v.x;
+                b[k] = v.y;
+            }
+            const int va = (h5i(a[0], a[1], a[2], a[3], a[4]) + 128) >> 8;
+            const int vb = (h5i(b[0], b[1], b[2], b[3], b[4]) + 128) >> 8;
+            short* o = im.g[lv + 1] + c * im.g_plane[lv + 1] + (long long)y * im.g_stride[lv + 1] + xo;
+            if (two) *reinterpret_cast<uint32_t*>(o) = pack16(va, vb);
+            else o[0] = (short)va;
+        }
+        float fa[5], fb[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            float2 v = *reinterpret_cast<const float2*>(&s_w[2 * yl + k][2 * p]);
+            fa[k] = v.x;
+            fb[k] = v.y;
+        }
+        const float wa = fmul(h5f(fa[0], fa[1], fa[2], fa[3], fa[4]), INV256);
+        const float wb = fmul(h5f(fb[0], fb[1], fb[2], fb[3], fb[4]), INV256);
+        float* o = im.wt[lv + 1] + (long long)y * im.wt_stride[lv + 1] + xo;
+        if (two) *reinterpret_cast<float2*>(o) = make_float2(wa, wb);
+        else o[0] = wa;
     }
 }
 
@@ -480,24 +555,18 @@ bool launched_ok() { return hipGetLastError() == hipSuccess; }
 
 }  // namespace
 
-bool stx_fast_mb_down0(stx_ctx* ctx, const StxMbImage& im)
+// One launch per pyramid level for ALL fed images (grid.z = image).  h_images mirrors d_images.
+bool stx_fast_mb_down_batch(stx_ctx* ctx, const StxMbImage* d_images, const StxMbImage* h_images, int n, int level)
 {
-    if (im.img0_is_s16 || im.fw < 8 || im.fh < 2) return false;
-    constexpr int R = 8;
-    const int ow = im.fw >> 1, oh = im.fh >> 1;
-    dim3 grid(((ow + 1) / 2 + 63) / 64, (oh + 4 * R - 1) / (4 * R));
-    hipLaunchKernelGGL((mb_down_fast_kernel<true, R>), grid, dim3(256), 0, ctx->stream, im, 0);
-    return launched_ok();
-}
-
-bool stx_fast_mb_down(stx_ctx* ctx, const StxMbImage& im, int level)
-{
-    const int iw = im.fw >> level, ih = im.fh >> level;
-    if (iw < 8 || ih < 2) return false;
-    constexpr int R = 4;
-    const int ow = iw >> 1, oh = ih >> 1;
-    dim3 grid(((ow + 1) / 2 + 63) / 64, (oh + 4 * R - 1) / (4 * R));
-    hipLaunchKernelGGL((mb_down_fast_kernel<false, R>), grid, dim3(256), 0, ctx->stream, im, level);
+    int mw = 0, mh = 0;
+    for (int i = 0; i < n; i++) {
+        mw = std::max(mw, (h_images[i].fw >> level) >> 1);
+        mh = std::max(mh, (h_images[i].fh >> level) >> 1);
+    }
+    if (n <= 0 || mw < 1 || mh < 1 || n > 65535) return false;
+    dim3 grid((mw + DN_TOW - 1) / DN_TOW, (mh + DN_TOH - 1) / DN_TOH, n);
+    if (level == 0) hipLaunchKernelGGL(mb_down0_lds_kernel, grid, dim3(256), 0, ctx->stream, d_images);
+    else hipLaunchKernelGGL(mb_down_lds_kernel, grid, dim3(256), 0, ctx->stream, d_images, level);
     return launched_ok();
 }
 

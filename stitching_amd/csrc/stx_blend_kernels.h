@@ -17,6 +17,5 @@ struct MbLevelK {
 
 // fast-path launchers (stx_blend_fast.hip); each returns false when its alignment / size
 // preconditions do not hold and the generic kernel must be used instead.
-bool stx_fast_mb_down0(stx_ctx* ctx, const StxMbImage& im);
-bool stx_fast_mb_down(stx_ctx* ctx, const StxMbImage& im, int level);
+bool stx_fast_mb_down_batch(stx_ctx* ctx, const StxMbImage* d_images, const StxMbImage* h_images, int n, int level);
 bool stx_fast_mb_level(stx_ctx* ctx, const MbLevelK& K);

@@ -134,8 +134,7 @@ struct StxMbImage {  // device-visible descriptor of one fed image (all levels)
     short* g[STX_MAX_BANDS + 1]; long long g_stride[STX_MAX_BANDS + 1]; long long g_plane[STX_MAX_BANDS + 1];
     float* wt[STX_MAX_BANDS + 1]; long long wt_stride[STX_MAX_BANDS + 1];
 };
-int stx_launch_mb_down0(stx_ctx* ctx, const StxMbImage& im);
-int stx_launch_mb_down(stx_ctx* ctx, const StxMbImage& im, int level /* produces level+1 */);
+int stx_launch_mb_pyramids(stx_ctx* ctx, const StxMbImage* d_images, const StxMbImage* h_images, int n, int num_bands);
 struct StxMbLevelLaunch {
     const StxMbImage* d_images; int n_images; int level; int num_bands;
     int pw, ph;                       // padded panorama size at this level
