@@ -72,9 +72,8 @@ void sincos_d(double x, double* s, double* c)
     const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
                  C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                  C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    if (!(std::fabs(x) < 1.0e6)) {  // far outside any panorama; NaN/Inf land here too
-        *s = std::sin(x);
-        *c = std::cos(x);
+    if (!(std::fabs(x) < 1.0e6)) {  // far outside any panorama (NaN/Inf land here too): defined as NaN
+        *s = *c = std::numeric_limits<double>::quiet_NaN();
         return;
     }
     double kd = std::nearbyint(x * INV_PIO2);

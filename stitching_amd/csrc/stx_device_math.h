@@ -25,9 +25,8 @@ STX_DEV void sincos_d(double x, double* s, double* c)
     const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
                  C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                  C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    if (!(fabs(x) < 1.0e6)) {  // outside the contract's domain (no panorama gets here)
-        *s = sin(x);
-        *c = cos(x);
+    if (!(fabs(x) < 1.0e6)) {  // outside the contract's domain (no panorama gets here): NaN
+        *s = *c = __longlong_as_double(0x7ff8000000000000ll);
         return;
     }
     double kd = rint(__dmul_rn(x, INV_PIO2));

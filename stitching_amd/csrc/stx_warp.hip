@@ -22,7 +22,7 @@ using namespace stxd;
 namespace {
 
 constexpr int WARP_TW = 256;  // tile width  (64 lanes x 4 px)
-constexpr int WARP_TH = 16;   // tile height (4 waves x 4 rows)
+constexpr int WARP_TH = 4;    // tile height (4 waves x 1 row)
 constexpr float PI_F = 3.14159274101257324f;  // static_cast<float>(CV_PI)
 
 struct WarpK {
@@ -63,132 +63,130 @@ STX_DEV uint32_t bil(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, uin
     return (h0 * (32u - fy) + h1 * fy + 512u) >> 10;
 }
 
-template <int TYPE, bool IMG, bool MASK>
-__global__ __launch_bounds__(256) void warp_kernel(WarpK P)
+// Separable part of mapBackward, evaluated once per destination column / row (fp64 "exact" trig):
+//   spherical  : col = (sin u', cos u'),           row = (sin(pi - v'), cos(pi - v'))
+//   cylindrical: col = (sin u', cos u'),           row = (v', -)
+//   plane      : col = (u'/scale - t0, -),         row = (v'/scale - t1, -)
+template <int TYPE>
+__global__ __launch_bounds__(256) void warp_tables_kernel(WarpK P, float2* __restrict__ colT, float2* __restrict__ rowT)
 {
-    __shared__ float s_rowa[WARP_TH];  // sph: sin(pi - v')      cyl/plane: v'
-    __shared__ float s_rowb[WARP_TH];  // sph: cos(pi - v')
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
-    const int x0 = blockIdx.x * WARP_TW + lane * 4;
-    const int y0 = blockIdx.y * WARP_TH;
-
-    if (tid < WARP_TH) {
-        float vv = (float)(P.tly + y0 + tid);
-        if (TYPE == STX_WARP_SPHERICAL) {
-            float a = fsub(PI_F, fdiv(vv, P.scale));
-            float s, c;
-            sincosf_x(a, &s, &c);
-            s_rowa[tid] = s;
-            s_rowb[tid] = c;
-        } else if (TYPE == STX_WARP_CYLINDRICAL) {
-            s_rowa[tid] = fdiv(vv, P.scale);
-        } else {
-            s_rowa[tid] = fsub(fdiv(vv, P.scale), P.t[1]);
-        }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < P.dw) {
+        const float uu = (float)(P.tlx + i);
+        float2 o = make_float2(0.f, 0.f);
+        if (TYPE == STX_WARP_SPHERICAL || TYPE == STX_WARP_CYLINDRICAL) sincosf_x(fdiv(uu, P.scale), &o.x, &o.y);
+        else o.x = fsub(fdiv(uu, P.scale), P.t[0]);
+        colT[i] = o;
+    } else if (i < P.dw + P.dh) {
+        const int r = i - P.dw;
+        const float vv = (float)(P.tly + r);
+        float2 o = make_float2(0.f, 0.f);
+        if (TYPE == STX_WARP_SPHERICAL) sincosf_x(fsub(PI_F, fdiv(vv, P.scale)), &o.x, &o.y);
+        else if (TYPE == STX_WARP_CYLINDRICAL) o.x = fdiv(vv, P.scale);
+        else o.x = fsub(fdiv(vv, P.scale), P.t[1]);
+        rowT[r] = o;
     }
-    float ca[4], cb[4];  // sph/cyl: sin(u'), cos(u')   plane: u'
+}
+
+// One lane = 4 adjacent destination pixels of one row; one wave = 256 px of a row; block = 4 rows.
+template <int TYPE, bool IMG, bool MASK>
+__global__ __launch_bounds__(256) void warp_kernel(WarpK P, const float2* __restrict__ colT, const float2* __restrict__ rowT)
+{
+    const int lane = threadIdx.x & 63;
+    const int x0 = blockIdx.x * WARP_TW + lane * 4;
+    const int y = blockIdx.y * WARP_TH + (threadIdx.x >> 6);
+    if (x0 >= P.dw || y >= P.dh) return;
+    float ca[4], cb[4];
+    {
+        // colT is padded to a multiple of 4 entries, 32-byte aligned per 4 columns
+        const float4 c01 = *reinterpret_cast<const float4*>(colT + x0);
+        const float4 c23 = *reinterpret_cast<const float4*>(colT + x0 + 2);
+        ca[0] = c01.x; cb[0] = c01.y; ca[1] = c01.z; cb[1] = c01.w;
+        ca[2] = c23.x; cb[2] = c23.y; ca[3] = c23.z; cb[3] = c23.w;
+    }
+    const float2 rt = rowT[y];
+    const float ra = rt.x, rb = rt.y;
+    const float omt = fsub(1.f, P.t[2]);
+    uint32_t out[3] = {0, 0, 0};
+    uint32_t mout = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        float uu = (float)(P.tlx + x0 + j);
-        if (TYPE == STX_WARP_SPHERICAL || TYPE == STX_WARP_CYLINDRICAL) {
-            sincosf_x(fdiv(uu, P.scale), &ca[j], &cb[j]);
+        float x, yy;
+        if (TYPE == STX_WARP_PLANE || TYPE == STX_WARP_AFFINE) {
+            float z;
+            x = fadd(fadd(fmul(P.kr[0], ca[j]), fmul(P.kr[1], ra)), fmul(P.kr[2], omt));
+            yy = fadd(fadd(fmul(P.kr[3], ca[j]), fmul(P.kr[4], ra)), fmul(P.kr[5], omt));
+            z = fadd(fadd(fmul(P.kr[6], ca[j]), fmul(P.kr[7], ra)), fmul(P.kr[8], omt));
+            x = fdiv(x, z);
+            yy = fdiv(yy, z);
         } else {
-            ca[j] = fsub(fdiv(uu, P.scale), P.t[0]);
-            cb[j] = 0.f;
-        }
-    }
-    __syncthreads();
-    if (x0 >= P.dw) return;
-    const float omt = fsub(1.f, P.t[2]);
-
-#pragma unroll 1
-    for (int r = 0; r < WARP_TH / 4; r++) {
-        const int ry = wv + 4 * r;
-        const int y = y0 + ry;
-        if (y >= P.dh) break;
-        const float ra = s_rowa[ry], rb = (TYPE == STX_WARP_SPHERICAL) ? s_rowb[ry] : 0.f;
-        uint32_t out[3] = {0, 0, 0};
-        uint32_t mout = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float x, yy;
-            if (TYPE == STX_WARP_PLANE || TYPE == STX_WARP_AFFINE) {
-                float z;
-                x = fadd(fadd(fmul(P.kr[0], ca[j]), fmul(P.kr[1], ra)), fmul(P.kr[2], omt));
-                yy = fadd(fadd(fmul(P.kr[3], ca[j]), fmul(P.kr[4], ra)), fmul(P.kr[5], omt));
-                z = fadd(fadd(fmul(P.kr[6], ca[j]), fmul(P.kr[7], ra)), fmul(P.kr[8], omt));
+            float x_, y_, z_;
+            if (TYPE == STX_WARP_SPHERICAL) {
+                x_ = fmul(ra, ca[j]);
+                y_ = rb;
+                z_ = fmul(ra, cb[j]);
+            } else {
+                x_ = ca[j];
+                y_ = ra;
+                z_ = cb[j];
+            }
+            x = dot3(P.kr[0], x_, P.kr[1], y_, P.kr[2], z_);
+            yy = dot3(P.kr[3], x_, P.kr[4], y_, P.kr[5], z_);
+            float z = dot3(P.kr[6], x_, P.kr[7], y_, P.kr[8], z_);
+            if (z > 0) {
                 x = fdiv(x, z);
                 yy = fdiv(yy, z);
             } else {
-                float x_, y_, z_;
-                if (TYPE == STX_WARP_SPHERICAL) {
-                    x_ = fmul(ra, ca[j]);
-                    y_ = rb;
-                    z_ = fmul(ra, cb[j]);
-                } else {
-                    x_ = ca[j];
-                    y_ = ra;
-                    z_ = cb[j];
-                }
-                x = dot3(P.kr[0], x_, P.kr[1], y_, P.kr[2], z_);
-                yy = dot3(P.kr[3], x_, P.kr[4], y_, P.kr[5], z_);
-                float z = dot3(P.kr[6], x_, P.kr[7], y_, P.kr[8], z_);
-                if (z > 0) {
-                    x = fdiv(x, z);
-                    yy = fdiv(yy, z);
-                } else {
-                    x = yy = -1.f;
-                }
-            }
-            if (IMG) {
-                // remap(): sx = cvRound(x*32); (ix, fx) = (sx >> 5 saturated to short, sx & 31)
-                int sx = cv_round(fmul(x, 32.f)), sy = cv_round(fmul(yy, 32.f));
-                uint32_t fx = (uint32_t)sx & 31u, fy = (uint32_t)sy & 31u;
-                int ix = sat_s16(sx >> 5), iy = sat_s16(sy >> 5);
-                uint32_t b, g, rr;
-                if ((unsigned)ix < (unsigned)(P.sw - 1) && (unsigned)iy < (unsigned)(P.sh - 1)) {
-                    long long a = (long long)iy * P.sstride + (long long)ix * 3;
-                    uint32_t l0, h0, l1, h1;
-                    load6(P.src, a, l0, h0);
-                    load6(P.src, a + P.sstride, l1, h1);
-                    b = bil(l0 & 255u, l0 >> 24, l1 & 255u, l1 >> 24, fx, fy);
-                    g = bil((l0 >> 8) & 255u, h0 & 255u, (l1 >> 8) & 255u, h1 & 255u, fx, fy);
-                    rr = bil((l0 >> 16) & 255u, (h0 >> 8) & 255u, (l1 >> 16) & 255u, (h1 >> 8) & 255u, fx, fy);
-                } else {
-                    // BORDER_REFLECT taps (borderInterpolate on each of the 4 taps)
-                    int sx0 = reflect(ix, P.sw), sx1 = reflect(ix + 1, P.sw);
-                    int sy0 = reflect(iy, P.sh), sy1 = reflect(iy + 1, P.sh);
-                    const uint8_t* r0 = P.src + (long long)sy0 * P.sstride;
-                    const uint8_t* r1 = P.src + (long long)sy1 * P.sstride;
-                    b = bil(r0[sx0 * 3], r0[sx1 * 3], r1[sx0 * 3], r1[sx1 * 3], fx, fy);
-                    g = bil(r0[sx0 * 3 + 1], r0[sx1 * 3 + 1], r1[sx0 * 3 + 1], r1[sx1 * 3 + 1], fx, fy);
-                    rr = bil(r0[sx0 * 3 + 2], r0[sx1 * 3 + 2], r1[sx0 * 3 + 2], r1[sx1 * 3 + 2], fx, fy);
-                }
-                // pack the 4 BGR pixels of this thread into 3 dwords
-                uint32_t px = b | (g << 8) | (rr << 16);  // 24 bits
-                if (j == 0) out[0] = px;
-                else if (j == 1) { out[0] |= px << 24; out[1] = px >> 8; }
-                else if (j == 2) { out[1] |= px << 16; out[2] = px >> 16; }
-                else out[2] |= px << 8;
-            }
-            if (MASK) {
-                // remapNearest: saturate_cast<short>(cvRound(x)); inside -> source (255), else 0
-                int nx = sat_s16(cv_round(x)), ny = sat_s16(cv_round(yy));
-                uint32_t m = 0;
-                if ((unsigned)nx < (unsigned)P.sw && (unsigned)ny < (unsigned)P.sh)
-                    m = P.msrc ? (uint32_t)P.msrc[(long long)ny * P.msstride + nx] : 255u;
-                mout |= m << (8 * j);
+                x = yy = -1.f;
             }
         }
         if (IMG) {
-            uint32_t* d = reinterpret_cast<uint32_t*>(P.dimg + (long long)y * P.dimg_stride + (long long)x0 * 3);
-            d[0] = out[0];
-            d[1] = out[1];
-            d[2] = out[2];
+            // remap(): sx = cvRound(x*32); (ix, fx) = (sx >> 5 saturated to short, sx & 31)
+            int sx = cv_round(fmul(x, 32.f)), sy = cv_round(fmul(yy, 32.f));
+            uint32_t fx = (uint32_t)sx & 31u, fy = (uint32_t)sy & 31u;
+            int ix = sat_s16(sx >> 5), iy = sat_s16(sy >> 5);
+            uint32_t b, g, rr;
+            if ((unsigned)ix < (unsigned)(P.sw - 1) && (unsigned)iy < (unsigned)(P.sh - 1)) {
+                long long a = (long long)iy * P.sstride + (long long)ix * 3;
+                uint32_t l0, h0, l1, h1;
+                load6(P.src, a, l0, h0);
+                load6(P.src, a + P.sstride, l1, h1);
+                b = bil(l0 & 255u, l0 >> 24, l1 & 255u, l1 >> 24, fx, fy);
+                g = bil((l0 >> 8) & 255u, h0 & 255u, (l1 >> 8) & 255u, h1 & 255u, fx, fy);
+                rr = bil((l0 >> 16) & 255u, (h0 >> 8) & 255u, (l1 >> 16) & 255u, (h1 >> 8) & 255u, fx, fy);
+            } else {
+                // BORDER_REFLECT taps (borderInterpolate on each of the 4 taps)
+                int sx0 = reflect(ix, P.sw), sx1 = reflect(ix + 1, P.sw);
+                int sy0 = reflect(iy, P.sh), sy1 = reflect(iy + 1, P.sh);
+                const uint8_t* r0 = P.src + (long long)sy0 * P.sstride;
+                const uint8_t* r1 = P.src + (long long)sy1 * P.sstride;
+                b = bil(r0[sx0 * 3], r0[sx1 * 3], r1[sx0 * 3], r1[sx1 * 3], fx, fy);
+                g = bil(r0[sx0 * 3 + 1], r0[sx1 * 3 + 1], r1[sx0 * 3 + 1], r1[sx1 * 3 + 1], fx, fy);
+                rr = bil(r0[sx0 * 3 + 2], r0[sx1 * 3 + 2], r1[sx0 * 3 + 2], r1[sx1 * 3 + 2], fx, fy);
+            }
+            // pack the 4 BGR pixels of this lane into 3 dwords
+            uint32_t px = b | (g << 8) | (rr << 16);  // 24 bits
+            if (j == 0) out[0] = px;
+            else if (j == 1) { out[0] |= px << 24; out[1] = px >> 8; }
+            else if (j == 2) { out[1] |= px << 16; out[2] = px >> 16; }
+            else out[2] |= px << 8;
         }
-        if (MASK) *reinterpret_cast<uint32_t*>(P.dmask + (long long)y * P.dmask_stride + x0) = mout;
+        if (MASK) {
+            // remapNearest: saturate_cast<short>(cvRound(x)); inside -> source (255), else 0
+            int nx = sat_s16(cv_round(x)), ny = sat_s16(cv_round(yy));
+            uint32_t m = 0;
+            if ((unsigned)nx < (unsigned)P.sw && (unsigned)ny < (unsigned)P.sh)
+                m = P.msrc ? (uint32_t)P.msrc[(long long)ny * P.msstride + nx] : 255u;
+            mout |= m << (8 * j);
+        }
     }
+    if (IMG) {
+        uint32_t* d = reinterpret_cast<uint32_t*>(P.dimg + (long long)y * P.dimg_stride + (long long)x0 * 3);
+        d[0] = out[0];
+        d[1] = out[1];
+        d[2] = out[2];
+    }
+    if (MASK) *reinterpret_cast<uint32_t*>(P.dmask + (long long)y * P.dmask_stride + x0) = mout;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -255,9 +253,17 @@ template <int TYPE>
 int launch_typed(stx_ctx* ctx, const WarpK& K, bool img, bool mask, dim3 grid)
 {
     hipStream_t s = ctx->stream;
-    if (img && mask) hipLaunchKernelGGL((warp_kernel<TYPE, true, true>), grid, dim3(256), 0, s, K);
-    else if (img) hipLaunchKernelGGL((warp_kernel<TYPE, true, false>), grid, dim3(256), 0, s, K);
-    else hipLaunchKernelGGL((warp_kernel<TYPE, false, true>), grid, dim3(256), 0, s, K);
+    // per-column / per-row trig tables (a few KB, L2 resident), freed in stream order
+    const size_t ncol = ((size_t)K.dw + 3) & ~(size_t)3;
+    void* tab = nullptr;
+    STX_TRY(stx_dev_alloc(ctx, (ncol + (size_t)K.dh) * sizeof(float2), &tab));
+    float2* colT = (float2*)tab;
+    float2* rowT = colT + ncol;
+    hipLaunchKernelGGL((warp_tables_kernel<TYPE>), dim3((K.dw + K.dh + 255) / 256), dim3(256), 0, s, K, colT, rowT);
+    if (img && mask) hipLaunchKernelGGL((warp_kernel<TYPE, true, true>), grid, dim3(256), 0, s, K, colT, rowT);
+    else if (img) hipLaunchKernelGGL((warp_kernel<TYPE, true, false>), grid, dim3(256), 0, s, K, colT, rowT);
+    else hipLaunchKernelGGL((warp_kernel<TYPE, false, true>), grid, dim3(256), 0, s, K, colT, rowT);
+    stx_dev_free(ctx, tab);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return stx_fail(STX_ERR_HIP, "warp kernel launch failed: %s", hipGetErrorString(e));
     return STX_OK;
