@@ -293,7 +293,28 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
 // ---------------------------------------------------------------------------------------------
 // gather + normalise + collapse.  One lane = 8 adjacent pixels x 2 rows; tile 512 x 8.
 // ---------------------------------------------------------------------------------------------
-STX_DEV int s6(int v) { return (int)(short)((v + 32) >> 6); }
+// pyrUp's FixPtCast<short,6>: (v + 32) >> 6.  The (short) cast is the identity here: the taps sum to 64,
+// so the result is a convex combination of int16 inputs (+ rounding) and stays inside int16.
+STX_DEV int s6(int v) { return (v + 32) >> 6; }
+
+// static_cast<short>(float) for |v| <= 32768 (products L*w with w <= 1, quotients acc/(w+eps) — see
+// DESIGN.md §4.4): v_cvt_i32_f32 truncates toward zero like cvttss2si and no wrap can occur.
+STX_DEV int trunc_small(float v) { return (int)v; }
+
+// n[c] / d for three numerators sharing one denominator, bit-identical to IEEE-754 division
+// (__fdiv_rn) whenever v_div_scale would not rescale — true here: d in [1e-5, #images], |n| <= 32768.
+// It is LLVM's own f32 fdiv expansion (rcp, 2 Newton fmas; then mul + 4 fmas per quotient) with the
+// reciprocal refinement shared.
+STX_DEV void div3_shared(float d, float n0, float n1, float n2, float& q0, float& q1, float& q2)
+{
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __fmaf_rn(-d, r, 1.0f);
+    r = __fmaf_rn(e, r, r);
+    float t, u;
+    t = __fmul_rn(n0, r); u = __fmaf_rn(-d, t, n0); t = __fmaf_rn(u, r, t); u = __fmaf_rn(-d, t, n0); q0 = __fmaf_rn(u, r, t);
+    t = __fmul_rn(n1, r); u = __fmaf_rn(-d, t, n1); t = __fmaf_rn(u, r, t); u = __fmaf_rn(-d, t, n1); q1 = __fmaf_rn(u, r, t);
+    t = __fmul_rn(n2, r); u = __fmaf_rn(-d, t, n2); t = __fmaf_rn(u, r, t); u = __fmaf_rn(-d, t, n2); q2 = __fmaf_rn(u, r, t);
+}
 
 // pyrUp_<FixPtCast<short,6>> of one plane for the 8x2 patch whose coarse origin is (cx, cy);
 // cx is a multiple of 4 and cx+3 < cw
@@ -395,7 +416,7 @@ __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
                         for (int j = 0; j < 8; j++) {
                             int g = (j & 1) ? s16hi(gw[j >> 1]) : s16lo(gw[j >> 1]);
                             int L = sat_s16(g - up[r][j]);
-                            acc[r][j][c] += trunc_s16(fmul((float)L, w[r][j]));
+                            acc[r][j][c] += trunc_small(fmul((float)L, w[r][j]));
                         }
                     }
                 }
@@ -467,7 +488,7 @@ __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
                         for (int c = 0; c < 3; c++) {
                             int L = (int)byte_of(pw_, 3 * j + c);
                             if (P.num_bands > 0) L = sat_s16(L - up[c][r][j]);
-                            acc[r][j][c] += trunc_s16(fmul((float)L, w));
+                            acc[r][j][c] += trunc_small(fmul((float)L, w));
                         }
                         ws[r][j] = fadd(ws[r][j], w);
                     }
@@ -484,8 +505,11 @@ __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const float den = fadd(ws[r][j], WEIGHT_EPS);
-#pragma unroll
-            for (int c = 0; c < 3; c++) v[r][j][c] = trunc_s16(fdiv((float)(short)acc[r][j][c], den));
+            float q0, q1, q2;
+            div3_shared(den, (float)(short)acc[r][j][0], (float)(short)acc[r][j][1], (float)(short)acc[r][j][2], q0, q1, q2);
+            v[r][j][0] = trunc_small(q0);
+            v[r][j][1] = trunc_small(q1);
+            v[r][j][2] = trunc_small(q2);
         }
     if (P.up) {
 #pragma unroll
