@@ -139,6 +139,25 @@ int stx_blend_finish(stx_blender* b, stx_buf** out_pano_u8, stx_buf** out_mask_u
 int stx_blend_finish_ex(stx_blender* b, stx_buf** out_pano_u8, stx_buf** out_mask_u8, stx_buf** out_pano_s16);
 int stx_blend_destroy(stx_blender* b);
 
+/* ---- sharded multi-band blending: one process per GPU, one stx_blender per rank ------------------
+ * No counterpart in the reference (it is single process, stitching/stitcher.py:247-254).  Every rank
+ * prepares the same roi; rank g produces the columns [x0, x1) of the panorama (stx_blend_set_band).
+ * An image fed on rank o whose 2^bands-aligned feed rectangle reaches another rank's columns is
+ * exported there as a CONTRIBUTION: per pyramid level the products (short)(L*W) and the weights W
+ * over a strip (stx_blend_export_contrib -> RCCL send/recv -> stx_blend_feed_contrib).  Integer sums
+ * are order independent and `order` (the global feed index) fixes the fp32 weight-sum order, so the
+ * assembled panorama is bit-identical to the single-GPU result.  DESIGN.md §6. */
+int stx_blend_set_band(stx_blender* b, int x0, int x1);
+int stx_blend_feed_ex(stx_blender* b, const stx_buf* img, const stx_buf* mask, int tlx, int tly, int order);
+/* strip rect (relative to the roi origin, level 0) and packed size of the contribution that an image
+ * of size (img_w, img_h) at corner (tlx, tly) owes to the owner of columns [band_x0, band_x1);
+ * w = 0 when it owes nothing.  Pure geometry: sender and receiver compute the same answer. */
+int stx_blend_contrib_rect(const stx_blender* b, int img_w, int img_h, int tlx, int tly, int band_x0, int band_x1,
+                           int out_rect_xywh[4], size_t* out_bytes);
+int stx_blend_export_contrib(stx_blender* b, int order, int band_x0, int band_x1, stx_buf** out_packed,
+                             int out_rect_xywh[4]);
+int stx_blend_feed_contrib(stx_blender* b, int order, const int rect_xywh[4], const stx_buf* packed);
+
 /* ---- measurement hooks (bench.py) -----------------------------------------------------
  * When enabled, every kernel launch on the ctx stream is bracketed by HIP events recorded
  * on that stream; stx_prof_get reports per-kernel call count, summed duration and the

@@ -24,7 +24,8 @@ EXPORTS = (
     "stx_buf_from_host stx_buf_alloc stx_buf_to_host stx_buf_view stx_buf_info stx_buf_device_ptr stx_buf_free "
     "stx_warp_roi stx_warp_rois stx_warp stx_warp_image_and_mask stx_warp_mask "
     "stx_result_roi stx_blend_create stx_blend_num_bands stx_blend_feed stx_blend_finish stx_blend_finish_ex "
-    "stx_blend_destroy stx_prof_enable stx_prof_reset stx_prof_count stx_prof_get stx_mark stx_mark_elapsed_ms"
+    "stx_blend_destroy stx_blend_set_band stx_blend_feed_ex stx_blend_contrib_rect stx_blend_export_contrib "
+    "stx_blend_feed_contrib stx_prof_enable stx_prof_reset stx_prof_count stx_prof_get stx_mark stx_mark_elapsed_ms"
 ).split()
 
 _lib = None
@@ -70,6 +71,12 @@ def lib():
     L.stx_blend_finish.argtypes = [vp, vpp, vpp]
     L.stx_blend_finish_ex.argtypes = [vp, vpp, vpp, vpp]
     L.stx_blend_destroy.argtypes = [vp]
+    L.stx_blend_set_band.argtypes = [vp, C.c_int, C.c_int]
+    L.stx_blend_feed_ex.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int]
+    L.stx_blend_contrib_rect.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip,
+                                         C.POINTER(C.c_size_t)]
+    L.stx_blend_export_contrib.argtypes = [vp, C.c_int, C.c_int, C.c_int, vpp, ip]
+    L.stx_blend_feed_contrib.argtypes = [vp, C.c_int, ip, vp]
     L.stx_prof_enable.argtypes = [vp, C.c_int]
     L.stx_prof_reset.argtypes = [vp]
     L.stx_prof_count.argtypes = [vp, ip]

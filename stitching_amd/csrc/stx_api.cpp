@@ -11,6 +11,7 @@
 #include <cstring>
 #include <memory>
 
+#include "stx_blend_kernels.h"
 #include "stx_internal.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -731,9 +732,12 @@ struct stx_blender {
     int fw = 0, fh = 0;                  // dst_roi_final_ size
     bool finished = false;
     // multiband (deferred gather)
-    std::vector<StxMbImage> images;
+    std::vector<StxMbImage> images;   // kept sorted by .order (the global feed order)
+    std::vector<char> built;          // pyramid of images[i] exists (kind 0)
     std::vector<stx_buf*> held;
     std::vector<void*> pyr_allocs;
+    int band_x0 = 0, band_x1 = 0;     // columns of the final roi this blender produces (sharded blending)
+    int next_order = 0;
     // no / feather (accumulate per feed, as OpenCV)
     void* dst = nullptr; long long dst_stride = 0;      // s16 HWC
     void* dmask = nullptr; long long dmask_stride = 0;  // u8
@@ -750,6 +754,7 @@ static void blender_release(stx_blender* b)
     stx_dev_free(b->ctx, b->dmask); b->dmask = nullptr;
     stx_dev_free(b->ctx, b->dw); b->dw = nullptr;
     b->images.clear();
+    b->built.clear();
 }
 
 STX_EXPORT int stx_blend_create(stx_ctx* ctx, int kind, int num_bands, float sharpness, const int roi_xywh[4],
@@ -776,6 +781,7 @@ STX_EXPORT int stx_blend_create(stx_ctx* ctx, int kind, int num_bands, float sha
         h += ((1 << nb) - h % (1 << nb)) % (1 << nb);
     }
     b->rx = roi_xywh[0]; b->ry = roi_xywh[1]; b->rw = w; b->rh = h;
+    b->band_x0 = 0; b->band_x1 = b->fw;
     if (kind != STX_BLEND_MULTIBAND) {
         b->dst_stride = (long long)align_up((size_t)w * 6, 64);
         b->dmask_stride = (long long)align_up((size_t)w, 64);
@@ -802,11 +808,11 @@ STX_EXPORT int stx_blend_num_bands(const stx_blender* b, int* out_num_bands)
     return STX_OK;
 }
 
-static int mb_feed(stx_blender* b, const stx_buf* img, const stx_buf* mask, int tlx, int tly)
+// MultiBandBlender::feed geometry: keep the image with a gap, snap to the 2^bands grid, stay inside dst_roi_.
+// Returns the feed rectangle (tl_new .. br_new) relative to the padded roi.
+static void mb_feed_rect(const stx_blender* b, int w, int h, int tlx, int tly, int* fx, int* fy, int* fw, int* fh)
 {
-    stx_ctx* ctx = b->ctx;
-    const int nb = b->num_bands, w = img->w, h = img->h;
-    // MultiBandBlender::feed: keep the image with a gap, snap to the 2^bands grid, stay inside dst_roi_
+    const int nb = b->num_bands;
     const int gap = 3 * (1 << nb);
     int tlnx = std::max(b->rx, tlx - gap), tlny = std::max(b->ry, tly - gap);
     int brnx = std::min(b->rx + b->rw, tlx + w + gap), brny = std::min(b->ry + b->rh, tly + h + gap);
@@ -818,18 +824,88 @@ static int mb_feed(stx_blender* b, const stx_buf* img, const stx_buf* mask, int 
     brnx = tlnx + width;
     brny = tlny + height;
     const int dy = std::max(brny - (b->ry + b->rh), 0), dx = std::max(brnx - (b->rx + b->rw), 0);
-    tlnx -= dx; brnx -= dx; tlny -= dy; brny -= dy;
+    tlnx -= dx; tlny -= dy;
+    *fx = tlnx - b->rx; *fy = tlny - b->ry; *fw = width; *fh = height;
+}
 
+// Region of every level that the columns [bx0, bx1) of the final panorama depend on (pyrUp halo:
+// level i needs level i+1 at (x >> 1) +- 1).  Origins are multiples of 8 for the vector kernels.
+static void mb_level_regions(const stx_blender* b, int bx0, int bx1, int* xb, int* xe)
+{
+    xb[0] = bx0; xe[0] = bx1;
+    for (int i = 1; i <= b->num_bands; i++) {
+        const int pw = b->rw >> i;
+        xb[i] = std::max(0, (xb[i - 1] >> 1) - 1) & ~7;
+        xe[i] = std::min(pw, ((((xe[i - 1] - 1) >> 1) + 2) + 7) & ~7);
+    }
+}
+
+// Level-0 column range [sx0, sx1) (2^bands aligned, clipped to the feed rect [fx, fx+fw)) of the
+// contribution an image must supply to the rank that owns the columns [bx0, bx1).
+static bool mb_contrib_range(const stx_blender* b, int fx, int fw, int bx0, int bx1, int* sx0, int* sx1)
+{
+    int xb[STX_MAX_BANDS + 1], xe[STX_MAX_BANDS + 1];
+    mb_level_regions(b, bx0, bx1, xb, xe);
+    const int nb = b->num_bands, al = (1 << nb) - 1;
+    long long lo = xb[0], hi = xe[0];
+    for (int i = 1; i <= nb; i++) {
+        lo = std::min(lo, (long long)xb[i] << i);
+        hi = std::max(hi, (long long)xe[i] << i);
+    }
+    lo = lo & ~(long long)al;
+    hi = (hi + al) & ~(long long)al;
+    lo = std::max(lo, (long long)fx);
+    hi = std::min(hi, (long long)fx + fw);
+    *sx0 = (int)lo; *sx1 = (int)hi;
+    return hi > lo;
+}
+
+// packed layout of a contribution strip of size (w, h) at level 0: per level i the three int16 planes
+// then the fp32 weights; every section starts on a 256-byte boundary
+struct ContribLayout {
+    size_t g_off[STX_MAX_BANDS + 1], w_off[STX_MAX_BANDS + 1];
+    long long g_stride[STX_MAX_BANDS + 1], w_stride[STX_MAX_BANDS + 1];
+    size_t bytes;
+};
+static void mb_contrib_layout(int nb, int w, int h, ContribLayout* L)
+{
+    size_t off = 0;
+    for (int i = 0; i <= nb; i++) {
+        const int lw = w >> i, lh = h >> i;
+        L->g_stride[i] = (long long)align_up((size_t)std::max(lw, 1), 32);
+        L->w_stride[i] = (long long)align_up((size_t)std::max(lw, 1), 16);
+        L->g_off[i] = off;
+        off = align_up(off + (size_t)L->g_stride[i] * std::max(lh, 1) * 3 * sizeof(short), 256);
+        L->w_off[i] = off;
+        off = align_up(off + (size_t)L->w_stride[i] * std::max(lh, 1) * sizeof(float), 256);
+    }
+    L->bytes = off;
+}
+
+static void mb_insert_sorted(stx_blender* b, const StxMbImage& im, bool is_built)
+{
+    size_t pos = b->images.size();
+    while (pos > 0 && b->images[pos - 1].order > im.order) pos--;
+    b->images.insert(b->images.begin() + pos, im);
+    b->built.insert(b->built.begin() + pos, is_built ? 1 : 0);
+}
+
+static int mb_feed(stx_blender* b, const stx_buf* img, const stx_buf* mask, int tlx, int tly, int order)
+{
+    stx_ctx* ctx = b->ctx;
+    const int nb = b->num_bands, w = img->w, h = img->h;
     StxMbImage im;
     memset(&im, 0, sizeof(im));
+    im.kind = 0;
+    im.order = order;
+    mb_feed_rect(b, w, h, tlx, tly, &im.fx, &im.fy, &im.fw, &im.fh);
     im.img0 = img->ptr; im.img0_stride = (long long)img->stride; im.img0_is_s16 = img->elem == STX_S16;
     im.mask0 = mask->ptr; im.mask0_stride = (long long)mask->stride;
     im.iw = w; im.ih = h;
     im.ix = tlx - b->rx; im.iy = tly - b->ry;
-    im.fx = tlnx - b->rx; im.fy = tlny - b->ry; im.fw = width; im.fh = height;
-    im.left = tlx - tlnx; im.top = tly - tlny;
+    im.left = im.ix - im.fx; im.top = im.iy - im.fy;
     for (int i = 1; i <= nb; i++) {
-        const int lw = width >> i, lh = height >> i;
+        const int lw = im.fw >> i, lh = im.fh >> i;
         const long long gs = (long long)align_up((size_t)lw, 32), ws = (long long)align_up((size_t)lw, 16);
         void *g = nullptr, *wt = nullptr;
         STX_TRY(stx_dev_alloc(ctx, (size_t)gs * lh * 3 * sizeof(short), &g));
@@ -839,8 +915,9 @@ static int mb_feed(stx_blender* b, const stx_buf* img, const stx_buf* mask, int 
         im.g[i] = (short*)g; im.g_stride[i] = gs; im.g_plane[i] = gs * lh;
         im.wt[i] = (float*)wt; im.wt_stride[i] = ws;
     }
-    // deferred: the pyramids of all images are built at blend() time, one launch per level
-    b->images.push_back(im);
+    // deferred: the pyramids of all images are built together (one launch per level), at the first
+    // export / blend() that needs them
+    mb_insert_sorted(b, im, nb == 0);
     stx_buf_retain(const_cast<stx_buf*>(img));
     stx_buf_retain(const_cast<stx_buf*>(mask));
     b->held.push_back(const_cast<stx_buf*>(img));
@@ -848,7 +925,57 @@ static int mb_feed(stx_blender* b, const stx_buf* img, const stx_buf* mask, int 
     return STX_OK;
 }
 
-STX_EXPORT int stx_blend_feed(stx_blender* b, const stx_buf* img, const stx_buf* mask, int tlx, int tly)
+// upload `n` descriptors (pageable host memory -> device; synchronises the stream)
+static int mb_upload(stx_blender* b, const StxMbImage* h, int n, StxMbImage** d_out)
+{
+    void* d = nullptr;
+    STX_TRY(stx_dev_alloc(b->ctx, sizeof(StxMbImage) * std::max(n, 1), &d));
+    b->pyr_allocs.push_back(d);
+    if (n > 0) {
+        STX_HIP(hipMemcpyAsync(d, h, sizeof(StxMbImage) * n, hipMemcpyHostToDevice, b->ctx->stream));
+        STX_HIP(hipStreamSynchronize(b->ctx->stream));
+    }
+    *d_out = (StxMbImage*)d;
+    return STX_OK;
+}
+
+static int mb_ensure_pyramids(stx_blender* b)
+{
+    std::vector<StxMbImage> todo;
+    for (size_t i = 0; i < b->images.size(); i++)
+        if (b->images[i].kind == 0 && !b->built[i]) todo.push_back(b->images[i]);
+    if (todo.empty()) return STX_OK;
+    StxMbImage* d = nullptr;
+    STX_TRY(mb_upload(b, todo.data(), (int)todo.size(), &d));
+    STX_TRY(stx_launch_mb_pyramids(b->ctx, d, todo.data(), (int)todo.size(), b->num_bands));
+    for (size_t i = 0; i < b->images.size(); i++) b->built[i] = 1;
+    return STX_OK;
+}
+
+static double mb_level_bytes(const stx_blender* b, const std::vector<StxMbImage>& imgs, int lv, int x0, int x1, bool emit,
+                             bool with16)
+{
+    // algorithmic bytes: every input element of the region once, every output element once
+    const int nb = b->num_bands;
+    const int ph = lv == 0 ? b->fh : b->rh >> lv;
+    double bytes = 0.0;
+    for (const StxMbImage& im : imgs) {
+        int rx = im.fx >> lv, rw = im.fw >> lv, ry = im.fy >> lv, rh = im.fh >> lv;
+        if (lv == 0 && im.kind == 0) { rx = im.ix; rw = im.iw; ry = im.iy; rh = im.ih; }
+        const double cols = std::max(0, std::min(rx + rw, x1) - std::max(rx, x0)), rows = std::min(ry + rh, ph) - ry;
+        if (cols <= 0 || rows <= 0) continue;
+        if (im.kind == 1) bytes += cols * rows * 10.0;
+        else if (lv == 0) bytes += cols * rows * ((im.img0_is_s16 ? 6 : 3) + 1) + (nb > 0 ? cols * rows * 6.0 / 4.0 : 0.0);
+        else bytes += cols * rows * 10.0 + (lv < nb ? cols * rows * 6.0 / 4.0 : 0.0);
+    }
+    const double area = (double)(x1 - x0) * ph;
+    if (emit) return bytes + area * 10.0;
+    if (lv < nb) bytes += area * 6.0 / 4.0;
+    bytes += lv == 0 ? area * (4 + (with16 ? 6 : 0)) : area * 6.0;
+    return bytes;
+}
+
+STX_EXPORT int stx_blend_feed_ex(stx_blender* b, const stx_buf* img, const stx_buf* mask, int tlx, int tly, int order)
 {
     if (!b || !img || !mask) return stx_fail(STX_ERR_INVALID, "null argument");
     if (b->finished) return stx_fail(STX_ERR_STATE, "feed after blend()");
@@ -866,7 +993,9 @@ STX_EXPORT int stx_blend_feed(stx_blender* b, const stx_buf* img, const stx_buf*
     if (tlx < b->rx || tly < b->ry || tlx + img->w > ux || tly + img->h > uy)
         return stx_fail(STX_ERR_INVALID, "feed: image at (%d,%d) size %dx%d leaves the prepared roi (%d,%d,%d,%d)", tlx, tly,
                         img->w, img->h, b->rx, b->ry, ux - b->rx, uy - b->ry);
-    if (b->kind == STX_BLEND_MULTIBAND) return mb_feed(b, img, mask, tlx, tly);
+    if (order < 0) order = b->next_order;
+    b->next_order = std::max(b->next_order, order + 1);
+    if (b->kind == STX_BLEND_MULTIBAND) return mb_feed(b, img, mask, tlx, tly, order);
     if (b->kind == STX_BLEND_NO)
         return stx_launch_no_feed(b->ctx, img, mask, (short*)b->dst, b->dst_stride, (uint8_t*)b->dmask, b->dmask_stride,
                                   tlx - b->rx, tly - b->ry);
@@ -874,59 +1003,169 @@ STX_EXPORT int stx_blend_feed(stx_blender* b, const stx_buf* img, const stx_buf*
                                    b->dw_stride, tlx - b->rx, tly - b->ry);
 }
 
+STX_EXPORT int stx_blend_feed(stx_blender* b, const stx_buf* img, const stx_buf* mask, int tlx, int tly)
+{
+    return stx_blend_feed_ex(b, img, mask, tlx, tly, -1);
+}
+
+static void mb_fill_common(const stx_blender* b, MbLevelK* K, const StxMbImage* d_images, int n, int lv)
+{
+    memset(K, 0, sizeof(*K));
+    K->images = d_images; K->n_images = n; K->level = lv; K->num_bands = b->num_bands;
+    K->pw = b->rw >> lv; K->ph = b->rh >> lv;
+    K->all_u8 = 1;
+}
+
 static int mb_finish(stx_blender* b, stx_buf* pano, stx_buf* pmask, stx_buf* pano16)
 {
     stx_ctx* ctx = b->ctx;
     const int nb = b->num_bands, n = (int)b->images.size();
-    void* d_images = nullptr;
-    STX_TRY(stx_dev_alloc(ctx, sizeof(StxMbImage) * std::max(n, 1), &d_images));
-    b->pyr_allocs.push_back(d_images);
-    if (n > 0) {
-        STX_HIP(hipMemcpyAsync(d_images, b->images.data(), sizeof(StxMbImage) * n, hipMemcpyHostToDevice, ctx->stream));
-        STX_HIP(hipStreamSynchronize(ctx->stream));  // images vector is pageable host memory
-        STX_TRY(stx_launch_mb_pyramids(ctx, (const StxMbImage*)d_images, b->images.data(), n, nb));
+    STX_TRY(mb_ensure_pyramids(b));
+    StxMbImage* d_images = nullptr;
+    STX_TRY(mb_upload(b, b->images.data(), n, &d_images));
+    bool all_u8 = true, has_contrib = false;
+    for (const StxMbImage& im : b->images) {
+        if (im.kind == 0 && im.img0_is_s16) all_u8 = false;
+        if (im.kind == 1) has_contrib = true;
     }
+    int xb[STX_MAX_BANDS + 1], xe[STX_MAX_BANDS + 1];
+    mb_level_regions(b, b->band_x0, b->band_x1, xb, xe);
     std::vector<short*> out(nb + 2, nullptr);
     std::vector<long long> ostride(nb + 2, 0), oplane(nb + 2, 0);
     for (int lv = nb; lv >= 0; lv--) {
-        const int pw = b->rw >> lv, ph = b->rh >> lv;
-        StxMbLevelLaunch L;
-        memset(&L, 0, sizeof(L));
-        L.d_images = (const StxMbImage*)d_images;
-        L.n_images = n; L.level = lv; L.num_bands = nb; L.pw = pw; L.ph = ph;
-        L.all_u8 = 1;
-        for (const StxMbImage& im : b->images) if (im.img0_is_s16) L.all_u8 = 0;
-        if (lv < nb) { L.up = out[lv + 1]; L.up_stride = ostride[lv + 1]; L.up_plane = oplane[lv + 1]; }
-        // algorithmic bytes: every input element once, every output element once
-        double bytes = 0.0;
-        for (const StxMbImage& im : b->images) {
-            if (lv == 0) {
-                bytes += (double)im.iw * im.ih * ((im.img0_is_s16 ? 6 : 3) + 1);
-                if (nb > 0) bytes += 6.0 * (im.iw / 2.0) * (im.ih / 2.0);
-            } else {
-                double lp = (double)(im.fw >> lv) * (im.fh >> lv);
-                bytes += lp * 10.0 + (lv < nb ? lp * 6.0 / 4.0 : 0.0);
-            }
+        MbLevelK K;
+        mb_fill_common(b, &K, d_images, n, lv);
+        K.all_u8 = all_u8 ? 1 : 0;
+        K.has_contrib = has_contrib ? 1 : 0;
+        K.x0 = xb[lv]; K.x1 = xe[lv]; K.y0 = 0; K.y1 = lv == 0 ? b->fh : b->rh >> lv;
+        if (lv < nb) {
+            K.up = out[lv + 1]; K.up_stride = ostride[lv + 1]; K.up_plane = oplane[lv + 1];
+            K.up_x0 = xb[lv + 1]; K.up_y0 = 0;
         }
-        if (lv < nb) bytes += 6.0 * (pw / 2.0) * (ph / 2.0);
         if (lv == 0) {
-            L.pano = pano->ptr; L.pano_stride = (long long)pano->stride;
-            L.pmask = pmask->ptr; L.pmask_stride = (long long)pmask->stride;
-            if (pano16) { L.pano16 = (short*)pano16->ptr; L.pano16_stride = (long long)pano16->stride; }
-            L.final_w = b->fw; L.final_h = b->fh;
-            bytes += (double)b->fw * b->fh * (4 + (pano16 ? 6 : 0));
+            K.pano = pano->ptr; K.pano_stride = (long long)pano->stride;
+            K.pmask = pmask->ptr; K.pmask_stride = (long long)pmask->stride;
+            if (pano16) { K.pano16 = (short*)pano16->ptr; K.pano16_stride = (long long)pano16->stride; }
+            K.pano_x0 = b->band_x0; K.pano_y0 = 0;
         } else {
-            const long long s = (long long)align_up((size_t)pw, 32);
+            const int w = xe[lv] - xb[lv], ph = b->rh >> lv;
+            const long long st = (long long)align_up((size_t)std::max(w, 1), 32);
             void* p = nullptr;
-            STX_TRY(stx_dev_alloc(ctx, (size_t)s * ph * 3 * sizeof(short), &p));
+            STX_TRY(stx_dev_alloc(ctx, (size_t)st * ph * 3 * sizeof(short), &p));
             b->pyr_allocs.push_back(p);
-            out[lv] = (short*)p; ostride[lv] = s; oplane[lv] = s * ph;
-            L.out = out[lv]; L.out_stride = s; L.out_plane = s * ph;
-            bytes += 6.0 * pw * ph;
+            out[lv] = (short*)p; ostride[lv] = st; oplane[lv] = st * ph;
+            K.out = out[lv]; K.out_stride = st; K.out_plane = st * ph;
+            K.out_x0 = xb[lv]; K.out_y0 = 0;
         }
-        L.algo_bytes = bytes;
-        STX_TRY(stx_launch_mb_level(ctx, L));
+        STX_TRY(stx_launch_mb_level(ctx, K, mb_level_bytes(b, b->images, lv, K.x0, K.x1, false, pano16 != nullptr)));
     }
+    return STX_OK;
+}
+
+// ---- sharded multi-band blending (one blender per rank) -------------------------------
+STX_EXPORT int stx_blend_set_band(stx_blender* b, int x0, int x1)
+{
+    if (!b) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (b->kind != STX_BLEND_MULTIBAND) return stx_fail(STX_ERR_UNSUPPORTED, "bands exist for the multi-band blender only");
+    if (b->finished) return stx_fail(STX_ERR_STATE, "set_band after blend()");
+    const int al = (1 << b->num_bands) - 1;
+    if (x0 < 0 || x1 > b->fw || x1 <= x0 || (x0 & al) || ((x1 & al) && x1 != b->fw) || (x0 & 7))
+        return stx_fail(STX_ERR_INVALID, "band [%d,%d) must lie in [0,%d) with edges on multiples of max(8, 2^bands)", x0, x1, b->fw);
+    b->band_x0 = x0; b->band_x1 = x1;
+    return STX_OK;
+}
+
+STX_EXPORT int stx_blend_contrib_rect(const stx_blender* b, int img_w, int img_h, int tlx, int tly, int band_x0, int band_x1,
+                                      int out_rect_xywh[4], size_t* out_bytes)
+{
+    if (!b || !out_rect_xywh) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (b->kind != STX_BLEND_MULTIBAND) return stx_fail(STX_ERR_UNSUPPORTED, "multi-band blender only");
+    int fx, fy, fw, fh, sx0, sx1;
+    mb_feed_rect(b, img_w, img_h, tlx, tly, &fx, &fy, &fw, &fh);
+    if (!mb_contrib_range(b, fx, fw, band_x0, band_x1, &sx0, &sx1)) {
+        out_rect_xywh[0] = out_rect_xywh[1] = out_rect_xywh[2] = out_rect_xywh[3] = 0;
+        if (out_bytes) *out_bytes = 0;
+        return STX_OK;
+    }
+    out_rect_xywh[0] = sx0; out_rect_xywh[1] = fy; out_rect_xywh[2] = sx1 - sx0; out_rect_xywh[3] = fh;
+    if (out_bytes) {
+        ContribLayout L;
+        mb_contrib_layout(b->num_bands, sx1 - sx0, fh, &L);
+        *out_bytes = L.bytes;
+    }
+    return STX_OK;
+}
+
+STX_EXPORT int stx_blend_export_contrib(stx_blender* b, int order, int band_x0, int band_x1, stx_buf** out_packed,
+                                        int out_rect_xywh[4])
+{
+    if (!b || !out_packed || !out_rect_xywh) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (b->kind != STX_BLEND_MULTIBAND) return stx_fail(STX_ERR_UNSUPPORTED, "multi-band blender only");
+    if (b->finished) return stx_fail(STX_ERR_STATE, "export after blend()");
+    STX_TRY(stx_set_device(b->ctx));
+    const StxMbImage* src = nullptr;
+    for (const StxMbImage& im : b->images) if (im.kind == 0 && im.order == order) src = &im;
+    if (!src) return stx_fail(STX_ERR_INVALID, "no fed image with order %d", order);
+    int sx0, sx1;
+    if (!mb_contrib_range(b, src->fx, src->fw, band_x0, band_x1, &sx0, &sx1))
+        return stx_fail(STX_ERR_INVALID, "image %d does not reach the columns [%d,%d)", order, band_x0, band_x1);
+    const int nb = b->num_bands, sw = sx1 - sx0, sh = src->fh;
+    ContribLayout L;
+    mb_contrib_layout(nb, sw, sh, &L);
+    STX_TRY(mb_ensure_pyramids(b));
+    // re-find: mb_ensure_pyramids does not move descriptors, but keep the copy local anyway
+    StxMbImage one = *src;
+    stx_buf* packed = nullptr;
+    STX_TRY(stx_buf_new(b->ctx, (int)std::min<size_t>(L.bytes, 1u << 30), (int)((L.bytes + (1u << 30) - 1) >> 30), 1, STX_U8, &packed));
+    if (packed->stride * (size_t)packed->h < L.bytes) { stx_buf_release(packed); return stx_fail(STX_ERR_OOM, "contribution too large"); }
+    StxMbImage* d_one = nullptr;
+    int rc = mb_upload(b, &one, 1, &d_one);
+    std::vector<StxMbImage> single(1, one);
+    for (int lv = 0; lv <= nb && rc == STX_OK; lv++) {
+        MbLevelK K;
+        mb_fill_common(b, &K, d_one, 1, lv);
+        K.all_u8 = one.img0_is_s16 ? 0 : 1;
+        K.x0 = sx0 >> lv; K.x1 = sx1 >> lv; K.y0 = one.fy >> lv; K.y1 = (one.fy + sh) >> lv;
+        K.emit = 1;
+        K.out = (short*)(packed->ptr + L.g_off[lv]); K.out_stride = L.g_stride[lv];
+        K.out_plane = L.g_stride[lv] * std::max(sh >> lv, 1);
+        K.out_x0 = K.x0; K.out_y0 = K.y0;
+        K.out_w = (float*)(packed->ptr + L.w_off[lv]); K.out_w_stride = L.w_stride[lv];
+        rc = stx_launch_mb_level(b->ctx, K, mb_level_bytes(b, single, lv, K.x0, K.x1, true, false));
+    }
+    if (rc != STX_OK) { stx_buf_release(packed); return rc; }
+    out_rect_xywh[0] = sx0; out_rect_xywh[1] = one.fy; out_rect_xywh[2] = sw; out_rect_xywh[3] = sh;
+    *out_packed = packed;
+    return STX_OK;
+}
+
+STX_EXPORT int stx_blend_feed_contrib(stx_blender* b, int order, const int rect_xywh[4], const stx_buf* packed)
+{
+    if (!b || !rect_xywh || !packed) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (b->kind != STX_BLEND_MULTIBAND) return stx_fail(STX_ERR_UNSUPPORTED, "multi-band blender only");
+    if (b->finished) return stx_fail(STX_ERR_STATE, "feed after blend()");
+    const int nb = b->num_bands, al = (1 << nb) - 1;
+    const int x = rect_xywh[0], y = rect_xywh[1], w = rect_xywh[2], h = rect_xywh[3];
+    if (w <= 0 || h <= 0 || ((x | y | w | h) & al) || x < 0 || y < 0 || x + w > b->rw || y + h > b->rh)
+        return stx_fail(STX_ERR_INVALID, "contribution rect (%d,%d,%d,%d) is not a 2^bands-aligned part of the roi", x, y, w, h);
+    ContribLayout L;
+    mb_contrib_layout(nb, w, h, &L);
+    if (packed->elem != STX_U8 || packed->c != 1 || packed->stride * (size_t)packed->h < L.bytes)
+        return stx_fail(STX_ERR_INVALID, "contribution buffer holds %zu bytes, layout needs %zu", packed->stride * (size_t)packed->h, L.bytes);
+    StxMbImage im;
+    memset(&im, 0, sizeof(im));
+    im.kind = 1;
+    im.order = order;
+    im.fx = x; im.fy = y; im.fw = w; im.fh = h;
+    for (int i = 0; i <= nb; i++) {
+        im.g[i] = (short*)(packed->ptr + L.g_off[i]); im.g_stride[i] = L.g_stride[i];
+        im.g_plane[i] = L.g_stride[i] * std::max(h >> i, 1);
+        im.wt[i] = (float*)(packed->ptr + L.w_off[i]); im.wt_stride[i] = L.w_stride[i];
+    }
+    mb_insert_sorted(b, im, true);
+    b->next_order = std::max(b->next_order, order + 1);
+    stx_buf_retain(const_cast<stx_buf*>(packed));
+    b->held.push_back(const_cast<stx_buf*>(packed));
     return STX_OK;
 }
 
@@ -936,7 +1175,7 @@ STX_EXPORT int stx_blend_finish_ex(stx_blender* b, stx_buf** out_pano_u8, stx_bu
     if (b->finished) return stx_fail(STX_ERR_STATE, "blend() was already called on this blender");
     STX_TRY(stx_set_device(b->ctx));
     stx_ctx* ctx = b->ctx;
-    const int ow = b->kind == STX_BLEND_MULTIBAND ? b->fw : b->rw, oh = b->kind == STX_BLEND_MULTIBAND ? b->fh : b->rh;
+    const int ow = b->kind == STX_BLEND_MULTIBAND ? b->band_x1 - b->band_x0 : b->rw, oh = b->kind == STX_BLEND_MULTIBAND ? b->fh : b->rh;
     stx_buf *pano = nullptr, *pmask = nullptr, *p16 = nullptr;
     int rc = stx_buf_new(ctx, ow, oh, 3, STX_U8, &pano);
     if (rc == STX_OK) rc = stx_buf_new(ctx, ow, oh, 1, STX_U8, &pmask);

@@ -154,80 +154,70 @@ STX_DEV int pyr_up_at(const short* __restrict__ plane, long long stride, int cw,
 }
 
 
-// levels >= 1: gather + normalise + collapse
+// gather + normalise + collapse of one level (generic, one pixel per lane; all levels, all kinds)
+template <bool L0>
 __global__ __launch_bounds__(256) void mb_level_kernel(MbLevelK P)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= P.pw || y >= P.ph) return;
+    const int x = P.x0 + blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = P.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.x1 || y >= P.y1) return;
     const int lv = P.level;
     int acc0 = 0, acc1 = 0, acc2 = 0;
     float ws = 0.f;
     for (int k = 0; k < P.n_images; k++) {
         const StxMbImage& im = P.images[k];
-        const int lx = x - (im.fx >> lv), ly = y - (im.fy >> lv);
-        const int lw = im.fw >> lv, lh = im.fh >> lv;
-        if ((unsigned)lx >= (unsigned)lw || (unsigned)ly >= (unsigned)lh) continue;
-        const float w = im.wt[lv][(long long)ly * im.wt_stride[lv] + lx];
-        const short* G = im.g[lv] + (long long)ly * im.g_stride[lv] + lx;
-        int L[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            int gval = G[c * im.g_plane[lv]];
-            if (lv < P.num_bands) {
-                int u = pyr_up_at(im.g[lv + 1] + c * im.g_plane[lv + 1], im.g_stride[lv + 1], lw >> 1, lh >> 1, lx, ly);
-                gval = sat_s16(gval - u);
-            }
-            L[c] = gval;
-        }
-        acc0 += trunc_s16(fmul((float)L[0], w));
-        acc1 += trunc_s16(fmul((float)L[1], w));
-        acc2 += trunc_s16(fmul((float)L[2], w));
-        ws = fadd(ws, w);
-    }
-    const float den = fadd(ws, WEIGHT_EPS);
-    int n[3];
-    n[0] = trunc_s16(fdiv((float)(short)acc0, den));
-    n[1] = trunc_s16(fdiv((float)(short)acc1, den));
-    n[2] = trunc_s16(fdiv((float)(short)acc2, den));
-    short* O = P.out + (long long)y * P.out_stride + x;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        int v = n[c];
-        if (P.up) v = sat_s16(pyr_up_at(P.up + c * P.up_plane, P.up_stride, P.pw >> 1, P.ph >> 1, x, y) + v);
-        O[c * P.out_plane] = (short)v;
-    }
-}
-
-// level 0: as above, reading the fed images directly; writes u8 panorama + mask (+ int16 result)
-__global__ __launch_bounds__(256) void mb_level0_kernel(MbLevelK P)
-{
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= P.final_w || y >= P.final_h) return;
-    int acc0 = 0, acc1 = 0, acc2 = 0;
-    float ws = 0.f;
-    for (int k = 0; k < P.n_images; k++) {
-        const StxMbImage& im = P.images[k];
-        // outside the image itself the bordered weight is the constant 0: (short)(L*0) = 0, w += 0
-        const int lx = x - im.ix, ly = y - im.iy;
-        if ((unsigned)lx >= (unsigned)im.iw || (unsigned)ly >= (unsigned)im.ih) continue;
-        const float w = fmul((float)im.mask0[(long long)ly * im.mask0_stride + lx], INV255);
-        int L[3];
-        if (im.img0_is_s16) load_px0<true>(im, lx, ly, L[0], L[1], L[2]);
-        else load_px0<false>(im, lx, ly, L[0], L[1], L[2]);
-        if (P.num_bands > 0) {
-            const int bx = x - im.fx, by = y - im.fy;
+        if (im.kind == 1 || !L0) {
+            const int lx = x - (im.fx >> lv), ly = y - (im.fy >> lv);
+            const int lw = im.fw >> lv, lh = im.fh >> lv;
+            if ((unsigned)lx >= (unsigned)lw || (unsigned)ly >= (unsigned)lh) continue;
+            const float w = im.wt[lv][(long long)ly * im.wt_stride[lv] + lx];
+            const short* G = im.g[lv] + (long long)ly * im.g_stride[lv] + lx;
+            int L[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                int u = pyr_up_at(im.g[1] + c * im.g_plane[1], im.g_stride[1], im.fw >> 1, im.fh >> 1, bx, by);
-                L[c] = sat_s16(L[c] - u);
+                int gval = G[c * im.g_plane[lv]];
+                if (im.kind == 0 && lv < P.num_bands) {
+                    int u = pyr_up_at(im.g[lv + 1] + c * im.g_plane[lv + 1], im.g_stride[lv + 1], lw >> 1, lh >> 1, lx, ly);
+                    gval = sat_s16(gval - u);
+                }
+                L[c] = gval;
             }
+            if (im.kind == 1) {  // already (short)(L * W)
+                acc0 += L[0]; acc1 += L[1]; acc2 += L[2];
+            } else {
+                acc0 += trunc_s16(fmul((float)L[0], w));
+                acc1 += trunc_s16(fmul((float)L[1], w));
+                acc2 += trunc_s16(fmul((float)L[2], w));
+            }
+            ws = fadd(ws, w);
+        } else {
+            // level 0 of a fed image: outside the image itself the bordered weight is the constant 0:
+            // (short)(L*0) = 0, w += 0
+            const int lx = x - im.ix, ly = y - im.iy;
+            if ((unsigned)lx >= (unsigned)im.iw || (unsigned)ly >= (unsigned)im.ih) continue;
+            const float w = fmul((float)im.mask0[(long long)ly * im.mask0_stride + lx], INV255);
+            int L[3];
+            if (im.img0_is_s16) load_px0<true>(im, lx, ly, L[0], L[1], L[2]);
+            else load_px0<false>(im, lx, ly, L[0], L[1], L[2]);
+            if (P.num_bands > 0) {
+                const int bx = x - im.fx, by = y - im.fy;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    int u = pyr_up_at(im.g[1] + c * im.g_plane[1], im.g_stride[1], im.fw >> 1, im.fh >> 1, bx, by);
+                    L[c] = sat_s16(L[c] - u);
+                }
+            }
+            acc0 += trunc_s16(fmul((float)L[0], w));
+            acc1 += trunc_s16(fmul((float)L[1], w));
+            acc2 += trunc_s16(fmul((float)L[2], w));
+            ws = fadd(ws, w);
         }
-        acc0 += trunc_s16(fmul((float)L[0], w));
-        acc1 += trunc_s16(fmul((float)L[1], w));
-        acc2 += trunc_s16(fmul((float)L[2], w));
-        ws = fadd(ws, w);
+    }
+    if (P.emit) {  // contribution strip for another rank: un-normalised
+        short* O = P.out + (long long)(y - P.out_y0) * P.out_stride + (x - P.out_x0);
+        O[0] = (short)acc0; O[P.out_plane] = (short)acc1; O[2 * P.out_plane] = (short)acc2;
+        P.out_w[(long long)(y - P.out_y0) * P.out_w_stride + (x - P.out_x0)] = ws;
+        return;
     }
     const float den = fadd(ws, WEIGHT_EPS);
     int v[3];
@@ -235,20 +225,27 @@ __global__ __launch_bounds__(256) void mb_level0_kernel(MbLevelK P)
     v[1] = trunc_s16(fdiv((float)(short)acc1, den));
     v[2] = trunc_s16(fdiv((float)(short)acc2, den));
     if (P.up) {
+        const short* U = P.up - ((long long)P.up_y0 * P.up_stride + P.up_x0);
 #pragma unroll
         for (int c = 0; c < 3; c++)
-            v[c] = sat_s16(pyr_up_at(P.up + c * P.up_plane, P.up_stride, P.pw >> 1, P.ph >> 1, x, y) + v[c]);
+            v[c] = sat_s16(pyr_up_at(U + c * P.up_plane, P.up_stride, P.pw >> 1, P.ph >> 1, x, y) + v[c]);
+    }
+    if (!L0) {
+        short* O = P.out + (long long)(y - P.out_y0) * P.out_stride + (x - P.out_x0);
+        O[0] = (short)v[0]; O[P.out_plane] = (short)v[1]; O[2 * P.out_plane] = (short)v[2];
+        return;
     }
     const bool keep = ws > WEIGHT_EPS;  // compare(dst_band_weights_0, WEIGHT_EPS, CMP_GT); setTo(0, !mask)
     if (!keep) v[0] = v[1] = v[2] = 0;
-    uint8_t* o = P.pano + (long long)y * P.pano_stride + x * 3;
+    const int ox = x - P.pano_x0, oy = y - P.pano_y0;
+    uint8_t* o = P.pano + (long long)oy * P.pano_stride + ox * 3;
     // convertScaleAbs: saturate_cast<uchar>(|x|)
     o[0] = (uint8_t)min(abs(v[0]), 255);
     o[1] = (uint8_t)min(abs(v[1]), 255);
     o[2] = (uint8_t)min(abs(v[2]), 255);
-    P.pmask[(long long)y * P.pmask_stride + x] = keep ? 255 : 0;
+    P.pmask[(long long)oy * P.pmask_stride + ox] = keep ? 255 : 0;
     if (P.pano16) {
-        short* o16 = reinterpret_cast<short*>(reinterpret_cast<uint8_t*>(P.pano16) + (long long)y * P.pano16_stride) + x * 3;
+        short* o16 = reinterpret_cast<short*>(reinterpret_cast<uint8_t*>(P.pano16) + (long long)oy * P.pano16_stride) + ox * 3;
         o16[0] = (short)v[0]; o16[1] = (short)v[1]; o16[2] = (short)v[2];
     }
 }
@@ -436,26 +433,14 @@ int stx_launch_mb_pyramids(stx_ctx* ctx, const StxMbImage* d_images, const StxMb
     return STX_OK;
 }
 
-int stx_launch_mb_level(stx_ctx* ctx, const StxMbLevelLaunch& L)
+int stx_launch_mb_level(stx_ctx* ctx, const MbLevelK& K, double algo_bytes)
 {
-    MbLevelK K;
-    K.images = L.d_images; K.n_images = L.n_images; K.level = L.level; K.num_bands = L.num_bands;
-    K.pw = L.pw; K.ph = L.ph;
-    K.out = L.out; K.out_stride = L.out_stride; K.out_plane = L.out_plane;
-    K.up = L.up; K.up_stride = L.up_stride; K.up_plane = L.up_plane;
-    K.pano = L.pano; K.pano_stride = L.pano_stride; K.pmask = L.pmask; K.pmask_stride = L.pmask_stride;
-    K.pano16 = L.pano16; K.pano16_stride = L.pano16_stride;
-    K.final_w = L.final_w; K.final_h = L.final_h;
-    K.all_u8 = L.all_u8;
-    if (L.level == 0) {
-        StxProfScope prof(ctx, "mb_level0", L.algo_bytes);
-        if (K.all_u8 && stx_fast_mb_level(ctx, K)) return STX_OK;
-        hipLaunchKernelGGL(mb_level0_kernel, grid64x4(L.final_w, L.final_h), dim3(256), 0, ctx->stream, K);
-        return check_launch("mb_level0");
-    }
-    StxProfScope prof(ctx, "mb_level", L.algo_bytes);
-    if (stx_fast_mb_level(ctx, K)) return STX_OK;
-    hipLaunchKernelGGL(mb_level_kernel, grid64x4(L.pw, L.ph), dim3(256), 0, ctx->stream, K);
+    if (K.x1 <= K.x0 || K.y1 <= K.y0) return STX_OK;
+    StxProfScope prof(ctx, K.emit ? "mb_contrib" : (K.level == 0 ? "mb_level0" : "mb_level"), algo_bytes);
+    if ((K.level > 0 || K.all_u8) && stx_fast_mb_level(ctx, K)) return STX_OK;
+    const dim3 grid = grid64x4(K.x1 - K.x0, K.y1 - K.y0);
+    if (K.level == 0) hipLaunchKernelGGL(mb_level_kernel<true>, grid, dim3(256), 0, ctx->stream, K);
+    else hipLaunchKernelGGL(mb_level_kernel<false>, grid, dim3(256), 0, ctx->stream, K);
     return check_launch("mb_level");
 }
 

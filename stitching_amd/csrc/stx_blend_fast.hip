@@ -346,17 +346,18 @@ STX_DEV void up_patch(const short* __restrict__ plane, long long stride, int cw,
     }
 }
 
-template <bool L0>
+// CONTRIB: the image table may hold received contribution strips (kind 1); EMIT: write un-normalised sums.
+// Both are compile-time so that the common single-GPU instantiation carries neither path.
+template <bool L0, bool CONTRIB, bool EMIT>
 __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
 {
     __shared__ int s_list[64];
     __shared__ int s_n;
     const int tid = threadIdx.x;
     const int lv = P.level;
-    const int tile_x = blockIdx.x * 512, tile_y = blockIdx.y * 8;
+    const int tile_x = P.x0 + blockIdx.x * 512, tile_y = P.y0 + blockIdx.y * 8;
     const int X0 = tile_x + (tid & 63) * 8, Y0 = tile_y + (tid >> 6) * 2;
-    const int lim_w = L0 ? P.final_w : P.pw, lim_h = L0 ? P.final_h : P.ph;
-    const bool active = X0 < lim_w && Y0 < lim_h;
+    const bool active = X0 < P.x1 && Y0 < P.y1;
 
     int acc[2][8][3];
     float ws[2][8];
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
             if (k < P.n_images) {
                 const StxMbImage& im = P.images[k];
                 int rx, ry, rw, rh;
-                if (L0) { rx = im.ix; ry = im.iy; rw = im.iw; rh = im.ih; }
+                if (L0 && !(CONTRIB && im.kind == 1)) { rx = im.ix; ry = im.iy; rw = im.iw; rh = im.ih; }
                 else { rx = im.fx >> lv; ry = im.fy >> lv; rw = im.fw >> lv; rh = im.fh >> lv; }
                 hit = rx < tile_x + 512 && rx + rw > tile_x && ry < tile_y + 8 && ry + rh > tile_y;
             }
@@ -390,7 +391,8 @@ __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
             const int k = __builtin_amdgcn_readfirstlane(s_list[i]);
             const StxMbImage& im = P.images[k];
             if (!active) continue;
-            if (!L0) {
+            if (!L0 || (CONTRIB && im.kind == 1)) {
+                const bool contrib = CONTRIB && im.kind == 1;  // rows already hold (short)(L * W)
                 const int lx0 = X0 - (im.fx >> lv), ly0 = Y0 - (im.fy >> lv);
                 const int lw = im.fw >> lv, lh = im.fh >> lv;
                 if ((unsigned)lx0 >= (unsigned)lw || (unsigned)ly0 >= (unsigned)lh) continue;
@@ -405,8 +407,9 @@ __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     int up[2][8];
-                    up_patch(im.g[lv + 1] + c * im.g_plane[lv + 1], im.g_stride[lv + 1], lw >> 1, lh >> 1, lx0 >> 1,
-                             ly0 >> 1, up);
+                    if (!contrib)
+                        up_patch(im.g[lv + 1] + c * im.g_plane[lv + 1], im.g_stride[lv + 1], lw >> 1, lh >> 1, lx0 >> 1,
+                                 ly0 >> 1, up);
 #pragma unroll
                     for (int r = 0; r < 2; r++) {
                         const short* gp = im.g[lv] + c * im.g_plane[lv] + (long long)(ly0 + r) * im.g_stride[lv] + lx0;
@@ -415,8 +418,12 @@ __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
                             int g = (j & 1) ? s16hi(gw[j >> 1]) : s16lo(gw[j >> 1]);
-                            int L = sat_s16(g - up[r][j]);
-                            acc[r][j][c] += trunc_small(fmul((float)L, w[r][j]));
+                            if (contrib) {
+                                acc[r][j][c] += g;
+                            } else {
+                                int L = sat_s16(g - up[r][j]);
+                                acc[r][j][c] += trunc_small(fmul((float)L, w[r][j]));
+                            }
                         }
                     }
                 }
@@ -498,6 +505,26 @@ __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
     }
     if (!active) return;
 
+    if (EMIT) {  // contribution strip for another rank: (short)acc and the weight sum, un-normalised
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            if (Y0 + r >= P.y1) break;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                uint4 o;
+                o.x = pack16(acc[r][0][c], acc[r][1][c]);
+                o.y = pack16(acc[r][2][c], acc[r][3][c]);
+                o.z = pack16(acc[r][4][c], acc[r][5][c]);
+                o.w = pack16(acc[r][6][c], acc[r][7][c]);
+                *reinterpret_cast<uint4*>(P.out + c * P.out_plane + (long long)(Y0 + r - P.out_y0) * P.out_stride + (X0 - P.out_x0)) = o;
+            }
+            float* ow = P.out_w + (long long)(Y0 + r - P.out_y0) * P.out_w_stride + (X0 - P.out_x0);
+            *reinterpret_cast<float4*>(ow) = make_float4(ws[r][0], ws[r][1], ws[r][2], ws[r][3]);
+            *reinterpret_cast<float4*>(ow + 4) = make_float4(ws[r][4], ws[r][5], ws[r][6], ws[r][7]);
+        }
+        return;
+    }
+
     // normalizeUsingWeightMap, then + pyrUp(finished coarser level), saturating
     int v[2][8][3];
 #pragma unroll
@@ -515,7 +542,8 @@ __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             int up[2][8];
-            up_patch(P.up + c * P.up_plane, P.up_stride, P.pw >> 1, P.ph >> 1, X0 >> 1, Y0 >> 1, up);
+            up_patch(P.up + c * P.up_plane - ((long long)P.up_y0 * P.up_stride + P.up_x0), P.up_stride, P.pw >> 1, P.ph >> 1,
+                     X0 >> 1, Y0 >> 1, up);
 #pragma unroll
             for (int r = 0; r < 2; r++)
 #pragma unroll
@@ -532,13 +560,15 @@ __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
                 o.y = pack16(v[r][2][c], v[r][3][c]);
                 o.z = pack16(v[r][4][c], v[r][5][c]);
                 o.w = pack16(v[r][6][c], v[r][7][c]);
-                *reinterpret_cast<uint4*>(P.out + c * P.out_plane + (long long)(Y0 + r) * P.out_stride + X0) = o;
+                if (Y0 + r < P.y1)
+                    *reinterpret_cast<uint4*>(P.out + c * P.out_plane + (long long)(Y0 + r - P.out_y0) * P.out_stride + (X0 - P.out_x0)) = o;
             }
     } else {
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             const int y = Y0 + r;
-            if (y >= P.final_h) break;
+            if (y >= P.y1) break;
+            const int oy = y - P.pano_y0, ox = X0 - P.pano_x0;
             uint32_t ob[6] = {0, 0, 0, 0, 0, 0}, om[2] = {0, 0};
 #pragma unroll
             for (int j = 0; j < 8; j++) {
@@ -552,14 +582,14 @@ __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
                 }
                 om[j >> 2] |= (keep ? 255u : 0u) << (8 * (j & 3));
             }
-            uint32_t* po = reinterpret_cast<uint32_t*>(P.pano + (long long)y * P.pano_stride + (long long)X0 * 3);
+            uint32_t* po = reinterpret_cast<uint32_t*>(P.pano + (long long)oy * P.pano_stride + (long long)ox * 3);
             *reinterpret_cast<uint2*>(po) = make_uint2(ob[0], ob[1]);
             *reinterpret_cast<uint2*>(po + 2) = make_uint2(ob[2], ob[3]);
             *reinterpret_cast<uint2*>(po + 4) = make_uint2(ob[4], ob[5]);
-            *reinterpret_cast<uint2*>(P.pmask + (long long)y * P.pmask_stride + X0) = make_uint2(om[0], om[1]);
+            *reinterpret_cast<uint2*>(P.pmask + (long long)oy * P.pmask_stride + ox) = make_uint2(om[0], om[1]);
             if (P.pano16) {
-                uint32_t* p16 = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(P.pano16) + (long long)y * P.pano16_stride +
-                                                            (long long)X0 * 6);
+                uint32_t* p16 = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(P.pano16) + (long long)oy * P.pano16_stride +
+                                                            (long long)ox * 6);
                 uint32_t s[12];
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {  // 2 pixels = 6 shorts = 3 dwords
@@ -596,14 +626,22 @@ bool stx_fast_mb_down_batch(stx_ctx* ctx, const StxMbImage* d_images, const StxM
 
 bool stx_fast_mb_level(stx_ctx* ctx, const MbLevelK& K)
 {
-    // 8-pixel strips must never straddle a feed-rectangle edge: 2^(B - level) >= 8
+    // 8-pixel strips must never straddle a feed-rectangle edge: 2^(B - level) >= 8; all origins 8-aligned
     if (K.num_bands - K.level < 3) return false;
-    if (K.level == 0) {
-        dim3 grid((K.final_w + 511) / 512, (K.final_h + 7) / 8);
-        hipLaunchKernelGGL(mb_level_fast_kernel<true>, grid, dim3(256), 0, ctx->stream, K);
+    if ((K.x0 | K.y0 | K.out_x0 | K.out_y0 | K.pano_x0 | K.pano_y0) & 7) return false;
+    if (K.up && ((K.up_x0 | K.up_y0) & 3)) return false;
+    if (K.n_images > 255) return false;
+    dim3 grid((K.x1 - K.x0 + 511) / 512, (K.y1 - K.y0 + 7) / 8);
+    hipStream_t st = ctx->stream;
+    if (K.emit) {
+        if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, true>), grid, dim3(256), 0, st, K);
+        else hipLaunchKernelGGL((mb_level_fast_kernel<false, false, true>), grid, dim3(256), 0, st, K);
+    } else if (K.has_contrib) {
+        if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, true, false>), grid, dim3(256), 0, st, K);
+        else hipLaunchKernelGGL((mb_level_fast_kernel<false, true, false>), grid, dim3(256), 0, st, K);
     } else {
-        dim3 grid((K.pw + 511) / 512, (K.ph + 7) / 8);
-        hipLaunchKernelGGL(mb_level_fast_kernel<false>, grid, dim3(256), 0, ctx->stream, K);
+        if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, false>), grid, dim3(256), 0, st, K);
+        else hipLaunchKernelGGL((mb_level_fast_kernel<false, false, false>), grid, dim3(256), 0, st, K);
     }
     return launched_ok();
 }

@@ -124,6 +124,9 @@ int stx_launch_roi_minmax(stx_ctx* ctx, int n, const StxProjector* projs, const 
 
 // multi-band -------------------------------------------------------------------------------------
 struct StxMbImage {  // device-visible descriptor of one fed image (all levels)
+    // kind 0: an image fed on this rank.  kind 1: a contribution strip received from another rank:
+    // per level i, g[i] holds (short)(L_i * W_i) and wt[i] holds W_i over the rect (fx,fy,fw,fh) >> i.
+    int kind; int order;
     const uint8_t* img0; long long img0_stride; int img0_is_s16;
     const uint8_t* mask0; long long mask0_stride;
     int iw, ih;            // image size
@@ -135,19 +138,8 @@ struct StxMbImage {  // device-visible descriptor of one fed image (all levels)
     float* wt[STX_MAX_BANDS + 1]; long long wt_stride[STX_MAX_BANDS + 1];
 };
 int stx_launch_mb_pyramids(stx_ctx* ctx, const StxMbImage* d_images, const StxMbImage* h_images, int n, int num_bands);
-struct StxMbLevelLaunch {
-    const StxMbImage* d_images; int n_images; int level; int num_bands;
-    int pw, ph;                       // padded panorama size at this level
-    short* out; long long out_stride, out_plane;            // normalised+collapsed level (planar s16), levels >= 1
-    const short* up; long long up_stride, up_plane;         // finished level+1 (null at level == num_bands)
-    // level 0 outputs
-    uint8_t* pano; long long pano_stride; uint8_t* pmask; long long pmask_stride;
-    short* pano16; long long pano16_stride;                 // optional int16 HWC result
-    int final_w, final_h;
-    int all_u8;
-    double algo_bytes;
-};
-int stx_launch_mb_level(stx_ctx* ctx, const StxMbLevelLaunch& L);
+struct MbLevelK;
+int stx_launch_mb_level(stx_ctx* ctx, const MbLevelK& K, double algo_bytes);
 
 // simple blenders --------------------------------------------------------------------------------
 int stx_launch_no_feed(stx_ctx* ctx, const stx_buf* img, const stx_buf* mask, short* dst, long long dst_stride,
