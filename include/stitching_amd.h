@@ -158,6 +158,18 @@ int stx_blend_export_contrib(stx_blender* b, int order, int band_x0, int band_x1
                              int out_rect_xywh[4]);
 int stx_blend_feed_contrib(stx_blender* b, int order, const int rect_xywh[4], const stx_buf* packed);
 
+/* ---- RCCL strip exchange over xGMI ---------------------------------------------------------------
+ * One communicator per rank (one process per GPU).  stx_comm_exchange issues every send / receive
+ * of one step as a single RCCL group on the context's HIP stream: it is ordered after the kernels
+ * that filled the send buffers and before the kernels that read the receive buffers.  The unique id
+ * (128 bytes, from rank 0) travels over the caller's control plane. */
+typedef struct stx_comm stx_comm;
+int stx_comm_unique_id(unsigned char out[128]);
+int stx_comm_create(stx_ctx* ctx, int nranks, int rank, const unsigned char id[128], stx_comm** out);
+int stx_comm_exchange(stx_comm* comm, int n_ops, const int* peers, const int* is_send, void* const* dev_ptrs,
+                      const size_t* bytes);
+int stx_comm_destroy(stx_comm* comm);
+
 /* ---- measurement hooks (bench.py) -----------------------------------------------------
  * When enabled, every kernel launch on the ctx stream is bracketed by HIP events recorded
  * on that stream; stx_prof_get reports per-kernel call count, summed duration and the

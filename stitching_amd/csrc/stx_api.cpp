@@ -760,8 +760,11 @@ static void blender_release(stx_blender* b)
 STX_EXPORT int stx_blend_create(stx_ctx* ctx, int kind, int num_bands, float sharpness, const int roi_xywh[4],
                                 stx_blender** out)
 {
-    if (!ctx || !roi_xywh || !out) return stx_fail(STX_ERR_INVALID, "null argument");
-    STX_TRY(stx_set_device(ctx));
+    if (!roi_xywh || !out) return stx_fail(STX_ERR_INVALID, "null argument");
+    // ctx == NULL: geometry-only multi-band blender (band count, feed / contribution rectangles) for
+    // planning on hosts without a GPU; it cannot be fed
+    if (!ctx && kind != STX_BLEND_MULTIBAND) return stx_fail(STX_ERR_INVALID, "ctx is null");
+    if (ctx) STX_TRY(stx_set_device(ctx));
     if (kind < STX_BLEND_NO || kind > STX_BLEND_MULTIBAND) return stx_fail(STX_ERR_INVALID, "unknown blender kind %d", kind);
     int w = roi_xywh[2], h = roi_xywh[3];
     if (w <= 0 || h <= 0) return stx_fail(STX_ERR_INVALID, "empty destination roi %dx%d", w, h);
@@ -979,6 +982,7 @@ STX_EXPORT int stx_blend_feed_ex(stx_blender* b, const stx_buf* img, const stx_b
 {
     if (!b || !img || !mask) return stx_fail(STX_ERR_INVALID, "null argument");
     if (b->finished) return stx_fail(STX_ERR_STATE, "feed after blend()");
+    if (!b->ctx) return stx_fail(STX_ERR_STATE, "geometry-only blender (created without a context)");
     STX_TRY(stx_set_device(b->ctx));
     // CV_Assert(img.type() == CV_16SC3 [|| CV_8UC3]); CV_Assert(mask.type() == CV_8U)
     if (img->c != 3 || (img->elem != STX_U8 && img->elem != STX_S16))
@@ -1102,6 +1106,7 @@ STX_EXPORT int stx_blend_export_contrib(stx_blender* b, int order, int band_x0, 
     if (!b || !out_packed || !out_rect_xywh) return stx_fail(STX_ERR_INVALID, "null argument");
     if (b->kind != STX_BLEND_MULTIBAND) return stx_fail(STX_ERR_UNSUPPORTED, "multi-band blender only");
     if (b->finished) return stx_fail(STX_ERR_STATE, "export after blend()");
+    if (!b->ctx) return stx_fail(STX_ERR_STATE, "geometry-only blender (created without a context)");
     STX_TRY(stx_set_device(b->ctx));
     const StxMbImage* src = nullptr;
     for (const StxMbImage& im : b->images) if (im.kind == 0 && im.order == order) src = &im;
@@ -1144,6 +1149,7 @@ STX_EXPORT int stx_blend_feed_contrib(stx_blender* b, int order, const int rect_
     if (!b || !rect_xywh || !packed) return stx_fail(STX_ERR_INVALID, "null argument");
     if (b->kind != STX_BLEND_MULTIBAND) return stx_fail(STX_ERR_UNSUPPORTED, "multi-band blender only");
     if (b->finished) return stx_fail(STX_ERR_STATE, "feed after blend()");
+    if (!b->ctx) return stx_fail(STX_ERR_STATE, "geometry-only blender (created without a context)");
     const int nb = b->num_bands, al = (1 << nb) - 1;
     const int x = rect_xywh[0], y = rect_xywh[1], w = rect_xywh[2], h = rect_xywh[3];
     if (w <= 0 || h <= 0 || ((x | y | w | h) & al) || x < 0 || y < 0 || x + w > b->rw || y + h > b->rh)
@@ -1173,6 +1179,7 @@ STX_EXPORT int stx_blend_finish_ex(stx_blender* b, stx_buf** out_pano_u8, stx_bu
 {
     if (!b) return stx_fail(STX_ERR_INVALID, "null argument");
     if (b->finished) return stx_fail(STX_ERR_STATE, "blend() was already called on this blender");
+    if (!b->ctx) return stx_fail(STX_ERR_STATE, "geometry-only blender (created without a context)");
     STX_TRY(stx_set_device(b->ctx));
     stx_ctx* ctx = b->ctx;
     const int ow = b->kind == STX_BLEND_MULTIBAND ? b->band_x1 - b->band_x0 : b->rw, oh = b->kind == STX_BLEND_MULTIBAND ? b->fh : b->rh;
@@ -1213,8 +1220,10 @@ STX_EXPORT int stx_blend_finish(stx_blender* b, stx_buf** out_pano_u8, stx_buf**
 STX_EXPORT int stx_blend_destroy(stx_blender* b)
 {
     if (!b) return STX_OK;
-    hipSetDevice(b->ctx->device);
-    blender_release(b);
+    if (b->ctx) {
+        hipSetDevice(b->ctx->device);
+        blender_release(b);
+    }
     delete b;
     return STX_OK;
 }

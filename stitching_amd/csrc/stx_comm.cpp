@@ -1,0 +1,134 @@
+// stx_comm.cpp — RCCL point-to-point exchange of contribution strips over xGMI.
+// librccl is loaded lazily (dlopen) by stx_comm_unique_id / stx_comm_create: single-GPU users never
+// touch it.  All sends and receives of one exchange are issued as ONE RCCL group on the context's
+// HIP stream, i.e. ordered after the kernels that produced the strips and before the gather kernels
+// that consume them — no host synchronisation in between.
+#include <dlfcn.h>
+
+#include <cstring>
+
+#include "stx_internal.h"
+
+namespace {
+
+typedef struct { char internal[128]; } RcclUniqueId;  // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
+typedef void* RcclComm;
+enum { RCCL_UINT8 = 1 };  // ncclUint8
+
+struct RcclApi {
+    void* handle = nullptr;
+    int (*GetUniqueId)(RcclUniqueId*) = nullptr;
+    int (*CommInitRank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(RcclComm) = nullptr;
+    int (*Send)(const void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+
+int load_rccl()
+{
+    if (g_rccl.handle) return STX_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return stx_fail(STX_ERR_UNSUPPORTED, "cannot load librccl: %s", dlerror());
+    RcclApi a;
+    a.handle = h;
+#define SYM(field, name)                                                                     \
+    *(void**)(&a.field) = dlsym(h, name);                                                    \
+    if (!a.field) return stx_fail(STX_ERR_UNSUPPORTED, "librccl lacks the symbol %s", name);
+    SYM(GetUniqueId, "ncclGetUniqueId")
+    SYM(CommInitRank, "ncclCommInitRank")
+    SYM(CommDestroy, "ncclCommDestroy")
+    SYM(Send, "ncclSend")
+    SYM(Recv, "ncclRecv")
+    SYM(GroupStart, "ncclGroupStart")
+    SYM(GroupEnd, "ncclGroupEnd")
+    SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    g_rccl = a;
+    return STX_OK;
+}
+
+#define STX_RCCL(call)                                                                                   \
+    do {                                                                                                 \
+        int r_ = (call);                                                                                 \
+        if (r_ != 0) return stx_fail(STX_ERR_HIP, "%s failed: %s", #call, g_rccl.GetErrorString(r_));    \
+    } while (0)
+
+}  // namespace
+
+struct stx_comm {
+    stx_ctx* ctx;
+    RcclComm comm;
+    int nranks, rank;
+};
+
+STX_EXPORT int stx_comm_unique_id(unsigned char out[128])
+{
+    if (!out) return stx_fail(STX_ERR_INVALID, "null argument");
+    STX_TRY(load_rccl());
+    RcclUniqueId id;
+    STX_RCCL(g_rccl.GetUniqueId(&id));
+    memcpy(out, id.internal, 128);
+    return STX_OK;
+}
+
+STX_EXPORT int stx_comm_create(stx_ctx* ctx, int nranks, int rank, const unsigned char id[128], stx_comm** out)
+{
+    if (!ctx || !id || !out) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return stx_fail(STX_ERR_INVALID, "rank %d of %d", rank, nranks);
+    STX_TRY(load_rccl());
+    STX_TRY(stx_set_device(ctx));
+    RcclUniqueId uid;
+    memcpy(uid.internal, id, 128);
+    RcclComm c = nullptr;
+    STX_RCCL(g_rccl.CommInitRank(&c, nranks, uid, rank));
+    stx_comm* k = new stx_comm();
+    k->ctx = ctx; k->comm = c; k->nranks = nranks; k->rank = rank;
+    *out = k;
+    return STX_OK;
+}
+
+STX_EXPORT int stx_comm_exchange(stx_comm* comm, int n_ops, const int* peers, const int* is_send, void* const* dev_ptrs,
+                                 const size_t* bytes)
+{
+    if (!comm || n_ops < 0 || (n_ops && (!peers || !is_send || !dev_ptrs || !bytes)))
+        return stx_fail(STX_ERR_INVALID, "bad argument");
+    if (n_ops == 0) return STX_OK;
+    STX_TRY(stx_set_device(comm->ctx));
+    for (int i = 0; i < n_ops; i++)
+        if (peers[i] < 0 || peers[i] >= comm->nranks || !dev_ptrs[i])
+            return stx_fail(STX_ERR_INVALID, "exchange op %d: peer %d / null buffer", i, peers[i]);
+    StxProfScope prof(comm->ctx, "rccl_exchange", 0.0);
+    STX_RCCL(g_rccl.GroupStart());
+    for (int i = 0; i < n_ops; i++) {
+        int r = is_send[i] ? g_rccl.Send(dev_ptrs[i], bytes[i], RCCL_UINT8, peers[i], comm->comm, comm->ctx->stream)
+                           : g_rccl.Recv(dev_ptrs[i], bytes[i], RCCL_UINT8, peers[i], comm->comm, comm->ctx->stream);
+        if (r != 0) {
+            g_rccl.GroupEnd();
+            return stx_fail(STX_ERR_HIP, "rccl %s to/from rank %d failed: %s", is_send[i] ? "send" : "recv", peers[i],
+                            g_rccl.GetErrorString(r));
+        }
+    }
+    STX_RCCL(g_rccl.GroupEnd());
+    return STX_OK;
+}
+
+STX_EXPORT int stx_comm_destroy(stx_comm* comm)
+{
+    if (!comm) return STX_OK;
+    if (g_rccl.handle && comm->comm) {
+        hipSetDevice(comm->ctx->device);
+        hipStreamSynchronize(comm->ctx->stream);
+        g_rccl.CommDestroy(comm->comm);
+    }
+    delete comm;
+    return STX_OK;
+}

@@ -1,0 +1,397 @@
+"""Sharded warp -> blend over the GPUs of one node (one process per GPU).
+
+The reference has no counterpart (single process, stitching/stitcher.py:247-254); this is the
+MI355X-first design of SURVEY.md §8(e) / DESIGN.md §6:
+
+  * images are dealt to ranks as contiguous runs (ring panoramas: contiguous yaw);
+  * rank g owns the panorama columns [b_g, b_{g+1}) (edges on multiples of max(8, 2^bands));
+  * every rank warps and builds pyramids for ITS images only;
+  * an image whose 2^bands-aligned feed rectangle reaches another rank's columns sends that rank a
+    CONTRIBUTION strip: per level the products (short)(L*W) and the weights W.  This is the only
+    data-path communication — point-to-point over xGMI (RCCL send/recv on the compute stream), a
+    few tens of MB per neighbour, never an all-reduce of the panorama pyramid;
+  * the receiver adds contributions in global feed order, so the assembled panorama is
+    bit-identical to the single-GPU result.
+
+`ShardPlan` is pure geometry (every rank computes the same plan from the global camera list);
+`ShardedStitchJob` runs one rank; transports move packed contribution buffers:
+`RcclTransport` (C ABI -> librccl), `GlooHostTransport` (host-staged, for tests / 1-GPU boxes).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, config
+from .blender import Blender, _BlenderHandle
+from .device import DeviceImage, as_device, get_context
+from .stitching_error import StitchingError
+from .synthetic import blend_strength_for_bands
+from .warper import Warper
+
+
+# ------------------------------------------------------------------------------------ blender handle
+class ShardBlender(_BlenderHandle):
+    """stx_blender with the sharding entry points of include/stitching_amd.h."""
+
+    def set_band(self, x0, x1):
+        _lib.check(self.ctx._lib.stx_blend_set_band(self._h, int(x0), int(x1)))
+
+    def feed_ex(self, img, mask, corner, order):
+        _lib.check(self.ctx._lib.stx_blend_feed_ex(self._h, img._h, mask._h, int(corner[0]), int(corner[1]), int(order)))
+
+    def contrib_rect(self, size, corner, band):
+        rect, nbytes = (C.c_int * 4)(), C.c_size_t()
+        _lib.check(self.ctx._lib.stx_blend_contrib_rect(self._h, int(size[0]), int(size[1]), int(corner[0]),
+                                                        int(corner[1]), int(band[0]), int(band[1]), rect,
+                                                        C.byref(nbytes)))
+        return tuple(int(v) for v in rect), int(nbytes.value)
+
+    def export_contrib(self, order, band):
+        out, rect = C.c_void_p(), (C.c_int * 4)()
+        _lib.check(self.ctx._lib.stx_blend_export_contrib(self._h, int(order), int(band[0]), int(band[1]), C.byref(out),
+                                                          rect))
+        return DeviceImage(self.ctx, out), tuple(int(v) for v in rect)
+
+    def feed_contrib(self, order, rect, packed):
+        r = (C.c_int * 4)(*[int(v) for v in rect])
+        _lib.check(self.ctx._lib.stx_blend_feed_contrib(self._h, int(order), r, packed._h))
+
+
+class GeometryContext:
+    """Stands in for a device context when only the plan (band count, feed / contribution
+    rectangles) is needed: blenders created on it cannot be fed."""
+
+    handle = None
+    device = -1
+
+    def __init__(self):
+        self._lib = _lib.lib()
+
+
+def make_shard_blender(ctx, roi, num_bands):
+    return ShardBlender(ctx or GeometryContext(), _lib.BLEND_MULTIBAND, num_bands, 0.0, roi)
+
+
+# ------------------------------------------------------------------------------------ plan (geometry)
+def owners_contiguous(n_images, world):
+    """image k -> rank; contiguous runs, sizes differ by at most one."""
+    base, extra = divmod(n_images, world)
+    out = []
+    for r in range(world):
+        out += [r] * (base + (1 if r < extra else 0))
+    return out
+
+
+def band_edges(corners, sizes, owners, world, roi, num_bands):
+    """Column bands [b_g, b_{g+1}) of the final roi, one per rank: the edge between two ranks sits
+    midway between the centres of their images, snapped down to a multiple of max(8, 2^bands)."""
+    align = max(8, 1 << num_bands)
+    fw = roi[2]
+    cx = [c[0] - roi[0] + s[0] / 2.0 for c, s in zip(corners, sizes)]
+    means = []
+    for g in range(world):
+        mine = [cx[k] for k in range(len(cx)) if owners[k] == g]
+        means.append(sum(mine) / len(mine) if mine else None)
+    edges = [0]
+    monotone = all(m is not None for m in means) and all(means[g] < means[g + 1] for g in range(world - 1))
+    for g in range(1, world):
+        if monotone:
+            right_of_prev = max(cx[k] for k in range(len(cx)) if owners[k] == g - 1)
+            left_of_next = min(cx[k] for k in range(len(cx)) if owners[k] == g)
+            e = 0.5 * (right_of_prev + left_of_next)
+        else:
+            e = fw * g / world
+        e = int(e) // align * align
+        e = min(max(e, edges[-1] + align), fw - align * (world - g))
+        edges.append(e)
+    edges.append(fw)
+    if any(edges[i + 1] <= edges[i] for i in range(world)):
+        raise StitchingError(f"panorama of width {fw} is too narrow for {world} bands of >= {align} columns")
+    return edges
+
+
+class ShardPlan:
+    """Who owns which columns and which contribution strips travel where.  Pure geometry: built from
+    the global corner/size lists, identical on every rank."""
+
+    def __init__(self, corners, warped_sizes, owners, world, blender_probe):
+        self.corners = [tuple(int(v) for v in c) for c in corners]
+        self.sizes = [tuple(int(v) for v in s) for s in warped_sizes]
+        self.owners = list(owners)
+        self.world = int(world)
+        self.roi = Blender.result_roi(self.corners, self.sizes)
+        self.num_bands = blender_probe.num_bands()
+        self.edges = band_edges(self.corners, self.sizes, self.owners, self.world, self.roi, self.num_bands)
+        # messages: (order k, src rank, dst rank, rect, bytes), sorted by (dst, k) so that every
+        # rank posts sends / receives in one global order
+        self.messages = []
+        for k, (c, s) in enumerate(zip(self.corners, self.sizes)):
+            for g in range(self.world):
+                if g == self.owners[k]:
+                    continue
+                rect, nbytes = blender_probe.contrib_rect(s, c, self.band(g))
+                if rect[2] > 0:
+                    self.messages.append((k, self.owners[k], g, rect, nbytes))
+        self.messages.sort(key=lambda m: (m[2], m[0]))
+
+    def band(self, g):
+        return (self.edges[g], self.edges[g + 1])
+
+    def sends(self, rank):
+        return [m for m in self.messages if m[1] == rank]
+
+    def recvs(self, rank):
+        return [m for m in self.messages if m[2] == rank]
+
+    def exchanged_bytes(self):
+        return sum(m[4] for m in self.messages)
+
+
+# ------------------------------------------------------------------------------------ transports
+class GlooHostTransport:
+    """Host-staged exchange over torch.distributed (gloo): device -> host -> peer -> device.
+    Works with several ranks on ONE GPU and on CPU-only rendezvous; used by the tests and as the
+    fallback when RCCL cannot initialise."""
+
+    name = "gloo-host"
+
+    def __init__(self, dist, ctx):
+        self.dist, self.ctx = dist, ctx
+
+    def exchange(self, sends, recvs):
+        """sends: [(dst, DeviceImage packed, nbytes)], recvs: [(src, nbytes)] -> [DeviceImage]"""
+        import torch
+
+        reqs, keep, rbufs = [], [], []
+        for src, nbytes in recvs:
+            t = torch.empty(nbytes, dtype=torch.uint8)
+            rbufs.append(t)
+            reqs.append(self.dist.irecv(t, src=src))
+        for dst, packed, nbytes in sends:
+            host = np.asarray(packed).reshape(-1)[:nbytes]
+            t = torch.from_numpy(np.ascontiguousarray(host))
+            keep.append(t)
+            reqs.append(self.dist.isend(t, dst=dst))
+        for r in reqs:
+            r.wait()
+        return [flat_device_buffer(self.ctx, t.numpy()) for t in rbufs]
+
+
+def flat_device_buffer(ctx, host_bytes):
+    """1-D uint8 host array -> flat device buffer with the geometry stx_blend_export_contrib uses."""
+    n = int(host_bytes.size)
+    w = min(n, 1 << 30)
+    h = (n + (1 << 30) - 1) >> 30
+    if h != 1:
+        raise StitchingError("contribution larger than 1 GiB is not supported by the host-staged transport")
+    return DeviceImage.from_numpy(host_bytes.reshape(1, w), ctx)
+
+
+class RcclTransport:
+    """RCCL send/recv of the packed contribution buffers on the context's HIP stream
+    (stx_comm_* in include/stitching_amd.h).  The unique id is distributed by the caller's
+    control-plane (torch.distributed gloo broadcast in bench.py)."""
+
+    name = "rccl"
+
+    def __init__(self, ctx, rank, world, unique_id):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        h = C.c_void_p()
+        uid = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        _lib.check(ctx._lib.stx_comm_create(ctx.handle, int(world), int(rank), uid, C.byref(h)))
+        self._h = h
+
+    @staticmethod
+    def unique_id():
+        uid = (C.c_ubyte * 128)()
+        _lib.check(_lib.lib().stx_comm_unique_id(uid))
+        return bytes(uid)
+
+    def exchange(self, sends, recvs):
+        lib = self.ctx._lib
+        rbufs = []
+        n = len(sends) + len(recvs)
+        peers, is_send = (C.c_int * n)(), (C.c_int * n)()
+        ptrs, sizes = (C.c_void_p * n)(), (C.c_size_t * n)()
+        i = 0
+        for src, nbytes in recvs:
+            out = C.c_void_p()
+            _lib.check(lib.stx_buf_alloc(self.ctx.handle, min(nbytes, 1 << 30), (nbytes + (1 << 30) - 1) >> 30, 1, _lib.U8,
+                                         C.byref(out)))
+            buf = DeviceImage(self.ctx, out)
+            rbufs.append(buf)
+            peers[i], is_send[i], ptrs[i], sizes[i] = src, 0, buf.device_ptr(), nbytes
+            i += 1
+        for dst, packed, nbytes in sends:
+            peers[i], is_send[i], ptrs[i], sizes[i] = dst, 1, packed.device_ptr(), nbytes
+            i += 1
+        if n:
+            _lib.check(lib.stx_comm_exchange(self._h, n, peers, is_send, ptrs, sizes))
+        return rbufs
+
+    def close(self):
+        if self._h is not None:
+            self.ctx._lib.stx_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------ one rank
+class ShardedStitchJob:
+    """One rank of a sharded panorama: device-resident local frames + the global camera list."""
+
+    def __init__(self, frames, cameras, all_cameras, rank, world, all_sizes=None, warper_type="spherical",
+                 blender_type="multiband", num_bands=5, blend_strength=None, ctx=None, dist=None, transport=None):
+        if blender_type != "multiband":
+            raise StitchingError("sharded blending is implemented for the multi-band blender")
+        self.ctx = ctx or get_context()
+        self.rank, self.world = int(rank), int(world)
+        self.frames = [as_device(f, self.ctx) for f in frames]
+        self.cameras = list(cameras)
+        self.all_cameras = list(all_cameras)
+        n = len(self.all_cameras)
+        self.owners = owners_contiguous(n, self.world)
+        self.my_orders = [k for k in range(n) if self.owners[k] == self.rank]
+        if len(self.my_orders) != len(self.frames):
+            raise StitchingError(f"rank {rank} holds {len(self.frames)} frames but owns {len(self.my_orders)} images")
+        size0 = (self.frames[0].width, self.frames[0].height)
+        self.all_sizes = list(all_sizes) if all_sizes is not None else [size0] * n
+        self.warper = Warper(warper_type)
+        self.warper.set_scale(self.all_cameras)
+        self.num_bands_req, self.blend_strength = num_bands, blend_strength
+        self.dist = dist
+        self.transport = transport
+        self.plan_ = None
+
+    @property
+    def source_pixels(self):
+        return sum(f.width * f.height for f in self.frames)
+
+    def plan(self):
+        corners, wsizes = self.warper.warp_rois(self.all_sizes, self.all_cameras)
+        roi = Blender.result_roi(corners, wsizes)
+        if self.blend_strength is None:
+            self.blend_strength = blend_strength_for_bands(self.num_bands_req, roi[2], roi[3])
+        blend_width = np.sqrt(roi[2] * roi[3]) * self.blend_strength / 100
+        self.req_bands = int((np.log(blend_width) / np.log(2.0) - 1.0))
+        self.roi = roi
+        probe = make_shard_blender(self.ctx, roi, self.req_bands)
+        self.plan_ = ShardPlan(corners, wsizes, self.owners, self.world, probe)
+        self.last_num_bands = self.plan_.num_bands
+        if self.transport is None:
+            self.transport = default_transport(self.ctx, self.rank, self.world, self.dist)
+        return self.plan_
+
+    def run(self):
+        """warp + feed local images, exchange contribution strips, blend this rank's band.
+        Returns device-resident (band u8x3, band mask u8)."""
+        p = self.plan_ or self.plan()
+        prev = config.device_resident()
+        config.set_device_resident(True)
+        try:
+            blender = make_shard_blender(self.ctx, self.roi, self.req_bands)
+            blender.set_band(*p.band(self.rank))
+            for frame, cam, k in zip(self.frames, self.cameras, self.my_orders):
+                img, mask, roi = self.warper.warp_image_and_mask(frame, cam)
+                if roi[0:2] != p.corners[k]:
+                    raise StitchingError("warp roi changed between plan() and run()")
+                blender.feed_ex(img, mask, p.corners[k], k)
+            sends = []
+            for (k, _src, dst, rect, nbytes) in p.sends(self.rank):
+                packed, r = blender.export_contrib(k, p.band(dst))
+                if r != rect:
+                    raise StitchingError("contribution geometry differs from the plan")
+                sends.append((dst, packed, nbytes))
+            recv_msgs = p.recvs(self.rank)
+            rbufs = self.transport.exchange(sends, [(m[1], m[4]) for m in recv_msgs])
+            for m, buf in zip(recv_msgs, rbufs):
+                blender.feed_contrib(m[0], m[3], buf)
+            pano, mask = blender.blend()
+        finally:
+            config.set_device_resident(prev)
+        return pano, mask
+
+    def gather(self, pano, mask):
+        """Assemble the full panorama on rank 0 (host side, outside any timed region)."""
+        band, bmask = np.asarray(pano), np.asarray(mask)
+        if self.world == 1 or self.dist is None:
+            return band, bmask
+        parts = [None] * self.world if self.rank == 0 else None
+        self.dist.gather_object((band, bmask), parts, dst=0)
+        if self.rank != 0:
+            return None, None
+        return np.concatenate([p[0] for p in parts], axis=1), np.concatenate([p[1] for p in parts], axis=1)
+
+
+def default_transport(ctx, rank, world, dist):
+    """RCCL when it initialises on this node, else the host-staged gloo transport."""
+    if world == 1:
+        return _NullTransport()
+    if dist is None:
+        raise StitchingError("a torch.distributed process group (gloo) is needed for the control plane")
+    import os
+
+    want = os.environ.get("STITCHING_AMD_TRANSPORT", "rccl")
+    ok = 0
+    tr = None
+    if want == "rccl":
+        try:
+            uid = [RcclTransport.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            tr = RcclTransport(ctx, rank, world, uid[0])
+            ok = 1
+        except Exception as e:  # noqa: BLE001 - any failure -> agree on the fallback below
+            import sys
+
+            print(f"[stitching_amd] rank {rank}: RCCL transport unavailable ({e}); using host-staged gloo", file=sys.stderr)
+    import torch
+
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        return tr
+    if tr is not None:
+        tr.close()
+    return GlooHostTransport(dist, ctx)
+
+
+class _NullTransport:
+    name = "none"
+
+    def exchange(self, sends, recvs):
+        if sends or recvs:
+            raise StitchingError("no transport for a single-rank job")
+        return []
+
+
+# ------------------------------------------------------------------------------------ test helper
+def virtual_sharded_blend(ctx, warped, masks, corners, sizes, world, num_bands):
+    """All `world` ranks simulated in ONE process on one GPU: same kernels, same geometry, the
+    exchange is a pointer hand-over.  Returns (panorama, mask, plan) as numpy arrays."""
+    n = len(warped)
+    owners = owners_contiguous(n, world)
+    roi = Blender.result_roi(corners, sizes)
+    probe = make_shard_blender(ctx, roi, num_bands)
+    plan = ShardPlan(corners, sizes, owners, world, probe)
+    blenders = []
+    for g in range(world):
+        b = make_shard_blender(ctx, roi, num_bands)
+        b.set_band(*plan.band(g))
+        blenders.append(b)
+    d_imgs = [as_device(w, ctx) for w in warped]
+    d_masks = [as_device(m, ctx) for m in masks]
+    for k in range(n):
+        blenders[owners[k]].feed_ex(d_imgs[k], d_masks[k], plan.corners[k], k)
+    for (k, src, dst, rect, nbytes) in plan.messages:
+        packed, r = blenders[src].export_contrib(k, plan.band(dst))
+        assert r == rect, (r, rect)
+        blenders[dst].feed_contrib(k, rect, packed)
+    bands = [b.blend() for b in blenders]
+    pano = np.concatenate([np.asarray(p) for p, _ in bands], axis=1)
+    mask = np.concatenate([np.asarray(m) for _, m in bands], axis=1)
+    return pano, mask, plan
