@@ -160,21 +160,29 @@ class GlooHostTransport:
 
     def exchange(self, sends, recvs):
         """sends: [(dst, DeviceImage packed, nbytes)], recvs: [(src, nbytes)] -> [DeviceImage]"""
-        import torch
+        host_sends = [(dst, np.asarray(packed).reshape(-1)[:nbytes]) for dst, packed, nbytes in sends]
+        return [flat_device_buffer(self.ctx, a) for a in gloo_exchange_host(self.dist, host_sends, recvs)]
 
-        reqs, keep, rbufs = [], [], []
-        for src, nbytes in recvs:
-            t = torch.empty(nbytes, dtype=torch.uint8)
-            rbufs.append(t)
-            reqs.append(self.dist.irecv(t, src=src))
-        for dst, packed, nbytes in sends:
-            host = np.asarray(packed).reshape(-1)[:nbytes]
-            t = torch.from_numpy(np.ascontiguousarray(host))
-            keep.append(t)
-            reqs.append(self.dist.isend(t, dst=dst))
-        for r in reqs:
-            r.wait()
-        return [flat_device_buffer(self.ctx, t.numpy()) for t in rbufs]
+
+def gloo_exchange_host(dist, sends, recvs):
+    """Point-to-point exchange of byte strips over a torch.distributed (gloo) group.
+    sends: [(dst, 1-D uint8 array)], recvs: [(src, nbytes)] -> [1-D uint8 arrays] in `recvs` order.
+    Every rank lists its messages in the plan's global (dst, order) order, so the k-th message
+    between a pair of ranks is the same message on both sides."""
+    import torch
+
+    reqs, keep, rbufs = [], [], []
+    for src, nbytes in recvs:
+        t = torch.empty(nbytes, dtype=torch.uint8)
+        rbufs.append(t)
+        reqs.append(dist.irecv(t, src=src))
+    for dst, host in sends:
+        t = torch.from_numpy(np.ascontiguousarray(host))
+        keep.append(t)
+        reqs.append(dist.isend(t, dst=dst))
+    for r in reqs:
+        r.wait()
+    return [t.numpy() for t in rbufs]
 
 
 def flat_device_buffer(ctx, host_bytes):

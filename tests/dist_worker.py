@@ -1,0 +1,67 @@
+"""Worker of tests/test_distributed_cpu.py: one rank of a world_size-N gloo group on CPU.
+
+Exercises everything of the sharded path that does not need a GPU: the plan (pure geometry through
+the C ABI with a NULL context), its agreement across ranks, and the strip exchange protocol
+(message order, sizes, payload integrity) over torch.distributed point-to-point."""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def payload(k, src, dst, nbytes):
+    rng = np.random.default_rng(1000003 * k + 1009 * src + dst)
+    return rng.integers(0, 256, size=nbytes, dtype=np.uint8)
+
+
+def main():
+    import torch.distributed as dist
+
+    from stitching_amd import distributed as D
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    case = json.loads(os.environ["STX_TEST_CASE"])
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    corners, sizes, req_bands = case["corners"], case["sizes"], case["req_bands"]
+    roi = D.Blender.result_roi(corners, sizes)
+    probe = D.make_shard_blender(None, roi, req_bands)  # geometry only: no GPU, no context
+    plan = D.ShardPlan(corners, sizes, D.owners_contiguous(len(corners), world), world, probe)
+
+    # 1. every rank derives the same plan
+    sig = hashlib.sha256(json.dumps([plan.edges, plan.messages, plan.num_bands]).encode()).hexdigest()
+    sigs = [None] * world
+    dist.all_gather_object(sigs, sig)
+    assert len(set(sigs)) == 1, "ranks disagree on the shard plan"
+
+    # 2. bands tile the panorama on multiples of max(8, 2^B)
+    align = max(8, 1 << plan.num_bands)
+    assert plan.edges[0] == 0 and plan.edges[-1] == roi[2]
+    assert all(e % align == 0 for e in plan.edges[:-1]) and all(b > a for a, b in zip(plan.edges, plan.edges[1:]))
+
+    # 3. the exchange: the bytes each rank receives are the bytes the owner sent, in plan order
+    sends = [(m[2], payload(m[0], m[1], m[2], m[4])) for m in plan.sends(rank)]
+    recv_msgs = plan.recvs(rank)
+    got = D.gloo_exchange_host(dist, sends, [(m[1], m[4]) for m in recv_msgs])
+    for m, a in zip(recv_msgs, got):
+        assert a.size == m[4] and np.array_equal(a, payload(m[0], m[1], m[2], m[4])), f"strip {m[:3]} corrupted"
+
+    # 4. whole-job throughput accounting of bench.py: MAX over ranks of the elapsed time
+    import torch
+
+    t = torch.tensor([0.5 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert float(t.item()) == 0.5 + world - 1
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"ok": True, "messages": len(plan.messages), "bytes": plan.exchanged_bytes(),
+                          "edges": plan.edges, "bands": plan.num_bands}))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -180,3 +180,20 @@ def test_sharded_blend_equals_single_gpu(oracle, gpu_ctx, world, strength, n):
     assert np.array_equal(mask, o["pmask"])
     d = pano.astype(int) - o["pano"].astype(int)
     assert not d.any(), f"{np.count_nonzero(d)} bytes differ, max {np.abs(d).max()}, bands {plan.edges}"
+
+
+@pytest.mark.timeout(180)
+def test_rccl_transport_self_exchange(gpu_ctx):
+    """The RCCL strip transport (dlopen'd librccl, ncclSend/ncclRecv grouped on the ctx stream) on a
+    1-rank communicator: a strip sent to self arrives intact.  Multi-rank behaviour is the same code
+    path with peers != rank (8-GPU node only)."""
+    from stitching_amd.distributed import RcclTransport
+    from stitching_amd.device import DeviceImage
+
+    tr = RcclTransport(gpu_ctx, 0, 1, RcclTransport.unique_id())
+    rng = np.random.default_rng(7)
+    host = rng.integers(0, 256, size=(1, 1 << 20), dtype=np.uint8)
+    src = DeviceImage.from_numpy(host, gpu_ctx)
+    (dst,) = tr.exchange([(0, src, host.size)], [(0, host.size)])
+    assert np.array_equal(np.asarray(dst), host)
+    tr.close()
