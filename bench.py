@@ -42,8 +42,39 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-frames", type=int, default=8, help="frames in the CPU-baseline sample")
     p.add_argument("--profile-steps", type=int, default=3)
+    p.add_argument("--e2e-steps", type=int, default=2, help="PCIe-inclusive passes (host frames in, host panorama out)")
     p.add_argument("--traffic-json", default=None, help="optional JSON with PMC-derived HBM bytes per launch")
     return p.parse_args()
+
+
+def survey_8d_bytes(src_sizes, corners, wsizes, bands):
+    """Algorithmic HBM bytes of ONE pass by SURVEY.md §8(d)'s model (OpenCV's dataflow with the maps
+    never stored): warp 3 P_s + 4 P_w; feed 4 P_w + (12 h + 8 h + 20 g) P_f; finish (10 + 6 + 12) g P_d
+    + 4 P_d, with g = sum_{i<=B} 4^-i, h = g - 1, P_f the 2^B-aligned feed rectangles
+    (MultiBandBlender::feed geometry) and P_d the padded panorama.  DESIGN.md §5."""
+    g = sum(4.0 ** -i for i in range(bands + 1))
+    h = g - 1.0
+    x0 = min(c[0] for c in corners)
+    y0 = min(c[1] for c in corners)
+    x1 = max(c[0] + s[0] for c, s in zip(corners, wsizes))
+    y1 = max(c[1] + s[1] for c, s in zip(corners, wsizes))
+    al = 1 << bands
+    pw, ph = -(-(x1 - x0) // al) * al, -(-(y1 - y0) // al) * al
+    gap = 3 * al
+    p_s = sum(w * hh for w, hh in src_sizes)
+    p_w = sum(w * hh for w, hh in wsizes)
+    p_f = 0
+    for (cx, cy), (w, hh) in zip(corners, wsizes):
+        tx, ty = max(x0, cx - gap), max(y0, cy - gap)
+        bx, by = min(x0 + pw, cx + w + gap), min(y0 + ph, cy + hh + gap)
+        tx, ty = x0 + (tx - x0) // al * al, y0 + (ty - y0) // al * al
+        p_f += (-(-(bx - tx) // al) * al) * (-(-(by - ty) // al) * al)
+    p_d = pw * ph
+    warp = 3.0 * p_s + 4.0 * p_w
+    feed = 4.0 * p_w + (12.0 * h + 8.0 * h + 20.0 * g) * p_f
+    finish = (10.0 + 6.0 + 12.0) * g * p_d + 4.0 * p_d
+    return {"warp": warp, "feed": feed, "finish": finish, "total": warp + feed + finish, "P_s": p_s, "P_w": p_w,
+            "P_f": p_f, "P_d": p_d}
 
 
 def cpu_baseline(args, frames, cams, all_cams):
@@ -190,6 +221,25 @@ def main():
                         "algo_GBps": round(kbytes / max(ksum, 1e-9) / 1e6, 1),
                         "frac_of_hbm_peak": round(kbytes / max(ksum, 1e-9) / 1e6 / HBM_PEAK_GBS, 4)},
     }
+    if world == 1 and hasattr(job, "corners") and args.blender == "multiband":
+        m = survey_8d_bytes(job.sizes, job.corners, job.warped_sizes, job.last_num_bands)
+        gbps = m["total"] / (ms_per_step / 1e3) / 1e9
+        result["path_roofline"] = {
+            "model": "SURVEY.md 8(d): algorithmic bytes of the warp + blend path (OpenCV dataflow, maps not stored)",
+            "bytes_per_source_px": round(m["total"] / m["P_s"], 2), "bytes_per_step": round(m["total"]),
+            "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBS, 4),
+            "P_s": m["P_s"], "P_w": m["P_w"], "P_f": m["P_f"], "P_d": m["P_d"]}
+    if world == 1 and args.e2e_steps > 0:
+        # PCIe-inclusive rate (never `value`): host numpy frames in, host panorama out
+        from stitching_amd.pipeline import stitch
+
+        job.warper.set_scale(all_cams)
+        t1 = time.perf_counter()
+        for _ in range(args.e2e_steps):
+            stitch(frames, cams, warper_type=args.warper, blender_type=args.blender, num_bands=args.bands)
+        e2e = (time.perf_counter() - t1) / args.e2e_steps
+        result["pcie_inclusive"] = {"value": round(src_mpix / e2e, 1), "unit": "Mpix/s", "ms_per_step": round(e2e * 1e3, 2),
+                                    "note": "pageable numpy frames H2D + roi sync + panorama D2H every step; not `value`"}
     if world == 1 and not args.no_cpu_baseline:
         cb, _ = cpu_baseline(args, frames, cams, all_cams)
         result["cpu_baseline"] = cb

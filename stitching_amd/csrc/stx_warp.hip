@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void roi_kernel(const RoiK* __restrict__ Ps, u
 }
 
 template <int TYPE>
-int launch_typed(stx_ctx* ctx, const WarpK& K, bool img, bool mask, dim3 grid)
+int launch_typed(stx_ctx* ctx, const WarpK& K, bool img, bool mask, dim3 grid, const char* prof_name, double algo_bytes)
 {
     hipStream_t s = ctx->stream;
     // per-column / per-row trig tables (a few KB, L2 resident), freed in stream order
@@ -259,10 +259,16 @@ int launch_typed(stx_ctx* ctx, const WarpK& K, bool img, bool mask, dim3 grid)
     STX_TRY(stx_dev_alloc(ctx, (ncol + (size_t)K.dh) * sizeof(float2), &tab));
     float2* colT = (float2*)tab;
     float2* rowT = colT + ncol;
-    hipLaunchKernelGGL((warp_tables_kernel<TYPE>), dim3((K.dw + K.dh + 255) / 256), dim3(256), 0, s, K, colT, rowT);
-    if (img && mask) hipLaunchKernelGGL((warp_kernel<TYPE, true, true>), grid, dim3(256), 0, s, K, colT, rowT);
-    else if (img) hipLaunchKernelGGL((warp_kernel<TYPE, true, false>), grid, dim3(256), 0, s, K, colT, rowT);
-    else hipLaunchKernelGGL((warp_kernel<TYPE, false, true>), grid, dim3(256), 0, s, K, colT, rowT);
+    {
+        StxProfScope prof(ctx, "warp_tables", (double)(K.dw + K.dh) * sizeof(float2));
+        hipLaunchKernelGGL((warp_tables_kernel<TYPE>), dim3((K.dw + K.dh + 255) / 256), dim3(256), 0, s, K, colT, rowT);
+    }
+    {
+        StxProfScope prof(ctx, prof_name, algo_bytes);
+        if (img && mask) hipLaunchKernelGGL((warp_kernel<TYPE, true, true>), grid, dim3(256), 0, s, K, colT, rowT);
+        else if (img) hipLaunchKernelGGL((warp_kernel<TYPE, true, false>), grid, dim3(256), 0, s, K, colT, rowT);
+        else hipLaunchKernelGGL((warp_kernel<TYPE, false, true>), grid, dim3(256), 0, s, K, colT, rowT);
+    }
     stx_dev_free(ctx, tab);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return stx_fail(STX_ERR_HIP, "warp kernel launch failed: %s", hipGetErrorString(e));
@@ -289,12 +295,12 @@ int stx_launch_warp(stx_ctx* ctx, const StxWarpLaunch& L)
     dim3 grid((L.dw + WARP_TW - 1) / WARP_TW, (L.dh + WARP_TH - 1) / WARP_TH);
     // algorithmic bytes: read the source once, write the warped image + mask once
     double bytes = (img ? 3.0 * L.sw * L.sh + 3.0 * L.dw * L.dh : 0.0) + (mask ? 1.0 * L.dw * L.dh : 0.0);
-    StxProfScope prof(ctx, img ? (mask ? "warp_img_mask" : "warp_img") : "warp_mask", bytes);
+    const char* name = img ? (mask ? "warp_img_mask" : "warp_img") : "warp_mask";
     switch (L.proj.type) {
     case STX_WARP_PLANE:
-    case STX_WARP_AFFINE: return launch_typed<STX_WARP_PLANE>(ctx, K, img, mask, grid);
-    case STX_WARP_CYLINDRICAL: return launch_typed<STX_WARP_CYLINDRICAL>(ctx, K, img, mask, grid);
-    case STX_WARP_SPHERICAL: return launch_typed<STX_WARP_SPHERICAL>(ctx, K, img, mask, grid);
+    case STX_WARP_AFFINE: return launch_typed<STX_WARP_PLANE>(ctx, K, img, mask, grid, name, bytes);
+    case STX_WARP_CYLINDRICAL: return launch_typed<STX_WARP_CYLINDRICAL>(ctx, K, img, mask, grid, name, bytes);
+    case STX_WARP_SPHERICAL: return launch_typed<STX_WARP_SPHERICAL>(ctx, K, img, mask, grid, name, bytes);
     }
     return stx_fail(STX_ERR_UNSUPPORTED, "warp type %d not implemented", L.proj.type);
 }
