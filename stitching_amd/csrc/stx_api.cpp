@@ -328,6 +328,16 @@ STX_EXPORT int stx_buf_from_host(stx_ctx* ctx, const void* host, size_t host_str
         stx_buf_release(b);
         return stx_fail(STX_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
     }
+    if (channels == 1 && elem == STX_U8) {  // masks: remember whether every byte is 0 or 255 (packed blend kernels)
+        bool binary = true;
+        for (int y = 0; y < h && binary; y++) {
+            const uint8_t* r = (const uint8_t*)host + (size_t)y * host_stride;
+            unsigned bad = 0;
+            for (int x = 0; x < w; x++) bad |= (unsigned)((r[x] + 1) & 0xfe);  // 0 -> 0, 255 -> 0, else nonzero
+            binary = bad == 0;
+        }
+        b->mask_binary = binary ? 1 : 0;
+    }
     *out = b;
     return STX_OK;
 }
@@ -357,6 +367,7 @@ STX_EXPORT int stx_buf_view(const stx_buf* buf, int x, int y, int w, int h, stx_
     v->w = w; v->h = h; v->c = buf->c; v->elem = buf->elem;
     v->stride = buf->stride;
     v->parent = root;
+    v->mask_binary = buf->mask_binary;
     stx_buf_retain(root);
     *out = v;
     return STX_OK;
@@ -659,6 +670,7 @@ static int warp_impl(stx_ctx* ctx, int type, float scale, const float* K, const 
     }
     int rc = stx_launch_warp(ctx, L);
     if (rc != STX_OK) { stx_buf_release(bi); stx_buf_release(bm); return rc; }
+    if (bm) bm->mask_binary = 1;  // remapNearest of a 255-filled source with a constant-0 border
     if (out_img) *out_img = bi;
     if (out_mask) *out_mask = bm;
     if (out_xywh) memcpy(out_xywh, roi, 16);
@@ -903,7 +915,7 @@ static int mb_feed(stx_blender* b, const stx_buf* img, const stx_buf* mask, int 
     im.order = order;
     mb_feed_rect(b, w, h, tlx, tly, &im.fx, &im.fy, &im.fw, &im.fh);
     im.img0 = img->ptr; im.img0_stride = (long long)img->stride; im.img0_is_s16 = img->elem == STX_S16;
-    im.mask0 = mask->ptr; im.mask0_stride = (long long)mask->stride;
+    im.mask0 = mask->ptr; im.mask0_stride = (long long)mask->stride; im.mask_binary = mask->mask_binary;
     im.iw = w; im.ih = h;
     im.ix = tlx - b->rx; im.iy = tly - b->ry;
     im.left = im.ix - im.fx; im.top = im.iy - im.fy;
@@ -1027,10 +1039,11 @@ static int mb_finish(stx_blender* b, stx_buf* pano, stx_buf* pmask, stx_buf* pan
     STX_TRY(mb_ensure_pyramids(b));
     StxMbImage* d_images = nullptr;
     STX_TRY(mb_upload(b, b->images.data(), n, &d_images));
-    bool all_u8 = true, has_contrib = false;
+    bool all_u8 = true, has_contrib = false, pk_ok = true;
     for (const StxMbImage& im : b->images) {
         if (im.kind == 0 && im.img0_is_s16) all_u8 = false;
         if (im.kind == 1) has_contrib = true;
+        if (im.kind != 0 || im.img0_is_s16 || !im.mask_binary) pk_ok = false;
     }
     int xb[STX_MAX_BANDS + 1], xe[STX_MAX_BANDS + 1];
     mb_level_regions(b, b->band_x0, b->band_x1, xb, xe);
@@ -1041,6 +1054,7 @@ static int mb_finish(stx_blender* b, stx_buf* pano, stx_buf* pmask, stx_buf* pan
         mb_fill_common(b, &K, d_images, n, lv);
         K.all_u8 = all_u8 ? 1 : 0;
         K.has_contrib = has_contrib ? 1 : 0;
+        K.pk_ok = pk_ok ? 1 : 0;
         K.x0 = xb[lv]; K.x1 = xe[lv]; K.y0 = 0; K.y1 = lv == 0 ? b->fh : b->rh >> lv;
         if (lv < nb) {
             K.up = out[lv + 1]; K.up_stride = ostride[lv + 1]; K.up_plane = oplane[lv + 1];

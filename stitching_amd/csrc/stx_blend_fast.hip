@@ -25,6 +25,17 @@ constexpr float WEIGHT_EPS = 1e-5f;
 constexpr float INV255 = 0.0039215688593685627f;  // (float)(1./255.)
 constexpr float INV256 = 0.00390625f;
 
+// Pointers read from a descriptor in memory are generic ("flat") to the compiler; all of ours are device
+// global memory.  Saying so gives global_load with an SGPR base + 32-bit lane offset instead of flat_load
+// with 64-bit lane address arithmetic (and keeps lgkmcnt free for scalar / LDS traffic).
+#define STX_GAS __attribute__((address_space(1)))
+template <class T> STX_DEV const STX_GAS T* gp(const T* p) { return (const STX_GAS T*)p; }
+template <class T> STX_DEV STX_GAS T* gp(T* p) { return (STX_GAS T*)p; }
+
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef v4u __attribute__((aligned(4))) v4u_a4;  // 16 bytes, only dword-aligned
+
 struct __attribute__((aligned(4))) U4a4 { uint32_t v[4]; };  // 16 bytes, only dword-aligned
 struct __attribute__((aligned(4))) U2a4 { uint32_t v[2]; };
 
@@ -40,15 +51,17 @@ STX_DEV float h5f(float s0, float s1, float s2, float s3, float s4)
 STX_DEV int h5i(int s0, int s1, int s2, int s3, int s4) { return s2 * 6 + (s1 + s3) * 4 + s0 + s4; }
 
 // ---------------------------------------------------------------------------------------------
-// pyrDown through LDS.  Workgroup = 64 x 16 outputs.
-//   phase 1: the 35 input rows the tile needs are streamed from HBM with 16-byte loads; each lane
+// pyrDown through LDS.  Workgroup = 64 x 14 outputs.
+//   phase 1: the 31 input rows the tile needs are streamed from HBM with 16-byte loads; each lane
 //            filters horizontally (1-4-6-4-1, stride 2) as it loads and parks the row sums in LDS
 //            (the 5-tap stencil is staged in LDS, never re-read from memory);
 //   phase 2: vertical 1-4-6-4-1 from LDS, (v + 128) >> 8, packed stores.
 // copyMakeBorder (REFLECT image / CONSTANT weight) and pyrDown's REFLECT_101 are index maps that
 // only the lanes at a border evaluate (per-wavefront slow path); interior lanes take vector loads.
 // ---------------------------------------------------------------------------------------------
-constexpr int DN_TOW = 64, DN_TOH = 16, DN_ROWS = 2 * DN_TOH + 3;
+// 64 x 14 outputs: the 31 input rows give 31*8 = 248 (levels >= 1) / 31*16 = 496 (level 0) load tasks, i.e. one /
+// two full passes of the 256 threads (16 rows would leave a third, 9 %-full pass)
+constexpr int DN_TOW = 64, DN_TOH = 14, DN_ROWS = 2 * DN_TOH + 3;
 
 // level 0 (u8 BGR + u8 mask): 4 outputs from 11 input pixels
 STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, short* hs1, short* hs2, float* hw)
@@ -141,7 +154,7 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
         const int yl = 2 * rg + rr, y = Y0 + yl;
-        if (y >= oh) break;
+        if (yl >= DN_TOH || y >= oh) break;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             int a[5], b[5];
@@ -259,7 +272,7 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
         const int yl = 2 * rg + rr, y = Y0 + yl;
-        if (y >= oh) break;
+        if (yl >= DN_TOH || y >= oh) break;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             int a[5], b[5];
@@ -343,6 +356,91 @@ STX_DEV void up_patch(const short* __restrict__ plane, long long stride, int cw,
         up[0][2 * j + 1] = s6(ho[0][j] + 6 * ho[1][j] + ho[2][j]);
         up[1][2 * j] = s6(4 * (he[1][j] + he[2][j]));
         up[1][2 * j + 1] = s6(4 * (ho[1][j] + ho[2][j]));
+    }
+}
+
+// normalizeUsingWeightMap, + pyrUp(finished coarser level) saturating, store (level >= 1: planar int16;
+// level 0: u8 panorama via convertScaleAbs, mask = weight > eps, optional int16 result)
+template <bool L0>
+STX_DEV void level_epilogue(const MbLevelK& P, int X0, int Y0, int (&acc)[2][8][3], float (&ws)[2][8])
+{
+    // normalizeUsingWeightMap, then + pyrUp(finished coarser level), saturating
+    int v[2][8][3];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float den = fadd(ws[r][j], WEIGHT_EPS);
+            float q0, q1, q2;
+            div3_shared(den, (float)(short)acc[r][j][0], (float)(short)acc[r][j][1], (float)(short)acc[r][j][2], q0, q1, q2);
+            v[r][j][0] = trunc_small(q0);
+            v[r][j][1] = trunc_small(q1);
+            v[r][j][2] = trunc_small(q2);
+        }
+    if (P.up) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            int up[2][8];
+            up_patch(P.up + c * P.up_plane - ((long long)P.up_y0 * P.up_stride + P.up_x0), P.up_stride, P.pw >> 1, P.ph >> 1,
+                     X0 >> 1, Y0 >> 1, up);
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[r][j][c] = sat_s16(up[r][j] + v[r][j][c]);
+        }
+    }
+    if (!L0) {
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                uint4 o;
+                o.x = pack16(v[r][0][c], v[r][1][c]);
+                o.y = pack16(v[r][2][c], v[r][3][c]);
+                o.z = pack16(v[r][4][c], v[r][5][c]);
+                o.w = pack16(v[r][6][c], v[r][7][c]);
+                if (Y0 + r < P.y1)
+                    *reinterpret_cast<uint4*>(P.out + c * P.out_plane + (long long)(Y0 + r - P.out_y0) * P.out_stride + (X0 - P.out_x0)) = o;
+            }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int y = Y0 + r;
+            if (y >= P.y1) break;
+            const int oy = y - P.pano_y0, ox = X0 - P.pano_x0;
+            uint32_t ob[6] = {0, 0, 0, 0, 0, 0}, om[2] = {0, 0};
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const bool keep = ws[r][j] > WEIGHT_EPS;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    if (!keep) v[r][j][c] = 0;
+                    const uint32_t u = (uint32_t)min(abs(v[r][j][c]), 255);  // convertScaleAbs
+                    const int bo = 3 * j + c;
+                    ob[bo >> 2] |= u << (8 * (bo & 3));
+                }
+                om[j >> 2] |= (keep ? 255u : 0u) << (8 * (j & 3));
+            }
+            uint32_t* po = reinterpret_cast<uint32_t*>(P.pano + (long long)oy * P.pano_stride + (long long)ox * 3);
+            *reinterpret_cast<uint2*>(po) = make_uint2(ob[0], ob[1]);
+            *reinterpret_cast<uint2*>(po + 2) = make_uint2(ob[2], ob[3]);
+            *reinterpret_cast<uint2*>(po + 4) = make_uint2(ob[4], ob[5]);
+            *reinterpret_cast<uint2*>(P.pmask + (long long)oy * P.pmask_stride + ox) = make_uint2(om[0], om[1]);
+            if (P.pano16) {
+                uint32_t* p16 = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(P.pano16) + (long long)oy * P.pano16_stride +
+                                                            (long long)ox * 6);
+                uint32_t s[12];
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {  // 2 pixels = 6 shorts = 3 dwords
+                    s[(j >> 1) * 3 + 0] = pack16(v[r][j][0], v[r][j][1]);
+                    s[(j >> 1) * 3 + 1] = pack16(v[r][j][2], v[r][j + 1][0]);
+                    s[(j >> 1) * 3 + 2] = pack16(v[r][j + 1][1], v[r][j + 1][2]);
+                }
+                *reinterpret_cast<uint4*>(p16) = make_uint4(s[0], s[1], s[2], s[3]);
+                *reinterpret_cast<uint4*>(p16 + 4) = make_uint4(s[4], s[5], s[6], s[7]);
+                *reinterpret_cast<uint4*>(p16 + 8) = make_uint4(s[8], s[9], s[10], s[11]);
+            }
+        }
     }
 }
 
@@ -525,84 +623,208 @@ __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
         return;
     }
 
-    // normalizeUsingWeightMap, then + pyrUp(finished coarser level), saturating
-    int v[2][8][3];
+    level_epilogue<L0>(P, X0, Y0, acc, ws);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Packed 16-bit level-0 gather for the reference's actual operating point: every fed image is u8
+// (stitching/blender.py:41 widens u8 warps to int16, so all values are 0..255) and every mask is
+// binary 0/255 (warped masks, seam masks).  Then
+//   * G_1 is 0..255, so pyrUp's sums (<= 64*255) fit unsigned 16-bit lanes: two pixels per VALU op;
+//   * W_0 is exactly 0.f or 1.f (255 * (float)(1/255.) rounds to 1.f), so (short)(L * W) is L or 0:
+//     the product / truncation become a bitwise AND, and the fp32 weight sum is an exact count.
+// Pixel pairs inside a lane's 8-pixel strip are kept in the order pyrUp produces them:
+//   pair 0 = (px0, px2), 1 = (px4, px6), 2 = (px1, px3), 3 = (px5, px7)   [lo half, hi half]
+// ---------------------------------------------------------------------------------------------
+typedef unsigned short pk16 __attribute__((ext_vector_type(2)));
+STX_DEV pk16 pk(uint32_t v) { return __builtin_bit_cast(pk16, v); }
+STX_DEV uint32_t unpk(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
+STX_DEV pk16 pk_splat(unsigned short v) { pk16 r = {v, v}; return r; }
+
+// pyrUp_<FixPtCast<short,6>> of one plane holding values 0..255 for the 8x2 patch with coarse origin (cx, cy)
+STX_DEV void up_patch_pk(const STX_GAS short* __restrict__ plane, uint32_t stride, int cw, int ch, int cx, int cy, pk16 up[2][4])
+{
+    const int rr[3] = {up_idx(cy - 1, ch), cy, up_idx(cy + 1, ch)};
+    const int cl = up_idx(cx - 1, cw), cr = up_idx(cx + 4, cw);
+    pk16 HE[3][2], HO[3][2];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const uint32_t ro = (uint32_t)rr[r] * stride;
+        const v2u v = *reinterpret_cast<const STX_GAS v2u*>(plane + (ro + (uint32_t)cx));  // (c1,c2) (c3,c4)
+        const uint32_t c0 = (uint32_t)(unsigned short)plane[ro + (uint32_t)cl], c5 = (uint32_t)(unsigned short)plane[ro + (uint32_t)cr];
+        const uint32_t B0 = v.x, B1 = v.y;
+        const uint32_t A0 = (B0 << 16) | c0;                          // (c0,c1)
+        const uint32_t A1 = __builtin_amdgcn_alignbit(B1, B0, 16);    // (c2,c3)
+        const uint32_t A2 = (B1 >> 16) | (c5 << 16);                  // (c4,c5)
+        HE[r][0] = pk(A0) + pk(B0) * pk_splat(6) + pk(A1);            // c[j] + 6 c[j+1] + c[j+2], j = 0,1
+        HE[r][1] = pk(A1) + pk(B1) * pk_splat(6) + pk(A2);            // j = 2,3
+        HO[r][0] = pk(B0) + pk(A1);                                   // c[j+1] + c[j+2] (the factor 4 is folded below)
+        HO[r][1] = pk(B1) + pk(A2);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        up[0][k] = (HE[0][k] + HE[1][k] * pk_splat(6) + HE[2][k] + pk_splat(32)) >> pk_splat(6);
+        up[0][2 + k] = (HO[0][k] + HO[1][k] * pk_splat(6) + HO[2][k] + pk_splat(8)) >> pk_splat(4);
+        up[1][k] = (HE[1][k] + HE[2][k] + pk_splat(8)) >> pk_splat(4);
+        up[1][2 + k] = (HO[1][k] + HO[2][k] + pk_splat(2)) >> pk_splat(2);
+    }
+}
+
+// bytes o1, o2 of the little-endian byte stream held in w[] -> (w[o1], 0, w[o2], 0)
+template <int O1, int O2>
+STX_DEV uint32_t pair_u8(const uint32_t* w)
+{
+    constexpr uint32_t sel = (uint32_t)(O1 & 3) | (0x0cu << 8) | ((uint32_t)(4 + (O2 & 3)) << 16) | (0x0cu << 24);
+    return __builtin_amdgcn_perm(w[O2 >> 2], w[O1 >> 2], sel);
+}
+// mask bytes a, b (0 or 255) of m[] -> (0xffff or 0, 0xffff or 0)
+template <int A, int B>
+STX_DEV uint32_t pair_mask(const uint32_t* m)
+{
+    constexpr uint32_t sel = (uint32_t)(A & 3) * 0x0101u | (uint32_t)(4 + (B & 3)) * 0x01010000u;
+    return __builtin_amdgcn_perm(m[B >> 2], m[A >> 2], sel);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void mb_level0_pk_kernel(MbLevelK P)
+{
+    __shared__ int s_list[64];
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+    const int tile_x = P.x0 + blockIdx.x * 512, tile_y = P.y0 + blockIdx.y * 8;
+    const int X0 = tile_x + (tid & 63) * 8, Y0 = tile_y + (tid >> 6) * 2;
+    const bool active = X0 < P.x1 && Y0 < P.y1;
+
+    uint32_t acc[2][3][4];  // [row][channel][pair]: int16 sums, wrap-around like OpenCV's short +=
+    uint32_t cnt[2][4];     // [row][pair]: number of images whose mask covers the pixel
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            acc[r][0][k] = acc[r][1][k] = acc[r][2][k] = 0;
+            cnt[r][k] = 0;
+        }
+
+    for (int base = 0; base < P.n_images; base += 64) {
+        __syncthreads();
+        if (tid < 64) {
+            const int k = base + tid;
+            bool hit = false;
+            if (k < P.n_images) {
+                const StxMbImage& im = P.images[k];
+                hit = im.ix < tile_x + 512 && im.ix + im.iw > tile_x && im.iy < tile_y + 8 && im.iy + im.ih > tile_y;
+            }
+            const unsigned long long m = __ballot(hit);
+            if (hit) s_list[__popcll(m & ((1ull << tid) - 1ull))] = k;
+            if (tid == 0) s_n = __popcll(m);
+        }
+        __syncthreads();
+        const int n_hit = s_n;
+        for (int i = 0; i < n_hit; i++) {
+            const int k = __builtin_amdgcn_readfirstlane(s_list[i]);
+            const StxMbImage& im = P.images[k];
+            if (!active) continue;
+            const int lx0 = X0 - im.ix, ly0 = Y0 - im.iy;
+            if (lx0 + 8 <= 0 || lx0 >= im.iw || ly0 + 2 <= 0 || ly0 >= im.ih) continue;
+            const bool fastx = lx0 >= 0 && lx0 + 8 <= im.iw;
+            uint32_t pw_[2][6], mw[2][2];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int ly = ly0 + r;
+#pragma unroll
+                for (int q = 0; q < 6; q++) pw_[r][q] = 0;
+                mw[r][0] = mw[r][1] = 0;
+                if ((unsigned)ly >= (unsigned)im.ih) continue;
+                if (fastx) {
+                    const uint32_t off = (uint32_t)ly * (uint32_t)im.img0_stride + (uint32_t)lx0 * 3u;
+                    const STX_GAS uint8_t* q = gp(im.img0) + (off & ~3u);
+                    const uint32_t s = off & 3u;
+                    const v4u d0 = *reinterpret_cast<const STX_GAS v4u_a4*>(q);
+                    const v4u d1 = *reinterpret_cast<const STX_GAS v4u_a4*>(q + 16);
+                    pw_[r][0] = __builtin_amdgcn_alignbyte(d0.y, d0.x, s);
+                    pw_[r][1] = __builtin_amdgcn_alignbyte(d0.z, d0.y, s);
+                    pw_[r][2] = __builtin_amdgcn_alignbyte(d0.w, d0.z, s);
+                    pw_[r][3] = __builtin_amdgcn_alignbyte(d1.x, d0.w, s);
+                    pw_[r][4] = __builtin_amdgcn_alignbyte(d1.y, d1.x, s);
+                    pw_[r][5] = __builtin_amdgcn_alignbyte(d1.z, d1.y, s);
+                    const uint32_t moff = (uint32_t)ly * (uint32_t)im.mask0_stride + (uint32_t)lx0;
+                    const STX_GAS uint8_t* mq = gp(im.mask0) + (moff & ~3u);
+                    const uint32_t ms = moff & 3u;
+                    const uint32_t m0 = *reinterpret_cast<const STX_GAS uint32_t*>(mq), m1 = *reinterpret_cast<const STX_GAS uint32_t*>(mq + 4),
+                                   m2 = *reinterpret_cast<const STX_GAS uint32_t*>(mq + 8);
+                    mw[r][0] = __builtin_amdgcn_alignbyte(m1, m0, ms);
+                    mw[r][1] = __builtin_amdgcn_alignbyte(m2, m1, ms);
+                } else {
+                    const STX_GAS uint8_t* irow = gp(im.img0) + (uint32_t)ly * (uint32_t)im.img0_stride;
+                    const STX_GAS uint8_t* mrow = gp(im.mask0) + (uint32_t)ly * (uint32_t)im.mask0_stride;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int lx = lx0 + j;
+                        if ((unsigned)lx < (unsigned)im.iw) {
+                            const STX_GAS uint8_t* p = irow + lx * 3;
+                            const uint32_t v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+                            const int bo = 3 * j;
+                            pw_[r][bo >> 2] |= v << (8 * (bo & 3));
+                            if ((bo & 3) > 1) pw_[r][(bo >> 2) + 1] |= v >> (32 - 8 * (bo & 3));
+                            mw[r][j >> 2] |= (uint32_t)mrow[lx] << (8 * (j & 3));
+                        }
+                    }
+                }
+            }
+            if ((mw[0][0] | mw[0][1] | mw[1][0] | mw[1][1]) == 0u) continue;  // nothing of this image under the patch
+            uint32_t M[2][4];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                M[r][0] = pair_mask<0, 2>(mw[r]);
+                M[r][1] = pair_mask<4, 6>(mw[r]);
+                M[r][2] = pair_mask<1, 3>(mw[r]);
+                M[r][3] = pair_mask<5, 7>(mw[r]);
+#pragma unroll
+                for (int q = 0; q < 4; q++) cnt[r][q] = unpk(pk(cnt[r][q]) - pk(M[r][q]));  // -(0xffff) = +1
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                pk16 up[2][4];
+                up_patch_pk(gp(im.g[1]) + c * im.g_plane[1], (uint32_t)im.g_stride[1], im.fw >> 1, im.fh >> 1, (X0 - im.fx) >> 1,
+                            (Y0 - im.fy) >> 1, up);
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    uint32_t px[4];
+                    if (c == 0) {
+                        px[0] = pair_u8<0, 6>(pw_[r]); px[1] = pair_u8<12, 18>(pw_[r]);
+                        px[2] = pair_u8<3, 9>(pw_[r]); px[3] = pair_u8<15, 21>(pw_[r]);
+                    } else if (c == 1) {
+                        px[0] = pair_u8<1, 7>(pw_[r]); px[1] = pair_u8<13, 19>(pw_[r]);
+                        px[2] = pair_u8<4, 10>(pw_[r]); px[3] = pair_u8<16, 22>(pw_[r]);
+                    } else {
+                        px[0] = pair_u8<2, 8>(pw_[r]); px[1] = pair_u8<14, 20>(pw_[r]);
+                        px[2] = pair_u8<5, 11>(pw_[r]); px[3] = pair_u8<17, 23>(pw_[r]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t L = unpk(pk(px[q]) - up[r][q]);  // in [-255, 255]: the saturating subtract never clips
+                        acc[r][c][q] = unpk(pk(acc[r][c][q]) + pk(L & M[r][q]));
+                    }
+                }
+            }
+        }
+    }
+    if (!active) return;
+
+    // hand over to the common epilogue: pair layout -> pixel order
+    int a[2][8][3];
+    float ws[2][8];
 #pragma unroll
     for (int r = 0; r < 2; r++)
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const float den = fadd(ws[r][j], WEIGHT_EPS);
-            float q0, q1, q2;
-            div3_shared(den, (float)(short)acc[r][j][0], (float)(short)acc[r][j][1], (float)(short)acc[r][j][2], q0, q1, q2);
-            v[r][j][0] = trunc_small(q0);
-            v[r][j][1] = trunc_small(q1);
-            v[r][j][2] = trunc_small(q2);
+            const int q = (j & 1) ? 2 + (j >> 2) : (j >> 2);
+            const bool hi = (j >> 1) & 1;
+#pragma unroll
+            for (int c = 0; c < 3; c++) a[r][j][c] = hi ? s16hi(acc[r][c][q]) : s16lo(acc[r][c][q]);
+            ws[r][j] = (float)(hi ? (cnt[r][q] >> 16) : (cnt[r][q] & 0xffffu));
         }
-    if (P.up) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            int up[2][8];
-            up_patch(P.up + c * P.up_plane - ((long long)P.up_y0 * P.up_stride + P.up_x0), P.up_stride, P.pw >> 1, P.ph >> 1,
-                     X0 >> 1, Y0 >> 1, up);
-#pragma unroll
-            for (int r = 0; r < 2; r++)
-#pragma unroll
-                for (int j = 0; j < 8; j++) v[r][j][c] = sat_s16(up[r][j] + v[r][j][c]);
-        }
-    }
-    if (!L0) {
-#pragma unroll
-        for (int r = 0; r < 2; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                uint4 o;
-                o.x = pack16(v[r][0][c], v[r][1][c]);
-                o.y = pack16(v[r][2][c], v[r][3][c]);
-                o.z = pack16(v[r][4][c], v[r][5][c]);
-                o.w = pack16(v[r][6][c], v[r][7][c]);
-                if (Y0 + r < P.y1)
-                    *reinterpret_cast<uint4*>(P.out + c * P.out_plane + (long long)(Y0 + r - P.out_y0) * P.out_stride + (X0 - P.out_x0)) = o;
-            }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const int y = Y0 + r;
-            if (y >= P.y1) break;
-            const int oy = y - P.pano_y0, ox = X0 - P.pano_x0;
-            uint32_t ob[6] = {0, 0, 0, 0, 0, 0}, om[2] = {0, 0};
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const bool keep = ws[r][j] > WEIGHT_EPS;
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    if (!keep) v[r][j][c] = 0;
-                    const uint32_t u = (uint32_t)min(abs(v[r][j][c]), 255);  // convertScaleAbs
-                    const int bo = 3 * j + c;
-                    ob[bo >> 2] |= u << (8 * (bo & 3));
-                }
-                om[j >> 2] |= (keep ? 255u : 0u) << (8 * (j & 3));
-            }
-            uint32_t* po = reinterpret_cast<uint32_t*>(P.pano + (long long)oy * P.pano_stride + (long long)ox * 3);
-            *reinterpret_cast<uint2*>(po) = make_uint2(ob[0], ob[1]);
-            *reinterpret_cast<uint2*>(po + 2) = make_uint2(ob[2], ob[3]);
-            *reinterpret_cast<uint2*>(po + 4) = make_uint2(ob[4], ob[5]);
-            *reinterpret_cast<uint2*>(P.pmask + (long long)oy * P.pmask_stride + ox) = make_uint2(om[0], om[1]);
-            if (P.pano16) {
-                uint32_t* p16 = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(P.pano16) + (long long)oy * P.pano16_stride +
-                                                            (long long)ox * 6);
-                uint32_t s[12];
-#pragma unroll
-                for (int j = 0; j < 8; j += 2) {  // 2 pixels = 6 shorts = 3 dwords
-                    s[(j >> 1) * 3 + 0] = pack16(v[r][j][0], v[r][j][1]);
-                    s[(j >> 1) * 3 + 1] = pack16(v[r][j][2], v[r][j + 1][0]);
-                    s[(j >> 1) * 3 + 2] = pack16(v[r][j + 1][1], v[r][j + 1][2]);
-                }
-                *reinterpret_cast<uint4*>(p16) = make_uint4(s[0], s[1], s[2], s[3]);
-                *reinterpret_cast<uint4*>(p16 + 4) = make_uint4(s[4], s[5], s[6], s[7]);
-                *reinterpret_cast<uint4*>(p16 + 8) = make_uint4(s[8], s[9], s[10], s[11]);
-            }
-        }
-    }
+    level_epilogue<true>(P, X0, Y0, a, ws);
 }
 
 bool launched_ok() { return hipGetLastError() == hipSuccess; }
@@ -633,7 +855,9 @@ bool stx_fast_mb_level(stx_ctx* ctx, const MbLevelK& K)
     if (K.n_images > 255) return false;
     dim3 grid((K.x1 - K.x0 + 511) / 512, (K.y1 - K.y0 + 7) / 8);
     hipStream_t st = ctx->stream;
-    if (K.emit) {
+    if (K.level == 0 && K.pk_ok && !K.emit && !K.has_contrib && K.num_bands > 0) {
+        hipLaunchKernelGGL(mb_level0_pk_kernel, grid, dim3(256), 0, st, K);
+    } else if (K.emit) {
         if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, true>), grid, dim3(256), 0, st, K);
         else hipLaunchKernelGGL((mb_level_fast_kernel<false, false, true>), grid, dim3(256), 0, st, K);
     } else if (K.has_contrib) {

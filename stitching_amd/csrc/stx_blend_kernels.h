@@ -20,6 +20,7 @@ struct MbLevelK {
     int pano_x0, pano_y0;
     int has_contrib;  // the image table holds kind-1 entries (received contribution strips)
     int all_u8;  // every level-0 source is u8x3 (the fast level-0 kernel has no int16 loader)
+    int pk_ok;   // every image is kind 0, u8x3, with a mask known to hold only 0 / 255 (packed 16-bit kernels)
 };
 
 // fast-path launchers (stx_blend_fast.hip); each returns false when its alignment / size

@@ -92,6 +92,7 @@ struct stx_buf {
     int w = 0, h = 0, c = 0, elem = 0;
     size_t stride = 0;  // bytes
     stx_buf* parent = nullptr;
+    int mask_binary = 0;  // 1: a u8x1 image known to hold only 0 and 255 (warped masks; scanned host uploads)
     std::atomic<int> refs{1};
 };
 
@@ -128,7 +129,7 @@ struct StxMbImage {  // device-visible descriptor of one fed image (all levels)
     // per level i, g[i] holds (short)(L_i * W_i) and wt[i] holds W_i over the rect (fx,fy,fw,fh) >> i.
     int kind; int order;
     const uint8_t* img0; long long img0_stride; int img0_is_s16;
-    const uint8_t* mask0; long long mask0_stride;
+    const uint8_t* mask0; long long mask0_stride; int mask_binary;
     int iw, ih;            // image size
     int ix, iy;            // image corner relative to the (padded) panorama roi
     int fx, fy, fw, fh;    // feed rect (tl_new .. br_new) relative to the panorama roi, level 0
