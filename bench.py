@@ -128,7 +128,9 @@ def main():
     from stitching_amd import synthetic
     from stitching_amd.pipeline import StitchJob
 
-    S.set_default_device(local_rank)
+    # STITCHING_AMD_FORCE_DEVICE: run every rank on one GPU (1-GPU boxes: exercises the sharded path with the
+    # host-staged transport; RCCL refuses two ranks on one device)
+    S.set_default_device(int(os.environ.get("STITCHING_AMD_FORCE_DEVICE", local_rank)))
     ctx = S.get_context()
 
     fpg = args.frames_per_gpu

@@ -13,6 +13,7 @@
 //                   8-pixel strip never straddles a feed-rectangle edge); level 0 writes the
 //                   u8 panorama + mask (+ int16 result)
 #include <algorithm>
+#include <cstdlib>
 
 #include "stx_blend_kernels.h"
 #include "stx_device_math.h"
@@ -771,7 +772,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                     }
                 }
             }
-            if ((mw[0][0] | mw[0][1] | mw[1][0] | mw[1][1]) == 0u) continue;  // nothing of this image under the patch
+            // (no early-out on an all-zero mask: it would put the G_1 loads behind the mask loads' round trip)
             uint32_t M[2][4];
 #pragma unroll
             for (int r = 0; r < 2; r++) {

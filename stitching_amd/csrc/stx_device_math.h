@@ -155,6 +155,9 @@ STX_DEV int trunc_s16(float v)
 STX_DEV int reflect(int p, int len)
 {
     if ((unsigned)p < (unsigned)len) return p;
+    // one mirror image away (the common case next to an image): no division
+    const int q = p < 0 ? -p - 1 : 2 * len - 1 - p;
+    if ((unsigned)q < (unsigned)len) return q;
     if (len == 1) return 0;
     int period = 2 * len;
     int m = p % period;

@@ -4,6 +4,9 @@
 #include <cstdint>
 #define ITERS 2048
 #define CH 8
+typedef unsigned short v2h __attribute__((ext_vector_type(2)));
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 template <int OP>
 __global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t seed)
 {
@@ -34,6 +37,18 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t seed)
             if (OP == 15) a[i] = (uint32_t)((int)(short)(a[i] & 0xffff)) + b; // v_bfe_i32 / sext + add
             if (OP == 16) f[i] = rintf(f[i]) + fc;                          // v_rndne + add
             if (OP == 17) a[i] = (a[i] > b) ? c : a[i] + 1;                 // cmp + cndmask + add
+            if (OP == 18) a[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(v2h, a[i]) + __builtin_bit_cast(v2h, b));  // v_pk_add_u16
+            if (OP == 19) a[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(v2h, a[i]) * __builtin_bit_cast(v2h, b) + __builtin_bit_cast(v2h, c));  // v_pk_mad_u16
+            if (OP == 20) a[i] = __builtin_amdgcn_perm(a[i], b, c);         // v_perm_b32
+            if (OP == 21) a[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(v2h, a[i]), __builtin_bit_cast(v2h, b), c, false);  // v_dot2_u32_u16
+            if (OP == 22) { v2f t = {f[i], f[(i + 1) % CH]}; v2f u = {fb, fb}, w = {fc, fc}; t = __builtin_elementwise_fma(t, u, w); f[i] = t.x; f[(i + 1) % CH] = t.y; }  // v_pk_fma_f32
+            if (OP == 23) a[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(v2h, a[i]) >> __builtin_bit_cast(v2h, 0x00020002u)) + b;  // v_pk_lshrrev_b16 + add
+            if (OP == 24) f[i] = (float)(short)(a[i] >> 16) + f[i];          // cvt_f32_i32 sdwa + add
+            if (OP == 25) a[i] = __builtin_amdgcn_sdot4((int)a[i], (int)b, (int)c, false);  // v_dot4_i32_i8
+            if (OP == 26) a[i] = __builtin_amdgcn_alignbit(a[i], b, 16);    // v_alignbit
+            if (OP == 27) a[i] = (a[i] << 16) | b;                           // v_lshl_or_b32
+            if (OP == 28) a[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(v2s, a[i]), __builtin_bit_cast(v2s, b)));  // v_pk_add_i16 clamp
+            if (OP == 29) a[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2s, a[i]), __builtin_bit_cast(v2s, b)));  // v_pk_max_i16
         }
     }
     uint32_t r = 0;
@@ -61,5 +76,8 @@ int main()
     run<8>("v_fma_f32", 1, d); run<9>("v_mul_f32", 1, d); run<10>("fdiv_rn (seq ~11)", 11, d); run<11>("v_alignbyte", 1, d);
     run<12>("rcp+add", 2, d); run<13>("ds_bpermute+add", 2, d); run<14>("cvt_ubyte+mul+add", 3, d); run<15>("sext16+add", 2, d);
     run<16>("rndne+add", 2, d); run<17>("cmp+cndmask+add", 3, d);
+    run<18>("v_pk_add_u16", 1, d); run<19>("v_pk_mad_u16", 1, d); run<20>("v_perm_b32", 1, d); run<21>("v_dot2_u32_u16", 1, d);
+    run<22>("v_pk_fma_f32 (0.5/elem)", 1, d); run<23>("pk_lshr16+add", 2, d); run<24>("cvt_f32_i16(sdwa)+add", 2, d); run<25>("v_dot4_i32_i8", 1, d);
+    run<26>("v_alignbit", 1, d); run<27>("v_lshl_or", 1, d); run<28>("v_pk_add_i16 clamp", 1, d); run<29>("v_pk_max_i16", 1, d);
     return 0;
 }
