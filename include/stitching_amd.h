@@ -113,6 +113,12 @@ int stx_warp(stx_ctx* ctx, int type, float scale, const float K[9], const float 
  * out_img / out_mask may each be NULL. */
 int stx_warp_image_and_mask(stx_ctx* ctx, int type, float scale, const float K[9], const float R[9],
                             const stx_buf* src, stx_buf** out_img, stx_buf** out_mask, int out_xywh[4]);
+/* batched form of the generator loops stitching/warper.py:39-41 (warp_images) and :54-56
+ * (create_and_warp_masks) for n cameras of one warper: ROIs in one device pass, then ONE table launch and
+ * ONE remap launch for all images (the per-image argument blocks travel as kernel arguments: no upload,
+ * no host synchronisation).  out_imgs / out_masks are arrays of n handles (either may be NULL). */
+int stx_warp_batch(stx_ctx* ctx, int type, float scale, int n, const float* K9s, const float* R9s,
+                   const stx_buf* const* srcs, stx_buf** out_imgs, stx_buf** out_masks, int* out_xywh);
 /* stitching/warper.py:58-68 without allocating the 255-filled source (size only) */
 int stx_warp_mask(stx_ctx* ctx, int type, float scale, const float K[9], const float R[9], int w, int h,
                   stx_buf** out_mask, int out_xywh[4]);

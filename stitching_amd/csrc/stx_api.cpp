@@ -699,6 +699,76 @@ STX_EXPORT int stx_warp(stx_ctx* ctx, int type, float scale, const float K[9], c
     return STX_OK;
 }
 
+STX_EXPORT int stx_warp_batch(stx_ctx* ctx, int type, float scale, int n, const float* K9s, const float* R9s,
+                              const stx_buf* const* srcs, stx_buf** out_imgs, stx_buf** out_masks, int* out_xywh)
+{
+    if (!ctx || !K9s || !R9s || !srcs || n < 0) return stx_fail(STX_ERR_INVALID, "bad argument");
+    if (!out_imgs && !out_masks) return stx_fail(STX_ERR_INVALID, "nothing requested");
+    if (n == 0) return STX_OK;
+    STX_TRY(stx_set_device(ctx));
+    std::vector<StxProjector> ps(n);
+    std::vector<int> rois(4 * (size_t)n), sizes(2 * (size_t)n);
+    for (int i = 0; i < n; i++) {
+        if (!srcs[i] || srcs[i]->elem != STX_U8 || srcs[i]->c != 3) return stx_fail(STX_ERR_INVALID, "warp source %d must be u8x3", i);
+        if (srcs[i]->ctx != ctx) return stx_fail(STX_ERR_INVALID, "warp source %d belongs to another context", i);
+        STX_TRY(stx_make_projector(type, scale, K9s + 9 * i, R9s + 9 * i, &ps[i]));
+        sizes[2 * i] = srcs[i]->w;
+        sizes[2 * i + 1] = srcs[i]->h;
+    }
+    // ROIs: cached ones as they are, all missing ones in ONE device pass (one synchronisation)
+    if (!g_roi_cache) g_roi_cache = new std::map<RoiKey, std::array<int, 4>>();
+    std::vector<int> miss;
+    for (int i = 0; i < n; i++) {
+        auto it = g_roi_cache->find(make_key(type, scale, K9s + 9 * i, R9s + 9 * i, sizes[2 * i], sizes[2 * i + 1]));
+        if (it != g_roi_cache->end()) memcpy(&rois[4 * i], it->second.data(), 16);
+        else miss.push_back(i);
+    }
+    if (!miss.empty()) {
+        const int m = (int)miss.size();
+        std::vector<StxProjector> mp(m);
+        std::vector<int> msz(2 * (size_t)m), mroi(4 * (size_t)m);
+        for (int j = 0; j < m; j++) { mp[j] = ps[miss[j]]; msz[2 * j] = sizes[2 * miss[j]]; msz[2 * j + 1] = sizes[2 * miss[j] + 1]; }
+        STX_TRY(rois_impl(ctx, m, mp.data(), msz.data(), mroi.data()));
+        if (g_roi_cache->size() > 8192) g_roi_cache->clear();
+        for (int j = 0; j < m; j++) {
+            const int i = miss[j];
+            memcpy(&rois[4 * i], &mroi[4 * j], 16);
+            (*g_roi_cache)[make_key(type, scale, K9s + 9 * i, R9s + 9 * i, sizes[2 * i], sizes[2 * i + 1])] = {
+                mroi[4 * j], mroi[4 * j + 1], mroi[4 * j + 2], mroi[4 * j + 3]};
+        }
+    }
+    std::vector<stx_buf*> bi(n, nullptr), bm(n, nullptr);
+    std::vector<StxWarpLaunch> Ls(n);
+    int rc = STX_OK;
+    for (int i = 0; i < n && rc == STX_OK; i++) {
+        const int* roi = &rois[4 * i];
+        if (roi[2] <= 0 || roi[3] <= 0 || (long long)roi[2] * roi[3] > (1ll << 33))
+            rc = stx_fail(STX_ERR_INVALID, "degenerate warp roi %dx%d (camera parameters?)", roi[2], roi[3]);
+        if (rc == STX_OK && out_imgs) rc = stx_buf_new(ctx, roi[2], roi[3], 3, STX_U8, &bi[i]);
+        if (rc == STX_OK && out_masks) rc = stx_buf_new(ctx, roi[2], roi[3], 1, STX_U8, &bm[i]);
+        if (rc != STX_OK) break;
+        StxWarpLaunch& L = Ls[i];
+        L.proj = ps[i];
+        L.tlx = roi[0]; L.tly = roi[1]; L.dw = roi[2]; L.dh = roi[3];
+        L.src = srcs[i]->ptr; L.sw = srcs[i]->w; L.sh = srcs[i]->h; L.sstride = srcs[i]->stride; L.src_channels = 3;
+        L.nearest_src = 0;
+        L.dimg = bi[i] ? bi[i]->ptr : nullptr; L.dimg_stride = bi[i] ? bi[i]->stride : 0;
+        L.dmask = bm[i] ? bm[i]->ptr : nullptr; L.dmask_stride = bm[i] ? bm[i]->stride : 0;
+    }
+    if (rc == STX_OK) rc = stx_launch_warp_batch(ctx, Ls.data(), n);
+    if (rc != STX_OK) {
+        for (int i = 0; i < n; i++) { stx_buf_release(bi[i]); stx_buf_release(bm[i]); }
+        return rc;
+    }
+    for (int i = 0; i < n; i++) {
+        if (bm[i]) bm[i]->mask_binary = 1;
+        if (out_imgs) out_imgs[i] = bi[i];
+        if (out_masks) out_masks[i] = bm[i];
+    }
+    if (out_xywh) memcpy(out_xywh, rois.data(), sizeof(int) * 4 * (size_t)n);
+    return STX_OK;
+}
+
 STX_EXPORT int stx_warp_image_and_mask(stx_ctx* ctx, int type, float scale, const float K[9], const float R[9],
                                        const stx_buf* src, stx_buf** out_img, stx_buf** out_mask, int out_xywh[4])
 {

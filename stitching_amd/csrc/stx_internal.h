@@ -121,6 +121,7 @@ struct StxWarpLaunch {
     int nearest_src;               // 1: out image = nearest sample of a u8x1 source (generic mask warp)
 };
 int stx_launch_warp(stx_ctx* ctx, const StxWarpLaunch& L);
+int stx_launch_warp_batch(stx_ctx* ctx, const StxWarpLaunch* Ls, int n);
 int stx_launch_roi_minmax(stx_ctx* ctx, int n, const StxProjector* projs, const int* sizes_wh, float* out_minmax4);
 
 // multi-band -------------------------------------------------------------------------------------

@@ -47,6 +47,15 @@ struct WarpK {
     float mx_hi, my_hi;
 };
 
+// Up to WARP_BATCH images per launch: the per-image argument blocks travel in the kernel-argument segment
+// (scalar loads indexed by blockIdx), so a batch needs no descriptor upload and no host synchronisation.
+constexpr int WARP_BATCH = 8;
+struct WarpBatchK {
+    WarpK k[WARP_BATCH];
+    float2* colT[WARP_BATCH];
+    float2* rowT[WARP_BATCH];
+};
+
 STX_DEV uint32_t ldg32(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
 
 // 6 consecutive bytes starting at byte address `a` (any alignment) -> lo = bytes 0..3, hi = bytes 4..7
@@ -75,8 +84,11 @@ STX_DEV uint32_t bil(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, uin
 //   cylindrical: col = (sin u', cos u'),           row = (v', -)
 //   plane      : col = (u'/scale - t0, -),         row = (v'/scale - t1, -)
 template <int TYPE>
-__global__ __launch_bounds__(256) void warp_tables_kernel(WarpK P, float2* __restrict__ colT, float2* __restrict__ rowT)
+__global__ __launch_bounds__(256) void warp_tables_kernel(WarpBatchK B)
 {
+    const WarpK& P = B.k[blockIdx.y];
+    float2* __restrict__ colT = B.colT[blockIdx.y];
+    float2* __restrict__ rowT = B.rowT[blockIdx.y];
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < P.dw) {
         const float uu = (float)(P.tlx + i);
@@ -292,8 +304,11 @@ STX_DEV void put_px(uint32_t (&out)[3], int j, uint32_t px)
 }
 
 template <int TYPE, bool IMG, bool MASK>
-__global__ __launch_bounds__(256) void warp_fast_kernel(WarpK P, const float2* __restrict__ colT, const float2* __restrict__ rowT)
+__global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
 {
+    const WarpK& P = B.k[blockIdx.z];
+    const float2* __restrict__ colT = B.colT[blockIdx.z];
+    const float2* __restrict__ rowT = B.rowT[blockIdx.z];
     const int lane = threadIdx.x & 63;
     const int x0 = blockIdx.x * WARP_TW + lane * 4;
     int y = blockIdx.y * (WARP_TH * P.rows_per_wave) + (threadIdx.x >> 6);
@@ -454,37 +469,62 @@ __global__ __launch_bounds__(256) void roi_kernel(const RoiK* __restrict__ Ps, u
     }
 }
 
+bool fast_ok(const WarpK& K)
+{
+    return !K.msrc && K.sw <= 32767 && K.sh <= 32767 && K.sw >= 2 && K.sh >= 2 && (long long)K.sstride * K.sh < (1ll << 31);
+}
+
 template <int TYPE>
-int launch_typed(stx_ctx* ctx, const WarpK& K, bool img, bool mask, dim3 grid, const char* prof_name, double algo_bytes)
+int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, const char* prof_name, const double* algo_bytes)
 {
     hipStream_t s = ctx->stream;
-    // per-column / per-row trig tables (a few KB, L2 resident), freed in stream order
-    const size_t ncol = ((size_t)K.dw + 3) & ~(size_t)3;
+    // per-column / per-row trig tables (a few KB per image, L2 resident), one allocation for the batch, freed in stream order
+    size_t total = 0;
+    for (int i = 0; i < n; i++) total += (((size_t)Ks[i].dw + 3) & ~(size_t)3) + (((size_t)Ks[i].dh + 3) & ~(size_t)3);
     void* tab = nullptr;
-    STX_TRY(stx_dev_alloc(ctx, (ncol + (size_t)K.dh) * sizeof(float2), &tab));
-    float2* colT = (float2*)tab;
-    float2* rowT = colT + ncol;
-    {
-        StxProfScope prof(ctx, "warp_tables", (double)(K.dw + K.dh) * sizeof(float2));
-        hipLaunchKernelGGL((warp_tables_kernel<TYPE>), dim3((K.dw + K.dh + 255) / 256), dim3(256), 0, s, K, colT, rowT);
-    }
-    {
-        StxProfScope prof(ctx, prof_name, algo_bytes);
-        const bool fast = !K.msrc && K.sw <= 32767 && K.sh <= 32767 && K.sw >= 2 && K.sh >= 2 &&
-                          (long long)K.sstride * K.sh < (1ll << 31);
+    STX_TRY(stx_dev_alloc(ctx, total * sizeof(float2), &tab));
+    float2* cursor = (float2*)tab;
+    for (int base = 0; base < n; base += WARP_BATCH) {
+        const int m = std::min(WARP_BATCH, n - base);
+        WarpBatchK B;
+        memset(&B, 0, sizeof(B));
+        int max_tab = 0, gx = 0, gy = 0;
+        bool fast = true;
+        double tab_bytes = 0.0, bytes = 0.0;
+        for (int i = 0; i < m; i++) {
+            const WarpK& K = Ks[base + i];
+            B.k[i] = K;
+            B.k[i].rows_per_wave = 1;  // measured (4000x3000): 1 row per wavefront 45.8 us, 2: 47.2, 4: 51.3, 8: 68.4
+            B.colT[i] = cursor;
+            cursor += ((size_t)K.dw + 3) & ~(size_t)3;
+            B.rowT[i] = cursor;
+            cursor += ((size_t)K.dh + 3) & ~(size_t)3;
+            max_tab = std::max(max_tab, K.dw + K.dh);
+            gx = std::max(gx, (K.dw + WARP_TW - 1) / WARP_TW);
+            gy = std::max(gy, (K.dh + WARP_TH - 1) / WARP_TH);
+            fast = fast && fast_ok(K);
+            tab_bytes += (double)(K.dw + K.dh) * sizeof(float2);
+            bytes += algo_bytes[base + i];
+        }
+        {
+            StxProfScope prof(ctx, "warp_tables", tab_bytes);
+            hipLaunchKernelGGL((warp_tables_kernel<TYPE>), dim3((max_tab + 255) / 256, m), dim3(256), 0, s, B);
+        }
         if (fast) {
-            // measured on MI355X (4000x3000 frame): 1 row per wavefront 45.8 us, 2: 47.2, 3: 49.9, 4: 51.3, 8: 68.4 --
-            // short wavefronts keep more independent gathers in flight; the row loop stays for tiny ROIs only
-            WarpK KF = K;
-            KF.rows_per_wave = 1;
-            const dim3 gf(grid.x, (K.dh + WARP_TH * KF.rows_per_wave - 1) / (WARP_TH * KF.rows_per_wave));
-            if (img && mask) hipLaunchKernelGGL((warp_fast_kernel<TYPE, true, true>), gf, dim3(256), 0, s, KF, colT, rowT);
-            else if (img) hipLaunchKernelGGL((warp_fast_kernel<TYPE, true, false>), gf, dim3(256), 0, s, KF, colT, rowT);
-            else hipLaunchKernelGGL((warp_fast_kernel<TYPE, false, true>), gf, dim3(256), 0, s, KF, colT, rowT);
+            StxProfScope prof(ctx, prof_name, bytes);
+            const dim3 gf(gx, gy, m);
+            if (img && mask) hipLaunchKernelGGL((warp_fast_kernel<TYPE, true, true>), gf, dim3(256), 0, s, B);
+            else if (img) hipLaunchKernelGGL((warp_fast_kernel<TYPE, true, false>), gf, dim3(256), 0, s, B);
+            else hipLaunchKernelGGL((warp_fast_kernel<TYPE, false, true>), gf, dim3(256), 0, s, B);
         } else {
-            if (img && mask) hipLaunchKernelGGL((warp_kernel<TYPE, true, true>), grid, dim3(256), 0, s, K, colT, rowT);
-            else if (img) hipLaunchKernelGGL((warp_kernel<TYPE, true, false>), grid, dim3(256), 0, s, K, colT, rowT);
-            else hipLaunchKernelGGL((warp_kernel<TYPE, false, true>), grid, dim3(256), 0, s, K, colT, rowT);
+            for (int i = 0; i < m; i++) {
+                StxProfScope prof(ctx, prof_name, algo_bytes[base + i]);
+                const WarpK& K = B.k[i];
+                const dim3 grid((K.dw + WARP_TW - 1) / WARP_TW, (K.dh + WARP_TH - 1) / WARP_TH);
+                if (img && mask) hipLaunchKernelGGL((warp_kernel<TYPE, true, true>), grid, dim3(256), 0, s, K, B.colT[i], B.rowT[i]);
+                else if (img) hipLaunchKernelGGL((warp_kernel<TYPE, true, false>), grid, dim3(256), 0, s, K, B.colT[i], B.rowT[i]);
+                else hipLaunchKernelGGL((warp_kernel<TYPE, false, true>), grid, dim3(256), 0, s, K, B.colT[i], B.rowT[i]);
+            }
         }
     }
     stx_dev_free(ctx, tab);
@@ -493,11 +533,10 @@ int launch_typed(stx_ctx* ctx, const WarpK& K, bool img, bool mask, dim3 grid, c
     return STX_OK;
 }
 
-}  // namespace
-
-int stx_launch_warp(stx_ctx* ctx, const StxWarpLaunch& L)
+void fill_warpk(const StxWarpLaunch& L, WarpK* Kp, double* bytes)
 {
-    WarpK K;
+    WarpK& K = *Kp;
+    memset(&K, 0, sizeof(K));
     for (int i = 0; i < 9; i++) K.kr[i] = L.proj.k_rinv[i];
     for (int i = 0; i < 3; i++) K.t[i] = L.proj.t[i];
     K.scale = L.proj.scale;
@@ -510,23 +549,37 @@ int stx_launch_warp(stx_ctx* ctx, const StxWarpLaunch& L)
     K.msstride = (long long)L.sstride;
     K.dimg = L.dimg; K.dimg_stride = (long long)L.dimg_stride;
     K.dmask = L.dmask; K.dmask_stride = (long long)L.dmask_stride;
+    K.rows_per_wave = 1;
     K.bx_hi = (float)(32.0 * (L.sw - 1) - 0.5);
     K.by_hi = (float)(32.0 * (L.sh - 1) - 0.5);
     // cvRound(v) <= n - 1: v <= n - 0.5 when n - 1 is even (the tie rounds down to it), v < n - 0.5 otherwise
     K.mx_hi = ((L.sw - 1) & 1) ? (float)(L.sw - 0.5) : std::nextafterf((float)(L.sw - 0.5), 3.0e38f);
     K.my_hi = ((L.sh - 1) & 1) ? (float)(L.sh - 0.5) : std::nextafterf((float)(L.sh - 0.5), 3.0e38f);
-    dim3 grid((L.dw + WARP_TW - 1) / WARP_TW, (L.dh + WARP_TH - 1) / WARP_TH);
     // algorithmic bytes: read the source once, write the warped image + mask once
-    double bytes = (img ? 3.0 * L.sw * L.sh + 3.0 * L.dw * L.dh : 0.0) + (mask ? 1.0 * L.dw * L.dh : 0.0);
-    const char* name = img ? (mask ? "warp_img_mask" : "warp_img") : "warp_mask";
-    switch (L.proj.type) {
-    case STX_WARP_PLANE:
-    case STX_WARP_AFFINE: return launch_typed<STX_WARP_PLANE>(ctx, K, img, mask, grid, name, bytes);
-    case STX_WARP_CYLINDRICAL: return launch_typed<STX_WARP_CYLINDRICAL>(ctx, K, img, mask, grid, name, bytes);
-    case STX_WARP_SPHERICAL: return launch_typed<STX_WARP_SPHERICAL>(ctx, K, img, mask, grid, name, bytes);
-    }
-    return stx_fail(STX_ERR_UNSUPPORTED, "warp type %d not implemented", L.proj.type);
+    *bytes = (img ? 3.0 * L.sw * L.sh + 3.0 * L.dw * L.dh : 0.0) + (mask ? 1.0 * L.dw * L.dh : 0.0);
 }
+
+}  // namespace
+
+// All launches of one call share the projector type and the (image, mask) output selection.
+int stx_launch_warp_batch(stx_ctx* ctx, const StxWarpLaunch* Ls, int n)
+{
+    if (n <= 0) return STX_OK;
+    std::vector<WarpK> Ks(n);
+    std::vector<double> bytes(n);
+    for (int i = 0; i < n; i++) fill_warpk(Ls[i], &Ks[i], &bytes[i]);
+    const bool img = Ls[0].dimg != nullptr, mask = Ls[0].dmask != nullptr;
+    const char* name = img ? (mask ? "warp_img_mask" : "warp_img") : "warp_mask";
+    switch (Ls[0].proj.type) {
+    case STX_WARP_PLANE:
+    case STX_WARP_AFFINE: return launch_typed<STX_WARP_PLANE>(ctx, Ks.data(), n, img, mask, name, bytes.data());
+    case STX_WARP_CYLINDRICAL: return launch_typed<STX_WARP_CYLINDRICAL>(ctx, Ks.data(), n, img, mask, name, bytes.data());
+    case STX_WARP_SPHERICAL: return launch_typed<STX_WARP_SPHERICAL>(ctx, Ks.data(), n, img, mask, name, bytes.data());
+    }
+    return stx_fail(STX_ERR_UNSUPPORTED, "warp type %d not implemented", Ls[0].proj.type);
+}
+
+int stx_launch_warp(stx_ctx* ctx, const StxWarpLaunch& L) { return stx_launch_warp_batch(ctx, &L, 1); }
 
 // out_minmax4[i] = {min u, min v, max u, max v} over the border of image i (cyl / spherical)
 int stx_launch_roi_minmax(stx_ctx* ctx, int n, const StxProjector* projs, const int* sizes_wh, float* out_minmax4)

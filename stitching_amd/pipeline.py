@@ -56,8 +56,8 @@ class StitchJob:
         try:
             blender = Blender(self.blender_type, self.blend_strength)
             blender.prepare(self.corners, self.warped_sizes)
-            for frame, cam, corner in zip(self.frames, self.cameras, self.corners):
-                img, mask, roi = self.warper.warp_image_and_mask(frame, cam)
+            imgs, masks, rois = self.warper.warp_images_and_masks(self.frames, self.cameras)
+            for img, mask, roi, corner in zip(imgs, masks, rois, self.corners):
                 if roi[0:2] != tuple(corner):
                     raise StitchingError("warp roi changed between plan() and run()")
                 blender.feed(img, mask, corner)

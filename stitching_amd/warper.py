@@ -147,6 +147,31 @@ class Warper:
                                                     src._h, C.byref(oi), C.byref(om), roi))
         return (self._result(DeviceImage(ctx, oi)), self._result(DeviceImage(ctx, om)), tuple(int(v) for v in roi))
 
+    def warp_images_and_masks(self, imgs, cameras, aspect=1):
+        """Batched form of warp_images + create_and_warp_masks (stitching/warper.py:39-41, 54-56) for a list of
+        images: one ROI pass, one table launch and one remap launch for all of them (stx_warp_batch).
+        Returns (warped_images, warped_masks, rois)."""
+        ctx = get_context()
+        srcs = [as_device(img, ctx) for img in imgs]
+        cameras = list(cameras)
+        n = min(len(srcs), len(cameras))
+        if n == 0:
+            return [], [], []
+        Ks = np.empty((n, 3, 3), np.float32)
+        Rs = np.empty((n, 3, 3), np.float32)
+        for i in range(n):
+            if srcs[i].channels != 3 or srcs[i].dtype != np.uint8:
+                raise StitchingError(f"warp_image expects a HxWx3 uint8 image, got {srcs[i].shape} {srcs[i].dtype}")
+            Ks[i], Rs[i] = self._K_R(cameras[i], aspect)
+        h_src = (C.c_void_p * n)(*[s._h for s in srcs[:n]])
+        h_img, h_mask = (C.c_void_p * n)(), (C.c_void_p * n)()
+        rois = np.zeros((n, 4), np.int32)
+        _lib.check(ctx._lib.stx_warp_batch(ctx.handle, self._type_id(), self._scale(aspect), n, _fp(Ks), _fp(Rs), h_src,
+                                           h_img, h_mask, rois.ctypes.data_as(C.POINTER(C.c_int))))
+        imgs_out = [self._result(DeviceImage(ctx, C.c_void_p(h_img[i]))) for i in range(n)]
+        masks_out = [self._result(DeviceImage(ctx, C.c_void_p(h_mask[i]))) for i in range(n)]
+        return imgs_out, masks_out, [tuple(int(v) for v in r) for r in rois]
+
     # ------------------------------------------------------------------ helpers
     def _type_id(self):
         if self.warper_type not in Warper.WARP_TYPE_CHOICES:

@@ -197,3 +197,24 @@ def test_rccl_transport_self_exchange(gpu_ctx):
     (dst,) = tr.exchange([(0, src, host.size)], [(0, host.size)])
     assert np.array_equal(np.asarray(dst), host)
     tr.close()
+
+
+@pytest.mark.parametrize("wtype", ["spherical", "cylindrical", "plane"])
+def test_batched_warp_equals_per_image(oracle, gpu_ctx, wtype):
+    """stx_warp_batch (one table launch + one remap launch per 8 images) against the oracle, with more
+    images than one launch holds and images of different sizes."""
+    n = 11
+    cams = synthetic.ring_cameras(n, 517, 389, span_deg=200.0 if wtype != "plane" else 60.0)
+    sizes = [(517, 389) if i % 3 else (401, 277) for i in range(n)]
+    for c, s in zip(cams, sizes):
+        c.ppx, c.ppy = s[0] / 2.0, s[1] / 2.0
+    imgs = [synthetic.make_frame(i, s[0], s[1]) for i, s in enumerate(sizes)]
+    g, o = S.Warper(wtype), oracle.Warper(wtype)
+    g.set_scale(cams)
+    o.set_scale(cams)
+    gi, gm, rois = g.warp_images_and_masks(imgs, cams)
+    assert len(gi) == len(gm) == len(rois) == n
+    for i in range(n):
+        assert rois[i] == o.warp_roi(sizes[i], cams[i])
+        assert np.array_equal(np.asarray(gi[i]), o.warp_image(imgs[i], cams[i])), f"image {i}"
+        assert np.array_equal(np.asarray(gm[i]), o.create_and_warp_mask(sizes[i], cams[i])), f"mask {i}"
