@@ -79,6 +79,8 @@ STX_EXPORT int stx_ctx_create(int device, stx_ctx** out)
     STX_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     ctx->pinned_bytes = 1 << 16;
     STX_HIP(hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault));
+    STX_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    STX_HIP(hipMalloc(&ctx->aux_scratch, ctx->pinned_bytes));
     *out = ctx.release();
     return STX_OK;
 }
@@ -101,6 +103,8 @@ STX_EXPORT int stx_ctx_destroy(stx_ctx* ctx)
     for (auto e : ctx->event_pool) hipEventDestroy(e);
     for (auto e : ctx->marks) if (e) hipEventDestroy(e);
     if (ctx->pinned) hipHostFree(ctx->pinned);
+    if (ctx->aux_scratch) hipFree(ctx->aux_scratch);
+    if (ctx->aux_stream) hipStreamDestroy(ctx->aux_stream);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return STX_OK;

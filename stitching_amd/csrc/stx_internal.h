@@ -54,6 +54,10 @@ struct StxPendingEvent {
 struct stx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // side stream + private device scratch of the ROI pass: it depends on nothing queued on `stream`, so a
+    // pipeline of panoramas can take its ROIs while the previous panorama is still blending
+    hipStream_t aux_stream = nullptr;
+    void* aux_scratch = nullptr;
     // caching allocator: bucket size -> free blocks
     std::map<size_t, std::vector<void*>> free_blocks;
     std::map<void*, size_t> block_size;

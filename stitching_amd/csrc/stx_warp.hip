@@ -424,9 +424,12 @@ STX_DEV uint32_t f2ord(float f)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-__global__ __launch_bounds__(256) void roi_kernel(const RoiK* __restrict__ Ps, uint32_t* __restrict__ out)
+constexpr int ROI_BATCH = 16;
+struct RoiBatchK { RoiK k[ROI_BATCH]; };
+
+__global__ __launch_bounds__(256) void roi_kernel(RoiBatchK B, float* __restrict__ out)
 {
-    const RoiK P = Ps[blockIdx.y];
+    const RoiK& P = B.k[blockIdx.y];
     const int npts = 2 * P.w + 2 * P.h;
     float mnu = 3.402823466e+38f, mnv = 3.402823466e+38f, mxu = -3.402823466e+38f, mxv = -3.402823466e+38f;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npts; p += gridDim.x * blockDim.x) {
@@ -460,12 +463,22 @@ __global__ __launch_bounds__(256) void roi_kernel(const RoiK* __restrict__ Ps, u
         if (c > mxu) mxu = c;
         if (d > mxv) mxv = d;
     }
+    // one partial result per block (no atomics, no initialisation pass): the host folds the partials
+    __shared__ float s_part[4][4];
     if ((threadIdx.x & 63) == 0) {
-        uint32_t* o = out + 4 * blockIdx.y;
-        atomicMin(o + 0, f2ord(mnu));
-        atomicMin(o + 1, f2ord(mnv));
-        atomicMax(o + 2, f2ord(mxu));
-        atomicMax(o + 3, f2ord(mxv));
+        const int wv = threadIdx.x >> 6;
+        s_part[wv][0] = mnu; s_part[wv][1] = mnv; s_part[wv][2] = mxu; s_part[wv][3] = mxv;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int wv = 1; wv < 4; wv++) {
+            if (s_part[wv][0] < mnu) mnu = s_part[wv][0];
+            if (s_part[wv][1] < mnv) mnv = s_part[wv][1];
+            if (s_part[wv][2] > mxu) mxu = s_part[wv][2];
+            if (s_part[wv][3] > mxv) mxv = s_part[wv][3];
+        }
+        float* o = out + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        o[0] = mnu; o[1] = mnv; o[2] = mxu; o[3] = mxv;
     }
 }
 
@@ -584,42 +597,45 @@ int stx_launch_warp(stx_ctx* ctx, const StxWarpLaunch& L) { return stx_launch_wa
 // out_minmax4[i] = {min u, min v, max u, max v} over the border of image i (cyl / spherical)
 int stx_launch_roi_minmax(stx_ctx* ctx, int n, const StxProjector* projs, const int* sizes_wh, float* out_minmax4)
 {
-    std::vector<RoiK> hk(n);
-    int maxpts = 0;
-    for (int i = 0; i < n; i++) {
-        for (int k = 0; k < 9; k++) hk[i].rk[k] = projs[i].r_kinv[k];
-        hk[i].scale = projs[i].scale;
-        hk[i].type = projs[i].type;
-        hk[i].w = sizes_wh[2 * i];
-        hk[i].h = sizes_wh[2 * i + 1];
-        maxpts = std::max(maxpts, 2 * hk[i].w + 2 * hk[i].h);
+    // Argument blocks travel as kernel arguments, per-block partial results come back through the context's
+    // pinned scratch: no pageable copies, no atomics.  The pass runs on the context's side stream with its own
+    // device scratch and only that stream is waited for, so work already queued on the main stream keeps going.
+    constexpr int BX = 32;  // blocks per image
+    const int cap = (int)(ctx->pinned_bytes / (16 * BX));
+    for (int start = 0; start < n; start += cap) {
+        const int cnt = std::min(cap, n - start);
+        float* dout = (float*)ctx->aux_scratch;
+        for (int base = 0; base < cnt; base += ROI_BATCH) {
+            const int m = std::min(ROI_BATCH, cnt - base);
+            RoiBatchK B;
+            memset(&B, 0, sizeof(B));
+            for (int i = 0; i < m; i++) {
+                RoiK& k = B.k[i];
+                const int g = start + base + i;
+                for (int q = 0; q < 9; q++) k.rk[q] = projs[g].r_kinv[q];
+                k.scale = projs[g].scale;
+                k.type = projs[g].type;
+                k.w = sizes_wh[2 * g];
+                k.h = sizes_wh[2 * g + 1];
+            }
+            hipLaunchKernelGGL(roi_kernel, dim3(BX, m), dim3(256), 0, ctx->aux_stream, B, dout + 4 * (size_t)BX * base);
+        }
+        const float* res = (const float*)ctx->pinned;
+        STX_HIP(hipMemcpyAsync(ctx->pinned, dout, 16 * (size_t)BX * cnt, hipMemcpyDeviceToHost, ctx->aux_stream));
+        STX_HIP(hipStreamSynchronize(ctx->aux_stream));
+        for (int i = 0; i < cnt; i++) {
+            // NaN-ignoring fold in the comparison form of the device loop
+            float mnu = 3.402823466e+38f, mnv = mnu, mxu = -mnu, mxv = -mnu;
+            for (int b = 0; b < BX; b++) {
+                const float* r = res + 4 * ((size_t)i * BX + b);
+                if (r[0] < mnu) mnu = r[0];
+                if (r[1] < mnv) mnv = r[1];
+                if (r[2] > mxu) mxu = r[2];
+                if (r[3] > mxv) mxv = r[3];
+            }
+            float* o = out_minmax4 + 4 * (size_t)(start + i);
+            o[0] = mnu; o[1] = mnv; o[2] = mxu; o[3] = mxv;
+        }
     }
-    void* dk = nullptr;
-    void* dout = nullptr;
-    STX_TRY(stx_dev_alloc(ctx, sizeof(RoiK) * n, &dk));
-    STX_TRY(stx_dev_alloc(ctx, 16 * n, &dout));
-    std::vector<uint32_t> init(4 * n);
-    for (int i = 0; i < n; i++) {
-        // ordered encodings of +FLT_MAX (for the minima) and -FLT_MAX (for the maxima)
-        init[4 * i + 0] = init[4 * i + 1] = 0x7f7fffffu | 0x80000000u;
-        init[4 * i + 2] = init[4 * i + 3] = ~0xff7fffffu;
-    }
-    STX_HIP(hipMemcpyAsync(dk, hk.data(), sizeof(RoiK) * n, hipMemcpyHostToDevice, ctx->stream));
-    STX_HIP(hipMemcpyAsync(dout, init.data(), 16 * n, hipMemcpyHostToDevice, ctx->stream));
-    {
-        StxProfScope prof(ctx, "roi_border_minmax", 0.0);
-        int bx = std::min(64, (maxpts + 255) / 256);
-        hipLaunchKernelGGL(roi_kernel, dim3(bx, n), dim3(256), 0, ctx->stream, (const RoiK*)dk, (uint32_t*)dout);
-    }
-    std::vector<uint32_t> res(4 * n);
-    STX_HIP(hipMemcpyAsync(res.data(), dout, 16 * n, hipMemcpyDeviceToHost, ctx->stream));
-    STX_HIP(hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < 4 * n; i++) {
-        uint32_t u = res[i];
-        u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-        memcpy(&out_minmax4[i], &u, 4);
-    }
-    stx_dev_free(ctx, dk);
-    stx_dev_free(ctx, dout);
     return STX_OK;
 }

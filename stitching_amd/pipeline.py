@@ -49,8 +49,9 @@ class StitchJob:
 
     def run(self):
         """warp every frame, feed it, blend.  Returns device-resident (panorama u8x3, mask u8)."""
-        if self.corners is None:
-            self.plan()
+        # one panorama = one ROI pass (the reference's eager Warper.warp_rois, stitching/stitcher.py:188):
+        # it belongs to the pass and is re-run every time (batched: one device pass, one synchronisation)
+        self.plan()
         prev = config.device_resident()
         config.set_device_resident(True)
         try:
