@@ -1,0 +1,145 @@
+"""BASELINE.json full-size runs on the GPU, checked through size-independent properties (the oracle
+needs minutes at these sizes, so it is not run here):
+
+  * reproduction: one image fed with its full warped mask comes back as the image, minus the known
+    1-LSB darkening of normalizeUsingWeightMap (x / (1 + 1e-5) truncated);
+  * idempotence: feeding the same image twice gives the same panorama as feeding it once
+    (weights 2, sums doubled: the normalised Laplacians are identical);
+  * order independence of the integer sums: permuting the feed order leaves the panorama bit-identical
+    when every pixel is covered by at most 2 images with 0/1 weights (fp32 sums of small integers are exact);
+  * sharding: column bands + contribution strips equal the single blender bit for bit;
+  * config 4 / 5 shapes (cylindrical 7 bands on 8000x6000 sources; affine + feather / no) run and are
+    self-consistent (mask == panorama coverage, panorama zero outside the mask).
+"""
+import numpy as np
+import pytest
+
+import stitching_amd as S
+from stitching_amd import synthetic
+from stitching_amd.pipeline import StitchJob
+
+pytestmark = pytest.mark.gpu
+
+W, H = 4000, 3000
+
+
+@pytest.fixture(scope="module")
+def frames(gpu_ctx):
+    return [S.DeviceImage.from_numpy(synthetic.make_frame(i, W, H), gpu_ctx) for i in range(4)]
+
+
+def test_config2_single_image_is_reproduced(gpu_ctx, frames):
+    cams = synthetic.ring_cameras(1, W, H)
+    S.set_device_resident(True)
+    try:
+        w = S.Warper("spherical")
+        w.set_scale(cams)
+        img, mask, roi = w.warp_image_and_mask(frames[0], cams[0])
+        b = S.Blender("multiband", synthetic.blend_strength_for_bands(5, roi[2], roi[3]))
+        b.prepare([roi[0:2]], [roi[2:4]])
+        b.feed(img, mask, roi[0:2])
+        pano, pmask = b.blend()
+        assert b.blender.num_bands() == 5
+    finally:
+        S.set_device_resident(False)
+    img, mask, pano, pmask = (np.asarray(a) for a in (img, mask, pano, pmask))
+    assert pano.shape == img.shape and np.array_equal(pmask, mask)
+    # deep interior (every weight of every level is exactly 1 there): each of the 6 levels loses at most 1 through
+    # the truncating divide by (1 + 1e-5), so the collapsed panorama is the image within +-6
+    hh, ww = mask.shape
+    ys, xs = slice(hh // 4, 3 * hh // 4), slice(ww // 4, 3 * ww // 4)
+    assert mask[hh // 4 - 300:3 * hh // 4 + 300, ww // 4 - 300:3 * ww // 4 + 300].all()
+    d = img.astype(np.int16)[ys, xs] - pano.astype(np.int16)[ys, xs]
+    assert np.abs(d).max() <= 6, (d.min(), d.max())
+    assert np.mean(np.abs(d)) < 2.0
+    assert not pano[mask == 0].any()
+
+
+def _run(frames, cams, order=None, repeat=1, **kw):
+    job = StitchJob(frames, cams, num_bands=5, **kw)
+    job.plan()
+    S.set_device_resident(True)
+    try:
+        imgs, masks, rois = job.warper.warp_images_and_masks(job.frames, job.cameras)
+        b = S.Blender("multiband", job.blend_strength)
+        b.prepare(job.corners, job.warped_sizes)
+        idx = list(range(len(frames))) if order is None else order
+        for _ in range(repeat):
+            for i in idx:
+                b.feed(imgs[i], masks[i], job.corners[i])
+        pano, pmask = b.blend()
+    finally:
+        S.set_device_resident(False)
+    return np.asarray(pano), np.asarray(pmask)
+
+
+def test_config2_feed_twice_and_feed_order(gpu_ctx, frames):
+    cams = synthetic.ring_cameras(8, W, H)[:4]
+    p1, m1 = _run(frames, cams)
+    p2, m2 = _run(frames, cams, repeat=2)
+    assert np.array_equal(m1, m2)
+    # doubled sums / doubled weights: (2a) / (2w + eps) vs a / (w + eps) may differ by the truncation tie only
+    d = np.abs(p1.astype(np.int16) - p2.astype(np.int16))
+    assert d.max() <= 1 and np.count_nonzero(d) < 0.02 * d.size
+    p3, m3 = _run(frames, cams, order=[3, 1, 0, 2])
+    assert np.array_equal(m1, m3)
+    d3 = np.abs(p1.astype(np.int16) - p3.astype(np.int16))
+    # int16 sums are order independent; fp32 weight sums differ at ULP level only where > 2 images overlap
+    assert d3.max() <= 1 and np.count_nonzero(d3) < 1e-4 * d3.size
+
+
+def test_config3_sharded_equals_single_full_size(gpu_ctx, frames):
+    from stitching_amd.distributed import virtual_sharded_blend
+
+    cams = synthetic.ring_cameras(8, W, H)[:4]
+    job = StitchJob(frames, cams, num_bands=5)
+    job.plan()
+    S.set_device_resident(True)
+    try:
+        imgs, masks, rois = job.warper.warp_images_and_masks(job.frames, job.cameras)
+        b = S.Blender("multiband", job.blend_strength)
+        b.prepare(job.corners, job.warped_sizes)
+        for i in range(4):
+            b.feed(imgs[i], masks[i], job.corners[i])
+        nb = b.blender.num_bands()
+        pano, pmask = (np.asarray(a) for a in b.blend())
+        roi = S.Blender.result_roi(job.corners, job.warped_sizes)
+        req = int(np.log(np.sqrt(roi[2] * roi[3]) * job.blend_strength / 100) / np.log(2.0) - 1.0)
+        sp, sm, plan = virtual_sharded_blend(gpu_ctx, imgs, masks, job.corners, job.warped_sizes, 2, req)
+    finally:
+        S.set_device_resident(False)
+    assert plan.num_bands == nb == 5 and plan.exchanged_bytes() > 0
+    assert np.array_equal(sm, pmask) and np.array_equal(sp, pano)
+
+
+def test_config4_cylindrical_7_bands_large_sources(gpu_ctx):
+    w, h = 8000, 6000
+    fr = [S.DeviceImage.from_numpy(synthetic.make_frame(i, w, h), gpu_ctx) for i in range(3)]
+    cams = synthetic.ring_cameras(8, w, h)[:3]
+    job = StitchJob(fr, cams, warper_type="cylindrical", num_bands=7)
+    pano, pmask = (np.asarray(a) for a in job.run())
+    assert job.last_num_bands == 7
+    assert pano.shape[:2] == pmask.shape and pmask.any()
+    assert set(np.unique(pmask)) <= {0, 255}
+    assert not pano[pmask == 0].any()
+    # every warped image lies inside the panorama and is covered by the mask
+    cov = np.count_nonzero(pmask) / pmask.size
+    assert 0.5 < cov <= 1.0
+
+
+@pytest.mark.parametrize("btype", ["feather", "no"])
+def test_config5_affine_tiles(gpu_ctx, btype):
+    tiles = [synthetic.make_frame(i, W, H) for i in range(4)]
+    cams = synthetic.affine_scan_cameras(4, W, H)
+    job = StitchJob(tiles, cams, warper_type="affine", blender_type=btype)
+    pano, pmask = (np.asarray(a) for a in job.run())
+    assert pano.shape[:2] == pmask.shape
+    assert not pano[pmask == 0].any()
+    if btype == "no":
+        # masked overwrite: the last fed tile is visible unchanged where it lies
+        x, y = job.corners[3][0] - min(c[0] for c in job.corners), job.corners[3][1] - min(c[1] for c in job.corners)
+        wi, _, _ = job.warper.warp_image_and_mask(tiles[3], cams[3])
+        wi = np.asarray(wi)
+        sub = pano[y:y + wi.shape[0], x:x + wi.shape[1]]
+        m = np.asarray(job.warper.create_and_warp_mask((W, H), cams[3])) > 0
+        assert np.array_equal(sub[m], wi[m])
