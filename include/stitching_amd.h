@@ -174,6 +174,13 @@ int stx_comm_unique_id(unsigned char out[128]);
 int stx_comm_create(stx_ctx* ctx, int nranks, int rank, const unsigned char id[128], stx_comm** out);
 int stx_comm_exchange(stx_comm* comm, int n_ops, const int* peers, const int* is_send, void* const* dev_ptrs,
                       const size_t* bytes);
+/* split form: _begin issues the group on the communicator's own stream, ordered after everything queued so far
+ * on the context stream; kernels queued on the context stream between _begin and _end (warps and pyramids of
+ * images that send nothing) overlap with the transfer; _end orders the context stream after the transfer.
+ * The buffers must stay alive until _end has been called. */
+int stx_comm_exchange_begin(stx_comm* comm, int n_ops, const int* peers, const int* is_send, void* const* dev_ptrs,
+                            const size_t* bytes);
+int stx_comm_exchange_end(stx_comm* comm);
 int stx_comm_destroy(stx_comm* comm);
 
 /* ---- measurement hooks (bench.py) -----------------------------------------------------

@@ -1,8 +1,9 @@
 // stx_comm.cpp — RCCL point-to-point exchange of contribution strips over xGMI.
 // librccl is loaded lazily (dlopen) by stx_comm_unique_id / stx_comm_create: single-GPU users never
-// touch it.  All sends and receives of one exchange are issued as ONE RCCL group on the context's
-// HIP stream, i.e. ordered after the kernels that produced the strips and before the gather kernels
-// that consume them — no host synchronisation in between.
+// touch it.  All sends and receives of one exchange are issued as ONE RCCL group on the communicator's
+// own HIP stream, ordered by events after the kernels that produced the strips (context stream) and
+// before the gather kernels that consume them — no host synchronisation in between, and kernels that
+// do not depend on the strips overlap with the transfer.
 #include <dlfcn.h>
 
 #include <cstring>
@@ -68,6 +69,11 @@ struct stx_comm {
     stx_ctx* ctx;
     RcclComm comm;
     int nranks, rank;
+    // exchanges run on their own stream so that independent kernels queued on the context stream after
+    // stx_comm_exchange_begin overlap with the transfer
+    hipStream_t stream = nullptr;
+    hipEvent_t ready = nullptr, done = nullptr;
+    bool in_flight = false;
 };
 
 STX_EXPORT int stx_comm_unique_id(unsigned char out[128])
@@ -96,39 +102,73 @@ STX_EXPORT int stx_comm_create(stx_ctx* ctx, int nranks, int rank, const unsigne
     return STX_OK;
 }
 
-STX_EXPORT int stx_comm_exchange(stx_comm* comm, int n_ops, const int* peers, const int* is_send, void* const* dev_ptrs,
-                                 const size_t* bytes)
+STX_EXPORT int stx_comm_exchange_begin(stx_comm* comm, int n_ops, const int* peers, const int* is_send, void* const* dev_ptrs,
+                                       const size_t* bytes)
 {
     if (!comm || n_ops < 0 || (n_ops && (!peers || !is_send || !dev_ptrs || !bytes)))
         return stx_fail(STX_ERR_INVALID, "bad argument");
-    if (n_ops == 0) return STX_OK;
+    if (comm->in_flight) return stx_fail(STX_ERR_STATE, "an exchange is already in flight on this communicator");
     STX_TRY(stx_set_device(comm->ctx));
     for (int i = 0; i < n_ops; i++)
         if (peers[i] < 0 || peers[i] >= comm->nranks || !dev_ptrs[i])
             return stx_fail(STX_ERR_INVALID, "exchange op %d: peer %d / null buffer", i, peers[i]);
-    StxProfScope prof(comm->ctx, "rccl_exchange", 0.0);
-    STX_RCCL(g_rccl.GroupStart());
-    for (int i = 0; i < n_ops; i++) {
-        int r = is_send[i] ? g_rccl.Send(dev_ptrs[i], bytes[i], RCCL_UINT8, peers[i], comm->comm, comm->ctx->stream)
-                           : g_rccl.Recv(dev_ptrs[i], bytes[i], RCCL_UINT8, peers[i], comm->comm, comm->ctx->stream);
-        if (r != 0) {
-            g_rccl.GroupEnd();
-            return stx_fail(STX_ERR_HIP, "rccl %s to/from rank %d failed: %s", is_send[i] ? "send" : "recv", peers[i],
-                            g_rccl.GetErrorString(r));
-        }
+    if (!comm->stream) {
+        STX_HIP(hipStreamCreateWithFlags(&comm->stream, hipStreamNonBlocking));
+        STX_HIP(hipEventCreateWithFlags(&comm->ready, hipEventDisableTiming));
+        STX_HIP(hipEventCreateWithFlags(&comm->done, hipEventDisableTiming));
     }
-    STX_RCCL(g_rccl.GroupEnd());
+    // the transfer starts after everything queued so far on the context stream (the kernels that filled the
+    // send buffers, the last users of the memory behind the receive buffers) ...
+    STX_HIP(hipEventRecord(comm->ready, comm->ctx->stream));
+    STX_HIP(hipStreamWaitEvent(comm->stream, comm->ready, 0));
+    if (n_ops > 0) {
+        STX_RCCL(g_rccl.GroupStart());
+        for (int i = 0; i < n_ops; i++) {
+            int r = is_send[i] ? g_rccl.Send(dev_ptrs[i], bytes[i], RCCL_UINT8, peers[i], comm->comm, comm->stream)
+                               : g_rccl.Recv(dev_ptrs[i], bytes[i], RCCL_UINT8, peers[i], comm->comm, comm->stream);
+            if (r != 0) {
+                g_rccl.GroupEnd();
+                return stx_fail(STX_ERR_HIP, "rccl %s to/from rank %d failed: %s", is_send[i] ? "send" : "recv", peers[i],
+                                g_rccl.GetErrorString(r));
+            }
+        }
+        STX_RCCL(g_rccl.GroupEnd());
+    }
+    STX_HIP(hipEventRecord(comm->done, comm->stream));
+    comm->in_flight = true;
     return STX_OK;
+}
+
+// ... and everything queued on the context stream after this call sees the received strips
+STX_EXPORT int stx_comm_exchange_end(stx_comm* comm)
+{
+    if (!comm) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (!comm->in_flight) return STX_OK;
+    STX_TRY(stx_set_device(comm->ctx));
+    STX_HIP(hipStreamWaitEvent(comm->ctx->stream, comm->done, 0));
+    comm->in_flight = false;
+    return STX_OK;
+}
+
+STX_EXPORT int stx_comm_exchange(stx_comm* comm, int n_ops, const int* peers, const int* is_send, void* const* dev_ptrs,
+                                 const size_t* bytes)
+{
+    STX_TRY(stx_comm_exchange_begin(comm, n_ops, peers, is_send, dev_ptrs, bytes));
+    return stx_comm_exchange_end(comm);
 }
 
 STX_EXPORT int stx_comm_destroy(stx_comm* comm)
 {
     if (!comm) return STX_OK;
+    hipSetDevice(comm->ctx->device);
+    if (comm->stream) hipStreamSynchronize(comm->stream);
     if (g_rccl.handle && comm->comm) {
-        hipSetDevice(comm->ctx->device);
         hipStreamSynchronize(comm->ctx->stream);
         g_rccl.CommDestroy(comm->comm);
     }
+    if (comm->ready) hipEventDestroy(comm->ready);
+    if (comm->done) hipEventDestroy(comm->done);
+    if (comm->stream) hipStreamDestroy(comm->stream);
     delete comm;
     return STX_OK;
 }

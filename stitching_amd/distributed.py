@@ -157,11 +157,21 @@ class GlooHostTransport:
 
     def __init__(self, dist, ctx):
         self.dist, self.ctx = dist, ctx
+        self._pending = None
 
     def exchange(self, sends, recvs):
         """sends: [(dst, DeviceImage packed, nbytes)], recvs: [(src, nbytes)] -> [DeviceImage]"""
         host_sends = [(dst, np.asarray(packed).reshape(-1)[:nbytes]) for dst, packed, nbytes in sends]
         return [flat_device_buffer(self.ctx, a) for a in gloo_exchange_host(self.dist, host_sends, recvs)]
+
+    # split form (same contract as RcclTransport): the host-staged exchange has nothing to overlap, it runs in finish()
+    def start(self, sends, recvs):
+        self._pending = (sends, recvs)
+
+    def finish(self):
+        sends, recvs = self._pending
+        self._pending = None
+        return self.exchange(sends, recvs)
 
 
 def gloo_exchange_host(dist, sends, recvs):
@@ -208,6 +218,7 @@ class RcclTransport:
         uid = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
         _lib.check(ctx._lib.stx_comm_create(ctx.handle, int(world), int(rank), uid, C.byref(h)))
         self._h = h
+        self._inflight = self._sent = None
 
     @staticmethod
     def unique_id():
@@ -215,12 +226,14 @@ class RcclTransport:
         _lib.check(_lib.lib().stx_comm_unique_id(uid))
         return bytes(uid)
 
-    def exchange(self, sends, recvs):
+    def start(self, sends, recvs):
+        """Issue the exchange on the communicator's stream (after everything queued so far on the context
+        stream).  Kernels launched on the context stream until finish() overlap with the transfer."""
         lib = self.ctx._lib
         rbufs = []
         n = len(sends) + len(recvs)
-        peers, is_send = (C.c_int * n)(), (C.c_int * n)()
-        ptrs, sizes = (C.c_void_p * n)(), (C.c_size_t * n)()
+        peers, is_send = (C.c_int * max(n, 1))(), (C.c_int * max(n, 1))()
+        ptrs, sizes = (C.c_void_p * max(n, 1))(), (C.c_size_t * max(n, 1))()
         i = 0
         for src, nbytes in recvs:
             out = C.c_void_p()
@@ -233,9 +246,19 @@ class RcclTransport:
         for dst, packed, nbytes in sends:
             peers[i], is_send[i], ptrs[i], sizes[i] = dst, 1, packed.device_ptr(), nbytes
             i += 1
-        if n:
-            _lib.check(lib.stx_comm_exchange(self._h, n, peers, is_send, ptrs, sizes))
+        _lib.check(lib.stx_comm_exchange_begin(self._h, n, peers, is_send, ptrs, sizes))
+        self._inflight = (rbufs, [p for _, p, _ in sends])  # both sides stay alive until finish()
+
+    def finish(self):
+        """Order the context stream after the transfer; returns the received strips."""
+        _lib.check(self.ctx._lib.stx_comm_exchange_end(self._h))
+        rbufs, self._sent = self._inflight  # sent strips are released on the next start() / close()
+        self._inflight = None
         return rbufs
+
+    def exchange(self, sends, recvs):
+        self.start(sends, recvs)
+        return self.finish()
 
     def close(self):
         if self._h is not None:
@@ -299,30 +322,50 @@ class ShardedStitchJob:
         """warp + feed local images, exchange contribution strips, blend this rank's band.
         Returns device-resident (band u8x3, band mask u8)."""
         p = self.plan_ or self.plan()
+        # this rank's share of the ROI pass belongs to every panorama (as in StitchJob.run)
+        local = {k: i for i, k in enumerate(self.my_orders)}
+        corners, _ = self.warper.warp_rois([self.all_sizes[k] for k in self.my_orders], self.cameras)
+        if [tuple(c) for c in corners] != [p.corners[k] for k in self.my_orders]:
+            raise StitchingError("warp rois changed between plan() and run()")
         prev = config.device_resident()
         config.set_device_resident(True)
         try:
             blender = make_shard_blender(self.ctx, self.roi, self.req_bands)
             blender.set_band(*p.band(self.rank))
-            for frame, cam, k in zip(self.frames, self.cameras, self.my_orders):
-                img, mask, roi = self.warper.warp_image_and_mask(frame, cam)
-                if roi[0:2] != p.corners[k]:
-                    raise StitchingError("warp roi changed between plan() and run()")
-                blender.feed_ex(img, mask, p.corners[k], k)
+            send_msgs = p.sends(self.rank)
+            recv_msgs = p.recvs(self.rank)
+            # 1. the images that owe strips to other ranks: warp, feed, export, start the exchange
+            senders = sorted({m[0] for m in send_msgs})
+            self._warp_and_feed(blender, [k for k in self.my_orders if k in senders], p)
             sends = []
-            for (k, _src, dst, rect, nbytes) in p.sends(self.rank):
+            for (k, _src, dst, rect, nbytes) in send_msgs:
                 packed, r = blender.export_contrib(k, p.band(dst))
                 if r != rect:
                     raise StitchingError("contribution geometry differs from the plan")
                 sends.append((dst, packed, nbytes))
-            recv_msgs = p.recvs(self.rank)
-            rbufs = self.transport.exchange(sends, [(m[1], m[4]) for m in recv_msgs])
+            self.transport.start(sends, [(m[1], m[4]) for m in recv_msgs])
+            # 2. the other images of this rank are warped and fed while the strips travel
+            self._warp_and_feed(blender, [k for k in self.my_orders if k not in senders], p)
+            # 3. received strips join the image table in global feed order; blend this rank's band
+            rbufs = self.transport.finish()
             for m, buf in zip(recv_msgs, rbufs):
                 blender.feed_contrib(m[0], m[3], buf)
             pano, mask = blender.blend()
         finally:
             config.set_device_resident(prev)
         return pano, mask
+
+    def _warp_and_feed(self, blender, orders, p):
+        if not orders:
+            return
+        local = {k: i for i, k in enumerate(self.my_orders)}
+        frames = [self.frames[local[k]] for k in orders]
+        cams = [self.cameras[local[k]] for k in orders]
+        imgs, masks, rois = self.warper.warp_images_and_masks(frames, cams)
+        for k, img, mask, roi in zip(orders, imgs, masks, rois):
+            if roi[0:2] != p.corners[k]:
+                raise StitchingError("warp roi changed between plan() and run()")
+            blender.feed_ex(img, mask, p.corners[k], k)
 
     def gather(self, pano, mask):
         """Assemble the full panorama on rank 0 (host side, outside any timed region)."""
@@ -374,6 +417,12 @@ class _NullTransport:
     def exchange(self, sends, recvs):
         if sends or recvs:
             raise StitchingError("no transport for a single-rank job")
+        return []
+
+    def start(self, sends, recvs):
+        self.exchange(sends, recvs)
+
+    def finish(self):
         return []
 
 

@@ -218,3 +218,65 @@ def test_batched_warp_equals_per_image(oracle, gpu_ctx, wtype):
         assert rois[i] == o.warp_roi(sizes[i], cams[i])
         assert np.array_equal(np.asarray(gi[i]), o.warp_image(imgs[i], cams[i])), f"image {i}"
         assert np.array_equal(np.asarray(gm[i]), o.create_and_warp_mask(sizes[i], cams[i])), f"mask {i}"
+
+
+def test_sharded_job_bands_equal_single_job(oracle, gpu_ctx):
+    """ShardedStitchJob.run() as bench.py drives it for N > 1 (boundary images first, exchange in flight while
+    the interior images are warped), both ranks executed one after the other on this GPU: pass 1 records
+    every rank's outgoing strips, pass 2 replays them as the incoming ones.  The concatenated bands are the
+    single-job panorama bit for bit."""
+    from stitching_amd.distributed import ShardedStitchJob, flat_device_buffer
+    from stitching_amd.pipeline import StitchJob
+
+    world, n, w, h = 2, 6, 803, 601
+    cams = synthetic.ring_cameras(n, w, h, span_deg=40.0 * n)
+    frames = [synthetic.make_frame(i, w, h) for i in range(n)]
+    single = StitchJob(frames, cams, num_bands=4)
+    pano, pmask = (np.asarray(a) for a in single.run())
+
+    class Recorder:
+        def __init__(self):
+            self.sent = []
+
+        def start(self, sends, recvs):
+            self.sent = [(dst, np.asarray(p).reshape(-1)[:nb].copy()) for dst, p, nb in sends]
+            self.recvs = recvs
+
+        def finish(self):
+            return [flat_device_buffer(gpu_ctx, np.zeros(nb, np.uint8)) for _, nb in self.recvs]
+
+    class Replay:
+        def __init__(self, inbox):
+            self.inbox = inbox
+
+        def start(self, sends, recvs):
+            self.recvs = recvs
+
+        def finish(self):
+            out = []
+            for src, nb in self.recvs:
+                a = self.inbox[src].pop(0)
+                assert a.size == nb
+                out.append(flat_device_buffer(gpu_ctx, a))
+            return out
+
+    per = n // world
+    jobs, recs = [], []
+    for r in range(world):
+        rec = Recorder()
+        job = ShardedStitchJob(frames[r * per:(r + 1) * per], cams[r * per:(r + 1) * per], cams, r, world, num_bands=4,
+                               ctx=gpu_ctx, transport=rec)
+        job.plan()
+        job.run()
+        jobs.append(job)
+        recs.append(rec)
+    assert jobs[0].last_num_bands == single.last_num_bands
+    bands = []
+    for r in range(world):
+        inbox = {src: [a for dst, a in recs[src].sent if dst == r] for src in range(world) if src != r}
+        jobs[r].transport = Replay(inbox)
+        bands.append(tuple(np.asarray(a) for a in jobs[r].run()))
+    sp = np.concatenate([b[0] for b in bands], axis=1)
+    sm = np.concatenate([b[1] for b in bands], axis=1)
+    assert sp.shape == pano.shape
+    assert np.array_equal(sm, pmask) and np.array_equal(sp, pano)
