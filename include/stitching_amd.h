@@ -163,6 +163,13 @@ int stx_blend_contrib_rect(const stx_blender* b, int img_w, int img_h, int tlx, 
 int stx_blend_export_contrib(stx_blender* b, int order, int band_x0, int band_x1, stx_buf** out_packed,
                              int out_rect_xywh[4]);
 int stx_blend_feed_contrib(stx_blender* b, int order, const int rect_xywh[4], const stx_buf* packed);
+/* flags travel with a strip over the caller's control plane.  STX_CONTRIB_U8_BINARY: the strip was exported from
+ * a u8 image whose mask holds only 0 / 255 (then its products are L or 0 and its weights 0.f or 1.f, and the
+ * receiver may keep the packed 16-bit level-0 kernel).  stx_buf_flags reads it off an exported strip (or a mask:
+ * the same bit says "only 0 / 255"). */
+#define STX_CONTRIB_U8_BINARY 1
+int stx_blend_feed_contrib_ex(stx_blender* b, int order, const int rect_xywh[4], const stx_buf* packed, int flags);
+int stx_buf_flags(const stx_buf* buf, int* out_flags);
 
 /* ---- RCCL strip exchange over xGMI ---------------------------------------------------------------
  * One communicator per rank (one process per GPU).  stx_comm_exchange issues every send / receive

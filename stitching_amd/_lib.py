@@ -18,6 +18,7 @@ INTER_NEAREST, INTER_LINEAR = 0, 1
 BORDER_CONSTANT, BORDER_REFLECT = 0, 2
 BLEND_NO, BLEND_FEATHER, BLEND_MULTIBAND = 0, 1, 2
 U8, S16, F32 = 0, 1, 2
+CONTRIB_U8_BINARY = 1
 
 EXPORTS = (
     "stx_version stx_last_error stx_device_count stx_ctx_create stx_ctx_destroy stx_ctx_sync "
@@ -25,7 +26,7 @@ EXPORTS = (
     "stx_warp_roi stx_warp_rois stx_warp stx_warp_image_and_mask stx_warp_batch stx_warp_mask "
     "stx_result_roi stx_blend_create stx_blend_num_bands stx_blend_feed stx_blend_finish stx_blend_finish_ex "
     "stx_blend_destroy stx_blend_set_band stx_blend_feed_ex stx_blend_contrib_rect stx_blend_export_contrib "
-    "stx_blend_feed_contrib stx_comm_unique_id stx_comm_create stx_comm_exchange stx_comm_exchange_begin stx_comm_exchange_end stx_comm_destroy stx_prof_enable stx_prof_reset stx_prof_count stx_prof_get stx_mark stx_mark_elapsed_ms"
+    "stx_blend_feed_contrib stx_blend_feed_contrib_ex stx_buf_flags stx_comm_unique_id stx_comm_create stx_comm_exchange stx_comm_exchange_begin stx_comm_exchange_end stx_comm_destroy stx_prof_enable stx_prof_reset stx_prof_count stx_prof_get stx_mark stx_mark_elapsed_ms"
 ).split()
 
 _lib = None
@@ -78,6 +79,8 @@ def lib():
                                          C.POINTER(C.c_size_t)]
     L.stx_blend_export_contrib.argtypes = [vp, C.c_int, C.c_int, C.c_int, vpp, ip]
     L.stx_blend_feed_contrib.argtypes = [vp, C.c_int, ip, vp]
+    L.stx_blend_feed_contrib_ex.argtypes = [vp, C.c_int, ip, vp, C.c_int]
+    L.stx_buf_flags.argtypes = [vp, ip]
     L.stx_comm_unique_id.argtypes = [C.POINTER(C.c_ubyte)]
     L.stx_comm_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte), vpp]
     L.stx_comm_exchange.argtypes = [vp, C.c_int, ip, ip, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]

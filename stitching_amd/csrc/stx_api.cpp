@@ -385,6 +385,13 @@ STX_EXPORT int stx_buf_info(const stx_buf* buf, int64_t info[6])
     return STX_OK;
 }
 
+STX_EXPORT int stx_buf_flags(const stx_buf* buf, int* out_flags)
+{
+    if (!buf || !out_flags) return stx_fail(STX_ERR_INVALID, "null argument");
+    *out_flags = buf->mask_binary ? STX_CONTRIB_U8_BINARY : 0;
+    return STX_OK;
+}
+
 STX_EXPORT int stx_buf_device_ptr(const stx_buf* buf, void** out)
 {
     if (!buf || !out) return stx_fail(STX_ERR_INVALID, "null argument");
@@ -1117,7 +1124,7 @@ static int mb_finish(stx_blender* b, stx_buf* pano, stx_buf* pmask, stx_buf* pan
     for (const StxMbImage& im : b->images) {
         if (im.kind == 0 && im.img0_is_s16) all_u8 = false;
         if (im.kind == 1) has_contrib = true;
-        if (im.kind != 0 || im.img0_is_s16 || !im.mask_binary) pk_ok = false;
+        if ((im.kind == 0 && im.img0_is_s16) || !im.mask_binary) pk_ok = false;
     }
     int xb[STX_MAX_BANDS + 1], xe[STX_MAX_BANDS + 1];
     mb_level_regions(b, b->band_x0, b->band_x1, xb, xe);
@@ -1228,11 +1235,17 @@ STX_EXPORT int stx_blend_export_contrib(stx_blender* b, int order, int band_x0, 
     }
     if (rc != STX_OK) { stx_buf_release(packed); return rc; }
     out_rect_xywh[0] = sx0; out_rect_xywh[1] = one.fy; out_rect_xywh[2] = sw; out_rect_xywh[3] = sh;
+    packed->mask_binary = (!one.img0_is_s16 && one.mask_binary) ? 1 : 0;  // read back with stx_buf_flags
     *out_packed = packed;
     return STX_OK;
 }
 
 STX_EXPORT int stx_blend_feed_contrib(stx_blender* b, int order, const int rect_xywh[4], const stx_buf* packed)
+{
+    return stx_blend_feed_contrib_ex(b, order, rect_xywh, packed, 0);
+}
+
+STX_EXPORT int stx_blend_feed_contrib_ex(stx_blender* b, int order, const int rect_xywh[4], const stx_buf* packed, int flags)
 {
     if (!b || !rect_xywh || !packed) return stx_fail(STX_ERR_INVALID, "null argument");
     if (b->kind != STX_BLEND_MULTIBAND) return stx_fail(STX_ERR_UNSUPPORTED, "multi-band blender only");
@@ -1250,6 +1263,7 @@ STX_EXPORT int stx_blend_feed_contrib(stx_blender* b, int order, const int rect_
     memset(&im, 0, sizeof(im));
     im.kind = 1;
     im.order = order;
+    im.mask_binary = (flags & STX_CONTRIB_U8_BINARY) ? 1 : 0;
     im.fx = x; im.fy = y; im.fw = w; im.fh = h;
     for (int i = 0; i <= nb; i++) {
         im.g[i] = (short*)(packed->ptr + L.g_off[i]); im.g_stride[i] = L.g_stride[i];

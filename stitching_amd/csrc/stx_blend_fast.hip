@@ -687,6 +687,7 @@ STX_DEV uint32_t pair_mask(const uint32_t* m)
     return __builtin_amdgcn_perm(m[B >> 2], m[A >> 2], sel);
 }
 
+template <bool CONTRIB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void mb_level0_pk_kernel(MbLevelK P)
 {
     __shared__ int s_list[64];
@@ -713,7 +714,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             bool hit = false;
             if (k < P.n_images) {
                 const StxMbImage& im = P.images[k];
-                hit = im.ix < tile_x + 512 && im.ix + im.iw > tile_x && im.iy < tile_y + 8 && im.iy + im.ih > tile_y;
+                int rx = im.ix, ry = im.iy, rw = im.iw, rh = im.ih;
+                if (CONTRIB && im.kind == 1) { rx = im.fx; ry = im.fy; rw = im.fw; rh = im.fh; }
+                hit = rx < tile_x + 512 && rx + rw > tile_x && ry < tile_y + 8 && ry + rh > tile_y;
             }
             const unsigned long long m = __ballot(hit);
             if (hit) s_list[__popcll(m & ((1ull << tid) - 1ull))] = k;
@@ -725,6 +728,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             const int k = __builtin_amdgcn_readfirstlane(s_list[i]);
             const StxMbImage& im = P.images[k];
             if (!active) continue;
+            if (CONTRIB && im.kind == 1) {
+                // strip received from another rank: rows hold (short)(L * W) = L or 0 and W = 0.f / 1.f
+                const int cx0 = X0 - im.fx, cy0 = Y0 - im.fy;
+                if ((unsigned)cx0 >= (unsigned)im.fw || (unsigned)cy0 >= (unsigned)im.fh) continue;
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const v4u gv = *reinterpret_cast<const STX_GAS v4u*>(
+                            gp(im.g[0]) + c * im.g_plane[0] + ((uint32_t)(cy0 + r) * (uint32_t)im.g_stride[0] + (uint32_t)cx0));
+                        acc[r][c][0] = unpk(pk(acc[r][c][0]) + pk(__builtin_amdgcn_perm(gv.y, gv.x, 0x05040100u)));
+                        acc[r][c][1] = unpk(pk(acc[r][c][1]) + pk(__builtin_amdgcn_perm(gv.w, gv.z, 0x05040100u)));
+                        acc[r][c][2] = unpk(pk(acc[r][c][2]) + pk(__builtin_amdgcn_perm(gv.y, gv.x, 0x07060302u)));
+                        acc[r][c][3] = unpk(pk(acc[r][c][3]) + pk(__builtin_amdgcn_perm(gv.w, gv.z, 0x07060302u)));
+                    }
+                    const STX_GAS float* wq = gp(im.wt[0]) + ((uint32_t)(cy0 + r) * (uint32_t)im.wt_stride[0] + (uint32_t)cx0);
+                    const v4u w0 = *reinterpret_cast<const STX_GAS v4u*>(wq), w1 = *reinterpret_cast<const STX_GAS v4u*>(wq + 4);
+                    // 1.f = 0x3f800000, 0.f = 0: bit 23 is the count
+                    const uint32_t i0 = (w0.x >> 23) & 1u, i1 = (w0.y >> 23) & 1u, i2 = (w0.z >> 23) & 1u, i3 = (w0.w >> 23) & 1u;
+                    const uint32_t i4 = (w1.x >> 23) & 1u, i5 = (w1.y >> 23) & 1u, i6 = (w1.z >> 23) & 1u, i7 = (w1.w >> 23) & 1u;
+                    cnt[r][0] = unpk(pk(cnt[r][0]) + pk(i0 | (i2 << 16)));
+                    cnt[r][1] = unpk(pk(cnt[r][1]) + pk(i4 | (i6 << 16)));
+                    cnt[r][2] = unpk(pk(cnt[r][2]) + pk(i1 | (i3 << 16)));
+                    cnt[r][3] = unpk(pk(cnt[r][3]) + pk(i5 | (i7 << 16)));
+                }
+                continue;
+            }
             const int lx0 = X0 - im.ix, ly0 = Y0 - im.iy;
             if (lx0 + 8 <= 0 || lx0 >= im.iw || ly0 + 2 <= 0 || ly0 >= im.ih) continue;
             const bool fastx = lx0 >= 0 && lx0 + 8 <= im.iw;
@@ -856,8 +886,9 @@ bool stx_fast_mb_level(stx_ctx* ctx, const MbLevelK& K)
     if (K.n_images > 255) return false;
     dim3 grid((K.x1 - K.x0 + 511) / 512, (K.y1 - K.y0 + 7) / 8);
     hipStream_t st = ctx->stream;
-    if (K.level == 0 && K.pk_ok && !K.emit && !K.has_contrib && K.num_bands > 0) {
-        hipLaunchKernelGGL(mb_level0_pk_kernel, grid, dim3(256), 0, st, K);
+    if (K.level == 0 && K.pk_ok && !K.emit && K.num_bands > 0) {
+        if (K.has_contrib) hipLaunchKernelGGL(mb_level0_pk_kernel<true>, grid, dim3(256), 0, st, K);
+        else hipLaunchKernelGGL(mb_level0_pk_kernel<false>, grid, dim3(256), 0, st, K);
     } else if (K.emit) {
         if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, true>), grid, dim3(256), 0, st, K);
         else hipLaunchKernelGGL((mb_level_fast_kernel<false, false, true>), grid, dim3(256), 0, st, K);

@@ -52,9 +52,9 @@ class ShardBlender(_BlenderHandle):
                                                           rect))
         return DeviceImage(self.ctx, out), tuple(int(v) for v in rect)
 
-    def feed_contrib(self, order, rect, packed):
+    def feed_contrib(self, order, rect, packed, flags=0):
         r = (C.c_int * 4)(*[int(v) for v in rect])
-        _lib.check(self.ctx._lib.stx_blend_feed_contrib(self._h, int(order), r, packed._h))
+        _lib.check(self.ctx._lib.stx_blend_feed_contrib_ex(self._h, int(order), r, packed._h, int(flags)))
 
 
 class GeometryContext:
@@ -348,8 +348,9 @@ class ShardedStitchJob:
             self._warp_and_feed(blender, [k for k in self.my_orders if k not in senders], p)
             # 3. received strips join the image table in global feed order; blend this rank's band
             rbufs = self.transport.finish()
+            # every strip of this job comes from a u8 warp with a 0 / 255 mask (warp_images_and_masks on all ranks)
             for m, buf in zip(recv_msgs, rbufs):
-                blender.feed_contrib(m[0], m[3], buf)
+                blender.feed_contrib(m[0], m[3], buf, _lib.CONTRIB_U8_BINARY)
             pano, mask = blender.blend()
         finally:
             config.set_device_resident(prev)
@@ -447,7 +448,9 @@ def virtual_sharded_blend(ctx, warped, masks, corners, sizes, world, num_bands):
     for (k, src, dst, rect, nbytes) in plan.messages:
         packed, r = blenders[src].export_contrib(k, plan.band(dst))
         assert r == rect, (r, rect)
-        blenders[dst].feed_contrib(k, rect, packed)
+        fl = C.c_int()
+        _lib.check(ctx._lib.stx_buf_flags(packed._h, C.byref(fl)))  # in-process hand-over: the flag rides along
+        blenders[dst].feed_contrib(k, rect, packed, fl.value)
     bands = [b.blend() for b in blenders]
     pano = np.concatenate([np.asarray(p) for p, _ in bands], axis=1)
     mask = np.concatenate([np.asarray(m) for _, m in bands], axis=1)
