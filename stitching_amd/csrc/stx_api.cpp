@@ -292,7 +292,8 @@ int stx_buf_new(stx_ctx* ctx, int w, int h, int c, int elem, stx_buf** out)
     b->w = w; b->h = h; b->c = c; b->elem = elem;
     // rows are 64-byte aligned and hold a whole number of 8-pixel groups (kernels store 4 or 8 px per lane)
     b->stride = align_up(align_up((size_t)w, 8) * c * stx_elem_bytes(elem), 64);
-    STX_TRY(stx_dev_alloc(ctx, b->stride * h, &b->base));
+    // + 64: the gather kernels read whole dwords around the last pixels of the last row
+    STX_TRY(stx_dev_alloc(ctx, b->stride * h + 64, &b->base));
     b->ptr = (uint8_t*)b->base;
     *out = b.release();
     return STX_OK;

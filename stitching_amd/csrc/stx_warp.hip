@@ -295,6 +295,41 @@ STX_DEV uint32_t sample_generic(const WarpK& P, float x, float yy)
     return b | (g << 8) | (rr << 16);
 }
 
+// One BORDER_REFLECT tap: the 3 bytes of source pixel (sx, sy) in the low 24 bits (32-bit offsets, global loads)
+STX_DEV uint32_t tap24(const STX_GAS uint8_t* src, uint32_t stride, int sx, int sy)
+{
+    const uint32_t off = (uint32_t)sy * stride + (uint32_t)sx * 3u;
+    const STX_GAS uint32_t* q = reinterpret_cast<const STX_GAS uint32_t*>(src + (off & ~3u));
+    return __builtin_amdgcn_alignbyte(q[1], q[0], off & 3u);
+}
+
+// remapBilinear with BORDER_REFLECT on every tap (borderInterpolate per tap, cvRound / short saturation emulated
+// exactly) for the pixels outside the interior; same packed blend as the interior path.  Fast-kernel
+// preconditions apply (source < 2^31 bytes).
+STX_DEV uint32_t sample_border(const WarpK& P, float x, float yy)
+{
+    const int sx = cv_round(fmul(x, 32.f)), sy = cv_round(fmul(yy, 32.f));
+    const uint32_t fx = (uint32_t)sx & 31u, fy = (uint32_t)sy & 31u;
+    const int ix = sat_s16(sx >> 5), iy = sat_s16(sy >> 5);
+    const int sx0 = reflect(ix, P.sw), sx1 = reflect(ix + 1, P.sw);
+    const int sy0 = reflect(iy, P.sh), sy1 = reflect(iy + 1, P.sh);
+    const STX_GAS uint8_t* src = (const STX_GAS uint8_t*)P.src;
+    const uint32_t stride = (uint32_t)P.sstride;
+    const uint32_t t00 = tap24(src, stride, sx0, sy0), t01 = tap24(src, stride, sx1, sy0);
+    const uint32_t t10 = tap24(src, stride, sx0, sy1), t11 = tap24(src, stride, sx1, sy1);
+    const uint32_t wy1 = fy * 0x10001u, wy0 = 0x200020u - wy1;
+    const uint32_t wx = fx * 0xffffu + 32u;
+    uint32_t o[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const uint32_t sel = c == 0 ? 0x0c040c00u : (c == 1 ? 0x0c050c01u : 0x0c060c02u);  // byte c of both taps
+        const v2h a = as_v2h(__builtin_amdgcn_perm(t01, t00, sel)), b = as_v2h(__builtin_amdgcn_perm(t11, t10, sel));
+        const v2h v = a * as_v2h(wy0) + b * as_v2h(wy1);
+        o[c] = __builtin_amdgcn_udot2(v, as_v2h(wx), 512u, false) >> 10;
+    }
+    return o[0] | (o[1] << 8) | (o[2] << 16);
+}
+
 STX_DEV void put_px(uint32_t (&out)[3], int j, uint32_t px)
 {
     if (j == 0) out[0] = px;
@@ -328,13 +363,20 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
     const float2 rt = rt_next;
     if (y + WARP_TH < P.dh) rt_next = rowT[y + WARP_TH];
     float xs[4], ys[4], zs[4];
-    bool easy = true;  // every division of this lane may use the shared-reciprocal sequence
+    // every division of this lane may use the shared-reciprocal sequence: all |z| (z for the rotation warpers,
+    // which also need z > 0) in [2^-60, 2^60] and all |x|, |y| <= 2^60.  Evaluated as integer min / max of the
+    // float bit patterns of z (a NaN z is "too big" or negative there, so it cannot slip through a NaN-dropping
+    // fp min) and one fp max over |x|, |y| (a NaN numerator gives NaN on both division paths).
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        project_xyz<TYPE>(P, ca[j], cb[j], rt.x, rt.y, omt, xs[j], ys[j], zs[j]);
-        const float az = (TYPE == STX_WARP_PLANE || TYPE == STX_WARP_AFFINE) ? fabsf(zs[j]) : zs[j];
-        easy = easy && az >= 0x1p-60f && fmaxf(fmaxf(fabsf(xs[j]), fabsf(ys[j])), az) <= 0x1p60f;
-    }
+    for (int j = 0; j < 4; j++) project_xyz<TYPE>(P, ca[j], cb[j], rt.x, rt.y, omt, xs[j], ys[j], zs[j]);
+    int zb[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        zb[j] = (TYPE == STX_WARP_PLANE || TYPE == STX_WARP_AFFINE) ? (__float_as_int(zs[j]) & 0x7fffffff) : __float_as_int(zs[j]);
+    const int zlo = min(min(zb[0], zb[1]), min(zb[2], zb[3])), zhi = max(max(zb[0], zb[1]), max(zb[2], zb[3]));
+    const float nmax = fmaxf(fmaxf(fmaxf(fabsf(xs[0]), fabsf(ys[0])), fmaxf(fabsf(xs[1]), fabsf(ys[1]))),
+                             fmaxf(fmaxf(fabsf(xs[2]), fabsf(ys[2])), fmaxf(fabsf(xs[3]), fabsf(ys[3]))));
+    const bool easy = zlo >= 0x21800000 /* 2^-60 */ && zhi <= 0x5d800000 /* 2^60 */ && nmax <= 0x1p60f;
     if (easy) {
 #pragma unroll
         for (int j = 0; j < 4; j++) div2_fast(zs[j], xs[j], ys[j], xs[j], ys[j]);
@@ -351,15 +393,20 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
     }
     uint32_t out[3] = {0, 0, 0};
     uint32_t mout = 0;
-    bool interior = IMG;
+    bool interior = false;
     float x32[4], y32[4];
     if (IMG) {
+        // all four samples in the interior: -0.5 <= v < hi for every coordinate, as two fp min / max chains per
+        // axis; the sum poisons the test when any coordinate is NaN (fp min / max would drop it)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             x32[j] = fmul(xs[j], 32.f);
             y32[j] = fmul(ys[j], 32.f);
-            interior = interior && x32[j] >= -0.5f && x32[j] < P.bx_hi && y32[j] >= -0.5f && y32[j] < P.by_hi;
         }
+        const float xmn = fminf(fminf(x32[0], x32[1]), fminf(x32[2], x32[3])), xmx = fmaxf(fmaxf(x32[0], x32[1]), fmaxf(x32[2], x32[3]));
+        const float ymn = fminf(fminf(y32[0], y32[1]), fminf(y32[2], y32[3])), ymx = fmaxf(fmaxf(y32[0], y32[1]), fmaxf(y32[2], y32[3]));
+        const float poison = ((x32[0] + x32[1]) + (x32[2] + x32[3])) + ((y32[0] + y32[1]) + (y32[2] + y32[3]));
+        interior = xmn >= -0.5f && xmx < P.bx_hi && ymn >= -0.5f && ymx < P.by_hi && poison == poison;
     }
     if (IMG && interior) {
         const STX_GAS uint8_t* src = (const STX_GAS uint8_t*)P.src;
@@ -392,7 +439,7 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
     } else {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            if (IMG) put_px(out, j, sample_generic(P, xs[j], ys[j]));
+            if (IMG) put_px(out, j, sample_border(P, xs[j], ys[j]));
             if (MASK) {
                 const bool in = xs[j] >= -0.5f && xs[j] < P.mx_hi && ys[j] >= -0.5f && ys[j] < P.my_hi;
                 mout |= (in ? 255u : 0u) << (8 * j);
