@@ -687,6 +687,176 @@ STX_DEV uint32_t pair_mask(const uint32_t* m)
     return __builtin_amdgcn_perm(m[B >> 2], m[A >> 2], sel);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Packed epilogue of the level-0 kernel (pair layout, see above).  Everything stays two pixels per register:
+//   normalise : where no pixel of the lane is covered by more than one image, (short)(a / (1 + 1e-5f)) is
+//               a - sign(a) (a / 1.00001 lies strictly between a - 1 and a for 0 < a < 1e5), i.e. three packed ops;
+//               otherwise the exact shared-reciprocal division per element;
+//   collapse  : pyrUp of the finished level 1 in signed 16-bit lanes when all 18 taps of the patch are within
+//               +-500 (then no intermediate leaves int16), else the 32-bit patch; saturating add;
+//   store     : |v| clamped to 255 (convertScaleAbs), zero where no image, bytes gathered with v_perm.
+// ---------------------------------------------------------------------------------------------
+typedef short pk16s __attribute__((ext_vector_type(2)));
+STX_DEV pk16s pks(uint32_t v) { return __builtin_bit_cast(pk16s, v); }
+STX_DEV uint32_t unpks(pk16s v) { return __builtin_bit_cast(uint32_t, v); }
+STX_DEV pk16s pks_splat(short v) { pk16s r = {v, v}; return r; }
+
+// returns false (and leaves `up` untouched) when a tap is outside [-500, 500]
+STX_DEV bool up_patch_pks(const STX_GAS short* __restrict__ plane, uint32_t stride, int cw, int ch, int cx, int cy, pk16s up[2][4])
+{
+    const int rr[3] = {up_idx(cy - 1, ch), cy, up_idx(cy + 1, ch)};
+    const int cl = up_idx(cx - 1, cw), cr = up_idx(cx + 4, cw);
+    pk16s HE[3][2], HO[3][2];
+    pk16 worst = pk_splat(0);
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const uint32_t ro = (uint32_t)rr[r] * stride;
+        const v2u v = *reinterpret_cast<const STX_GAS v2u*>(plane + (ro + (uint32_t)cx));  // (c1,c2) (c3,c4)
+        const uint32_t c0 = (uint32_t)(unsigned short)plane[ro + (uint32_t)cl], c5 = (uint32_t)(unsigned short)plane[ro + (uint32_t)cr];
+        const uint32_t B0 = v.x, B1 = v.y;
+        const uint32_t A0 = (B0 << 16) | c0;                          // (c0,c1)
+        const uint32_t A1 = __builtin_amdgcn_alignbit(B1, B0, 16);    // (c2,c3)
+        const uint32_t A2 = (B1 >> 16) | (c5 << 16);                  // (c4,c5)
+        worst = __builtin_elementwise_max(worst, pk(A0) + pk_splat(500));
+        worst = __builtin_elementwise_max(worst, pk(A1) + pk_splat(500));
+        worst = __builtin_elementwise_max(worst, pk(A2) + pk_splat(500));
+        HE[r][0] = pks(A0) + pks(B0) * pks_splat(6) + pks(A1);
+        HE[r][1] = pks(A1) + pks(B1) * pks_splat(6) + pks(A2);
+        HO[r][0] = pks(B0) + pks(A1);
+        HO[r][1] = pks(B1) + pks(A2);
+    }
+    if (unpk(__builtin_elementwise_min(worst, pk_splat(1000))) != unpk(worst)) return false;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        up[0][k] = (HE[0][k] + HE[1][k] * pks_splat(6) + HE[2][k] + pks_splat(32)) >> pks_splat(6);
+        up[0][2 + k] = (HO[0][k] + HO[1][k] * pks_splat(6) + HO[2][k] + pks_splat(8)) >> pks_splat(4);
+        up[1][k] = (HE[1][k] + HE[2][k] + pks_splat(8)) >> pks_splat(4);
+        up[1][2 + k] = (HO[1][k] + HO[2][k] + pks_splat(2)) >> pks_splat(2);
+    }
+    return true;
+}
+
+// pair register / half that hold pixel j of a lane's 8-pixel strip
+constexpr int pair_of(int j) { return (j & 1) ? 2 + (j >> 2) : (j >> 2); }
+constexpr int half_of(int j) { return (j >> 1) & 1; }
+
+// output dword K of a row of 8 BGR pixels from the per-channel pair registers U[c][q] (values 0..255 in each half)
+template <int K>
+STX_DEV uint32_t bgr_dword(const uint32_t (&U)[3][4])
+{
+    constexpr int b0 = 4 * K, b1 = b0 + 1, b2 = b0 + 2, b3 = b0 + 3;
+    constexpr uint32_t s01 = (uint32_t)(2 * half_of(b0 / 3)) | ((uint32_t)(4 + 2 * half_of(b1 / 3)) << 8) | 0x0c0c0000u;
+    constexpr uint32_t s23 = 0x00000c0cu | ((uint32_t)(2 * half_of(b2 / 3)) << 16) | ((uint32_t)(4 + 2 * half_of(b3 / 3)) << 24);
+    const uint32_t lo = __builtin_amdgcn_perm(U[b1 % 3][pair_of(b1 / 3)], U[b0 % 3][pair_of(b0 / 3)], s01);
+    const uint32_t hi = __builtin_amdgcn_perm(U[b3 % 3][pair_of(b3 / 3)], U[b2 % 3][pair_of(b2 / 3)], s23);
+    return lo | hi;
+}
+
+STX_DEV void level0_epilogue_pk(const MbLevelK& P, int X0, int Y0, uint32_t (&acc)[2][3][4], uint32_t (&cnt)[2][4])
+{
+    // ---- normalizeUsingWeightMap
+    uint32_t v[2][3][4];
+    const uint32_t anyc = (cnt[0][0] | cnt[0][1] | cnt[0][2] | cnt[0][3]) | (cnt[1][0] | cnt[1][1] | cnt[1][2] | cnt[1][3]);
+    if ((anyc & 0xfffefffeu) == 0u) {
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const pk16s a = pks(acc[r][c][q]);
+                    const pk16s sg = __builtin_elementwise_min(__builtin_elementwise_max(a, pks_splat(-1)), pks_splat(1));
+                    v[r][c][q] = unpks(a - sg);
+                }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int o[2][3];
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) {
+                    const float den = fadd((float)(hf ? (cnt[r][q] >> 16) : (cnt[r][q] & 0xffffu)), WEIGHT_EPS);
+                    float q0, q1, q2;
+                    div3_shared(den, (float)(hf ? s16hi(acc[r][0][q]) : s16lo(acc[r][0][q])),
+                                (float)(hf ? s16hi(acc[r][1][q]) : s16lo(acc[r][1][q])),
+                                (float)(hf ? s16hi(acc[r][2][q]) : s16lo(acc[r][2][q])), q0, q1, q2);
+                    o[hf][0] = trunc_small(q0); o[hf][1] = trunc_small(q1); o[hf][2] = trunc_small(q2);
+                }
+#pragma unroll
+                for (int c = 0; c < 3; c++) v[r][c][q] = pack16(o[0][c], o[1][c]);
+            }
+    }
+    // ---- + pyrUp(finished level 1), saturating
+    if (P.up) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const short* plane = P.up + c * P.up_plane - ((long long)P.up_y0 * P.up_stride + P.up_x0);
+            pk16s up[2][4];
+            if (!up_patch_pks(gp(plane), (uint32_t)P.up_stride, P.pw >> 1, P.ph >> 1, X0 >> 1, Y0 >> 1, up)) {
+                int u32[2][8];
+                up_patch(plane, P.up_stride, P.pw >> 1, P.ph >> 1, X0 >> 1, Y0 >> 1, u32);
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    up[r][0] = pks(pack16(u32[r][0], u32[r][2]));
+                    up[r][1] = pks(pack16(u32[r][4], u32[r][6]));
+                    up[r][2] = pks(pack16(u32[r][1], u32[r][3]));
+                    up[r][3] = pks(pack16(u32[r][5], u32[r][7]));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[r][c][q] = unpks(__builtin_elementwise_add_sat(up[r][q], pks(v[r][c][q])));
+        }
+    }
+    // ---- mask = weight > eps, zero outside, convertScaleAbs, store
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int y = Y0 + r;
+        if (y >= P.y1) break;
+        const int oy = y - P.pano_y0, ox = X0 - P.pano_x0;
+        uint32_t keep[4], U[3][4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) keep[q] = unpk(pk_splat(0) - __builtin_elementwise_min(pk(cnt[r][q]), pk_splat(1)));
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                v[r][c][q] &= keep[q];
+                const pk16s x = pks(v[r][c][q]);
+                const pk16s ax = __builtin_elementwise_max(x, __builtin_elementwise_sub_sat(pks_splat(0), x));
+                U[c][q] = unpks(__builtin_elementwise_min(ax, pks_splat(255)));
+            }
+        uint32_t* po = reinterpret_cast<uint32_t*>(P.pano + (long long)oy * P.pano_stride + (long long)ox * 3);
+        *reinterpret_cast<uint2*>(po) = make_uint2(bgr_dword<0>(U), bgr_dword<1>(U));
+        *reinterpret_cast<uint2*>(po + 2) = make_uint2(bgr_dword<2>(U), bgr_dword<3>(U));
+        *reinterpret_cast<uint2*>(po + 4) = make_uint2(bgr_dword<4>(U), bgr_dword<5>(U));
+        // mask bytes of pixels 0..3 = keep[0].lo, keep[2].lo, keep[0].hi, keep[2].hi; 4..7 likewise from keep[1], keep[3]
+        *reinterpret_cast<uint2*>(P.pmask + (long long)oy * P.pmask_stride + ox) =
+            make_uint2(__builtin_amdgcn_perm(keep[2], keep[0], 0x06020400u), __builtin_amdgcn_perm(keep[3], keep[1], 0x06020400u));
+        if (P.pano16) {
+            uint32_t* p16 = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(P.pano16) + (long long)oy * P.pano16_stride + (long long)ox * 6);
+            int w[8][3];
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) w[j][c] = half_of(j) ? s16hi(v[r][c][pair_of(j)]) : s16lo(v[r][c][pair_of(j)]);
+            uint32_t t[12];
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                t[(j >> 1) * 3 + 0] = pack16(w[j][0], w[j][1]);
+                t[(j >> 1) * 3 + 1] = pack16(w[j][2], w[j + 1][0]);
+                t[(j >> 1) * 3 + 2] = pack16(w[j + 1][1], w[j + 1][2]);
+            }
+            *reinterpret_cast<uint4*>(p16) = make_uint4(t[0], t[1], t[2], t[3]);
+            *reinterpret_cast<uint4*>(p16 + 4) = make_uint4(t[4], t[5], t[6], t[7]);
+            *reinterpret_cast<uint4*>(p16 + 8) = make_uint4(t[8], t[9], t[10], t[11]);
+        }
+    }
+}
+
 template <bool CONTRIB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void mb_level0_pk_kernel(MbLevelK P)
 {
@@ -842,20 +1012,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
     if (!active) return;
 
-    // hand over to the common epilogue: pair layout -> pixel order
-    int a[2][8][3];
-    float ws[2][8];
-#pragma unroll
-    for (int r = 0; r < 2; r++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int q = (j & 1) ? 2 + (j >> 2) : (j >> 2);
-            const bool hi = (j >> 1) & 1;
-#pragma unroll
-            for (int c = 0; c < 3; c++) a[r][j][c] = hi ? s16hi(acc[r][c][q]) : s16lo(acc[r][c][q]);
-            ws[r][j] = (float)(hi ? (cnt[r][q] >> 16) : (cnt[r][q] & 0xffffu));
-        }
-    level_epilogue<true>(P, X0, Y0, a, ws);
+    level0_epilogue_pk(P, X0, Y0, acc, cnt);
 }
 
 bool launched_ok() { return hipGetLastError() == hipSuccess; }
