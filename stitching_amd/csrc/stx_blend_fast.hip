@@ -22,6 +22,9 @@ using namespace stxd;
 
 namespace {
 
+#ifndef STX_L0_WAVES
+#define STX_L0_WAVES 4
+#endif
 constexpr float WEIGHT_EPS = 1e-5f;
 constexpr float INV255 = 0.0039215688593685627f;  // (float)(1./255.)
 constexpr float INV256 = 0.00390625f;
@@ -450,8 +453,6 @@ STX_DEV void level_epilogue(const MbLevelK& P, int X0, int Y0, int (&acc)[2][8][
 template <bool L0, bool CONTRIB, bool EMIT>
 __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
 {
-    __shared__ int s_list[64];
-    __shared__ int s_n;
     const int tid = threadIdx.x;
     const int lv = P.level;
     const int tile_x = P.x0 + blockIdx.x * 512, tile_y = P.y0 + blockIdx.y * 8;
@@ -468,26 +469,24 @@ __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
             ws[r][j] = 0.f;
         }
 
+    // every wavefront finds the images under ITS two rows of the tile with one ballot (no LDS list, no barrier:
+    // the other three wavefronts of the block no longer wait for the first one's descriptor loads)
     for (int base = 0; base < P.n_images; base += 64) {
-        __syncthreads();
-        if (tid < 64) {
-            const int k = base + tid;
-            bool hit = false;
-            if (k < P.n_images) {
-                const StxMbImage& im = P.images[k];
+        bool hit = false;
+        {
+            const int kk = base + (tid & 63);
+            if (kk < P.n_images) {
+                const StxMbImage& im = P.images[kk];
                 int rx, ry, rw, rh;
                 if (L0 && !(CONTRIB && im.kind == 1)) { rx = im.ix; ry = im.iy; rw = im.iw; rh = im.ih; }
                 else { rx = im.fx >> lv; ry = im.fy >> lv; rw = im.fw >> lv; rh = im.fh >> lv; }
-                hit = rx < tile_x + 512 && rx + rw > tile_x && ry < tile_y + 8 && ry + rh > tile_y;
+                hit = rx < tile_x + 512 && rx + rw > tile_x && ry < Y0 + 2 && ry + rh > Y0;
             }
-            const unsigned long long m = __ballot(hit);
-            if (hit) s_list[__popcll(m & ((1ull << tid) - 1ull))] = k;
-            if (tid == 0) s_n = __popcll(m);
         }
-        __syncthreads();
-        const int cnt = s_n;
-        for (int i = 0; i < cnt; i++) {
-            const int k = __builtin_amdgcn_readfirstlane(s_list[i]);
+        unsigned long long todo = __ballot(hit);
+        while (todo) {
+            const int k = base + (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
             const StxMbImage& im = P.images[k];
             if (!active) continue;
             if (!L0 || (CONTRIB && im.kind == 1)) {
@@ -858,10 +857,8 @@ STX_DEV void level0_epilogue_pk(const MbLevelK& P, int X0, int Y0, uint32_t (&ac
 }
 
 template <bool CONTRIB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void mb_level0_pk_kernel(MbLevelK P)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVES, 8))) void mb_level0_pk_kernel(MbLevelK P)
 {
-    __shared__ int s_list[64];
-    __shared__ int s_n;
     const int tid = threadIdx.x;
     const int tile_x = P.x0 + blockIdx.x * 512, tile_y = P.y0 + blockIdx.y * 8;
     const int X0 = tile_x + (tid & 63) * 8, Y0 = tile_y + (tid >> 6) * 2;
@@ -877,25 +874,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             cnt[r][k] = 0;
         }
 
+    // every wavefront finds the images under ITS two rows with one ballot (no LDS list, no barrier)
     for (int base = 0; base < P.n_images; base += 64) {
-        __syncthreads();
-        if (tid < 64) {
-            const int k = base + tid;
-            bool hit = false;
-            if (k < P.n_images) {
-                const StxMbImage& im = P.images[k];
+        bool hit = false;
+        {
+            const int kk = base + (tid & 63);
+            if (kk < P.n_images) {
+                const StxMbImage& im = P.images[kk];
                 int rx = im.ix, ry = im.iy, rw = im.iw, rh = im.ih;
                 if (CONTRIB && im.kind == 1) { rx = im.fx; ry = im.fy; rw = im.fw; rh = im.fh; }
-                hit = rx < tile_x + 512 && rx + rw > tile_x && ry < tile_y + 8 && ry + rh > tile_y;
+                hit = rx < tile_x + 512 && rx + rw > tile_x && ry < Y0 + 2 && ry + rh > Y0;
             }
-            const unsigned long long m = __ballot(hit);
-            if (hit) s_list[__popcll(m & ((1ull << tid) - 1ull))] = k;
-            if (tid == 0) s_n = __popcll(m);
         }
-        __syncthreads();
-        const int n_hit = s_n;
-        for (int i = 0; i < n_hit; i++) {
-            const int k = __builtin_amdgcn_readfirstlane(s_list[i]);
+        unsigned long long todo = __ballot(hit);
+        while (todo) {
+            const int k = base + (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
             const StxMbImage& im = P.images[k];
             if (!active) continue;
             if (CONTRIB && im.kind == 1) {
