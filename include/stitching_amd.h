@@ -145,6 +145,17 @@ int stx_blend_finish(stx_blender* b, stx_buf** out_pano_u8, stx_buf** out_mask_u
 int stx_blend_finish_ex(stx_blender* b, stx_buf** out_pano_u8, stx_buf** out_mask_u8, stx_buf** out_pano_s16);
 int stx_blend_destroy(stx_blender* b);
 
+/* ---- "next" rows either side of the path -----------------------------------------------------
+ * stx_gain_apply      <- stitching/exposure_error_compensator.py:43-45 compensator.apply(idx, corner, img, mask) for the
+ *                        "gain" / "channel" compensators (GainCompensator::apply, ChannelsCompensator::apply =
+ *                        cv::multiply(image, gain): fp32 product, cvRound, saturate to u8), in place on the warped image
+ *                        between warp and feed (stitching/stitcher.py:123,219-221).  The block compensators need
+ *                        cv::resize of the gain map and stay on the host.
+ * stx_timelapse_frame <- stitching/timelapser.py:36-52 timelapser.process(img, mask, corner) + getDst():
+ *                        zero frame of the roi given to initialize(), the image pasted at its corner. */
+int stx_gain_apply(stx_ctx* ctx, stx_buf* img_u8x3, const float gains_bgr[3]);
+int stx_timelapse_frame(stx_ctx* ctx, const stx_buf* img, int tlx, int tly, const int dst_roi_xywh[4], stx_buf** out_frame);
+
 /* ---- sharded multi-band blending: one process per GPU, one stx_blender per rank ------------------
  * No counterpart in the reference (it is single process, stitching/stitcher.py:247-254).  Every rank
  * prepares the same roi; rank g produces the columns [x0, x1) of the panorama (stx_blend_set_band).

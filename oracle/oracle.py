@@ -369,3 +369,28 @@ class Blender:
         for img, mask, corner in zip(imgs, masks, corners):
             blender.feed(img, mask, corner)
         return blender.blend()
+
+
+# ------------------------------------------------------------------ "next" rows
+def gain_apply(img, gains):
+    """GainCompensator::apply / ChannelsCompensator::apply = cv::multiply(u8x3 image, scalar gain(s)) [OCV-MEM]:
+    arithm_op demotes the double scalar to float for 8-bit sources, multiplies in fp32 and stores
+    saturate_cast<uchar>(float) = cvRound (half to even) + clamp."""
+    img = np.asarray(img, np.uint8)
+    g = np.atleast_1d(np.asarray(gains, np.float64)).astype(np.float32)
+    g = np.full(3, g[0], np.float32) if g.size == 1 else g[:3]
+    v = img.astype(np.float32) * g[None, None, :]
+    return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+
+
+def timelapse_frame(img, corner, dst_roi):
+    """Timelapser::process + getDst [OCV-MEM]: zero frame of dst_roi, the image pasted at its corner (clipped
+    to the roi: TimelapserCrop keeps only the common area)."""
+    img = np.asarray(img)
+    x, y, w, h = dst_roi
+    out = np.zeros((h, w) + img.shape[2:], img.dtype)
+    x0, y0 = max(corner[0], x), max(corner[1], y)
+    x1, y1 = min(corner[0] + img.shape[1], x + w), min(corner[1] + img.shape[0], y + h)
+    if x1 > x0 and y1 > y0:
+        out[y0 - y:y1 - y, x0 - x:x1 - x] = img[y0 - corner[1]:y1 - corner[1], x0 - corner[0]:x1 - corner[0]]
+    return out

@@ -407,6 +407,41 @@ STX_EXPORT int stx_buf_free(stx_buf* buf)
 }
 
 // ---------------------------------------------------------------------------------------------
+// "next" rows: exposure gain between warp and feed (N1), timelapse frames (N4)
+// ---------------------------------------------------------------------------------------------
+STX_EXPORT int stx_gain_apply(stx_ctx* ctx, stx_buf* img, const float gains_bgr[3])
+{
+    if (!ctx || !img || !gains_bgr) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (img->elem != STX_U8 || img->c != 3) return stx_fail(STX_ERR_INVALID, "gain apply needs a u8x3 image");
+    if (img->ctx != ctx) return stx_fail(STX_ERR_INVALID, "image belongs to another context");
+    STX_TRY(stx_set_device(ctx));
+    return stx_launch_gain_apply(ctx, img, gains_bgr);
+}
+
+STX_EXPORT int stx_timelapse_frame(stx_ctx* ctx, const stx_buf* img, int tlx, int tly, const int dst_roi_xywh[4], stx_buf** out_frame)
+{
+    if (!ctx || !img || !dst_roi_xywh || !out_frame) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (img->ctx != ctx) return stx_fail(STX_ERR_INVALID, "image belongs to another context");
+    const int rx = dst_roi_xywh[0], ry = dst_roi_xywh[1], rw = dst_roi_xywh[2], rh = dst_roi_xywh[3];
+    if (rw <= 0 || rh <= 0) return stx_fail(STX_ERR_INVALID, "empty timelapse roi %dx%d", rw, rh);
+    STX_TRY(stx_set_device(ctx));
+    stx_buf* f = nullptr;
+    STX_TRY(stx_buf_new(ctx, rw, rh, img->c, img->elem, &f));
+    // Timelapser::process: dst_.setTo(0); img.copyTo(dst_(Rect(tl - dst_roi_.tl(), img.size()))), clipped to the roi
+    hipError_t e = hipMemsetAsync(f->ptr, 0, f->stride * (size_t)rh, ctx->stream);
+    const int x0 = std::max(tlx, rx), y0 = std::max(tly, ry);
+    const int x1 = std::min(tlx + img->w, rx + rw), y1 = std::min(tly + img->h, ry + rh);
+    const size_t px = (size_t)img->c * stx_elem_bytes(img->elem);
+    if (e == hipSuccess && x1 > x0 && y1 > y0)
+        e = hipMemcpy2DAsync(f->ptr + (size_t)(y0 - ry) * f->stride + (size_t)(x0 - rx) * px, f->stride,
+                             img->ptr + (size_t)(y0 - tly) * img->stride + (size_t)(x0 - tlx) * px, img->stride,
+                             (size_t)(x1 - x0) * px, (size_t)(y1 - y0), hipMemcpyDeviceToDevice, ctx->stream);
+    if (e != hipSuccess) { stx_buf_release(f); return stx_fail(STX_ERR_HIP, "timelapse frame: %s", hipGetErrorString(e)); }
+    *out_frame = f;
+    return STX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // projector: ProjectorBase::setCameraParams, AffineWarper::getRTfromHomogeneous
 // ---------------------------------------------------------------------------------------------
 static void inv3x3_f32(const float* m, float* o)

@@ -514,3 +514,46 @@ int stx_launch_simple_finish(stx_ctx* ctx, int kind, short* dst, long long dst_s
     hipLaunchKernelGGL(simple_finish_kernel, grid64x4(w, h), dim3(256), 0, ctx->stream, K);
     return check_launch("simple_finish");
 }
+
+// ---------------------------------------------------------------------------------------------
+// "next" rows of the scope table: consumers / producers either side of the path
+// ---------------------------------------------------------------------------------------------
+namespace {
+// GainCompensator::apply / ChannelsCompensator::apply: cv::multiply(u8x3 image, double scalar) evaluates in fp32
+// (arithm_op demotes a CV_64F scalar to CV_32F for 8-bit sources) and stores saturate_cast<uchar>(float) = cvRound + clamp
+struct GainK { uint8_t* img; long long stride; int w, h; float g[3]; };
+__global__ __launch_bounds__(256) void gain_apply_kernel(GainK P)
+{
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;  // 4 pixels = 12 bytes = 3 dwords per lane
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x4 >= P.w || y >= P.h) return;
+    uint8_t* row = P.img + (long long)y * P.stride;
+    if (x4 + 4 <= P.w) {
+        uint32_t* q = reinterpret_cast<uint32_t*>(row + (long long)x4 * 3);
+        uint32_t d[3] = {q[0], q[1], q[2]}, o[3] = {0, 0, 0};
+#pragma unroll
+        for (int b = 0; b < 12; b++) {
+            const float v = stxd::fmul((float)((d[b >> 2] >> (8 * (b & 3))) & 255u), P.g[b % 3]);
+            const int r = min(max(stxd::cv_round(v), 0), 255);
+            o[b >> 2] |= (uint32_t)r << (8 * (b & 3));
+        }
+        q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
+    } else {
+        for (int x = x4; x < P.w; x++)
+            for (int c = 0; c < 3; c++) {
+                const float v = stxd::fmul((float)row[x * 3 + c], P.g[c]);
+                row[x * 3 + c] = (uint8_t)min(max(stxd::cv_round(v), 0), 255);
+            }
+    }
+}
+}  // namespace
+
+int stx_launch_gain_apply(stx_ctx* ctx, stx_buf* img, const float g[3])
+{
+    GainK K;
+    K.img = img->ptr; K.stride = (long long)img->stride; K.w = img->w; K.h = img->h;
+    K.g[0] = g[0]; K.g[1] = g[1]; K.g[2] = g[2];
+    StxProfScope prof(ctx, "gain_apply", 6.0 * img->w * img->h);
+    hipLaunchKernelGGL(gain_apply_kernel, dim3((img->w + 255) / 256, (img->h + 3) / 4), dim3(256), 0, ctx->stream, K);
+    return check_launch("gain_apply");
+}

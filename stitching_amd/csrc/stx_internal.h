@@ -147,6 +147,9 @@ int stx_launch_mb_pyramids(stx_ctx* ctx, const StxMbImage* d_images, const StxMb
 struct MbLevelK;
 int stx_launch_mb_level(stx_ctx* ctx, const MbLevelK& K, double algo_bytes);
 
+// pointwise exposure gain (next row N1) --------------------------------------------------------------
+int stx_launch_gain_apply(stx_ctx* ctx, stx_buf* img, const float g[3]);
+
 // simple blenders --------------------------------------------------------------------------------
 int stx_launch_no_feed(stx_ctx* ctx, const stx_buf* img, const stx_buf* mask, short* dst, long long dst_stride,
                        uint8_t* dmask, long long dmask_stride, int dx, int dy);

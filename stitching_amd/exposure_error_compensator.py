@@ -1,0 +1,64 @@
+"""ExposureErrorCompensator.apply on the device.
+
+The reference class (stitching/exposure_error_compensator.py:6-45) wraps cv.detail exposure compensators:
+`feed` estimates gains on low-resolution images (out of scope: a small least-squares solve, it stays in OpenCV),
+`apply(idx, corner, img, mask)` multiplies the final-resolution warped image by the gain, between warp and
+blend (stitching/stitcher.py:123,219-221).  This class keeps the surface and runs `apply` in HBM for the
+"gain" and "channel" compensators (one gain per image / per channel); gains come from `set_gains` — e.g. from
+the cv2 compensator's getMatGains() after its feed().  The block compensators interpolate a gain map with
+cv::resize and are not implemented here.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib, config
+from .device import as_device, get_context
+from .stitching_error import StitchingError
+
+
+class ExposureErrorCompensator:
+    COMPENSATOR_CHOICES = OrderedDict()
+    COMPENSATOR_CHOICES["gain_blocks"] = 2  # cv.detail.ExposureCompensator_GAIN_BLOCKS
+    COMPENSATOR_CHOICES["gain"] = 1  # ..._GAIN
+    COMPENSATOR_CHOICES["channel"] = 3  # ..._CHANNELS
+    COMPENSATOR_CHOICES["channel_blocks"] = 4  # ..._CHANNELS_BLOCKS
+    COMPENSATOR_CHOICES["no"] = 0  # ..._NO
+
+    DEFAULT_COMPENSATOR = list(COMPENSATOR_CHOICES.keys())[0]
+    DEFAULT_NR_FEEDS = 1
+    DEFAULT_BLOCK_SIZE = 32
+    SUPPORTED_ON_DEVICE = ("gain", "channel", "no")
+
+    def __init__(self, compensator=DEFAULT_COMPENSATOR, nr_feeds=DEFAULT_NR_FEEDS, block_size=DEFAULT_BLOCK_SIZE):
+        if compensator not in self.COMPENSATOR_CHOICES:
+            raise StitchingError(f"unknown compensator {compensator!r}")
+        self.compensator_type = compensator
+        self.nr_feeds, self.block_size = nr_feeds, block_size
+        self.gains = None
+
+    def set_gains(self, gains):
+        """gains[i]: scalar ("gain") or 3 per-channel BGR values ("channel") for image i."""
+        self.gains = [np.atleast_1d(np.asarray(g, np.float64)).reshape(-1) for g in gains]
+
+    def feed(self, *args):
+        raise StitchingError("gain estimation (ExposureCompensator::feed) is outside the MI355X hot path: run it in OpenCV "
+                             "and pass getMatGains() to set_gains()")
+
+    def apply(self, idx, corner, img, mask):
+        """-> the compensated image (same object for device images: the product is written in place, as OpenCV does)."""
+        if self.compensator_type == "no":
+            return img
+        if self.compensator_type not in self.SUPPORTED_ON_DEVICE:
+            raise StitchingError(f"compensator {self.compensator_type!r} is not implemented by the MI355X back end "
+                                 f"(implemented: {', '.join(self.SUPPORTED_ON_DEVICE)})")
+        if self.gains is None:
+            raise StitchingError("ExposureErrorCompensator.set_gains(gains) must be called before apply")
+        g = self.gains[idx]
+        g3 = np.full(3, g[0], np.float64) if g.size == 1 else g[:3]
+        g3 = np.ascontiguousarray(g3, np.float32)  # arithm_op demotes the double scalar to float for 8-bit images
+        ctx = get_context()
+        d = as_device(img, ctx)
+        _lib.check(ctx._lib.stx_gain_apply(ctx.handle, d._h, g3.ctypes.data_as(C.POINTER(C.c_float))))
+        return d if config.device_resident() else d.numpy()

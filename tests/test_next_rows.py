@@ -1,0 +1,117 @@
+"""SURVEY.md §8f "next" rows built so far: N1 exposure gain apply (gain / channel compensators) and N4 the
+Timelapser sink.  CPU: host logic + known answers of the oracle restatement; GPU: bit-exact vs the oracle."""
+import numpy as np
+import pytest
+
+import stitching_amd as S
+from stitching_amd import synthetic
+
+
+# ---------------------------------------------------------------- CPU
+def test_compensator_surface_and_errors():
+    E = S.ExposureErrorCompensator
+    assert list(E.COMPENSATOR_CHOICES) == ["gain_blocks", "gain", "channel", "channel_blocks", "no"]
+    assert E.DEFAULT_COMPENSATOR == "gain_blocks" and E.DEFAULT_NR_FEEDS == 1 and E.DEFAULT_BLOCK_SIZE == 32
+    img = np.zeros((4, 4, 3), np.uint8)
+    assert E("no").apply(0, (0, 0), img, None) is img
+    with pytest.raises(S.StitchingError):
+        E("gain").apply(0, (0, 0), img, None)  # no gains yet
+    with pytest.raises(S.StitchingError):
+        E("gain_blocks").apply(0, (0, 0), img, None)  # block compensators stay on the host
+    with pytest.raises(S.StitchingError):
+        E("gain").feed([], [], [])
+    with pytest.raises(S.StitchingError):
+        E("bogus")
+
+
+def test_gain_apply_known_answers(oracle):
+    img = np.array([[[100, 101, 255], [0, 1, 200]]], np.uint8)
+    out = oracle.gain_apply(img, 1.5)
+    assert out.tolist() == [[[150, 152, 255], [0, 2, 255]]]  # 151.5 -> 152 (half to even), 382.5 saturates
+    out = oracle.gain_apply(img, [0.5, 1.0, 2.0])
+    assert out.tolist() == [[[50, 101, 255], [0, 1, 255]]]
+    assert oracle.gain_apply(np.full((1, 1, 3), 5, np.uint8), 0.5).tolist() == [[[2, 2, 2]]]  # 2.5 -> 2
+
+
+def test_timelapser_rois_and_filenames():
+    t = S.Timelapser("as_is")
+    t.initialize([(10, 20), (60, 0)], [(100, 50), (80, 90)])
+    assert t.dst_roi == (10, 0, 130, 90)
+    c = S.Timelapser("crop", "fx_")
+    c.initialize([(10, 20), (60, 0)], [(100, 50), (80, 90)])
+    assert c.dst_roi == (60, 20, 50, 50)
+    assert c.get_fixed_filename("/a/b/img1.jpg") == "/a/b/fx_img1.jpg"
+    assert S.Timelapser().do_timelapse is False and S.Timelapser.TIMELAPSE_CHOICES == ("no", "as_is", "crop")
+    with pytest.raises(S.StitchingError):
+        S.Timelapser("crop").initialize([(0, 0), (500, 0)], [(100, 100), (100, 100)])
+
+
+def test_timelapse_frame_known_answer(oracle):
+    img = np.arange(2 * 3 * 3, dtype=np.uint8).reshape(2, 3, 3)
+    f = oracle.timelapse_frame(img, (4, 1), (3, 0, 3, 4))
+    assert f.shape == (4, 3, 3) and not f[0].any() and not f[3].any() and not f[:, 0].any()
+    assert np.array_equal(f[1:3, 1:3], img[:, 0:2])
+
+
+# ---------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,gains", [(517, 389, 1.137), (64, 5, 0.61), (1203, 7, [1.08, 0.93, 1.31]), (3, 2, 2.5)])
+def test_gain_apply_bit_exact(oracle, gpu_ctx, w, h, gains):
+    img = synthetic.make_frame(3, max(w, 16), max(h, 12))[:h, :w]
+    e = S.ExposureErrorCompensator("gain" if np.isscalar(gains) else "channel")
+    e.set_gains([0.0, gains])
+    out = e.apply(1, (0, 0), img, None)
+    assert np.array_equal(out, oracle.gain_apply(img, gains))
+
+
+@pytest.mark.gpu
+def test_gain_between_warp_and_feed_device_resident(oracle, gpu_ctx):
+    """The stitcher's order (stitching/stitcher.py:119-127): warp -> compensate -> blend, all in HBM."""
+    from tests import helpers
+
+    imgs, cams = helpers.small_ring(3, 400, 300, span=110.0)
+    gains = [1.1, 0.9, 1.05]
+    ow = oracle.Warper("spherical")
+    ow.set_scale(cams)
+    o_imgs = [oracle.gain_apply(ow.warp_image(i, c), g) for i, c, g in zip(imgs, cams, gains)]
+    o_masks = [ow.create_and_warp_mask((400, 300), c) for c in cams]
+    corners, sizes = ow.warp_rois([(400, 300)] * 3, cams)
+    ob = oracle.Blender("multiband", 10)
+    ob.prepare(corners, sizes)
+    for a, m, c in zip(o_imgs, o_masks, corners):
+        ob.feed(a, m, c)
+    o_pano, o_mask = ob.blend()
+    S.set_device_resident(True)
+    try:
+        w = S.Warper("spherical")
+        w.set_scale(cams)
+        d_imgs, d_masks, rois = w.warp_images_and_masks(imgs, cams)
+        e = S.ExposureErrorCompensator("gain")
+        e.set_gains(gains)
+        b = S.Blender("multiband", 10)
+        b.prepare(corners, sizes)
+        for i in range(3):
+            b.feed(e.apply(i, corners[i], d_imgs[i], d_masks[i]), d_masks[i], corners[i])
+        pano, mask = b.blend()
+    finally:
+        S.set_device_resident(False)
+    assert np.array_equal(np.asarray(mask), o_mask) and np.array_equal(np.asarray(pano), o_pano)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["as_is", "crop"])
+def test_timelapser_frames(oracle, gpu_ctx, kind):
+    from tests import helpers
+
+    imgs, cams = helpers.small_ring(3, 400, 300, span=60.0)
+    w = S.Warper("spherical")
+    w.set_scale(cams)
+    warped = [np.asarray(a) for a in w.warp_images(imgs, cams)]
+    corners, sizes = w.warp_rois([(400, 300)] * 3, cams)
+    t = S.Timelapser(kind)
+    t.initialize(corners, sizes)
+    for img, corner in zip(warped, corners):
+        t.process_frame(img, corner)
+        frame = t.get_frame()
+        assert frame.shape[:2] == (t.dst_roi[3], t.dst_roi[2])
+        assert np.array_equal(frame, oracle.timelapse_frame(img, corner, t.dst_roi))
