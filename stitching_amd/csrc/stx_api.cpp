@@ -79,6 +79,8 @@ STX_EXPORT int stx_ctx_create(int device, stx_ctx** out)
     STX_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     ctx->pinned_bytes = 1 << 16;
     STX_HIP(hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault));
+    ctx->stage_bytes = 1 << 20;
+    STX_HIP(hipHostMalloc((void**)&ctx->stage, ctx->stage_bytes, hipHostMallocDefault));
     STX_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
     STX_HIP(hipMalloc(&ctx->aux_scratch, ctx->pinned_bytes));
     *out = ctx.release();
@@ -103,6 +105,7 @@ STX_EXPORT int stx_ctx_destroy(stx_ctx* ctx)
     for (auto e : ctx->event_pool) hipEventDestroy(e);
     for (auto e : ctx->marks) if (e) hipEventDestroy(e);
     if (ctx->pinned) hipHostFree(ctx->pinned);
+    if (ctx->stage) hipHostFree(ctx->stage);
     if (ctx->aux_scratch) hipFree(ctx->aux_scratch);
     if (ctx->aux_stream) hipStreamDestroy(ctx->aux_stream);
     hipStreamDestroy(ctx->stream);
@@ -1057,15 +1060,28 @@ static int mb_feed(stx_blender* b, const stx_buf* img, const stx_buf* mask, int 
     return STX_OK;
 }
 
-// upload `n` descriptors (pageable host memory -> device; synchronises the stream)
+// upload `n` descriptors through the context's pinned ring: asynchronous, in stream order, no host wait
 static int mb_upload(stx_blender* b, const StxMbImage* h, int n, StxMbImage** d_out)
 {
+    stx_ctx* ctx = b->ctx;
     void* d = nullptr;
-    STX_TRY(stx_dev_alloc(b->ctx, sizeof(StxMbImage) * std::max(n, 1), &d));
+    STX_TRY(stx_dev_alloc(ctx, sizeof(StxMbImage) * std::max(n, 1), &d));
     b->pyr_allocs.push_back(d);
     if (n > 0) {
-        STX_HIP(hipMemcpyAsync(d, h, sizeof(StxMbImage) * n, hipMemcpyHostToDevice, b->ctx->stream));
-        STX_HIP(hipStreamSynchronize(b->ctx->stream));
+        const size_t bytes = sizeof(StxMbImage) * (size_t)n;
+        if (bytes > ctx->stage_bytes) {  // larger than the ring: plain synchronous copy
+            STX_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+            STX_HIP(hipStreamSynchronize(ctx->stream));
+        } else {
+            if (ctx->stage_off + bytes > ctx->stage_bytes) {  // wrap: earlier slots may still be in flight
+                STX_HIP(hipStreamSynchronize(ctx->stream));
+                ctx->stage_off = 0;
+            }
+            uint8_t* slot = ctx->stage + ctx->stage_off;
+            memcpy(slot, h, bytes);
+            ctx->stage_off += (bytes + 255) & ~(size_t)255;
+            STX_HIP(hipMemcpyAsync(d, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
+        }
     }
     *d_out = (StxMbImage*)d;
     return STX_OK;

@@ -65,6 +65,10 @@ struct stx_ctx {
     // pinned scratch for small device->host results (ROI min/max)
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
+    // pinned ring for small host->device uploads (descriptor tables): truly asynchronous copies, the stream is
+    // only synchronised when the ring wraps
+    uint8_t* stage = nullptr;
+    size_t stage_bytes = 0, stage_off = 0;
     // profiler
     bool prof_on = false;
     std::vector<StxProfEntry> prof;
