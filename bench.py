@@ -43,7 +43,8 @@ def parse():
     p.add_argument("--cpu-frames", type=int, default=8, help="frames in the CPU-baseline sample")
     p.add_argument("--profile-steps", type=int, default=3)
     p.add_argument("--e2e-steps", type=int, default=2, help="PCIe-inclusive passes (host frames in, host panorama out)")
-    p.add_argument("--traffic-json", default=None, help="optional JSON with PMC-derived HBM bytes per launch")
+    p.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_traffic.json"),
+                   help="JSON with PMC-derived HBM bytes per launch (tools/make_traffic_json.py)")
     return p.parse_args()
 
 
@@ -199,7 +200,10 @@ def main():
     achieved = bytes_per_launch / (avg_ms / 1e3) / 1e9
     traffic = None
     if args.traffic_json and os.path.exists(args.traffic_json):
-        traffic = json.load(open(args.traffic_json)).get(dom["kernel"])
+        t = json.load(open(args.traffic_json)).get(dom["kernel"])
+        # measured on config 2 only (profiles/): per-launch bytes of the same kernel on the same workload
+        if t and world == 1 and (args.width, args.height, args.frames_per_gpu, args.bands) == (4000, 3000, 8, 5):
+            traffic = round(t["traffic_bytes"])
     roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_launch_us": round(avg_ms * 1e3, 2), "algo_bytes_per_launch": round(bytes_per_launch),

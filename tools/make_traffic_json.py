@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes -> profiles/<tag>_traffic.json: HBM bytes per launch for the kernels
+bench.py names.  FETCH_SIZE / WRITE_SIZE are reported in KB; per MI355X_MICROARCH.md (HBM section)
+gfx950's FETCH_SIZE counts 128-byte read requests at 64 B, so reads are doubled ("corrected"); WRITE_SIZE is taken
+as reported (uncalibrated).  usage: make_traffic_json.py <dir with pmc*_counter_collection.csv> <out.json>"""
+import csv
+import glob
+import json
+import re
+import sys
+from collections import defaultdict
+
+NAMES = [("warp_fast_kernel<3, true, true>", "warp_img_mask"), ("warp_fast_kernel<2, true, true>", "warp_img_mask"),
+         ("warp_fast_kernel<0, true, true>", "warp_img_mask"), ("mb_level0_pk_kernel", "mb_level0"),
+         ("mb_down0_lds_kernel", "mb_down0"), ("mb_down_lds_kernel", "mb_down"), ("warp_tables_kernel", "warp_tables")]
+
+
+def main(d, out):
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in sorted(glob.glob(f"{d}/*counter_collection.csv")):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
+                continue
+            k = re.sub(r"\(anonymous namespace\)::", "", row["Kernel_Name"]).replace("void ", "")
+            acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    res = {}
+    for k, c in acc.items():
+        for pat, name in NAMES:
+            if k.startswith(pat) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                fetch_kb = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"])
+                write_kb = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
+                res[name] = {"hip_kernel": k, "fetch_bytes_raw": fetch_kb * 1024, "write_bytes_raw": write_kb * 1024,
+                             "traffic_bytes": 2 * fetch_kb * 1024 + write_kb * 1024,
+                             "note": "2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, mean per launch"}
+    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    for k, v in res.items():
+        print(f"{k:16s} fetch {v['fetch_bytes_raw']/1e6:9.1f} MB (x2 = {2*v['fetch_bytes_raw']/1e6:9.1f})  write {v['write_bytes_raw']/1e6:9.1f} MB")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
