@@ -42,6 +42,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-frames", type=int, default=8, help="frames in the CPU-baseline sample")
     p.add_argument("--profile-steps", type=int, default=3)
+    p.add_argument("--streams", type=int, default=2, help="panoramas in flight (contexts = HIP streams) at N = 1; "
+                   "measured: 1 -> 93.0, 2 -> 105.9, 3 -> 99.6 Gpix/s")
     p.add_argument("--e2e-steps", type=int, default=2, help="PCIe-inclusive passes (host frames in, host panorama out)")
     p.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_traffic.json"),
                    help="JSON with PMC-derived HBM bytes per launch (tools/make_traffic_json.py)")
@@ -150,21 +152,32 @@ def main():
         job = StitchJob(frames, cams, warper_type=args.warper, blender_type=args.blender, num_bands=args.bands, ctx=ctx)
         job.warper.set_scale(all_cams)
     job.plan()
+    # --streams S (N = 1): S contexts = S HIP streams; consecutive panoramas (independent steps) alternate between
+    # them, so the small coarse-level kernels of one panorama overlap with the large kernels of the next
+    jobs, ctxs = [job], [ctx]
+    if world == 1:
+        for _ in range(1, max(1, args.streams)):
+            c = S.Context(ctx.device)
+            j = StitchJob(job.frames, cams, warper_type=args.warper, blender_type=args.blender, num_bands=args.bands, ctx=c)
+            j.warper.set_scale(all_cams)
+            j.plan()
+            jobs.append(j)
+            ctxs.append(c)
 
     def barrier():
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        out = job.run()
+    for i in range(args.warmup * len(jobs)):
+        out = jobs[i % len(jobs)].run()
         del out
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = job.run()
+    for i in range(args.steps):
+        out = jobs[i % len(jobs)].run()
         del out
-    ctx.sync()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -218,6 +231,7 @@ def main():
         "config": {"workload": f"{n_total} synthetic {args.width}x{args.height} frames, {args.warper} warp + "
                                f"{getattr(job, 'last_num_bands', args.bands)}-band {args.blender} blend, inputs resident in HBM",
                    "frames_per_gpu": fpg, "sharding": "contiguous yaw runs" if world > 1 else "single GPU",
+                   "panoramas_in_flight": len(jobs),
                    "source_mpix_per_step": round(src_mpix, 2)},
         "roofline": roofline,
         "kernels": [{"kernel": k["kernel"], "calls_per_step": k["calls"] / max(1, args.profile_steps),

@@ -64,11 +64,12 @@ class Blender:
     DEFAULT_BLEND_STRENGTH = 5
 
     def __init__(
-        self, blender_type=DEFAULT_BLENDER, blend_strength=DEFAULT_BLEND_STRENGTH
+        self, blender_type=DEFAULT_BLENDER, blend_strength=DEFAULT_BLEND_STRENGTH, ctx=None
     ):
         self.blender_type = blender_type
         self.blend_strength = blend_strength
         self.blender = None
+        self.ctx = ctx  # None: the process-wide context of the default device
 
     @staticmethod
     def result_roi(corners, sizes):
@@ -85,7 +86,7 @@ class Blender:
     def prepare(self, corners, sizes):
         dst_sz = Blender.result_roi(corners, sizes)
         blend_width = np.sqrt(dst_sz[2] * dst_sz[3]) * self.blend_strength / 100
-        ctx = get_context()
+        ctx = self.ctx or get_context()
 
         if self.blender_type == "no" or blend_width < 1:
             self.blender = _BlenderHandle(ctx, _lib.BLEND_NO, 0, 0.0, dst_sz)

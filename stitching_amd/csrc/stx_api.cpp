@@ -760,7 +760,8 @@ STX_EXPORT int stx_warp_batch(stx_ctx* ctx, int type, float scale, int n, const 
     std::vector<int> rois(4 * (size_t)n), sizes(2 * (size_t)n);
     for (int i = 0; i < n; i++) {
         if (!srcs[i] || srcs[i]->elem != STX_U8 || srcs[i]->c != 3) return stx_fail(STX_ERR_INVALID, "warp source %d must be u8x3", i);
-        if (srcs[i]->ctx != ctx) return stx_fail(STX_ERR_INVALID, "warp source %d belongs to another context", i);
+        // sources may live in another context of the same device (long-lived read-only inputs shared by several streams)
+        if (srcs[i]->ctx->device != ctx->device) return stx_fail(STX_ERR_INVALID, "warp source %d lives on another device", i);
         STX_TRY(stx_make_projector(type, scale, K9s + 9 * i, R9s + 9 * i, &ps[i]));
         sizes[2 * i] = srcs[i]->w;
         sizes[2 * i + 1] = srcs[i]->h;

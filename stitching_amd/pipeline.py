@@ -28,7 +28,7 @@ class StitchJob:
         self.frames = [as_device(f, self.ctx) for f in frames]
         self.cameras = list(cameras)
         self.sizes = [(f.width, f.height) for f in self.frames]
-        self.warper = Warper(warper_type)
+        self.warper = Warper(warper_type, ctx=self.ctx)
         self.warper.set_scale(self.cameras)
         self.blender_type = blender_type
         self.num_bands = num_bands
@@ -55,7 +55,7 @@ class StitchJob:
         prev = config.device_resident()
         config.set_device_resident(True)
         try:
-            blender = Blender(self.blender_type, self.blend_strength)
+            blender = Blender(self.blender_type, self.blend_strength, ctx=self.ctx)
             blender.prepare(self.corners, self.warped_sizes)
             imgs, masks, rois = self.warper.warp_images_and_masks(self.frames, self.cameras)
             for img, mask, roi, corner in zip(imgs, masks, rois, self.corners):

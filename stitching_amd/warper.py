@@ -57,9 +57,13 @@ class Warper:
 
     DEFAULT_WARP_TYPE = "spherical"
 
-    def __init__(self, warper_type=DEFAULT_WARP_TYPE):
+    def __init__(self, warper_type=DEFAULT_WARP_TYPE, ctx=None):
         self.warper_type = warper_type
         self.scale = None
+        self.ctx = ctx  # None: the process-wide context of the default device
+
+    def _ctx(self):
+        return self.ctx or get_context()
 
     # ------------------------------------------------------------------ reference surface
     def set_scale(self, cameras):
@@ -71,7 +75,7 @@ class Warper:
             yield self.warp_image(img, camera, aspect)
 
     def warp_image(self, img, camera, aspect=1):
-        ctx = get_context()
+        ctx = self._ctx()
         src = as_device(img, ctx)
         if src.channels != 3 or src.dtype != np.uint8:
             raise StitchingError(f"warp_image expects a HxWx3 uint8 image, got {src.shape} {src.dtype}")
@@ -86,7 +90,7 @@ class Warper:
             yield self.create_and_warp_mask(size, camera, aspect)
 
     def create_and_warp_mask(self, size, camera, aspect=1):
-        ctx = get_context()
+        ctx = self._ctx()
         K, R = self._K_R(camera, aspect)
         out, roi = C.c_void_p(), (C.c_int * 4)()
         _lib.check(ctx._lib.stx_warp_mask(ctx.handle, self._type_id(), self._scale(aspect), _fp(K), _fp(R),
@@ -99,7 +103,7 @@ class Warper:
         roi_corners, roi_sizes = [], []
         if n == 0:
             return roi_corners, roi_sizes
-        ctx = get_context()
+        ctx = self._ctx()
         Ks = np.empty((n, 3, 3), np.float32)
         Rs = np.empty((n, 3, 3), np.float32)
         for i in range(n):
@@ -116,7 +120,7 @@ class Warper:
         return roi_corners, roi_sizes
 
     def warp_roi(self, size, camera, aspect=1):
-        ctx = get_context()
+        ctx = self._ctx()
         K, R = self._K_R(camera, aspect)
         roi = (C.c_int * 4)()
         _lib.check(ctx._lib.stx_warp_roi(ctx.handle, self._type_id(), self._scale(aspect), _fp(K), _fp(R),
@@ -139,7 +143,7 @@ class Warper:
     def warp_image_and_mask(self, img, camera, aspect=1):
         """Fused form of warp_image + create_and_warp_mask for one camera: the backward map is
         evaluated once.  Returns (warped_image, warped_mask, (x, y, w, h))."""
-        ctx = get_context()
+        ctx = self._ctx()
         src = as_device(img, ctx)
         K, R = self._K_R(camera, aspect)
         oi, om, roi = C.c_void_p(), C.c_void_p(), (C.c_int * 4)()
@@ -151,7 +155,7 @@ class Warper:
         """Batched form of warp_images + create_and_warp_masks (stitching/warper.py:39-41, 54-56) for a list of
         images: one ROI pass, one table launch and one remap launch for all of them (stx_warp_batch).
         Returns (warped_images, warped_masks, rois)."""
-        ctx = get_context()
+        ctx = self._ctx()
         srcs = [as_device(img, ctx) for img in imgs]
         cameras = list(cameras)
         n = min(len(srcs), len(cameras))

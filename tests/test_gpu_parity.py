@@ -280,3 +280,25 @@ def test_sharded_job_bands_equal_single_job(oracle, gpu_ctx):
     sm = np.concatenate([b[1] for b in bands], axis=1)
     assert sp.shape == pano.shape
     assert np.array_equal(sm, pmask) and np.array_equal(sp, pano)
+
+
+def test_two_contexts_interleaved(oracle, gpu_ctx):
+    """bench.py keeps two panoramas in flight on two contexts (= two HIP streams) that share the source frames:
+    interleaved runs give the panorama of a single run, and both contexts stay independent."""
+    from stitching_amd.pipeline import StitchJob
+
+    imgs, cams = helpers.small_ring(4, 640, 480, span=150.0)
+    a = StitchJob(imgs, cams, num_bands=4, ctx=gpu_ctx)
+    ref_pano, ref_mask = (np.asarray(x) for x in a.run())
+    ctx2 = S.Context(gpu_ctx.device)
+    try:
+        b = StitchJob(a.frames, cams, num_bands=4, ctx=ctx2)  # frames live in the first context
+        outs = []
+        for i in range(6):
+            outs.append((a if i % 2 == 0 else b).run())
+        for pano, mask in outs:
+            assert np.array_equal(np.asarray(pano), ref_pano) and np.array_equal(np.asarray(mask), ref_mask)
+        del outs, b
+    finally:
+        ctx2.sync()
+        ctx2.close()
