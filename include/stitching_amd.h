@@ -199,6 +199,11 @@ int stx_comm_exchange(stx_comm* comm, int n_ops, const int* peers, const int* is
 int stx_comm_exchange_begin(stx_comm* comm, int n_ops, const int* peers, const int* is_send, void* const* dev_ptrs,
                             const size_t* bytes);
 int stx_comm_exchange_end(stx_comm* comm);
+/* same, for a context other than the one the communicator was created on (same device): one communicator serves
+ * several panoramas in flight on different streams; their exchanges are serialised on the communicator's stream */
+int stx_comm_exchange_begin_on(stx_comm* comm, stx_ctx* on, int n_ops, const int* peers, const int* is_send,
+                               void* const* dev_ptrs, const size_t* bytes);
+int stx_comm_exchange_end_on(stx_comm* comm, stx_ctx* on);
 int stx_comm_destroy(stx_comm* comm);
 
 /* ---- measurement hooks (bench.py) -----------------------------------------------------

@@ -46,7 +46,8 @@ class _BlenderHandle:
     def __del__(self):
         try:
             if self._h is not None:
-                self.ctx._lib.stx_blend_destroy(self._h)
+                if getattr(self.ctx, "handle", None) or getattr(self.ctx, "device", 0) == -1:
+                    self.ctx._lib.stx_blend_destroy(self._h)
                 self._h = None
         except Exception:
             pass

@@ -105,8 +105,20 @@ STX_EXPORT int stx_comm_create(stx_ctx* ctx, int nranks, int rank, const unsigne
 STX_EXPORT int stx_comm_exchange_begin(stx_comm* comm, int n_ops, const int* peers, const int* is_send, void* const* dev_ptrs,
                                        const size_t* bytes)
 {
-    if (!comm || n_ops < 0 || (n_ops && (!peers || !is_send || !dev_ptrs || !bytes)))
+    return stx_comm_exchange_begin_on(comm, comm ? comm->ctx : nullptr, n_ops, peers, is_send, dev_ptrs, bytes);
+}
+
+STX_EXPORT int stx_comm_exchange_end(stx_comm* comm) { return stx_comm_exchange_end_on(comm, comm ? comm->ctx : nullptr); }
+
+// `on`: the context (same device) whose stream produced the send buffers and will consume the receive buffers.
+// One communicator serves several contexts (panoramas in flight on different streams): their exchanges run one
+// after the other on the communicator's stream, in the order the begin calls were made — the same on every rank.
+STX_EXPORT int stx_comm_exchange_begin_on(stx_comm* comm, stx_ctx* on, int n_ops, const int* peers, const int* is_send,
+                                          void* const* dev_ptrs, const size_t* bytes)
+{
+    if (!comm || !on || n_ops < 0 || (n_ops && (!peers || !is_send || !dev_ptrs || !bytes)))
         return stx_fail(STX_ERR_INVALID, "bad argument");
+    if (on->device != comm->ctx->device) return stx_fail(STX_ERR_INVALID, "context lives on another device than the communicator");
     if (comm->in_flight) return stx_fail(STX_ERR_STATE, "an exchange is already in flight on this communicator");
     STX_TRY(stx_set_device(comm->ctx));
     for (int i = 0; i < n_ops; i++)
@@ -119,7 +131,7 @@ STX_EXPORT int stx_comm_exchange_begin(stx_comm* comm, int n_ops, const int* pee
     }
     // the transfer starts after everything queued so far on the context stream (the kernels that filled the
     // send buffers, the last users of the memory behind the receive buffers) ...
-    STX_HIP(hipEventRecord(comm->ready, comm->ctx->stream));
+    STX_HIP(hipEventRecord(comm->ready, on->stream));
     STX_HIP(hipStreamWaitEvent(comm->stream, comm->ready, 0));
     if (n_ops > 0) {
         STX_RCCL(g_rccl.GroupStart());
@@ -140,12 +152,12 @@ STX_EXPORT int stx_comm_exchange_begin(stx_comm* comm, int n_ops, const int* pee
 }
 
 // ... and everything queued on the context stream after this call sees the received strips
-STX_EXPORT int stx_comm_exchange_end(stx_comm* comm)
+STX_EXPORT int stx_comm_exchange_end_on(stx_comm* comm, stx_ctx* on)
 {
-    if (!comm) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (!comm || !on) return stx_fail(STX_ERR_INVALID, "null argument");
     if (!comm->in_flight) return STX_OK;
     STX_TRY(stx_set_device(comm->ctx));
-    STX_HIP(hipStreamWaitEvent(comm->ctx->stream, comm->done, 0));
+    STX_HIP(hipStreamWaitEvent(on->stream, comm->done, 0));
     comm->in_flight = false;
     return STX_OK;
 }

@@ -183,7 +183,8 @@ class DeviceImage:
 
     def free(self):
         if self._h is not None:
-            self.ctx._lib.stx_buf_free(self._h)
+            if self.ctx.handle:  # a closed context has already returned all of its device memory
+                self.ctx._lib.stx_buf_free(self._h)
             self._h = None
 
     def __del__(self):

@@ -159,19 +159,19 @@ class GlooHostTransport:
         self.dist, self.ctx = dist, ctx
         self._pending = None
 
-    def exchange(self, sends, recvs):
+    def exchange(self, sends, recvs, ctx=None):
         """sends: [(dst, DeviceImage packed, nbytes)], recvs: [(src, nbytes)] -> [DeviceImage]"""
         host_sends = [(dst, np.asarray(packed).reshape(-1)[:nbytes]) for dst, packed, nbytes in sends]
-        return [flat_device_buffer(self.ctx, a) for a in gloo_exchange_host(self.dist, host_sends, recvs)]
+        return [flat_device_buffer(ctx or self.ctx, a) for a in gloo_exchange_host(self.dist, host_sends, recvs)]
 
     # split form (same contract as RcclTransport): the host-staged exchange has nothing to overlap, it runs in finish()
-    def start(self, sends, recvs):
-        self._pending = (sends, recvs)
+    def start(self, sends, recvs, ctx=None):
+        self._pending = (sends, recvs, ctx)
 
     def finish(self):
-        sends, recvs = self._pending
+        sends, recvs, ctx = self._pending
         self._pending = None
-        return self.exchange(sends, recvs)
+        return self.exchange(sends, recvs, ctx)
 
 
 def gloo_exchange_host(dist, sends, recvs):
@@ -226,10 +226,13 @@ class RcclTransport:
         _lib.check(_lib.lib().stx_comm_unique_id(uid))
         return bytes(uid)
 
-    def start(self, sends, recvs):
-        """Issue the exchange on the communicator's stream (after everything queued so far on the context
-        stream).  Kernels launched on the context stream until finish() overlap with the transfer."""
-        lib = self.ctx._lib
+    def start(self, sends, recvs, ctx=None):
+        """Issue the exchange on the communicator's stream (after everything queued so far on the stream of `ctx`,
+        default: the communicator's context).  Kernels launched on that stream until finish() overlap with the
+        transfer.  Several contexts (panoramas in flight) may share one transport: call start/finish pairs in the
+        same order on every rank."""
+        ctx = ctx or self.ctx
+        lib = ctx._lib
         rbufs = []
         n = len(sends) + len(recvs)
         peers, is_send = (C.c_int * max(n, 1))(), (C.c_int * max(n, 1))()
@@ -237,27 +240,30 @@ class RcclTransport:
         i = 0
         for src, nbytes in recvs:
             out = C.c_void_p()
-            _lib.check(lib.stx_buf_alloc(self.ctx.handle, min(nbytes, 1 << 30), (nbytes + (1 << 30) - 1) >> 30, 1, _lib.U8,
+            _lib.check(lib.stx_buf_alloc(ctx.handle, min(nbytes, 1 << 30), (nbytes + (1 << 30) - 1) >> 30, 1, _lib.U8,
                                          C.byref(out)))
-            buf = DeviceImage(self.ctx, out)
+            buf = DeviceImage(ctx, out)
             rbufs.append(buf)
             peers[i], is_send[i], ptrs[i], sizes[i] = src, 0, buf.device_ptr(), nbytes
             i += 1
         for dst, packed, nbytes in sends:
             peers[i], is_send[i], ptrs[i], sizes[i] = dst, 1, packed.device_ptr(), nbytes
             i += 1
-        _lib.check(lib.stx_comm_exchange_begin(self._h, n, peers, is_send, ptrs, sizes))
-        self._inflight = (rbufs, [p for _, p, _ in sends])  # both sides stay alive until finish()
+        _lib.check(lib.stx_comm_exchange_begin_on(self._h, ctx.handle, n, peers, is_send, ptrs, sizes))
+        self._inflight = (rbufs, [p for _, p, _ in sends], ctx)  # both sides stay alive until finish()
 
     def finish(self):
         """Order the context stream after the transfer; returns the received strips."""
-        _lib.check(self.ctx._lib.stx_comm_exchange_end(self._h))
-        rbufs, self._sent = self._inflight  # sent strips are released on the next start() / close()
+        rbufs, sent, ctx = self._inflight
+        _lib.check(ctx._lib.stx_comm_exchange_end_on(self._h, ctx.handle))
+        # the sent strips must outlive the transfer: they are released only after a later exchange of the same
+        # context has been ordered behind this one (two generations are kept)
+        self._sent = (self._sent or [])[-2:] + [sent]
         self._inflight = None
         return rbufs
 
-    def exchange(self, sends, recvs):
-        self.start(sends, recvs)
+    def exchange(self, sends, recvs, ctx=None):
+        self.start(sends, recvs, ctx)
         return self.finish()
 
     def close(self):
@@ -292,7 +298,7 @@ class ShardedStitchJob:
             raise StitchingError(f"rank {rank} holds {len(self.frames)} frames but owns {len(self.my_orders)} images")
         size0 = (self.frames[0].width, self.frames[0].height)
         self.all_sizes = list(all_sizes) if all_sizes is not None else [size0] * n
-        self.warper = Warper(warper_type)
+        self.warper = Warper(warper_type, ctx=self.ctx)
         self.warper.set_scale(self.all_cameras)
         self.num_bands_req, self.blend_strength = num_bands, blend_strength
         self.dist = dist
@@ -343,7 +349,7 @@ class ShardedStitchJob:
                 if r != rect:
                     raise StitchingError("contribution geometry differs from the plan")
                 sends.append((dst, packed, nbytes))
-            self.transport.start(sends, [(m[1], m[4]) for m in recv_msgs])
+            self.transport.start(sends, [(m[1], m[4]) for m in recv_msgs], self.ctx)
             # 2. the other images of this rank are warped and fed while the strips travel
             self._warp_and_feed(blender, [k for k in self.my_orders if k not in senders], p)
             # 3. received strips join the image table in global feed order; blend this rank's band
@@ -420,7 +426,7 @@ class _NullTransport:
             raise StitchingError("no transport for a single-rank job")
         return []
 
-    def start(self, sends, recvs):
+    def start(self, sends, recvs, ctx=None):
         self.exchange(sends, recvs)
 
     def finish(self):

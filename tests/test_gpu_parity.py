@@ -196,7 +196,21 @@ def test_rccl_transport_self_exchange(gpu_ctx):
     src = DeviceImage.from_numpy(host, gpu_ctx)
     (dst,) = tr.exchange([(0, src, host.size)], [(0, host.size)])
     assert np.array_equal(np.asarray(dst), host)
-    tr.close()
+    # a second context (second panorama in flight) shares the communicator: begin_on / end_on
+    ctx2 = S.Context(gpu_ctx.device)
+    try:
+        for rep in range(3):
+            for c in (gpu_ctx, ctx2):
+                h2 = rng.integers(0, 256, size=(1, 300001), dtype=np.uint8)
+                s2 = DeviceImage.from_numpy(h2, c)
+                tr.start([(0, s2, h2.size)], [(0, h2.size)], c)
+                (d2,) = tr.finish()
+                assert d2.ctx is c and np.array_equal(np.asarray(d2), h2)
+                del s2, d2
+    finally:
+        tr.close()
+        ctx2.sync()
+        ctx2.close()
 
 
 @pytest.mark.parametrize("wtype", ["spherical", "cylindrical", "plane"])
@@ -238,7 +252,7 @@ def test_sharded_job_bands_equal_single_job(oracle, gpu_ctx):
         def __init__(self):
             self.sent = []
 
-        def start(self, sends, recvs):
+        def start(self, sends, recvs, ctx=None):
             self.sent = [(dst, np.asarray(p).reshape(-1)[:nb].copy()) for dst, p, nb in sends]
             self.recvs = recvs
 
@@ -249,7 +263,7 @@ def test_sharded_job_bands_equal_single_job(oracle, gpu_ctx):
         def __init__(self, inbox):
             self.inbox = inbox
 
-        def start(self, sends, recvs):
+        def start(self, sends, recvs, ctx=None):
             self.recvs = recvs
 
         def finish(self):
