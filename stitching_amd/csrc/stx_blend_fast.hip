@@ -363,6 +363,41 @@ STX_DEV void up_patch(const short* __restrict__ plane, long long stride, int cw,
     }
 }
 
+// packed 16-bit helpers (two pixels per VGPR) shared by the level kernels; see mb_level0_pk_kernel below
+typedef unsigned short pk16 __attribute__((ext_vector_type(2)));
+STX_DEV pk16 pk(uint32_t v) { return __builtin_bit_cast(pk16, v); }
+STX_DEV uint32_t unpk(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
+STX_DEV pk16 pk_splat(unsigned short v) { pk16 r = {v, v}; return r; }
+
+// pyrUp_<FixPtCast<short,6>> of one plane holding values 0..255 for the 8x2 patch with coarse origin (cx, cy)
+STX_DEV void up_patch_pk(const STX_GAS short* __restrict__ plane, uint32_t stride, int cw, int ch, int cx, int cy, pk16 up[2][4])
+{
+    const int rr[3] = {up_idx(cy - 1, ch), cy, up_idx(cy + 1, ch)};
+    const int cl = up_idx(cx - 1, cw), cr = up_idx(cx + 4, cw);
+    pk16 HE[3][2], HO[3][2];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const uint32_t ro = (uint32_t)rr[r] * stride;
+        const v2u v = *reinterpret_cast<const STX_GAS v2u*>(plane + (ro + (uint32_t)cx));  // (c1,c2) (c3,c4)
+        const uint32_t c0 = (uint32_t)(unsigned short)plane[ro + (uint32_t)cl], c5 = (uint32_t)(unsigned short)plane[ro + (uint32_t)cr];
+        const uint32_t B0 = v.x, B1 = v.y;
+        const uint32_t A0 = (B0 << 16) | c0;                          // (c0,c1)
+        const uint32_t A1 = __builtin_amdgcn_alignbit(B1, B0, 16);    // (c2,c3)
+        const uint32_t A2 = (B1 >> 16) | (c5 << 16);                  // (c4,c5)
+        HE[r][0] = pk(A0) + pk(B0) * pk_splat(6) + pk(A1);            // c[j] + 6 c[j+1] + c[j+2], j = 0,1
+        HE[r][1] = pk(A1) + pk(B1) * pk_splat(6) + pk(A2);            // j = 2,3
+        HO[r][0] = pk(B0) + pk(A1);                                   // c[j+1] + c[j+2] (the factor 4 is folded below)
+        HO[r][1] = pk(B1) + pk(A2);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        up[0][k] = (HE[0][k] + HE[1][k] * pk_splat(6) + HE[2][k] + pk_splat(32)) >> pk_splat(6);
+        up[0][2 + k] = (HO[0][k] + HO[1][k] * pk_splat(6) + HO[2][k] + pk_splat(8)) >> pk_splat(4);
+        up[1][k] = (HE[1][k] + HE[2][k] + pk_splat(8)) >> pk_splat(4);
+        up[1][2 + k] = (HO[1][k] + HO[2][k] + pk_splat(2)) >> pk_splat(2);
+    }
+}
+
 // normalizeUsingWeightMap, + pyrUp(finished coarser level) saturating, store (level >= 1: planar int16;
 // level 0: u8 panorama via convertScaleAbs, mask = weight > eps, optional int16 result)
 template <bool L0>
@@ -450,7 +485,8 @@ STX_DEV void level_epilogue(const MbLevelK& P, int X0, int Y0, int (&acc)[2][8][
 
 // CONTRIB: the image table may hold received contribution strips (kind 1); EMIT: write un-normalised sums.
 // Both are compile-time so that the common single-GPU instantiation carries neither path.
-template <bool L0, bool CONTRIB, bool EMIT>
+// U8SRC (levels >= 1): every image was fed as u8, so G_i is 0..255 and pyrUp / the Laplacian run in packed 16-bit lanes
+template <bool L0, bool CONTRIB, bool EMIT, bool U8SRC>
 __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
 {
     const int tid = threadIdx.x;
@@ -504,14 +540,37 @@ __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
                 }
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
+                    if (U8SRC && !contrib) {
+                        pk16 upk[2][4];
+                        up_patch_pk(gp(im.g[lv + 1]) + c * im.g_plane[lv + 1], (uint32_t)im.g_stride[lv + 1], lw >> 1, lh >> 1,
+                                    lx0 >> 1, ly0 >> 1, upk);
+#pragma unroll
+                        for (int r = 0; r < 2; r++) {
+                            const v4u gv = *reinterpret_cast<const STX_GAS v4u*>(
+                                gp(im.g[lv]) + c * im.g_plane[lv] + ((uint32_t)(ly0 + r) * (uint32_t)im.g_stride[lv] + (uint32_t)lx0));
+                            // natural pairs (0,1)(2,3)(4,5)(6,7) -> the pyrUp pair order (0,2)(4,6)(1,3)(5,7)
+                            const uint32_t Lq[4] = {
+                                unpk(pk(__builtin_amdgcn_perm(gv.y, gv.x, 0x05040100u)) - upk[r][0]),
+                                unpk(pk(__builtin_amdgcn_perm(gv.w, gv.z, 0x05040100u)) - upk[r][1]),
+                                unpk(pk(__builtin_amdgcn_perm(gv.y, gv.x, 0x07060302u)) - upk[r][2]),
+                                unpk(pk(__builtin_amdgcn_perm(gv.w, gv.z, 0x07060302u)) - upk[r][3])};
+#pragma unroll
+                            for (int j = 0; j < 8; j++) {
+                                const int q = (j & 1) ? 2 + (j >> 2) : (j >> 2);
+                                const int L = ((j >> 1) & 1) ? s16hi(Lq[q]) : s16lo(Lq[q]);  // in [-255, 255]: subtract never saturates
+                                acc[r][j][c] += trunc_small(fmul((float)L, w[r][j]));
+                            }
+                        }
+                        continue;
+                    }
                     int up[2][8];
                     if (!contrib)
                         up_patch(im.g[lv + 1] + c * im.g_plane[lv + 1], im.g_stride[lv + 1], lw >> 1, lh >> 1, lx0 >> 1,
                                  ly0 >> 1, up);
 #pragma unroll
                     for (int r = 0; r < 2; r++) {
-                        const short* gp = im.g[lv] + c * im.g_plane[lv] + (long long)(ly0 + r) * im.g_stride[lv] + lx0;
-                        uint4 gv = *reinterpret_cast<const uint4*>(gp);
+                        const short* grow = im.g[lv] + c * im.g_plane[lv] + (long long)(ly0 + r) * im.g_stride[lv] + lx0;
+                        uint4 gv = *reinterpret_cast<const uint4*>(grow);
                         const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
@@ -637,40 +696,6 @@ __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
 // Pixel pairs inside a lane's 8-pixel strip are kept in the order pyrUp produces them:
 //   pair 0 = (px0, px2), 1 = (px4, px6), 2 = (px1, px3), 3 = (px5, px7)   [lo half, hi half]
 // ---------------------------------------------------------------------------------------------
-typedef unsigned short pk16 __attribute__((ext_vector_type(2)));
-STX_DEV pk16 pk(uint32_t v) { return __builtin_bit_cast(pk16, v); }
-STX_DEV uint32_t unpk(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
-STX_DEV pk16 pk_splat(unsigned short v) { pk16 r = {v, v}; return r; }
-
-// pyrUp_<FixPtCast<short,6>> of one plane holding values 0..255 for the 8x2 patch with coarse origin (cx, cy)
-STX_DEV void up_patch_pk(const STX_GAS short* __restrict__ plane, uint32_t stride, int cw, int ch, int cx, int cy, pk16 up[2][4])
-{
-    const int rr[3] = {up_idx(cy - 1, ch), cy, up_idx(cy + 1, ch)};
-    const int cl = up_idx(cx - 1, cw), cr = up_idx(cx + 4, cw);
-    pk16 HE[3][2], HO[3][2];
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const uint32_t ro = (uint32_t)rr[r] * stride;
-        const v2u v = *reinterpret_cast<const STX_GAS v2u*>(plane + (ro + (uint32_t)cx));  // (c1,c2) (c3,c4)
-        const uint32_t c0 = (uint32_t)(unsigned short)plane[ro + (uint32_t)cl], c5 = (uint32_t)(unsigned short)plane[ro + (uint32_t)cr];
-        const uint32_t B0 = v.x, B1 = v.y;
-        const uint32_t A0 = (B0 << 16) | c0;                          // (c0,c1)
-        const uint32_t A1 = __builtin_amdgcn_alignbit(B1, B0, 16);    // (c2,c3)
-        const uint32_t A2 = (B1 >> 16) | (c5 << 16);                  // (c4,c5)
-        HE[r][0] = pk(A0) + pk(B0) * pk_splat(6) + pk(A1);            // c[j] + 6 c[j+1] + c[j+2], j = 0,1
-        HE[r][1] = pk(A1) + pk(B1) * pk_splat(6) + pk(A2);            // j = 2,3
-        HO[r][0] = pk(B0) + pk(A1);                                   // c[j+1] + c[j+2] (the factor 4 is folded below)
-        HO[r][1] = pk(B1) + pk(A2);
-    }
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        up[0][k] = (HE[0][k] + HE[1][k] * pk_splat(6) + HE[2][k] + pk_splat(32)) >> pk_splat(6);
-        up[0][2 + k] = (HO[0][k] + HO[1][k] * pk_splat(6) + HO[2][k] + pk_splat(8)) >> pk_splat(4);
-        up[1][k] = (HE[1][k] + HE[2][k] + pk_splat(8)) >> pk_splat(4);
-        up[1][2 + k] = (HO[1][k] + HO[2][k] + pk_splat(2)) >> pk_splat(2);
-    }
-}
-
 // bytes o1, o2 of the little-endian byte stream held in w[] -> (w[o1], 0, w[o2], 0)
 template <int O1, int O2>
 STX_DEV uint32_t pair_u8(const uint32_t* w)
@@ -1041,14 +1066,17 @@ bool stx_fast_mb_level(stx_ctx* ctx, const MbLevelK& K)
         if (K.has_contrib) hipLaunchKernelGGL(mb_level0_pk_kernel<true>, grid, dim3(256), 0, st, K);
         else hipLaunchKernelGGL(mb_level0_pk_kernel<false>, grid, dim3(256), 0, st, K);
     } else if (K.emit) {
-        if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, true>), grid, dim3(256), 0, st, K);
-        else hipLaunchKernelGGL((mb_level_fast_kernel<false, false, true>), grid, dim3(256), 0, st, K);
+        if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, true, false>), grid, dim3(256), 0, st, K);
+        else if (K.all_u8) hipLaunchKernelGGL((mb_level_fast_kernel<false, false, true, true>), grid, dim3(256), 0, st, K);
+        else hipLaunchKernelGGL((mb_level_fast_kernel<false, false, true, false>), grid, dim3(256), 0, st, K);
     } else if (K.has_contrib) {
-        if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, true, false>), grid, dim3(256), 0, st, K);
-        else hipLaunchKernelGGL((mb_level_fast_kernel<false, true, false>), grid, dim3(256), 0, st, K);
+        if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, true, false, false>), grid, dim3(256), 0, st, K);
+        else if (K.all_u8) hipLaunchKernelGGL((mb_level_fast_kernel<false, true, false, true>), grid, dim3(256), 0, st, K);
+        else hipLaunchKernelGGL((mb_level_fast_kernel<false, true, false, false>), grid, dim3(256), 0, st, K);
     } else {
-        if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, false>), grid, dim3(256), 0, st, K);
-        else hipLaunchKernelGGL((mb_level_fast_kernel<false, false, false>), grid, dim3(256), 0, st, K);
+        if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, false, false>), grid, dim3(256), 0, st, K);
+        else if (K.all_u8) hipLaunchKernelGGL((mb_level_fast_kernel<false, false, false, true>), grid, dim3(256), 0, st, K);
+        else hipLaunchKernelGGL((mb_level_fast_kernel<false, false, false, false>), grid, dim3(256), 0, st, K);
     }
     return launched_ok();
 }
