@@ -36,6 +36,18 @@ constexpr float INV256 = 0.00390625f;
 template <class T> STX_DEV const STX_GAS T* gp(const T* p) { return (const STX_GAS T*)p; }
 template <class T> STX_DEV STX_GAS T* gp(T* p) { return (STX_GAS T*)p; }
 
+// tile (tx, ty) of workgroup b under the XCD-aware order; false when b is padding
+STX_DEV bool xcd_tile(const StxTileMap& M, uint32_t b, int& tx, int& ty)
+{
+    const uint32_t local = b >> 3;
+    const uint32_t band_i = M.band_tiles == 1 ? local : __umulhi(local, M.magic_band);
+    const uint32_t within = local - band_i * (uint32_t)M.band_tiles;
+    const uint32_t wy = M.tiles_x == 1 ? within : __umulhi(within, M.magic_tx);
+    tx = (int)(within - wy * (uint32_t)M.tiles_x);
+    ty = (int)((band_i * 8u + (b & 7u)) * (uint32_t)M.band_rows + wy);
+    return ty < M.tiles_y;
+}
+
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef v4u __attribute__((aligned(4))) v4u_a4;  // 16 bytes, only dword-aligned
@@ -66,6 +78,7 @@ STX_DEV int h5i(int s0, int s1, int s2, int s3, int s4) { return s2 * 6 + (s1 + 
 // 64 x 14 outputs: the 31 input rows give 31*8 = 248 (levels >= 1) / 31*16 = 496 (level 0) load tasks, i.e. one /
 // two full passes of the 256 threads (16 rows would leave a third, 9 %-full pass)
 constexpr int DN_TOW = 64, DN_TOH = 14, DN_ROWS = 2 * DN_TOH + 3;
+constexpr int DN_BAND = 2;  // tile rows per XCD band
 
 // level 0 (u8 BGR + u8 mask): 4 outputs from 11 input pixels
 STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, short* hs1, short* hs2, float* hw)
@@ -136,14 +149,16 @@ STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, s
 }
 
 // blockIdx.z = image: all fed images are processed by one launch (deferred pyramid build)
-__global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __restrict__ images)
+__global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __restrict__ images, StxTileMap M)
 {
     __shared__ short s_h[3][DN_ROWS][DN_TOW];  // horizontal sums, <= 255*16
     __shared__ float s_w[DN_ROWS][DN_TOW];
     const StxMbImage& im = images[blockIdx.z];
     const int tid = threadIdx.x;
     const int ow = im.fw >> 1, oh = im.fh >> 1;
-    const int X0 = blockIdx.x * DN_TOW, Y0 = blockIdx.y * DN_TOH;
+    int tile_tx, tile_ty;
+    if (!xcd_tile(M, blockIdx.x, tile_tx, tile_ty)) return;
+    const int X0 = tile_tx * DN_TOW, Y0 = tile_ty * DN_TOH;
     if (im.img0_is_s16 || X0 >= ow || Y0 >= oh) return;  // int16 sources take the generic kernel
     for (int task = tid; task < DN_ROWS * (DN_TOW / 4); task += 256) {
         const int r = task / (DN_TOW / 4), q = task % (DN_TOW / 4);
@@ -208,7 +223,7 @@ STX_DEV void dn_load19_s16(const short* __restrict__ p, int c0, int iw, bool fas
     }
 }
 
-__global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __restrict__ images, int lv)
+__global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __restrict__ images, int lv, StxTileMap M)
 {
     __shared__ int s_h[3][DN_ROWS][DN_TOW];
     __shared__ float s_w[DN_ROWS][DN_TOW];
@@ -216,7 +231,9 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
     const int tid = threadIdx.x;
     const int iw = im.fw >> lv, ih = im.fh >> lv;
     const int ow = iw >> 1, oh = ih >> 1;
-    const int X0 = blockIdx.x * DN_TOW, Y0 = blockIdx.y * DN_TOH;
+    int tile_tx, tile_ty;
+    if (!xcd_tile(M, blockIdx.x, tile_tx, tile_ty)) return;
+    const int X0 = tile_tx * DN_TOW, Y0 = tile_ty * DN_TOH;
     if (X0 >= ow || Y0 >= oh) return;
     const short* G = im.g[lv];
     const long long gs = im.g_stride[lv], gp = im.g_plane[lv];
@@ -1047,9 +1064,12 @@ bool stx_fast_mb_down_batch(stx_ctx* ctx, const StxMbImage* d_images, const StxM
         mh = std::max(mh, (h_images[i].fh >> level) >> 1);
     }
     if (n <= 0 || mw < 1 || mh < 1 || n > 65535) return false;
-    dim3 grid((mw + DN_TOW - 1) / DN_TOW, (mh + DN_TOH - 1) / DN_TOH, n);
-    if (level == 0) hipLaunchKernelGGL(mb_down0_lds_kernel, grid, dim3(256), 0, ctx->stream, d_images);
-    else hipLaunchKernelGGL(mb_down_lds_kernel, grid, dim3(256), 0, ctx->stream, d_images, level);
+    // tiles of 64 outputs are only 3-4 cache lines wide: horizontal neighbours must share an L2 or every edge line is
+    // fetched twice (measured for level 0: 556 MB fetched for 354 MB of input with the plain order)
+    const StxTileMap M = stx_tile_map((mw + DN_TOW - 1) / DN_TOW, (mh + DN_TOH - 1) / DN_TOH, DN_BAND);
+    dim3 grid(stx_tile_grid(M), 1, n);
+    if (level == 0) hipLaunchKernelGGL(mb_down0_lds_kernel, grid, dim3(256), 0, ctx->stream, d_images, M);
+    else hipLaunchKernelGGL(mb_down_lds_kernel, grid, dim3(256), 0, ctx->stream, d_images, level, M);
     return launched_ok();
 }
 
