@@ -55,6 +55,59 @@ typedef v4u __attribute__((aligned(4))) v4u_a4;  // 16 bytes, only dword-aligned
 struct __attribute__((aligned(4))) U4a4 { uint32_t v[4]; };  // 16 bytes, only dword-aligned
 struct __attribute__((aligned(4))) U2a4 { uint32_t v[2]; };
 
+// packed 16-bit helpers (two pixels per VGPR) shared by the level kernels; see mb_level0_pk_kernel below
+typedef unsigned short pk16 __attribute__((ext_vector_type(2)));
+STX_DEV pk16 pk(uint32_t v) { return __builtin_bit_cast(pk16, v); }
+STX_DEV uint32_t unpk(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
+STX_DEV pk16 pk_splat(unsigned short v) { pk16 r = {v, v}; return r; }
+
+// pyrUp_<FixPtCast<short,6>> of one plane holding values 0..255 for the 8x2 patch with coarse origin (cx, cy)
+STX_DEV void up_patch_pk(const STX_GAS short* __restrict__ plane, uint32_t stride, int cw, int ch, int cx, int cy, pk16 up[2][4])
+{
+    const int rr[3] = {up_idx(cy - 1, ch), cy, up_idx(cy + 1, ch)};
+    const int cl = up_idx(cx - 1, cw), cr = up_idx(cx + 4, cw);
+    pk16 HE[3][2], HO[3][2];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const uint32_t ro = (uint32_t)rr[r] * stride;
+        const v2u v = *reinterpret_cast<const STX_GAS v2u*>(plane + (ro + (uint32_t)cx));  // (c1,c2) (c3,c4)
+        const uint32_t c0 = (uint32_t)(unsigned short)plane[ro + (uint32_t)cl], c5 = (uint32_t)(unsigned short)plane[ro + (uint32_t)cr];
+        const uint32_t B0 = v.x, B1 = v.y;
+        const uint32_t A0 = (B0 << 16) | c0;                          // (c0,c1)
+        const uint32_t A1 = __builtin_amdgcn_alignbit(B1, B0, 16);    // (c2,c3)
+        const uint32_t A2 = (B1 >> 16) | (c5 << 16);                  // (c4,c5)
+        HE[r][0] = pk(A0) + pk(B0) * pk_splat(6) + pk(A1);            // c[j] + 6 c[j+1] + c[j+2], j = 0,1
+        HE[r][1] = pk(A1) + pk(B1) * pk_splat(6) + pk(A2);            // j = 2,3
+        HO[r][0] = pk(B0) + pk(A1);                                   // c[j+1] + c[j+2] (the factor 4 is folded below)
+        HO[r][1] = pk(B1) + pk(A2);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        up[0][k] = (HE[0][k] + HE[1][k] * pk_splat(6) + HE[2][k] + pk_splat(32)) >> pk_splat(6);
+        up[0][2 + k] = (HO[0][k] + HO[1][k] * pk_splat(6) + HO[2][k] + pk_splat(8)) >> pk_splat(4);
+        up[1][k] = (HE[1][k] + HE[2][k] + pk_splat(8)) >> pk_splat(4);
+        up[1][2 + k] = (HO[1][k] + HO[2][k] + pk_splat(2)) >> pk_splat(2);
+    }
+}
+
+
+// bytes o1, o2 of the little-endian byte stream held in w[] -> (w[o1], 0, w[o2], 0)
+template <int O1, int O2>
+STX_DEV uint32_t pair_u8(const uint32_t* w)
+{
+    constexpr uint32_t sel = (uint32_t)(O1 & 3) | (0x0cu << 8) | ((uint32_t)(4 + (O2 & 3)) << 16) | (0x0cu << 24);
+    return __builtin_amdgcn_perm(w[O2 >> 2], w[O1 >> 2], sel);
+}
+// mask bytes a, b (0 or 255) of m[] -> (0xffff or 0, 0xffff or 0)
+template <int A, int B>
+STX_DEV uint32_t pair_mask(const uint32_t* m)
+{
+    constexpr uint32_t sel = (uint32_t)(A & 3) * 0x0101u | (uint32_t)(4 + (B & 3)) * 0x01010000u;
+    return __builtin_amdgcn_perm(m[B >> 2], m[A >> 2], sel);
+}
+
+
+
 STX_DEV int s16lo(uint32_t v) { return (int)(short)(v & 0xffffu); }
 STX_DEV int s16hi(uint32_t v) { return (int)(short)(v >> 16); }
 STX_DEV uint32_t pack16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
@@ -81,6 +134,8 @@ constexpr int DN_TOW = 64, DN_TOH = 14, DN_ROWS = 2 * DN_TOH + 3;
 constexpr int DN_BAND = 2;  // tile rows per XCD band
 
 // level 0 (u8 BGR + u8 mask): 4 outputs from 11 input pixels
+// PK: every image of the launch is u8 with a 0 / 255 mask (decided on the host: no per-task branch in the kernel)
+template <bool PK>
 STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, short* hs1, short* hs2, float* hw)
 {
     const int by = reflect101(row, im.fh) - im.top;  // bordered row -> image row
@@ -108,6 +163,45 @@ STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, s
         w[6] = __builtin_amdgcn_alignbyte(d1.v[3], d1.v[2], s);
         w[7] = __builtin_amdgcn_alignbyte(d2.v[0], d1.v[3], s);
         w[8] = __builtin_amdgcn_alignbyte(d2.v[1], d2.v[0], s);
+        if (PK) {
+            // packed path (u8 image, 0 / 255 mask): outputs o = 0..3 use pixels 2o .. 2o+4 with weights 1 4 6 4 1;
+            // as pairs (out0,out1) = (p0,p2) + 4(p1,p3) + 6(p2,p4) + 4(p3,p5) + (p4,p6), (out2,out3) likewise from p4..p10
+            short* hs[3] = {hs0, hs1, hs2};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const pk16 A = pk(c == 0 ? pair_u8<0, 6>(w) : c == 1 ? pair_u8<1, 7>(w) : pair_u8<2, 8>(w));
+                const pk16 Bp = pk(c == 0 ? pair_u8<3, 9>(w) : c == 1 ? pair_u8<4, 10>(w) : pair_u8<5, 11>(w));
+                const pk16 Cp = pk(c == 0 ? pair_u8<6, 12>(w) : c == 1 ? pair_u8<7, 13>(w) : pair_u8<8, 14>(w));
+                const pk16 D = pk(c == 0 ? pair_u8<9, 15>(w) : c == 1 ? pair_u8<10, 16>(w) : pair_u8<11, 17>(w));
+                const pk16 E = pk(c == 0 ? pair_u8<12, 18>(w) : c == 1 ? pair_u8<13, 19>(w) : pair_u8<14, 20>(w));
+                const pk16 F = pk(c == 0 ? pair_u8<15, 21>(w) : c == 1 ? pair_u8<16, 22>(w) : pair_u8<17, 23>(w));
+                const pk16 G = pk(c == 0 ? pair_u8<18, 24>(w) : c == 1 ? pair_u8<19, 25>(w) : pair_u8<20, 26>(w));
+                const pk16 H = pk(c == 0 ? pair_u8<21, 27>(w) : c == 1 ? pair_u8<22, 28>(w) : pair_u8<23, 29>(w));
+                const pk16 I = pk(c == 0 ? pair_u8<24, 30>(w) : c == 1 ? pair_u8<25, 31>(w) : pair_u8<26, 32>(w));
+                const pk16 o01 = A + E + Cp * pk_splat(6) + (Bp + D) * pk_splat(4);
+                const pk16 o23 = E + I + G * pk_splat(6) + (F + H) * pk_splat(4);
+                *reinterpret_cast<uint2*>(hs[c]) = make_uint2(unpk(o01), unpk(o23));
+            }
+            if (yin) {
+                const long long moff = (long long)by * im.mask0_stride + a0;  // 11 bytes
+                const uint8_t* mq = im.mask0 + (moff & ~3ll);
+                const uint32_t ms = (uint32_t)moff & 3u;
+                U4a4 m = *reinterpret_cast<const U4a4*>(mq);
+                uint32_t mb[3];  // 0 / 255 -> 0 / 1: W_0 is exactly 0.f or 1.f, the fp32 row sums are small integers
+                mb[0] = __builtin_amdgcn_alignbyte(m.v[1], m.v[0], ms) & 0x01010101u;
+                mb[1] = __builtin_amdgcn_alignbyte(m.v[2], m.v[1], ms) & 0x01010101u;
+                mb[2] = __builtin_amdgcn_alignbyte(m.v[3], m.v[2], ms) & 0x01010101u;
+                const pk16 o01 = pk(pair_u8<0, 2>(mb)) + pk(pair_u8<4, 6>(mb)) + pk(pair_u8<2, 4>(mb)) * pk_splat(6) +
+                                 (pk(pair_u8<1, 3>(mb)) + pk(pair_u8<3, 5>(mb))) * pk_splat(4);
+                const pk16 o23 = pk(pair_u8<4, 6>(mb)) + pk(pair_u8<8, 10>(mb)) + pk(pair_u8<6, 8>(mb)) * pk_splat(6) +
+                                 (pk(pair_u8<5, 7>(mb)) + pk(pair_u8<7, 9>(mb))) * pk_splat(4);
+                *reinterpret_cast<float4*>(hw) = make_float4((float)(unpk(o01) & 0xffffu), (float)(unpk(o01) >> 16),
+                                                             (float)(unpk(o23) & 0xffffu), (float)(unpk(o23) >> 16));
+            } else {
+                *reinterpret_cast<float4*>(hw) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 11; j++) {
             px[j][0] = (int)byte_of(w, 3 * j);
@@ -149,6 +243,7 @@ STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, s
 }
 
 // blockIdx.z = image: all fed images are processed by one launch (deferred pyramid build)
+template <bool PK>
 __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __restrict__ images, StxTileMap M)
 {
     __shared__ short s_h[3][DN_ROWS][DN_TOW];  // horizontal sums, <= 255*16
@@ -162,8 +257,8 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
     if (im.img0_is_s16 || X0 >= ow || Y0 >= oh) return;  // int16 sources take the generic kernel
     for (int task = tid; task < DN_ROWS * (DN_TOW / 4); task += 256) {
         const int r = task / (DN_TOW / 4), q = task % (DN_TOW / 4);
-        dn_task_level0(im, 2 * Y0 - 2 + r, X0 + 4 * q, &s_h[0][r][4 * q], &s_h[1][r][4 * q], &s_h[2][r][4 * q],
-                       &s_w[r][4 * q]);
+        dn_task_level0<PK>(im, 2 * Y0 - 2 + r, X0 + 4 * q, &s_h[0][r][4 * q], &s_h[1][r][4 * q], &s_h[2][r][4 * q],
+                           &s_w[r][4 * q]);
     }
     __syncthreads();
     const int p = tid & 31, rg = tid >> 5;  // output pair, row group (2 rows)
@@ -176,18 +271,14 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
         if (yl >= DN_TOH || y >= oh) break;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            int a[5], b[5];
+            // two outputs per register: the row sums are <= 255 * 16, the column sum + 128 <= 65408 fits 16 bits
+            pk16 a[5];
 #pragma unroll
-            for (int k = 0; k < 5; k++) {
-                uint32_t v = *reinterpret_cast<const uint32_t*>(&s_h[c][2 * yl + k][2 * p]);
-                a[k] = s16lo(v);
-                b[k] = s16hi(v);
-            }
-            const int va = (h5i(a[0], a[1], a[2], a[3], a[4]) + 128) >> 8;
-            const int vb = (h5i(b[0], b[1], b[2], b[3], b[4]) + 128) >> 8;
+            for (int k = 0; k < 5; k++) a[k] = pk(*reinterpret_cast<const uint32_t*>(&s_h[c][2 * yl + k][2 * p]));
+            const pk16 v = (a[0] + a[4] + a[2] * pk_splat(6) + (a[1] + a[3]) * pk_splat(4) + pk_splat(128)) >> pk_splat(8);
             short* o = im.g[1] + c * im.g_plane[1] + (long long)y * im.g_stride[1] + xo;
-            if (two) *reinterpret_cast<uint32_t*>(o) = pack16(va, vb);
-            else o[0] = (short)va;
+            if (two) *reinterpret_cast<uint32_t*>(o) = unpk(v);
+            else o[0] = (short)(unpk(v) & 0xffffu);
         }
         float fa[5], fb[5];
 #pragma unroll
@@ -377,41 +468,6 @@ STX_DEV void up_patch(const short* __restrict__ plane, long long stride, int cw,
         up[0][2 * j + 1] = s6(ho[0][j] + 6 * ho[1][j] + ho[2][j]);
         up[1][2 * j] = s6(4 * (he[1][j] + he[2][j]));
         up[1][2 * j + 1] = s6(4 * (ho[1][j] + ho[2][j]));
-    }
-}
-
-// packed 16-bit helpers (two pixels per VGPR) shared by the level kernels; see mb_level0_pk_kernel below
-typedef unsigned short pk16 __attribute__((ext_vector_type(2)));
-STX_DEV pk16 pk(uint32_t v) { return __builtin_bit_cast(pk16, v); }
-STX_DEV uint32_t unpk(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
-STX_DEV pk16 pk_splat(unsigned short v) { pk16 r = {v, v}; return r; }
-
-// pyrUp_<FixPtCast<short,6>> of one plane holding values 0..255 for the 8x2 patch with coarse origin (cx, cy)
-STX_DEV void up_patch_pk(const STX_GAS short* __restrict__ plane, uint32_t stride, int cw, int ch, int cx, int cy, pk16 up[2][4])
-{
-    const int rr[3] = {up_idx(cy - 1, ch), cy, up_idx(cy + 1, ch)};
-    const int cl = up_idx(cx - 1, cw), cr = up_idx(cx + 4, cw);
-    pk16 HE[3][2], HO[3][2];
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const uint32_t ro = (uint32_t)rr[r] * stride;
-        const v2u v = *reinterpret_cast<const STX_GAS v2u*>(plane + (ro + (uint32_t)cx));  // (c1,c2) (c3,c4)
-        const uint32_t c0 = (uint32_t)(unsigned short)plane[ro + (uint32_t)cl], c5 = (uint32_t)(unsigned short)plane[ro + (uint32_t)cr];
-        const uint32_t B0 = v.x, B1 = v.y;
-        const uint32_t A0 = (B0 << 16) | c0;                          // (c0,c1)
-        const uint32_t A1 = __builtin_amdgcn_alignbit(B1, B0, 16);    // (c2,c3)
-        const uint32_t A2 = (B1 >> 16) | (c5 << 16);                  // (c4,c5)
-        HE[r][0] = pk(A0) + pk(B0) * pk_splat(6) + pk(A1);            // c[j] + 6 c[j+1] + c[j+2], j = 0,1
-        HE[r][1] = pk(A1) + pk(B1) * pk_splat(6) + pk(A2);            // j = 2,3
-        HO[r][0] = pk(B0) + pk(A1);                                   // c[j+1] + c[j+2] (the factor 4 is folded below)
-        HO[r][1] = pk(B1) + pk(A2);
-    }
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        up[0][k] = (HE[0][k] + HE[1][k] * pk_splat(6) + HE[2][k] + pk_splat(32)) >> pk_splat(6);
-        up[0][2 + k] = (HO[0][k] + HO[1][k] * pk_splat(6) + HO[2][k] + pk_splat(8)) >> pk_splat(4);
-        up[1][k] = (HE[1][k] + HE[2][k] + pk_splat(8)) >> pk_splat(4);
-        up[1][2 + k] = (HO[1][k] + HO[2][k] + pk_splat(2)) >> pk_splat(2);
     }
 }
 
@@ -713,22 +769,6 @@ __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
 // Pixel pairs inside a lane's 8-pixel strip are kept in the order pyrUp produces them:
 //   pair 0 = (px0, px2), 1 = (px4, px6), 2 = (px1, px3), 3 = (px5, px7)   [lo half, hi half]
 // ---------------------------------------------------------------------------------------------
-// bytes o1, o2 of the little-endian byte stream held in w[] -> (w[o1], 0, w[o2], 0)
-template <int O1, int O2>
-STX_DEV uint32_t pair_u8(const uint32_t* w)
-{
-    constexpr uint32_t sel = (uint32_t)(O1 & 3) | (0x0cu << 8) | ((uint32_t)(4 + (O2 & 3)) << 16) | (0x0cu << 24);
-    return __builtin_amdgcn_perm(w[O2 >> 2], w[O1 >> 2], sel);
-}
-// mask bytes a, b (0 or 255) of m[] -> (0xffff or 0, 0xffff or 0)
-template <int A, int B>
-STX_DEV uint32_t pair_mask(const uint32_t* m)
-{
-    constexpr uint32_t sel = (uint32_t)(A & 3) * 0x0101u | (uint32_t)(4 + (B & 3)) * 0x01010000u;
-    return __builtin_amdgcn_perm(m[B >> 2], m[A >> 2], sel);
-}
-
-
 // ---------------------------------------------------------------------------------------------
 // Packed epilogue of the level-0 kernel (pair layout, see above).  Everything stays two pixels per register:
 //   normalise : where no pixel of the lane is covered by more than one image, (short)(a / (1 + 1e-5f)) is
@@ -1067,8 +1107,11 @@ bool stx_fast_mb_down_batch(stx_ctx* ctx, const StxMbImage* d_images, const StxM
     // tiles of 64 outputs are only 3-4 cache lines wide: horizontal neighbours must share an L2 or every edge line is
     // fetched twice (measured for level 0: 556 MB fetched for 354 MB of input with the plain order)
     const StxTileMap M = stx_tile_map((mw + DN_TOW - 1) / DN_TOW, (mh + DN_TOH - 1) / DN_TOH, DN_BAND);
+    bool pk_ok = true;  // packed 16-bit row sums need u8 images with 0 / 255 masks
+    for (int i = 0; i < n; i++) pk_ok = pk_ok && !h_images[i].img0_is_s16 && h_images[i].mask_binary;
     dim3 grid(stx_tile_grid(M), 1, n);
-    if (level == 0) hipLaunchKernelGGL(mb_down0_lds_kernel, grid, dim3(256), 0, ctx->stream, d_images, M);
+    if (level == 0 && pk_ok) hipLaunchKernelGGL(mb_down0_lds_kernel<true>, grid, dim3(256), 0, ctx->stream, d_images, M);
+    else if (level == 0) hipLaunchKernelGGL(mb_down0_lds_kernel<false>, grid, dim3(256), 0, ctx->stream, d_images, M);
     else hipLaunchKernelGGL(mb_down_lds_kernel, grid, dim3(256), 0, ctx->stream, d_images, level, M);
     return launched_ok();
 }
