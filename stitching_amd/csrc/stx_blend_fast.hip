@@ -39,6 +39,12 @@ template <class T> STX_DEV STX_GAS T* gp(T* p) { return (STX_GAS T*)p; }
 // tile (tx, ty) of workgroup b under the XCD-aware order; false when b is padding
 STX_DEV bool xcd_tile(const StxTileMap& M, uint32_t b, int& tx, int& ty)
 {
+    if (M.plain) {
+        const uint32_t wy = M.tiles_x == 1 ? b : __umulhi(b, M.magic_tx);
+        tx = (int)(b - wy * (uint32_t)M.tiles_x);
+        ty = (int)wy;
+        return true;
+    }
     const uint32_t local = b >> 3;
     const uint32_t band_i = M.band_tiles == 1 ? local : __umulhi(local, M.magic_band);
     const uint32_t within = local - band_i * (uint32_t)M.band_tiles;
@@ -132,6 +138,7 @@ STX_DEV int h5i(int s0, int s1, int s2, int s3, int s4) { return s2 * 6 + (s1 + 
 // two full passes of the 256 threads (16 rows would leave a third, 9 %-full pass)
 constexpr int DN_TOW = 64, DN_TOH = 14, DN_ROWS = 2 * DN_TOH + 3;
 constexpr int DN_BAND = 2;  // tile rows per XCD band
+constexpr int LV_BAND = 4;  // same for the 512 x 8 tiles of the level kernels
 
 // level 0 (u8 BGR + u8 mask): 4 outputs from 11 input pixels
 // PK: every image of the launch is u8 with a 0 / 255 mask (decided on the host: no per-task branch in the kernel)
@@ -564,7 +571,9 @@ __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
 {
     const int tid = threadIdx.x;
     const int lv = P.level;
-    const int tile_x = P.x0 + blockIdx.x * 512, tile_y = P.y0 + blockIdx.y * 8;
+    int tile_tx, tile_ty;
+    if (!xcd_tile(P.tiles, blockIdx.x, tile_tx, tile_ty)) return;
+    const int tile_x = P.x0 + tile_tx * 512, tile_y = P.y0 + tile_ty * 8;
     const int X0 = tile_x + (tid & 63) * 8, Y0 = tile_y + (tid >> 6) * 2;
     const bool active = X0 < P.x1 && Y0 < P.y1;
 
@@ -942,7 +951,9 @@ template <bool CONTRIB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVES, 8))) void mb_level0_pk_kernel(MbLevelK P)
 {
     const int tid = threadIdx.x;
-    const int tile_x = P.x0 + blockIdx.x * 512, tile_y = P.y0 + blockIdx.y * 8;
+    int tile_tx, tile_ty;
+    if (!xcd_tile(P.tiles, blockIdx.x, tile_tx, tile_ty)) return;
+    const int tile_x = P.x0 + tile_tx * 512, tile_y = P.y0 + tile_ty * 8;
     const int X0 = tile_x + (tid & 63) * 8, Y0 = tile_y + (tid >> 6) * 2;
     const bool active = X0 < P.x1 && Y0 < P.y1;
 
@@ -1104,9 +1115,11 @@ bool stx_fast_mb_down_batch(stx_ctx* ctx, const StxMbImage* d_images, const StxM
         mh = std::max(mh, (h_images[i].fh >> level) >> 1);
     }
     if (n <= 0 || mw < 1 || mh < 1 || n > 65535) return false;
-    // tiles of 64 outputs are only 3-4 cache lines wide: horizontal neighbours must share an L2 or every edge line is
-    // fetched twice (measured for level 0: 556 MB fetched for 354 MB of input with the plain order)
-    const StxTileMap M = stx_tile_map((mw + DN_TOW - 1) / DN_TOW, (mh + DN_TOH - 1) / DN_TOH, DN_BAND);
+    // Tile order: XCD bands cut the level-0 fetch from 556 to 340 MB (354 MB of input) at equal kernel time, but with two
+    // panoramas in flight the plain row-major order is 2 % faster end to end (A/B on one box: 103.3 vs 101.2 Gpix/s), so
+    // the pyramid build keeps the plain order; the gather and warp kernels are neutral and keep the bands.
+    StxTileMap M = stx_tile_map((mw + DN_TOW - 1) / DN_TOW, (mh + DN_TOH - 1) / DN_TOH, DN_BAND);
+    M.plain = 1;
     bool pk_ok = true;  // packed 16-bit row sums need u8 images with 0 / 255 masks
     for (int i = 0; i < n; i++) pk_ok = pk_ok && !h_images[i].img0_is_s16 && h_images[i].mask_binary;
     dim3 grid(stx_tile_grid(M), 1, n);
@@ -1123,23 +1136,26 @@ bool stx_fast_mb_level(stx_ctx* ctx, const MbLevelK& K)
     if ((K.x0 | K.y0 | K.out_x0 | K.out_y0 | K.pano_x0 | K.pano_y0) & 7) return false;
     if (K.up && ((K.up_x0 | K.up_y0) & 3)) return false;
     if (K.n_images > 255) return false;
-    dim3 grid((K.x1 - K.x0 + 511) / 512, (K.y1 - K.y0 + 7) / 8);
+    // vertically adjacent 512 x 8 tiles share the G_{i+1} / finished-level rows of their pyrUp halos: keep them on one XCD
+    MbLevelK KT = K;
+    KT.tiles = stx_tile_map((K.x1 - K.x0 + 511) / 512, (K.y1 - K.y0 + 7) / 8, LV_BAND);
+    dim3 grid(stx_tile_grid(KT.tiles), 1);
     hipStream_t st = ctx->stream;
     if (K.level == 0 && K.pk_ok && !K.emit && K.num_bands > 0) {
-        if (K.has_contrib) hipLaunchKernelGGL(mb_level0_pk_kernel<true>, grid, dim3(256), 0, st, K);
-        else hipLaunchKernelGGL(mb_level0_pk_kernel<false>, grid, dim3(256), 0, st, K);
+        if (K.has_contrib) hipLaunchKernelGGL(mb_level0_pk_kernel<true>, grid, dim3(256), 0, st, KT);
+        else hipLaunchKernelGGL(mb_level0_pk_kernel<false>, grid, dim3(256), 0, st, KT);
     } else if (K.emit) {
-        if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, true, false>), grid, dim3(256), 0, st, K);
-        else if (K.all_u8) hipLaunchKernelGGL((mb_level_fast_kernel<false, false, true, true>), grid, dim3(256), 0, st, K);
-        else hipLaunchKernelGGL((mb_level_fast_kernel<false, false, true, false>), grid, dim3(256), 0, st, K);
+        if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, true, false>), grid, dim3(256), 0, st, KT);
+        else if (K.all_u8) hipLaunchKernelGGL((mb_level_fast_kernel<false, false, true, true>), grid, dim3(256), 0, st, KT);
+        else hipLaunchKernelGGL((mb_level_fast_kernel<false, false, true, false>), grid, dim3(256), 0, st, KT);
     } else if (K.has_contrib) {
-        if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, true, false, false>), grid, dim3(256), 0, st, K);
-        else if (K.all_u8) hipLaunchKernelGGL((mb_level_fast_kernel<false, true, false, true>), grid, dim3(256), 0, st, K);
-        else hipLaunchKernelGGL((mb_level_fast_kernel<false, true, false, false>), grid, dim3(256), 0, st, K);
+        if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, true, false, false>), grid, dim3(256), 0, st, KT);
+        else if (K.all_u8) hipLaunchKernelGGL((mb_level_fast_kernel<false, true, false, true>), grid, dim3(256), 0, st, KT);
+        else hipLaunchKernelGGL((mb_level_fast_kernel<false, true, false, false>), grid, dim3(256), 0, st, KT);
     } else {
-        if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, false, false>), grid, dim3(256), 0, st, K);
-        else if (K.all_u8) hipLaunchKernelGGL((mb_level_fast_kernel<false, false, false, true>), grid, dim3(256), 0, st, K);
-        else hipLaunchKernelGGL((mb_level_fast_kernel<false, false, false, false>), grid, dim3(256), 0, st, K);
+        if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, false, false>), grid, dim3(256), 0, st, KT);
+        else if (K.all_u8) hipLaunchKernelGGL((mb_level_fast_kernel<false, false, false, true>), grid, dim3(256), 0, st, KT);
+        else hipLaunchKernelGGL((mb_level_fast_kernel<false, false, false, false>), grid, dim3(256), 0, st, KT);
     }
     return launched_ok();
 }

@@ -3,6 +3,31 @@
 #pragma once
 #include "stx_internal.h"
 
+// XCD-aware tile order (DESIGN.md §3.1): workgroup b runs on XCD b % 8 (observed, used for speed only) and the per-XCD
+// L2s share nothing, so tiles are dealt to the XCDs in bands of `band_rows` tile rows: neighbouring tiles — which share
+// halo rows and the cache lines at their common edge — meet in one L2.  Index math by reciprocal multiplication.
+struct StxTileMap {
+    int tiles_x, tiles_y, band_rows, band_tiles;
+    unsigned magic_tx, magic_band;  // floor(2^32 / d) + 1 for d = tiles_x, band_tiles (unused when d == 1)
+    int plain;  // 1: row-major order, tile = workgroup index (the hardware's round-robin over the XCDs)
+};
+inline StxTileMap stx_tile_map(int tiles_x, int tiles_y, int band_rows)
+{
+    StxTileMap m;
+    m.tiles_x = tiles_x; m.tiles_y = tiles_y; m.band_rows = band_rows; m.band_tiles = band_rows * tiles_x;
+    m.magic_tx = (unsigned)((1ull << 32) / (unsigned)tiles_x) + 1u;
+    m.magic_band = (unsigned)((1ull << 32) / (unsigned)m.band_tiles) + 1u;
+    m.plain = 0;
+    return m;
+}
+// 1-D grid size (x) that covers every tile: 8 XCDs x whole bands
+inline unsigned stx_tile_grid(const StxTileMap& m)
+{
+    if (m.plain) return (unsigned)(m.tiles_x * m.tiles_y);
+    const int bands = (m.tiles_y + m.band_rows - 1) / m.band_rows;
+    return 8u * (unsigned)(((bands + 7) / 8) * m.band_tiles);
+}
+
 struct MbLevelK {
     const StxMbImage* images;
     int n_images, level, num_bands, pw, ph;  // pw, ph: padded panorama size at this level (pyrUp border rule)
@@ -20,30 +45,9 @@ struct MbLevelK {
     int pano_x0, pano_y0;
     int has_contrib;  // the image table holds kind-1 entries (received contribution strips)
     int all_u8;  // every level-0 source is u8x3 (the fast level-0 kernel has no int16 loader)
+    StxTileMap tiles;  // fast kernels: XCD-aware order of the 512 x 8 tiles
     int pk_ok;   // every image is kind 0, u8x3, with a mask known to hold only 0 / 255 (packed 16-bit kernels)
 };
-
-// XCD-aware tile order (DESIGN.md §3.1): workgroup b runs on XCD b % 8 (observed, used for speed only) and the per-XCD
-// L2s share nothing, so tiles are dealt to the XCDs in bands of `band_rows` tile rows: neighbouring tiles — which share
-// halo rows and the cache lines at their common edge — meet in one L2.  Index math by reciprocal multiplication.
-struct StxTileMap {
-    int tiles_x, tiles_y, band_rows, band_tiles;
-    unsigned magic_tx, magic_band;  // floor(2^32 / d) + 1 for d = tiles_x, band_tiles (unused when d == 1)
-};
-inline StxTileMap stx_tile_map(int tiles_x, int tiles_y, int band_rows)
-{
-    StxTileMap m;
-    m.tiles_x = tiles_x; m.tiles_y = tiles_y; m.band_rows = band_rows; m.band_tiles = band_rows * tiles_x;
-    m.magic_tx = (unsigned)((1ull << 32) / (unsigned)tiles_x) + 1u;
-    m.magic_band = (unsigned)((1ull << 32) / (unsigned)m.band_tiles) + 1u;
-    return m;
-}
-// 1-D grid size (x) that covers every tile: 8 XCDs x whole bands
-inline unsigned stx_tile_grid(const StxTileMap& m)
-{
-    const int bands = (m.tiles_y + m.band_rows - 1) / m.band_rows;
-    return 8u * (unsigned)(((bands + 7) / 8) * m.band_tiles);
-}
 
 // fast-path launchers (stx_blend_fast.hip); each returns false when its alignment / size
 // preconditions do not hold and the generic kernel must be used instead.
