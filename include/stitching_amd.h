@@ -173,6 +173,9 @@ int stx_blend_contrib_rect(const stx_blender* b, int img_w, int img_h, int tlx, 
                            int out_rect_xywh[4], size_t* out_bytes);
 int stx_blend_export_contrib(stx_blender* b, int order, int band_x0, int band_x1, stx_buf** out_packed,
                              int out_rect_xywh[4]);
+/* build the pyramids of every image fed so far now (they are otherwise built at the first export / blend()):
+ * a sharded rank calls it for its interior images while its strips are still in flight */
+int stx_blend_build(stx_blender* b);
 int stx_blend_feed_contrib(stx_blender* b, int order, const int rect_xywh[4], const stx_buf* packed);
 /* flags travel with a strip over the caller's control plane.  STX_CONTRIB_U8_BINARY: the strip was exported from
  * a u8 image whose mask holds only 0 / 255 (then its products are L or 0 and its weights 0.f or 1.f, and the

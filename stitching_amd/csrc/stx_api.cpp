@@ -1293,6 +1293,16 @@ STX_EXPORT int stx_blend_export_contrib(stx_blender* b, int order, int band_x0, 
     return STX_OK;
 }
 
+STX_EXPORT int stx_blend_build(stx_blender* b)
+{
+    if (!b) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (b->kind != STX_BLEND_MULTIBAND) return STX_OK;
+    if (b->finished) return stx_fail(STX_ERR_STATE, "build after blend()");
+    if (!b->ctx) return stx_fail(STX_ERR_STATE, "geometry-only blender (created without a context)");
+    STX_TRY(stx_set_device(b->ctx));
+    return mb_ensure_pyramids(b);
+}
+
 STX_EXPORT int stx_blend_feed_contrib(stx_blender* b, int order, const int rect_xywh[4], const stx_buf* packed)
 {
     return stx_blend_feed_contrib_ex(b, order, rect_xywh, packed, 0);

@@ -52,6 +52,10 @@ class ShardBlender(_BlenderHandle):
                                                           rect))
         return DeviceImage(self.ctx, out), tuple(int(v) for v in rect)
 
+    def build(self):
+        """Build the pyramids of everything fed so far (otherwise deferred to the first export / blend())."""
+        _lib.check(self.ctx._lib.stx_blend_build(self._h))
+
     def feed_contrib(self, order, rect, packed, flags=0):
         r = (C.c_int * 4)(*[int(v) for v in rect])
         _lib.check(self.ctx._lib.stx_blend_feed_contrib_ex(self._h, int(order), r, packed._h, int(flags)))
@@ -352,6 +356,7 @@ class ShardedStitchJob:
             self.transport.start(sends, [(m[1], m[4]) for m in recv_msgs], self.ctx)
             # 2. the other images of this rank are warped and fed while the strips travel
             self._warp_and_feed(blender, [k for k in self.my_orders if k not in senders], p)
+            blender.build()  # ... and so are their pyramids, before this stream starts waiting for the exchange
             # 3. received strips join the image table in global feed order; blend this rank's band
             rbufs = self.transport.finish()
             # every strip of this job comes from a u8 warp with a 0 / 255 mask (warp_images_and_masks on all ranks)
