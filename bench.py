@@ -119,10 +119,25 @@ def cpu_baseline(args, frames, cams, all_cams):
     pano, _ = b.blend()
     dt = time.perf_counter() - t0
     mpix = sum(f.shape[0] * f.shape[1] for f in frames) / 1e6
-    return {"value": round(mpix / dt, 3), "unit": "Mpix/s", "cores": cores, "kind": "port",
-            "sample": f"{n} frames {args.width}x{args.height}, {args.warper} warp + {b.blender.num_bands()}-band "
-                      f"blend, {dt:.2f} s wall on {cores} of {O.max_threads()} OpenMP threads (fastest of {cand} on one warp); "
-                      f"CPU restatement of OpenCV's algorithm (oracle/), not OpenCV"}, np.asarray(pano)
+    res = {"value": round(mpix / dt, 3), "unit": "Mpix/s", "cores": cores, "kind": "port",
+           "sample": f"{n} frames {args.width}x{args.height}, {args.warper} warp + {b.blender.num_bands()}-band "
+                     f"blend, {dt:.2f} s wall on {cores} of {O.max_threads()} OpenMP threads (fastest of {cand} on one warp); "
+                     f"CPU restatement of OpenCV's algorithm (oracle/), not OpenCV"}
+    # the reference's own dataflow on ONE frame (stitching/warper.py:44,59: two PyRotationWarper.warp calls, each
+    # building both fp32 maps in OpenCV's serial buildMaps loop, then cv::remap), for scale against the fused port above
+    t1 = time.perf_counter()
+    roi = w.warp_roi(sizes[0], cams[0])
+    K0 = O.Warper.get_K(cams[0])
+    O.set_num_threads(1)
+    xm, ym = O.build_maps(args.warper, w.scale, K0, cams[0].R, roi)
+    xm2, ym2 = O.build_maps(args.warper, w.scale, K0, cams[0].R, roi)
+    O.set_num_threads(cores)
+    O.remap_linear(frames[0], xm, ym)
+    O.remap_nearest(np.full(frames[0].shape[:2], 255, np.uint8), xm2, ym2)
+    dt_ref = time.perf_counter() - t1
+    res["reference_dataflow_warp"] = {"value": round(frames[0].shape[0] * frames[0].shape[1] / 1e6 / dt_ref, 3), "unit": "Mpix/s",
+                                      "sample": f"1 frame, maps materialised twice by a serial buildMaps + remap x2: {dt_ref:.2f} s"}
+    return res, np.asarray(pano)
 
 
 def main():
