@@ -167,7 +167,10 @@ def main():
 
     fpg = args.frames_per_gpu
     n_total = fpg * world
-    all_cams = synthetic.ring_cameras(n_total, args.width, args.height, focal_factor=0.75 * world)
+    if args.warper == "affine":  # BASELINE config 5: scan tiles, camera.R carries the affine homography
+        all_cams = synthetic.affine_scan_cameras(n_total, args.width, args.height)
+    else:
+        all_cams = synthetic.ring_cameras(n_total, args.width, args.height, focal_factor=0.75 * world)
     my = range(rank * fpg, (rank + 1) * fpg)
     frames = [synthetic.make_frame(i, args.width, args.height) for i in my]
     cams = [all_cams[i] for i in my]

@@ -289,47 +289,120 @@ __global__ __launch_bounds__(256) void no_feed_kernel(SimpleFeedK P)
     P.dmask[(long long)(y + P.dy) * P.dmask_stride + x + P.dx] |= m;
 }
 
-// distanceTransform(mask, DIST_L1, 3): exact city-block distance to the nearest zero pixel.
-// Pass 1 (one thread per column): vertical distance, down then up.  INF when the column has no zero.
+// distanceTransform(mask, DIST_L1, 3): exact city-block distance to the nearest zero pixel, as two separable passes
+// that are plain prefix / suffix minima and therefore parallel:
+//   columns: g(x, y) = min(y - last zero row <= y, first zero row >= y - y), INF when the column has no zero.
+//            Chunks of DT_RC rows: kernel 1 records each chunk's first / last zero row, kernel 2 folds the summaries of
+//            the chunks above / below (<= h / DT_RC coalesced loads) and sweeps its own rows.  Lanes run along x.
+//   rows:    f(x) = min_x' (|x - x'| + g(x')) = min( x + min_{x'<=x} (g(x') - x'),  -x + min_{x'>=x} (g(x') + x') ):
+//            one wavefront per row, 256 pixels per step (16-byte loads), wave-level min scans, a scalar carry between
+//            steps; the backward sweep also produces the weight map
+//            weight = min(dist * sharpness, 1), dist = (L1 >= 8192 or no zero) ? 8192.f : (float)L1
+//            (distanceTransform_3x3's 16.16 fixed point saturates at INT_MAX >> 2, i.e. 8192.0f).
+// Same integers as the serial recurrences cur = min(v, cur + 1) of the reference.
 constexpr int DT_INF = 1 << 28;
-__global__ __launch_bounds__(64) void dt_cols_kernel(const uint8_t* __restrict__ mask, long long mstride, int w, int h,
-                                                    int* __restrict__ d, long long dstride)
+constexpr int DT_RC = 64;
+__global__ __launch_bounds__(64) void dt_col_summary_kernel(const uint8_t* __restrict__ mask, long long mstride, int w, int h,
+                                                           int* __restrict__ first, int* __restrict__ last, long long sstride)
 {
-    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int x = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y;
     if (x >= w) return;
-    int cur = DT_INF;
-    for (int y = 0; y < h; y++) {
-        cur = mask[(long long)y * mstride + x] ? min(cur + 1, DT_INF) : 0;
-        d[(long long)y * dstride + x] = cur;
+    const int y0 = c * DT_RC, y1 = min(h, y0 + DT_RC);
+    int f = DT_INF, l = -DT_INF;
+    for (int y = y0; y < y1; y++)
+        if (mask[(long long)y * mstride + x] == 0) {
+            if (f == DT_INF) f = y;
+            l = y;
+        }
+    first[(long long)c * sstride + x] = f;
+    last[(long long)c * sstride + x] = l;
+}
+__global__ __launch_bounds__(64) void dt_col_fill_kernel(const uint8_t* __restrict__ mask, long long mstride, int w, int h,
+                                                        const int* __restrict__ first, const int* __restrict__ last, long long sstride,
+                                                        int n_chunks, int* __restrict__ d, long long dstride)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y;
+    if (x >= w) return;
+    int prev = -DT_INF, next = DT_INF;
+    for (int k = 0; k < c; k++) prev = max(prev, last[(long long)k * sstride + x]);
+    for (int k = n_chunks - 1; k > c; k--) next = min(next, first[(long long)k * sstride + x]);
+    const int y0 = c * DT_RC, y1 = min(h, y0 + DT_RC);
+    for (int y = y0; y < y1; y++) {
+        if (mask[(long long)y * mstride + x] == 0) prev = y;
+        d[(long long)y * dstride + x] = prev == -DT_INF ? DT_INF : y - prev;
     }
-    cur = DT_INF;
-    for (int y = h - 1; y >= 0; y--) {
-        int v = d[(long long)y * dstride + x];
-        cur = v == 0 ? 0 : min(cur + 1, DT_INF);
-        d[(long long)y * dstride + x] = min(v, cur);
+    for (int y = y1 - 1; y >= y0; y--) {
+        const int v = d[(long long)y * dstride + x];
+        if (v == 0) next = y;
+        d[(long long)y * dstride + x] = min(v, next == DT_INF ? DT_INF : next - y);
     }
 }
-// Pass 2 (one thread per row): f(x) = min_x' (|x - x'| + g(x')), then the weight map
-//   weight = min(dist * sharpness, 1), dist = (L1 >= 8192 or no zero) ? 8192.f : (float)L1
-// (distanceTransform_3x3's 16.16 fixed point saturates at INT_MAX>>2, i.e. 8192.0f).
-__global__ __launch_bounds__(64) void dt_rows_kernel(int* __restrict__ d, long long dstride, int w, int h, float sharpness,
-                                                    float* __restrict__ wmap, long long wstride)
+
+STX_DEV int wave_excl_prefix_min(int v, int lane)  // min over lanes < lane (INT_MAX for lane 0)
 {
-    const int y = blockIdx.x * 64 + threadIdx.x;
-    if (y >= h) return;
-    int* row = d + (long long)y * dstride;
-    int cur = DT_INF;
-    for (int x = 0; x < w; x++) {
-        cur = min(row[x], min(cur + 1, DT_INF));
-        row[x] = cur;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o);
+        if (lane >= o) v = min(v, t);
     }
-    cur = DT_INF;
+    const int e = __shfl_up(v, 1);
+    return lane == 0 ? 0x7fffffff : e;
+}
+STX_DEV int wave_excl_suffix_min(int v, int lane)  // min over lanes > lane
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_down(v, o);
+        if (lane + o < 64) v = min(v, t);
+    }
+    const int e = __shfl_down(v, 1);
+    return lane == 63 ? 0x7fffffff : e;
+}
+
+__global__ __launch_bounds__(256) void dt_rows_kernel(int* __restrict__ d, long long dstride, int w, int h, float sharpness,
+                                                     float* __restrict__ wmap, long long wstride)
+{
+    const int lane = threadIdx.x & 63;
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (y >= h) return;
+    int* row = d + (long long)y * dstride;       // dstride is a multiple of 16: every 4-pixel group is 16-byte aligned
     float* wr = wmap + (long long)y * wstride;
-    for (int x = w - 1; x >= 0; x--) {
-        cur = min(row[x], min(cur + 1, DT_INF));
-        float dist = cur >= 8192 ? 8192.f : (float)cur;
-        float t = fmul(dist, sharpness);
-        wr[x] = t > 1.f ? 1.f : t;
+    const int nseg = (w + 255) / 256;
+    int carry = 1 << 29;
+    for (int s = 0; s < nseg; s++) {             // forward: F(x) = x + min_{x' <= x} (g(x') - x')
+        const int x0 = s * 256 + lane * 4;
+        int4 g = make_int4(DT_INF, DT_INF, DT_INF, DT_INF);
+        if (x0 < w) g = *reinterpret_cast<const int4*>(row + x0);
+        int p0 = (x0 + 0 < w ? g.x : DT_INF) - (x0 + 0), p1 = (x0 + 1 < w ? g.y : DT_INF) - (x0 + 1);
+        int p2 = (x0 + 2 < w ? g.z : DT_INF) - (x0 + 2), p3 = (x0 + 3 < w ? g.w : DT_INF) - (x0 + 3);
+        p1 = min(p1, p0); p2 = min(p2, p1); p3 = min(p3, p2);
+        const int before = min(carry, wave_excl_prefix_min(p3, lane));
+        p0 = min(p0, before); p1 = min(p1, before); p2 = min(p2, before); p3 = min(p3, before);
+        if (x0 < w) *reinterpret_cast<int4*>(row + x0) = make_int4(p0 + x0, p1 + x0 + 1, p2 + x0 + 2, p3 + x0 + 3);
+        carry = __shfl(p3, 63);  // includes the old carry
+    }
+    carry = 1 << 29;
+    for (int s = nseg - 1; s >= 0; s--) {        // backward: f(x) = -x + min_{x' >= x} (F(x') + x'), then the weight
+        const int x0 = s * 256 + lane * 4;
+        int4 g = make_int4(DT_INF, DT_INF, DT_INF, DT_INF);
+        if (x0 < w) g = *reinterpret_cast<const int4*>(row + x0);
+        int p0 = (x0 + 0 < w ? g.x : DT_INF) + (x0 + 0), p1 = (x0 + 1 < w ? g.y : DT_INF) + (x0 + 1);
+        int p2 = (x0 + 2 < w ? g.z : DT_INF) + (x0 + 2), p3 = (x0 + 3 < w ? g.w : DT_INF) + (x0 + 3);
+        p2 = min(p2, p3); p1 = min(p1, p2); p0 = min(p0, p1);
+        const int after = min(carry, wave_excl_suffix_min(p0, lane));
+        p0 = min(p0, after); p1 = min(p1, after); p2 = min(p2, after); p3 = min(p3, after);
+        carry = __shfl(p0, 0);
+        if (x0 < w) {
+            const int f[4] = {p0 - x0, p1 - (x0 + 1), p2 - (x0 + 2), p3 - (x0 + 3)};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float dist = f[j] >= 8192 ? 8192.f : (float)f[j];
+                const float t = fmul(dist, sharpness);
+                o[j] = t > 1.f ? 1.f : t;
+            }
+            *reinterpret_cast<float4*>(wr + x0) = make_float4(o[0], o[1], o[2], o[3]);
+        }
     }
 }
 
@@ -476,16 +549,25 @@ int stx_launch_feather_feed(stx_ctx* ctx, const stx_buf* img, const stx_buf* mas
     int rc = stx_dev_alloc(ctx, sizeof(float) * dstride * h, &wmap);
     if (rc != STX_OK) { stx_dev_free(ctx, dist); return rc; }
     double px = (double)w * h;
+    const int n_chunks = (h + DT_RC - 1) / DT_RC;
+    void* summ = nullptr;
+    rc = stx_dev_alloc(ctx, sizeof(int) * 2 * (size_t)dstride * n_chunks, &summ);
+    if (rc != STX_OK) { stx_dev_free(ctx, dist); stx_dev_free(ctx, wmap); return rc; }
+    int* first = (int*)summ;
+    int* last = first + (size_t)dstride * n_chunks;
     {
-        StxProfScope prof(ctx, "feather_dt_cols", px * (1 + 4));
-        hipLaunchKernelGGL(dt_cols_kernel, dim3((w + 63) / 64), dim3(64), 0, ctx->stream, mask->ptr,
-                           (long long)mask->stride, w, h, (int*)dist, dstride);
+        StxProfScope prof(ctx, "feather_dt_cols", px * (1 + 1 + 4 + 4));
+        hipLaunchKernelGGL(dt_col_summary_kernel, dim3((w + 63) / 64, n_chunks), dim3(64), 0, ctx->stream, mask->ptr,
+                           (long long)mask->stride, w, h, first, last, dstride);
+        hipLaunchKernelGGL(dt_col_fill_kernel, dim3((w + 63) / 64, n_chunks), dim3(64), 0, ctx->stream, mask->ptr,
+                           (long long)mask->stride, w, h, (const int*)first, (const int*)last, dstride, n_chunks, (int*)dist, dstride);
     }
     {
-        StxProfScope prof(ctx, "feather_dt_rows", px * (4 + 4));
-        hipLaunchKernelGGL(dt_rows_kernel, dim3((h + 63) / 64), dim3(64), 0, ctx->stream, (int*)dist, dstride, w, h,
+        StxProfScope prof(ctx, "feather_dt_rows", px * (4 + 4 + 4 + 4));
+        hipLaunchKernelGGL(dt_rows_kernel, dim3((h + 3) / 4), dim3(256), 0, ctx->stream, (int*)dist, dstride, w, h,
                            sharpness, (float*)wmap, dstride);
     }
+    stx_dev_free(ctx, summ);
     SimpleFeedK K;
     fill_feed(K, img, mask, dx, dy);
     K.dst = dst; K.dst_stride = dst_stride; K.dw = dw; K.dw_stride = dw_stride;
