@@ -154,6 +154,13 @@ int stx_blend_destroy(stx_blender* b);
  * stx_timelapse_frame <- stitching/timelapser.py:36-52 timelapser.process(img, mask, corner) + getDst():
  *                        zero frame of the roi given to initialize(), the image pasted at its corner. */
 int stx_gain_apply(stx_ctx* ctx, stx_buf* img_u8x3, const float gains_bgr[3]);
+/* stx_resize_linear_exact <- stitching/images.py:122-124 cv.resize(img, size, interpolation=cv.INTER_LINEAR_EXACT) (u8x1 / u8x3:
+ *                            the final-resolution resize of Images.resize, next row N3)
+ * stx_seam_mask_resize    <- stitching/seam_finder.py:37-43 SeamFinder.resize: cv.dilate(seam_mask, None), cv.resize(...,
+ *                            INTER_LINEAR_EXACT) to the size of the final warped mask, cv.bitwise_and with it (next row N2);
+ *                            one fused kernel, the result is what Blender.feed receives (stitching/stitcher.py:124,127) */
+int stx_resize_linear_exact(stx_ctx* ctx, const stx_buf* src_u8, int dst_w, int dst_h, stx_buf** out);
+int stx_seam_mask_resize(stx_ctx* ctx, const stx_buf* seam_mask_u8x1, const stx_buf* final_mask_u8x1, stx_buf** out);
 int stx_timelapse_frame(stx_ctx* ctx, const stx_buf* img, int tlx, int tly, const int dst_roi_xywh[4], stx_buf** out_frame);
 
 /* ---- sharded multi-band blending: one process per GPU, one stx_blender per rank ------------------

@@ -394,3 +394,60 @@ def timelapse_frame(img, corner, dst_roi):
     if x1 > x0 and y1 > y0:
         out[y0 - y:y1 - y, x0 - x:x1 - x] = img[y0 - corner[1]:y1 - corner[1], x0 - corner[0]:x1 - corner[0]]
     return out
+
+
+def _linear_exact_coeffs(src_n, dst_n):
+    """interpolationLinear<ufixedpoint16>::getCoeffs of cv::resize(INTER_LINEAR_EXACT) [OCV-MEM, resize.cpp]:
+    scale = 1 / (dst / src) in double (softdouble there = IEEE double), fval = scale * (v + 0.5) - 0.5,
+    offset = floor(fval), coeff1 = cvRound((fval - offset) * 256) (8.8 fixed point), coeff0 = 256 - coeff1;
+    destination pixels left of the first source pixel copy source 0, those at or beyond the last copy the last.
+    Returns (ofs, c0, c1) with c0 = 256, c1 = 0 at the borders (then the row sum is src << 8)."""
+    inv_scale = float(dst_n) / float(src_n)
+    scale = 1.0 / inv_scale
+    v = np.arange(dst_n, dtype=np.float64)
+    fval = scale * (v + 0.5) - 0.5
+    ival = np.floor(fval).astype(np.int64)
+    interior = (ival >= 0) & (ival < src_n - 1) & (src_n > 1)
+    right = (ival >= src_n - 1) & (ival >= 0) & (src_n > 1)
+    ofs = np.where(interior, ival, np.where(right, src_n - 1, 0)).astype(np.int64)
+    c1 = np.where(interior, np.rint((fval - ival) * 256.0), 0).astype(np.int64)
+    return ofs, 256 - c1, c1, interior
+
+
+def resize_linear_exact(src, size):
+    """cv::resize(src, dsize, 0, 0, INTER_LINEAR_EXACT) for 8-bit images [OCV-MEM]: horizontal pass in 8.8 fixed
+    point (p0 * c0 + p1 * c1), vertical pass in 16.16 with round-half-up ((h0 * d0 + h1 * d1 + 2^15) >> 16);
+    rows outside the source take one row sum: (h + 128) >> 8.
+    Reference call sites: stitching/images.py:122-124, stitching/seam_finder.py:39-41."""
+    src = np.asarray(src, np.uint8)
+    dw, dh = int(size[0]), int(size[1])
+    sh, sw = src.shape[:2]
+    s = src.reshape(sh, sw, -1).astype(np.int64)
+    ox, cx0, cx1, ix = _linear_exact_coeffs(sw, dw)
+    oy, cy0, cy1, iy = _linear_exact_coeffs(sh, dh)
+    ox1 = np.minimum(ox + 1, sw - 1)
+    h = s[:, ox, :] * cx0[None, :, None] + s[:, ox1, :] * cx1[None, :, None]  # (sh, dw, c), 8.8 fixed point
+    oy1 = np.minimum(oy + 1, sh - 1)
+    v = h[oy] * cy0[:, None, None] + h[oy1] * cy1[:, None, None]
+    out = np.where(iy[:, None, None], (v + 32768) >> 16, (h[oy] + 128) >> 8)
+    out = np.clip(out, 0, 255).astype(np.uint8)
+    return out.reshape((dh, dw) + src.shape[2:])
+
+
+def dilate3x3(mask):
+    """cv::dilate(mask, None): 3x3 rectangle, anchor at the centre, pixels outside the image do not take part."""
+    m = np.asarray(mask, np.uint8)
+    p = np.pad(m, 1, constant_values=0)
+    out = np.zeros_like(m)
+    for dy in range(3):
+        for dx in range(3):
+            out = np.maximum(out, p[dy:dy + m.shape[0], dx:dx + m.shape[1]])
+    return out
+
+
+def seam_resize(seam_mask, mask):
+    """SeamFinder.resize (stitching/seam_finder.py:37-43): dilate, resize to the final mask's size with
+    INTER_LINEAR_EXACT, AND with the final-resolution warped mask."""
+    mask = np.asarray(mask, np.uint8)
+    r = resize_linear_exact(dilate3x3(seam_mask), (mask.shape[1], mask.shape[0]))
+    return np.bitwise_and(r, mask)

@@ -444,6 +444,88 @@ STX_EXPORT int stx_timelapse_frame(stx_ctx* ctx, const stx_buf* img, int tlx, in
     return STX_OK;
 }
 
+// interpolationLinear<ufixedpoint16>::getCoeffs of cv::resize(INTER_LINEAR_EXACT) [OCV-MEM]: all in double precision
+// (softdouble upstream = IEEE double; this file is compiled with -ffp-contract=off)
+static void linear_exact_table(int src_n, int dst_n, std::vector<int>& t)
+{
+    t.resize(2 * (size_t)dst_n);
+    const double inv_scale = (double)dst_n / (double)src_n;
+    const double scale = 1.0 / inv_scale;
+    for (int v = 0; v < dst_n; v++) {
+        const double fval = scale * ((double)v + 0.5) - 0.5;
+        const int ival = (int)std::floor(fval);
+        int ofs = 0, c1 = 0, interior = 0;
+        if (ival >= 0 && src_n > 1) {
+            if (ival < src_n - 1) { ofs = ival; c1 = (int)std::nearbyint((fval - (double)ival) * 256.0); interior = 1; }
+            else ofs = src_n - 1;
+        }
+        t[2 * (size_t)v] = ofs;
+        t[2 * (size_t)v + 1] = c1 | (interior << 16);
+    }
+}
+
+// small host array -> device through the context's pinned ring (asynchronous); the caller frees *d_out
+static int upload_small(stx_ctx* ctx, const void* h, size_t bytes, void** d_out)
+{
+    void* d = nullptr;
+    STX_TRY(stx_dev_alloc(ctx, std::max<size_t>(bytes, 4), &d));
+    if (bytes > ctx->stage_bytes) {
+        hipError_t e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { stx_dev_free(ctx, d); return stx_fail(STX_ERR_HIP, "upload: %s", hipGetErrorString(e)); }
+    } else if (bytes > 0) {
+        if (ctx->stage_off + bytes > ctx->stage_bytes) {
+            hipError_t e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { stx_dev_free(ctx, d); return stx_fail(STX_ERR_HIP, "upload: %s", hipGetErrorString(e)); }
+            ctx->stage_off = 0;
+        }
+        uint8_t* slot = ctx->stage + ctx->stage_off;
+        memcpy(slot, h, bytes);
+        ctx->stage_off += (bytes + 255) & ~(size_t)255;
+        hipError_t e = hipMemcpyAsync(d, slot, bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) { stx_dev_free(ctx, d); return stx_fail(STX_ERR_HIP, "upload: %s", hipGetErrorString(e)); }
+    }
+    *d_out = d;
+    return STX_OK;
+}
+
+static int resize_impl(stx_ctx* ctx, const stx_buf* src, int dw, int dh, bool dilate, const stx_buf* andmask, stx_buf** out)
+{
+    if (src->elem != STX_U8 || (src->c != 1 && src->c != 3)) return stx_fail(STX_ERR_UNSUPPORTED, "resize needs a u8x1 or u8x3 image");
+    if (dw <= 0 || dh <= 0) return stx_fail(STX_ERR_INVALID, "resize to %dx%d", dw, dh);
+    if (src->ctx->device != ctx->device) return stx_fail(STX_ERR_INVALID, "image lives on another device");
+    std::vector<int> xt, yt;
+    linear_exact_table(src->w, dw, xt);
+    linear_exact_table(src->h, dh, yt);
+    std::vector<int> both(xt);
+    both.insert(both.end(), yt.begin(), yt.end());
+    void* d_tab = nullptr;
+    STX_TRY(upload_small(ctx, both.data(), both.size() * sizeof(int), &d_tab));
+    stx_buf* dst = nullptr;
+    int rc = stx_buf_new(ctx, dw, dh, src->c, STX_U8, &dst);
+    if (rc == STX_OK) rc = stx_launch_resize_exact(ctx, src, dst, (const int*)d_tab, (const int*)d_tab + xt.size(), dilate, andmask);
+    stx_dev_free(ctx, d_tab);  // stream-ordered reuse
+    if (rc != STX_OK) { stx_buf_release(dst); return rc; }
+    *out = dst;
+    return STX_OK;
+}
+
+STX_EXPORT int stx_resize_linear_exact(stx_ctx* ctx, const stx_buf* src, int dst_w, int dst_h, stx_buf** out)
+{
+    if (!ctx || !src || !out) return stx_fail(STX_ERR_INVALID, "null argument");
+    STX_TRY(stx_set_device(ctx));
+    return resize_impl(ctx, src, dst_w, dst_h, false, nullptr, out);
+}
+
+STX_EXPORT int stx_seam_mask_resize(stx_ctx* ctx, const stx_buf* seam_mask, const stx_buf* final_mask, stx_buf** out)
+{
+    if (!ctx || !seam_mask || !final_mask || !out) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (seam_mask->c != 1 || seam_mask->elem != STX_U8 || final_mask->c != 1 || final_mask->elem != STX_U8)
+        return stx_fail(STX_ERR_INVALID, "seam masks are u8x1");
+    STX_TRY(stx_set_device(ctx));
+    return resize_impl(ctx, seam_mask, final_mask->w, final_mask->h, true, final_mask, out);
+}
+
 // ---------------------------------------------------------------------------------------------
 // projector: ProjectorBase::setCameraParams, AffineWarper::getRTfromHomogeneous
 // ---------------------------------------------------------------------------------------------

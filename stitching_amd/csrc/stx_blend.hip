@@ -639,3 +639,76 @@ int stx_launch_gain_apply(stx_ctx* ctx, stx_buf* img, const float g[3])
     hipLaunchKernelGGL(gain_apply_kernel, dim3((img->w + 255) / 256, (img->h + 3) / 4), dim3(256), 0, ctx->stream, K);
     return check_launch("gain_apply");
 }
+
+// ---------------------------------------------------------------------------------------------
+// cv::resize(INTER_LINEAR_EXACT) for 8-bit images (next rows N2 / N3): 8.8 fixed-point coefficients made on the host in
+// double precision exactly as interpolationLinear<ufixedpoint16>::getCoeffs does (tables: x = offset, y = coeff1 |
+// interior << 16), horizontal sums p0 * c0 + p1 * c1 in 8.8, vertical (h0 * d0 + h1 * d1 + 2^15) >> 16, rows
+// outside the source (h + 128) >> 8.  DILATE: the source is read through cv::dilate(3x3) on the fly and the result is
+// ANDed with a mask of the destination size (SeamFinder.resize, stitching/seam_finder.py:37-43).
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct ResizeK {
+    const uint8_t* src; long long sstride; int sw, sh;
+    uint8_t* dst; long long dstride; int dw, dh;
+    const int2* xt; const int2* yt;
+    const uint8_t* andmask; long long amstride;
+};
+template <int C, bool DILATE>
+STX_DEV uint32_t resize_src(const ResizeK& P, int x, int y, int ch)
+{
+    if (!DILATE) return P.src[(long long)y * P.sstride + x * C + ch];
+    uint32_t m = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+            const int xx = x + dx, yy = y + dy;
+            if ((unsigned)xx < (unsigned)P.sw && (unsigned)yy < (unsigned)P.sh) m = max(m, (uint32_t)P.src[(long long)yy * P.sstride + xx]);
+        }
+    return m;
+}
+template <int C, bool DILATE>
+__global__ __launch_bounds__(256) void resize_exact_kernel(ResizeK P)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.dw || y >= P.dh) return;
+    const int2 tx = P.xt[x], ty = P.yt[y];
+    const int ox = tx.x, oy = ty.x;
+    const uint32_t cx1 = (uint32_t)tx.y & 0xffffu, cx0 = 256u - cx1, cy1 = (uint32_t)ty.y & 0xffffu, cy0 = 256u - cy1;
+    const bool iy = (ty.y >> 16) != 0;
+    const int ox1 = min(ox + 1, P.sw - 1), oy1 = min(oy + 1, P.sh - 1);
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) {
+        const uint32_t h0 = resize_src<C, DILATE>(P, ox, oy, ch) * cx0 + resize_src<C, DILATE>(P, ox1, oy, ch) * cx1;
+        uint32_t v;
+        if (iy) {
+            const uint32_t h1 = resize_src<C, DILATE>(P, ox, oy1, ch) * cx0 + resize_src<C, DILATE>(P, ox1, oy1, ch) * cx1;
+            v = (h0 * cy0 + h1 * cy1 + 32768u) >> 16;
+        } else {
+            v = (h0 + 128u) >> 8;
+        }
+        v = min(v, 255u);
+        if (P.andmask) v &= P.andmask[(long long)y * P.amstride + x];
+        P.dst[(long long)y * P.dstride + x * C + ch] = (uint8_t)v;
+    }
+}
+}  // namespace
+
+int stx_launch_resize_exact(stx_ctx* ctx, const stx_buf* src, stx_buf* dst, const int* d_xt, const int* d_yt, bool dilate,
+                            const stx_buf* andmask)
+{
+    ResizeK K;
+    K.src = src->ptr; K.sstride = (long long)src->stride; K.sw = src->w; K.sh = src->h;
+    K.dst = dst->ptr; K.dstride = (long long)dst->stride; K.dw = dst->w; K.dh = dst->h;
+    K.xt = (const int2*)d_xt; K.yt = (const int2*)d_yt;
+    K.andmask = andmask ? andmask->ptr : nullptr; K.amstride = andmask ? (long long)andmask->stride : 0;
+    const dim3 grid((dst->w + 63) / 64, (dst->h + 3) / 4);
+    StxProfScope prof(ctx, dilate ? "seam_mask_resize" : "resize_linear_exact", (double)src->w * src->h * src->c + (double)dst->w * dst->h * dst->c * (andmask ? 2 : 1));
+    if (dilate) hipLaunchKernelGGL((resize_exact_kernel<1, true>), grid, dim3(256), 0, ctx->stream, K);
+    else if (src->c == 1) hipLaunchKernelGGL((resize_exact_kernel<1, false>), grid, dim3(256), 0, ctx->stream, K);
+    else if (src->c == 3) hipLaunchKernelGGL((resize_exact_kernel<3, false>), grid, dim3(256), 0, ctx->stream, K);
+    else return stx_fail(STX_ERR_UNSUPPORTED, "resize: 1 or 3 channels");
+    return check_launch("resize_linear_exact");
+}

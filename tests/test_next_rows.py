@@ -115,3 +115,70 @@ def test_timelapser_frames(oracle, gpu_ctx, kind):
         frame = t.get_frame()
         assert frame.shape[:2] == (t.dst_roi[3], t.dst_roi[2])
         assert np.array_equal(frame, oracle.timelapse_frame(img, corner, t.dst_roi))
+
+
+# ---------------------------------------------------------------- N2 / N3: INTER_LINEAR_EXACT resize, seam-mask resize
+def test_resize_linear_exact_known_answers(oracle):
+    a = (np.arange(12).reshape(3, 4) * 20).astype(np.uint8)
+    assert np.array_equal(oracle.resize_linear_exact(a, (4, 3)), a)  # identity
+    # 2x upscale of the ramp 0 20 40 60: sample positions -0.25 0.25 0.75 ... in source pixels
+    assert oracle.resize_linear_exact(a, (8, 3))[0].tolist() == [0, 5, 15, 25, 35, 45, 55, 60]
+    assert oracle.resize_linear_exact(a, (2, 2)).tolist() == [[30, 70], [150, 190]]  # 2x2 box means
+    assert oracle.resize_linear_exact(np.array([[7]], np.uint8), (3, 2)).tolist() == [[7, 7, 7], [7, 7, 7]]
+    c = np.full((5, 7, 3), 200, np.uint8)
+    assert (oracle.resize_linear_exact(c, (13, 9)) == 200).all()  # constants are preserved (coefficients sum to 256)
+    m = np.zeros((5, 5), np.uint8)
+    m[2, 2] = 255
+    d = oracle.dilate3x3(m)
+    assert d[1:4, 1:4].all() and d.sum() == 9 * 255
+
+
+def test_seam_finder_surface():
+    assert S.SeamFinder.DEFAULT_SEAM_FINDER == "dp_color" and "no" in S.SeamFinder.SEAM_FINDER_CHOICES
+    with pytest.raises(S.StitchingError):
+        S.SeamFinder("bogus")
+    with pytest.raises(S.StitchingError):
+        S.SeamFinder().find([], [], [])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src,dst", [((640, 480), (4000, 3000)), ((4000, 3000), (1549, 1162)), ((37, 23), (37, 23)),
+                                      ((5, 3), (64, 41)), ((1, 1), (9, 4)), ((301, 200), (300, 77))])
+def test_resize_linear_exact_bit_exact(oracle, gpu_ctx, src, dst):
+    img = synthetic.make_frame(2, max(src[0], 16), max(src[1], 12))[:src[1], :src[0]]
+    assert np.array_equal(S.resize_linear_exact(img, dst), oracle.resize_linear_exact(img, dst))
+    g = np.ascontiguousarray(img[:, :, 1])
+    assert np.array_equal(S.resize_linear_exact(g, dst), oracle.resize_linear_exact(g, dst))
+
+
+@pytest.mark.gpu
+def test_seam_mask_resize_feeds_the_blender(oracle, gpu_ctx):
+    """The stitcher's final-resolution mask path (stitching/stitcher.py:124,127, seam_finder.py:37-43): low-resolution
+    seam masks -> dilate + INTER_LINEAR_EXACT + AND with the warped mask -> Blender.feed.  The resized masks have grey
+    edges, so the general (non-packed) blend kernels run; everything stays bit-exact."""
+    from tests import helpers
+
+    imgs, cams = helpers.small_ring(3, 640, 480, span=110.0)
+    ow = oracle.Warper("spherical")
+    ow.set_scale(cams)
+    wi = [ow.warp_image(i, c) for i, c in zip(imgs, cams)]
+    wm = [ow.create_and_warp_mask((640, 480), c) for c in cams]
+    corners, sizes = ow.warp_rois([(640, 480)] * 3, cams)
+    # low-resolution Voronoi seam masks at 1/5 scale
+    low = []
+    for m, c, s in zip(synthetic.voronoi_seam_masks(wm, corners, sizes), corners, sizes):
+        low.append(np.ascontiguousarray(m[::5, ::5]))
+    o_masks = [oracle.seam_resize(l, m) for l, m in zip(low, wm)]
+    g_masks = [S.SeamFinder.resize(l, m) for l, m in zip(low, wm)]
+    for a, b in zip(g_masks, o_masks):
+        assert np.array_equal(a, b)
+    assert any(((m > 0) & (m < 255)).any() for m in o_masks)  # grey edges exist
+    g, o = S.Blender("multiband", 20), oracle.Blender("multiband", 20)
+    g.prepare(corners, sizes)
+    o.prepare(corners, sizes)
+    for a, m, c in zip(wi, o_masks, corners):
+        g.feed(a, m, c)
+        o.feed(a, m, c)
+    gp, gm = g.blend()
+    op, om = o.blend()
+    assert np.array_equal(gm, om) and np.array_equal(gp, op)
