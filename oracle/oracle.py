@@ -451,3 +451,48 @@ def seam_resize(seam_mask, mask):
     mask = np.asarray(mask, np.uint8)
     r = resize_linear_exact(dilate3x3(seam_mask), (mask.shape[1], mask.shape[0]))
     return np.bitwise_and(r, mask)
+
+
+def _linear_f32_coeffs(src_n, dst_n, clamp_offsets):
+    """Coefficient set-up of cv::resize(INTER_LINEAR) for CV_32F [OCV-MEM, resize.cpp resizeGeneric / linear]:
+    f = (float)((d + 0.5) * scale - 0.5) with scale = 1 / (dst / src) in double, s = floor(f), f -= s (float).
+    Horizontal (clamp_offsets): s < 0 -> s = 0, f = 0; s >= n - 1 -> s = n - 1, f = 0 (the second tap is not read).
+    Vertical: no adjustment of f; the two rows are clamped to [0, n - 1] when they are fetched."""
+    scale = 1.0 / (float(dst_n) / float(src_n))
+    d = np.arange(dst_n, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    if clamp_offsets:
+        lo, hi = s < 0, s >= src_n - 1
+        f = np.where(lo | hi, np.float32(0), f).astype(np.float32)
+        s = np.where(lo, 0, np.where(hi, src_n - 1, s))
+    return s, (np.float32(1) - f).astype(np.float32), f
+
+
+def resize_linear_f32(src, size):
+    """cv::resize(src, dsize, 0, 0, INTER_LINEAR) for one-channel CV_32F [OCV-MEM]: fp32 throughout, horizontal
+    D = S[s] * a0 + S[s + 1] * a1 (S[s] alone at the right end), vertical dst = R0 * b0 + R1 * b1 (no FMA: baseline build)."""
+    src = np.asarray(src, np.float32)
+    dw, dh = int(size[0]), int(size[1])
+    sh, sw = src.shape
+    sx, a0, a1 = _linear_f32_coeffs(sw, dw, True)
+    sy, b0, b1 = _linear_f32_coeffs(sh, dh, False)
+    sx1 = np.minimum(sx + 1, sw - 1)
+    two = sx < sw - 1  # beyond xmax only S[s] * 1 is evaluated
+    h = np.where(two[None, :], (src[:, sx] * a0[None, :]).astype(np.float32) + (src[:, sx1] * a1[None, :]).astype(np.float32),
+                 src[:, sx]).astype(np.float32)
+    r0, r1 = np.clip(sy, 0, sh - 1), np.clip(sy + 1, 0, sh - 1)
+    return ((h[r0] * b0[:, None]).astype(np.float32) + (h[r1] * b1[:, None]).astype(np.float32)).astype(np.float32)
+
+
+def block_gain_apply(img, gain_map):
+    """BlocksCompensator::apply [OCV-MEM]: the fp32 gain map (one per image; block_size-spaced) is resized to the image
+    size with INTER_LINEAR when the sizes differ, replicated over the channels and multiplied in:
+    cv::multiply(u8x3 image, CV_32FC3 gains) evaluates in fp32 and stores saturate_cast<uchar>(cvRound(product))."""
+    img = np.asarray(img, np.uint8)
+    g = np.asarray(gain_map, np.float32)
+    if g.shape != img.shape[:2]:
+        g = resize_linear_f32(g, (img.shape[1], img.shape[0]))
+    v = (img.astype(np.float32) * g[:, :, None]).astype(np.float32)
+    return np.clip(np.rint(v), 0, 255).astype(np.uint8)

@@ -510,6 +510,46 @@ static int resize_impl(stx_ctx* ctx, const stx_buf* src, int dw, int dh, bool di
     return STX_OK;
 }
 
+// coefficient set-up of cv::resize(INTER_LINEAR) for CV_32F [OCV-MEM]: f = (float)((d + 0.5) * scale - 0.5), s = floor(f),
+// f -= s; horizontal offsets are clamped with f = 0 at both ends, vertical ones are not (rows are clamped when fetched)
+static void linear_f32_table(int src_n, int dst_n, bool clamp_offsets, std::vector<int>& t)
+{
+    t.resize(2 * (size_t)dst_n);
+    const double scale = 1.0 / ((double)dst_n / (double)src_n);
+    for (int d = 0; d < dst_n; d++) {
+        float f = (float)(((double)d + 0.5) * scale - 0.5);
+        int sidx = (int)std::floor(f);
+        f = f - (float)sidx;
+        if (clamp_offsets) {
+            if (sidx < 0) { sidx = 0; f = 0.f; }
+            else if (sidx >= src_n - 1) { sidx = src_n - 1; f = 0.f; }
+        }
+        int bits;
+        memcpy(&bits, &f, 4);
+        t[2 * (size_t)d] = sidx;
+        t[2 * (size_t)d + 1] = bits;
+    }
+}
+
+STX_EXPORT int stx_block_gain_apply(stx_ctx* ctx, stx_buf* img, const stx_buf* gain_map)
+{
+    if (!ctx || !img || !gain_map) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (img->elem != STX_U8 || img->c != 3) return stx_fail(STX_ERR_INVALID, "block gain apply needs a u8x3 image");
+    if (gain_map->elem != STX_F32 || gain_map->c != 1) return stx_fail(STX_ERR_INVALID, "the gain map must be f32x1");
+    if (img->ctx != ctx || gain_map->ctx->device != ctx->device) return stx_fail(STX_ERR_INVALID, "buffers belong to another context");
+    STX_TRY(stx_set_device(ctx));
+    std::vector<int> xt, yt;
+    linear_f32_table(gain_map->w, img->w, true, xt);
+    linear_f32_table(gain_map->h, img->h, false, yt);
+    std::vector<int> both(xt);
+    both.insert(both.end(), yt.begin(), yt.end());
+    void* d_tab = nullptr;
+    STX_TRY(upload_small(ctx, both.data(), both.size() * sizeof(int), &d_tab));
+    const int rc = stx_launch_block_gain(ctx, img, gain_map, (const int*)d_tab, (const int*)d_tab + xt.size());
+    stx_dev_free(ctx, d_tab);
+    return rc;
+}
+
 STX_EXPORT int stx_resize_linear_exact(stx_ctx* ctx, const stx_buf* src, int dst_w, int dst_h, stx_buf** out)
 {
     if (!ctx || !src || !out) return stx_fail(STX_ERR_INVALID, "null argument");

@@ -712,3 +712,48 @@ int stx_launch_resize_exact(stx_ctx* ctx, const stx_buf* src, stx_buf* dst, cons
     else return stx_fail(STX_ERR_UNSUPPORTED, "resize: 1 or 3 channels");
     return check_launch("resize_linear_exact");
 }
+
+// ---------------------------------------------------------------------------------------------
+// BlocksCompensator::apply (next row N1, the reference's default "gain_blocks" compensator): the small fp32 gain map is
+// interpolated to the image size exactly as cv::resize(INTER_LINEAR) does for CV_32F — fp32 throughout, horizontal
+// S[s] * a0 + S[s+1] * a1 (S[s] alone at the right end), vertical R0 * b0 + R1 * b1 with the rows clamped, no FMA — and
+// multiplied in with cv::multiply's fp32 product + cvRound + saturation.  Fused: the full-size gain map never exists.
+// Tables (host, double -> float as upstream): x = (s, bits of f), y likewise (s may be -1).
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct BlockGainK {
+    uint8_t* img; long long stride; int w, h;
+    const float* gmap; long long gstride; int gw, gh;  // gstride in floats
+    const int2* xt; const int2* yt;
+};
+STX_DEV float gain_hrow(const BlockGainK& P, int row, int sx, float a0, float a1)
+{
+    const float* r = P.gmap + (long long)row * P.gstride;
+    if (sx >= P.gw - 1) return r[sx];
+    return stxd::fadd(stxd::fmul(r[sx], a0), stxd::fmul(r[sx + 1], a1));
+}
+__global__ __launch_bounds__(256) void block_gain_kernel(BlockGainK P)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.w || y >= P.h) return;
+    const int2 tx = P.xt[x], ty = P.yt[y];
+    const float a1 = __int_as_float(tx.y), a0 = stxd::fsub(1.f, a1), b1 = __int_as_float(ty.y), b0 = stxd::fsub(1.f, b1);
+    const int r0 = min(max(ty.x, 0), P.gh - 1), r1 = min(max(ty.x + 1, 0), P.gh - 1);
+    const float g = stxd::fadd(stxd::fmul(gain_hrow(P, r0, tx.x, a0, a1), b0), stxd::fmul(gain_hrow(P, r1, tx.x, a0, a1), b1));
+    uint8_t* p = P.img + (long long)y * P.stride + x * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) p[c] = (uint8_t)min(max(stxd::cv_round(stxd::fmul((float)p[c], g)), 0), 255);
+}
+}  // namespace
+
+int stx_launch_block_gain(stx_ctx* ctx, stx_buf* img, const stx_buf* gmap, const int* d_xt, const int* d_yt)
+{
+    BlockGainK K;
+    K.img = img->ptr; K.stride = (long long)img->stride; K.w = img->w; K.h = img->h;
+    K.gmap = (const float*)gmap->ptr; K.gstride = (long long)(gmap->stride / sizeof(float)); K.gw = gmap->w; K.gh = gmap->h;
+    K.xt = (const int2*)d_xt; K.yt = (const int2*)d_yt;
+    StxProfScope prof(ctx, "block_gain_apply", 6.0 * img->w * img->h);
+    hipLaunchKernelGGL(block_gain_kernel, dim3((img->w + 63) / 64, (img->h + 3) / 4), dim3(256), 0, ctx->stream, K);
+    return check_launch("block_gain_apply");
+}

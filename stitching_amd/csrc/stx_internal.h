@@ -153,6 +153,7 @@ int stx_launch_mb_level(stx_ctx* ctx, const MbLevelK& K, double algo_bytes);
 
 // pointwise exposure gain (next row N1) --------------------------------------------------------------
 int stx_launch_gain_apply(stx_ctx* ctx, stx_buf* img, const float g[3]);
+int stx_launch_block_gain(stx_ctx* ctx, stx_buf* img, const stx_buf* gmap, const int* d_xt, const int* d_yt);
 // cv::resize(INTER_LINEAR_EXACT) u8 (next rows N2 / N3); d_xt / d_yt: device tables of (offset, coeff1 | interior << 16)
 int stx_launch_resize_exact(stx_ctx* ctx, const stx_buf* src, stx_buf* dst, const int* d_xt, const int* d_yt, bool dilate,
                             const stx_buf* andmask);

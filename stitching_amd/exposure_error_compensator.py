@@ -5,8 +5,8 @@ The reference class (stitching/exposure_error_compensator.py:6-45) wraps cv.deta
 `apply(idx, corner, img, mask)` multiplies the final-resolution warped image by the gain, between warp and
 blend (stitching/stitcher.py:123,219-221).  This class keeps the surface and runs `apply` in HBM for the
 "gain" and "channel" compensators (one gain per image / per channel); gains come from `set_gains` — e.g. from
-the cv2 compensator's getMatGains() after its feed().  The block compensators interpolate a gain map with
-cv::resize and are not implemented here.
+the cv2 compensator's getMatGains() after its feed().  "gain_blocks" (the reference's default) interpolates its
+fp32 gain map with cv::resize(INTER_LINEAR) inside the same kernel; "channel_blocks" is not implemented.
 """
 import ctypes as C
 from collections import OrderedDict
@@ -29,7 +29,7 @@ class ExposureErrorCompensator:
     DEFAULT_COMPENSATOR = list(COMPENSATOR_CHOICES.keys())[0]
     DEFAULT_NR_FEEDS = 1
     DEFAULT_BLOCK_SIZE = 32
-    SUPPORTED_ON_DEVICE = ("gain", "channel", "no")
+    SUPPORTED_ON_DEVICE = ("gain_blocks", "gain", "channel", "no")
 
     def __init__(self, compensator=DEFAULT_COMPENSATOR, nr_feeds=DEFAULT_NR_FEEDS, block_size=DEFAULT_BLOCK_SIZE):
         if compensator not in self.COMPENSATOR_CHOICES:
@@ -39,8 +39,12 @@ class ExposureErrorCompensator:
         self.gains = None
 
     def set_gains(self, gains):
-        """gains[i]: scalar ("gain") or 3 per-channel BGR values ("channel") for image i."""
-        self.gains = [np.atleast_1d(np.asarray(g, np.float64)).reshape(-1) for g in gains]
+        """gains[i]: scalar ("gain"), 3 per-channel BGR values ("channel") or the fp32 gain map ("gain_blocks":
+        cv2's compensator.getMatGains()[i]) for image i."""
+        if self.compensator_type == "gain_blocks":
+            self.gains = [np.ascontiguousarray(np.asarray(g, np.float32).reshape(np.asarray(g).shape[:2])) for g in gains]
+        else:
+            self.gains = [np.atleast_1d(np.asarray(g, np.float64)).reshape(-1) for g in gains]
 
     def feed(self, *args):
         raise StitchingError("gain estimation (ExposureCompensator::feed) is outside the MI355X hot path: run it in OpenCV "
@@ -56,6 +60,12 @@ class ExposureErrorCompensator:
         if self.gains is None:
             raise StitchingError("ExposureErrorCompensator.set_gains(gains) must be called before apply")
         g = self.gains[idx]
+        if self.compensator_type == "gain_blocks":
+            ctx = get_context()
+            d = as_device(img, ctx)
+            gm = as_device(g, ctx)
+            _lib.check(ctx._lib.stx_block_gain_apply(ctx.handle, d._h, gm._h))
+            return d if config.device_resident() else d.numpy()
         g3 = np.full(3, g[0], np.float64) if g.size == 1 else g[:3]
         g3 = np.ascontiguousarray(g3, np.float32)  # arithm_op demotes the double scalar to float for 8-bit images
         ctx = get_context()

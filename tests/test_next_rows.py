@@ -17,7 +17,7 @@ def test_compensator_surface_and_errors():
     with pytest.raises(S.StitchingError):
         E("gain").apply(0, (0, 0), img, None)  # no gains yet
     with pytest.raises(S.StitchingError):
-        E("gain_blocks").apply(0, (0, 0), img, None)  # block compensators stay on the host
+        E("channel_blocks").apply(0, (0, 0), img, None)  # not implemented on the device
     with pytest.raises(S.StitchingError):
         E("gain").feed([], [], [])
     with pytest.raises(S.StitchingError):
@@ -182,3 +182,28 @@ def test_seam_mask_resize_feeds_the_blender(oracle, gpu_ctx):
     gp, gm = g.blend()
     op, om = o.blend()
     assert np.array_equal(gm, om) and np.array_equal(gp, op)
+
+
+def test_resize_linear_f32_known_answers(oracle):
+    g = np.array([[1.0, 1.5], [0.5, 2.0]], np.float32)
+    r = oracle.resize_linear_f32(g, (6, 4))
+    assert r.dtype == np.float32 and r.shape == (4, 6)
+    assert r[0, 0] == 1.0 and r[0, -1] == 1.5 and r[-1, 0] == 0.5 and r[-1, -1] == 2.0  # ends clamp to the corner samples
+    assert abs(r[1, 2] - 1.125) < 1e-6
+    assert np.allclose(oracle.resize_linear_f32(np.full((3, 5), 1.25, np.float32), (17, 11)), 1.25, atol=2e-7)
+    img = np.full((4, 6, 3), 100, np.uint8)
+    assert oracle.block_gain_apply(img, g)[0, 0].tolist() == [100, 100, 100]
+    assert oracle.block_gain_apply(img, g)[-1, -1].tolist() == [200, 200, 200]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,bs", [(517, 389, 32), (1203, 907, 32), (64, 48, 32), (33, 17, 32), (300, 200, 7)])
+def test_block_gain_apply_bit_exact(oracle, gpu_ctx, w, h, bs):
+    """the reference's default compensator: gain map of ceil(size / block_size) blocks, bilinearly resized and multiplied in"""
+    img = synthetic.make_frame(4, max(w, 16), max(h, 12))[:h, :w]
+    rng = np.random.default_rng(w + h)
+    gmap = (0.6 + 0.9 * rng.random(((h + bs - 1) // bs, (w + bs - 1) // bs))).astype(np.float32)
+    e = S.ExposureErrorCompensator("gain_blocks")
+    e.set_gains([gmap])
+    out = e.apply(0, (0, 0), img.copy(), None)
+    assert np.array_equal(out, oracle.block_gain_apply(img, gmap))
