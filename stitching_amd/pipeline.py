@@ -69,6 +69,41 @@ class StitchJob:
         return pano, pmask
 
 
+def compose(frames, cameras, warper_type="spherical", blender_type="multiband", blend_strength=Blender.DEFAULT_BLEND_STRENGTH,
+            compensator=None, seam_masks=None, ctx=None):
+    """The final-resolution half of Stitcher.stitch (stitching/stitcher.py:117-128) with every intermediate in HBM:
+
+        warp_final_resolution_imgs / masks   (:119-121, Warper)            -> one batched warp
+        compensate_exposure_errors           (:123, ExposureErrorCompensator.apply; gains from the low-res pass)
+        resize_seam_masks                    (:124, SeamFinder.resize; seam masks from the low-res pass)
+        blend_images + create_final_panorama (:126-128, Blender)
+
+    `compensator`: an ExposureErrorCompensator with set_gains() done, or None; `seam_masks`: low-resolution seam
+    masks (one per image, e.g. from cv2's seam finder), or None for the full warped masks.
+    Returns device-resident (panorama u8x3, mask u8)."""
+    ctx = ctx or get_context()
+    prev = config.device_resident()
+    config.set_device_resident(True)
+    try:
+        warper = Warper(warper_type, ctx=ctx)
+        warper.set_scale(cameras)
+        imgs, masks, rois = warper.warp_images_and_masks([as_device(f, ctx) for f in frames], cameras)
+        corners, sizes = [r[0:2] for r in rois], [r[2:4] for r in rois]
+        if compensator is not None:
+            imgs = [compensator.apply(i, corners[i], img, masks[i]) for i, img in enumerate(imgs)]
+        if seam_masks is not None:
+            from .seam_finder import SeamFinder
+
+            masks = [SeamFinder.resize(s, m) for s, m in zip(seam_masks, masks)]
+        blender = Blender(blender_type, blend_strength, ctx=ctx)
+        blender.prepare(corners, sizes)
+        for img, mask, corner in zip(imgs, masks, corners):
+            blender.feed(img, mask, corner)
+        return blender.blend()
+    finally:
+        config.set_device_resident(prev)
+
+
 def stitch(frames, cameras, **kw):
     """Convenience: numpy frames in, numpy panorama out (PCIe-inclusive path)."""
     job = StitchJob(frames, cameras, **kw)

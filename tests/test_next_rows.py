@@ -207,3 +207,32 @@ def test_block_gain_apply_bit_exact(oracle, gpu_ctx, w, h, bs):
     e.set_gains([gmap])
     out = e.apply(0, (0, 0), img.copy(), None)
     assert np.array_equal(out, oracle.block_gain_apply(img, gmap))
+
+
+@pytest.mark.gpu
+def test_compose_final_resolution_pipeline(oracle, gpu_ctx):
+    """pipeline.compose = the final-resolution half of Stitcher.stitch (stitching/stitcher.py:117-128): warp ->
+    gain_blocks apply -> seam-mask resize -> multi-band blend, all in HBM, against the same chain of oracle calls."""
+    from stitching_amd.pipeline import compose
+    from tests import helpers
+
+    imgs, cams = helpers.small_ring(4, 640, 480, span=150.0)
+    ow = oracle.Warper("spherical")
+    ow.set_scale(cams)
+    wi = [ow.warp_image(i, c) for i, c in zip(imgs, cams)]
+    wm = [ow.create_and_warp_mask((640, 480), c) for c in cams]
+    corners, sizes = ow.warp_rois([(640, 480)] * 4, cams)
+    rng = np.random.default_rng(11)
+    gmaps = [(0.8 + 0.4 * rng.random(((s[1] + 31) // 32, (s[0] + 31) // 32))).astype(np.float32) for s in sizes]
+    low = [np.ascontiguousarray(m[::6, ::6]) for m in synthetic.voronoi_seam_masks(wm, corners, sizes)]
+    oi = [oracle.block_gain_apply(a, g) for a, g in zip(wi, gmaps)]
+    om = [oracle.seam_resize(l, m) for l, m in zip(low, wm)]
+    ob = oracle.Blender("multiband", 15)
+    ob.prepare(corners, sizes)
+    for a, m, c in zip(oi, om, corners):
+        ob.feed(a, m, c)
+    op, omask = ob.blend()
+    comp = S.ExposureErrorCompensator("gain_blocks")
+    comp.set_gains(gmaps)
+    pano, mask = compose(imgs, cams, blend_strength=15, compensator=comp, seam_masks=low)
+    assert np.array_equal(np.asarray(mask), omask) and np.array_equal(np.asarray(pano), op)
