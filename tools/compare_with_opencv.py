@@ -63,7 +63,72 @@ def main():
             print(f"{name:24s} trig={'libm' if trig == 0 else 'exact'} roi_equal={roi_ok} warp max|d|={dmax} differing={nbad}")
             worst = max(worst, dmax)
     print("worst warped-pixel difference vs OpenCV:", worst, "(north star budget: 1 LSB)")
-    return 0 if worst <= 1 else 1
+
+    # ---- blenders: the reference's own call sequence (stitching/blender.py:23-48) on oracle-warped inputs
+    from stitching_amd import synthetic
+
+    worst_blend = 0
+    for name, p in G.CASES.items():
+        imgs, cams = G.inputs_for(p)
+        ow = O.Warper(p["warper"])
+        ow.set_scale(cams)
+        aspect = p.get("aspect", 1)
+        sizes0 = [(im.shape[1], im.shape[0]) for im in imgs]
+        wi = [ow.warp_image(im, c, aspect) for im, c in zip(imgs, cams)]
+        wm = [ow.create_and_warp_mask(s, c, aspect) for s, c in zip(sizes0, cams)]
+        corners, sizes = ow.warp_rois(sizes0, cams, aspect)
+        if p.get("voronoi"):
+            wm = synthetic.voronoi_seam_masks(wm, corners, sizes)
+        strength = p.get("strength", 5)
+        ob = O.Blender(p["blender"], strength)
+        ob.prepare(corners, sizes)
+        dst_sz = cv.detail.resultRoi(corners=corners, sizes=sizes)
+        bw = np.sqrt(dst_sz[2] * dst_sz[3]) * strength / 100
+        if p["blender"] == "no" or bw < 1:
+            cb = cv.detail.Blender_createDefault(cv.detail.Blender_NO)
+        elif p["blender"] == "multiband":
+            cb = cv.detail_MultiBandBlender()
+            cb.setNumBands(int((np.log(bw) / np.log(2.0) - 1.0)))
+        else:
+            cb = cv.detail_FeatherBlender()
+            cb.setSharpness(1.0 / bw)
+        cb.prepare(dst_sz)
+        for a, m, c in zip(wi, wm, corners):
+            ob.feed(a, m, c)
+            cb.feed(cv.UMat(a.astype(np.int16)), m, c)
+        op, om = ob.blend()
+        cp, cm = cb.blend(None, None)
+        cp = cv.convertScaleAbs(cp)
+        cp, cm = (x.get() if hasattr(x, "get") else x for x in (cp, cm))
+        d = np.abs(op.astype(int) - cp.astype(int)) if op.shape == cp.shape else np.array([999])
+        print(f"{name:24s} blend max|d|={int(d.max())} differing={int(np.count_nonzero(d))} mask_equal={np.array_equal(om, cm)}")
+        worst_blend = max(worst_blend, int(d.max()))
+    print("worst panorama difference vs OpenCV:", worst_blend, "(north star budget: 1 LSB)")
+
+    # ---- next rows: resize (INTER_LINEAR_EXACT), dilate, seam resize, gain apply, block gain apply
+    rng = np.random.default_rng(3)
+    img = synthetic.make_frame(0, 640, 480)
+    worst_next = 0
+    for dst in ((4000, 3000), (317, 211), (640, 480)):
+        d = np.abs(O.resize_linear_exact(img, dst).astype(int) - cv.resize(img, dst, interpolation=cv.INTER_LINEAR_EXACT).astype(int))
+        print(f"resize INTER_LINEAR_EXACT -> {dst}: max|d|={int(d.max())}")
+        worst_next = max(worst_next, int(d.max()))
+    m = (rng.random((96, 128)) > 0.6).astype(np.uint8) * 255
+    big = (rng.random((480, 640)) > 0.1).astype(np.uint8) * 255
+    ref = cv.bitwise_and(cv.resize(cv.dilate(m, None), (640, 480), 0, 0, cv.INTER_LINEAR_EXACT), big)
+    d = np.abs(O.seam_resize(m, big).astype(int) - ref.astype(int))
+    print(f"SeamFinder.resize: max|d|={int(d.max())}")
+    worst_next = max(worst_next, int(d.max()))
+    d = np.abs(O.gain_apply(img, 1.137).astype(int) - cv.multiply(img, 1.137).astype(int))
+    print(f"multiply(image, gain): max|d|={int(d.max())}")
+    worst_next = max(worst_next, int(d.max()))
+    gm = (0.7 + 0.6 * rng.random((15, 20))).astype(np.float32)
+    full = cv.resize(gm, (640, 480), interpolation=cv.INTER_LINEAR)
+    ref = cv.multiply(img, cv.merge([full, full, full]), dtype=cv.CV_8UC3)
+    d = np.abs(O.block_gain_apply(img, gm).astype(int) - ref.astype(int))
+    print(f"BlocksCompensator::apply: max|d|={int(d.max())}")
+    worst_next = max(worst_next, int(d.max()))
+    return 0 if max(worst, worst_blend, worst_next) <= 1 else 1
 
 
 if __name__ == "__main__":
