@@ -129,14 +129,11 @@ class Warper:
 
     @staticmethod
     def get_K(camera, aspect=1):
-        K = camera.K().astype(np.float32)
-        """ Modification of intrinsic parameters needed if cameras were
-        obtained on different scale than the scale of the Images which should
-        be warped """
-        K[0, 0] *= aspect
-        K[0, 2] *= aspect
-        K[1, 1] *= aspect
-        K[1, 2] *= aspect
+        """3x3 fp32 intrinsics of `camera` for images `aspect` times the size the cameras were estimated on
+        (stitching/warper.py:84-94): focal lengths and principal point scale with the image, the skew row does not."""
+        K = np.array(camera.K(), dtype=np.float32)
+        for r, c in ((0, 0), (0, 2), (1, 1), (1, 2)):
+            K[r, c] *= aspect
         return K
 
     # ------------------------------------------------------------------ back-end extras
