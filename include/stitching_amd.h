@@ -155,7 +155,8 @@ int stx_blend_destroy(stx_blender* b);
  *                        zero frame of the roi given to initialize(), the image pasted at its corner. */
 int stx_gain_apply(stx_ctx* ctx, stx_buf* img_u8x3, const float gains_bgr[3]);
 /* the reference's default compensator "gain_blocks": BlocksCompensator::apply = cv::resize(gain map, image size,
- * INTER_LINEAR) [fp32] + cv::multiply, fused (the full-size gain map is never stored); gain_map is f32x1 */
+ * INTER_LINEAR) [fp32] + cv::multiply, fused (the full-size gain map is never stored); gain_map is f32x1, or f32x3 (BGR
+ * maps, interleaved) for "channel_blocks" (BlocksChannelsCompensator) */
 int stx_block_gain_apply(stx_ctx* ctx, stx_buf* img_u8x3, const stx_buf* gain_map_f32);
 /* stx_resize_linear_exact <- stitching/images.py:122-124 cv.resize(img, size, interpolation=cv.INTER_LINEAR_EXACT) (u8x1 / u8x3:
  *                            the final-resolution resize of Images.resize, next row N3)

@@ -492,7 +492,9 @@ def block_gain_apply(img, gain_map):
     cv::multiply(u8x3 image, CV_32FC3 gains) evaluates in fp32 and stores saturate_cast<uchar>(cvRound(product))."""
     img = np.asarray(img, np.uint8)
     g = np.asarray(gain_map, np.float32)
-    if g.shape != img.shape[:2]:
-        g = resize_linear_f32(g, (img.shape[1], img.shape[0]))
-    v = (img.astype(np.float32) * g[:, :, None]).astype(np.float32)
+    if g.ndim == 2:
+        g = g[:, :, None]
+    if g.shape[:2] != img.shape[:2]:  # cv::resize works per channel (BlocksChannelsCompensator: CV_32FC3 maps)
+        g = np.stack([resize_linear_f32(g[:, :, c], (img.shape[1], img.shape[0])) for c in range(g.shape[2])], axis=2)
+    v = (img.astype(np.float32) * g).astype(np.float32)
     return np.clip(np.rint(v), 0, 255).astype(np.uint8)

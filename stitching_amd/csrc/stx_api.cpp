@@ -535,7 +535,8 @@ STX_EXPORT int stx_block_gain_apply(stx_ctx* ctx, stx_buf* img, const stx_buf* g
 {
     if (!ctx || !img || !gain_map) return stx_fail(STX_ERR_INVALID, "null argument");
     if (img->elem != STX_U8 || img->c != 3) return stx_fail(STX_ERR_INVALID, "block gain apply needs a u8x3 image");
-    if (gain_map->elem != STX_F32 || gain_map->c != 1) return stx_fail(STX_ERR_INVALID, "the gain map must be f32x1");
+    if (gain_map->elem != STX_F32 || (gain_map->c != 1 && gain_map->c != 3))
+        return stx_fail(STX_ERR_INVALID, "the gain map must be f32x1 (gain_blocks) or f32x3 (channel_blocks)");
     if (img->ctx != ctx || gain_map->ctx->device != ctx->device) return stx_fail(STX_ERR_INVALID, "buffers belong to another context");
     STX_TRY(stx_set_device(ctx));
     std::vector<int> xt, yt;

@@ -723,14 +723,14 @@ int stx_launch_resize_exact(stx_ctx* ctx, const stx_buf* src, stx_buf* dst, cons
 namespace {
 struct BlockGainK {
     uint8_t* img; long long stride; int w, h;
-    const float* gmap; long long gstride; int gw, gh;  // gstride in floats
+    const float* gmap; long long gstride; int gw, gh, gc;  // gstride in floats; gc = 1 (one map) or 3 (BGR maps, interleaved)
     const int2* xt; const int2* yt;
 };
-STX_DEV float gain_hrow(const BlockGainK& P, int row, int sx, float a0, float a1)
+STX_DEV float gain_hrow(const BlockGainK& P, int row, int sx, int ch, float a0, float a1)
 {
-    const float* r = P.gmap + (long long)row * P.gstride;
-    if (sx >= P.gw - 1) return r[sx];
-    return stxd::fadd(stxd::fmul(r[sx], a0), stxd::fmul(r[sx + 1], a1));
+    const float* r = P.gmap + (long long)row * P.gstride + ch;
+    if (sx >= P.gw - 1) return r[sx * P.gc];
+    return stxd::fadd(stxd::fmul(r[sx * P.gc], a0), stxd::fmul(r[(sx + 1) * P.gc], a1));
 }
 __global__ __launch_bounds__(256) void block_gain_kernel(BlockGainK P)
 {
@@ -740,10 +740,14 @@ __global__ __launch_bounds__(256) void block_gain_kernel(BlockGainK P)
     const int2 tx = P.xt[x], ty = P.yt[y];
     const float a1 = __int_as_float(tx.y), a0 = stxd::fsub(1.f, a1), b1 = __int_as_float(ty.y), b0 = stxd::fsub(1.f, b1);
     const int r0 = min(max(ty.x, 0), P.gh - 1), r1 = min(max(ty.x + 1, 0), P.gh - 1);
-    const float g = stxd::fadd(stxd::fmul(gain_hrow(P, r0, tx.x, a0, a1), b0), stxd::fmul(gain_hrow(P, r1, tx.x, a0, a1), b1));
     uint8_t* p = P.img + (long long)y * P.stride + x * 3;
+    float g = 0.f;
 #pragma unroll
-    for (int c = 0; c < 3; c++) p[c] = (uint8_t)min(max(stxd::cv_round(stxd::fmul((float)p[c], g)), 0), 255);
+    for (int c = 0; c < 3; c++) {
+        if (c == 0 || P.gc == 3)
+            g = stxd::fadd(stxd::fmul(gain_hrow(P, r0, tx.x, c, a0, a1), b0), stxd::fmul(gain_hrow(P, r1, tx.x, c, a0, a1), b1));
+        p[c] = (uint8_t)min(max(stxd::cv_round(stxd::fmul((float)p[c], g)), 0), 255);
+    }
 }
 }  // namespace
 
@@ -752,6 +756,7 @@ int stx_launch_block_gain(stx_ctx* ctx, stx_buf* img, const stx_buf* gmap, const
     BlockGainK K;
     K.img = img->ptr; K.stride = (long long)img->stride; K.w = img->w; K.h = img->h;
     K.gmap = (const float*)gmap->ptr; K.gstride = (long long)(gmap->stride / sizeof(float)); K.gw = gmap->w; K.gh = gmap->h;
+    K.gc = gmap->c;
     K.xt = (const int2*)d_xt; K.yt = (const int2*)d_yt;
     StxProfScope prof(ctx, "block_gain_apply", 6.0 * img->w * img->h);
     hipLaunchKernelGGL(block_gain_kernel, dim3((img->w + 63) / 64, (img->h + 3) / 4), dim3(256), 0, ctx->stream, K);

@@ -5,8 +5,8 @@ The reference class (stitching/exposure_error_compensator.py:6-45) wraps cv.deta
 `apply(idx, corner, img, mask)` multiplies the final-resolution warped image by the gain, between warp and
 blend (stitching/stitcher.py:123,219-221).  This class keeps the surface and runs `apply` in HBM for the
 "gain" and "channel" compensators (one gain per image / per channel); gains come from `set_gains` — e.g. from
-the cv2 compensator's getMatGains() after its feed().  "gain_blocks" (the reference's default) interpolates its
-fp32 gain map with cv::resize(INTER_LINEAR) inside the same kernel; "channel_blocks" is not implemented.
+the cv2 compensator's getMatGains() after its feed().  "gain_blocks" (the reference's default) and "channel_blocks" interpolate their
+fp32 gain maps (one / three channels) with cv::resize(INTER_LINEAR) inside the same kernel.
 """
 import ctypes as C
 from collections import OrderedDict
@@ -29,7 +29,7 @@ class ExposureErrorCompensator:
     DEFAULT_COMPENSATOR = list(COMPENSATOR_CHOICES.keys())[0]
     DEFAULT_NR_FEEDS = 1
     DEFAULT_BLOCK_SIZE = 32
-    SUPPORTED_ON_DEVICE = ("gain_blocks", "gain", "channel", "no")
+    SUPPORTED_ON_DEVICE = ("gain_blocks", "gain", "channel", "channel_blocks", "no")
 
     def __init__(self, compensator=DEFAULT_COMPENSATOR, nr_feeds=DEFAULT_NR_FEEDS, block_size=DEFAULT_BLOCK_SIZE):
         if compensator not in self.COMPENSATOR_CHOICES:
@@ -43,6 +43,8 @@ class ExposureErrorCompensator:
         cv2's compensator.getMatGains()[i]) for image i."""
         if self.compensator_type == "gain_blocks":
             self.gains = [np.ascontiguousarray(np.asarray(g, np.float32).reshape(np.asarray(g).shape[:2])) for g in gains]
+        elif self.compensator_type == "channel_blocks":  # CV_32FC3 gain maps (one BGR triple per block)
+            self.gains = [np.ascontiguousarray(np.asarray(g, np.float32)) for g in gains]
         else:
             self.gains = [np.atleast_1d(np.asarray(g, np.float64)).reshape(-1) for g in gains]
 
@@ -60,7 +62,7 @@ class ExposureErrorCompensator:
         if self.gains is None:
             raise StitchingError("ExposureErrorCompensator.set_gains(gains) must be called before apply")
         g = self.gains[idx]
-        if self.compensator_type == "gain_blocks":
+        if self.compensator_type in ("gain_blocks", "channel_blocks"):
             ctx = get_context()
             d = as_device(img, ctx)
             gm = as_device(g, ctx)

@@ -17,8 +17,6 @@ def test_compensator_surface_and_errors():
     with pytest.raises(S.StitchingError):
         E("gain").apply(0, (0, 0), img, None)  # no gains yet
     with pytest.raises(S.StitchingError):
-        E("channel_blocks").apply(0, (0, 0), img, None)  # not implemented on the device
-    with pytest.raises(S.StitchingError):
         E("gain").feed([], [], [])
     with pytest.raises(S.StitchingError):
         E("bogus")
@@ -207,6 +205,10 @@ def test_block_gain_apply_bit_exact(oracle, gpu_ctx, w, h, bs):
     e.set_gains([gmap])
     out = e.apply(0, (0, 0), img.copy(), None)
     assert np.array_equal(out, oracle.block_gain_apply(img, gmap))
+    gmap3 = (0.6 + 0.9 * rng.random(gmap.shape + (3,))).astype(np.float32)  # channel_blocks: one BGR triple per block
+    e3 = S.ExposureErrorCompensator("channel_blocks")
+    e3.set_gains([gmap3])
+    assert np.array_equal(e3.apply(0, (0, 0), img.copy(), None), oracle.block_gain_apply(img, gmap3))
 
 
 @pytest.mark.gpu
