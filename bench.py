@@ -301,6 +301,34 @@ def main():
         e2e = (time.perf_counter() - t1) / args.e2e_steps
         result["pcie_inclusive"] = {"value": round(src_mpix / e2e, 1), "unit": "Mpix/s", "ms_per_step": round(e2e * 1e3, 2),
                                     "note": "pageable numpy frames H2D + roi sync + panorama D2H every step; not `value`"}
+        # the same with page-locked frames (a decoder writing into stitching_amd.pinned_empty arrays) and a
+        # page-locked panorama buffer
+        import numpy as np
+
+        from stitching_amd import pinned_empty
+        from stitching_amd.pipeline import StitchJob
+
+        pframes = []
+        for f in frames:
+            pf = pinned_empty(f.shape, f.dtype)
+            np.copyto(pf, f)
+            pframes.append(pf)
+        pout = {}
+
+        def pinned_step():
+            pano, pmask = StitchJob(pframes, cams, warper_type=args.warper, blender_type=args.blender,
+                                    num_bands=args.bands).run()
+            for key, d in (("pano", pano), ("mask", pmask)):
+                if key not in pout or pout[key].shape != d.shape:
+                    pout[key] = pinned_empty(d.shape, d.dtype)
+                d.numpy(out=pout[key])
+
+        pinned_step()
+        t1 = time.perf_counter()
+        for _ in range(args.e2e_steps):
+            pinned_step()
+        e2p = (time.perf_counter() - t1) / args.e2e_steps
+        result["pcie_inclusive"]["pinned"] = {"value": round(src_mpix / e2p, 1), "ms_per_step": round(e2p * 1e3, 2)}
     if world == 1 and not args.no_cpu_baseline:
         cb, _ = cpu_baseline(args, frames, cams, all_cams)
         result["cpu_baseline"] = cb

@@ -82,6 +82,10 @@ int stx_ctx_sync(stx_ctx* ctx);
 int stx_buf_from_host(stx_ctx* ctx, const void* host, size_t host_stride_bytes, int w, int h, int channels, int elem,
                       stx_buf** out);
 int stx_buf_alloc(stx_ctx* ctx, int w, int h, int channels, int elem, stx_buf** out);
+/* page-locked host memory (for decoded frames / read-backs): stx_buf_from_host / stx_buf_to_host on such memory run at
+ * PCIe rate instead of the pageable-copy rate (the cv.imread -> UMat staging in front of stitching/images.py:111) */
+int stx_host_alloc(size_t bytes, void** out);
+int stx_host_free(void* p);
 int stx_buf_to_host(const stx_buf* buf, void* host, size_t host_stride_bytes);
 /* rectangular sub-view sharing the parent's memory (numpy slicing in stitching/cropper.py:150-151) */
 int stx_buf_view(const stx_buf* buf, int x, int y, int w, int h, stx_buf** out);

@@ -5,7 +5,7 @@ PyTorch, no OpenCV, no CPU fallback)."""
 from .blender import Blender
 from .camera import CameraParams
 from .config import device_resident, set_device_resident
-from .device import Context, DeviceImage, as_device, device_count, get_context, set_default_device
+from .device import Context, DeviceImage, as_device, device_count, get_context, pinned_empty, set_default_device
 from .exposure_error_compensator import ExposureErrorCompensator
 from .seam_finder import SeamFinder, resize_linear_exact
 from .stitching_error import StitchingError, StitchingWarning
@@ -15,6 +15,6 @@ from .warper import Warper
 __all__ = [
     "Blender", "CameraParams", "Context", "DeviceImage", "ExposureErrorCompensator", "StitchingError", "StitchingWarning",
     "SeamFinder", "Timelapser", "Warper", "resize_linear_exact",
-    "as_device", "device_count", "device_resident", "get_context", "set_default_device", "set_device_resident",
+    "as_device", "device_count", "pinned_empty", "device_resident", "get_context", "set_default_device", "set_device_resident",
 ]
 __version__ = "0.1.0"

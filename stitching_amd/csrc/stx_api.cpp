@@ -350,6 +350,24 @@ STX_EXPORT int stx_buf_from_host(stx_ctx* ctx, const void* host, size_t host_str
     return STX_OK;
 }
 
+// Page-locked host memory for the frames a decoder produces and for read-backs: copies from / to it run at PCIe
+// rate without the driver's staging through pageable memory (next row N3: staging of the source frames).
+STX_EXPORT int stx_host_alloc(size_t bytes, void** out)
+{
+    if (!out || bytes == 0) return stx_fail(STX_ERR_INVALID, "bad argument");
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return stx_fail(STX_ERR_OOM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    *out = p;
+    return STX_OK;
+}
+
+STX_EXPORT int stx_host_free(void* p)
+{
+    if (p) hipHostFree(p);
+    return STX_OK;
+}
+
 STX_EXPORT int stx_buf_to_host(const stx_buf* buf, void* host, size_t host_stride)
 {
     if (!buf || !host) return stx_fail(STX_ERR_INVALID, "null argument");

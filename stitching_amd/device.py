@@ -94,6 +94,35 @@ def get_context(device=None):
         return ctx
 
 
+class _PinnedBlock:
+    """Owns one page-locked host allocation and exposes it through the array interface: numpy arrays made from it
+    keep it alive as their .base."""
+
+    def __init__(self, nbytes):
+        self._lib = _lib.lib()
+        p = C.c_void_p()
+        _lib.check(self._lib.stx_host_alloc(int(nbytes), C.byref(p)))
+        self.ptr = p
+        self.__array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (p.value, False), "version": 3}
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._lib.stx_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.uint8):
+    """numpy array in page-locked host memory: decode frames into it (or np.copyto) and the upload in
+    Warper.warp_image / DeviceImage.from_numpy runs at PCIe rate; DeviceImage.numpy(out=such an array) likewise."""
+    dt = np.dtype(dtype)
+    count = int(np.prod(shape))
+    raw = np.asarray(_PinnedBlock(max(count * dt.itemsize, 1)))
+    return raw[:count * dt.itemsize].view(dt).reshape(shape)
+
+
 class DeviceImage:
     """A 2-D image in HBM (u8 / int16 / fp32, 1..4 interleaved channels)."""
 
@@ -146,8 +175,12 @@ class DeviceImage:
     def size(self):
         return self.height * self.width * self.channels
 
-    def numpy(self):
-        out = np.empty(self.shape, self.dtype)
+    def numpy(self, out=None):
+        """Host copy; `out`: a C-contiguous array of this shape / dtype to copy into (e.g. from pinned_empty)."""
+        if out is None:
+            out = np.empty(self.shape, self.dtype)
+        elif out.shape != self.shape or out.dtype != self.dtype or not out.flags.c_contiguous:
+            raise StitchingError(f"out must be a C-contiguous {self.dtype} array of shape {self.shape}")
         _lib.check(self.ctx._lib.stx_buf_to_host(self._h, out.ctypes.data_as(C.c_void_p), out.strides[0]))
         return out
 

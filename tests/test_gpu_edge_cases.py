@@ -133,3 +133,29 @@ def test_camera_looking_away(oracle, gpu_ctx):
         if roi[2] * roi[3] < 4_000_000:
             assert np.array_equal(g.warp_image(img, cam), o.warp_image(img, cam)), wtype
             assert np.array_equal(g.create_and_warp_mask((200, 150), cam), o.create_and_warp_mask((200, 150), cam)), wtype
+
+
+def test_pinned_host_arrays_round_trip(gpu_ctx):
+    """stx_host_alloc / pinned_empty: uploads from and read-backs into page-locked arrays equal the pageable ones."""
+    import gc
+
+    rng = np.random.default_rng(11)
+    ref = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    pin = S.pinned_empty(ref.shape, ref.dtype)
+    assert pin.shape == ref.shape and pin.dtype == ref.dtype and pin.flags.c_contiguous
+    np.copyto(pin, ref)
+    d = S.DeviceImage.from_numpy(pin, gpu_ctx)
+    assert np.array_equal(d.numpy(), ref)
+    out = S.pinned_empty(ref.shape, ref.dtype)
+    got = d.numpy(out=out)
+    assert got is out and np.array_equal(out, ref)
+    with pytest.raises(S.StitchingError):
+        d.numpy(out=np.empty((37, 53), np.uint8))
+    # the allocation lives as long as any view of it
+    view = pin[5:9]
+    del pin
+    gc.collect()
+    assert np.array_equal(view, ref[5:9])
+    s16 = S.pinned_empty((4, 6), np.int16)
+    s16[:] = -3
+    assert int(s16.sum()) == -72
