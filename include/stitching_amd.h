@@ -41,12 +41,27 @@ extern "C" {
 #define STX_ERR_STATE (-4)       /* call order violated (e.g. feed after finish)      */
 #define STX_ERR_UNSUPPORTED (-5) /* valid in the reference, not implemented here      */
 
-/* warper types: index into Warper.WARP_TYPE_CHOICES (stitching/warper.py:10-27) that this
- * back end implements; cv.PyRotationWarper(type, scale) string -> id in the Python shim */
+/* warper types: the names of Warper.WARP_TYPE_CHOICES (stitching/warper.py:10-27);
+ * cv.PyRotationWarper(type, scale) string -> id in the Python shim */
 #define STX_WARP_PLANE 0
 #define STX_WARP_AFFINE 1
 #define STX_WARP_CYLINDRICAL 2
 #define STX_WARP_SPHERICAL 3
+/* the other twelve names cv.PyRotationWarper accepts: generic RotationWarperBase<P> warpers (roi from every source
+ * pixel, per-pixel projector), (a, b) fixed by the name as in PyRotationWarper's constructor */
+#define STX_WARP_FISHEYE 4
+#define STX_WARP_STEREOGRAPHIC 5
+#define STX_WARP_COMPRESSED_PLANE_A2B1 6
+#define STX_WARP_COMPRESSED_PLANE_A15B1 7
+#define STX_WARP_COMPRESSED_PLANE_PORTRAIT_A2B1 8
+#define STX_WARP_COMPRESSED_PLANE_PORTRAIT_A15B1 9
+#define STX_WARP_PANINI_A2B1 10
+#define STX_WARP_PANINI_A15B1 11
+#define STX_WARP_PANINI_PORTRAIT_A2B1 12
+#define STX_WARP_PANINI_PORTRAIT_A15B1 13
+#define STX_WARP_MERCATOR 14
+#define STX_WARP_TRANSVERSE_MERCATOR 15
+#define STX_WARP_TYPE_COUNT 16
 
 /* cv.INTER_* / cv.BORDER_* values used by stitching/warper.py:49-50,65-66 */
 #define STX_INTER_NEAREST 0

@@ -18,7 +18,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libstx_oracle.so")
 
-WARP_TYPES = {"plane": 0, "affine": 1, "cylindrical": 2, "spherical": 3}
+WARP_TYPES = {"plane": 0, "affine": 1, "cylindrical": 2, "spherical": 3, "fisheye": 4, "stereographic": 5,
+              "compressedPlaneA2B1": 6, "compressedPlaneA1.5B1": 7, "compressedPlanePortraitA2B1": 8,
+              "compressedPlanePortraitA1.5B1": 9, "paniniA2B1": 10, "paniniA1.5B1": 11, "paniniPortraitA2B1": 12,
+              "paniniPortraitA1.5B1": 13, "mercator": 14, "transverseMercator": 15}
 BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REFLECT, BORDER_REFLECT_101 = 0, 1, 2, 4
 TRIG_LIBM, TRIG_EXACT = 0, 1
 
@@ -68,6 +71,11 @@ def lib():
         L.orc_atan2_d.restype = C.c_double
         L.orc_acos_d.argtypes = [C.c_double]
         L.orc_acos_d.restype = C.c_double
+        for fn in ("tan", "asin", "atan", "log", "exp", "sinh", "cosh"):
+            f = getattr(L, f"orc_{fn}_d")
+            f.argtypes = [C.c_double]
+            f.restype = C.c_double
+        L.orc_map_point.argtypes = [C.c_int, C.c_float, fp, fp, C.c_int, C.c_int, C.c_float, C.c_float, fp]
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_set_num_threads.restype = None
         _lib = L

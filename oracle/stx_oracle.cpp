@@ -166,12 +166,120 @@ double acos_d(double w)
     return atan2_d(std::sqrt(t), w);
 }
 
+// The projectors beyond plane / cylindrical / spherical also call tanf, asinf, atanf, logf, sinhf, coshf.
+double tan_d(double x)
+{
+    double s, c;
+    sincos_d(x, &s, &c);
+    return s / c;
+}
+
+double asin_d(double w)
+{
+    // asin(w) = atan2(w, sqrt((1-w)(1+w))); NaN for |w| > 1 like libm
+    double t = (1.0 - w) * (1.0 + w);
+    return atan2_d(w, std::sqrt(t));
+}
+
+inline uint64_t d2u(double v) { uint64_t u; std::memcpy(&u, &v, 8); return u; }
+inline double u2d(uint64_t u) { double v; std::memcpy(&v, &u, 8); return v; }
+
+// fdlibm e_log.c: x = 2^k (1 + f), log(1 + f) = f - f^2/2 + s (f^2/2 + R(s^2)), s = f / (2 + f)
+double log_d(double x)
+{
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    if (x != x) return x;
+    if (x < 0.0) return std::numeric_limits<double>::quiet_NaN();
+    if (x == 0.0) return -std::numeric_limits<double>::infinity();
+    if (x == std::numeric_limits<double>::infinity()) return x;
+    int k = 0;
+    if (x < 2.2250738585072014e-308) {
+        x = x * 18014398509481984.0;  // 2^54
+        k = -54;
+    }
+    uint64_t bits = d2u(x);
+    int hx = (int)(bits >> 32);
+    k += (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    const int i = (hx + 0x95f64) & 0x100000;  // mantissa >= sqrt(2): halve it, bump k
+    bits = ((uint64_t)(uint32_t)(hx | (i ^ 0x3ff00000)) << 32) | (bits & 0xffffffffull);
+    k += i >> 20;
+    const double f = u2d(bits) - 1.0;
+    const double dk = (double)k;
+    const double s = f / (2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    const double hfsq = (0.5 * f) * f;
+    return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+}
+
+// fdlibm e_exp.c: x = k ln2 + r, exp(r) = 1 + r + r c / (2 - c)
+double exp_d(double x)
+{
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10,
+                 INV_LN2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x > 7.09782712893383973096e+02) return std::numeric_limits<double>::infinity();
+    if (x < -7.45133219101941108420e+02) return 0.0;
+    double hi = x, lo = 0.0;
+    int k = 0;
+    if (std::fabs(x) > 0.34657359027997264) {  // 0.5 ln2
+        k = (int)(INV_LN2 * x + (x < 0.0 ? -0.5 : 0.5));
+        const double t = (double)k;
+        hi = x - t * LN2_HI;
+        lo = t * LN2_LO;
+    }
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    const int k1 = k / 2, k2 = k - k1;  // 2^k in two normal factors
+    return (y * u2d((uint64_t)(k1 + 1023) << 52)) * u2d((uint64_t)(k2 + 1023) << 52);
+}
+
+double sinh_d(double x)
+{
+    if (x != x) return x;
+    const double a = std::fabs(x);
+    double r;
+    if (a < 0.03125) {  // odd Taylor series: the difference of exponentials would cancel
+        const double z = a * a;
+        const double p = z * (1.66666666666666657415e-01 + z * (8.33333333333333321769e-03 +
+                         z * (1.98412698412698412526e-04 + z * 2.75573192239858925110e-06)));
+        r = a + a * p;
+    } else {
+        const double e = exp_d(a);
+        r = 0.5 * (e - 1.0 / e);
+    }
+    return x < 0.0 ? -r : r;
+}
+
+double cosh_d(double x)
+{
+    if (x != x) return x;
+    const double e = exp_d(std::fabs(x));
+    return 0.5 * (e + 1.0 / e);
+}
+
 struct Trig {
     int mode;
     float sin_(float x) const { if (!mode) return sinf(x); double s, c; sincos_d((double)x, &s, &c); return (float)s; }
     float cos_(float x) const { if (!mode) return cosf(x); double s, c; sincos_d((double)x, &s, &c); return (float)c; }
     float atan2_(float y, float x) const { return mode ? (float)atan2_d((double)y, (double)x) : atan2f(y, x); }
     float acos_(float w) const { return mode ? (float)acos_d((double)w) : acosf(w); }
+    float tan_(float x) const { return mode ? (float)tan_d((double)x) : tanf(x); }
+    float asin_(float w) const { return mode ? (float)asin_d((double)w) : asinf(w); }
+    float atan_(float x) const { return mode ? (float)atan_d((double)x) : atanf(x); }
+    float log_(float x) const { return mode ? (float)log_d((double)x) : logf(x); }
+    float sinh_(float x) const { return mode ? (float)sinh_d((double)x) : sinhf(x); }
+    float cosh_(float x) const { return mode ? (float)cosh_d((double)x) : coshf(x); }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -218,12 +326,18 @@ int border_interpolate(int p, int len, int type)
 // Projectors (modules/stitching/include/opencv2/stitching/detail/warpers_inl.hpp,
 // modules/stitching/src/warpers.cpp)
 // ------------------------------------------------------------------------------------------
-enum { W_PLANE = 0, W_AFFINE = 1, W_CYLINDRICAL = 2, W_SPHERICAL = 3, W_FISHEYE = 4,
-       W_STEREOGRAPHIC = 5, W_COMPRESSED_PLANE = 6, W_COMPRESSED_PLANE_PORTRAIT = 7,
-       W_PANINI = 8, W_PANINI_PORTRAIT = 9, W_MERCATOR = 10, W_TRANSVERSE_MERCATOR = 11 };
+// warper ids = the 16 names cv.PyRotationWarper accepts (stitching/warper.py:11-28), in that order of appearance in
+// OpenCV's PyRotationWarper constructor; `family` + (a, b) is what the projector templates are instantiated with
+enum { W_PLANE = 0, W_AFFINE = 1, W_CYLINDRICAL = 2, W_SPHERICAL = 3, W_FISHEYE = 4, W_STEREOGRAPHIC = 5,
+       W_CPLANE_A2B1 = 6, W_CPLANE_A15B1 = 7, W_CPLANE_PORTRAIT_A2B1 = 8, W_CPLANE_PORTRAIT_A15B1 = 9,
+       W_PANINI_A2B1 = 10, W_PANINI_A15B1 = 11, W_PANINI_PORTRAIT_A2B1 = 12, W_PANINI_PORTRAIT_A15B1 = 13,
+       W_MERCATOR = 14, W_TRANSVERSE_MERCATOR = 15, W_COUNT = 16 };
+enum { F_PLANE = 0, F_CYLINDRICAL, F_SPHERICAL, F_FISHEYE, F_STEREOGRAPHIC, F_CRECT, F_CRECT_PORTRAIT, F_PANINI,
+       F_PANINI_PORTRAIT, F_MERCATOR, F_TRANSVERSE_MERCATOR };
 
 struct Projector {
-    int type;
+    int type;    // W_*
+    int family;  // F_*
     float scale;
     float a, b;  // compressed-rectilinear / panini parameters
     float k[9], rinv[9], r_kinv[9], k_rinv[9], t[3];
@@ -284,6 +398,24 @@ void make_projector(Projector& p, int type, float scale, const float* K, const f
     p.scale = scale;
     p.a = p.b = 1.f;
     p.tr.mode = trig;
+    switch (type) {
+    case W_PLANE: case W_AFFINE: p.family = F_PLANE; break;
+    case W_CYLINDRICAL: p.family = F_CYLINDRICAL; break;
+    case W_SPHERICAL: p.family = F_SPHERICAL; break;
+    case W_FISHEYE: p.family = F_FISHEYE; break;
+    case W_STEREOGRAPHIC: p.family = F_STEREOGRAPHIC; break;
+    // PyRotationWarper: "compressedPlaneA2B1" -> CompressedRectilinearWarper(2.0f, 1.0f), "...A1.5B1" -> (1.5f, 1.0f), etc.
+    case W_CPLANE_A2B1: p.family = F_CRECT; p.a = 2.0f; break;
+    case W_CPLANE_A15B1: p.family = F_CRECT; p.a = 1.5f; break;
+    case W_CPLANE_PORTRAIT_A2B1: p.family = F_CRECT_PORTRAIT; p.a = 2.0f; break;
+    case W_CPLANE_PORTRAIT_A15B1: p.family = F_CRECT_PORTRAIT; p.a = 1.5f; break;
+    case W_PANINI_A2B1: p.family = F_PANINI; p.a = 2.0f; break;
+    case W_PANINI_A15B1: p.family = F_PANINI; p.a = 1.5f; break;
+    case W_PANINI_PORTRAIT_A2B1: p.family = F_PANINI_PORTRAIT; p.a = 2.0f; break;
+    case W_PANINI_PORTRAIT_A15B1: p.family = F_PANINI_PORTRAIT; p.a = 1.5f; break;
+    case W_MERCATOR: p.family = F_MERCATOR; break;
+    default: p.family = F_TRANSVERSE_MERCATOR; break;
+    }
     float T[3] = {0.f, 0.f, 0.f};
     if (type == W_AFFINE) {
         // R = H with H[0,2]=H[1,2]=0, transposed; T = -(R * (H[0,2], H[1,2], 0))
@@ -310,25 +442,79 @@ const float PI_F = static_cast<float>(3.14159265358979323846);
 void map_forward(const Projector& p, float x, float y, float& u, float& v)
 {
     const float* rk = p.r_kinv;
+    const Trig& T = p.tr;
     float x_ = rk[0] * x + rk[1] * y + rk[2];
     float y_ = rk[3] * x + rk[4] * y + rk[5];
     float z_ = rk[6] * x + rk[7] * y + rk[8];
-    switch (p.type) {
-    case W_PLANE:
-    case W_AFFINE:
+    if (p.family == F_CRECT_PORTRAIT || p.family == F_PANINI_PORTRAIT) {  // the portrait projectors swap the roles of rows 0 and 1
+        float t = x_; x_ = y_; y_ = t;
+    }
+    switch (p.family) {
+    case F_PLANE:
         x_ = p.t[0] + x_ / z_ * (1 - p.t[2]);
         y_ = p.t[1] + y_ / z_ * (1 - p.t[2]);
         u = p.scale * x_;
         v = p.scale * y_;
         break;
-    case W_CYLINDRICAL:
-        u = p.scale * p.tr.atan2_(x_, z_);
+    case F_CYLINDRICAL:
+        u = p.scale * T.atan2_(x_, z_);
         v = p.scale * y_ / sqrtf(x_ * x_ + z_ * z_);
         break;
-    case W_SPHERICAL: {
-        u = p.scale * p.tr.atan2_(x_, z_);
+    case F_SPHERICAL: {
+        u = p.scale * T.atan2_(x_, z_);
         float w = y_ / sqrtf(x_ * x_ + y_ * y_ + z_ * z_);
-        v = p.scale * (PI_F - p.tr.acos_(w == w ? w : 0));
+        v = p.scale * (PI_F - T.acos_(w == w ? w : 0));
+        break;
+    }
+    case F_FISHEYE: {  // FisheyeProjector::mapForward
+        float u_ = T.atan2_(x_, z_);
+        float v_ = PI_F - T.acos_(y_ / sqrtf(x_ * x_ + y_ * y_ + z_ * z_));
+        u = p.scale * v_ * T.cos_(u_);
+        v = p.scale * v_ * T.sin_(u_);
+        break;
+    }
+    case F_STEREOGRAPHIC: {  // StereographicProjector::mapForward
+        float u_ = T.atan2_(x_, z_);
+        float v_ = PI_F - T.acos_(y_ / sqrtf(x_ * x_ + y_ * y_ + z_ * z_));
+        float r = T.sin_(v_) / (1 - T.cos_(v_));
+        u = p.scale * r * T.cos_(u_);
+        v = p.scale * r * T.sin_(u_);
+        break;
+    }
+    case F_CRECT:            // CompressedRectilinearProjector::mapForward
+    case F_CRECT_PORTRAIT: {  // CompressedRectilinearPortraitProjector::mapForward (u negated)
+        float u_ = T.atan2_(x_, z_);
+        float v_ = T.asin_(y_ / sqrtf(x_ * x_ + y_ * y_ + z_ * z_));
+        float s = p.family == F_CRECT ? p.scale : -p.scale;
+        u = s * p.a * T.tan_(u_ / p.a);
+        v = p.scale * p.b * T.tan_(v_) / T.cos_(u_);
+        break;
+    }
+    case F_PANINI:            // PaniniProjector::mapForward
+    case F_PANINI_PORTRAIT: {  // PaniniPortraitProjector::mapForward (u negated)
+        float u_ = T.atan2_(x_, z_);
+        float v_ = T.asin_(y_ / sqrtf(x_ * x_ + y_ * y_ + z_ * z_));
+        float tg = p.a * T.tan_(u_ / p.a);
+        float s = p.family == F_PANINI ? p.scale : -p.scale;
+        u = s * tg;
+        float sinu = T.sin_(u_);
+        if (std::fabs((double)sinu) < 1E-7) v = p.scale * p.b * T.tan_(v_);
+        else v = p.scale * p.b * tg * T.tan_(v_) / sinu;
+        break;
+    }
+    case F_MERCATOR: {  // MercatorProjector::mapForward
+        float u_ = T.atan2_(x_, z_);
+        float v_ = T.asin_(y_ / sqrtf(x_ * x_ + y_ * y_ + z_ * z_));
+        u = p.scale * u_;
+        v = p.scale * T.log_(T.tan_((float)(3.14159265358979323846 / 4) + v_ / 2));
+        break;
+    }
+    case F_TRANSVERSE_MERCATOR: {  // TransverseMercatorProjector::mapForward
+        float u_ = T.atan2_(x_, z_);
+        float v_ = T.asin_(y_ / sqrtf(x_ * x_ + y_ * y_ + z_ * z_));
+        float B = T.cos_(v_) * T.sin_(u_);
+        u = p.scale / 2 * T.log_((1 + B) / (1 - B));
+        v = p.scale * T.atan2_(T.tan_(v_), T.cos_(u_));
         break;
     }
     default:
@@ -340,10 +526,10 @@ void map_forward(const Projector& p, float x, float y, float& u, float& v)
 void map_backward(const Projector& p, float u, float v, float& x, float& y)
 {
     const float* kr = p.k_rinv;
+    const Trig& T = p.tr;
     float x_, y_, z_, z;
-    switch (p.type) {
-    case W_PLANE:
-    case W_AFFINE:
+    switch (p.family) {
+    case F_PLANE:
         u = u / p.scale - p.t[0];
         v = v / p.scale - p.t[1];
         x = kr[0] * u + kr[1] * v + kr[2] * (1 - p.t[2]);
@@ -352,25 +538,101 @@ void map_backward(const Projector& p, float u, float v, float& x, float& y)
         x /= z;
         y /= z;
         return;
-    case W_CYLINDRICAL:
+    case F_CYLINDRICAL:
         u /= p.scale;
         v /= p.scale;
-        x_ = p.tr.sin_(u);
+        x_ = T.sin_(u);
         y_ = v;
-        z_ = p.tr.cos_(u);
+        z_ = T.cos_(u);
         break;
-    case W_SPHERICAL: {
+    case F_SPHERICAL: {
         u /= p.scale;
         v /= p.scale;
-        float sinv = p.tr.sin_(PI_F - v);
-        x_ = sinv * p.tr.sin_(u);
-        y_ = p.tr.cos_(PI_F - v);
-        z_ = sinv * p.tr.cos_(u);
+        float sinv = T.sin_(PI_F - v);
+        x_ = sinv * T.sin_(u);
+        y_ = T.cos_(PI_F - v);
+        z_ = sinv * T.cos_(u);
+        break;
+    }
+    case F_FISHEYE: {  // FisheyeProjector::mapBackward
+        u /= p.scale;
+        v /= p.scale;
+        float u_ = T.atan2_(v, u);
+        float v_ = sqrtf(u * u + v * v);
+        float sinv = T.sin_(PI_F - v_);
+        x_ = sinv * T.sin_(u_);
+        y_ = T.cos_(PI_F - v_);
+        z_ = sinv * T.cos_(u_);
+        break;
+    }
+    case F_STEREOGRAPHIC: {  // StereographicProjector::mapBackward
+        u /= p.scale;
+        v /= p.scale;
+        float u_ = T.atan2_(v, u);
+        float r = sqrtf(u * u + v * v);
+        float v_ = 2 * T.atan_(1.f / r);
+        float sinv = T.sin_(PI_F - v_);
+        x_ = sinv * T.sin_(u_);
+        y_ = T.cos_(PI_F - v_);
+        z_ = sinv * T.cos_(u_);
+        break;
+    }
+    case F_CRECT:
+    case F_CRECT_PORTRAIT: {  // CompressedRectilinear[Portrait]Projector::mapBackward
+        u /= (p.family == F_CRECT ? p.scale : -p.scale);
+        v /= p.scale;
+        float aatg = p.a * T.atan_(u / p.a);
+        float u_ = aatg;
+        float v_ = T.atan_(v * T.cos_(aatg) / p.b);
+        float cosv = T.cos_(v_);
+        x_ = cosv * T.sin_(u_);
+        y_ = T.sin_(v_);
+        z_ = cosv * T.cos_(u_);
+        break;
+    }
+    case F_PANINI:
+    case F_PANINI_PORTRAIT: {  // Panini[Portrait]Projector::mapBackward
+        u /= (p.family == F_PANINI ? p.scale : -p.scale);
+        v /= p.scale;
+        float lamda = p.a * T.atan_(u / p.a);
+        float u_ = lamda;
+        float v_;
+        if (lamda == lamda) v_ = T.atan_(v * T.sin_(lamda) / (p.b * p.a * T.tan_(lamda / p.a)));
+        else v_ = 0.f;
+        float cosv = T.cos_(v_);
+        x_ = cosv * T.sin_(u_);
+        y_ = T.sin_(v_);
+        z_ = cosv * T.cos_(u_);
+        break;
+    }
+    case F_MERCATOR: {  // MercatorProjector::mapBackward
+        u /= p.scale;
+        v /= p.scale;
+        float v_ = T.atan_(T.sinh_(v));
+        float u_ = u;
+        float cosv = T.cos_(v_);
+        x_ = cosv * T.sin_(u_);
+        y_ = T.sin_(v_);
+        z_ = cosv * T.cos_(u_);
+        break;
+    }
+    case F_TRANSVERSE_MERCATOR: {  // TransverseMercatorProjector::mapBackward
+        u /= p.scale;
+        v /= p.scale;
+        float v_ = T.asin_(T.sin_(v) / T.cosh_(u));
+        float u_ = T.atan2_(T.sinh_(u), T.cos_(v));
+        float cosv = T.cos_(v_);
+        x_ = cosv * T.sin_(u_);
+        y_ = T.sin_(v_);
+        z_ = cosv * T.cos_(u_);
         break;
     }
     default:
         x = y = -1;
         return;
+    }
+    if (p.family == F_CRECT_PORTRAIT || p.family == F_PANINI_PORTRAIT) {  // portrait: y_ = cosv sin u_, x_ = sin v_
+        float t = x_; x_ = y_; y_ = t;
     }
     x = kr[0] * x_ + kr[1] * y_ + kr[2] * z_;
     y = kr[3] * x_ + kr[4] * y_ + kr[5] * z_;
@@ -395,7 +657,23 @@ void detect_result_roi(const Projector& p, int w, int h, int* tl, int* br)
 {
     MinMax mm;
     float u, v;
-    if (p.type == W_PLANE || p.type == W_AFFINE) {
+    if (p.family > F_SPHERICAL) {
+        // RotationWarperBase::detectResultRoi: every source pixel (the warpers without an override)
+        // (rows folded per thread: min / max over the non-NaN values does not depend on the order)
+        std::vector<MinMax> rows((size_t)h);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+        for (int y = 0; y < h; ++y) {
+            float uu, vv;
+            for (int x = 0; x < w; ++x) {
+                map_forward(p, (float)x, (float)y, uu, vv);
+                rows[y].add(uu, vv);
+            }
+        }
+        for (int y = 0; y < h; ++y) {
+            mm.tl_u = (std::min)(mm.tl_u, rows[y].tl_u); mm.tl_v = (std::min)(mm.tl_v, rows[y].tl_v);
+            mm.br_u = (std::max)(mm.br_u, rows[y].br_u); mm.br_v = (std::max)(mm.br_v, rows[y].br_v);
+        }
+    } else if (p.type == W_PLANE || p.type == W_AFFINE) {
         map_forward(p, 0, 0, u, v); mm.add(u, v);
         map_forward(p, 0, (float)(h - 1), u, v); mm.add(u, v);
         map_forward(p, (float)(w - 1), 0, u, v); mm.add(u, v);
@@ -893,7 +1171,7 @@ ORC_API int orc_get_max_threads()
 // RotationWarper::warpRoi -> (x, y, w, h)
 ORC_API int orc_warp_roi(int type, float scale, const float* K, const float* R, int w, int h, int trig, int* out_xywh)
 {
-    if (type < 0 || type > W_SPHERICAL) return -1;
+    if (type < 0 || type >= W_COUNT) return -1;
     Projector p;
     make_projector(p, type, scale, K, R, trig);
     int tl[2], br[2];
@@ -907,7 +1185,7 @@ ORC_API int orc_warp_roi(int type, float scale, const float* K, const float* R, 
 ORC_API int orc_build_maps(int type, float scale, const float* K, const float* R, int trig, int tlx, int tly, int dw,
                            int dh, float* xmap, float* ymap)
 {
-    if (type < 0 || type > W_SPHERICAL) return -1;
+    if (type < 0 || type >= W_COUNT) return -1;
     Projector p;
     make_projector(p, type, scale, K, R, trig);
 #pragma omp parallel for num_threads(g_threads) schedule(static)
@@ -955,7 +1233,7 @@ ORC_API int orc_remap_nearest_u8(const uint8_t* src, int sw, int sh, int cn, con
 ORC_API int orc_warp_fused(int type, float scale, const float* K, const float* R, int trig, const uint8_t* src, int sw,
                            int sh, int cn, const int* xywh, uint8_t* dst_img, uint8_t* dst_mask)
 {
-    if (type < 0 || type > W_SPHERICAL) return -1;
+    if (type < 0 || type >= W_COUNT) return -1;
     init_bilinear_tab();
     Projector p;
     make_projector(p, type, scale, K, R, trig);
@@ -1041,3 +1319,21 @@ ORC_API void orc_blender_destroy(void* h) { delete (Blender*)h; }
 ORC_API void orc_sincos_d(double x, double* s, double* c) { sincos_d(x, s, c); }
 ORC_API double orc_atan2_d(double y, double x) { return atan2_d(y, x); }
 ORC_API double orc_acos_d(double w) { return acos_d(w); }
+ORC_API double orc_tan_d(double x) { return tan_d(x); }
+ORC_API double orc_asin_d(double w) { return asin_d(w); }
+ORC_API double orc_atan_d(double x) { return atan_d(x); }
+ORC_API double orc_log_d(double x) { return log_d(x); }
+ORC_API double orc_exp_d(double x) { return exp_d(x); }
+ORC_API double orc_sinh_d(double x) { return sinh_d(x); }
+ORC_API double orc_cosh_d(double x) { return cosh_d(x); }
+// mapForward / mapBackward of one point (tests)
+ORC_API int orc_map_point(int type, float scale, const float* K, const float* R, int trig, int backward, float a, float b,
+                          float* out2)
+{
+    if (type < 0 || type >= W_COUNT) return -1;
+    Projector p;
+    make_projector(p, type, scale, K, R, trig);
+    if (backward) map_backward(p, a, b, out2[0], out2[1]);
+    else map_forward(p, a, b, out2[0], out2[1]);
+    return 0;
+}

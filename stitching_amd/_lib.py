@@ -14,6 +14,11 @@ LIB_PATH = os.path.join(_HERE, "libstitching_amd.so")
 # constants of include/stitching_amd.h
 STX_OK = 0
 WARP_PLANE, WARP_AFFINE, WARP_CYLINDRICAL, WARP_SPHERICAL = 0, 1, 2, 3
+# cv.PyRotationWarper(name, scale): name -> STX_WARP_* id
+WARP_TYPE_IDS = {"plane": 0, "affine": 1, "cylindrical": 2, "spherical": 3, "fisheye": 4, "stereographic": 5,
+                 "compressedPlaneA2B1": 6, "compressedPlaneA1.5B1": 7, "compressedPlanePortraitA2B1": 8,
+                 "compressedPlanePortraitA1.5B1": 9, "paniniA2B1": 10, "paniniA1.5B1": 11, "paniniPortraitA2B1": 12,
+                 "paniniPortraitA1.5B1": 13, "mercator": 14, "transverseMercator": 15}
 INTER_NEAREST, INTER_LINEAR = 0, 1
 BORDER_CONSTANT, BORDER_REFLECT = 0, 2
 BLEND_NO, BLEND_FEATHER, BLEND_MULTIBAND = 0, 1, 2

@@ -623,13 +623,22 @@ static void mul3x3_f32(const float* a, const float* b, float* d)
 
 int stx_make_projector(int type, float scale, const float* K, const float* R, StxProjector* p)
 {
-    if (type < STX_WARP_PLANE || type > STX_WARP_SPHERICAL)
+    if (type < STX_WARP_PLANE || type >= STX_WARP_TYPE_COUNT)
         return stx_fail(STX_ERR_UNSUPPORTED, "warper type id %d is not implemented by this back end", type);
     if (!K || !R) return stx_fail(STX_ERR_INVALID, "K and R must be 3x3 fp32");
     for (int i = 0; i < 9; i++)
         if (!std::isfinite(K[i]) || !std::isfinite(R[i])) return stx_fail(STX_ERR_INVALID, "K/R contain non-finite values");
     p->type = type;
     p->scale = scale;
+    // PyRotationWarper's constructor: "compressedPlaneA2B1" -> CompressedRectilinearWarper(2.0f, 1.0f), "...A1.5B1" -> (1.5f, 1.0f), ...
+    static const struct { int family; float a; } kTypes[STX_WARP_TYPE_COUNT] = {
+        {STX_F_PLANE, 1.f}, {STX_F_PLANE, 1.f}, {STX_F_CYLINDRICAL, 1.f}, {STX_F_SPHERICAL, 1.f}, {STX_F_FISHEYE, 1.f},
+        {STX_F_STEREOGRAPHIC, 1.f}, {STX_F_CRECT, 2.0f}, {STX_F_CRECT, 1.5f}, {STX_F_CRECT_PORTRAIT, 2.0f},
+        {STX_F_CRECT_PORTRAIT, 1.5f}, {STX_F_PANINI, 2.0f}, {STX_F_PANINI, 1.5f}, {STX_F_PANINI_PORTRAIT, 2.0f},
+        {STX_F_PANINI_PORTRAIT, 1.5f}, {STX_F_MERCATOR, 1.f}, {STX_F_TRANSVERSE_MERCATOR, 1.f}};
+    p->family = kTypes[type].family;
+    p->a = kTypes[type].a;
+    p->b = 1.0f;
     float Rm[9], T[3] = {0.f, 0.f, 0.f};
     if (type == STX_WARP_AFFINE) {
         // R' = (H with H[0,2] = H[1,2] = 0)^T ; T' = -(R' * (H[0,2], H[1,2], 0)); scale is ignored (1.0)

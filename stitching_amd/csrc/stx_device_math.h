@@ -1,6 +1,6 @@
 // stx_device_math.h — device-side scalar helpers for the gfx950 kernels.
 //
-// Exact-trig contract: sin/cos/atan2/acos are evaluated in fp64 with a fixed
+// Exact-trig contract: sin/cos/atan2/acos (and tan/asin/atan/log/sinh/cosh) are evaluated in fp64 with a fixed
 // sequence of IEEE fma/mul/add/div/sqrt operations (fdlibm minimax coefficients), then rounded
 // once to fp32.  The same sequence on any IEEE machine gives the same bits, so the oracle's
 // trig=exact mode and these routines agree bit-for-bit; versus libm sinf/cosf/atan2f/acosf
@@ -118,6 +118,114 @@ STX_DEV double acos_d(double w)
     return atan2_d(__dsqrt_rn(t), w);
 }
 
+// --- the projectors beyond plane / cylindrical / spherical also need tan, asin, atan, log, sinh, cosh (same
+// contract: a fixed sequence of IEEE fp64 operations, one rounding to fp32)
+STX_DEV double tan_d(double x)
+{
+    double s, c;
+    sincos_d(x, &s, &c);
+    return __ddiv_rn(s, c);
+}
+
+STX_DEV double asin_d(double w)
+{
+    double t = __dmul_rn(__dsub_rn(1.0, w), __dadd_rn(1.0, w));
+    return atan2_d(w, __dsqrt_rn(t));
+}
+
+STX_DEV double pow2_d(int k) { return __longlong_as_double((long long)(k + 1023) << 52); }
+
+// fdlibm e_log.c: x = 2^k (1 + f), log(1 + f) = f - f^2/2 + s (f^2/2 + R(s^2)), s = f / (2 + f)
+STX_DEV double log_d(double x)
+{
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    if (x != x) return x;
+    if (x < 0.0) return __longlong_as_double(0x7ff8000000000000ll);
+    if (x == 0.0) return __longlong_as_double(0xfff0000000000000ll);
+    if (x == __longlong_as_double(0x7ff0000000000000ll)) return x;
+    int k = 0;
+    if (x < 2.2250738585072014e-308) {
+        x = __dmul_rn(x, 18014398509481984.0);
+        k = -54;
+    }
+    unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    int hx = (int)(bits >> 32);
+    k += (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    const int i = (hx + 0x95f64) & 0x100000;
+    bits = ((unsigned long long)(unsigned)(hx | (i ^ 0x3ff00000)) << 32) | (bits & 0xffffffffull);
+    k += i >> 20;
+    const double f = __dsub_rn(__longlong_as_double((long long)bits), 1.0);
+    const double dk = (double)k;
+    const double s = __ddiv_rn(f, __dadd_rn(2.0, f));
+    const double z = __dmul_rn(s, s), w = __dmul_rn(z, z);
+    const double t1 = __dmul_rn(w, __dadd_rn(Lg2, __dmul_rn(w, __dadd_rn(Lg4, __dmul_rn(w, Lg6)))));
+    const double t2 = __dmul_rn(z, __dadd_rn(Lg1, __dmul_rn(w, __dadd_rn(Lg3, __dmul_rn(w, __dadd_rn(Lg5, __dmul_rn(w, Lg7)))))));
+    const double R = __dadd_rn(t2, t1);
+    const double hfsq = __dmul_rn(__dmul_rn(0.5, f), f);
+    return __dsub_rn(__dmul_rn(dk, LN2_HI),
+                     __dsub_rn(__dsub_rn(hfsq, __dadd_rn(__dmul_rn(s, __dadd_rn(hfsq, R)), __dmul_rn(dk, LN2_LO))), f));
+}
+
+// fdlibm e_exp.c: x = k ln2 + r, exp(r) = 1 + r + r c / (2 - c)
+STX_DEV double exp_d(double x)
+{
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10,
+                 INV_LN2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x > 7.09782712893383973096e+02) return __longlong_as_double(0x7ff0000000000000ll);
+    if (x < -7.45133219101941108420e+02) return 0.0;
+    double hi = x, lo = 0.0;
+    int k = 0;
+    if (fabs(x) > 0.34657359027997264) {
+        k = (int)__dadd_rn(__dmul_rn(INV_LN2, x), x < 0.0 ? -0.5 : 0.5);
+        const double t = (double)k;
+        hi = __dsub_rn(x, __dmul_rn(t, LN2_HI));
+        lo = __dmul_rn(t, LN2_LO);
+    }
+    const double r = __dsub_rn(hi, lo);
+    const double t = __dmul_rn(r, r);
+    const double c = __dsub_rn(r, __dmul_rn(t, __dadd_rn(P1, __dmul_rn(t, __dadd_rn(P2, __dmul_rn(t, __dadd_rn(P3, __dmul_rn(t, __dadd_rn(P4, __dmul_rn(t, P5))))))))));
+    const double y = __dsub_rn(1.0, __dsub_rn(__dsub_rn(lo, __ddiv_rn(__dmul_rn(r, c), __dsub_rn(2.0, c))), hi));
+    const int k1 = k / 2, k2 = k - k1;
+    return __dmul_rn(__dmul_rn(y, pow2_d(k1)), pow2_d(k2));
+}
+
+STX_DEV double sinh_d(double x)
+{
+    if (x != x) return x;
+    const double a = fabs(x);
+    double r;
+    if (a < 0.03125) {
+        const double z = __dmul_rn(a, a);
+        const double p = __dmul_rn(z, __dadd_rn(1.66666666666666657415e-01, __dmul_rn(z, __dadd_rn(8.33333333333333321769e-03,
+                         __dmul_rn(z, __dadd_rn(1.98412698412698412526e-04, __dmul_rn(z, 2.75573192239858925110e-06)))))));
+        r = __dadd_rn(a, __dmul_rn(a, p));
+    } else {
+        const double e = exp_d(a);
+        r = __dmul_rn(0.5, __dsub_rn(e, __ddiv_rn(1.0, e)));
+    }
+    return x < 0.0 ? -r : r;
+}
+
+STX_DEV double cosh_d(double x)
+{
+    if (x != x) return x;
+    const double e = exp_d(fabs(x));
+    return __dmul_rn(0.5, __dadd_rn(e, __ddiv_rn(1.0, e)));
+}
+
+STX_DEV float tanf_x(float x) { return (float)tan_d((double)x); }
+STX_DEV float asinf_x(float w) { return (float)asin_d((double)w); }
+STX_DEV float atanf_x(float x) { return (float)atan_d((double)x); }
+STX_DEV float logf_x(float x) { return (float)log_d((double)x); }
+STX_DEV float sinhf_x(float x) { return (float)sinh_d((double)x); }
+STX_DEV float coshf_x(float x) { return (float)cosh_d((double)x); }
 STX_DEV float sinf_x(float x) { double s, c; sincos_d((double)x, &s, &c); return (float)s; }
 STX_DEV float cosf_x(float x) { double s, c; sincos_d((double)x, &s, &c); return (float)c; }
 STX_DEV void sincosf_x(float x, float* s, float* c) { double sd, cd; sincos_d((double)x, &sd, &cd); *s = (float)sd; *c = (float)cd; }
@@ -129,6 +237,9 @@ STX_DEV float fmul(float a, float b) { return __fmul_rn(a, b); }
 STX_DEV float fadd(float a, float b) { return __fadd_rn(a, b); }
 STX_DEV float fsub(float a, float b) { return __fsub_rn(a, b); }
 STX_DEV float fdiv(float a, float b) { return __fdiv_rn(a, b); }
+// correctly rounded fp32 square root (sqrtss): sqrtf gets the compiler's fix-up sequence, __fsqrt_rn is the bare
+// v_sqrt_f32 (1 ulp) on this target
+STX_DEV float fsqrt(float a) { return sqrtf(a); }
 // a0*b0 + a1*b1 + a2*b2, left to right
 STX_DEV float dot3(float a0, float b0, float a1, float b1, float a2, float b2)
 {

@@ -112,8 +112,13 @@ void stx_buf_release(stx_buf* b);
 // ---------------------------------------------------------------------------------------------
 // projector (host side of ProjectorBase::setCameraParams)
 // ---------------------------------------------------------------------------------------------
+// projector families behind the 16 warper ids (id -> family, a, b: stx_make_projector)
+enum { STX_F_PLANE = 0, STX_F_CYLINDRICAL, STX_F_SPHERICAL, STX_F_FISHEYE, STX_F_STEREOGRAPHIC, STX_F_CRECT,
+       STX_F_CRECT_PORTRAIT, STX_F_PANINI, STX_F_PANINI_PORTRAIT, STX_F_MERCATOR, STX_F_TRANSVERSE_MERCATOR };
 struct StxProjector {
     int type;
+    int family;
+    float a, b;
     float scale;
     float k[9], rinv[9], r_kinv[9], k_rinv[9], t[3];
 };

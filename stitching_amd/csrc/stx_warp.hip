@@ -32,6 +32,8 @@ struct WarpK {
     float kr[9];
     float t[3];
     float scale;
+    int family;    // STX_F_* (the general kernel switches on it; the typed kernels are instantiated per family)
+    float pa, pb;  // compressed-rectilinear / panini parameters
     int tlx, tly, dw, dh, sw, sh;
     long long sstride;
     const uint8_t* src;   // u8x3 source of the bilinear image (IMG)
@@ -484,13 +486,149 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
 }
 
 // ---------------------------------------------------------------------------------------------
+// The twelve projectors without a separable backward map (fisheye, stereographic, compressed rectilinear,
+// panini, mercator, transverse mercator): per-pixel mapBackward with the exact-trig routines, then the same
+// fixed-point sampling as warp_kernel.  Formulas: OpenCV warpers_inl.hpp [OCV-MEM], every fp32 step rounded separately.
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ void backward_dir(int family, float a, float b, float scale, float u, float v, float* out3)
+{
+    float x_, y_, z_;
+    const bool portrait = family == STX_F_CRECT_PORTRAIT || family == STX_F_PANINI_PORTRAIT;
+    u = fdiv(u, portrait ? -scale : scale);
+    v = fdiv(v, scale);
+    if (family == STX_F_FISHEYE || family == STX_F_STEREOGRAPHIC) {
+        const float u_ = atan2f_x(v, u);
+        const float r = fsqrt(fadd(fmul(u, u), fmul(v, v)));
+        const float v_ = family == STX_F_FISHEYE ? r : fmul(2.f, atanf_x(fdiv(1.f, r)));
+        float sinv, cosv, su, cu;
+        sincosf_x(fsub(PI_F, v_), &sinv, &cosv);
+        sincosf_x(u_, &su, &cu);
+        x_ = fmul(sinv, su);
+        y_ = cosv;
+        z_ = fmul(sinv, cu);
+    } else {
+        float u_, v_;
+        if (family == STX_F_CRECT || family == STX_F_CRECT_PORTRAIT) {
+            u_ = fmul(a, atanf_x(fdiv(u, a)));
+            v_ = atanf_x(fdiv(fmul(v, cosf_x(u_)), b));
+        } else if (family == STX_F_PANINI || family == STX_F_PANINI_PORTRAIT) {
+            u_ = fmul(a, atanf_x(fdiv(u, a)));
+            if (u_ == u_) v_ = atanf_x(fdiv(fmul(v, sinf_x(u_)), fmul(fmul(b, a), tanf_x(fdiv(u_, a)))));
+            else v_ = 0.f;
+        } else if (family == STX_F_MERCATOR) {
+            v_ = atanf_x(sinhf_x(v));
+            u_ = u;
+        } else {  // transverse mercator
+            v_ = asinf_x(fdiv(sinf_x(v), coshf_x(u)));
+            u_ = atan2f_x(sinhf_x(u), cosf_x(v));
+        }
+        float sv, cv, su, cu;
+        sincosf_x(v_, &sv, &cv);
+        sincosf_x(u_, &su, &cu);
+        x_ = fmul(cv, su);
+        y_ = sv;
+        z_ = fmul(cv, cu);
+        if (portrait) { const float t = x_; x_ = y_; y_ = t; }
+    }
+    out3[0] = x_; out3[1] = y_; out3[2] = z_;
+}
+
+template <bool IMG, bool MASK>
+__global__ __launch_bounds__(256) void warp_general_kernel(WarpK P)
+{
+    const int lane = threadIdx.x & 63;
+    const int x0 = blockIdx.x * WARP_TW + lane * 4;
+    const int y = blockIdx.y * WARP_TH + (threadIdx.x >> 6);
+    if (x0 >= P.dw || y >= P.dh) return;
+    uint32_t out[3] = {0, 0, 0};
+    uint32_t mout = 0;
+    const float vv = (float)(P.tly + y);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float d[3];
+        backward_dir(P.family, P.pa, P.pb, P.scale, (float)(P.tlx + x0 + j), vv, d);
+        float x = dot3(P.kr[0], d[0], P.kr[1], d[1], P.kr[2], d[2]);
+        float yy = dot3(P.kr[3], d[0], P.kr[4], d[1], P.kr[5], d[2]);
+        const float z = dot3(P.kr[6], d[0], P.kr[7], d[1], P.kr[8], d[2]);
+        if (z > 0) {
+            x = fdiv(x, z);
+            yy = fdiv(yy, z);
+        } else {
+            x = yy = -1.f;
+        }
+        if (IMG) put_px(out, j, sample_generic(P, x, yy));
+        if (MASK) {
+            int nx = sat_s16(cv_round(x)), ny = sat_s16(cv_round(yy));
+            uint32_t m = 0;
+            if ((unsigned)nx < (unsigned)P.sw && (unsigned)ny < (unsigned)P.sh)
+                m = P.msrc ? (uint32_t)P.msrc[(long long)ny * P.msstride + nx] : 255u;
+            mout |= m << (8 * j);
+        }
+    }
+    if (IMG) {
+        uint32_t* d = reinterpret_cast<uint32_t*>(P.dimg + (long long)y * P.dimg_stride + (long long)x0 * 3);
+        d[0] = out[0];
+        d[1] = out[1];
+        d[2] = out[2];
+    }
+    if (MASK) *reinterpret_cast<uint32_t*>(P.dmask + (long long)y * P.dmask_stride + x0) = mout;
+}
+
+// ---------------------------------------------------------------------------------------------
 // ROI: forward-project the source border, NaN-ignoring float min/max
 // ---------------------------------------------------------------------------------------------
 struct RoiK {
     float rk[9];
     float scale;
     int type, w, h;
+    int family;    // STX_F_*
+    float pa, pb;
+    int full;      // 1: every source pixel (RotationWarperBase::detectResultRoi), 0: the border (detectResultRoiByBorder)
 };
+
+// mapForward of the projectors without a detectResultRoi override; direction already multiplied by r_kinv
+__device__ __noinline__ void forward_general(int family, float a, float b, float scale, float x_, float y_, float z_, float* out2)
+{
+    const bool portrait = family == STX_F_CRECT_PORTRAIT || family == STX_F_PANINI_PORTRAIT;
+    if (portrait) { const float t = x_; x_ = y_; y_ = t; }
+    const float u_ = atan2f_x(x_, z_);
+    const float w = fdiv(y_, fsqrt(fadd(fadd(fmul(x_, x_), fmul(y_, y_)), fmul(z_, z_))));
+    float u, v;
+    if (family == STX_F_FISHEYE || family == STX_F_STEREOGRAPHIC) {
+        const float v_ = fsub(PI_F, acosf_x(w));
+        float su, cu;
+        sincosf_x(u_, &su, &cu);
+        float r = v_;
+        if (family == STX_F_STEREOGRAPHIC) {
+            float sv, cv;
+            sincosf_x(v_, &sv, &cv);
+            r = fdiv(sv, fsub(1.f, cv));
+        }
+        u = fmul(fmul(scale, r), cu);
+        v = fmul(fmul(scale, r), su);
+    } else {
+        const float v_ = asinf_x(w);
+        const float s = portrait ? -scale : scale;
+        if (family == STX_F_CRECT || family == STX_F_CRECT_PORTRAIT) {
+            u = fmul(fmul(s, a), tanf_x(fdiv(u_, a)));
+            v = fdiv(fmul(fmul(scale, b), tanf_x(v_)), cosf_x(u_));
+        } else if (family == STX_F_PANINI || family == STX_F_PANINI_PORTRAIT) {
+            const float tg = fmul(a, tanf_x(fdiv(u_, a)));
+            u = fmul(s, tg);
+            const float sinu = sinf_x(u_);
+            if ((double)fabsf(sinu) < 1E-7) v = fmul(fmul(scale, b), tanf_x(v_));
+            else v = fdiv(fmul(fmul(fmul(scale, b), tg), tanf_x(v_)), sinu);
+        } else if (family == STX_F_MERCATOR) {
+            u = fmul(scale, u_);
+            v = fmul(scale, logf_x(tanf_x(fadd((float)(3.14159265358979323846 / 4), fdiv(v_, 2.f)))));
+        } else {  // transverse mercator
+            const float B = fmul(cosf_x(v_), sinf_x(u_));
+            u = fmul(fdiv(scale, 2.f), logf_x(fdiv(fadd(1.f, B), fsub(1.f, B))));
+            v = fmul(scale, atan2f_x(tanf_x(v_), cosf_x(u_)));
+        }
+    }
+    out2[0] = u; out2[1] = v;
+}
 
 STX_DEV uint32_t f2ord(float f)
 {
@@ -501,14 +639,16 @@ STX_DEV uint32_t f2ord(float f)
 constexpr int ROI_BATCH = 16;
 struct RoiBatchK { RoiK k[ROI_BATCH]; };
 
+template <bool GEN>  // GEN: the per-pixel projector families (every source pixel), else cylindrical / spherical borders
 __global__ __launch_bounds__(256) void roi_kernel(RoiBatchK B, float* __restrict__ out)
 {
     const RoiK& P = B.k[blockIdx.y];
-    const int npts = 2 * P.w + 2 * P.h;
+    const int npts = GEN ? P.w * P.h : 2 * P.w + 2 * P.h;
     float mnu = 3.402823466e+38f, mnv = 3.402823466e+38f, mxu = -3.402823466e+38f, mxv = -3.402823466e+38f;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npts; p += gridDim.x * blockDim.x) {
         float x, y;
-        if (p < P.w) { x = (float)p; y = 0.f; }
+        if (GEN) { const int py = p / P.w; x = (float)(p - py * P.w); y = (float)py; }
+        else if (p < P.w) { x = (float)p; y = 0.f; }
         else if (p < 2 * P.w) { x = (float)(p - P.w); y = (float)(P.h - 1); }
         else if (p < 2 * P.w + P.h) { x = 0.f; y = (float)(p - 2 * P.w); }
         else { x = (float)(P.w - 1); y = (float)(p - 2 * P.w - P.h); }
@@ -516,13 +656,19 @@ __global__ __launch_bounds__(256) void roi_kernel(RoiBatchK B, float* __restrict
         float x_ = fadd(fadd(fmul(P.rk[0], x), fmul(P.rk[1], y)), P.rk[2]);
         float y_ = fadd(fadd(fmul(P.rk[3], x), fmul(P.rk[4], y)), P.rk[5]);
         float z_ = fadd(fadd(fmul(P.rk[6], x), fmul(P.rk[7], y)), P.rk[8]);
-        float u = fmul(P.scale, atan2f_x(x_, z_)), v;
-        if (P.type == STX_WARP_SPHERICAL) {
-            float n = __fsqrt_rn(fadd(fadd(fmul(x_, x_), fmul(y_, y_)), fmul(z_, z_)));
+        float u, v;
+        if (GEN) {
+            float o[2];
+            forward_general(P.family, P.pa, P.pb, P.scale, x_, y_, z_, o);
+            u = o[0]; v = o[1];
+        } else if (P.type == STX_WARP_SPHERICAL) {
+            u = fmul(P.scale, atan2f_x(x_, z_));
+            float n = fsqrt(fadd(fadd(fmul(x_, x_), fmul(y_, y_)), fmul(z_, z_)));
             float w = fdiv(y_, n);
             v = fmul(P.scale, fsub(PI_F, acosf_x(w == w ? w : 0.f)));
         } else {  // cylindrical
-            v = fdiv(fmul(P.scale, y_), __fsqrt_rn(fadd(fmul(x_, x_), fmul(z_, z_))));
+            u = fmul(P.scale, atan2f_x(x_, z_));
+            v = fdiv(fmul(P.scale, y_), fsqrt(fadd(fmul(x_, x_), fmul(z_, z_))));
         }
         if (u < mnu) mnu = u;
         if (v < mnv) mnv = v;
@@ -633,6 +779,22 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
     return STX_OK;
 }
 
+// per-pixel projector warpers: one launch per image
+int launch_general(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, const char* prof_name, const double* algo_bytes)
+{
+    for (int i = 0; i < n; i++) {
+        StxProfScope prof(ctx, prof_name, algo_bytes[i]);
+        const WarpK& K = Ks[i];
+        const dim3 grid((K.dw + WARP_TW - 1) / WARP_TW, (K.dh + WARP_TH - 1) / WARP_TH);
+        if (img && mask) hipLaunchKernelGGL((warp_general_kernel<true, true>), grid, dim3(256), 0, ctx->stream, K);
+        else if (img) hipLaunchKernelGGL((warp_general_kernel<true, false>), grid, dim3(256), 0, ctx->stream, K);
+        else hipLaunchKernelGGL((warp_general_kernel<false, true>), grid, dim3(256), 0, ctx->stream, K);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return stx_fail(STX_ERR_HIP, "warp kernel launch failed: %s", hipGetErrorString(e));
+    return STX_OK;
+}
+
 void fill_warpk(const StxWarpLaunch& L, WarpK* Kp, double* bytes)
 {
     WarpK& K = *Kp;
@@ -640,6 +802,7 @@ void fill_warpk(const StxWarpLaunch& L, WarpK* Kp, double* bytes)
     for (int i = 0; i < 9; i++) K.kr[i] = L.proj.k_rinv[i];
     for (int i = 0; i < 3; i++) K.t[i] = L.proj.t[i];
     K.scale = L.proj.scale;
+    K.family = L.proj.family; K.pa = L.proj.a; K.pb = L.proj.b;
     K.tlx = L.tlx; K.tly = L.tly; K.dw = L.dw; K.dh = L.dh;
     K.sw = L.sw; K.sh = L.sh;
     const bool img = L.dimg != nullptr, mask = L.dmask != nullptr;
@@ -670,13 +833,12 @@ int stx_launch_warp_batch(stx_ctx* ctx, const StxWarpLaunch* Ls, int n)
     for (int i = 0; i < n; i++) fill_warpk(Ls[i], &Ks[i], &bytes[i]);
     const bool img = Ls[0].dimg != nullptr, mask = Ls[0].dmask != nullptr;
     const char* name = img ? (mask ? "warp_img_mask" : "warp_img") : "warp_mask";
-    switch (Ls[0].proj.type) {
-    case STX_WARP_PLANE:
-    case STX_WARP_AFFINE: return launch_typed<STX_WARP_PLANE>(ctx, Ks.data(), n, img, mask, name, bytes.data());
-    case STX_WARP_CYLINDRICAL: return launch_typed<STX_WARP_CYLINDRICAL>(ctx, Ks.data(), n, img, mask, name, bytes.data());
-    case STX_WARP_SPHERICAL: return launch_typed<STX_WARP_SPHERICAL>(ctx, Ks.data(), n, img, mask, name, bytes.data());
+    switch (Ls[0].proj.family) {
+    case STX_F_PLANE: return launch_typed<STX_WARP_PLANE>(ctx, Ks.data(), n, img, mask, name, bytes.data());
+    case STX_F_CYLINDRICAL: return launch_typed<STX_WARP_CYLINDRICAL>(ctx, Ks.data(), n, img, mask, name, bytes.data());
+    case STX_F_SPHERICAL: return launch_typed<STX_WARP_SPHERICAL>(ctx, Ks.data(), n, img, mask, name, bytes.data());
+    default: return launch_general(ctx, Ks.data(), n, img, mask, name, bytes.data());
     }
-    return stx_fail(STX_ERR_UNSUPPORTED, "warp type %d not implemented", Ls[0].proj.type);
 }
 
 int stx_launch_warp(stx_ctx* ctx, const StxWarpLaunch& L) { return stx_launch_warp_batch(ctx, &L, 1); }
@@ -687,7 +849,9 @@ int stx_launch_roi_minmax(stx_ctx* ctx, int n, const StxProjector* projs, const 
     // Argument blocks travel as kernel arguments, per-block partial results come back through the context's
     // pinned scratch: no pageable copies, no atomics.  The pass runs on the context's side stream with its own
     // device scratch and only that stream is waited for, so work already queued on the main stream keeps going.
-    constexpr int BX = 32;  // blocks per image
+    // blocks per image: 32 for the border walk, 256 when every source pixel is projected (one family per call)
+    const bool full = n > 0 && projs[0].family > STX_F_SPHERICAL;
+    const int BX = full ? 256 : 32;
     const int cap = (int)(ctx->pinned_bytes / (16 * BX));
     for (int start = 0; start < n; start += cap) {
         const int cnt = std::min(cap, n - start);
@@ -704,8 +868,12 @@ int stx_launch_roi_minmax(stx_ctx* ctx, int n, const StxProjector* projs, const 
                 k.type = projs[g].type;
                 k.w = sizes_wh[2 * g];
                 k.h = sizes_wh[2 * g + 1];
+                k.family = projs[g].family; k.pa = projs[g].a; k.pb = projs[g].b;
+                k.full = full ? 1 : 0;
+                if (full && (long long)k.w * k.h > 0x7fffffffll) return stx_fail(STX_ERR_UNSUPPORTED, "image of %dx%d pixels", k.w, k.h);
             }
-            hipLaunchKernelGGL(roi_kernel, dim3(BX, m), dim3(256), 0, ctx->aux_stream, B, dout + 4 * (size_t)BX * base);
+            if (full) hipLaunchKernelGGL(roi_kernel<true>, dim3(BX, m), dim3(256), 0, ctx->aux_stream, B, dout + 4 * (size_t)BX * base);
+            else hipLaunchKernelGGL(roi_kernel<false>, dim3(BX, m), dim3(256), 0, ctx->aux_stream, B, dout + 4 * (size_t)BX * base);
         }
         const float* res = (const float*)ctx->pinned;
         STX_HIP(hipMemcpyAsync(ctx->pinned, dout, 16 * (size_t)BX * cnt, hipMemcpyDeviceToHost, ctx->aux_stream));

@@ -15,8 +15,7 @@ from . import _lib, config
 from .device import DeviceImage, as_device, get_context
 from .stitching_error import StitchingError
 
-_TYPE_IDS = {"plane": _lib.WARP_PLANE, "affine": _lib.WARP_AFFINE, "cylindrical": _lib.WARP_CYLINDRICAL,
-             "spherical": _lib.WARP_SPHERICAL}
+_TYPE_IDS = _lib.WARP_TYPE_IDS
 
 
 def _mat33(m, what):
@@ -52,7 +51,8 @@ class Warper:
         "mercator",
         "transverseMercator",
     )
-    # implemented by the HIP back end (BASELINE.json configs use spherical, cylindrical, affine)
+    # all sixteen run on the device; spherical / cylindrical / plane / affine (the BASELINE.json configurations)
+    # through the table-driven fast kernels, the other twelve through the per-pixel projector kernel
     SUPPORTED_WARP_TYPES = tuple(_TYPE_IDS)
 
     DEFAULT_WARP_TYPE = "spherical"

@@ -56,11 +56,11 @@ def test_matrix_validation_mirrors_cv_assert():
     assert _mat33(np.eye(3, dtype=np.float32), "R").flags["C_CONTIGUOUS"]
 
 
-def test_unsupported_and_unknown_types_raise():
-    w = S.Warper("fisheye")
-    w.scale = 1.0
-    with pytest.raises(S.StitchingError, match="not implemented"):
-        w._type_id()
+def test_all_reference_warper_names_have_an_id_and_unknown_types_raise():
+    # every name cv.PyRotationWarper accepts (stitching/warper.py:10-27) maps to a distinct STX_WARP_* id
+    ids = [S.Warper(name)._type_id() for name in S.Warper.WARP_TYPE_CHOICES]
+    assert sorted(ids) == list(range(16))
+    assert S.Warper.SUPPORTED_WARP_TYPES and set(S.Warper.SUPPORTED_WARP_TYPES) == set(S.Warper.WARP_TYPE_CHOICES)
     with pytest.raises(S.StitchingError, match="unknown"):
         S.Warper("bogus")._type_id()
     with pytest.raises(S.StitchingError):

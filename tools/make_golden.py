@@ -47,6 +47,19 @@ CASES = {
     # aspect != 1 (the reference's low/final resolution ratio, stitching/warper.py:44,86-94)
     "spherical_aspect": dict(n=3, w=320, h=240, span=100.0, warper="spherical", blender="multiband", strength=8,
                              aspect=0.37),
+    # per-pixel projector warpers: the two of the reference's boat tests (tests/test_stitcher.py:85,110) + one of each
+    # remaining family
+    "fisheye_mb": dict(n=3, w=300, h=220, span=90.0, warper="fisheye", blender="multiband", strength=8),
+    "compressed_plane_a2b1_mb": dict(n=3, w=300, h=220, span=90.0, warper="compressedPlaneA2B1", blender="multiband",
+                                     strength=8),
+    "stereographic_no": dict(n=3, w=240, h=180, span=80.0, warper="stereographic", blender="no", strength=5),
+    "compressed_portrait_a15b1_no": dict(n=3, w=240, h=180, span=80.0, warper="compressedPlanePortraitA1.5B1", blender="no",
+                                         strength=5),
+    "panini_a2b1_feather": dict(n=3, w=240, h=180, span=80.0, warper="paniniA2B1", blender="feather", strength=5),
+    "panini_portrait_a15b1_no": dict(n=3, w=240, h=180, span=80.0, warper="paniniPortraitA1.5B1", blender="no", strength=5),
+    "mercator_mb": dict(n=3, w=240, h=180, span=80.0, warper="mercator", blender="multiband", strength=8),
+    "transverse_mercator_mb": dict(n=3, w=240, h=180, span=80.0, warper="transverseMercator", blender="multiband",
+                                   strength=8),
 }
 SMALL = "plane_mb3"
 
