@@ -45,9 +45,8 @@ struct WarpK {
     long long dmask_stride;
     // interior test of the fast kernel, in 1/32-px units: cvRound(v) >> 5 in [0, n-2]  <=>  -0.5 <= v < 32(n-1) - 0.5
     int band_rows;      // fast kernel: tile rows per XCD band
-    int tiles_x, tiles_y, band_tiles, plain_order;
+    int tiles_x, tiles_y, band_tiles;
     uint32_t magic_tx, magic_band;  // floor(2^32 / d) + 1 for d = tiles_x, band_tiles
-    int rows_per_wave;  // fast kernel: destination rows handled by one wavefront (rows y, y + 4, y + 8, ...)
     float bx_hi, by_hi;
     // nearest-neighbour inside test: cvRound(v) in [0, n-1]  <=>  -0.5 <= v < m_hi (ties go to even)
     float mx_hi, my_hi;
@@ -351,34 +350,36 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
     const float2* __restrict__ colT = B.colT[blockIdx.z];
     const float2* __restrict__ rowT = B.rowT[blockIdx.z];
     const int lane = threadIdx.x & 63;
+    // The per-image scalars of the tile-index math and of the tests below are fetched up front, as a few wide scalar
+    // loads with one wait: a wavefront lives for 256 pixels only, and the compiler otherwise sinks every one of these
+    // kernel-argument loads to its first use (about fifteen dependent scalar-cache round trips per wavefront).
+    int tiles_x = P.tiles_x, tiles_y = P.tiles_y, band_tiles = P.band_tiles, band_rows = P.band_rows;
+    uint32_t magic_tx = P.magic_tx, magic_band = P.magic_band;
+    int dw = P.dw, dh = P.dh;
+    float bx_hi = P.bx_hi, by_hi = P.by_hi, mx_hi = P.mx_hi, my_hi = P.my_hi;
+    unsigned long long src_a = (unsigned long long)P.src, dimg_a = (unsigned long long)P.dimg, dmask_a = (unsigned long long)P.dmask;
+    long long dimg_stride = P.dimg_stride, dmask_stride = P.dmask_stride;
+    uint32_t sstride = (uint32_t)P.sstride;
+    asm volatile("" : "+s"(tiles_x), "+s"(tiles_y), "+s"(band_tiles), "+s"(band_rows), "+s"(magic_tx), "+s"(magic_band), "+s"(dw),
+                 "+s"(dh), "+s"(bx_hi), "+s"(by_hi), "+s"(mx_hi), "+s"(my_hi));
+    asm volatile("" : "+s"(src_a), "+s"(dimg_a), "+s"(dmask_a), "+s"(dimg_stride), "+s"(dmask_stride), "+s"(sstride));
     // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only), and the
     // per-XCD L2s do not share lines.  Bands of WARP_BAND tile rows go round-robin to the XCDs: vertically adjacent
     // tiles — which read the same source rows — mostly meet in one L2 instead of fetching those rows once per
-    // XCD (measured for 8 frames of 36 MB: 605 MB fetched with the plain order, 288 MB with whole-image eighths —
-    // but then the curved-border bands unbalance the XCDs — and 360 MB with bands of 4 tile rows).
+    // XCD (measured for 8 frames of 36 MB: 605 MB fetched with the plain row-major order, 288 MB with whole-image
+    // eighths — but then the curved-border bands unbalance the XCDs — and 360 MB with bands of 4 tile rows; the
+    // kernel time is the same for all three).
     // divisions by the per-image constants use host-made reciprocals (n * m >> 32, exact for n * d < 2^32)
-    if (P.plain_order) {  // row-major: the hardware's round-robin of consecutive tiles over the XCDs
-        const uint32_t wy0 = P.tiles_x == 1 ? blockIdx.x : __umulhi(blockIdx.x, P.magic_tx);
-        if ((int)wy0 >= P.tiles_y) return;
-    }
     const uint32_t local = blockIdx.x >> 3;
-    const uint32_t band_i = P.band_tiles == 1 ? local : __umulhi(local, P.magic_band);  // local / (band_rows * tiles_x)
-    const uint32_t within = local - band_i * (uint32_t)P.band_tiles;
-    const uint32_t wy = P.tiles_x == 1 ? within : __umulhi(within, P.magic_tx);  // within / tiles_x (2^32 / 1 has no 32-bit magic)
-    int tile_x = (int)(within - wy * (uint32_t)P.tiles_x);
-    int tile_y = (int)((band_i * 8u + (blockIdx.x & 7u)) * (uint32_t)P.band_rows + wy);
-    const int tiles_y = P.tiles_y;
-    if (P.plain_order) {
-        const uint32_t wy0 = P.tiles_x == 1 ? blockIdx.x : __umulhi(blockIdx.x, P.magic_tx);
-        tile_y = (int)wy0;
-        tile_x = (int)(blockIdx.x - wy0 * (uint32_t)P.tiles_x);
-    }
+    const uint32_t band_i = band_tiles == 1 ? local : __umulhi(local, magic_band);  // local / (band_rows * tiles_x)
+    const uint32_t within = local - band_i * (uint32_t)band_tiles;
+    const uint32_t wy = tiles_x == 1 ? within : __umulhi(within, magic_tx);  // within / tiles_x (2^32 / 1 has no 32-bit magic)
+    const int tile_x = (int)(within - wy * (uint32_t)tiles_x);
+    const int tile_y = (int)((band_i * 8u + (blockIdx.x & 7u)) * (uint32_t)band_rows + wy);
     if (tile_y >= tiles_y) return;
     const int x0 = tile_x * WARP_TW + lane * 4;
-    int y = tile_y * (WARP_TH * P.rows_per_wave) + (threadIdx.x >> 6);
-    if (x0 >= P.dw || y >= P.dh) return;
-    // the column table entries are per-lane constants of the row loop; a wavefront walks rows y, y+4, ...
-    // so that its start-up latency (kernel arguments, table loads) is paid once per rows_per_wave rows
+    const int y = tile_y * WARP_TH + (threadIdx.x >> 6);
+    if (x0 >= dw || y >= dh) return;
     float ca[4], cb[4];
     {
         const float4 c01 = *reinterpret_cast<const float4*>(colT + x0);
@@ -387,10 +388,8 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
         ca[2] = c23.x; cb[2] = c23.y; ca[3] = c23.z; cb[3] = c23.w;
     }
     const float omt = fsub(1.f, P.t[2]);
-    float2 rt_next = rowT[y];
-    for (int it = 0; it < P.rows_per_wave && y < P.dh; it++, y += WARP_TH) {
-    const float2 rt = rt_next;
-    if (y + WARP_TH < P.dh) rt_next = rowT[y + WARP_TH];
+    const float2 rt = rowT[y];
+    {
     float xs[4], ys[4], zs[4];
     // every division of this lane may use the shared-reciprocal sequence: all |z| (z for the rotation warpers,
     // which also need z > 0) in [2^-60, 2^60] and all |x|, |y| <= 2^60.  Evaluated as integer min / max of the
@@ -435,11 +434,11 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
         const float xmn = fminf(fminf(x32[0], x32[1]), fminf(x32[2], x32[3])), xmx = fmaxf(fmaxf(x32[0], x32[1]), fmaxf(x32[2], x32[3]));
         const float ymn = fminf(fminf(y32[0], y32[1]), fminf(y32[2], y32[3])), ymx = fmaxf(fmaxf(y32[0], y32[1]), fmaxf(y32[2], y32[3]));
         const float poison = ((x32[0] + x32[1]) + (x32[2] + x32[3])) + ((y32[0] + y32[1]) + (y32[2] + y32[3]));
-        interior = xmn >= -0.5f && xmx < P.bx_hi && ymn >= -0.5f && ymx < P.by_hi && poison == poison;
+        interior = xmn >= -0.5f && xmx < bx_hi && ymn >= -0.5f && ymx < by_hi && poison == poison;
     }
     if (IMG && interior) {
-        const STX_GAS uint8_t* src = (const STX_GAS uint8_t*)P.src;
-        const uint32_t stride = (uint32_t)P.sstride;
+        const STX_GAS uint8_t* src = (const STX_GAS uint8_t*)src_a;
+        const uint32_t stride = sstride;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int sx = (int)rintf(x32[j]), sy = (int)rintf(y32[j]);  // cvRound; in range by the interior test
@@ -470,19 +469,19 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
         for (int j = 0; j < 4; j++) {
             if (IMG) put_px(out, j, sample_border(P, xs[j], ys[j]));
             if (MASK) {
-                const bool in = xs[j] >= -0.5f && xs[j] < P.mx_hi && ys[j] >= -0.5f && ys[j] < P.my_hi;
+                const bool in = xs[j] >= -0.5f && xs[j] < mx_hi && ys[j] >= -0.5f && ys[j] < my_hi;
                 mout |= (in ? 255u : 0u) << (8 * j);
             }
         }
     }
     if (IMG) {
-        uint32_t* d = reinterpret_cast<uint32_t*>(P.dimg + (long long)y * P.dimg_stride + (long long)x0 * 3);
+        uint32_t* d = reinterpret_cast<uint32_t*>((uint8_t*)dimg_a + (long long)y * dimg_stride + (long long)x0 * 3);
         d[0] = out[0];
         d[1] = out[1];
         d[2] = out[2];
     }
-    if (MASK) *reinterpret_cast<uint32_t*>(P.dmask + (long long)y * P.dmask_stride + x0) = mout;
-    }  // row loop
+    if (MASK) *reinterpret_cast<uint32_t*>((uint8_t*)dmask_a + (long long)y * dmask_stride + x0) = mout;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -727,14 +726,12 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
         for (int i = 0; i < m; i++) {
             const WarpK& K = Ks[base + i];
             B.k[i] = K;
-            B.k[i].rows_per_wave = 1;
             B.k[i].band_rows = WARP_BAND;
-            B.k[i].plain_order = 0;  // A/B on one box: banded and plain order give the same time; banded fetches 40 % less
             B.k[i].tiles_x = (K.dw + WARP_TW - 1) / WARP_TW;
             B.k[i].tiles_y = (K.dh + WARP_TH - 1) / WARP_TH;
             B.k[i].band_tiles = B.k[i].band_rows * B.k[i].tiles_x;
             B.k[i].magic_tx = (uint32_t)((1ull << 32) / (uint32_t)B.k[i].tiles_x) + 1u;
-            B.k[i].magic_band = (uint32_t)((1ull << 32) / (uint32_t)B.k[i].band_tiles) + 1u;  // measured (4000x3000): 1 row per wavefront 45.8 us, 2: 47.2, 4: 51.3, 8: 68.4
+            B.k[i].magic_band = (uint32_t)((1ull << 32) / (uint32_t)B.k[i].band_tiles) + 1u;
             B.colT[i] = cursor;
             cursor += ((size_t)K.dw + 3) & ~(size_t)3;
             B.rowT[i] = cursor;
@@ -756,7 +753,7 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
             for (int i = 0; i < m; i++) {
                 const int tx = (B.k[i].dw + WARP_TW - 1) / WARP_TW, ty = (B.k[i].dh + WARP_TH - 1) / WARP_TH;
                 const int wb = B.k[i].band_rows, bands = (ty + wb - 1) / wb;
-                per_xcd = std::max(per_xcd, B.k[i].plain_order ? (tx * ty + 7) / 8 : ((bands + 7) / 8) * wb * tx);
+                per_xcd = std::max(per_xcd, ((bands + 7) / 8) * wb * tx);
             }
             const dim3 gf(8 * per_xcd, 1, m);  // 1-D tile index per image, see the kernel's XCD-aware order
             if (img && mask) hipLaunchKernelGGL((warp_fast_kernel<TYPE, true, true>), gf, dim3(256), 0, s, B);
@@ -812,7 +809,6 @@ void fill_warpk(const StxWarpLaunch& L, WarpK* Kp, double* bytes)
     K.msstride = (long long)L.sstride;
     K.dimg = L.dimg; K.dimg_stride = (long long)L.dimg_stride;
     K.dmask = L.dmask; K.dmask_stride = (long long)L.dmask_stride;
-    K.rows_per_wave = 1;
     K.bx_hi = (float)(32.0 * (L.sw - 1) - 0.5);
     K.by_hi = (float)(32.0 * (L.sh - 1) - 0.5);
     // cvRound(v) <= n - 1: v <= n - 0.5 when n - 1 is even (the tie rounds down to it), v < n - 0.5 otherwise
