@@ -74,16 +74,20 @@ STX_EXPORT int stx_ctx_create(int device, stx_ctx** out)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return stx_fail(STX_ERR_UNSUPPORTED, "device %d is %s; this library is built for gfx950 (MI355X) only", device,
                         prop.gcnArchName);
-    std::unique_ptr<stx_ctx> ctx(new stx_ctx());
+    stx_ctx* ctx = new stx_ctx();
     ctx->device = device;
-    STX_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     ctx->pinned_bytes = 1 << 16;
-    STX_HIP(hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault));
     ctx->stage_bytes = 1 << 20;
-    STX_HIP(hipHostMalloc((void**)&ctx->stage, ctx->stage_bytes, hipHostMallocDefault));
-    STX_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-    STX_HIP(hipMalloc(&ctx->aux_scratch, ctx->pinned_bytes));
-    *out = ctx.release();
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->stage, ctx->stage_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(&ctx->aux_scratch, ctx->pinned_bytes);
+    if (e != hipSuccess) {
+        stx_ctx_destroy(ctx);  // releases whatever was created
+        return stx_fail(STX_ERR_HIP, "context set-up failed: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
     return STX_OK;
 }
 
@@ -99,7 +103,8 @@ STX_EXPORT int stx_ctx_destroy(stx_ctx* ctx)
 {
     if (!ctx) return STX_OK;
     hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->aux_stream) hipStreamSynchronize(ctx->aux_stream);
     for (auto& kv : ctx->block_size) hipFree(kv.first);
     for (auto& p : ctx->prof_pending) { hipEventDestroy(p.start); hipEventDestroy(p.stop); }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
@@ -108,7 +113,7 @@ STX_EXPORT int stx_ctx_destroy(stx_ctx* ctx)
     if (ctx->stage) hipHostFree(ctx->stage);
     if (ctx->aux_scratch) hipFree(ctx->aux_scratch);
     if (ctx->aux_stream) hipStreamDestroy(ctx->aux_stream);
-    hipStreamDestroy(ctx->stream);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return STX_OK;
 }
