@@ -329,6 +329,35 @@ def main():
             pinned_step()
         e2p = (time.perf_counter() - t1) / args.e2e_steps
         result["pcie_inclusive"]["pinned"] = {"value": round(src_mpix / e2p, 1), "ms_per_step": round(e2p * 1e3, 2)}
+        # ... and as a stream of panoramas alternating between two contexts with queued (asynchronous) uploads and
+        # read-backs: the upload of one panorama overlaps the read-back of the previous one (both PCIe directions busy)
+        if len(ctxs) >= 2:
+            pouts = [dict(), dict()]
+
+            def piped_step(i):
+                c, po = ctxs[i % 2], pouts[i % 2]
+                c.sync()  # this context's previous panorama has landed in its host buffers
+                pano, pmask = StitchJob(pframes, cams, warper_type=args.warper, blender_type=args.blender,
+                                        num_bands=args.bands, ctx=c, async_upload=True).run()
+                for key, d in (("pano", pano), ("mask", pmask)):
+                    if key not in po or po[key].shape != d.shape:
+                        po[key] = pinned_empty(d.shape, d.dtype)
+                    d.numpy(out=po[key], wait=False)
+
+            for i in range(2):
+                piped_step(i)
+            for c in ctxs[:2]:
+                c.sync()
+            n_piped = 2 * max(2, args.e2e_steps)
+            t1 = time.perf_counter()
+            for i in range(n_piped):
+                piped_step(i)
+            for c in ctxs[:2]:
+                c.sync()
+            e2q = (time.perf_counter() - t1) / n_piped
+            same = all(np.array_equal(pouts[k]["pano"], pout["pano"]) for k in range(2))
+            result["pcie_inclusive"]["pinned_pipelined"] = {"value": round(src_mpix / e2q, 1), "ms_per_step": round(e2q * 1e3, 2),
+                                                            "equals_synchronous_result": bool(same)}
     if world == 1 and not args.no_cpu_baseline:
         cb, _ = cpu_baseline(args, frames, cams, all_cams)
         result["cpu_baseline"] = cb

@@ -102,6 +102,12 @@ int stx_buf_alloc(stx_ctx* ctx, int w, int h, int channels, int elem, stx_buf** 
 int stx_host_alloc(size_t bytes, void** out);
 int stx_host_free(void* p);
 int stx_buf_to_host(const stx_buf* buf, void* host, size_t host_stride_bytes);
+/* asynchronous forms for page-locked host memory (stx_host_alloc): the copy is queued on the context's stream and the
+ * call returns; the host memory must stay untouched (upload) / unread (read-back) until stx_ctx_sync(ctx).  With pageable
+ * memory they behave like the synchronous calls.  Two contexts fed alternately keep both PCIe directions busy. */
+int stx_buf_from_host_async(stx_ctx* ctx, const void* host, size_t host_stride_bytes, int w, int h, int channels, int elem,
+                            stx_buf** out);
+int stx_buf_to_host_async(const stx_buf* buf, void* host, size_t host_stride_bytes);
 /* rectangular sub-view sharing the parent's memory (numpy slicing in stitching/cropper.py:150-151) */
 int stx_buf_view(const stx_buf* buf, int x, int y, int w, int h, stx_buf** out);
 /* info = {w, h, channels, elem, stride_bytes, device} */

@@ -27,7 +27,7 @@ CONTRIB_U8_BINARY = 1
 
 EXPORTS = (
     "stx_version stx_last_error stx_device_count stx_ctx_create stx_ctx_destroy stx_ctx_sync "
-    "stx_host_alloc stx_host_free stx_buf_from_host stx_buf_alloc stx_buf_to_host stx_buf_view stx_buf_info stx_buf_device_ptr stx_buf_free "
+    "stx_host_alloc stx_host_free stx_buf_from_host stx_buf_from_host_async stx_buf_alloc stx_buf_to_host stx_buf_to_host_async stx_buf_view stx_buf_info stx_buf_device_ptr stx_buf_free "
     "stx_warp_roi stx_warp_rois stx_warp stx_warp_image_and_mask stx_warp_batch stx_warp_mask "
     "stx_gain_apply stx_block_gain_apply stx_resize_linear_exact stx_seam_mask_resize stx_timelapse_frame stx_result_roi stx_blend_create stx_blend_num_bands stx_blend_feed stx_blend_finish stx_blend_finish_ex "
     "stx_blend_destroy stx_blend_set_band stx_blend_feed_ex stx_blend_contrib_rect stx_blend_export_contrib "
@@ -59,10 +59,12 @@ def lib():
     L.stx_ctx_destroy.argtypes = [vp]
     L.stx_ctx_sync.argtypes = [vp]
     L.stx_buf_from_host.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, vpp]
+    L.stx_buf_from_host_async.argtypes = L.stx_buf_from_host.argtypes
     L.stx_buf_alloc.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vpp]
     L.stx_host_alloc.argtypes = [C.c_size_t, vpp]
     L.stx_host_free.argtypes = [vp]
     L.stx_buf_to_host.argtypes = [vp, vp, C.c_size_t]
+    L.stx_buf_to_host_async.argtypes = [vp, vp, C.c_size_t]
     L.stx_buf_view.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vpp]
     L.stx_buf_info.argtypes = [vp, C.POINTER(C.c_int64)]
     L.stx_buf_device_ptr.argtypes = [vp, vpp]

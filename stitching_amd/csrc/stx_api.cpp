@@ -325,8 +325,20 @@ STX_EXPORT int stx_buf_alloc(stx_ctx* ctx, int w, int h, int channels, int elem,
     return stx_buf_new(ctx, w, h, channels, elem, out);
 }
 
-STX_EXPORT int stx_buf_from_host(stx_ctx* ctx, const void* host, size_t host_stride, int w, int h, int channels,
-                                 int elem, stx_buf** out)
+// true when [p, p + bytes) is page-locked host memory known to the runtime (stx_host_alloc, hipHostMalloc, hipHostRegister)
+static bool is_pinned_host(const void* p)
+{
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof(a));
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // an unregistered pointer is an expected answer, not a sticky error
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+static int buf_from_host(stx_ctx* ctx, const void* host, size_t host_stride, int w, int h, int channels, int elem, bool wait,
+                         stx_buf** out)
 {
     if (!ctx || !host || !out) return stx_fail(STX_ERR_INVALID, "null argument");
     STX_TRY(stx_set_device(ctx));
@@ -335,8 +347,9 @@ STX_EXPORT int stx_buf_from_host(stx_ctx* ctx, const void* host, size_t host_str
     stx_buf* b = nullptr;
     STX_TRY(stx_buf_new(ctx, w, h, channels, elem, &b));
     hipError_t e = hipMemcpy2DAsync(b->ptr, b->stride, host, host_stride, row, h, hipMemcpyHostToDevice, ctx->stream);
-    // the host buffer is only borrowed for this call
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    // the host buffer is only borrowed for this call — unless the caller asked for the asynchronous form and the
+    // memory is page-locked (a pageable source is staged by the runtime; waiting keeps that case simple and safe)
+    if (e == hipSuccess && (wait || !is_pinned_host(host))) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         stx_buf_release(b);
         return stx_fail(STX_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
@@ -353,6 +366,18 @@ STX_EXPORT int stx_buf_from_host(stx_ctx* ctx, const void* host, size_t host_str
     }
     *out = b;
     return STX_OK;
+}
+
+STX_EXPORT int stx_buf_from_host(stx_ctx* ctx, const void* host, size_t host_stride, int w, int h, int channels,
+                                 int elem, stx_buf** out)
+{
+    return buf_from_host(ctx, host, host_stride, w, h, channels, elem, true, out);
+}
+
+STX_EXPORT int stx_buf_from_host_async(stx_ctx* ctx, const void* host, size_t host_stride, int w, int h, int channels,
+                                       int elem, stx_buf** out)
+{
+    return buf_from_host(ctx, host, host_stride, w, h, channels, elem, false, out);
 }
 
 // Page-locked host memory for the frames a decoder produces and for read-backs: copies from / to it run at PCIe
@@ -373,7 +398,7 @@ STX_EXPORT int stx_host_free(void* p)
     return STX_OK;
 }
 
-STX_EXPORT int stx_buf_to_host(const stx_buf* buf, void* host, size_t host_stride)
+static int buf_to_host(const stx_buf* buf, void* host, size_t host_stride, bool wait)
 {
     if (!buf || !host) return stx_fail(STX_ERR_INVALID, "null argument");
     STX_TRY(stx_set_device(buf->ctx));
@@ -381,8 +406,15 @@ STX_EXPORT int stx_buf_to_host(const stx_buf* buf, void* host, size_t host_strid
     if (host_stride < row) return stx_fail(STX_ERR_INVALID, "host stride %zu < row bytes %zu", host_stride, row);
     STX_HIP(hipMemcpy2DAsync(host, host_stride, buf->ptr, buf->stride, row, buf->h, hipMemcpyDeviceToHost,
                              buf->ctx->stream));
-    STX_HIP(hipStreamSynchronize(buf->ctx->stream));
+    if (wait || !is_pinned_host(host)) STX_HIP(hipStreamSynchronize(buf->ctx->stream));
     return STX_OK;
+}
+
+STX_EXPORT int stx_buf_to_host(const stx_buf* buf, void* host, size_t host_stride) { return buf_to_host(buf, host, host_stride, true); }
+
+STX_EXPORT int stx_buf_to_host_async(const stx_buf* buf, void* host, size_t host_stride)
+{
+    return buf_to_host(buf, host, host_stride, false);
 }
 
 STX_EXPORT int stx_buf_view(const stx_buf* buf, int x, int y, int w, int h, stx_buf** out)

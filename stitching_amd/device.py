@@ -138,7 +138,9 @@ class DeviceImage:
 
     # ---- construction
     @classmethod
-    def from_numpy(cls, arr, ctx=None):
+    def from_numpy(cls, arr, ctx=None, wait=True):
+        """Upload.  wait=False: `arr` is page-locked (pinned_empty) and stays untouched until ctx.sync(); the copy is only
+        queued (pageable arrays are copied synchronously either way)."""
         ctx = ctx or get_context()
         a = np.asarray(arr)
         if a.ndim == 2:
@@ -154,8 +156,10 @@ class DeviceImage:
         if not a.flags["C_CONTIGUOUS"]:
             a = np.ascontiguousarray(a)
         out = C.c_void_p()
-        _lib.check(ctx._lib.stx_buf_from_host(ctx.handle, a.ctypes.data_as(C.c_void_p), a.strides[0], w, h, c,
-                                              _ELEMS[a.dtype], C.byref(out)))
+        if not wait and a is not arr and not np.shares_memory(a, arr):
+            wait = True  # a temporary copy was made above: it must not be freed under the queued transfer
+        fn = ctx._lib.stx_buf_from_host if wait else ctx._lib.stx_buf_from_host_async
+        _lib.check(fn(ctx.handle, a.ctypes.data_as(C.c_void_p), a.strides[0], w, h, c, _ELEMS[a.dtype], C.byref(out)))
         return cls(ctx, out)
 
     # ---- numpy-like surface
@@ -175,13 +179,16 @@ class DeviceImage:
     def size(self):
         return self.height * self.width * self.channels
 
-    def numpy(self, out=None):
-        """Host copy; `out`: a C-contiguous array of this shape / dtype to copy into (e.g. from pinned_empty)."""
+    def numpy(self, out=None, wait=True):
+        """Host copy; `out`: a C-contiguous array of this shape / dtype to copy into (e.g. from pinned_empty).
+        wait=False (needs a page-locked `out`): the read-back is only queued; `out` is valid after ctx.sync()."""
         if out is None:
             out = np.empty(self.shape, self.dtype)
+            wait = True
         elif out.shape != self.shape or out.dtype != self.dtype or not out.flags.c_contiguous:
             raise StitchingError(f"out must be a C-contiguous {self.dtype} array of shape {self.shape}")
-        _lib.check(self.ctx._lib.stx_buf_to_host(self._h, out.ctypes.data_as(C.c_void_p), out.strides[0]))
+        fn = self.ctx._lib.stx_buf_to_host if wait else self.ctx._lib.stx_buf_to_host_async
+        _lib.check(fn(self._h, out.ctypes.data_as(C.c_void_p), out.strides[0]))
         return out
 
     def __array__(self, dtype=None, copy=None):
@@ -230,8 +237,8 @@ class DeviceImage:
         return f"DeviceImage(shape={self.shape}, dtype={self.dtype}, device={self.ctx.device})"
 
 
-def as_device(img, ctx=None):
-    """numpy array or DeviceImage -> DeviceImage on `ctx` (uploads when needed)."""
+def as_device(img, ctx=None, wait=True):
+    """numpy array or DeviceImage -> DeviceImage on `ctx` (uploads when needed; wait: see DeviceImage.from_numpy)."""
     if isinstance(img, DeviceImage):
         return img
-    return DeviceImage.from_numpy(img, ctx)
+    return DeviceImage.from_numpy(img, ctx, wait)

@@ -21,11 +21,13 @@ class StitchJob:
     """Pre-staged inputs of one panorama: device-resident source frames + cameras."""
 
     def __init__(self, frames, cameras, warper_type="spherical", blender_type="multiband", num_bands=None,
-                 blend_strength=Blender.DEFAULT_BLEND_STRENGTH, ctx=None):
+                 blend_strength=Blender.DEFAULT_BLEND_STRENGTH, ctx=None, async_upload=False):
+        """async_upload: numpy frames in page-locked memory (pinned_empty) are only queued for upload; they must stay
+        untouched until ctx.sync() (a streaming caller alternates two contexts)."""
         if len(frames) != len(cameras) or not frames:
             raise StitchingError("need one camera per frame and at least one frame")
         self.ctx = ctx or get_context()
-        self.frames = [as_device(f, self.ctx) for f in frames]
+        self.frames = [as_device(f, self.ctx, wait=not async_upload) for f in frames]
         self.cameras = list(cameras)
         self.sizes = [(f.width, f.height) for f in self.frames]
         self.warper = Warper(warper_type, ctx=self.ctx)

@@ -159,3 +159,15 @@ def test_pinned_host_arrays_round_trip(gpu_ctx):
     s16 = S.pinned_empty((4, 6), np.int16)
     s16[:] = -3
     assert int(s16.sum()) == -72
+    # queued (asynchronous) upload and read-back: valid after ctx.sync(); pageable arrays silently take the waiting path
+    pin2 = S.pinned_empty(ref.shape, ref.dtype)
+    np.copyto(pin2, ref)
+    d2 = S.DeviceImage.from_numpy(pin2, gpu_ctx, wait=False)
+    out2 = S.pinned_empty(ref.shape, ref.dtype)
+    out2[:] = 0
+    d2.numpy(out=out2, wait=False)
+    gpu_ctx.sync()
+    assert np.array_equal(out2, ref)
+    d3 = S.DeviceImage.from_numpy(ref[:, ::-1], gpu_ctx, wait=False)  # non-contiguous, pageable: copied synchronously
+    pageable = np.zeros(ref.shape, ref.dtype)
+    assert np.array_equal(d3.numpy(out=pageable, wait=False), ref[:, ::-1])
