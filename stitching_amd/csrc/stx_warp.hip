@@ -439,30 +439,48 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
     if (IMG && interior) {
         const STX_GAS uint8_t* src = (const STX_GAS uint8_t*)src_a;
         const uint32_t stride = sstride;
+        // Every channel value comes out of its dot product already in byte 2 of the register:
+        //   64 * (h0 * (32 - fx) + h1 * fx + 512)  =  ((h0 * (32 - fx) + h1 * fx + 512) >> 10) << 16  + a remainder below bit 16
+        // (weights scaled by 64: <= 2048, sums < 2^25), so the 12 result bytes of the lane's four pixels are placed into
+        // the three output dwords by byte permutes alone: no shifts, masks or ors.
+        uint32_t X[4][3];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int sx = (int)rintf(x32[j]), sy = (int)rintf(y32[j]);  // cvRound; in range by the interior test
             const uint32_t fx = (uint32_t)sx & 31u, fy = (uint32_t)sy & 31u;
-            const uint32_t a = (uint32_t)(sy >> 5) * stride + (uint32_t)(sx >> 5) * 3u;
+            // row < 2^15 and stride < 2^24 (fast_ok): 24-bit multiply, full rate
+            const uint32_t a = __umul24((uint32_t)(sy >> 5), stride) + (uint32_t)(sx >> 5) * 3u;
             const STX_GAS uint32_t* q0 = reinterpret_cast<const STX_GAS uint32_t*>(src + (a & ~3u));
             const STX_GAS uint32_t* q1 = reinterpret_cast<const STX_GAS uint32_t*>(src + ((a & ~3u) + stride));
             const uint32_t d0 = q0[0], d1 = q0[1], d2 = q0[2], e0 = q1[0], e1 = q1[1], e2 = q1[2];
-            const uint32_t s = a & 3u;
-            const uint32_t l0 = __builtin_amdgcn_alignbyte(d1, d0, s), h0 = __builtin_amdgcn_alignbyte(d2, d1, s);
-            const uint32_t l1 = __builtin_amdgcn_alignbyte(e1, e0, s), h1 = __builtin_amdgcn_alignbyte(e2, e1, s);
+            const uint32_t sh = a & 3u;
+            const uint32_t l0 = __builtin_amdgcn_alignbyte(d1, d0, sh), h0 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+            const uint32_t l1 = __builtin_amdgcn_alignbyte(e1, e0, sh), h1 = __builtin_amdgcn_alignbyte(e2, e1, sh);
             const uint32_t wy1 = fy * 0x10001u, wy0 = 0x200020u - wy1;  // (fy, fy), (32 - fy, 32 - fy)
-            const uint32_t wx = fx * 0xffffu + 32u;                     // (32 - fx, fx)
-            uint32_t o[3];
+            const uint32_t wx = __umul24(fx, 0x3fffc0u) + 2048u;        // (64 (32 - fx), 64 fx)
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 // (left tap, right tap) of channel c as two u16: bytes c and c + 3 of the 6-byte BGRBGR group
                 const uint32_t sel = c == 0 ? 0x0c030c00u : (c == 1 ? 0x0c040c01u : 0x0c050c02u);
                 const v2h t0 = as_v2h(__builtin_amdgcn_perm(h0, l0, sel)), t1 = as_v2h(__builtin_amdgcn_perm(h1, l1, sel));
                 const v2h v = t0 * as_v2h(wy0) + t1 * as_v2h(wy1);  // vertical lerp of both taps, <= 255 * 32
-                o[c] = __builtin_amdgcn_udot2(v, as_v2h(wx), 512u, false) >> 10;
+                X[j][c] = __builtin_amdgcn_udot2(v, as_v2h(wx), 32768u, false);
             }
-            put_px(out, j, o[0] | (o[1] << 8) | (o[2] << 16));
         }
+        // v_perm_b32(hi, lo, sel): selector bytes 0-3 take lo's bytes, 4-7 hi's, 0x0c gives zero
+        constexpr uint32_t SEL_A = 0x0c0c0602u;  // (lo.b2, hi.b2, 0, 0)
+        constexpr uint32_t SEL_B = 0x0c060100u;  // (lo.b0, lo.b1, hi.b2, 0)
+        constexpr uint32_t SEL_C = 0x06020100u;  // (lo.b0, lo.b1, lo.b2, hi.b2)
+        uint32_t t;
+        t = __builtin_amdgcn_perm(X[0][1], X[0][0], SEL_A);  // b0 g0
+        t = __builtin_amdgcn_perm(X[0][2], t, SEL_B);        // b0 g0 r0
+        out[0] = __builtin_amdgcn_perm(X[1][0], t, SEL_C);   // b0 g0 r0 b1
+        t = __builtin_amdgcn_perm(X[1][2], X[1][1], SEL_A);  // g1 r1
+        t = __builtin_amdgcn_perm(X[2][0], t, SEL_B);        // g1 r1 b2
+        out[1] = __builtin_amdgcn_perm(X[2][1], t, SEL_C);   // g1 r1 b2 g2
+        t = __builtin_amdgcn_perm(X[3][0], X[2][2], SEL_A);  // r2 b3
+        t = __builtin_amdgcn_perm(X[3][1], t, SEL_B);        // r2 b3 g3
+        out[2] = __builtin_amdgcn_perm(X[3][2], t, SEL_C);   // r2 b3 g3 r3
         mout = 0xffffffffu;  // interior taps => the rounded sample position is inside as well
     } else {
 #pragma unroll
