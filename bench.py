@@ -178,8 +178,10 @@ def main():
     if world > 1:
         from stitching_amd.distributed import ShardedStitchJob
 
+        # with two panoramas in flight the other panorama's kernels cover the exchange: no boundary / interior split
+        split = max(1, args.streams) < 2
         job = ShardedStitchJob(frames, cams, all_cams, rank, world, warper_type=args.warper,
-                               blender_type=args.blender, num_bands=args.bands, ctx=ctx, dist=dist)
+                               blender_type=args.blender, num_bands=args.bands, ctx=ctx, dist=dist, split_boundary=split)
     else:
         job = StitchJob(frames, cams, warper_type=args.warper, blender_type=args.blender, num_bands=args.bands, ctx=ctx)
         job.warper.set_scale(all_cams)
@@ -195,7 +197,7 @@ def main():
         else:
             # the ranks' second panorama in flight shares the transport (one communicator, exchanges in issue order)
             j = ShardedStitchJob(job.frames, cams, all_cams, rank, world, warper_type=args.warper, blender_type=args.blender,
-                                 num_bands=args.bands, ctx=c, dist=dist, transport=job.transport)
+                                 num_bands=args.bands, ctx=c, dist=dist, transport=job.transport, split_boundary=split)
         j.plan()
         jobs.append(j)
         ctxs.append(c)

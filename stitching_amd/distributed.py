@@ -287,7 +287,12 @@ class ShardedStitchJob:
     """One rank of a sharded panorama: device-resident local frames + the global camera list."""
 
     def __init__(self, frames, cameras, all_cameras, rank, world, all_sizes=None, warper_type="spherical",
-                 blender_type="multiband", num_bands=5, blend_strength=None, ctx=None, dist=None, transport=None):
+                 blender_type="multiband", num_bands=5, blend_strength=None, ctx=None, dist=None, transport=None,
+                 split_boundary=True):
+        """split_boundary: warp / feed the images that owe strips to other ranks first and the rest while the strips
+        travel (lowest latency of ONE panorama).  A caller that keeps several panoramas in flight on several contexts
+        passes False: all local images go through one warp launch and one pyramid build, and the other panorama's
+        kernels fill the time of the exchange."""
         if blender_type != "multiband":
             raise StitchingError("sharded blending is implemented for the multi-band blender")
         self.ctx = ctx or get_context()
@@ -307,6 +312,7 @@ class ShardedStitchJob:
         self.num_bands_req, self.blend_strength = num_bands, blend_strength
         self.dist = dist
         self.transport = transport
+        self.split_boundary = bool(split_boundary)
         self.plan_ = None
 
     @property
@@ -345,7 +351,7 @@ class ShardedStitchJob:
             send_msgs = p.sends(self.rank)
             recv_msgs = p.recvs(self.rank)
             # 1. the images that owe strips to other ranks: warp, feed, export, start the exchange
-            senders = sorted({m[0] for m in send_msgs})
+            senders = sorted({m[0] for m in send_msgs}) if self.split_boundary else list(self.my_orders)
             self._warp_and_feed(blender, [k for k in self.my_orders if k in senders], p)
             sends = []
             for (k, _src, dst, rect, nbytes) in send_msgs:

@@ -234,9 +234,11 @@ def test_batched_warp_equals_per_image(oracle, gpu_ctx, wtype):
         assert np.array_equal(np.asarray(gm[i]), o.create_and_warp_mask(sizes[i], cams[i])), f"mask {i}"
 
 
-def test_sharded_job_bands_equal_single_job(oracle, gpu_ctx):
-    """ShardedStitchJob.run() as bench.py drives it for N > 1 (boundary images first, exchange in flight while
-    the interior images are warped), both ranks executed one after the other on this GPU: pass 1 records
+@pytest.mark.parametrize("split", [True, False])
+def test_sharded_job_bands_equal_single_job(oracle, gpu_ctx, split):
+    """ShardedStitchJob.run() as bench.py drives it for N > 1 (split: boundary images first, exchange in flight while
+    the interior images are warped; not split: one warp launch and one pyramid build for all local images, as with
+    several panoramas in flight), both ranks executed one after the other on this GPU: pass 1 records
     every rank's outgoing strips, pass 2 replays them as the incoming ones.  The concatenated bands are the
     single-job panorama bit for bit."""
     from stitching_amd.distributed import ShardedStitchJob, flat_device_buffer
@@ -279,7 +281,7 @@ def test_sharded_job_bands_equal_single_job(oracle, gpu_ctx):
     for r in range(world):
         rec = Recorder()
         job = ShardedStitchJob(frames[r * per:(r + 1) * per], cams[r * per:(r + 1) * per], cams, r, world, num_bands=4,
-                               ctx=gpu_ctx, transport=rec)
+                               ctx=gpu_ctx, transport=rec, split_boundary=split)
         job.plan()
         job.run()
         jobs.append(job)
