@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""Per-rank device time of the sharded job on ONE GPU: rank R of an N-rank ring runs alone with a replay transport
+(received strips = zero-filled buffers of the planned sizes, allocated once), two panoramas in flight — what one GPU
+of an N-GPU node does per step, without the exchange itself.  usage: python tools/sim_rank.py [N] [R] [steps]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import stitching_amd as S  # noqa: E402
+from stitching_amd import synthetic  # noqa: E402
+from stitching_amd.distributed import ShardedStitchJob, flat_device_buffer  # noqa: E402
+
+
+class ZeroStrips:
+    name = "replay"
+
+    def __init__(self):
+        self.cache = {}
+
+    def start(self, sends, recvs, ctx=None):
+        self.ctx, self.recvs = ctx, recvs
+
+    def finish(self):
+        out = []
+        for i, (src, nb) in enumerate(self.recvs):
+            key = (id(self.ctx), i, nb)
+            if key not in self.cache:
+                self.cache[key] = flat_device_buffer(self.ctx, np.zeros(nb, np.uint8))
+            out.append(self.cache[key])
+        return out
+
+
+def main():
+    world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    rank = int(sys.argv[2]) if len(sys.argv) > 2 else world // 2
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+    fpg, w, h = 8, 4000, 3000
+    cams = synthetic.ring_cameras(fpg * world, w, h, focal_factor=0.75 * world)
+    my = range(rank * fpg, (rank + 1) * fpg)
+    frames = [synthetic.make_frame(i, w, h) for i in my]
+    ctxs = [S.get_context(), S.Context(S.get_context().device)]
+    jobs = []
+    for split in (False, True):
+        js = []
+        for c in ctxs:
+            j = ShardedStitchJob(frames if not js else js[0].frames, [cams[i] for i in my], cams, rank, world, ctx=c,
+                                 transport=ZeroStrips(), split_boundary=split)
+            j.plan()
+            js.append(j)
+        jobs.append(js)
+    res = {"world": world, "rank": rank}
+    for split, js in zip((False, True), jobs):
+        for i in range(4):
+            js[i % 2].run()
+        for c in ctxs:
+            c.sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out = js[i % 2].run()
+            del out
+        for c in ctxs:
+            c.sync()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        p = js[0].plan_
+        res["split" if split else "nosplit"] = {"ms_per_step": round(ms, 4), "mpix_per_s": round(fpg * w * h / ms / 1e3, 1),
+                                                "sends": len(p.sends(rank)), "recvs": len(p.recvs(rank)),
+                                                "sent_MB": round(sum(m[4] for m in p.sends(rank)) / 1e6, 1)}
+    # kernel breakdown of one no-split step on one context
+    c = ctxs[0]
+    c.prof_enable(True)
+    c.prof_reset()
+    for _ in range(5):
+        jobs[0][0].run()
+    res["kernels_nosplit_us_per_step"] = {k["kernel"]: [round(k["calls"] / 5, 1), round(k["total_ms"] * 1e3 / 5, 1)]
+                                          for k in c.prof_results()}
+    c.prof_enable(False)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
