@@ -389,7 +389,6 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
     }
     const float omt = fsub(1.f, P.t[2]);
     const float2 rt = rowT[y];
-    {
     float xs[4], ys[4], zs[4];
     // every division of this lane may use the shared-reciprocal sequence: all |z| (z for the rotation warpers,
     // which also need z > 0) in [2^-60, 2^60] and all |x|, |y| <= 2^60.  Evaluated as integer min / max of the
@@ -499,7 +498,6 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
         d[2] = out[2];
     }
     if (MASK) *reinterpret_cast<uint32_t*>((uint8_t*)dmask_a + (long long)y * dmask_stride + x0) = mout;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------

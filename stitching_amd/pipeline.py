@@ -44,6 +44,9 @@ class StitchJob:
     def plan(self):
         """Eager ROI pass (stitching/stitcher.py:188 warp_rois is eager too); one device sync."""
         self.corners, self.warped_sizes = self.warper.warp_rois(self.sizes, self.cameras)
+        if any(w <= 0 or h <= 0 for w, h in self.warped_sizes):
+            raise StitchingError(f"degenerate warp roi {self.warped_sizes}: the {self.warper.warper_type!r} projection cannot "
+                                 "represent these cameras")
         if self.num_bands is not None:
             roi = Blender.result_roi(self.corners, self.warped_sizes)
             self.blend_strength = blend_strength_for_bands(self.num_bands, roi[2], roi[3])
