@@ -1044,6 +1044,8 @@ STX_EXPORT int stx_result_roi(int n, const int* corners_xy, const int* sizes_wh,
     return STX_OK;
 }
 
+constexpr size_t MB_FRONT_PAD = 64;  // bytes in front of every int16 pyramid / finished-level buffer (keeps 64-byte alignment)
+
 struct stx_blender {
     stx_ctx* ctx = nullptr;
     int kind = 0, num_bands = 0;
@@ -1231,11 +1233,12 @@ static int mb_feed(stx_blender* b, const stx_buf* img, const stx_buf* mask, int 
         const int lw = im.fw >> i, lh = im.fh >> i;
         const long long gs = (long long)align_up((size_t)lw, 32), ws = (long long)align_up((size_t)lw, 16);
         void *g = nullptr, *wt = nullptr;
-        STX_TRY(stx_dev_alloc(ctx, (size_t)gs * lh * 3 * sizeof(short), &g));
+        // MB_FRONT_PAD: the pyrUp tap loads of the gather kernels start two samples in front of a row (up_row_window)
+        STX_TRY(stx_dev_alloc(ctx, MB_FRONT_PAD + (size_t)gs * lh * 3 * sizeof(short), &g));
         b->pyr_allocs.push_back(g);
         STX_TRY(stx_dev_alloc(ctx, (size_t)ws * lh * sizeof(float), &wt));
         b->pyr_allocs.push_back(wt);
-        im.g[i] = (short*)g; im.g_stride[i] = gs; im.g_plane[i] = gs * lh;
+        im.g[i] = (short*)((uint8_t*)g + MB_FRONT_PAD); im.g_stride[i] = gs; im.g_plane[i] = gs * lh;
         im.wt[i] = (float*)wt; im.wt_stride[i] = ws;
     }
     // deferred: the pyramids of all images are built together (one launch per level), at the first
@@ -1390,9 +1393,9 @@ static int mb_finish(stx_blender* b, stx_buf* pano, stx_buf* pmask, stx_buf* pan
             const int w = xe[lv] - xb[lv], ph = b->rh >> lv;
             const long long st = (long long)align_up((size_t)std::max(w, 1), 32);
             void* p = nullptr;
-            STX_TRY(stx_dev_alloc(ctx, (size_t)st * ph * 3 * sizeof(short), &p));
+            STX_TRY(stx_dev_alloc(ctx, MB_FRONT_PAD + (size_t)st * ph * 3 * sizeof(short), &p));
             b->pyr_allocs.push_back(p);
-            out[lv] = (short*)p; ostride[lv] = st; oplane[lv] = st * ph;
+            out[lv] = (short*)((uint8_t*)p + MB_FRONT_PAD); ostride[lv] = st; oplane[lv] = st * ph;
             K.out = out[lv]; K.out_stride = st; K.out_plane = st * ph;
             K.out_x0 = xb[lv]; K.out_y0 = 0;
         }

@@ -22,8 +22,10 @@ using namespace stxd;
 
 namespace {
 
+// waves per SIMD the level-0 gather is compiled for: 5 = 95 VGPRs without spills (A/B on one box: 218 us at 4, 206 us at 5;
+// 6 would spill 14 registers)
 #ifndef STX_L0_WAVES
-#define STX_L0_WAVES 4
+#define STX_L0_WAVES 5
 #endif
 constexpr float WEIGHT_EPS = 1e-5f;
 constexpr float INV255 = 0.0039215688593685627f;  // (float)(1./255.)
@@ -67,25 +69,39 @@ STX_DEV pk16 pk(uint32_t v) { return __builtin_bit_cast(pk16, v); }
 STX_DEV uint32_t unpk(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
 STX_DEV pk16 pk_splat(unsigned short v) { pk16 r = {v, v}; return r; }
 
+// The six coarse samples c0..c5 = plane[cx - 1 .. cx + 4] of one row, as the pairs the 8-wide pyrUp patch needs, from ONE
+// dword-aligned 16-byte load of plane[cx - 2 .. cx + 5] (cx is a multiple of 4, so the window starts 4 bytes before an
+// 8-byte boundary).  pyrUp's border rule — column -1 -> 1, column cw -> cw - 1 — only changes c0 (to c2, when cx == 0)
+// and c5 (to c4, when cx + 4 == cw): two selects instead of two more loads with their own addresses.  The two shorts in
+// front of a plane's first row are read and never used: every plane this is called on has >= 4 readable bytes in front.
+struct UpRow { uint32_t A0, B0, A1, B1, A2; };  // (c0,c1) (c1,c2) (c2,c3) (c3,c4) (c4,c5)
+STX_DEV UpRow up_row_window(const STX_GAS short* __restrict__ plane, uint32_t elem_off, bool left_edge, bool right_edge)
+{
+    const v4u w = *reinterpret_cast<const STX_GAS v4u_a4*>(plane + elem_off - 2);  // (x,c0) (c1,c2) (c3,c4) (c5,x)
+    UpRow r;
+    r.B0 = w.y;
+    r.B1 = w.z;
+    r.A1 = __builtin_amdgcn_alignbit(w.z, w.y, 16);
+    const uint32_t a0 = __builtin_amdgcn_alignbit(w.y, w.x, 16), a0e = __builtin_amdgcn_alignbit(w.y, w.y, 16);  // (c0,c1) / (c2,c1)
+    const uint32_t a2 = __builtin_amdgcn_alignbit(w.w, w.z, 16), a2e = __builtin_amdgcn_perm(w.z, w.z, 0x03020302u);  // (c4,c5) / (c4,c4)
+    r.A0 = left_edge ? a0e : a0;
+    r.A2 = right_edge ? a2e : a2;
+    return r;
+}
+
 // pyrUp_<FixPtCast<short,6>> of one plane holding values 0..255 for the 8x2 patch with coarse origin (cx, cy)
 STX_DEV void up_patch_pk(const STX_GAS short* __restrict__ plane, uint32_t stride, int cw, int ch, int cx, int cy, pk16 up[2][4])
 {
     const int rr[3] = {up_idx(cy - 1, ch), cy, up_idx(cy + 1, ch)};
-    const int cl = up_idx(cx - 1, cw), cr = up_idx(cx + 4, cw);
+    const bool le = cx == 0, re = cx + 4 >= cw;
     pk16 HE[3][2], HO[3][2];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        const uint32_t ro = (uint32_t)rr[r] * stride;
-        const v2u v = *reinterpret_cast<const STX_GAS v2u*>(plane + (ro + (uint32_t)cx));  // (c1,c2) (c3,c4)
-        const uint32_t c0 = (uint32_t)(unsigned short)plane[ro + (uint32_t)cl], c5 = (uint32_t)(unsigned short)plane[ro + (uint32_t)cr];
-        const uint32_t B0 = v.x, B1 = v.y;
-        const uint32_t A0 = (B0 << 16) | c0;                          // (c0,c1)
-        const uint32_t A1 = __builtin_amdgcn_alignbit(B1, B0, 16);    // (c2,c3)
-        const uint32_t A2 = (B1 >> 16) | (c5 << 16);                  // (c4,c5)
-        HE[r][0] = pk(A0) + pk(B0) * pk_splat(6) + pk(A1);            // c[j] + 6 c[j+1] + c[j+2], j = 0,1
-        HE[r][1] = pk(A1) + pk(B1) * pk_splat(6) + pk(A2);            // j = 2,3
-        HO[r][0] = pk(B0) + pk(A1);                                   // c[j+1] + c[j+2] (the factor 4 is folded below)
-        HO[r][1] = pk(B1) + pk(A2);
+        const UpRow t = up_row_window(plane, (uint32_t)rr[r] * stride + (uint32_t)cx, le, re);
+        HE[r][0] = pk(t.A0) + pk(t.B0) * pk_splat(6) + pk(t.A1);            // c[j] + 6 c[j+1] + c[j+2], j = 0,1
+        HE[r][1] = pk(t.A1) + pk(t.B1) * pk_splat(6) + pk(t.A2);            // j = 2,3
+        HO[r][0] = pk(t.B0) + pk(t.A1);                                     // c[j+1] + c[j+2] (the factor 4 is folded below)
+        HO[r][1] = pk(t.B1) + pk(t.A2);
     }
 #pragma unroll
     for (int k = 0; k < 2; k++) {
@@ -796,25 +812,19 @@ STX_DEV pk16s pks_splat(short v) { pk16s r = {v, v}; return r; }
 STX_DEV bool up_patch_pks(const STX_GAS short* __restrict__ plane, uint32_t stride, int cw, int ch, int cx, int cy, pk16s up[2][4])
 {
     const int rr[3] = {up_idx(cy - 1, ch), cy, up_idx(cy + 1, ch)};
-    const int cl = up_idx(cx - 1, cw), cr = up_idx(cx + 4, cw);
+    const bool le = cx == 0, re = cx + 4 >= cw;
     pk16s HE[3][2], HO[3][2];
     pk16 worst = pk_splat(0);
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        const uint32_t ro = (uint32_t)rr[r] * stride;
-        const v2u v = *reinterpret_cast<const STX_GAS v2u*>(plane + (ro + (uint32_t)cx));  // (c1,c2) (c3,c4)
-        const uint32_t c0 = (uint32_t)(unsigned short)plane[ro + (uint32_t)cl], c5 = (uint32_t)(unsigned short)plane[ro + (uint32_t)cr];
-        const uint32_t B0 = v.x, B1 = v.y;
-        const uint32_t A0 = (B0 << 16) | c0;                          // (c0,c1)
-        const uint32_t A1 = __builtin_amdgcn_alignbit(B1, B0, 16);    // (c2,c3)
-        const uint32_t A2 = (B1 >> 16) | (c5 << 16);                  // (c4,c5)
-        worst = __builtin_elementwise_max(worst, pk(A0) + pk_splat(500));
-        worst = __builtin_elementwise_max(worst, pk(A1) + pk_splat(500));
-        worst = __builtin_elementwise_max(worst, pk(A2) + pk_splat(500));
-        HE[r][0] = pks(A0) + pks(B0) * pks_splat(6) + pks(A1);
-        HE[r][1] = pks(A1) + pks(B1) * pks_splat(6) + pks(A2);
-        HO[r][0] = pks(B0) + pks(A1);
-        HO[r][1] = pks(B1) + pks(A2);
+        const UpRow t = up_row_window(plane, (uint32_t)rr[r] * stride + (uint32_t)cx, le, re);
+        worst = __builtin_elementwise_max(worst, pk(t.A0) + pk_splat(500));
+        worst = __builtin_elementwise_max(worst, pk(t.A1) + pk_splat(500));
+        worst = __builtin_elementwise_max(worst, pk(t.A2) + pk_splat(500));
+        HE[r][0] = pks(t.A0) + pks(t.B0) * pks_splat(6) + pks(t.A1);
+        HE[r][1] = pks(t.A1) + pks(t.B1) * pks_splat(6) + pks(t.A2);
+        HO[r][0] = pks(t.B0) + pks(t.A1);
+        HO[r][1] = pks(t.B1) + pks(t.A2);
     }
     if (unpk(__builtin_elementwise_min(worst, pk_splat(1000))) != unpk(worst)) return false;
 #pragma unroll
