@@ -469,16 +469,17 @@ STX_DEV void div3_shared(float d, float n0, float n1, float n2, float& q0, float
 STX_DEV void up_patch(const short* __restrict__ plane, long long stride, int cw, int ch, int cx, int cy, int up[2][8])
 {
     const int rr[3] = {up_idx(cy - 1, ch), cy, up_idx(cy + 1, ch)};
-    const int cl = up_idx(cx - 1, cw), cr = up_idx(cx + 4, cw);
+    const bool le = cx == 0, re = cx + 4 >= cw;  // pyrUp's border rule: column -1 -> 1, column cw -> cw - 1
     int he[3][4], ho[3][4];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
         const short* p = plane + (long long)rr[r] * stride;
         int c[6];
-        uint2 v = *reinterpret_cast<const uint2*>(p + cx);
-        c[0] = p[cl];
-        c[1] = s16lo(v.x); c[2] = s16hi(v.x); c[3] = s16lo(v.y); c[4] = s16hi(v.y);
-        c[5] = p[cr];
+        // one dword-aligned 16-byte window plane[cx - 2 .. cx + 5] instead of an 8-byte load and two single samples
+        const v4u w = *reinterpret_cast<const v4u_a4*>(p + cx - 2);
+        c[1] = s16lo(w.y); c[2] = s16hi(w.y); c[3] = s16lo(w.z); c[4] = s16hi(w.z);
+        c[0] = le ? c[2] : s16hi(w.x);
+        c[5] = re ? c[4] : s16lo(w.w);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             he[r][j] = c[j] + 6 * c[j + 1] + c[j + 2];
@@ -1125,11 +1126,10 @@ bool stx_fast_mb_down_batch(stx_ctx* ctx, const StxMbImage* d_images, const StxM
         mh = std::max(mh, (h_images[i].fh >> level) >> 1);
     }
     if (n <= 0 || mw < 1 || mh < 1 || n > 65535) return false;
-    // Tile order: XCD bands cut the level-0 fetch from 556 to 340 MB (354 MB of input) at equal kernel time, but with two
-    // panoramas in flight the plain row-major order is 2 % faster end to end (A/B on one box: 103.3 vs 101.2 Gpix/s), so
-    // the pyramid build keeps the plain order; the gather and warp kernels are neutral and keep the bands.
+    // Tile order: XCD bands (2 tile rows per band) cut the level-0 fetch from 584 to 340 MB for 314 MB of input at equal
+    // kernel time and equal end-to-end throughput (A/B on one box, two panoramas in flight: 116.1 / 116.9 against
+    // 116.5 / 116.9 Gpix/s) — kept for the HBM traffic they leave to the co-running kernels.
     StxTileMap M = stx_tile_map((mw + DN_TOW - 1) / DN_TOW, (mh + DN_TOH - 1) / DN_TOH, DN_BAND);
-    M.plain = 1;
     bool pk_ok = true;  // packed 16-bit row sums need u8 images with 0 / 255 masks
     for (int i = 0; i < n; i++) pk_ok = pk_ok && !h_images[i].img0_is_s16 && h_images[i].mask_binary;
     dim3 grid(stx_tile_grid(M), 1, n);
