@@ -22,8 +22,8 @@ using namespace stxd;
 
 namespace {
 
-// waves per SIMD the level-0 gather is compiled for: 5 = 95 VGPRs without spills (A/B on one box: 218 us at 4, 206 us at 5;
-// 6 would spill 14 registers)
+// waves per SIMD the level-0 gather is compiled for: 5 = 95 VGPRs without spills (A/B on one box: 218 us at 4, 206 us at 5,
+// 283 us at 6: 80 VGPRs spill in the collapse)
 #ifndef STX_L0_WAVES
 #define STX_L0_WAVES 5
 #endif
@@ -969,14 +969,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVE
     const bool active = X0 < P.x1 && Y0 < P.y1;
 
     uint32_t acc[2][3][4];  // [row][channel][pair]: int16 sums, wrap-around like OpenCV's short +=
-    uint32_t cnt[2][4];     // [row][pair]: number of images whose mask covers the pixel
+    uint32_t cntb[2][2];    // [row][px / 4]: number of images whose mask covers the pixel, one byte per pixel (<= 255 images)
 #pragma unroll
-    for (int r = 0; r < 2; r++)
+    for (int r = 0; r < 2; r++) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            acc[r][0][k] = acc[r][1][k] = acc[r][2][k] = 0;
-            cnt[r][k] = 0;
-        }
+        for (int k = 0; k < 4; k++) acc[r][0][k] = acc[r][1][k] = acc[r][2][k] = 0;
+        cntb[r][0] = cntb[r][1] = 0;
+    }
 
     // every wavefront finds the images under ITS two rows with one ballot (no LDS list, no barrier)
     for (int base = 0; base < P.n_images; base += 64) {
@@ -1016,10 +1015,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVE
                     // 1.f = 0x3f800000, 0.f = 0: bit 23 is the count
                     const uint32_t i0 = (w0.x >> 23) & 1u, i1 = (w0.y >> 23) & 1u, i2 = (w0.z >> 23) & 1u, i3 = (w0.w >> 23) & 1u;
                     const uint32_t i4 = (w1.x >> 23) & 1u, i5 = (w1.y >> 23) & 1u, i6 = (w1.z >> 23) & 1u, i7 = (w1.w >> 23) & 1u;
-                    cnt[r][0] = unpk(pk(cnt[r][0]) + pk(i0 | (i2 << 16)));
-                    cnt[r][1] = unpk(pk(cnt[r][1]) + pk(i4 | (i6 << 16)));
-                    cnt[r][2] = unpk(pk(cnt[r][2]) + pk(i1 | (i3 << 16)));
-                    cnt[r][3] = unpk(pk(cnt[r][3]) + pk(i5 | (i7 << 16)));
+                    cntb[r][0] += i0 | (i1 << 8) | (i2 << 16) | (i3 << 24);
+                    cntb[r][1] += i4 | (i5 << 8) | (i6 << 16) | (i7 << 24);
                 }
                 continue;
             }
@@ -1074,12 +1071,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVE
             uint32_t M[2][4];
 #pragma unroll
             for (int r = 0; r < 2; r++) {
-                M[r][0] = pair_mask<0, 2>(mw[r]);
-                M[r][1] = pair_mask<4, 6>(mw[r]);
-                M[r][2] = pair_mask<1, 3>(mw[r]);
-                M[r][3] = pair_mask<5, 7>(mw[r]);
-#pragma unroll
-                for (int q = 0; q < 4; q++) cnt[r][q] = unpk(pk(cnt[r][q]) - pk(M[r][q]));  // -(0xffff) = +1
+                // the mask as 0 / 1: the coverage counters add its bytes, and as 16-bit pairs (short)(L * W) = L * m folds into
+                // the accumulation as one v_pk_mad_u16 (the low 16 bits of L * 1 are L for negative L too)
+                const uint32_t m01[2] = {mw[r][0] & 0x01010101u, mw[r][1] & 0x01010101u};
+                M[r][0] = pair_u8<0, 2>(m01);
+                M[r][1] = pair_u8<4, 6>(m01);
+                M[r][2] = pair_u8<1, 3>(m01);
+                M[r][3] = pair_u8<5, 7>(m01);
+                cntb[r][0] += m01[0];  // four byte counters per register: no carry below 256 images
+                cntb[r][1] += m01[1];
             }
 #pragma unroll
             for (int c = 0; c < 3; c++) {
@@ -1101,8 +1101,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVE
                     }
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        const uint32_t L = unpk(pk(px[q]) - up[r][q]);  // in [-255, 255]: the saturating subtract never clips
-                        acc[r][c][q] = unpk(pk(acc[r][c][q]) + pk(L & M[r][q]));
+                        const pk16 L = pk(px[q]) - up[r][q];  // in [-255, 255]: the saturating subtract never clips
+                        acc[r][c][q] = unpk(L * pk(M[r][q]) + pk(acc[r][c][q]));
                     }
                 }
             }
@@ -1110,6 +1110,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVE
     }
     if (!active) return;
 
+    uint32_t cnt[2][4];  // the epilogue wants the counts in the pair layout of acc
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        cnt[r][0] = pair_u8<0, 2>(cntb[r]);
+        cnt[r][1] = pair_u8<4, 6>(cntb[r]);
+        cnt[r][2] = pair_u8<1, 3>(cntb[r]);
+        cnt[r][3] = pair_u8<5, 7>(cntb[r]);
+    }
     level0_epilogue_pk(P, X0, Y0, acc, cnt);
 }
 
