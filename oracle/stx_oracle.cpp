@@ -29,10 +29,15 @@
 // OpenCV binary exists here to generate any.  What pins this oracle instead: closed-form
 // known-answer tests and seeded SHA-256 goldens of its own output (tests/, tests/golden/).
 //
-// Trig modes.  OpenCV calls libm sinf/cosf/atan2f/acosf.  trig=0 ("libm") does the same
-// (literal restatement).  trig=1 ("exact") uses the double-precision polynomial routines
-// below and rounds once to fp32; it is what the HIP kernels reproduce bit-for-bit, and
-// tests/ measure its drift from trig=0 (<= 1 ULP fp32).
+// Warpers.  All sixteen names cv.PyRotationWarper accepts (stitching/warper.py:10-27): plane, affine,
+// cylindrical, spherical with their detectResultRoi overrides, and the twelve RotationWarperBase<P>
+// warpers (fisheye, stereographic, compressedPlane*, panini*, mercator, transverseMercator) with the
+// generic every-pixel detectResultRoi; (a, b) as PyRotationWarper's constructor fixes them.
+//
+// Trig modes.  OpenCV calls libm sinf/cosf/atan2f/acosf (and tanf/asinf/atanf/logf/sinhf/coshf in the
+// twelve other projectors).  trig=0 ("libm") does the same (literal restatement).  trig=1 ("exact")
+// uses the double-precision polynomial routines below and rounds once to fp32; it is what the HIP
+// kernels reproduce bit-for-bit, and tests/ measure its drift from trig=0 (<= 1 ULP fp32 per call).
 //
 // Build: see oracle/Makefile (g++ -O3 -march=x86-64-v3 -ffp-contract=off -fopenmp).
 // -ffp-contract=off matters: OpenCV's baseline x86-64 build has no FMA contraction.
