@@ -377,25 +377,30 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
     const int tile_x = (int)(within - wy * (uint32_t)tiles_x);
     const int tile_y = (int)((band_i * 8u + (blockIdx.x & 7u)) * (uint32_t)band_rows + wy);
     if (tile_y >= tiles_y) return;
-    const int x0 = tile_x * WARP_TW + lane * 4;
-    const int y = tile_y * WARP_TH + (threadIdx.x >> 6);
-    if (x0 >= dw || y >= dh) return;
-    float ca[4], cb[4];
-    {
-        const float4 c01 = *reinterpret_cast<const float4*>(colT + x0);
-        const float4 c23 = *reinterpret_cast<const float4*>(colT + x0 + 2);
-        ca[0] = c01.x; cb[0] = c01.y; ca[1] = c01.z; cb[1] = c01.w;
-        ca[2] = c23.x; cb[2] = c23.y; ca[3] = c23.z; cb[3] = c23.w;
-    }
+    // Lane layout: a wavefront covers 64 columns x WARP_TH rows, one lane = one column, its WARP_TH pixels one below
+    // the other (the workgroup's four wavefronts sit side by side: a 256 x 4 tile).  For every row the 64 lanes then
+    // gather from ADJACENT source positions — about 3 cache lines per load instruction instead of the 8 that four
+    // horizontal pixels per lane touched (one-line-gathers experiment: the scattered form cost 50 of 250 us) — and the
+    // row constants are wave-uniform.  The 3-byte results go through LDS to leave as whole dwords: 768 + 256 bytes per
+    // wavefront, written bytewise, read back as the 192 + 64 dwords of the wavefront's 4 rows.
+    __shared__ uint32_t s_px[4][WARP_TH][48];  // [wavefront][row][dword]: 64 px x 3 B
+    __shared__ uint32_t s_mk[4][WARP_TH][16];  // [wavefront][row][dword]: 64 px x 1 B
+    const int wv = threadIdx.x >> 6;
+    const int xw = tile_x * WARP_TW + wv * 64;  // first column of this wavefront
+    const int y0 = tile_y * WARP_TH;
+    // columns / rows beyond the image are computed on clamped table entries (harmless) and never stored
+    const float2 ct = colT[min(xw + lane, dw - 1)];
     const float omt = fsub(1.f, P.t[2]);
-    const float2 rt = rowT[y];
     float xs[4], ys[4], zs[4];
     // every division of this lane may use the shared-reciprocal sequence: all |z| (z for the rotation warpers,
     // which also need z > 0) in [2^-60, 2^60] and all |x|, |y| <= 2^60.  Evaluated as integer min / max of the
     // float bit patterns of z (a NaN z is "too big" or negative there, so it cannot slip through a NaN-dropping
     // fp min) and one fp max over |x|, |y| (a NaN numerator gives NaN on both division paths).
 #pragma unroll
-    for (int j = 0; j < 4; j++) project_xyz<TYPE>(P, ca[j], cb[j], rt.x, rt.y, omt, xs[j], ys[j], zs[j]);
+    for (int j = 0; j < 4; j++) {
+        const float2 rt = rowT[min(y0 + j, dh - 1)];
+        project_xyz<TYPE>(P, ct.x, ct.y, rt.x, rt.y, omt, xs[j], ys[j], zs[j]);
+    }
     int zb[4];
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -418,8 +423,8 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
             }
         }
     }
-    uint32_t out[3] = {0, 0, 0};
-    uint32_t mout = 0;
+    uint8_t* const lpx = reinterpret_cast<uint8_t*>(&s_px[wv][0][0]) + lane * 3;  // + 192 per row, + channel
+    uint8_t* const lmk = reinterpret_cast<uint8_t*>(&s_mk[wv][0][0]) + lane;      // + 64 per row
     bool interior = false;
     float x32[4], y32[4];
     if (IMG) {
@@ -440,9 +445,7 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
         const uint32_t stride = sstride;
         // Every channel value comes out of its dot product already in byte 2 of the register:
         //   64 * (h0 * (32 - fx) + h1 * fx + 512)  =  ((h0 * (32 - fx) + h1 * fx + 512) >> 10) << 16  + a remainder below bit 16
-        // (weights scaled by 64: <= 2048, sums < 2^25), so the 12 result bytes of the lane's four pixels are placed into
-        // the three output dwords by byte permutes alone: no shifts, masks or ors.
-        uint32_t X[4][3];
+        // (weights scaled by 64: <= 2048, sums < 2^25): the byte is stored to LDS as it is (ds_write_b8_d16_hi).
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int sx = (int)rintf(x32[j]), sy = (int)rintf(y32[j]);  // cvRound; in range by the interior test
@@ -463,41 +466,42 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
                 const uint32_t sel = c == 0 ? 0x0c030c00u : (c == 1 ? 0x0c040c01u : 0x0c050c02u);
                 const v2h t0 = as_v2h(__builtin_amdgcn_perm(h0, l0, sel)), t1 = as_v2h(__builtin_amdgcn_perm(h1, l1, sel));
                 const v2h v = t0 * as_v2h(wy0) + t1 * as_v2h(wy1);  // vertical lerp of both taps, <= 255 * 32
-                X[j][c] = __builtin_amdgcn_udot2(v, as_v2h(wx), 32768u, false);
+                lpx[192 * j + c] = (uint8_t)(__builtin_amdgcn_udot2(v, as_v2h(wx), 32768u, false) >> 16);
             }
+            if (MASK) lmk[64 * j] = 255;  // interior taps => the rounded sample position is inside as well
         }
-        // v_perm_b32(hi, lo, sel): selector bytes 0-3 take lo's bytes, 4-7 hi's, 0x0c gives zero
-        constexpr uint32_t SEL_A = 0x0c0c0602u;  // (lo.b2, hi.b2, 0, 0)
-        constexpr uint32_t SEL_B = 0x0c060100u;  // (lo.b0, lo.b1, hi.b2, 0)
-        constexpr uint32_t SEL_C = 0x06020100u;  // (lo.b0, lo.b1, lo.b2, hi.b2)
-        uint32_t t;
-        t = __builtin_amdgcn_perm(X[0][1], X[0][0], SEL_A);  // b0 g0
-        t = __builtin_amdgcn_perm(X[0][2], t, SEL_B);        // b0 g0 r0
-        out[0] = __builtin_amdgcn_perm(X[1][0], t, SEL_C);   // b0 g0 r0 b1
-        t = __builtin_amdgcn_perm(X[1][2], X[1][1], SEL_A);  // g1 r1
-        t = __builtin_amdgcn_perm(X[2][0], t, SEL_B);        // g1 r1 b2
-        out[1] = __builtin_amdgcn_perm(X[2][1], t, SEL_C);   // g1 r1 b2 g2
-        t = __builtin_amdgcn_perm(X[3][0], X[2][2], SEL_A);  // r2 b3
-        t = __builtin_amdgcn_perm(X[3][1], t, SEL_B);        // r2 b3 g3
-        out[2] = __builtin_amdgcn_perm(X[3][2], t, SEL_C);   // r2 b3 g3 r3
-        mout = 0xffffffffu;  // interior taps => the rounded sample position is inside as well
     } else {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            if (IMG) put_px(out, j, sample_border(P, xs[j], ys[j]));
+            if (IMG) {
+                const uint32_t px = sample_border(P, xs[j], ys[j]);
+                lpx[192 * j] = (uint8_t)px;
+                lpx[192 * j + 1] = (uint8_t)(px >> 8);
+                lpx[192 * j + 2] = (uint8_t)(px >> 16);
+            }
             if (MASK) {
                 const bool in = xs[j] >= -0.5f && xs[j] < mx_hi && ys[j] >= -0.5f && ys[j] < my_hi;
-                mout |= (in ? 255u : 0u) << (8 * j);
+                lmk[64 * j] = in ? 255 : 0;
             }
         }
     }
+    __syncthreads();
     if (IMG) {
-        uint32_t* d = reinterpret_cast<uint32_t*>((uint8_t*)dimg_a + (long long)y * dimg_stride + (long long)x0 * 3);
-        d[0] = out[0];
-        d[1] = out[1];
-        d[2] = out[2];
+        // the wavefront's 4 x 48 dwords leave as three coalesced stores per lane; a dword is skipped when it would pass
+        // the end of the row pitch (last tile of a row) or of the image (last tile row)
+        uint8_t* const drow = (uint8_t*)dimg_a + (long long)xw * 3;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int idx = lane + 64 * k, r = idx / 48, cdw = idx - r * 48;
+            if (y0 + r < dh && (long long)xw * 3 + cdw * 4 + 4 <= dimg_stride)
+                *reinterpret_cast<uint32_t*>(drow + (long long)(y0 + r) * dimg_stride + cdw * 4) = s_px[wv][r][cdw];
+        }
     }
-    if (MASK) *reinterpret_cast<uint32_t*>((uint8_t*)dmask_a + (long long)y * dmask_stride + x0) = mout;
+    if (MASK) {
+        const int r = lane >> 4, cdw = lane & 15;
+        if (y0 + r < dh && (long long)xw + cdw * 4 + 4 <= dmask_stride)
+            *reinterpret_cast<uint32_t*>((uint8_t*)dmask_a + (long long)(y0 + r) * dmask_stride + xw + cdw * 4) = s_mk[wv][r][cdw];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
