@@ -209,6 +209,10 @@ int stx_blend_contrib_rect(const stx_blender* b, int img_w, int img_h, int tlx, 
                            int out_rect_xywh[4], size_t* out_bytes);
 int stx_blend_export_contrib(stx_blender* b, int order, int band_x0, int band_x1, stx_buf** out_packed,
                              int out_rect_xywh[4]);
+/* all the strips a rank owes in one call (n images / destination bands): same results, one kernel launch per kernel
+ * instantiation instead of one per strip and level; out_packed[n], out_rects_xywh[4 n] */
+int stx_blend_export_contribs(stx_blender* b, int n, const int* orders, const int* band_x0s, const int* band_x1s,
+                              stx_buf** out_packed, int* out_rects_xywh);
 /* build the pyramids of every image fed so far now (they are otherwise built at the first export / blend()):
  * a sharded rank calls it for its interior images while its strips are still in flight */
 int stx_blend_build(stx_blender* b);

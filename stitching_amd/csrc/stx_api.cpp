@@ -1441,45 +1441,89 @@ STX_EXPORT int stx_blend_contrib_rect(const stx_blender* b, int img_w, int img_h
 STX_EXPORT int stx_blend_export_contrib(stx_blender* b, int order, int band_x0, int band_x1, stx_buf** out_packed,
                                         int out_rect_xywh[4])
 {
-    if (!b || !out_packed || !out_rect_xywh) return stx_fail(STX_ERR_INVALID, "null argument");
+    return stx_blend_export_contribs(b, 1, &order, &band_x0, &band_x1, out_packed, out_rect_xywh);
+}
+
+// All strips a rank owes in one call: the (strip, level) argument blocks are grouped by kernel instantiation and every
+// group is ONE launch (blockIdx.z = block), instead of levels x strips small launches.
+STX_EXPORT int stx_blend_export_contribs(stx_blender* b, int n, const int* orders, const int* band_x0s, const int* band_x1s,
+                                         stx_buf** out_packed, int* out_rects_xywh)
+{
+    if (!b || n < 0 || (n > 0 && (!orders || !band_x0s || !band_x1s || !out_packed || !out_rects_xywh)))
+        return stx_fail(STX_ERR_INVALID, "null argument");
     if (b->kind != STX_BLEND_MULTIBAND) return stx_fail(STX_ERR_UNSUPPORTED, "multi-band blender only");
     if (b->finished) return stx_fail(STX_ERR_STATE, "export after blend()");
     if (!b->ctx) return stx_fail(STX_ERR_STATE, "geometry-only blender (created without a context)");
+    if (n == 0) return STX_OK;
     STX_TRY(stx_set_device(b->ctx));
-    const StxMbImage* src = nullptr;
-    for (const StxMbImage& im : b->images) if (im.kind == 0 && im.order == order) src = &im;
-    if (!src) return stx_fail(STX_ERR_INVALID, "no fed image with order %d", order);
-    int sx0, sx1;
-    if (!mb_contrib_range(b, src->fx, src->fw, band_x0, band_x1, &sx0, &sx1))
-        return stx_fail(STX_ERR_INVALID, "image %d does not reach the columns [%d,%d)", order, band_x0, band_x1);
-    const int nb = b->num_bands, sw = sx1 - sx0, sh = src->fh;
-    ContribLayout L;
-    mb_contrib_layout(nb, sw, sh, &L);
-    STX_TRY(mb_ensure_pyramids(b));
-    // re-find: mb_ensure_pyramids does not move descriptors, but keep the copy local anyway
-    StxMbImage one = *src;
-    stx_buf* packed = nullptr;
-    STX_TRY(stx_buf_new(b->ctx, (int)std::min<size_t>(L.bytes, 1u << 30), (int)((L.bytes + (1u << 30) - 1) >> 30), 1, STX_U8, &packed));
-    if (packed->stride * (size_t)packed->h < L.bytes) { stx_buf_release(packed); return stx_fail(STX_ERR_OOM, "contribution too large"); }
-    StxMbImage* d_one = nullptr;
-    int rc = mb_upload(b, &one, 1, &d_one);
-    std::vector<StxMbImage> single(1, one);
-    for (int lv = 0; lv <= nb && rc == STX_OK; lv++) {
-        MbLevelK K;
-        mb_fill_common(b, &K, d_one, 1, lv);
-        K.all_u8 = one.img0_is_s16 ? 0 : 1;
-        K.x0 = sx0 >> lv; K.x1 = sx1 >> lv; K.y0 = one.fy >> lv; K.y1 = (one.fy + sh) >> lv;
-        K.emit = 1;
-        K.out = (short*)(packed->ptr + L.g_off[lv]); K.out_stride = L.g_stride[lv];
-        K.out_plane = L.g_stride[lv] * std::max(sh >> lv, 1);
-        K.out_x0 = K.x0; K.out_y0 = K.y0;
-        K.out_w = (float*)(packed->ptr + L.w_off[lv]); K.out_w_stride = L.w_stride[lv];
-        rc = stx_launch_mb_level(b->ctx, K, mb_level_bytes(b, single, lv, K.x0, K.x1, true, false));
+    const int nb = b->num_bands;
+    std::vector<StxMbImage> srcs(n);
+    std::vector<int> sx0(n), sx1(n);
+    for (int i = 0; i < n; i++) {
+        const StxMbImage* src = nullptr;
+        for (const StxMbImage& im : b->images) if (im.kind == 0 && im.order == orders[i]) src = &im;
+        if (!src) return stx_fail(STX_ERR_INVALID, "no fed image with order %d", orders[i]);
+        if (!mb_contrib_range(b, src->fx, src->fw, band_x0s[i], band_x1s[i], &sx0[i], &sx1[i]))
+            return stx_fail(STX_ERR_INVALID, "image %d does not reach the columns [%d,%d)", orders[i], band_x0s[i], band_x1s[i]);
+        srcs[i] = *src;
     }
-    if (rc != STX_OK) { stx_buf_release(packed); return rc; }
-    out_rect_xywh[0] = sx0; out_rect_xywh[1] = one.fy; out_rect_xywh[2] = sw; out_rect_xywh[3] = sh;
-    packed->mask_binary = (!one.img0_is_s16 && one.mask_binary) ? 1 : 0;  // read back with stx_buf_flags
-    *out_packed = packed;
+    STX_TRY(mb_ensure_pyramids(b));
+    std::vector<stx_buf*> packed(n, nullptr);
+    auto release_all = [&]() { for (stx_buf* p : packed) stx_buf_release(p); };
+    std::vector<ContribLayout> Ls(n);
+    for (int i = 0; i < n; i++) {
+        mb_contrib_layout(nb, sx1[i] - sx0[i], srcs[i].fh, &Ls[i]);
+        int rc = stx_buf_new(b->ctx, (int)std::min<size_t>(Ls[i].bytes, 1u << 30), (int)((Ls[i].bytes + (1u << 30) - 1) >> 30), 1, STX_U8,
+                             &packed[i]);
+        if (rc == STX_OK && packed[i]->stride * (size_t)packed[i]->h < Ls[i].bytes) rc = stx_fail(STX_ERR_OOM, "contribution too large");
+        if (rc != STX_OK) { release_all(); return rc; }
+    }
+    StxMbImage* d_srcs = nullptr;
+    int rc = mb_upload(b, srcs.data(), n, &d_srcs);
+    if (rc != STX_OK) { release_all(); return rc; }
+    // one argument block per (strip, level), sorted by the kernel instantiation it needs
+    struct Item { int cls; MbLevelK K; };
+    std::vector<Item> items;
+    double bytes = 0.0;
+    for (int i = 0; i < n; i++) {
+        const StxMbImage& one = srcs[i];
+        const int sh = one.fh;
+        std::vector<StxMbImage> single(1, one);
+        for (int lv = 0; lv <= nb; lv++) {
+            MbLevelK K;
+            mb_fill_common(b, &K, d_srcs + i, 1, lv);
+            K.all_u8 = one.img0_is_s16 ? 0 : 1;
+            K.x0 = sx0[i] >> lv; K.x1 = sx1[i] >> lv; K.y0 = one.fy >> lv; K.y1 = (one.fy + sh) >> lv;
+            K.emit = 1;
+            K.out = (short*)(packed[i]->ptr + Ls[i].g_off[lv]); K.out_stride = Ls[i].g_stride[lv];
+            K.out_plane = Ls[i].g_stride[lv] * std::max(sh >> lv, 1);
+            K.out_x0 = K.x0; K.out_y0 = K.y0;
+            K.out_w = (float*)(packed[i]->ptr + Ls[i].w_off[lv]); K.out_w_stride = Ls[i].w_stride[lv];
+            if (K.x1 <= K.x0 || K.y1 <= K.y0) continue;
+            Item it;
+            it.cls = stx_fast_mb_emit_class(K, &it.K);
+            if (it.cls < 0) it.cls = lv == 0 ? -1 : -2;  // generic kernel, level 0 / level >= 1 instantiation
+            items.push_back(it);
+            bytes += mb_level_bytes(b, single, lv, K.x0, K.x1, true, false);
+        }
+    }
+    std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& c) { return a.cls < c.cls; });
+    std::vector<MbLevelK> Ks(items.size());
+    std::vector<int> classes(items.size());
+    for (size_t i = 0; i < items.size(); i++) { Ks[i] = items[i].K; classes[i] = items[i].cls; }
+    void* d_Ks = nullptr;
+    rc = upload_small(b->ctx, Ks.data(), Ks.size() * sizeof(MbLevelK), &d_Ks);
+    if (rc == STX_OK) {
+        rc = stx_launch_mb_emit_batch(b->ctx, (const MbLevelK*)d_Ks, Ks.data(), classes.data(), (int)Ks.size(), bytes);
+        stx_dev_free(b->ctx, d_Ks);  // stream-ordered reuse
+    }
+    if (rc != STX_OK) { release_all(); return rc; }
+    for (int i = 0; i < n; i++) {
+        out_rects_xywh[4 * i] = sx0[i]; out_rects_xywh[4 * i + 1] = srcs[i].fy;
+        out_rects_xywh[4 * i + 2] = sx1[i] - sx0[i]; out_rects_xywh[4 * i + 3] = srcs[i].fh;
+        packed[i]->mask_binary = (!srcs[i].img0_is_s16 && srcs[i].mask_binary) ? 1 : 0;  // read back with stx_buf_flags
+        out_packed[i] = packed[i];
+    }
     return STX_OK;
 }
 

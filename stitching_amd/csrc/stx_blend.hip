@@ -156,7 +156,7 @@ STX_DEV int pyr_up_at(const short* __restrict__ plane, long long stride, int cw,
 
 // gather + normalise + collapse of one level (generic, one pixel per lane; all levels, all kinds)
 template <bool L0>
-__global__ __launch_bounds__(256) void mb_level_kernel(MbLevelK P)
+STX_DEV void mb_level_body(const MbLevelK& P)
 {
     const int x = P.x0 + blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = P.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -248,6 +248,19 @@ __global__ __launch_bounds__(256) void mb_level_kernel(MbLevelK P)
         short* o16 = reinterpret_cast<short*>(reinterpret_cast<uint8_t*>(P.pano16) + (long long)oy * P.pano16_stride) + ox * 3;
         o16[0] = (short)v[0]; o16[1] = (short)v[1]; o16[2] = (short)v[2];
     }
+}
+
+template <bool L0>
+__global__ __launch_bounds__(256) void mb_level_kernel(MbLevelK P)
+{
+    mb_level_body<L0>(P);
+}
+
+// batched strip export through the generic kernel: blockIdx.z picks the argument block (see mb_emit_multi_kernel)
+template <bool L0>
+__global__ __launch_bounds__(256) void mb_level_multi_kernel(const MbLevelK* __restrict__ Ps)
+{
+    mb_level_body<L0>(Ps[blockIdx.z]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -515,6 +528,32 @@ int stx_launch_mb_level(stx_ctx* ctx, const MbLevelK& K, double algo_bytes)
     if (K.level == 0) hipLaunchKernelGGL(mb_level_kernel<true>, grid, dim3(256), 0, ctx->stream, K);
     else hipLaunchKernelGGL(mb_level_kernel<false>, grid, dim3(256), 0, ctx->stream, K);
     return check_launch("mb_level");
+}
+
+int stx_launch_mb_emit_batch(stx_ctx* ctx, const MbLevelK* d_Ks, const MbLevelK* h_Ks, const int* classes, int n, double bytes)
+{
+    if (n <= 0) return STX_OK;
+    StxProfScope prof(ctx, "mb_contrib", bytes);
+    for (int start = 0; start < n;) {
+        int end = start;
+        // generic blocks split into level 0 (class -1 stays -1) and level >= 1 (-2) by the caller's sort key
+        while (end < n && classes[end] == classes[start]) end++;
+        const int cls = classes[start], count = end - start;
+        if (cls >= 0) {
+            if (!stx_fast_mb_emit_launch(ctx, cls, d_Ks + start, h_Ks + start, count)) return check_launch("mb_contrib");
+        } else {
+            int gx = 1, gy = 1;
+            for (int i = start; i < end; i++) {
+                gx = std::max(gx, (h_Ks[i].x1 - h_Ks[i].x0 + 63) / 64);
+                gy = std::max(gy, (h_Ks[i].y1 - h_Ks[i].y0 + 3) / 4);
+            }
+            const dim3 grid(gx, gy, count);
+            if (cls == -1) hipLaunchKernelGGL(mb_level_multi_kernel<true>, grid, dim3(256), 0, ctx->stream, d_Ks + start);
+            else hipLaunchKernelGGL(mb_level_multi_kernel<false>, grid, dim3(256), 0, ctx->stream, d_Ks + start);
+        }
+        start = end;
+    }
+    return check_launch("mb_contrib");
 }
 
 static void fill_feed(SimpleFeedK& K, const stx_buf* img, const stx_buf* mask, int dx, int dy)

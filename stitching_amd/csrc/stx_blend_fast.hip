@@ -584,7 +584,7 @@ STX_DEV void level_epilogue(const MbLevelK& P, int X0, int Y0, int (&acc)[2][8][
 // Both are compile-time so that the common single-GPU instantiation carries neither path.
 // U8SRC (levels >= 1): every image was fed as u8, so G_i is 0..255 and pyrUp / the Laplacian run in packed 16-bit lanes
 template <bool L0, bool CONTRIB, bool EMIT, bool U8SRC>
-__global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
+STX_DEV void mb_level_fast_body(const MbLevelK& P)
 {
     const int tid = threadIdx.x;
     const int lv = P.level;
@@ -782,6 +782,20 @@ __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
     }
 
     level_epilogue<L0>(P, X0, Y0, acc, ws);
+}
+
+template <bool L0, bool CONTRIB, bool EMIT, bool U8SRC>
+__global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
+{
+    mb_level_fast_body<L0, CONTRIB, EMIT, U8SRC>(P);
+}
+
+// Strip export for sharded blending: ONE launch for all (strip, level) pairs that take the same instantiation; blockIdx.z
+// picks the argument block from a device array, blocks beyond a member's own tile grid leave at once.
+template <bool L0, bool U8SRC>
+__global__ __launch_bounds__(256) void mb_emit_multi_kernel(const MbLevelK* __restrict__ Ps)
+{
+    mb_level_fast_body<L0, false, true, U8SRC>(Ps[blockIdx.z]);
 }
 
 
@@ -1148,7 +1162,8 @@ bool stx_fast_mb_down_batch(stx_ctx* ctx, const StxMbImage* d_images, const StxM
     return launched_ok();
 }
 
-bool stx_fast_mb_level(stx_ctx* ctx, const MbLevelK& K)
+// preconditions of the register-blocked gather kernels; fills the tile map
+static bool fast_level_ok(const MbLevelK& K, MbLevelK* KT)
 {
     // 8-pixel strips must never straddle a feed-rectangle edge: 2^(B - level) >= 8; all origins 8-aligned
     if (K.num_bands - K.level < 3) return false;
@@ -1156,8 +1171,35 @@ bool stx_fast_mb_level(stx_ctx* ctx, const MbLevelK& K)
     if (K.up && ((K.up_x0 | K.up_y0) & 3)) return false;
     if (K.n_images > 255) return false;
     // vertically adjacent 512 x 8 tiles share the G_{i+1} / finished-level rows of their pyrUp halos: keep them on one XCD
-    MbLevelK KT = K;
-    KT.tiles = stx_tile_map((K.x1 - K.x0 + 511) / 512, (K.y1 - K.y0 + 7) / 8, LV_BAND);
+    *KT = K;
+    KT->tiles = stx_tile_map((K.x1 - K.x0 + 511) / 512, (K.y1 - K.y0 + 7) / 8, LV_BAND);
+    return true;
+}
+
+// Batched strip export (emit): class of the instantiation a (strip, level) argument block needs — 0: level 0, 1: level >= 1 of
+// u8 pyramids, 2: level >= 1 general, -1: not eligible for the register-blocked kernels (generic kernel).  Fills the tile map.
+int stx_fast_mb_emit_class(const MbLevelK& K, MbLevelK* KT)
+{
+    if (!(K.level > 0 || K.all_u8) || !fast_level_ok(K, KT)) { *KT = K; return -1; }
+    return K.level == 0 ? 0 : (K.all_u8 ? 1 : 2);
+}
+
+// h_Ks: host copies of the `count` argument blocks at d_Ks, all of class `cls`
+bool stx_fast_mb_emit_launch(stx_ctx* ctx, int cls, const MbLevelK* d_Ks, const MbLevelK* h_Ks, int count)
+{
+    unsigned gx = 1;
+    for (int i = 0; i < count; i++) gx = std::max(gx, stx_tile_grid(h_Ks[i].tiles));
+    const dim3 grid(gx, 1, (unsigned)count);
+    if (cls == 0) hipLaunchKernelGGL((mb_emit_multi_kernel<true, false>), grid, dim3(256), 0, ctx->stream, d_Ks);
+    else if (cls == 1) hipLaunchKernelGGL((mb_emit_multi_kernel<false, true>), grid, dim3(256), 0, ctx->stream, d_Ks);
+    else hipLaunchKernelGGL((mb_emit_multi_kernel<false, false>), grid, dim3(256), 0, ctx->stream, d_Ks);
+    return launched_ok();
+}
+
+bool stx_fast_mb_level(stx_ctx* ctx, const MbLevelK& K)
+{
+    MbLevelK KT;
+    if (!fast_level_ok(K, &KT)) return false;
     dim3 grid(stx_tile_grid(KT.tiles), 1);
     hipStream_t st = ctx->stream;
     if (K.level == 0 && K.pk_ok && !K.emit && K.num_bands > 0) {

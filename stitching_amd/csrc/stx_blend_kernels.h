@@ -53,3 +53,9 @@ struct MbLevelK {
 // preconditions do not hold and the generic kernel must be used instead.
 bool stx_fast_mb_down_batch(stx_ctx* ctx, const StxMbImage* d_images, const StxMbImage* h_images, int n, int level);
 bool stx_fast_mb_level(stx_ctx* ctx, const MbLevelK& K);
+// batched strip export: see stx_blend_fast.hip
+int stx_fast_mb_emit_class(const MbLevelK& K, MbLevelK* KT);
+bool stx_fast_mb_emit_launch(stx_ctx* ctx, int cls, const MbLevelK* d_Ks, const MbLevelK* h_Ks, int count);
+// all argument blocks of one batched strip export (any mix of strips and levels): grouped by kernel instantiation,
+// one launch per group.  d_Ks mirrors h_Ks (sorted by class by the caller: classes[i] ascending); bytes: algorithmic bytes
+int stx_launch_mb_emit_batch(stx_ctx* ctx, const MbLevelK* d_Ks, const MbLevelK* h_Ks, const int* classes, int n, double bytes);

@@ -52,6 +52,19 @@ class ShardBlender(_BlenderHandle):
                                                           rect))
         return DeviceImage(self.ctx, out), tuple(int(v) for v in rect)
 
+    def export_contribs(self, items):
+        """items: [(order, band)] -> [(packed DeviceImage, rect)]: all strips in one call, one launch per kernel
+        instantiation instead of one per strip and level (stx_blend_export_contribs)."""
+        n = len(items)
+        if n == 0:
+            return []
+        orders = (C.c_int * n)(*[int(o) for o, _ in items])
+        x0s = (C.c_int * n)(*[int(b[0]) for _, b in items])
+        x1s = (C.c_int * n)(*[int(b[1]) for _, b in items])
+        outs, rects = (C.c_void_p * n)(), (C.c_int * (4 * n))()
+        _lib.check(self.ctx._lib.stx_blend_export_contribs(self._h, n, orders, x0s, x1s, outs, rects))
+        return [(DeviceImage(self.ctx, C.c_void_p(outs[i])), tuple(int(v) for v in rects[4 * i:4 * i + 4])) for i in range(n)]
+
     def build(self):
         """Build the pyramids of everything fed so far (otherwise deferred to the first export / blend())."""
         _lib.check(self.ctx._lib.stx_blend_build(self._h))
@@ -354,8 +367,8 @@ class ShardedStitchJob:
             senders = sorted({m[0] for m in send_msgs}) if self.split_boundary else list(self.my_orders)
             self._warp_and_feed(blender, [k for k in self.my_orders if k in senders], p)
             sends = []
-            for (k, _src, dst, rect, nbytes) in send_msgs:
-                packed, r = blender.export_contrib(k, p.band(dst))
+            exported = blender.export_contribs([(k, p.band(dst)) for (k, _src, dst, _rect, _nbytes) in send_msgs])
+            for (k, _src, dst, rect, nbytes), (packed, r) in zip(send_msgs, exported):
                 if r != rect:
                     raise StitchingError("contribution geometry differs from the plan")
                 sends.append((dst, packed, nbytes))
