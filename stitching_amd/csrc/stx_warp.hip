@@ -43,13 +43,20 @@ struct WarpK {
     long long dimg_stride;
     uint8_t* dmask;
     long long dmask_stride;
-    // interior test of the fast kernel, in 1/32-px units: cvRound(v) >> 5 in [0, n-2]  <=>  -0.5 <= v < 32(n-1) - 0.5
     int band_rows;      // fast kernel: tile rows per XCD band
     int tiles_x, tiles_y, band_tiles;
     uint32_t magic_tx, magic_band;  // floor(2^32 / d) + 1 for d = tiles_x, band_tiles
-    float bx_hi, by_hi;
-    // nearest-neighbour inside test: cvRound(v) in [0, n-1]  <=>  -0.5 <= v < m_hi (ties go to even)
-    float mx_hi, my_hi;
+    // Fast kernel, sample positions in 1/32-px units.  s = cvRound(32 v) is read off the bit pattern of
+    // fl(32 v + 1.5 * 2^23) = RND_U0 + s (round-half-even of the fp add = cvRound, |32 v| < 2^22), so ranges of s are
+    // unsigned ranges of that pattern and a NaN / infinite coordinate is above every upper bound.
+    //   interior: s >> 5 in [0, n-2]                       <=>  pattern in [RND_U0, u*_int]
+    //   zone    : s >> 5 in [-n, 2n-2] and inside int16    <=>  pattern in [u*_zlo, u*_zhi]  (one mirror image away)
+    uint32_t ux_int, uy_int;
+    uint32_t ux_zlo, ux_zhi, uy_zlo, uy_zhi;
+    // nearest-neighbour inside test on 32 v: cvRound(v) in [0, n-1]  <=>  -16 <= 32 v < m32_hi (ties go to even)
+    float mx32_hi, my32_hi;
+    float c2, c5, c8;  // plane: kr2 (1 - t2), kr5 (1 - t2), kr8 (1 - t2), each rounded once (host fp32 = device fp32)
+    int num_ok;  // host-proved: |numerators| <= 2^60 and finite tables, the per-lane magnitude test is skipped
 };
 
 // Up to WARP_BATCH images per launch: the per-image argument blocks travel in the kernel-argument segment
@@ -58,8 +65,11 @@ constexpr int WARP_BATCH = 8;
 struct WarpBatchK {
     WarpK k[WARP_BATCH];
     float2* colT[WARP_BATCH];
-    float2* rowT[WARP_BATCH];
+    // row table, in blocks of 4 destination rows (one tile row): rowT[4 b + 0..3] = {ra x4}, {p1 x4}, {p4 x4}, {p7 x4} of rows
+    // 4 b .. 4 b + 3 (rows beyond the image repeat the last one); rowT[dh4 + r / 4][r % 4] = rb of row r (dh4 = dh rounded up to 4)
+    float4* rowT[WARP_BATCH];
 };
+constexpr uint32_t RND_U0 = 0x4B400000u;  // bit pattern of 1.5 * 2^23
 
 STX_DEV uint32_t ldg32(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
 
@@ -85,36 +95,48 @@ STX_DEV uint32_t bil(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, uin
 }
 
 // Separable part of mapBackward, evaluated once per destination column / row (fp64 "exact" trig):
-//   spherical  : col = (sin u', cos u'),           row = (sin(pi - v'), cos(pi - v'))
-//   cylindrical: col = (sin u', cos u'),           row = (v', -)
-//   plane      : col = (u'/scale - t0, -),         row = (v'/scale - t1, -)
+//   spherical  : col = (sin u', cos u'),           row: ra = sin(pi - v'), rb = cos(pi - v')
+//   cylindrical: col = (sin u', cos u'),           row: ra = v'
+//   plane      : col = (u'/scale - t0, -),         row: ra = v'/scale - t1
+// plus the products of the projector that depend on the row only, each rounded once exactly as the per-pixel
+// evaluation rounds it (dot3 = (k0 x_ + k1 y_) + k2 z_ with y_ = rb / ra / ra):
+//   p1 = kr1 y_, p4 = kr4 y_, p7 = kr7 y_;  plane: c2 = kr2 (1 - t2), c5 = kr5 (1 - t2), c8 = kr8 (1 - t2)
+STX_DEV int round_up4(int v) { return (v + 3) & ~3; }
+
 template <int TYPE>
 __global__ __launch_bounds__(256) void warp_tables_kernel(WarpBatchK B)
 {
     const WarpK& P = B.k[blockIdx.y];
     float2* __restrict__ colT = B.colT[blockIdx.y];
-    float2* __restrict__ rowT = B.rowT[blockIdx.y];
+    float* __restrict__ rowT = reinterpret_cast<float*>(B.rowT[blockIdx.y]);
     const int i = blockIdx.x * 256 + threadIdx.x;
+    const int dh4 = round_up4(P.dh);
     if (i < P.dw) {
         const float uu = (float)(P.tlx + i);
         float2 o = make_float2(0.f, 0.f);
         if (TYPE == STX_WARP_SPHERICAL || TYPE == STX_WARP_CYLINDRICAL) sincosf_x(fdiv(uu, P.scale), &o.x, &o.y);
         else o.x = fsub(fdiv(uu, P.scale), P.t[0]);
         colT[i] = o;
-    } else if (i < P.dw + P.dh) {
-        const int r = i - P.dw;
+    } else if (i < P.dw + dh4) {
+        const int slot = i - P.dw, r = min(slot, P.dh - 1);  // the padding rows repeat the last row
         const float vv = (float)(P.tly + r);
-        float2 o = make_float2(0.f, 0.f);
-        if (TYPE == STX_WARP_SPHERICAL) sincosf_x(fsub(PI_F, fdiv(vv, P.scale)), &o.x, &o.y);
-        else if (TYPE == STX_WARP_CYLINDRICAL) o.x = fdiv(vv, P.scale);
-        else o.x = fsub(fdiv(vv, P.scale), P.t[1]);
-        rowT[r] = o;
+        float ra = 0.f, rb = 0.f;
+        if (TYPE == STX_WARP_SPHERICAL) sincosf_x(fsub(PI_F, fdiv(vv, P.scale)), &ra, &rb);
+        else if (TYPE == STX_WARP_CYLINDRICAL) ra = fdiv(vv, P.scale);
+        else ra = fsub(fdiv(vv, P.scale), P.t[1]);
+        const float y_ = TYPE == STX_WARP_SPHERICAL ? rb : ra;
+        float* blk = rowT + 16 * (slot >> 2) + (slot & 3);
+        blk[0] = ra;
+        blk[4] = fmul(P.kr[1], y_);
+        blk[8] = fmul(P.kr[4], y_);
+        blk[12] = fmul(P.kr[7], y_);
+        rowT[4 * dh4 + slot] = rb;
     }
 }
 
 // One lane = 4 adjacent destination pixels of one row; one wave = 256 px of a row; block = 4 rows.
 template <int TYPE, bool IMG, bool MASK>
-__global__ __launch_bounds__(256) void warp_kernel(WarpK P, const float2* __restrict__ colT, const float2* __restrict__ rowT)
+__global__ __launch_bounds__(256) void warp_kernel(WarpK P, const float2* __restrict__ colT, const float4* __restrict__ rowT)
 {
     const int lane = threadIdx.x & 63;
     const int x0 = blockIdx.x * WARP_TW + lane * 4;
@@ -128,8 +150,8 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpK P, const float2* __rest
         ca[0] = c01.x; cb[0] = c01.y; ca[1] = c01.z; cb[1] = c01.w;
         ca[2] = c23.x; cb[2] = c23.y; ca[3] = c23.z; cb[3] = c23.w;
     }
-    const float2 rt = rowT[y];
-    const float ra = rt.x, rb = rt.y;
+    const float* rowF = reinterpret_cast<const float*>(rowT);
+    const float ra = rowF[16 * (y >> 2) + (y & 3)], rb = rowF[4 * round_up4(P.dh) + y];
     const float omt = fsub(1.f, P.t[2]);
     uint32_t out[3] = {0, 0, 0};
     uint32_t mout = 0;
@@ -215,20 +237,28 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpK P, const float2* __rest
 
 
 // ---------------------------------------------------------------------------------------------
-// Fast kernel.  Same results as warp_kernel (bit for bit), about half the VALU work:
+// Fast kernel.  Same results as warp_kernel (bit for bit), well under half the VALU work:
+//   * the products of the projector that depend on the row only come from the row table, those that depend on the
+//     column only are formed once per lane (a lane owns one column, its 4 pixels one below the other);
 //   * x/z and y/z share one Newton-refined reciprocal and finish with the fma sequence of the IEEE
 //     division expansion (correctly rounded whenever no rescaling is needed: |z| in [2^-60, 2^60],
 //     |x|, |y| <= 2^60; anything else takes __fdiv_rn);
-//   * a lane whose four pixels all sample the interior of the source (decided on the fp32 values, so
-//     no cvRound range emulation, no short saturation, no border arithmetic) does the Q15 bilinear
-//     blend with packed 16-bit ops: per channel 2 v_perm + v_pk_mul/mad_u16 (vertical lerp of both
-//     taps) + v_dot2_u32_u16 (horizontal lerp + 512), and knows its mask is 255;
-//   * every other lane runs the generic per-pixel code.
-// Preconditions (host): source < 2^31 bytes, sw, sh <= 32767, no nearest-neighbour source image.
+//   * cvRound(32 v) is one fp add (RND_U0 trick, see WarpK); the range tests are unsigned min / max of the patterns;
+//   * the sampling path is chosen PER WAVEFRONT (ballots), so no wavefront runs two of them:
+//       interior : every sample of the wavefront has its 4 taps inside the source — packed 16-bit blend, per channel
+//                  2 v_perm + v_pk_mul/mad_u16 (vertical lerp of both taps) + v_dot2_u32_u16 (horizontal lerp + rounding);
+//       mirror   : every sample is at most one mirror image away from the source (BORDER_REFLECT).  Mirroring the
+//                  position (s -> -s - 32 below, s -> 64 n - 32 - s above, clamped at the edges where both taps fall on
+//                  the edge pixel) turns the two reflected taps into an adjacent pixel pair again, weights in [0, 32]:
+//                  the interior code with 7 more integer ops per axis.  Masks by the nearest-neighbour range test;
+//       generic  : anything else (several mirror images away, divisions that need rescaling): per-tap borderInterpolate.
+// Preconditions (host): source < 2^31 bytes, 2 <= sw, sh <= 32767, no nearest-neighbour source image.
 // ---------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned short v2h __attribute__((ext_vector_type(2)));
 #define STX_GAS __attribute__((address_space(1)))
+#define STX_CAS __attribute__((address_space(4)))
 
 STX_DEV v2h as_v2h(uint32_t v) { return __builtin_bit_cast(v2h, v); }
 
@@ -248,31 +278,308 @@ STX_DEV void div2_fast(float d, float n0, float n1, float& q0, float& q1)
     q1 = t.y;
 }
 
-// numerators and denominator of mapBackward for one pixel (exactly the arithmetic of warp_kernel)
-template <int TYPE>
-STX_DEV void project_xyz(const WarpK& P, float ca, float cb, float ra, float rb, float omt, float& x, float& yy, float& z)
+// One BORDER_REFLECT tap: the 3 bytes of source pixel (sx, sy) in the low 24 bits (32-bit offsets, global loads)
+STX_DEV uint32_t tap24(const STX_GAS uint8_t* src, uint32_t stride, int sx, int sy)
 {
-    if (TYPE == STX_WARP_PLANE || TYPE == STX_WARP_AFFINE) {
-        x = fadd(fadd(fmul(P.kr[0], ca), fmul(P.kr[1], ra)), fmul(P.kr[2], omt));
-        yy = fadd(fadd(fmul(P.kr[3], ca), fmul(P.kr[4], ra)), fmul(P.kr[5], omt));
-        z = fadd(fadd(fmul(P.kr[6], ca), fmul(P.kr[7], ra)), fmul(P.kr[8], omt));
-    } else {
-        float x_, y_, z_;
-        if (TYPE == STX_WARP_SPHERICAL) {
-            x_ = fmul(ra, ca);
-            y_ = rb;
-            z_ = fmul(ra, cb);
-        } else {
-            x_ = ca;
-            y_ = ra;
-            z_ = cb;
-        }
-        x = dot3(P.kr[0], x_, P.kr[1], y_, P.kr[2], z_);
-        yy = dot3(P.kr[3], x_, P.kr[4], y_, P.kr[5], z_);
-        z = dot3(P.kr[6], x_, P.kr[7], y_, P.kr[8], z_);
+    const uint32_t off = (uint32_t)sy * stride + (uint32_t)sx * 3u;
+    const STX_GAS uint32_t* q = reinterpret_cast<const STX_GAS uint32_t*>(src + (off & ~3u));
+    return __builtin_amdgcn_alignbyte(q[1], q[0], off & 3u);
+}
+
+// remapBilinear with BORDER_REFLECT on every tap (borderInterpolate per tap, cvRound / short saturation emulated
+// exactly); x32, y32 = 32 x, 32 y.  Same packed blend as the interior path.  Fast-kernel preconditions apply.
+STX_DEV uint32_t sample_border(const STX_GAS uint8_t* src, uint32_t stride, int sw, int sh, float x32, float y32)
+{
+    const int sx = cv_round(x32), sy = cv_round(y32);
+    const uint32_t fx = (uint32_t)sx & 31u, fy = (uint32_t)sy & 31u;
+    const int ix = sat_s16(sx >> 5), iy = sat_s16(sy >> 5);
+    const int sx0 = reflect(ix, sw), sx1 = reflect(ix + 1, sw);
+    const int sy0 = reflect(iy, sh), sy1 = reflect(iy + 1, sh);
+    const uint32_t t00 = tap24(src, stride, sx0, sy0), t01 = tap24(src, stride, sx1, sy0);
+    const uint32_t t10 = tap24(src, stride, sx0, sy1), t11 = tap24(src, stride, sx1, sy1);
+    const uint32_t wy1 = fy * 0x10001u, wy0 = 0x200020u - wy1;
+    const uint32_t wx = fx * 0xffffu + 32u;
+    uint32_t o[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const uint32_t sel = c == 0 ? 0x0c040c00u : (c == 1 ? 0x0c050c01u : 0x0c060c02u);  // byte c of both taps
+        const v2h a = as_v2h(__builtin_amdgcn_perm(t01, t00, sel)), b = as_v2h(__builtin_amdgcn_perm(t11, t10, sel));
+        const v2h v = a * as_v2h(wy0) + b * as_v2h(wy1);
+        o[c] = __builtin_amdgcn_udot2(v, as_v2h(wx), 512u, false) >> 10;
+    }
+    return o[0] | (o[1] << 8) | (o[2] << 16);
+}
+
+// The adjacent pixel pair (pixel ix and ix + 1 of row iy and of row iy + 1), weights fx, fy in [0, 32] for the right /
+// lower one: three channel bytes to LDS at p[0..2].  Every channel value comes out of its dot product already in byte 2
+// of the register:  64 (h0 (32 - fx) + h1 fx + 512) = ((h0 (32 - fx) + h1 fx + 512) >> 10) << 16 + a remainder below
+// bit 16 (weights scaled by 64: <= 2048, sums < 2^25); the byte is stored as it is (ds_write_b8_d16_hi).
+STX_DEV void blend_pair_to_lds(const STX_GAS uint8_t* src, uint32_t stride, uint32_t ix, uint32_t iy, uint32_t fx, uint32_t fy,
+                               uint8_t* p)
+{
+    // row < 2^15 and stride < 2^24 (fast_ok): 24-bit multiply, full rate
+    const uint32_t a = __umul24(iy, stride) + ix * 3u;
+    const STX_GAS uint32_t* q0 = reinterpret_cast<const STX_GAS uint32_t*>(src + (a & ~3u));
+    const STX_GAS uint32_t* q1 = reinterpret_cast<const STX_GAS uint32_t*>(src + ((a & ~3u) + stride));
+    const uint32_t d0 = q0[0], d1 = q0[1], d2 = q0[2], e0 = q1[0], e1 = q1[1], e2 = q1[2];
+    const uint32_t sh = a & 3u;
+    const uint32_t l0 = __builtin_amdgcn_alignbyte(d1, d0, sh), h0 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    const uint32_t l1 = __builtin_amdgcn_alignbyte(e1, e0, sh), h1 = __builtin_amdgcn_alignbyte(e2, e1, sh);
+    const uint32_t wy1 = fy * 0x10001u, wy0 = 0x200020u - wy1;  // (fy, fy), (32 - fy, 32 - fy)
+    const uint32_t wx = __umul24(fx, 0x3fffc0u) + 2048u;        // (64 (32 - fx), 64 fx)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        // (left tap, right tap) of channel c as two u16: bytes c and c + 3 of the 6-byte BGRBGR group
+        const uint32_t sel = c == 0 ? 0x0c030c00u : (c == 1 ? 0x0c040c01u : 0x0c050c02u);
+        const v2h t0 = as_v2h(__builtin_amdgcn_perm(h0, l0, sel)), t1 = as_v2h(__builtin_amdgcn_perm(h1, l1, sel));
+        const v2h v = t0 * as_v2h(wy0) + t1 * as_v2h(wy1);  // vertical lerp of both taps, <= 255 * 32
+        p[c] = (uint8_t)(__builtin_amdgcn_udot2(v, as_v2h(wx), 32768u, false) >> 16);
     }
 }
 
+// BORDER_REFLECT within one mirror image: position s (1/32 px, any value of the zone) -> base pixel and right weight
+STX_DEV void mirror_axis(int s, int n, uint32_t& ip, uint32_t& fp)
+{
+    int m = max(max(s, -32 - s), 0);                    // below the image: s -> -s - 32; both taps on pixel 0 -> 0
+    m = min(min(m, 64 * n - 32 - m), 32 * (n - 1));     // above: s -> 64 n - 32 - s; both taps on pixel n-1 -> 32 (n-1)
+    const int i = min(m >> 5, n - 2);
+    ip = (uint32_t)i;
+    fp = (uint32_t)(m - (i << 5));                      // 0..32
+}
+
+template <int TYPE, bool IMG, bool MASK>
+__global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
+{
+    const WarpK& P = B.k[blockIdx.z];
+    const float2* __restrict__ colT = B.colT[blockIdx.z];
+    const STX_CAS v4f* rowT = (const STX_CAS v4f*)B.rowT[blockIdx.z];  // wave-uniform reads: scalar loads
+    const int lane = threadIdx.x & 63;
+    // The per-image scalars of the tile-index math and of the tests below are fetched up front, as a few wide scalar
+    // loads with one wait: a wavefront lives for 256 pixels only, and the compiler otherwise sinks every one of these
+    // kernel-argument loads to its first use (about fifteen dependent scalar-cache round trips per wavefront).
+    int tiles_x = P.tiles_x, tiles_y = P.tiles_y, band_tiles = P.band_tiles, band_rows = P.band_rows;
+    uint32_t magic_tx = P.magic_tx, magic_band = P.magic_band;
+    int dw = P.dw, dh = P.dh;
+    uint32_t ux_int = P.ux_int, uy_int = P.uy_int;
+    int num_ok = P.num_ok;
+    unsigned long long src_a = (unsigned long long)P.src, dimg_a = (unsigned long long)P.dimg, dmask_a = (unsigned long long)P.dmask;
+    long long dimg_stride = P.dimg_stride, dmask_stride = P.dmask_stride;
+    uint32_t sstride = (uint32_t)P.sstride;
+    asm volatile("" : "+s"(tiles_x), "+s"(tiles_y), "+s"(band_tiles), "+s"(band_rows), "+s"(magic_tx), "+s"(magic_band), "+s"(dw),
+                 "+s"(dh), "+s"(ux_int), "+s"(uy_int), "+s"(num_ok));
+    asm volatile("" : "+s"(src_a), "+s"(dimg_a), "+s"(dmask_a), "+s"(dimg_stride), "+s"(dmask_stride), "+s"(sstride));
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only), and the
+    // per-XCD L2s do not share lines.  Bands of WARP_BAND tile rows go round-robin to the XCDs: vertically adjacent
+    // tiles — which read the same source rows — mostly meet in one L2 instead of fetching those rows once per
+    // XCD (measured for 8 frames of 36 MB: 605 MB fetched with the plain row-major order, 288 MB with whole-image
+    // eighths — but then the curved-border bands unbalance the XCDs — and 360 MB with bands of 4 tile rows; the
+    // kernel time is the same for all three).
+    // divisions by the per-image constants use host-made reciprocals (n * m >> 32, exact for n * d < 2^32)
+    const uint32_t local = blockIdx.x >> 3;
+    const uint32_t band_i = band_tiles == 1 ? local : __umulhi(local, magic_band);  // local / (band_rows * tiles_x)
+    const uint32_t within = local - band_i * (uint32_t)band_tiles;
+    const uint32_t wy = tiles_x == 1 ? within : __umulhi(within, magic_tx);  // within / tiles_x (2^32 / 1 has no 32-bit magic)
+    const int tile_x = (int)(within - wy * (uint32_t)tiles_x);
+    const int tile_y = (int)((band_i * 8u + (blockIdx.x & 7u)) * (uint32_t)band_rows + wy);
+    if (tile_y >= tiles_y) return;
+    // Lane layout: a wavefront covers 64 columns x WARP_TH rows, one lane = one column, its WARP_TH pixels one below
+    // the other (the workgroup's four wavefronts sit side by side: a 256 x 4 tile).  For every row the 64 lanes then
+    // gather from ADJACENT source positions — about 3 cache lines per load instruction instead of the 8 that four
+    // horizontal pixels per lane touched (one-line-gathers experiment: the scattered form cost 50 of 250 us) — and the
+    // row constants are wave-uniform.  The 3-byte results go through LDS to leave as whole dwords: 768 + 256 bytes per
+    // wavefront, written bytewise, read back as the 192 + 64 dwords of the wavefront's 4 rows.  Only the wavefront
+    // itself reads what it wrote (LDS operations of one wavefront execute in order): no workgroup barrier.
+    __shared__ uint32_t s_px[4][WARP_TH][48];  // [wavefront][row][dword]: 64 px x 3 B
+    __shared__ uint32_t s_mk[4][WARP_TH][16];  // [wavefront][row][dword]: 64 px x 1 B
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and known to be
+    const int xw = tile_x * WARP_TW + wv * 64;  // first column of this wavefront
+    const int y0 = tile_y * WARP_TH;
+    // columns beyond the image are computed on the clamped table entry, rows beyond it on the repeated last row
+    // (harmless) and never stored
+    const float2 ct = colT[min(xw + lane, dw - 1)];
+    // The wavefront's 4 rows as two row pairs: every step below is a packed fp32 operation on (row 2h, row 2h + 1).
+    // Row constants: one 64-byte block {ra x4}, {p1 x4}, {p4 x4}, {p7 x4} per tile row, a single scalar load.
+    const v4f RA = rowT[4 * tile_y], P1 = rowT[4 * tile_y + 1], P4 = rowT[4 * tile_y + 2], P7 = rowT[4 * tile_y + 3];
+    v2f X[2], Y[2], Z[2];
+    {
+        const v2f ra[2] = {{RA.x, RA.y}, {RA.z, RA.w}}, p1[2] = {{P1.x, P1.y}, {P1.z, P1.w}};
+        const v2f p4[2] = {{P4.x, P4.y}, {P4.z, P4.w}}, p7[2] = {{P7.x, P7.y}, {P7.z, P7.w}};
+        if (TYPE == STX_WARP_SPHERICAL) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const v2f x_ = ra[h] * ct.x, z_ = ra[h] * ct.y;
+                X[h] = (x_ * P.kr[0] + p1[h]) + z_ * P.kr[2];
+                Y[h] = (x_ * P.kr[3] + p4[h]) + z_ * P.kr[5];
+                Z[h] = (x_ * P.kr[6] + p7[h]) + z_ * P.kr[8];
+            }
+        } else {
+            // column-only products, once per lane
+            const float q0 = fmul(P.kr[0], ct.x), q3 = fmul(P.kr[3], ct.x), q6 = fmul(P.kr[6], ct.x);
+            float r2, r5, r8;
+            if (TYPE == STX_WARP_CYLINDRICAL) { r2 = fmul(P.kr[2], ct.y); r5 = fmul(P.kr[5], ct.y); r8 = fmul(P.kr[8], ct.y); }
+            else { r2 = P.c2; r5 = P.c5; r8 = P.c8; }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                X[h] = (p1[h] + q0) + r2;
+                Y[h] = (p4[h] + q3) + r5;
+                Z[h] = (p7[h] + q6) + r8;
+            }
+        }
+    }
+    // every division of this lane may use the shared-reciprocal sequence: all |z| (z for the rotation warpers,
+    // which also need z > 0) in [2^-60, 2^60] and all |x|, |y| <= 2^60.  Evaluated as integer min / max of the
+    // float bit patterns of z (a NaN z is "too big" or negative there, so it cannot slip through a NaN-dropping
+    // fp min) and one fp max over |x|, |y| (a NaN numerator gives NaN on both division paths) — the latter only when
+    // the host could not bound the numerators from the camera (num_ok: a wave-uniform branch).
+    int zb[4] = {__float_as_int(Z[0].x), __float_as_int(Z[0].y), __float_as_int(Z[1].x), __float_as_int(Z[1].y)};
+    if (TYPE == STX_WARP_PLANE || TYPE == STX_WARP_AFFINE) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) zb[j] &= 0x7fffffff;
+    }
+    const int zlo = min(min(zb[0], zb[1]), min(zb[2], zb[3])), zhi = max(max(zb[0], zb[1]), max(zb[2], zb[3]));
+    bool easy = zlo >= 0x21800000 /* 2^-60 */ && zhi <= 0x5d800000 /* 2^60 */;
+    if (!num_ok) {
+        const float nmax = fmaxf(fmaxf(fmaxf(fabsf(X[0].x), fabsf(Y[0].x)), fmaxf(fabsf(X[0].y), fabsf(Y[0].y))),
+                                 fmaxf(fmaxf(fabsf(X[1].x), fabsf(Y[1].x)), fmaxf(fabsf(X[1].y), fabsf(Y[1].y))));
+        easy = easy && nmax <= 0x1p60f;
+    }
+    if (easy) {
+        // x/z and y/z of a row pair: Newton-refined reciprocals, then the fma sequence of the IEEE division expansion
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const v2f d = Z[h], nd = -d;
+            v2f r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+            const v2f one = {1.0f, 1.0f};
+            const v2f e = __builtin_elementwise_fma(nd, r, one);
+            r = __builtin_elementwise_fma(e, r, r);
+            v2f t = X[h] * r;
+            v2f u = __builtin_elementwise_fma(nd, t, X[h]);
+            t = __builtin_elementwise_fma(u, r, t);
+            u = __builtin_elementwise_fma(nd, t, X[h]);
+            X[h] = __builtin_elementwise_fma(u, r, t);
+            t = Y[h] * r;
+            u = __builtin_elementwise_fma(nd, t, Y[h]);
+            t = __builtin_elementwise_fma(u, r, t);
+            u = __builtin_elementwise_fma(nd, t, Y[h]);
+            Y[h] = __builtin_elementwise_fma(u, r, t);
+        }
+    } else {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const float z = e ? Z[h].y : Z[h].x, x = e ? X[h].y : X[h].x, y = e ? Y[h].y : Y[h].x;
+                float qx = -1.f, qy = -1.f;
+                if (TYPE == STX_WARP_PLANE || TYPE == STX_WARP_AFFINE || z > 0) {
+                    qx = fdiv(x, z);
+                    qy = fdiv(y, z);
+                }
+                if (e) { X[h].y = qx; Y[h].y = qy; } else { X[h].x = qx; Y[h].x = qy; }
+            }
+        }
+    }
+    // 32 x, 32 y (exact) and their cvRound as bit patterns
+    uint32_t ux[4], uy[4];
+    float xs[4], ys[4];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const v2f x32 = X[h] * 32.f, y32 = Y[h] * 32.f;
+        const v2f tx = x32 + 12582912.f, ty = y32 + 12582912.f;
+        xs[2 * h] = x32.x; xs[2 * h + 1] = x32.y; ys[2 * h] = y32.x; ys[2 * h + 1] = y32.y;
+        ux[2 * h] = __float_as_uint(tx.x); ux[2 * h + 1] = __float_as_uint(tx.y);
+        uy[2 * h] = __float_as_uint(ty.x); uy[2 * h + 1] = __float_as_uint(ty.y);
+    }
+    const uint32_t uxmn = min(min(ux[0], ux[1]), min(ux[2], ux[3])), uxmx = max(max(ux[0], ux[1]), max(ux[2], ux[3]));
+    const uint32_t uymn = min(min(uy[0], uy[1]), min(uy[2], uy[3])), uymx = max(max(uy[0], uy[1]), max(uy[2], uy[3]));
+    const STX_GAS uint8_t* src = (const STX_GAS uint8_t*)src_a;
+    uint8_t* const lpx = reinterpret_cast<uint8_t*>(&s_px[wv][0][0]) + lane * 3;  // + 192 per row, + channel
+    uint8_t* const lmk = reinterpret_cast<uint8_t*>(&s_mk[wv][0][0]) + lane;      // + 64 per row
+    // interior: valid for the image samples; the nearest-neighbour mask sample of an interior position is inside too
+    const bool lane_int = uxmn >= RND_U0 && uxmx <= ux_int && uymn >= RND_U0 && uymx <= uy_int;
+    const bool wave_int = __builtin_amdgcn_ballot_w64(!lane_int) == 0;
+    if (wave_int) {
+        if (IMG) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                blend_pair_to_lds(src, sstride, __builtin_amdgcn_ubfe(ux[j], 5, 17), __builtin_amdgcn_ubfe(uy[j], 5, 17), ux[j] & 31u,
+                                  uy[j] & 31u, lpx + 192 * j);
+        }
+    } else {
+        const int sw = P.sw, sh = P.sh;
+        const float mx32_hi = P.mx32_hi, my32_hi = P.my32_hi;
+        if (MASK) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool in = xs[j] >= -16.f && xs[j] < mx32_hi && ys[j] >= -16.f && ys[j] < my32_hi;
+                lmk[64 * j] = in ? 255 : 0;
+            }
+        }
+        if (IMG) {
+            const bool lane_zone = uxmn >= P.ux_zlo && uxmx <= P.ux_zhi && uymn >= P.uy_zlo && uymx <= P.uy_zhi;
+            if (__builtin_amdgcn_ballot_w64(!lane_zone) == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    uint32_t ix, iy, fx, fy;
+                    mirror_axis((int)(ux[j] - RND_U0), sw, ix, fx);
+                    mirror_axis((int)(uy[j] - RND_U0), sh, iy, fy);
+                    blend_pair_to_lds(src, sstride, ix, iy, fx, fy, lpx + 192 * j);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t px = sample_border(src, sstride, sw, sh, xs[j], ys[j]);
+                    lpx[192 * j] = (uint8_t)px;
+                    lpx[192 * j + 1] = (uint8_t)(px >> 8);
+                    lpx[192 * j + 2] = (uint8_t)(px >> 16);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // The wavefront's 4 x 192 bytes (4 x 64 of the mask) sit in LDS in the order lane * 12 (lane * 4): lane = 16 r + c
+    // stores the 12 (4) bytes at column offset 12 c (4 c) of row r — one 12-byte and one 4-byte store per lane.
+    const int r = lane >> 4, c = lane & 15;
+    const bool full = y0 + WARP_TH <= dh && (long long)xw * 3 + 192 <= dimg_stride && dimg_stride < (1ll << 24) &&
+                      (long long)xw + 64 <= dmask_stride && dmask_stride < (1ll << 24);
+    if (full) {
+        if (IMG) {
+            const uint32_t* sp = &s_px[wv][0][0] + lane * 3;
+            STX_GAS uint8_t* base = (STX_GAS uint8_t*)(dimg_a + (unsigned long long)y0 * (unsigned long long)dimg_stride + (unsigned long long)xw * 3ull);
+            STX_GAS uint32_t* d = reinterpret_cast<STX_GAS uint32_t*>(base + (__umul24((uint32_t)r, (uint32_t)dimg_stride) + (uint32_t)c * 12u));
+            const uint32_t a0 = sp[0], a1 = sp[1], a2 = sp[2];
+            d[0] = a0; d[1] = a1; d[2] = a2;
+        }
+        if (MASK) {
+            STX_GAS uint8_t* base = (STX_GAS uint8_t*)(dmask_a + (unsigned long long)y0 * (unsigned long long)dmask_stride + (unsigned long long)xw);
+            *reinterpret_cast<STX_GAS uint32_t*>(base + (__umul24((uint32_t)r, (uint32_t)dmask_stride) + (uint32_t)c * 4u)) =
+                wave_int ? 0xffffffffu : s_mk[wv][r][c];
+        }
+    } else {
+        if (IMG) {
+            // a dword is skipped when it would pass the end of the row pitch (last tile of a row) or of the image (last tile row)
+            uint8_t* const drow = (uint8_t*)dimg_a + (long long)xw * 3;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int idx = lane + 64 * k, rr = idx / 48, cdw = idx - rr * 48;
+                if (y0 + rr < dh && (long long)xw * 3 + cdw * 4 + 4 <= dimg_stride)
+                    *reinterpret_cast<uint32_t*>(drow + (long long)(y0 + rr) * dimg_stride + cdw * 4) = s_px[wv][rr][cdw];
+            }
+        }
+        if (MASK) {
+            if (y0 + r < dh && (long long)xw + c * 4 + 4 <= dmask_stride)
+                *reinterpret_cast<uint32_t*>((uint8_t*)dmask_a + (long long)(y0 + r) * dmask_stride + xw + c * 4) =
+                    wave_int ? 0xffffffffu : s_mk[wv][r][c];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The twelve projectors without a separable backward map (fisheye, stereographic, compressed rectilinear,
+// panini, mercator, transverse mercator): per-pixel mapBackward with the exact-trig routines, then the same
+// fixed-point sampling as warp_kernel.  Formulas: OpenCV warpers_inl.hpp [OCV-MEM], every fp32 step rounded separately.
+// ---------------------------------------------------------------------------------------------
 // generic remapBilinear / BORDER_REFLECT sample of one pixel -> 24-bit BGR
 STX_DEV uint32_t sample_generic(const WarpK& P, float x, float yy)
 {
@@ -300,41 +607,6 @@ STX_DEV uint32_t sample_generic(const WarpK& P, float x, float yy)
     return b | (g << 8) | (rr << 16);
 }
 
-// One BORDER_REFLECT tap: the 3 bytes of source pixel (sx, sy) in the low 24 bits (32-bit offsets, global loads)
-STX_DEV uint32_t tap24(const STX_GAS uint8_t* src, uint32_t stride, int sx, int sy)
-{
-    const uint32_t off = (uint32_t)sy * stride + (uint32_t)sx * 3u;
-    const STX_GAS uint32_t* q = reinterpret_cast<const STX_GAS uint32_t*>(src + (off & ~3u));
-    return __builtin_amdgcn_alignbyte(q[1], q[0], off & 3u);
-}
-
-// remapBilinear with BORDER_REFLECT on every tap (borderInterpolate per tap, cvRound / short saturation emulated
-// exactly) for the pixels outside the interior; same packed blend as the interior path.  Fast-kernel
-// preconditions apply (source < 2^31 bytes).
-STX_DEV uint32_t sample_border(const WarpK& P, float x, float yy)
-{
-    const int sx = cv_round(fmul(x, 32.f)), sy = cv_round(fmul(yy, 32.f));
-    const uint32_t fx = (uint32_t)sx & 31u, fy = (uint32_t)sy & 31u;
-    const int ix = sat_s16(sx >> 5), iy = sat_s16(sy >> 5);
-    const int sx0 = reflect(ix, P.sw), sx1 = reflect(ix + 1, P.sw);
-    const int sy0 = reflect(iy, P.sh), sy1 = reflect(iy + 1, P.sh);
-    const STX_GAS uint8_t* src = (const STX_GAS uint8_t*)P.src;
-    const uint32_t stride = (uint32_t)P.sstride;
-    const uint32_t t00 = tap24(src, stride, sx0, sy0), t01 = tap24(src, stride, sx1, sy0);
-    const uint32_t t10 = tap24(src, stride, sx0, sy1), t11 = tap24(src, stride, sx1, sy1);
-    const uint32_t wy1 = fy * 0x10001u, wy0 = 0x200020u - wy1;
-    const uint32_t wx = fx * 0xffffu + 32u;
-    uint32_t o[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const uint32_t sel = c == 0 ? 0x0c040c00u : (c == 1 ? 0x0c050c01u : 0x0c060c02u);  // byte c of both taps
-        const v2h a = as_v2h(__builtin_amdgcn_perm(t01, t00, sel)), b = as_v2h(__builtin_amdgcn_perm(t11, t10, sel));
-        const v2h v = a * as_v2h(wy0) + b * as_v2h(wy1);
-        o[c] = __builtin_amdgcn_udot2(v, as_v2h(wx), 512u, false) >> 10;
-    }
-    return o[0] | (o[1] << 8) | (o[2] << 16);
-}
-
 STX_DEV void put_px(uint32_t (&out)[3], int j, uint32_t px)
 {
     if (j == 0) out[0] = px;
@@ -343,172 +615,6 @@ STX_DEV void put_px(uint32_t (&out)[3], int j, uint32_t px)
     else out[2] |= px << 8;
 }
 
-template <int TYPE, bool IMG, bool MASK>
-__global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
-{
-    const WarpK& P = B.k[blockIdx.z];
-    const float2* __restrict__ colT = B.colT[blockIdx.z];
-    const float2* __restrict__ rowT = B.rowT[blockIdx.z];
-    const int lane = threadIdx.x & 63;
-    // The per-image scalars of the tile-index math and of the tests below are fetched up front, as a few wide scalar
-    // loads with one wait: a wavefront lives for 256 pixels only, and the compiler otherwise sinks every one of these
-    // kernel-argument loads to its first use (about fifteen dependent scalar-cache round trips per wavefront).
-    int tiles_x = P.tiles_x, tiles_y = P.tiles_y, band_tiles = P.band_tiles, band_rows = P.band_rows;
-    uint32_t magic_tx = P.magic_tx, magic_band = P.magic_band;
-    int dw = P.dw, dh = P.dh;
-    float bx_hi = P.bx_hi, by_hi = P.by_hi, mx_hi = P.mx_hi, my_hi = P.my_hi;
-    unsigned long long src_a = (unsigned long long)P.src, dimg_a = (unsigned long long)P.dimg, dmask_a = (unsigned long long)P.dmask;
-    long long dimg_stride = P.dimg_stride, dmask_stride = P.dmask_stride;
-    uint32_t sstride = (uint32_t)P.sstride;
-    asm volatile("" : "+s"(tiles_x), "+s"(tiles_y), "+s"(band_tiles), "+s"(band_rows), "+s"(magic_tx), "+s"(magic_band), "+s"(dw),
-                 "+s"(dh), "+s"(bx_hi), "+s"(by_hi), "+s"(mx_hi), "+s"(my_hi));
-    asm volatile("" : "+s"(src_a), "+s"(dimg_a), "+s"(dmask_a), "+s"(dimg_stride), "+s"(dmask_stride), "+s"(sstride));
-    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only), and the
-    // per-XCD L2s do not share lines.  Bands of WARP_BAND tile rows go round-robin to the XCDs: vertically adjacent
-    // tiles — which read the same source rows — mostly meet in one L2 instead of fetching those rows once per
-    // XCD (measured for 8 frames of 36 MB: 605 MB fetched with the plain row-major order, 288 MB with whole-image
-    // eighths — but then the curved-border bands unbalance the XCDs — and 360 MB with bands of 4 tile rows; the
-    // kernel time is the same for all three).
-    // divisions by the per-image constants use host-made reciprocals (n * m >> 32, exact for n * d < 2^32)
-    const uint32_t local = blockIdx.x >> 3;
-    const uint32_t band_i = band_tiles == 1 ? local : __umulhi(local, magic_band);  // local / (band_rows * tiles_x)
-    const uint32_t within = local - band_i * (uint32_t)band_tiles;
-    const uint32_t wy = tiles_x == 1 ? within : __umulhi(within, magic_tx);  // within / tiles_x (2^32 / 1 has no 32-bit magic)
-    const int tile_x = (int)(within - wy * (uint32_t)tiles_x);
-    const int tile_y = (int)((band_i * 8u + (blockIdx.x & 7u)) * (uint32_t)band_rows + wy);
-    if (tile_y >= tiles_y) return;
-    // Lane layout: a wavefront covers 64 columns x WARP_TH rows, one lane = one column, its WARP_TH pixels one below
-    // the other (the workgroup's four wavefronts sit side by side: a 256 x 4 tile).  For every row the 64 lanes then
-    // gather from ADJACENT source positions — about 3 cache lines per load instruction instead of the 8 that four
-    // horizontal pixels per lane touched (one-line-gathers experiment: the scattered form cost 50 of 250 us) — and the
-    // row constants are wave-uniform.  The 3-byte results go through LDS to leave as whole dwords: 768 + 256 bytes per
-    // wavefront, written bytewise, read back as the 192 + 64 dwords of the wavefront's 4 rows.
-    __shared__ uint32_t s_px[4][WARP_TH][48];  // [wavefront][row][dword]: 64 px x 3 B
-    __shared__ uint32_t s_mk[4][WARP_TH][16];  // [wavefront][row][dword]: 64 px x 1 B
-    const int wv = threadIdx.x >> 6;
-    const int xw = tile_x * WARP_TW + wv * 64;  // first column of this wavefront
-    const int y0 = tile_y * WARP_TH;
-    // columns / rows beyond the image are computed on clamped table entries (harmless) and never stored
-    const float2 ct = colT[min(xw + lane, dw - 1)];
-    const float omt = fsub(1.f, P.t[2]);
-    float xs[4], ys[4], zs[4];
-    // every division of this lane may use the shared-reciprocal sequence: all |z| (z for the rotation warpers,
-    // which also need z > 0) in [2^-60, 2^60] and all |x|, |y| <= 2^60.  Evaluated as integer min / max of the
-    // float bit patterns of z (a NaN z is "too big" or negative there, so it cannot slip through a NaN-dropping
-    // fp min) and one fp max over |x|, |y| (a NaN numerator gives NaN on both division paths).
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const float2 rt = rowT[min(y0 + j, dh - 1)];
-        project_xyz<TYPE>(P, ct.x, ct.y, rt.x, rt.y, omt, xs[j], ys[j], zs[j]);
-    }
-    int zb[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-        zb[j] = (TYPE == STX_WARP_PLANE || TYPE == STX_WARP_AFFINE) ? (__float_as_int(zs[j]) & 0x7fffffff) : __float_as_int(zs[j]);
-    const int zlo = min(min(zb[0], zb[1]), min(zb[2], zb[3])), zhi = max(max(zb[0], zb[1]), max(zb[2], zb[3]));
-    const float nmax = fmaxf(fmaxf(fmaxf(fabsf(xs[0]), fabsf(ys[0])), fmaxf(fabsf(xs[1]), fabsf(ys[1]))),
-                             fmaxf(fmaxf(fabsf(xs[2]), fabsf(ys[2])), fmaxf(fabsf(xs[3]), fabsf(ys[3]))));
-    const bool easy = zlo >= 0x21800000 /* 2^-60 */ && zhi <= 0x5d800000 /* 2^60 */ && nmax <= 0x1p60f;
-    if (easy) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) div2_fast(zs[j], xs[j], ys[j], xs[j], ys[j]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (TYPE == STX_WARP_PLANE || TYPE == STX_WARP_AFFINE || zs[j] > 0) {
-                xs[j] = fdiv(xs[j], zs[j]);
-                ys[j] = fdiv(ys[j], zs[j]);
-            } else {
-                xs[j] = ys[j] = -1.f;
-            }
-        }
-    }
-    uint8_t* const lpx = reinterpret_cast<uint8_t*>(&s_px[wv][0][0]) + lane * 3;  // + 192 per row, + channel
-    uint8_t* const lmk = reinterpret_cast<uint8_t*>(&s_mk[wv][0][0]) + lane;      // + 64 per row
-    bool interior = false;
-    float x32[4], y32[4];
-    if (IMG) {
-        // all four samples in the interior: -0.5 <= v < hi for every coordinate, as two fp min / max chains per
-        // axis; the sum poisons the test when any coordinate is NaN (fp min / max would drop it)
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            x32[j] = fmul(xs[j], 32.f);
-            y32[j] = fmul(ys[j], 32.f);
-        }
-        const float xmn = fminf(fminf(x32[0], x32[1]), fminf(x32[2], x32[3])), xmx = fmaxf(fmaxf(x32[0], x32[1]), fmaxf(x32[2], x32[3]));
-        const float ymn = fminf(fminf(y32[0], y32[1]), fminf(y32[2], y32[3])), ymx = fmaxf(fmaxf(y32[0], y32[1]), fmaxf(y32[2], y32[3]));
-        const float poison = ((x32[0] + x32[1]) + (x32[2] + x32[3])) + ((y32[0] + y32[1]) + (y32[2] + y32[3]));
-        interior = xmn >= -0.5f && xmx < bx_hi && ymn >= -0.5f && ymx < by_hi && poison == poison;
-    }
-    if (IMG && interior) {
-        const STX_GAS uint8_t* src = (const STX_GAS uint8_t*)src_a;
-        const uint32_t stride = sstride;
-        // Every channel value comes out of its dot product already in byte 2 of the register:
-        //   64 * (h0 * (32 - fx) + h1 * fx + 512)  =  ((h0 * (32 - fx) + h1 * fx + 512) >> 10) << 16  + a remainder below bit 16
-        // (weights scaled by 64: <= 2048, sums < 2^25): the byte is stored to LDS as it is (ds_write_b8_d16_hi).
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int sx = (int)rintf(x32[j]), sy = (int)rintf(y32[j]);  // cvRound; in range by the interior test
-            const uint32_t fx = (uint32_t)sx & 31u, fy = (uint32_t)sy & 31u;
-            // row < 2^15 and stride < 2^24 (fast_ok): 24-bit multiply, full rate
-            const uint32_t a = __umul24((uint32_t)(sy >> 5), stride) + (uint32_t)(sx >> 5) * 3u;
-            const STX_GAS uint32_t* q0 = reinterpret_cast<const STX_GAS uint32_t*>(src + (a & ~3u));
-            const STX_GAS uint32_t* q1 = reinterpret_cast<const STX_GAS uint32_t*>(src + ((a & ~3u) + stride));
-            const uint32_t d0 = q0[0], d1 = q0[1], d2 = q0[2], e0 = q1[0], e1 = q1[1], e2 = q1[2];
-            const uint32_t sh = a & 3u;
-            const uint32_t l0 = __builtin_amdgcn_alignbyte(d1, d0, sh), h0 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-            const uint32_t l1 = __builtin_amdgcn_alignbyte(e1, e0, sh), h1 = __builtin_amdgcn_alignbyte(e2, e1, sh);
-            const uint32_t wy1 = fy * 0x10001u, wy0 = 0x200020u - wy1;  // (fy, fy), (32 - fy, 32 - fy)
-            const uint32_t wx = __umul24(fx, 0x3fffc0u) + 2048u;        // (64 (32 - fx), 64 fx)
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                // (left tap, right tap) of channel c as two u16: bytes c and c + 3 of the 6-byte BGRBGR group
-                const uint32_t sel = c == 0 ? 0x0c030c00u : (c == 1 ? 0x0c040c01u : 0x0c050c02u);
-                const v2h t0 = as_v2h(__builtin_amdgcn_perm(h0, l0, sel)), t1 = as_v2h(__builtin_amdgcn_perm(h1, l1, sel));
-                const v2h v = t0 * as_v2h(wy0) + t1 * as_v2h(wy1);  // vertical lerp of both taps, <= 255 * 32
-                lpx[192 * j + c] = (uint8_t)(__builtin_amdgcn_udot2(v, as_v2h(wx), 32768u, false) >> 16);
-            }
-            if (MASK) lmk[64 * j] = 255;  // interior taps => the rounded sample position is inside as well
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (IMG) {
-                const uint32_t px = sample_border(P, xs[j], ys[j]);
-                lpx[192 * j] = (uint8_t)px;
-                lpx[192 * j + 1] = (uint8_t)(px >> 8);
-                lpx[192 * j + 2] = (uint8_t)(px >> 16);
-            }
-            if (MASK) {
-                const bool in = xs[j] >= -0.5f && xs[j] < mx_hi && ys[j] >= -0.5f && ys[j] < my_hi;
-                lmk[64 * j] = in ? 255 : 0;
-            }
-        }
-    }
-    __syncthreads();
-    if (IMG) {
-        // the wavefront's 4 x 48 dwords leave as three coalesced stores per lane; a dword is skipped when it would pass
-        // the end of the row pitch (last tile of a row) or of the image (last tile row)
-        uint8_t* const drow = (uint8_t*)dimg_a + (long long)xw * 3;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const int idx = lane + 64 * k, r = idx / 48, cdw = idx - r * 48;
-            if (y0 + r < dh && (long long)xw * 3 + cdw * 4 + 4 <= dimg_stride)
-                *reinterpret_cast<uint32_t*>(drow + (long long)(y0 + r) * dimg_stride + cdw * 4) = s_px[wv][r][cdw];
-        }
-    }
-    if (MASK) {
-        const int r = lane >> 4, cdw = lane & 15;
-        if (y0 + r < dh && (long long)xw + cdw * 4 + 4 <= dmask_stride)
-            *reinterpret_cast<uint32_t*>((uint8_t*)dmask_a + (long long)(y0 + r) * dmask_stride + xw + cdw * 4) = s_mk[wv][r][cdw];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// The twelve projectors without a separable backward map (fisheye, stereographic, compressed rectilinear,
-// panini, mercator, transverse mercator): per-pixel mapBackward with the exact-trig routines, then the same
-// fixed-point sampling as warp_kernel.  Formulas: OpenCV warpers_inl.hpp [OCV-MEM], every fp32 step rounded separately.
-// ---------------------------------------------------------------------------------------------
 __device__ __noinline__ void backward_dir(int family, float a, float b, float scale, float u, float v, float* out3)
 {
     float x_, y_, z_;
@@ -732,7 +838,8 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
     hipStream_t s = ctx->stream;
     // per-column / per-row trig tables (a few KB per image, L2 resident), one allocation for the batch, freed in stream order
     size_t total = 0;
-    for (int i = 0; i < n; i++) total += (((size_t)Ks[i].dw + 3) & ~(size_t)3) + (((size_t)Ks[i].dh + 3) & ~(size_t)3);
+    // in float2 units: dw4 column entries + dh4 / 4 row blocks of 16 floats + dh4 floats (rb), rounded up to 3 dh4 float2
+    for (int i = 0; i < n; i++) total += (((size_t)Ks[i].dw + 3) & ~(size_t)3) + 3 * (((size_t)Ks[i].dh + 3) & ~(size_t)3) + 32;
     void* tab = nullptr;
     STX_TRY(stx_dev_alloc(ctx, total * sizeof(float2), &tab));
     float2* cursor = (float2*)tab;
@@ -754,13 +861,14 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
             B.k[i].magic_band = (uint32_t)((1ull << 32) / (uint32_t)B.k[i].band_tiles) + 1u;
             B.colT[i] = cursor;
             cursor += ((size_t)K.dw + 3) & ~(size_t)3;
-            B.rowT[i] = cursor;
-            cursor += ((size_t)K.dh + 3) & ~(size_t)3;
-            max_tab = std::max(max_tab, K.dw + K.dh);
+            cursor = reinterpret_cast<float2*>(((uintptr_t)cursor + 63) & ~(uintptr_t)63);  // 64-byte aligned row blocks
+            B.rowT[i] = reinterpret_cast<float4*>(cursor);
+            cursor += 3 * (((size_t)K.dh + 3) & ~(size_t)3);
+            max_tab = std::max(max_tab, K.dw + ((K.dh + 3) & ~3));
             gx = std::max(gx, (K.dw + WARP_TW - 1) / WARP_TW);
             gy = std::max(gy, (K.dh + WARP_TH - 1) / WARP_TH);
             fast = fast && fast_ok(K);
-            tab_bytes += (double)(K.dw + K.dh) * sizeof(float2);
+            tab_bytes += (double)K.dw * sizeof(float2) + (double)K.dh * 5 * sizeof(float);
             bytes += algo_bytes[base + i];
         }
         {
@@ -829,11 +937,38 @@ void fill_warpk(const StxWarpLaunch& L, WarpK* Kp, double* bytes)
     K.msstride = (long long)L.sstride;
     K.dimg = L.dimg; K.dimg_stride = (long long)L.dimg_stride;
     K.dmask = L.dmask; K.dmask_stride = (long long)L.dmask_stride;
-    K.bx_hi = (float)(32.0 * (L.sw - 1) - 0.5);
-    K.by_hi = (float)(32.0 * (L.sh - 1) - 0.5);
-    // cvRound(v) <= n - 1: v <= n - 0.5 when n - 1 is even (the tie rounds down to it), v < n - 0.5 otherwise
-    K.mx_hi = ((L.sw - 1) & 1) ? (float)(L.sw - 0.5) : std::nextafterf((float)(L.sw - 0.5), 3.0e38f);
-    K.my_hi = ((L.sh - 1) & 1) ? (float)(L.sh - 0.5) : std::nextafterf((float)(L.sh - 0.5), 3.0e38f);
+    // fast kernel: ranges of s = cvRound(32 v) as bit patterns of fl(32 v + 1.5 * 2^23), see WarpK
+    const int zx_lo = std::max(-32 * L.sw, -32768 * 32), zx_hi = std::min(64 * L.sw - 33, 32767 * 32 + 31);
+    const int zy_lo = std::max(-32 * L.sh, -32768 * 32), zy_hi = std::min(64 * L.sh - 33, 32767 * 32 + 31);
+    K.ux_int = RND_U0 + (uint32_t)(32 * (L.sw - 1) - 1);
+    K.uy_int = RND_U0 + (uint32_t)(32 * (L.sh - 1) - 1);
+    K.ux_zlo = RND_U0 + (uint32_t)zx_lo; K.ux_zhi = RND_U0 + (uint32_t)zx_hi;
+    K.uy_zlo = RND_U0 + (uint32_t)zy_lo; K.uy_zhi = RND_U0 + (uint32_t)zy_hi;
+    // cvRound(v) <= n - 1: v <= n - 0.5 when n - 1 is even (the tie rounds down to it), v < n - 0.5 otherwise; times 32 (exact)
+    K.mx32_hi = 32.f * (((L.sw - 1) & 1) ? (float)(L.sw - 0.5) : std::nextafterf((float)(L.sw - 0.5), 3.0e38f));
+    K.my32_hi = 32.f * (((L.sh - 1) & 1) ? (float)(L.sh - 0.5) : std::nextafterf((float)(L.sh - 0.5), 3.0e38f));
+    // Can the numerators of x/z, y/z exceed 2^60, can a table entry be non-finite?  Bounds of |x_|, |y_|, |z_| from the
+    // camera: unit vectors for the rotation warpers (y_ = v / scale for the cylinder), table magnitudes for the plane.
+    {
+        bool ok = std::isfinite(K.scale) && std::fabs(K.scale) > 1e-30f;
+        for (int i = 0; i < 9; i++) ok = ok && std::isfinite(K.kr[i]);
+        for (int i = 0; i < 3; i++) ok = ok && std::isfinite(K.t[i]);
+        const double sc = std::fabs((double)K.scale);
+        const double umax = std::max(std::fabs((double)L.tlx), std::fabs((double)L.tlx + L.dw)) / std::max(sc, 1e-30);
+        const double vmax = std::max(std::fabs((double)L.tly), std::fabs((double)L.tly + L.dh)) / std::max(sc, 1e-30);
+        double bx = 1.0001, by = 1.0001, bz = 1.0001;
+        if (L.proj.family == STX_F_SPHERICAL) ok = ok && umax < 5e5 && vmax < 5e5;
+        else if (L.proj.family == STX_F_CYLINDRICAL) { ok = ok && umax < 5e5; by = vmax * 1.0001; }
+        else { bx = (umax + std::fabs((double)K.t[0])) * 1.0001; by = (vmax + std::fabs((double)K.t[1])) * 1.0001; bz = (1.0 + std::fabs((double)K.t[2])) * 1.0001; }
+        for (int r = 0; r < 2; r++)
+            ok = ok && std::fabs((double)K.kr[3 * r]) * bx + std::fabs((double)K.kr[3 * r + 1]) * by + std::fabs((double)K.kr[3 * r + 2]) * bz <= 0x1p59;
+        K.num_ok = ok ? 1 : 0;
+    }
+    {
+        volatile float omt = 1.f - K.t[2];  // volatile: every step rounded to fp32, no contraction
+        volatile float c2 = K.kr[2] * omt, c5 = K.kr[5] * omt, c8 = K.kr[8] * omt;
+        K.c2 = c2; K.c5 = c5; K.c8 = c8;
+    }
     // algorithmic bytes: read the source once, write the warped image + mask once
     *bytes = (img ? 3.0 * L.sw * L.sh + 3.0 * L.dw * L.dh : 0.0) + (mask ? 1.0 * L.dw * L.dh : 0.0);
 }
