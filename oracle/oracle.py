@@ -78,6 +78,7 @@ def lib():
         L.orc_map_point.argtypes = [C.c_int, C.c_float, fp, fp, C.c_int, C.c_int, C.c_float, C.c_float, fp]
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_set_num_threads.restype = None
+        L.orc_set_model.argtypes = [C.c_int, C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -99,6 +100,21 @@ def set_num_threads(n):
 
 def max_threads():
     return lib().orc_get_max_threads()
+
+
+# Arithmetic models of the two places where OpenCV builds differ from one another (stx_oracle.cpp: g_pyr32f, g_remap).
+# The default — scalar pyrDown order, classic fixed-point remap — is what the HIP kernels reproduce bit for bit.
+PYRDOWN32F_MODELS = {"scalar": 0, "simd_v": 1, "simd_hv": 3, "simd_v_fma": 5, "simd_hv_fma": 7}
+REMAP_MODELS = {"q15": 0, "float": 1, "float_fma": 3}
+
+
+def set_model(pyrdown32f="scalar", lanes=4, remap="q15"):
+    """Select the evaluation order of pyrDown(CV_32F) and the remap model; returns the previous setting as a
+    dict that can be passed back with set_model(**prev)."""
+    prev = lib().orc_set_model(PYRDOWN32F_MODELS[pyrdown32f], int(lanes), REMAP_MODELS[remap])
+    inv_p = {v: k for k, v in PYRDOWN32F_MODELS.items()}
+    inv_r = {v: k for k, v in REMAP_MODELS.items()}
+    return dict(pyrdown32f=inv_p[prev & 7], lanes=(prev >> 8) & 255, remap=inv_r[(prev >> 16) & 3])
 
 
 # ------------------------------------------------------------------ primitive wrappers

@@ -60,6 +60,20 @@ namespace {
 
 int g_threads = 1;
 
+// Alternative arithmetic models of the two places where OpenCV builds differ from one another (sensitivity studies,
+// tests/test_oracle_models.py, tools/oracle_sensitivity.py).  Defaults = the literal scalar / classic restatement.
+//   g_pyr32f: evaluation order of pyrDown on CV_32F (the blend weights).  bit 0: vertical pass in the universal-intrinsic
+//             order  (r1 + r3 + r2) * 4 + (r0 + r4 + (r2 + r2))  (PyrDownVecV<float,float>; the SSE2 code of 3.x / 4.0 has the
+//             same order); bit 1: horizontal pass  r2 * 6 + ((r1 + r3) * 4 + (r0 + r4))  (PyrDownVecH<float,float,1>, 4.2+);
+//             bit 2: v_muladd is fused (FMA3 / NEON builds).  Vector groups of g_pyr32f_lanes outputs start at x = 1
+//             (horizontal; x = 0 is the left-border column) / x = 0 (vertical); the leftover columns and the border
+//             columns use the scalar order.  [OCV-MEM]
+//   g_remap : 0 = classic fixed-point remap (1/32-px positions, Q15 table); 1 = fp32 bilinear on the unquantised
+//             position, the shape of the rewritten 5.x kernels (floor, alpha/beta in fp32, p + a * (q - p), round to
+//             nearest even): an UNVERIFIED model, for sensitivity only; bit 1: the three lerps are fused (fma).
+int g_pyr32f = 0, g_pyr32f_lanes = 4, g_remap = 0;
+inline float muladd_model(float a, float b, float c, bool fused) { return fused ? __builtin_fmaf(a, b, c) : a * b + c; }
+
 // ------------------------------------------------------------------------------------------
 // "exact" trig: double precision, explicit fma, then one rounding to fp32.
 // Coefficients are the classic fdlibm minimax sets (k_sin.c, k_cos.c, s_atan.c).
@@ -396,7 +410,8 @@ void set_camera_params(Projector& p, const float* K, const float* R, const float
     p.t[0] = T[0]; p.t[1] = T[1]; p.t[2] = T[2];
 }
 
-// AffineWarper::getRTfromHomogeneous + the creator's scale = 1
+// AffineWarper::getRTfromHomogeneous; cv::AffineWarper::create(scale) = makePtr<detail::AffineWarper>(scale) and
+// detail::AffineWarper(float scale = 1.f) : PlaneWarper(scale): the caller's scale is kept
 void make_projector(Projector& p, int type, float scale, const float* K, const float* Rin, int trig)
 {
     p.type = type;
@@ -435,7 +450,6 @@ void make_projector(Projector& p, int type, float scale, const float* K, const f
             float v = Rt[i * 3 + 0] * t0 + Rt[i * 3 + 1] * t1 + Rt[i * 3 + 2] * 0.f;
             T[i] = v * -1.f;
         }
-        p.scale = 1.f;  // AffineWarperCreator ignores scale; AffineWarper() : PlaneWarper(1.f)
         set_camera_params(p, K, Rt, T);
         return;
     }
@@ -808,6 +822,28 @@ inline void bilinear_px(const uint8_t* S0, int sw, int sh, size_t sstep, int cn,
     }
 }
 
+// fp32 bilinear on the unquantised position (g_remap & 1): sensitivity model of the rewritten remap kernels, see g_remap
+inline void bilinear_px_float(const uint8_t* S0, int sw, int sh, size_t sstep, int cn, float x, float y, int border, uint8_t* D)
+{
+    const bool fused = g_remap & 2;
+    if (!(x > -1.0e9f && x < 1.0e9f && y > -1.0e9f && y < 1.0e9f)) { x = -1.f; y = -1.f; }
+    const float fxf = std::floor(x), fyf = std::floor(y);
+    const int ix = (int)fxf, iy = (int)fyf;
+    const float a = x - fxf, b = y - fyf;
+    int sx0 = border_interpolate(ix, sw, border), sx1 = border_interpolate(ix + 1, sw, border);
+    int sy0 = border_interpolate(iy, sh, border), sy1 = border_interpolate(iy + 1, sh, border);
+    static const uint8_t cval[4] = {0, 0, 0, 0};
+    const uint8_t* v0 = sx0 >= 0 && sy0 >= 0 ? S0 + sy0 * sstep + sx0 * cn : cval;
+    const uint8_t* v1 = sx1 >= 0 && sy0 >= 0 ? S0 + sy0 * sstep + sx1 * cn : cval;
+    const uint8_t* v2 = sx0 >= 0 && sy1 >= 0 ? S0 + sy1 * sstep + sx0 * cn : cval;
+    const uint8_t* v3 = sx1 >= 0 && sy1 >= 0 ? S0 + sy1 * sstep + sx1 * cn : cval;
+    for (int k = 0; k < cn; k++) {
+        const float p00 = v0[k], p01 = v1[k], p10 = v2[k], p11 = v3[k];
+        const float t = muladd_model(a, p01 - p00, p00, fused), u = muladd_model(a, p11 - p10, p10, fused);
+        D[k] = sat_u8(cv_round(muladd_model(b, u - t, t, fused)));
+    }
+}
+
 // remapNearest<uchar>, BORDER_CONSTANT 0; map quantised by saturate_cast<short>(float)
 inline void nearest_px(const uint8_t* S0, int sw, int sh, size_t sstep, int cn, float x, float y, uint8_t* D)
 {
@@ -824,60 +860,75 @@ inline void nearest_px(const uint8_t* S0, int sw, int sh, size_t sstep, int cn, 
 // Pyramids (modules/imgproc/src/pyramids.cpp)
 // ------------------------------------------------------------------------------------------
 // pyrDown_<FixPtCast<short,8>>: 5x5 [1 4 6 4 1]^2, BORDER_REFLECT_101, int32 sums, (v+128)>>8
+// (integer sums: the SIMD and scalar paths of OpenCV give the same bits)
 void pyr_down_16s(const int16_t* src, int w, int h, int cn, int16_t* dst)
 {
     int dw = (w + 1) / 2, dh = (h + 1) / 2;
-#pragma omp parallel for num_threads(g_threads) schedule(static)
-    for (int y = 0; y < dh; y++) {
-        std::vector<int> rows((size_t)5 * dw * cn);
-        for (int k = 0; k < 5; k++) {
-            int sy = border_interpolate(2 * y - 2 + k, h, B_REFLECT_101);
-            const int16_t* s = src + (size_t)sy * w * cn;
-            int* row = rows.data() + (size_t)k * dw * cn;
-            for (int x = 0; x < dw; x++) {
-                int x0 = border_interpolate(2 * x - 2, w, B_REFLECT_101) * cn;
-                int x1 = border_interpolate(2 * x - 1, w, B_REFLECT_101) * cn;
-                int x2 = border_interpolate(2 * x, w, B_REFLECT_101) * cn;
-                int x3 = border_interpolate(2 * x + 1, w, B_REFLECT_101) * cn;
-                int x4 = border_interpolate(2 * x + 2, w, B_REFLECT_101) * cn;
-                for (int c = 0; c < cn; c++)
-                    row[x * cn + c] = s[x2 + c] * 6 + (s[x1 + c] + s[x3 + c]) * 4 + s[x0 + c] + s[x4 + c];
+#pragma omp parallel num_threads(g_threads)
+    {
+        std::vector<int> rows((size_t)5 * dw * cn);  // one ring of 5 filtered rows per thread
+        std::vector<int> xi((size_t)5 * dw);
+        for (int x = 0; x < dw; x++)
+            for (int k = 0; k < 5; k++) xi[(size_t)5 * x + k] = border_interpolate(2 * x - 2 + k, w, B_REFLECT_101) * cn;
+#pragma omp for schedule(static)
+        for (int y = 0; y < dh; y++) {
+            for (int k = 0; k < 5; k++) {
+                int sy = border_interpolate(2 * y - 2 + k, h, B_REFLECT_101);
+                const int16_t* s = src + (size_t)sy * w * cn;
+                int* row = rows.data() + (size_t)k * dw * cn;
+                for (int x = 0; x < dw; x++) {
+                    const int* X = &xi[(size_t)5 * x];
+                    for (int c = 0; c < cn; c++)
+                        row[x * cn + c] = s[X[2] + c] * 6 + (s[X[1] + c] + s[X[3] + c]) * 4 + s[X[0] + c] + s[X[4] + c];
+                }
             }
-        }
-        int16_t* d = dst + (size_t)y * dw * cn;
-        const int *r0 = rows.data(), *r1 = r0 + dw * cn, *r2 = r1 + dw * cn, *r3 = r2 + dw * cn, *r4 = r3 + dw * cn;
-        for (int x = 0; x < dw * cn; x++) {
-            int v = r2[x] * 6 + (r1[x] + r3[x]) * 4 + r0[x] + r4[x];
-            d[x] = (int16_t)((v + 128) >> 8);
+            int16_t* d = dst + (size_t)y * dw * cn;
+            const int *r0 = rows.data(), *r1 = r0 + dw * cn, *r2 = r1 + dw * cn, *r3 = r2 + dw * cn, *r4 = r3 + dw * cn;
+            for (int x = 0; x < dw * cn; x++) {
+                int v = r2[x] * 6 + (r1[x] + r3[x]) * 4 + r0[x] + r4[x];
+                d[x] = (int16_t)((v + 128) >> 8);
+            }
         }
     }
 }
 
-// pyrDown_<FltCast<float,8>>, scalar evaluation order of the C source, no FMA
+// pyrDown_<FltCast<float,8>>; g_pyr32f selects the evaluation order (default: the scalar C expression, no FMA)
 void pyr_down_32f(const float* src, int w, int h, float* dst)
 {
     int dw = (w + 1) / 2, dh = (h + 1) / 2;
-#pragma omp parallel for num_threads(g_threads) schedule(static)
-    for (int y = 0; y < dh; y++) {
+    const bool vsimd = g_pyr32f & 1, hsimd = g_pyr32f & 2, fused = g_pyr32f & 4;
+    const int L = g_pyr32f_lanes > 0 ? g_pyr32f_lanes : 4;
+    // outputs [1, hx1) of a row / [0, vx1) of the vertical pass are formed by the vector code
+    const int width0 = std::min((w - 5 / 2 - 1) / 2 + 1, dw);
+    const int hx1 = hsimd && width0 > 1 ? 1 + ((width0 - 1) / L) * L : 1;
+    const int vx1 = vsimd ? (dw / L) * L : 0;
+#pragma omp parallel num_threads(g_threads)
+    {
         std::vector<float> rows((size_t)5 * dw);
-        for (int k = 0; k < 5; k++) {
-            int sy = border_interpolate(2 * y - 2 + k, h, B_REFLECT_101);
-            const float* s = src + (size_t)sy * w;
-            float* row = rows.data() + (size_t)k * dw;
-            for (int x = 0; x < dw; x++) {
-                int x0 = border_interpolate(2 * x - 2, w, B_REFLECT_101);
-                int x1 = border_interpolate(2 * x - 1, w, B_REFLECT_101);
-                int x2 = border_interpolate(2 * x, w, B_REFLECT_101);
-                int x3 = border_interpolate(2 * x + 1, w, B_REFLECT_101);
-                int x4 = border_interpolate(2 * x + 2, w, B_REFLECT_101);
-                row[x] = s[x2] * 6 + (s[x1] + s[x3]) * 4 + s[x0] + s[x4];
+#pragma omp for schedule(static)
+        for (int y = 0; y < dh; y++) {
+            for (int k = 0; k < 5; k++) {
+                int sy = border_interpolate(2 * y - 2 + k, h, B_REFLECT_101);
+                const float* s = src + (size_t)sy * w;
+                float* row = rows.data() + (size_t)k * dw;
+                for (int x = 0; x < dw; x++) {
+                    int x0 = border_interpolate(2 * x - 2, w, B_REFLECT_101);
+                    int x1 = border_interpolate(2 * x - 1, w, B_REFLECT_101);
+                    int x2 = border_interpolate(2 * x, w, B_REFLECT_101);
+                    int x3 = border_interpolate(2 * x + 1, w, B_REFLECT_101);
+                    int x4 = border_interpolate(2 * x + 2, w, B_REFLECT_101);
+                    if (x >= 1 && x < hx1) row[x] = muladd_model(s[x2], 6.f, muladd_model(s[x1] + s[x3], 4.f, s[x0] + s[x4], fused), fused);
+                    else row[x] = s[x2] * 6 + (s[x1] + s[x3]) * 4 + s[x0] + s[x4];
+                }
             }
-        }
-        float* d = dst + (size_t)y * dw;
-        const float *r0 = rows.data(), *r1 = r0 + dw, *r2 = r1 + dw, *r3 = r2 + dw, *r4 = r3 + dw;
-        for (int x = 0; x < dw; x++) {
-            float v = r2[x] * 6 + (r1[x] + r3[x]) * 4 + r0[x] + r4[x];
-            d[x] = v * (float)(1. / 256);
+            float* d = dst + (size_t)y * dw;
+            const float *r0 = rows.data(), *r1 = r0 + dw, *r2 = r1 + dw, *r3 = r2 + dw, *r4 = r3 + dw;
+            for (int x = 0; x < dw; x++) {
+                float v;
+                if (x < vx1) v = muladd_model(r1[x] + r3[x] + r2[x], 4.f, r0[x] + r4[x] + (r2[x] + r2[x]), fused);
+                else v = r2[x] * 6 + (r1[x] + r3[x]) * 4 + r0[x] + r4[x];
+                d[x] = v * (float)(1. / 256);
+            }
         }
     }
 }
@@ -889,26 +940,29 @@ inline int up_idx(int i, int n) { return i < 0 ? (n > 1 ? 1 : 0) : (i >= n ? n -
 void pyr_up_16s(const int16_t* src, int w, int h, int cn, int16_t* dst)
 {
     int dw = 2 * w;
-#pragma omp parallel for num_threads(g_threads) schedule(static)
-    for (int y = 0; y < h; y++) {
+#pragma omp parallel num_threads(g_threads)
+    {
         std::vector<int> rows((size_t)3 * dw * cn);
-        for (int k = 0; k < 3; k++) {
-            const int16_t* s = src + (size_t)up_idx(y - 1 + k, h) * w * cn;
-            int* row = rows.data() + (size_t)k * dw * cn;
-            for (int x = 0; x < w; x++) {
-                int xl = up_idx(x - 1, w) * cn, xc = x * cn, xr = up_idx(x + 1, w) * cn;
-                for (int c = 0; c < cn; c++) {
-                    row[(2 * x) * cn + c] = s[xl + c] + s[xc + c] * 6 + s[xr + c];
-                    row[(2 * x + 1) * cn + c] = (s[xc + c] + s[xr + c]) * 4;
+#pragma omp for schedule(static)
+        for (int y = 0; y < h; y++) {
+            for (int k = 0; k < 3; k++) {
+                const int16_t* s = src + (size_t)up_idx(y - 1 + k, h) * w * cn;
+                int* row = rows.data() + (size_t)k * dw * cn;
+                for (int x = 0; x < w; x++) {
+                    int xl = up_idx(x - 1, w) * cn, xc = x * cn, xr = up_idx(x + 1, w) * cn;
+                    for (int c = 0; c < cn; c++) {
+                        row[(2 * x) * cn + c] = s[xl + c] + s[xc + c] * 6 + s[xr + c];
+                        row[(2 * x + 1) * cn + c] = (s[xc + c] + s[xr + c]) * 4;
+                    }
                 }
             }
-        }
-        const int *r0 = rows.data(), *r1 = r0 + dw * cn, *r2 = r1 + dw * cn;
-        int16_t* d0 = dst + (size_t)(2 * y) * dw * cn;
-        int16_t* d1 = d0 + (size_t)dw * cn;
-        for (int x = 0; x < dw * cn; x++) {
-            d1[x] = (int16_t)(((r1[x] + r2[x]) * 4 + 32) >> 6);
-            d0[x] = (int16_t)((r0[x] + r1[x] * 6 + r2[x] + 32) >> 6);
+            const int *r0 = rows.data(), *r1 = r0 + dw * cn, *r2 = r1 + dw * cn;
+            int16_t* d0 = dst + (size_t)(2 * y) * dw * cn;
+            int16_t* d1 = d0 + (size_t)dw * cn;
+            for (int x = 0; x < dw * cn; x++) {
+                d1[x] = (int16_t)(((r1[x] + r2[x]) * 4 + 32) >> 6);
+                d0[x] = (int16_t)((r0[x] + r1[x] * 6 + r2[x] + 32) >> 6);
+            }
         }
     }
 }
@@ -1096,7 +1150,9 @@ struct Blender {
             Img16 up;
             up.create(lap[i].w, lap[i].h);
             pyr_up_16s(lap[i + 1].d.data(), lap[i + 1].w, lap[i + 1].h, 3, up.d.data());
-            for (size_t k = 0; k < lap[i].d.size(); k++) lap[i].d[k] = sat_s16((int)lap[i].d[k] - (int)up.d[k]);
+            const long long nk = (long long)lap[i].d.size();
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+            for (long long k = 0; k < nk; k++) lap[i].d[k] = sat_s16((int)lap[i].d[k] - (int)up.d[k]);
         }
         for (int i = 0; i < nb; ++i) {
             wp[i + 1].create((wp[i].w + 1) / 2, (wp[i].h + 1) / 2);
@@ -1138,11 +1194,14 @@ struct Blender {
                 up.create(pyr_laplace[i - 1].w, pyr_laplace[i - 1].h);
                 pyr_up_16s(pyr_laplace[i].d.data(), pyr_laplace[i].w, pyr_laplace[i].h, 3, up.d.data());
                 Img16& L = pyr_laplace[i - 1];
-                for (size_t k = 0; k < L.d.size(); k++) L.d[k] = sat_s16((int)up.d[k] + (int)L.d[k]);
+                const long long nk = (long long)L.d.size();
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+                for (long long k = 0; k < nk; k++) L.d[k] = sat_s16((int)up.d[k] + (int)L.d[k]);
             }
             ow = fw; oh = fh;
             dst.create(ow, oh);
             dst_mask.create(ow, oh);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
             for (int y = 0; y < oh; y++)
                 for (int x = 0; x < ow; x++) {
                     for (int c = 0; c < 3; c++) dst.d[((size_t)y * ow + x) * 3 + c] = pyr_laplace[0].d[((size_t)y * rw + x) * 3 + c];
@@ -1150,7 +1209,9 @@ struct Blender {
                 }
         }
         // Blender::blend: dst_.setTo(0, dst_mask_ == 0)
-        for (size_t i = 0; i < (size_t)ow * oh; i++) {
+        const long long npx = (long long)ow * oh;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+        for (long long i = 0; i < npx; i++) {
             bool keep = dst_mask.d[i] != 0;
             for (int c = 0; c < 3; c++) out[i * 3 + c] = keep ? dst.d[i * 3 + c] : (int16_t)0;
             out_mask[i] = dst_mask.d[i];
@@ -1164,6 +1225,15 @@ struct Blender {
 // C entry points (ctypes)
 // ==========================================================================================
 ORC_API void orc_set_num_threads(int n) { g_threads = n < 1 ? 1 : n; }
+// arithmetic-model switches (see g_pyr32f / g_remap); returns the previous packed setting
+ORC_API int orc_set_model(int pyr32f, int pyr32f_lanes, int remap)
+{
+    const int prev = g_pyr32f | (g_pyr32f_lanes << 8) | (g_remap << 16);
+    g_pyr32f = pyr32f & 7;
+    g_pyr32f_lanes = pyr32f_lanes > 0 ? pyr32f_lanes : 4;
+    g_remap = remap & 3;
+    return prev;
+}
 ORC_API int orc_get_max_threads()
 {
 #ifdef _OPENMP
@@ -1213,6 +1283,11 @@ ORC_API int orc_remap_linear_u8(const uint8_t* src, int sw, int sh, int cn, cons
 #pragma omp parallel for num_threads(g_threads) schedule(static)
     for (int v = 0; v < dh; ++v)
         for (int u = 0; u < dw; ++u) {
+            if (g_remap & 1) {
+                bilinear_px_float(src, sw, sh, sstep, cn, xmap[(size_t)v * dw + u], ymap[(size_t)v * dw + u], border,
+                                  dst + ((size_t)v * dw + u) * cn);
+                continue;
+            }
             int ix, iy, fxy;
             quantise_linear(xmap[(size_t)v * dw + u], ymap[(size_t)v * dw + u], ix, iy, fxy);
             bilinear_px(src, sw, sh, sstep, cn, ix, iy, fxy, border, dst + ((size_t)v * dw + u) * cn);
@@ -1249,7 +1324,9 @@ ORC_API int orc_warp_fused(int type, float scale, const float* K, const float* R
         for (int u = 0; u < dw; ++u) {
             float x, y;
             map_backward(p, (float)(u + tlx), (float)(v + tly), x, y);
-            if (dst_img) {
+            if (dst_img && (g_remap & 1)) {
+                bilinear_px_float(src, sw, sh, sstep, cn, x, y, B_REFLECT, dst_img + ((size_t)v * dw + u) * cn);
+            } else if (dst_img) {
                 int ix, iy, fxy;
                 quantise_linear(x, y, ix, iy, fxy);
                 bilinear_px(src, sw, sh, sstep, cn, ix, iy, fxy, B_REFLECT, dst_img + ((size_t)v * dw + u) * cn);

@@ -678,7 +678,8 @@ int stx_make_projector(int type, float scale, const float* K, const float* R, St
     p->b = 1.0f;
     float Rm[9], T[3] = {0.f, 0.f, 0.f};
     if (type == STX_WARP_AFFINE) {
-        // R' = (H with H[0,2] = H[1,2] = 0)^T ; T' = -(R' * (H[0,2], H[1,2], 0)); scale is ignored (1.0)
+        // R' = (H with H[0,2] = H[1,2] = 0)^T ; T' = -(R' * (H[0,2], H[1,2], 0)); the caller's scale is kept
+        // (cv::AffineWarper::create(scale) -> detail::AffineWarper(scale) : PlaneWarper(scale))
         float H[9];
         memcpy(H, R, sizeof(H));
         const float t0 = H[2], t1 = H[5];
@@ -692,7 +693,6 @@ int stx_make_projector(int type, float scale, const float* K, const float* R, St
             v = v + Rm[i * 3 + 2] * 0.f;
             T[i] = v * -1.f;
         }
-        p->scale = 1.f;
     } else {
         memcpy(Rm, R, sizeof(Rm));
     }

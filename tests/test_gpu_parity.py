@@ -55,6 +55,27 @@ def test_affine_warp_bit_exact(oracle, gpu_ctx):
         assert np.array_equal(g.create_and_warp_mask((300, 200), cam), o.create_and_warp_mask((300, 200), cam))
 
 
+@pytest.mark.parametrize("aspect", [0.4, 2.5])
+def test_affine_warp_at_another_resolution(oracle, gpu_ctx, aspect):
+    """AffineStitcher warps low-res and final-res images with K and the warper scale multiplied by `aspect`
+    (stitching/warper.py:44,59,80,86-93); cv::AffineWarper keeps that scale (detail::AffineWarper(scale))."""
+    cams = synthetic.affine_scan_cameras(4, 300, 200)
+    w, h = int(round(300 * aspect)), int(round(200 * aspect))
+    imgs = [synthetic.make_frame(10 + i, w, h) for i in range(4)]
+    g, o = S.Warper("affine"), oracle.Warper("affine")
+    g.set_scale(cams)
+    o.set_scale(cams)
+    for img, cam in zip(imgs, cams):
+        assert g.warp_roi((w, h), cam, aspect) == o.warp_roi((w, h), cam, aspect)
+        assert np.array_equal(g.warp_image(img, cam, aspect), o.warp_image(img, cam, aspect))
+        assert np.array_equal(g.create_and_warp_mask((w, h), cam, aspect), o.create_and_warp_mask((w, h), cam, aspect))
+    # the tiles land `aspect` times as far apart as at the registration resolution
+    c1, _ = o.warp_rois([(300, 200)] * 4, cams)
+    ca, _ = o.warp_rois([(w, h)] * 4, cams, aspect)
+    for (x1, y1), (xa, ya) in zip(c1, ca):
+        assert abs(xa - x1 * aspect) <= 2 and abs(ya - y1 * aspect) <= 2
+
+
 @pytest.mark.parametrize("btype,strength", [("multiband", 5), ("multiband", 20), ("feather", 5), ("no", 5)])
 def test_blend_bit_exact(oracle, gpu_ctx, btype, strength):
     imgs, cams = helpers.small_ring(4, 400, 300, span=160.0)

@@ -94,15 +94,23 @@ def test_plane_warper_identity_map(oracle):
     assert np.all(w.create_and_warp_mask((64, 48), cam) == 255)
 
 
-def test_affine_warper_translation_and_scale_ignored(oracle):
+def test_affine_warper_translation_and_scale(oracle):
     H = np.array([[1, 0, 10], [0, 1, -7], [0, 0, 1]], np.float32)
     cam = oracle.CameraParams(focal=1.0, R=H)
     w = oracle.Warper("affine")
-    w.scale = 123.0  # AffineWarperCreator ignores the scale
-    # getRTfromHomogeneous: R' = H_rot^T, T' = -R' t  =>  mapForward(p) = H^-1 p  (H maps panorama -> image)
+    w.set_scale([cam])  # median focal = 1
+    # getRTfromHomogeneous: R' = H_rot^T, T' = -R' t  =>  mapForward(p) = scale * H^-1 K^-1 p  (H maps panorama -> image)
     assert w.warp_roi((50, 40), cam) == (-10, 7, 50, 40)
     img = synthetic.make_frame(2, 50, 40)
     assert np.abs(w.warp_image(img, cam).astype(int) - img.astype(int)).max() <= 1
+    # cv::AffineWarper::create(scale) keeps the scale (detail::AffineWarper(scale) : PlaneWarper(scale)): u = scale * x_
+    w.scale = 2.0
+    assert w.warp_roi((50, 40), cam) == (-20, 14, 99, 79)
+    # the reference warps at another resolution with K and the scale both multiplied by `aspect` (stitching/warper.py:44,86-93):
+    # mapForward(p) = aspect * H^-1 (p / aspect): the translation scales with the resolution, the tile keeps its size
+    w.scale = 1.0
+    assert w.warp_roi((50, 40), cam, aspect=0.5) == (-5, 3, 50, 40)
+    assert w.warp_roi((100, 80), cam, aspect=2.0) == (-20, 14, 100, 80)
 
 
 def test_spherical_pole_inclusion(oracle):
