@@ -72,6 +72,53 @@ def ring_cameras(n_frames, width, height, focal_factor=0.75, span_deg=340.0, jit
     return cams
 
 
+def _lon_half_extent_deg(width, height, focal, pitch_deg, roll_deg=1.5):
+    """Largest |longitude| (relative to the optical axis' yaw) reached by the border of a frame pitched by pitch_deg."""
+    best = 0.0
+    for pd in (pitch_deg - 1.5, pitch_deg + 1.5):
+        for rd in (-roll_deg, roll_deg):
+            R = rot_x(math.radians(pd)) @ rot_z(math.radians(rd))
+            for t in np.linspace(-1.0, 1.0, 33):
+                for x, y in ((t * width / 2, -height / 2), (t * width / 2, height / 2), (-width / 2, t * height / 2), (width / 2, t * height / 2)):
+                    d = R @ np.array([x / focal, y / focal, 1.0])
+                    if d[2] <= 0 and abs(d[0]) < 1e-9:
+                        return 180.0
+                    best = max(best, abs(math.degrees(math.atan2(d[0], d[2]))))
+    return best
+
+
+def grid_cameras(n_yaw, n_pitch, width, height, focal_factor=0.75, span_deg=340.0, max_edge_lat_deg=83.0, jitter=True):
+    """BASELINE configs 3 / 4: `n_pitch` rows of `n_yaw` cameras, focal = focal_factor * width, pitch rows
+    0.70 * vfov apart and centred on the equator, compressed so that no frame edge passes latitude max_edge_lat_deg
+    (4 rows of 4000x3000 at focal_factor 0.75: +-18.6 and +-55.8 degrees — SURVEY's "clamped to |pitch| < 60"; a
+    cylindrical panorama needs a lower limit, v = scale * tan(latitude)).  Yaw steps as ring_cameras, but the fields of
+    view tile at most the span that keeps every frame — the pitched rows reach far in longitude — off the +-180 degree
+    seam of the parametrisation (a frame across the seam gets the full-circle ROI: 4.7 x its source at config 3).
+    Order: yaw-major (all pitch rows of the first yaw step, then the next), so contiguous runs of the list are
+    contiguous panorama columns — the run a GPU owns.
+
+    8 x 4, 4000x3000: config 3 (32 frames, 4 per GPU at N = 8); 16 x 4, 8000x6000, max_edge_lat_deg 50: config 4."""
+    focal = focal_factor * width
+    hfov = 2.0 * math.degrees(math.atan(width / (2.0 * focal)))
+    vfov = 2.0 * math.degrees(math.atan(height / (2.0 * focal)))
+    ptop = max(0.0, min(0.70 * vfov * (n_pitch - 1) / 2.0, max_edge_lat_deg - vfov / 2.0 - 1.5))
+    pitches = [0.0] if n_pitch == 1 else list(np.linspace(-ptop, ptop, n_pitch))
+    reach = max(_lon_half_extent_deg(width, height, focal, p) for p in pitches)
+    half = min((span_deg - hfov) / 2.0, 177.0 - reach)
+    if half < 0:
+        raise ValueError("frames pitched this far cover more than the whole circle of longitudes")
+    yaws = [0.0] if n_yaw == 1 else list(np.linspace(-half, half, n_yaw))
+    cams = []
+    for i, yaw in enumerate(yaws):
+        for j, pitch in enumerate(pitches):
+            k = i * n_pitch + j
+            dp = 1.5 * math.sin(1.7 * k) if jitter else 0.0
+            roll = 1.0 * math.cos(2.3 * k) if jitter else 0.0
+            R = rot_y(math.radians(yaw)) @ rot_x(math.radians(pitch + dp)) @ rot_z(math.radians(roll))
+            cams.append(CameraParams(focal=focal, aspect=1.0, ppx=width / 2.0, ppy=height / 2.0, R=R.astype(np.float32)))
+    return cams
+
+
 def affine_scan_cameras(n_tiles, width, height, pitch_factor=0.7, max_rot_deg=2.0):
     """BASELINE config 5 (AffineStitcher path): tiles on a near-square grid; camera.R carries the
     3x3 affine H (rotation <= max_rot_deg, translation = pitch_factor * tile size per grid step),

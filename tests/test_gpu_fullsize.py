@@ -1,5 +1,11 @@
-"""BASELINE.json full-size runs on the GPU, checked through size-independent properties (the oracle
-needs minutes at these sizes, so it is not run here):
+"""BASELINE.json full-size runs on the GPU.
+
+Part 1 (test_*_vs_oracle): every BASELINE configuration bit for bit against the CPU oracle at FULL size — config 2
+(8 x 4000x3000, spherical, 5 bands), config 3 (32 x 4000x3000 as 8 yaw x 4 pitch rows; single blender and 2 / 8
+virtual shards), config 4's per-GPU share (8 x 8000x6000, cylindrical, 7 bands), config 5 (16 affine tiles, feather and
+"no").  The oracle needs seconds to tens of seconds per configuration on the GPU box's host cores.
+
+Part 2: size-independent properties:
 
   * reproduction: one image fed with its full warped mask comes back as the image, minus the known
     1-LSB darkening of normalizeUsingWeightMap (x / (1 + 1e-5) truncated);
@@ -143,3 +149,109 @@ def test_config5_affine_tiles(gpu_ctx, btype):
         sub = pano[y:y + wi.shape[0], x:x + wi.shape[1]]
         m = np.asarray(job.warper.create_and_warp_mask((W, H), cams[3])) > 0
         assert np.array_equal(sub[m], wi[m])
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Part 1: full-size comparisons with the oracle
+# ------------------------------------------------------------------------------------------------------------
+def _oracle_threads(oracle):
+    oracle.set_num_threads(max(1, min(oracle.max_threads(), 64)))
+
+
+def _oracle_panorama(oracle, frames, cams, warper_type, blender_type="multiband", num_bands=None, blend_strength=5):
+    _oracle_threads(oracle)
+    w = oracle.Warper(warper_type)
+    w.set_scale(cams)
+    sizes = [(f.shape[1], f.shape[0]) for f in frames]
+    corners, wsizes = w.warp_rois(sizes, cams)
+    roi = oracle.result_roi(corners, wsizes)
+    if num_bands is not None:
+        blend_strength = synthetic.blend_strength_for_bands(num_bands, roi[2], roi[3])
+    b = oracle.Blender(blender_type, blend_strength)
+    b.prepare(corners, wsizes)
+    for f, c, s, corner in zip(frames, cams, sizes, corners):
+        b.feed(w.warp_image(f, c), w.create_and_warp_mask(s, c), corner)
+    pano, pmask = b.blend()
+    return dict(corners=corners, sizes=wsizes, pano=np.asarray(pano), pmask=np.asarray(pmask), blender=b)
+
+
+def _assert_same(g_pano, g_mask, o):
+    g_pano, g_mask = np.asarray(g_pano), np.asarray(g_mask)
+    assert g_pano.shape == o["pano"].shape and g_mask.shape == o["pmask"].shape
+    assert np.array_equal(g_mask, o["pmask"]), f"{np.count_nonzero(g_mask != o['pmask'])} mask bytes differ"
+    if not np.array_equal(g_pano, o["pano"]):
+        d = np.abs(g_pano.astype(np.int16) - o["pano"].astype(np.int16))
+        raise AssertionError(f"panorama differs from the oracle: max {d.max()}, {np.count_nonzero(d)} of {d.size} bytes")
+
+
+def test_config2_vs_oracle(oracle, gpu_ctx):
+    """BASELINE configs[1]: 8 x 4000x3000, spherical warp, 5 bands — the bench workload, bit for bit."""
+    cams = synthetic.ring_cameras(8, W, H)
+    frames = [synthetic.make_frame(i, W, H) for i in range(8)]
+    job = StitchJob(frames, cams, num_bands=5)
+    pano, pmask = job.run()
+    assert job.last_num_bands == 5
+    o = _oracle_panorama(oracle, frames, cams, "spherical", num_bands=5)
+    assert job.corners == o["corners"] and job.warped_sizes == o["sizes"]
+    _assert_same(pano, pmask, o)
+
+
+def test_config3_vs_oracle_single_and_sharded(oracle, gpu_ctx):
+    """BASELINE configs[2]: 32 x 4000x3000 as 8 yaw steps x 4 pitch rows (the +-56 degree rows warp to twice their
+    source size), spherical, 5 bands: the single blender, 2 virtual shards (16 frames each) and 8 virtual shards (one yaw
+    column of 4 stacked frames per rank — the N = 8 layout of bench.py) all equal the oracle bit for bit."""
+    from stitching_amd.distributed import virtual_sharded_blend
+
+    cams = synthetic.grid_cameras(8, 4, W, H)
+    frames = [synthetic.make_frame(i, W, H) for i in range(32)]
+    o = _oracle_panorama(oracle, frames, cams, "spherical", num_bands=5)
+    job = StitchJob(frames, cams, num_bands=5)
+    job.plan()
+    assert job.corners == o["corners"] and job.warped_sizes == o["sizes"]
+    S.set_device_resident(True)
+    try:
+        imgs, masks, rois = job.warper.warp_images_and_masks(job.frames, job.cameras)
+        b = S.Blender("multiband", job.blend_strength)
+        b.prepare(job.corners, job.warped_sizes)
+        for i in range(32):
+            b.feed(imgs[i], masks[i], job.corners[i])
+        assert b.blender.num_bands() == 5
+        _assert_same(*b.blend(), o)
+        roi = S.Blender.result_roi(job.corners, job.warped_sizes)
+        req = int(np.log(np.sqrt(roi[2] * roi[3]) * job.blend_strength / 100) / np.log(2.0) - 1.0)
+        for world in (2, 8):
+            sp, sm, plan = virtual_sharded_blend(gpu_ctx, imgs, masks, job.corners, job.warped_sizes, world, req)
+            assert plan.num_bands == 5 and plan.exchanged_bytes() > 0
+            if world == 8:
+                # every rank owns one yaw column of 4 stacked frames; the wide +-56 degree rows reach past the neighbours
+                assert all(plan.owners[4 * g:4 * g + 4] == [g] * 4 for g in range(8))
+                assert any(abs(m[1] - m[2]) > 1 for m in plan.messages)
+            _assert_same(sp, sm, o)
+    finally:
+        S.set_device_resident(False)
+
+
+def test_config4_share_vs_oracle(oracle, gpu_ctx):
+    """BASELINE configs[3]: 64 x 8000x6000, cylindrical, 7 bands over 8 GPUs = 16 yaw steps x 4 pitch rows, 8 frames per
+    GPU.  One GPU's share (2 yaw columns x 4 rows) at full size against the oracle."""
+    w, h = 8000, 6000
+    cams = synthetic.grid_cameras(16, 4, w, h, max_edge_lat_deg=50.0)[24:32]
+    frames = [synthetic.make_frame(100 + i, w, h) for i in range(8)]
+    job = StitchJob(frames, cams, warper_type="cylindrical", num_bands=7)
+    pano, pmask = job.run()
+    assert job.last_num_bands == 7
+    o = _oracle_panorama(oracle, frames, cams, "cylindrical", num_bands=7)
+    assert job.corners == o["corners"] and job.warped_sizes == o["sizes"]
+    _assert_same(pano, pmask, o)
+
+
+@pytest.mark.parametrize("btype", ["feather", "no"])
+def test_config5_vs_oracle(oracle, gpu_ctx, btype):
+    """BASELINE configs[4]: AffineStitcher path, 16 scan tiles 4000x3000, affine warp, feather / no blender."""
+    tiles = [synthetic.make_frame(i, W, H) for i in range(16)]
+    cams = synthetic.affine_scan_cameras(16, W, H)
+    job = StitchJob(tiles, cams, warper_type="affine", blender_type=btype)
+    pano, pmask = job.run()
+    o = _oracle_panorama(oracle, tiles, cams, "affine", blender_type=btype)
+    assert job.corners == o["corners"] and job.warped_sizes == o["sizes"]
+    _assert_same(pano, pmask, o)
