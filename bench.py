@@ -1,23 +1,30 @@
 #!/usr/bin/env python
 """bench.py — warp + multi-band blend throughput on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without RANK in the environment: spawns its N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one batch of synthetic input: every source frame
-(already resident in HBM) is warped (spherical, fused image + mask), fed to the 5-band blender
-and the panorama is produced in HBM.  N = 1 runs BASELINE.json configs[1]
-(8 synthetic 4000x3000 frames).  N > 1 is weak scaling: 8 frames per GPU, 8N frames in one ring
-panorama (stitching_amd/synthetic.py: ring_cameras), sharded as contiguous yaw runs.
+A "step" is one pass of the hot path over one batch of synthetic input: every source frame (already resident in HBM) is
+warped (fused image + mask), fed to the blender and the panorama is produced in HBM.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
-HIP events on the stream the kernel runs on) and `cpu_baseline` (the oracle, timed on the host
-cores, N = 1 only).  torch is imported only for N > 1 (rendezvous / barrier); the product path is
-ctypes -> libstitching_amd.so.
+  N = 1   BASELINE.json configs[1]: 8 synthetic 4000x3000 frames, spherical warp + 5-band blend.
+  N > 1   BASELINE.json configs[2] ("config 3"): 4000x3000 frames as yaw columns x 4 pitch rows (f = 0.75 W), one column
+          of 4 frames per GPU — N = 8 is the 32-frame configuration itself, N = 2 / 4 are 2 / 4 of its 8 columns (same
+          yaw step, same geometry per GPU: weak scaling).  --config 4: 8000x6000, cylindrical, 7 bands, two columns =
+          8 frames per GPU (N = 8: configs[3], 64 frames).  --config 2 --gpus N: the tele-ring family of round 1.
+  --config 3 / 4 at N = 1: one GPU's share of that configuration, unsharded (the same-family single-GPU rate).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP events on the
+stream the kernel runs on), `parity` (N = 1: the panorama of the timed path against the oracle's) and `cpu_baseline`
+(the oracle, timed on the host cores, N = 1 only).  torch is imported only for N > 1 (rendezvous / barrier); the
+product path is ctypes -> libstitching_amd.so.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import socket
 import sys
 import time
 
@@ -26,6 +33,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MIN_TIMED_S = 0.5      # the timed region is repeated in rounds of --steps until it holds at least this much work
 
 
 def parse():
@@ -33,21 +41,76 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--frames-per-gpu", type=int, default=8)
-    p.add_argument("--width", type=int, default=4000)
-    p.add_argument("--height", type=int, default=3000)
-    p.add_argument("--bands", type=int, default=5)
-    p.add_argument("--warper", default="spherical")
-    p.add_argument("--blender", default="multiband")
+    p.add_argument("--config", type=int, default=0, help="BASELINE configuration 2..5 (1-based as in DESIGN.md); default: 2 at "
+                   "N = 1, 3 at N > 1")
+    p.add_argument("--frames-per-gpu", type=int, default=0, help="config 2 only (default 8)")
+    p.add_argument("--width", type=int, default=0)
+    p.add_argument("--height", type=int, default=0)
+    p.add_argument("--bands", type=int, default=0)
+    p.add_argument("--warper", default="")
+    p.add_argument("--blender", default="")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extra", action="store_true", help="skip the extra legs (seam masks, configs 4 / 5, latency)")
     p.add_argument("--cpu-frames", type=int, default=8, help="frames in the CPU-baseline sample")
     p.add_argument("--profile-steps", type=int, default=3)
+    p.add_argument("--min-seconds", type=float, default=MIN_TIMED_S)
     p.add_argument("--streams", type=int, default=2, help="panoramas in flight per GPU (contexts = HIP streams); N = 1 "
                    "measured: 1 -> 93.0, 2 -> 105.9, 3 -> 99.6 Gpix/s")
     p.add_argument("--e2e-steps", type=int, default=2, help="PCIe-inclusive passes (host frames in, host panorama out)")
-    p.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_traffic.json"),
+    p.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r02_traffic.json"),
                    help="JSON with PMC-derived HBM bytes per launch (tools/make_traffic_json.py)")
     return p.parse_args()
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources: a traffic profile is only quoted for the build it was measured on."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "stitching_amd", "csrc", "*"))):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def workload(args, world):
+    """Cameras and shapes of the configuration (all ranks build the same description)."""
+    from stitching_amd import synthetic
+
+    cfg = args.config or (2 if world == 1 else 3)
+    w = dict(cfg=cfg)
+    if cfg == 2:
+        w.update(width=4000, height=3000, warper="spherical", blender="multiband", bands=5, fpg=args.frames_per_gpu or 8)
+    elif cfg == 3:
+        w.update(width=4000, height=3000, warper="spherical", blender="multiband", bands=5, fpg=4)
+    elif cfg == 4:
+        w.update(width=8000, height=6000, warper="cylindrical", blender="multiband", bands=7, fpg=8)
+    elif cfg == 5:
+        w.update(width=4000, height=3000, warper="affine", blender="feather", bands=0, fpg=16)
+    else:
+        raise SystemExit(f"bench.py: unknown --config {cfg}")
+    for k, v in (("width", args.width), ("height", args.height), ("bands", args.bands), ("warper", args.warper), ("blender", args.blender)):
+        if v:
+            w[k] = v
+    W, H, fpg = w["width"], w["height"], w["fpg"]
+    n_total = fpg * world
+    if w["warper"] == "affine":
+        if world > 1:
+            raise SystemExit("bench.py: config 5 (AffineStitcher tiles) is a single-GPU configuration")
+        cams = synthetic.affine_scan_cameras(n_total, W, H)
+        name = f"BASELINE config 5: {n_total} scan tiles {W}x{H}, affine warp + {w['blender']} blender"
+    elif cfg == 2:
+        cams = synthetic.ring_cameras(n_total, W, H, focal_factor=0.75 * world)
+        name = (f"BASELINE config 2: {n_total} synthetic {W}x{H} frames, one ring" if world == 1 else
+                f"config-2 family: {n_total} synthetic {W}x{H} frames, one tele ring (focal 0.75 W x {world}), {fpg} per GPU")
+    elif cfg == 3:
+        cams = synthetic.grid_cameras(world, 4, W, H, layout_yaw=8)
+        name = (f"BASELINE config 3{'' if world == 8 else ' family'}: {n_total} synthetic {W}x{H} frames = {world} of 8 yaw columns x 4 pitch "
+                f"rows (f = 0.75 W, rows at +-18.6 / +-55.8 deg), one column per GPU")
+    else:
+        cams = synthetic.grid_cameras(2 * world, 4, W, H, max_edge_lat_deg=50.0, layout_yaw=16)
+        name = (f"BASELINE config 4{'' if world == 8 else ' family'}: {n_total} synthetic {W}x{H} frames = {2 * world} of 16 yaw columns x 4 "
+                f"pitch rows (f = 0.75 W), two columns per GPU")
+    w.update(cams=cams, n_total=n_total, name=name)
+    return w
 
 
 def survey_8d_bytes(src_sizes, corners, wsizes, bands):
@@ -80,9 +143,9 @@ def survey_8d_bytes(src_sizes, corners, wsizes, bands):
             "P_f": p_f, "P_d": p_d}
 
 
-def cpu_baseline(args, frames, cams, all_cams):
+def cpu_baseline(wl, frames, cams, all_cams, n_frames):
     """The oracle (CPU restatement of OpenCV's algorithm — NOT OpenCV; see oracle/stx_oracle.cpp)
-    on the same workload, all host cores (OpenMP)."""
+    on the same workload, all host cores (OpenMP).  Returns (record, panorama, mask)."""
     import numpy as np
 
     from oracle import oracle as O
@@ -91,7 +154,7 @@ def cpu_baseline(args, frames, cams, all_cams):
     O.build()
     # OpenMP thread count: all hardware threads is not the fastest choice on a 256-thread host (memory-bound
     # pyramids, SMT); calibrate on one warp and keep the best
-    w0 = O.Warper(args.warper)
+    w0 = O.Warper(wl["warper"])
     w0.set_scale(all_cams)
     best = (None, 1)
     cand = sorted({c for c in (8, 16, 32, 64, 128, O.max_threads()) if c <= O.max_threads()})
@@ -104,23 +167,25 @@ def cpu_baseline(args, frames, cams, all_cams):
             best = (dt, c)
     cores = best[1]
     O.set_num_threads(cores)
-    n = min(args.cpu_frames, len(frames))
+    n = min(n_frames, len(frames))
     frames, cams = frames[:n], cams[:n]
     sizes = [(f.shape[1], f.shape[0]) for f in frames]
-    w = O.Warper(args.warper)
+    w = O.Warper(wl["warper"])
     w.set_scale(all_cams)
     t0 = time.perf_counter()
     corners, wsizes = w.warp_rois(sizes, cams)
     roi = O.result_roi(corners, wsizes)
-    b = O.Blender(args.blender, blend_strength_for_bands(args.bands, roi[2], roi[3]))
+    strength = blend_strength_for_bands(wl["bands"], roi[2], roi[3]) if wl["blender"] == "multiband" else 5
+    b = O.Blender(wl["blender"], strength)
     b.prepare(corners, wsizes)
     for f, c, corner in zip(frames, cams, corners):
         b.feed(w.warp_image(f, c), w.create_and_warp_mask((f.shape[1], f.shape[0]), c), corner)
-    pano, _ = b.blend()
+    pano, pmask = b.blend()
     dt = time.perf_counter() - t0
     mpix = sum(f.shape[0] * f.shape[1] for f in frames) / 1e6
+    bands_txt = f"{b.blender.num_bands()}-band " if wl["blender"] == "multiband" else ""
     res = {"value": round(mpix / dt, 3), "unit": "Mpix/s", "cores": cores, "kind": "port",
-           "sample": f"{n} frames {args.width}x{args.height}, {args.warper} warp + {b.blender.num_bands()}-band "
+           "sample": f"{n} frames {wl['width']}x{wl['height']}, {wl['warper']} warp + {bands_txt}{wl['blender']} "
                      f"blend, {dt:.2f} s wall on {cores} of {O.max_threads()} OpenMP threads (fastest of {cand} on one warp); "
                      f"CPU restatement of OpenCV's algorithm (oracle/), not OpenCV"}
     # the reference's own dataflow on ONE frame (stitching/warper.py:44,59: two PyRotationWarper.warp calls, each
@@ -129,26 +194,58 @@ def cpu_baseline(args, frames, cams, all_cams):
     roi = w.warp_roi(sizes[0], cams[0])
     K0 = O.Warper.get_K(cams[0])
     O.set_num_threads(1)
-    xm, ym = O.build_maps(args.warper, w.scale, K0, cams[0].R, roi)
-    xm2, ym2 = O.build_maps(args.warper, w.scale, K0, cams[0].R, roi)
+    xm, ym = O.build_maps(wl["warper"], w.scale, K0, cams[0].R, roi)
+    xm2, ym2 = O.build_maps(wl["warper"], w.scale, K0, cams[0].R, roi)
     O.set_num_threads(cores)
     O.remap_linear(frames[0], xm, ym)
     O.remap_nearest(np.full(frames[0].shape[:2], 255, np.uint8), xm2, ym2)
     dt_ref = time.perf_counter() - t1
     res["reference_dataflow_warp"] = {"value": round(frames[0].shape[0] * frames[0].shape[1] / 1e6 / dt_ref, 3), "unit": "Mpix/s",
                                       "sample": f"1 frame, maps materialised twice by a serial buildMaps + remap x2: {dt_ref:.2f} s"}
-    return res, np.asarray(pano)
+    return res, np.asarray(pano), np.asarray(pmask)
+
+
+def timed_rounds(run_step, barrier, steps, warmup, n_inflight, min_seconds, reduce_max):
+    """W warm-up steps, then rounds of exactly K timed steps (barrier + stream sync on both sides, max over ranks) until
+    the rounds hold >= min_seconds of work.  Returns (seconds per round list)."""
+    for i in range(warmup * n_inflight):
+        run_step(i)
+    rounds = []
+    total = 0.0
+    while True:
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            run_step(i)
+        barrier()
+        dt = reduce_max(time.perf_counter() - t0)
+        rounds.append(dt)
+        total += dt
+        if total >= min_seconds or len(rounds) >= 200:
+            return rounds
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: become `torch.distributed.run` with N ranks on this node."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
 
 
 def main():
     args = parse()
+    if "RANK" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-            sys.exit(2)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -156,51 +253,57 @@ def main():
         dist = dist_mod
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
+    import numpy as np
+
     import stitching_amd as S
     from stitching_amd import synthetic
     from stitching_amd.pipeline import StitchJob
 
-    # STITCHING_AMD_FORCE_DEVICE: run every rank on one GPU (1-GPU boxes: exercises the sharded path with the
-    # host-staged transport; RCCL refuses two ranks on one device)
-    S.set_default_device(int(os.environ.get("STITCHING_AMD_FORCE_DEVICE", local_rank)))
+    # One process per GPU.  A box with fewer GPUs than ranks (the 1-GPU harness; STITCHING_AMD_FORCE_DEVICE pins it
+    # explicitly) puts several ranks on one device: the sharded path then runs with the host-staged transport
+    # (RCCL refuses two ranks on one device) and the line says so.
+    ndev = S.device_count()
+    if "STITCHING_AMD_FORCE_DEVICE" in os.environ:
+        dev = int(os.environ["STITCHING_AMD_FORCE_DEVICE"])
+        shared = world > 1
+    else:
+        dev = local_rank % max(1, ndev)
+        shared = world > ndev
+    if shared and world > 1:
+        os.environ.setdefault("STITCHING_AMD_TRANSPORT", "gloo")
+    S.set_default_device(dev)
     ctx = S.get_context()
 
-    fpg = args.frames_per_gpu
-    n_total = fpg * world
-    if args.warper == "affine":  # BASELINE config 5: scan tiles, camera.R carries the affine homography
-        all_cams = synthetic.affine_scan_cameras(n_total, args.width, args.height)
-    else:
-        all_cams = synthetic.ring_cameras(n_total, args.width, args.height, focal_factor=0.75 * world)
+    wl = workload(args, world)
+    W, H, fpg, n_total, all_cams = wl["width"], wl["height"], wl["fpg"], wl["n_total"], wl["cams"]
     my = range(rank * fpg, (rank + 1) * fpg)
-    frames = [synthetic.make_frame(i, args.width, args.height) for i in my]
+    frames = [synthetic.make_frame(i, W, H) for i in my]
     cams = [all_cams[i] for i in my]
+    nb = wl["bands"] if wl["blender"] == "multiband" else None
 
-    if world > 1:
-        from stitching_amd.distributed import ShardedStitchJob
+    def make_job(c, frames_):
+        if world > 1:
+            from stitching_amd.distributed import ShardedStitchJob
 
-        # with two panoramas in flight the other panorama's kernels cover the exchange: no boundary / interior split
-        split = max(1, args.streams) < 2
-        job = ShardedStitchJob(frames, cams, all_cams, rank, world, warper_type=args.warper,
-                               blender_type=args.blender, num_bands=args.bands, ctx=ctx, dist=dist, split_boundary=split)
-    else:
-        job = StitchJob(frames, cams, warper_type=args.warper, blender_type=args.blender, num_bands=args.bands, ctx=ctx)
-        job.warper.set_scale(all_cams)
-    job.plan()
-    # --streams S (N = 1): S contexts = S HIP streams; consecutive panoramas (independent steps) alternate between
-    # them, so the small coarse-level kernels of one panorama overlap with the large kernels of the next
-    jobs, ctxs = [job], [ctx]
-    for _ in range(1, max(1, args.streams)):
-        c = S.Context(ctx.device)
-        if world == 1:
-            j = StitchJob(job.frames, cams, warper_type=args.warper, blender_type=args.blender, num_bands=args.bands, ctx=c)
-            j.warper.set_scale(all_cams)
-        else:
-            # the ranks' second panorama in flight shares the transport (one communicator, exchanges in issue order)
-            j = ShardedStitchJob(job.frames, cams, all_cams, rank, world, warper_type=args.warper, blender_type=args.blender,
-                                 num_bands=args.bands, ctx=c, dist=dist, transport=job.transport, split_boundary=split)
+            # with two panoramas in flight the other panorama's kernels cover the exchange: no boundary / interior split
+            return ShardedStitchJob(frames_, cams, all_cams, rank, world, warper_type=wl["warper"], blender_type=wl["blender"],
+                                    num_bands=nb, ctx=c, dist=dist, split_boundary=max(1, args.streams) < 2,
+                                    transport=(jobs[0].transport if jobs else None))
+        j = StitchJob(frames_, cams, warper_type=wl["warper"], blender_type=wl["blender"], num_bands=nb, ctx=c)
+        j.warper.set_scale(all_cams)
+        return j
+
+    # --streams S: S contexts = S HIP streams; consecutive panoramas (independent steps) alternate between them, so the
+    # small coarse-level kernels of one panorama overlap with the large kernels of the next.  At N > 1 the panoramas in
+    # flight of a rank share ONE transport (one communicator, exchanges in issue order)
+    jobs, ctxs = [], []
+    for s_i in range(max(1, args.streams)):
+        c = ctx if s_i == 0 else S.Context(ctx.device)
+        j = make_job(c, frames if s_i == 0 else jobs[0].frames)
         j.plan()
         jobs.append(j)
         ctxs.append(c)
+    job = jobs[0]
 
     def barrier():
         for c in ctxs:
@@ -208,22 +311,22 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    for i in range(args.warmup * len(jobs)):
-        out = jobs[i % len(jobs)].run()
-        del out
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = jobs[i % len(jobs)].run()
-        del out
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
+    def reduce_max(dt):
+        if dist is None:
+            return dt
         import torch
 
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
+
+    def run_step(i):
+        out = jobs[i % len(jobs)].run()
+        del out
+
+    rounds = timed_rounds(run_step, barrier, args.steps, args.warmup, len(jobs), args.min_seconds, reduce_max)
+    steps_executed = args.steps * len(rounds)
+    dt_total = sum(rounds)
 
     # per-kernel durations: HIP events on the ctx stream, separate pass over the same steps
     ctx.prof_reset()
@@ -235,138 +338,262 @@ def main():
     kernels = ctx.prof_results()
     ctx.prof_reset()
 
+    # the same-family single-GPU rate (N > 1): this rank's share as an unsharded panorama of its own — no strips, no
+    # exchange, the whole band; what `value / n_gpus` is to be compared with, since the N = 1 line is another geometry
+    share = None
+    if world > 1:
+        sj = [StitchJob(jobs[0].frames, cams, warper_type=wl["warper"], blender_type=wl["blender"], num_bands=nb, ctx=c) for c in ctxs]
+        for j in sj:
+            j.warper.set_scale(all_cams)
+        sr = timed_rounds(lambda i: sj[i % len(sj)].run(), barrier, max(4, args.steps // 2), 1, len(sj), args.min_seconds / 2, reduce_max)
+        share = fpg * W * H / 1e6 / (sum(sr) / (max(4, args.steps // 2) * len(sr)))
+        del sj
+
     if rank != 0:
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
         return
 
-    src_mpix = n_total * args.width * args.height / 1e6
-    # warped (destination) pixels of all frames: the tele ring of N > 1 has less spherical compression than config 2
-    # (ROI 4043x3055 instead of 3528x2782 per frame), i.e. 1.23x the warp / pyramid work per source pixel
+    src_mpix = n_total * W * H / 1e6
     wsz = job.plan_.sizes if world > 1 else job.warped_sizes
     warped_mpix = sum(w * h for w, h in wsz) / 1e6
-    ms_per_step = dt / args.steps * 1e3
+    ms_per_step = dt_total / steps_executed * 1e3
     value = src_mpix / (ms_per_step / 1e3)
+    per_round = sorted(src_mpix * args.steps / r for r in rounds)
     kernels.sort(key=lambda k: -k["total_ms"])
     dom = kernels[0]
     avg_ms = dom["total_ms"] / dom["calls"]
     bytes_per_launch = dom["algo_bytes"] / dom["calls"]
     achieved = bytes_per_launch / (avg_ms / 1e3) / 1e9
     traffic = None
+    khash = kernel_source_hash()
     if args.traffic_json and os.path.exists(args.traffic_json):
-        t = json.load(open(args.traffic_json)).get(dom["kernel"])
-        # measured on config 2 only (profiles/): per-launch bytes of the same kernel on the same workload
-        if t and world == 1 and (args.width, args.height, args.frames_per_gpu, args.bands) == (4000, 3000, 8, 5):
+        tj = json.load(open(args.traffic_json))
+        t = tj.get(dom["kernel"])
+        # per-launch PMC bytes of the same kernel on the same workload AND the same kernel sources; anything else: null
+        if t and tj.get("kernel_source_hash") == khash and tj.get("workload_cfg", 2) == wl["cfg"] and world == 1:
             traffic = round(t["traffic_bytes"])
     roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_launch_us": round(avg_ms * 1e3, 2), "algo_bytes_per_launch": round(bytes_per_launch),
-                "launches_per_step": dom["calls"] / max(1, args.profile_steps)}
+                "launches_per_step": dom["calls"] / max(1, args.profile_steps), "kernel_source_hash": khash}
     ksum = sum(k["total_ms"] for k in kernels)
     kbytes = sum(k["algo_bytes"] for k in kernels)
+    bands_txt = f"{getattr(job, 'last_num_bands', wl['bands'])}-band " if wl["blender"] == "multiband" else ""
     result = {
         "metric": "warped+blended Mpix/s", "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8/int16 (fixed-point remap, int32 pyramid sums, fp32 weights)",
         "data": "synthetic",
-        "config": {"workload": f"{n_total} synthetic {args.width}x{args.height} frames, {args.warper} warp + "
-                               f"{getattr(job, 'last_num_bands', args.bands)}-band {args.blender} blend, inputs resident in HBM",
-                   "frames_per_gpu": fpg, "sharding": "contiguous yaw runs" if world > 1 else "single GPU",
+        "steps_executed": steps_executed,
+        "timed_rounds": {"rounds": len(rounds), "steps_per_round": args.steps, "seconds": round(dt_total, 4),
+                         "value_min": round(per_round[0], 1), "value_median": round(per_round[len(per_round) // 2], 1),
+                         "value_max": round(per_round[-1], 1),
+                         "note": "rounds of exactly --steps steps, repeated until >= %.2g s are timed; value = all steps / all time" % args.min_seconds},
+        "config": {"workload": f"{wl['name']}; {wl['warper']} warp + {bands_txt}{wl['blender']} blend, inputs resident in HBM",
+                   "baseline_config": wl["cfg"], "frames_per_gpu": fpg,
+                   "sharding": ("contiguous yaw columns -> panorama column bands, contribution strips "
+                                f"({jobs[0].transport.name})") if world > 1 else "single GPU",
+                   "ranks_share_a_gpu": bool(shared and world > 1),
                    "panoramas_in_flight": len(jobs),
                    "warped_mpix_per_step": round(warped_mpix, 2),
                    "source_mpix_per_step": round(src_mpix, 2)},
         "roofline": roofline,
         "kernels": [{"kernel": k["kernel"], "calls_per_step": k["calls"] / max(1, args.profile_steps),
                      "avg_us": round(k["total_ms"] / k["calls"] * 1e3, 2),
-                     "algo_GBps": round(k["algo_bytes"] / max(k["total_ms"], 1e-9) / 1e6, 1)} for k in kernels],
+                     "algo_GBps": round(k["algo_bytes"] / max(k["total_ms"], 1e-9) / 1e6, 1),
+                     "frac_of_hbm_peak": round(k["algo_bytes"] / max(k["total_ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4)} for k in kernels],
         "all_kernels": {"sum_ms_per_step": round(ksum / max(1, args.profile_steps), 4),
                         "algo_GBps": round(kbytes / max(ksum, 1e-9) / 1e6, 1),
-                        "frac_of_hbm_peak": round(kbytes / max(ksum, 1e-9) / 1e6 / HBM_PEAK_GBS, 4)},
+                        "frac_of_hbm_peak": round(kbytes / max(ksum, 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
+                        "note": "bytes the fused kernels move (algorithmic, per kernel) / summed kernel time: the bandwidth fraction of the path"},
     }
-    if world == 1 and hasattr(job, "corners") and args.blender == "multiband":
+    if world > 1:
+        p = job.plan_
+        result["config"]["exchange"] = {"messages": len(p.messages), "bytes_per_step": p.exchanged_bytes(),
+                                        "rank0_sends_MB": round(sum(m[4] for m in p.sends(0)) / 1e6, 1)}
+        result["same_family_single_gpu"] = {
+            "value_per_gpu": round(share, 1), "unit": "Mpix/s",
+            "efficiency_vs_it": round(value / world / share, 4),
+            "note": "slowest rank's rate on its own 4-frame (8-frame) share as an unsharded panorama, measured in this run: the "
+                    "single-GPU rate of THIS geometry (the N = 1 line runs config 2, whose frames warp to 0.82 of their "
+                    "source size; config 3's +-56 degree rows warp to 2.0 x)"}
+    if world == 1 and hasattr(job, "corners") and wl["blender"] == "multiband":
         m = survey_8d_bytes(job.sizes, job.corners, job.warped_sizes, job.last_num_bands)
         gbps = m["total"] / (ms_per_step / 1e3) / 1e9
-        result["path_roofline"] = {
-            "model": "SURVEY.md 8(d): algorithmic bytes of the warp + blend path (OpenCV dataflow, maps not stored)",
+        result["model_speed_index"] = {
+            "model": "SURVEY.md 8(d): bytes OpenCV's UNFUSED dataflow would move for this pass (maps not stored) / step time. "
+                     "Not a bandwidth fraction of this implementation (the fused path moves about 2.3x fewer bytes): see "
+                     "all_kernels.frac_of_hbm_peak and kernels[].frac_of_hbm_peak for that",
             "bytes_per_source_px": round(m["total"] / m["P_s"], 2), "bytes_per_step": round(m["total"]),
-            "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBS, 4),
+            "model_GBps": round(gbps, 1), "index_vs_8TBps": round(gbps / HBM_PEAK_GBS, 4),
             "P_s": m["P_s"], "P_w": m["P_w"], "P_f": m["P_f"], "P_d": m["P_d"]}
-    if world == 1 and args.e2e_steps > 0:
-        # PCIe-inclusive rate (never `value`): host numpy frames in, host panorama out
-        from stitching_amd.pipeline import stitch
-
-        job.warper.set_scale(all_cams)
-        t1 = time.perf_counter()
-        for _ in range(args.e2e_steps):
-            stitch(frames, cams, warper_type=args.warper, blender_type=args.blender, num_bands=args.bands)
-        e2e = (time.perf_counter() - t1) / args.e2e_steps
-        result["pcie_inclusive"] = {"value": round(src_mpix / e2e, 1), "unit": "Mpix/s", "ms_per_step": round(e2e * 1e3, 2),
-                                    "note": "pageable numpy frames H2D + roi sync + panorama D2H every step; not `value`"}
-        # the same with page-locked frames (a decoder writing into stitching_amd.pinned_empty arrays) and a
-        # page-locked panorama buffer
-        import numpy as np
-
-        from stitching_amd import pinned_empty
-        from stitching_amd.pipeline import StitchJob
-
-        pframes = []
-        for f in frames:
-            pf = pinned_empty(f.shape, f.dtype)
-            np.copyto(pf, f)
-            pframes.append(pf)
-        pout = {}
-
-        def pinned_step():
-            pano, pmask = StitchJob(pframes, cams, warper_type=args.warper, blender_type=args.blender,
-                                    num_bands=args.bands).run()
-            for key, d in (("pano", pano), ("mask", pmask)):
-                if key not in pout or pout[key].shape != d.shape:
-                    pout[key] = pinned_empty(d.shape, d.dtype)
-                d.numpy(out=pout[key])
-
-        pinned_step()
-        t1 = time.perf_counter()
-        for _ in range(args.e2e_steps):
-            pinned_step()
-        e2p = (time.perf_counter() - t1) / args.e2e_steps
-        result["pcie_inclusive"]["pinned"] = {"value": round(src_mpix / e2p, 1), "ms_per_step": round(e2p * 1e3, 2)}
-        # ... and as a stream of panoramas alternating between two contexts with queued (asynchronous) uploads and
-        # read-backs: the upload of one panorama overlaps the read-back of the previous one (both PCIe directions busy)
-        if len(ctxs) >= 2:
-            pouts = [dict(), dict()]
-
-            def piped_step(i):
-                c, po = ctxs[i % 2], pouts[i % 2]
-                c.sync()  # this context's previous panorama has landed in its host buffers
-                pano, pmask = StitchJob(pframes, cams, warper_type=args.warper, blender_type=args.blender,
-                                        num_bands=args.bands, ctx=c, async_upload=True).run()
-                for key, d in (("pano", pano), ("mask", pmask)):
-                    if key not in po or po[key].shape != d.shape:
-                        po[key] = pinned_empty(d.shape, d.dtype)
-                    d.numpy(out=po[key], wait=False)
-
-            for i in range(2):
-                piped_step(i)
-            for c in ctxs[:2]:
-                c.sync()
-            n_piped = 2 * max(2, args.e2e_steps)
+    if world == 1:
+        # latency of ONE panorama: one stream, a device sync after every step
+        lat_job = jobs[0]
+        for _ in range(2):
+            lat_job.run()
+        ctx.sync()
+        lats = []
+        for _ in range(max(5, args.steps // 2)):
             t1 = time.perf_counter()
-            for i in range(n_piped):
-                piped_step(i)
-            for c in ctxs[:2]:
-                c.sync()
-            e2q = (time.perf_counter() - t1) / n_piped
-            same = all(np.array_equal(pouts[k]["pano"], pout["pano"]) for k in range(2))
-            result["pcie_inclusive"]["pinned_pipelined"] = {"value": round(src_mpix / e2q, 1), "ms_per_step": round(e2q * 1e3, 2),
-                                                            "equals_synchronous_result": bool(same)}
+            out = lat_job.run()
+            ctx.sync()
+            lats.append(time.perf_counter() - t1)
+            del out
+        lats.sort()
+        result["latency_ms_single_stream"] = {"median": round(lats[len(lats) // 2] * 1e3, 4), "min": round(lats[0] * 1e3, 4),
+                                              "max": round(lats[-1] * 1e3, 4), "panoramas": len(lats)}
+    if world == 1 and not args.no_extra:
+        result["extra"] = extra_legs(args, S, synthetic, StitchJob, ctxs, wl, jobs[0], all_cams)
+    if world == 1 and args.e2e_steps > 0:
+        result["pcie_inclusive"] = pcie_legs(args, S, StitchJob, ctxs, wl, frames, cams, src_mpix, nb)
     if world == 1 and not args.no_cpu_baseline:
-        cb, _ = cpu_baseline(args, frames, cams, all_cams)
+        cb, o_pano, o_mask = cpu_baseline(wl, frames, cams, all_cams, args.cpu_frames)
         result["cpu_baseline"] = cb
+        if args.cpu_frames >= len(frames):
+            # the panorama of the timed path (same job object, same kernels) against the oracle's, byte for byte
+            g_pano, g_mask = (np.asarray(a) for a in jobs[0].run())
+            if g_pano.shape == o_pano.shape:
+                d = np.abs(g_pano.astype(np.int16) - o_pano.astype(np.int16))
+                result["parity"] = {"vs": "oracle (oracle/stx_oracle.cpp, default model: exact trig, scalar pyrDown order, Q15 remap)",
+                                    "max_abs_diff": int(d.max()), "differing_bytes": int(np.count_nonzero(d)),
+                                    "mask_equal": bool(np.array_equal(g_mask, o_mask)), "panorama_shape": list(g_pano.shape)}
+            else:
+                result["parity"] = {"vs": "oracle", "shape_mismatch": [list(g_pano.shape), list(o_pano.shape)]}
     print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def quick_rate(jobs, ctxs, mpix, steps=6, warmup=2, min_seconds=0.25):
+    def barrier():
+        for c in ctxs:
+            c.sync()
+
+    r = timed_rounds(lambda i: jobs[i % len(jobs)].run(), barrier, steps, warmup, len(jobs), min_seconds, lambda x: x)
+    ms = sum(r) / (steps * len(r)) * 1e3
+    return {"value": round(mpix / (ms / 1e3), 1), "unit": "Mpix/s", "ms_per_step": round(ms, 4), "steps_executed": steps * len(r)}
+
+
+def extra_legs(args, S, synthetic, StitchJob, ctxs, wl, job, all_cams):
+    """Other operating points on the same GPU, same timing method (two panoramas in flight), fewer steps.  Not `value`."""
+    import numpy as np
+
+    out = {}
+    if wl["cfg"] == 2 and wl["blender"] == "multiband":
+        src_mpix = sum(w * h for w, h in job.sizes) / 1e6
+        # (ii) of SURVEY 8(d): Voronoi seam masks ANDed with the warped masks (binary, full resolution)
+        S.set_device_resident(True)
+        try:
+            _, masks, _ = job.warper.warp_images_and_masks(job.frames, job.cameras)
+            h_masks = [np.asarray(m) for m in masks]
+        finally:
+            S.set_device_resident(False)
+        seams = synthetic.voronoi_seam_masks(h_masks, job.corners, job.warped_sizes)
+        js = []
+        for c in ctxs:
+            j = StitchJob(job.frames, job.cameras, num_bands=wl["bands"], ctx=c, feed_masks=[S.DeviceImage.from_numpy(m, c) for m in seams])
+            j.warper.set_scale(all_cams)
+            js.append(j)
+        out["voronoi_seam_masks"] = dict(quick_rate(js, ctxs, src_mpix), note="full-resolution 0/255 seam masks fed instead of the warped masks")
+        # the reference's default pipeline: low-resolution seam masks resized per panorama (SeamFinder.resize) -> grey edges,
+        # non-binary masks -> the fp32-weight level-0 kernel
+        low = [np.ascontiguousarray(m[::11, ::11]) for m in seams]
+        js = []
+        for c in ctxs:
+            j = StitchJob(job.frames, job.cameras, num_bands=wl["bands"], ctx=c, seam_masks=[S.DeviceImage.from_numpy(m, c) for m in low])
+            j.warper.set_scale(all_cams)
+            js.append(j)
+        out["resized_seam_masks"] = dict(quick_rate(js, ctxs, src_mpix),
+                                         note="0.09-scale seam masks -> SeamFinder.resize on the device every step (dilate, "
+                                              "INTER_LINEAR_EXACT, AND): non-binary masks, fp32-weight level-0 gather")
+        del js
+    if wl["cfg"] == 2:
+        # BASELINE configs[3] (config 4), one GPU's share: 8 x 8000x6000, cylindrical, 7 bands
+        cams4 = synthetic.grid_cameras(2, 4, 8000, 6000, max_edge_lat_deg=50.0, layout_yaw=16)
+        fr4 = [S.DeviceImage.from_numpy(synthetic.make_frame(100 + i, 8000, 6000), ctxs[0]) for i in range(8)]
+        js = [StitchJob(fr4, cams4, warper_type="cylindrical", num_bands=7, ctx=c) for c in ctxs]
+        out["config4_share"] = dict(quick_rate(js, ctxs, 8 * 48.0, steps=4), bands=7,
+                                    note="8 x 8000x6000 (2 of 16 yaw columns x 4 pitch rows), cylindrical warp + 7-band blend")
+        del js, fr4
+        # BASELINE configs[4] (config 5): 16 affine scan tiles, feather / no
+        cams5 = synthetic.affine_scan_cameras(16, 4000, 3000)
+        fr5 = [S.DeviceImage.from_numpy(synthetic.make_frame(i, 4000, 3000), ctxs[0]) for i in range(16)]
+        for bt in ("feather", "no"):
+            js = [StitchJob(fr5, cams5, warper_type="affine", blender_type=bt, ctx=c) for c in ctxs]
+            out[f"config5_{bt}"] = dict(quick_rate(js, ctxs, 16 * 12.0, steps=4), note=f"16 affine scan tiles 4000x3000, {bt} blender")
+        del js, fr5
+    return out
+
+
+def pcie_legs(args, S, StitchJob, ctxs, wl, frames, cams, src_mpix, nb):
+    """PCIe-inclusive rates (never `value`): host numpy frames in, host panorama out."""
+    import numpy as np
+
+    from stitching_amd import pinned_empty
+    from stitching_amd.pipeline import stitch
+
+    kw = dict(warper_type=wl["warper"], blender_type=wl["blender"], num_bands=nb)
+    stitch(frames, cams, **kw)
+    t1 = time.perf_counter()
+    for _ in range(args.e2e_steps):
+        stitch(frames, cams, **kw)
+    e2e = (time.perf_counter() - t1) / args.e2e_steps
+    res = {"value": round(src_mpix / e2e, 1), "unit": "Mpix/s", "ms_per_step": round(e2e * 1e3, 2),
+           "note": "pageable numpy frames H2D + roi sync + panorama D2H every step; not `value`"}
+    # the same with page-locked frames (a decoder writing into stitching_amd.pinned_empty arrays) and a page-locked panorama buffer
+    pframes = []
+    for f in frames:
+        pf = pinned_empty(f.shape, f.dtype)
+        np.copyto(pf, f)
+        pframes.append(pf)
+    pout = {}
+
+    def pinned_step():
+        pano, pmask = StitchJob(pframes, cams, **kw).run()
+        for key, d in (("pano", pano), ("mask", pmask)):
+            if key not in pout or pout[key].shape != d.shape:
+                pout[key] = pinned_empty(d.shape, d.dtype)
+            d.numpy(out=pout[key])
+
+    pinned_step()
+    t1 = time.perf_counter()
+    for _ in range(args.e2e_steps):
+        pinned_step()
+    e2p = (time.perf_counter() - t1) / args.e2e_steps
+    res["pinned"] = {"value": round(src_mpix / e2p, 1), "ms_per_step": round(e2p * 1e3, 2)}
+    # ... and as a stream of panoramas alternating between two contexts with queued (asynchronous) uploads and
+    # read-backs: the upload of one panorama overlaps the read-back of the previous one (both PCIe directions busy)
+    if len(ctxs) >= 2:
+        pouts = [dict(), dict()]
+
+        def piped_step(i):
+            c, po = ctxs[i % 2], pouts[i % 2]
+            c.sync()  # this context's previous panorama has landed in its host buffers
+            pano, pmask = StitchJob(pframes, cams, ctx=c, async_upload=True, **kw).run()
+            for key, d in (("pano", pano), ("mask", pmask)):
+                if key not in po or po[key].shape != d.shape:
+                    po[key] = pinned_empty(d.shape, d.dtype)
+                d.numpy(out=po[key], wait=False)
+
+        for i in range(2):
+            piped_step(i)
+        for c in ctxs[:2]:
+            c.sync()
+        n_piped = 2 * max(2, args.e2e_steps)
+        t1 = time.perf_counter()
+        for i in range(n_piped):
+            piped_step(i)
+        for c in ctxs[:2]:
+            c.sync()
+        e2q = (time.perf_counter() - t1) / n_piped
+        same = all(np.array_equal(pouts[k]["pano"], pout["pano"]) for k in range(2))
+        res["pinned_pipelined"] = {"value": round(src_mpix / e2q, 1), "ms_per_step": round(e2q * 1e3, 2),
+                                   "equals_synchronous_result": bool(same)}
+    return res
 
 
 if __name__ == "__main__":

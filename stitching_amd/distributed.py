@@ -285,7 +285,8 @@ class RcclTransport:
 
     def close(self):
         if self._h is not None:
-            self.ctx._lib.stx_comm_destroy(self._h)
+            if self.ctx.handle:  # stx_comm_destroy uses the context's device and stream: never after Context.close()
+                self.ctx._lib.stx_comm_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -419,20 +420,27 @@ def default_transport(ctx, rank, world, dist):
     import os
 
     want = os.environ.get("STITCHING_AMD_TRANSPORT", "rccl")
-    ok = 0
-    tr = None
-    if want == "rccl":
+    import sys
+
+    import torch
+
+    # Every rank issues the same sequence of collectives whatever fails where: (1) rank 0 ALWAYS broadcasts — the unique
+    # id, or None when librccl is missing / refused or RCCL is not wanted; (2) ranks that got an id try to join the
+    # communicator; (3) one all-reduce(MIN) decides for everybody.
+    uid = [None]
+    if rank == 0 and want == "rccl":
         try:
-            uid = [RcclTransport.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
+            uid = [RcclTransport.unique_id()]
+        except Exception as e:  # noqa: BLE001
+            print(f"[stitching_amd] rank 0: no RCCL unique id ({e}); using host-staged gloo", file=sys.stderr)
+    dist.broadcast_object_list(uid, src=0)
+    ok, tr = 0, None
+    if uid[0] is not None:
+        try:
             tr = RcclTransport(ctx, rank, world, uid[0])
             ok = 1
         except Exception as e:  # noqa: BLE001 - any failure -> agree on the fallback below
-            import sys
-
             print(f"[stitching_amd] rank {rank}: RCCL transport unavailable ({e}); using host-staged gloo", file=sys.stderr)
-    import torch
-
     flag = torch.tensor([ok], dtype=torch.int32)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) == 1:

@@ -21,9 +21,13 @@ class StitchJob:
     """Pre-staged inputs of one panorama: device-resident source frames + cameras."""
 
     def __init__(self, frames, cameras, warper_type="spherical", blender_type="multiband", num_bands=None,
-                 blend_strength=Blender.DEFAULT_BLEND_STRENGTH, ctx=None, async_upload=False):
+                 blend_strength=Blender.DEFAULT_BLEND_STRENGTH, ctx=None, async_upload=False, feed_masks=None, seam_masks=None):
         """async_upload: numpy frames in page-locked memory (pinned_empty) are only queued for upload; they must stay
-        untouched until ctx.sync() (a streaming caller alternates two contexts)."""
+        untouched until ctx.sync() (a streaming caller alternates two contexts).
+        feed_masks: final-resolution u8 masks fed to the blender instead of the warped masks (seam masks already at the
+        warped size); seam_masks: LOW-resolution seam masks, resized on the device every run exactly as the reference
+        does per panorama (SeamFinder.resize, stitching/stitcher.py:124: dilate, INTER_LINEAR_EXACT, AND with the warped
+        mask) — its grey edges make the masks non-binary."""
         if len(frames) != len(cameras) or not frames:
             raise StitchingError("need one camera per frame and at least one frame")
         self.ctx = ctx or get_context()
@@ -36,6 +40,8 @@ class StitchJob:
         self.num_bands = num_bands
         self.blend_strength = blend_strength
         self.corners = self.warped_sizes = None
+        self.feed_masks = None if feed_masks is None else [as_device(m, self.ctx) for m in feed_masks]
+        self.seam_masks = None if seam_masks is None else [as_device(m, self.ctx) for m in seam_masks]
 
     @property
     def source_pixels(self):
@@ -63,6 +69,12 @@ class StitchJob:
             blender = Blender(self.blender_type, self.blend_strength, ctx=self.ctx)
             blender.prepare(self.corners, self.warped_sizes)
             imgs, masks, rois = self.warper.warp_images_and_masks(self.frames, self.cameras)
+            if self.feed_masks is not None:
+                masks = self.feed_masks
+            elif self.seam_masks is not None:
+                from .seam_finder import SeamFinder
+
+                masks = [SeamFinder.resize(s, m) for s, m in zip(self.seam_masks, masks)]
             for img, mask, roi, corner in zip(imgs, masks, rois, self.corners):
                 if roi[0:2] != tuple(corner):
                     raise StitchingError("warp roi changed between plan() and run()")

@@ -42,9 +42,14 @@ class SeamFinder:
 
     @staticmethod
     def resize(seam_mask, mask):
-        """stitching/seam_finder.py:37-43 — returns the final-resolution seam mask for Blender.feed."""
-        ctx = get_context()
-        s, m = as_device(np.asarray(seam_mask) if not isinstance(seam_mask, DeviceImage) else seam_mask, ctx), as_device(mask, ctx)
+        """stitching/seam_finder.py:37-43 — returns the final-resolution seam mask for Blender.feed.  `seam_mask` may be
+        what cv2's finders return (a cv.UMat: `.get()` is called), a numpy array or a DeviceImage."""
+        ctx = mask.ctx if isinstance(mask, DeviceImage) else (seam_mask.ctx if isinstance(seam_mask, DeviceImage) else get_context())
+        if not isinstance(seam_mask, DeviceImage):
+            seam_mask = np.asarray(seam_mask.get() if hasattr(seam_mask, "get") else seam_mask)
+        if not isinstance(mask, DeviceImage):
+            mask = np.asarray(mask.get() if hasattr(mask, "get") else mask)
+        s, m = as_device(seam_mask, ctx), as_device(mask, ctx)
         out = C.c_void_p()
         _lib.check(ctx._lib.stx_seam_mask_resize(ctx.handle, s._h, m._h, C.byref(out)))
         r = DeviceImage(ctx, out)

@@ -87,7 +87,8 @@ def _lon_half_extent_deg(width, height, focal, pitch_deg, roll_deg=1.5):
     return best
 
 
-def grid_cameras(n_yaw, n_pitch, width, height, focal_factor=0.75, span_deg=340.0, max_edge_lat_deg=83.0, jitter=True):
+def grid_cameras(n_yaw, n_pitch, width, height, focal_factor=0.75, span_deg=340.0, max_edge_lat_deg=83.0, jitter=True,
+                 layout_yaw=None):
     """BASELINE configs 3 / 4: `n_pitch` rows of `n_yaw` cameras, focal = focal_factor * width, pitch rows
     0.70 * vfov apart and centred on the equator, compressed so that no frame edge passes latitude max_edge_lat_deg
     (4 rows of 4000x3000 at focal_factor 0.75: +-18.6 and +-55.8 degrees — SURVEY's "clamped to |pitch| < 60"; a
@@ -97,7 +98,9 @@ def grid_cameras(n_yaw, n_pitch, width, height, focal_factor=0.75, span_deg=340.
     Order: yaw-major (all pitch rows of the first yaw step, then the next), so contiguous runs of the list are
     contiguous panorama columns — the run a GPU owns.
 
-    8 x 4, 4000x3000: config 3 (32 frames, 4 per GPU at N = 8); 16 x 4, 8000x6000, max_edge_lat_deg 50: config 4."""
+    8 x 4, 4000x3000: config 3 (32 frames, 4 per GPU at N = 8); 16 x 4, 8000x6000, max_edge_lat_deg 50: config 4.
+    layout_yaw: take the yaw step of the layout with that many columns and place only `n_yaw` columns (centred) — the
+    weak-scaling family of a config: N GPUs hold N (2 N) of its 8 (16) columns, geometry per GPU unchanged."""
     focal = focal_factor * width
     hfov = 2.0 * math.degrees(math.atan(width / (2.0 * focal)))
     vfov = 2.0 * math.degrees(math.atan(height / (2.0 * focal)))
@@ -107,7 +110,9 @@ def grid_cameras(n_yaw, n_pitch, width, height, focal_factor=0.75, span_deg=340.
     half = min((span_deg - hfov) / 2.0, 177.0 - reach)
     if half < 0:
         raise ValueError("frames pitched this far cover more than the whole circle of longitudes")
-    yaws = [0.0] if n_yaw == 1 else list(np.linspace(-half, half, n_yaw))
+    ly = layout_yaw or n_yaw
+    step = 0.0 if ly == 1 else 2.0 * half / (ly - 1)
+    yaws = [step * (i - (n_yaw - 1) / 2.0) for i in range(n_yaw)]
     cams = []
     for i, yaw in enumerate(yaws):
         for j, pitch in enumerate(pitches):

@@ -6,7 +6,7 @@ cp stitching_amd/libstitching_amd.so /tmp/orig.so
 for rep in 1 2; do
 for w in orig var; do
   if [ $w = var ]; then cp $V stitching_amd/libstitching_amd.so; else cp /tmp/orig.so stitching_amd/libstitching_amd.so; fi
-  timeout 300 python bench.py --no-cpu-baseline --e2e-steps 0 --steps 30 "$@" > /tmp/b.json 2>/dev/null
+  timeout 300 python bench.py --no-cpu-baseline --no-extra --e2e-steps 0 --steps 30 "$@" > /tmp/b.json 2>/dev/null
   python - <<PY
 import json
 d=json.loads(open('/tmp/b.json').read().strip().splitlines()[-1])

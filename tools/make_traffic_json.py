@@ -5,10 +5,23 @@ gfx950's FETCH_SIZE counts 128-byte read requests at 64 B, so reads are doubled 
 as reported (uncalibrated).  usage: make_traffic_json.py <dir with pmc*_counter_collection.csv> <out.json>"""
 import csv
 import glob
+import hashlib
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_hash():
+    """as bench.py: the profile is quoted only for the kernel sources it was measured on"""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "stitching_amd", "csrc", "*"))):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 NAMES = [("warp_fast_kernel<3, true, true>", "warp_img_mask"), ("warp_fast_kernel<2, true, true>", "warp_img_mask"),
          ("warp_fast_kernel<0, true, true>", "warp_img_mask"), ("mb_level0_pk_kernel", "mb_level0"),
@@ -32,8 +45,11 @@ def main(d, out):
                 res[name] = {"hip_kernel": k, "fetch_bytes_raw": fetch_kb * 1024, "write_bytes_raw": write_kb * 1024,
                              "traffic_bytes": 2 * fetch_kb * 1024 + write_kb * 1024,
                              "note": "2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, mean per launch"}
+    items = dict(res)
+    res["kernel_source_hash"] = kernel_source_hash()
+    res["workload_cfg"] = 2
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
-    for k, v in res.items():
+    for k, v in items.items():
         print(f"{k:16s} fetch {v['fetch_bytes_raw']/1e6:9.1f} MB (x2 = {2*v['fetch_bytes_raw']/1e6:9.1f})  write {v['write_bytes_raw']/1e6:9.1f} MB")
 
 

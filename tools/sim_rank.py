@@ -1,7 +1,9 @@
 #!/usr/bin/env python
-"""Per-rank device time of the sharded job on ONE GPU: rank R of an N-rank ring runs alone with a replay transport
+"""Per-rank device time of the sharded job on ONE GPU: rank R of an N-rank job runs alone with a replay transport
 (received strips = zero-filled buffers of the planned sizes, allocated once), two panoramas in flight — what one GPU
-of an N-GPU node does per step, without the exchange itself.  usage: python tools/sim_rank.py [N] [R] [steps]"""
+of an N-GPU node does per step, without the exchange itself.  Workload = bench.py's at N > 1: BASELINE config 3
+(N of 8 yaw columns x 4 pitch rows, one column per GPU; `ring`: the tele ring of round 1, 8 frames per GPU).
+usage: python tools/sim_rank.py [N] [R] [steps] [config3|config4|ring]"""
 import json
 import os
 import sys
@@ -38,8 +40,18 @@ def main():
     world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     rank = int(sys.argv[2]) if len(sys.argv) > 2 else world // 2
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 30
-    fpg, w, h = 8, 4000, 3000
-    cams = synthetic.ring_cameras(fpg * world, w, h, focal_factor=0.75 * world)
+    layout = sys.argv[4] if len(sys.argv) > 4 else "config3"
+    kw = {}
+    if layout == "ring":
+        fpg, w, h = 8, 4000, 3000
+        cams = synthetic.ring_cameras(fpg * world, w, h, focal_factor=0.75 * world)
+    elif layout == "config4":
+        fpg, w, h = 8, 8000, 6000
+        cams = synthetic.grid_cameras(2 * world, 4, w, h, max_edge_lat_deg=50.0, layout_yaw=16)
+        kw = dict(warper_type="cylindrical", num_bands=7)
+    else:
+        fpg, w, h = 4, 4000, 3000
+        cams = synthetic.grid_cameras(world, 4, w, h, layout_yaw=8)
     my = range(rank * fpg, (rank + 1) * fpg)
     frames = [synthetic.make_frame(i, w, h) for i in my]
     ctxs = [S.get_context(), S.Context(S.get_context().device)]
@@ -48,11 +60,30 @@ def main():
         js = []
         for c in ctxs:
             j = ShardedStitchJob(frames if not js else js[0].frames, [cams[i] for i in my], cams, rank, world, ctx=c,
-                                 transport=ZeroStrips(), split_boundary=split)
+                                 transport=ZeroStrips(), split_boundary=split, **kw)
             j.plan()
             js.append(j)
         jobs.append(js)
-    res = {"world": world, "rank": rank}
+    res = {"world": world, "rank": rank, "layout": layout, "frames_per_gpu": fpg}
+    # the same frames as an unsharded panorama of their own (the same-family single-GPU rate)
+    from stitching_amd.pipeline import StitchJob  # noqa: E402
+
+    sj = [StitchJob(jobs[0][0].frames, [cams[i] for i in my], ctx=c, **({"warper_type": kw["warper_type"], "num_bands": kw["num_bands"]} if kw else {"num_bands": 5})) for c in ctxs]
+    for j in sj:
+        j.warper.set_scale(cams)
+    for i in range(4):
+        sj[i % 2].run()
+    for c in ctxs:
+        c.sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = sj[i % 2].run()
+        del out
+    for c in ctxs:
+        c.sync()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    res["unsharded_share"] = {"ms_per_step": round(ms, 4), "mpix_per_s": round(fpg * w * h / ms / 1e3, 1)}
+    del sj
     for split, js in zip((False, True), jobs):
         for i in range(4):
             js[i % 2].run()
