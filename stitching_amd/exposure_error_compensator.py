@@ -7,6 +7,12 @@ blend (stitching/stitcher.py:123,219-221).  This class keeps the surface and run
 "gain" and "channel" compensators (one gain per image / per channel); gains come from `set_gains` — e.g. from
 the cv2 compensator's getMatGains() after its feed().  "gain_blocks" (the reference's default) and "channel_blocks" interpolate their
 fp32 gain maps (one / three channels) with cv::resize(INTER_LINEAR) inside the same kernel.
+
+`feed` delegates: when cv2 is importable the constructor builds the same cv.detail compensator the reference builds
+(stitching/exposure_error_compensator.py:25-37), `feed(corners, imgs, masks)` runs its estimation on the low-resolution
+images and hands `getMatGains()` to `set_gains` — so `Stitcher.estimate_exposure_errors` / `compensate_exposure_errors`
+(stitching/stitcher.py:210-221) work unmodified with this class in place of the reference's.  Any object with
+`feed(corners, imgs, masks)` and `getMatGains()` can be passed as `estimator=` instead.
 """
 import ctypes as C
 from collections import OrderedDict
@@ -31,12 +37,26 @@ class ExposureErrorCompensator:
     DEFAULT_BLOCK_SIZE = 32
     SUPPORTED_ON_DEVICE = ("gain_blocks", "gain", "channel", "channel_blocks", "no")
 
-    def __init__(self, compensator=DEFAULT_COMPENSATOR, nr_feeds=DEFAULT_NR_FEEDS, block_size=DEFAULT_BLOCK_SIZE):
+    def __init__(self, compensator=DEFAULT_COMPENSATOR, nr_feeds=DEFAULT_NR_FEEDS, block_size=DEFAULT_BLOCK_SIZE, estimator=None):
         if compensator not in self.COMPENSATOR_CHOICES:
             raise StitchingError(f"unknown compensator {compensator!r}")
         self.compensator_type = compensator
         self.nr_feeds, self.block_size = nr_feeds, block_size
         self.gains = None
+        self.compensator = estimator if estimator is not None else self._cv_estimator(compensator, nr_feeds, block_size)
+
+    @staticmethod
+    def _cv_estimator(compensator, nr_feeds, block_size):
+        """The cv.detail object of stitching/exposure_error_compensator.py:25-37, or None without cv2."""
+        try:
+            import cv2 as cv
+        except ImportError:
+            return None
+        if compensator == "channel":
+            return cv.detail_ChannelsCompensator(nr_feeds)
+        if compensator == "channel_blocks":
+            return cv.detail_BlocksChannelsCompensator(block_size, block_size, nr_feeds)
+        return cv.detail.ExposureCompensator_createDefault(ExposureErrorCompensator.COMPENSATOR_CHOICES[compensator])
 
     def set_gains(self, gains):
         """gains[i]: scalar ("gain"), 3 per-channel BGR values ("channel") or the fp32 gain map ("gain_blocks":
@@ -48,9 +68,17 @@ class ExposureErrorCompensator:
         else:
             self.gains = [np.atleast_1d(np.asarray(g, np.float64)).reshape(-1) for g in gains]
 
-    def feed(self, *args):
-        raise StitchingError("gain estimation (ExposureCompensator::feed) is outside the MI355X hot path: run it in OpenCV "
-                             "and pass getMatGains() to set_gains()")
+    def feed(self, corners, imgs, masks):
+        """Gain estimation on the low-resolution images (ExposureCompensator::feed: a small least-squares solve, outside
+        the MI355X hot path) by the estimator — cv2's when importable — then set_gains(getMatGains())."""
+        if self.compensator_type == "no":
+            return
+        if self.compensator is None:
+            raise StitchingError("gain estimation (ExposureCompensator::feed) needs OpenCV, which is not importable here: pass "
+                                 "an estimator= object or call set_gains() with the gains of a cv2 compensator")
+        host = lambda a: np.asarray(a.get() if hasattr(a, "get") else a)  # noqa: E731 - device images / cv.UMat -> numpy
+        self.compensator.feed(list(corners), [host(i) for i in imgs], [host(m) for m in masks])
+        self.set_gains([host(g) for g in self.compensator.getMatGains()])
 
     def apply(self, idx, corner, img, mask):
         """-> the compensated image (same object for device images: the product is written in place, as OpenCV does)."""

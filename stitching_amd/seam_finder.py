@@ -31,14 +31,35 @@ class SeamFinder:
     SEAM_FINDER_CHOICES = ("dp_color", "dp_colorgrad", "gc_color", "gc_colorgrad", "voronoi", "no")
     DEFAULT_SEAM_FINDER = SEAM_FINDER_CHOICES[0]
 
-    def __init__(self, finder=DEFAULT_SEAM_FINDER):
+    def __init__(self, finder=DEFAULT_SEAM_FINDER, estimator=None):
+        """`estimator`: any object with find(imgs_float, corners, masks) -> seam masks; default: the cv.detail finder the
+        reference builds for this name (stitching/seam_finder.py:14-35) when cv2 is importable."""
         if finder not in self.SEAM_FINDER_CHOICES:
             raise StitchingError(f"unknown seam finder {finder!r}")
-        self.finder = finder
+        self.finder_type = finder
+        self.finder = estimator if estimator is not None else self._cv_finder(finder)
+
+    @staticmethod
+    def _cv_finder(finder):
+        try:
+            import cv2 as cv
+        except ImportError:
+            return None
+        if finder.startswith("dp_"):
+            return cv.detail_DpSeamFinder("COLOR" if finder == "dp_color" else "COLOR_GRAD")
+        if finder.startswith("gc_"):
+            return cv.detail_GraphCutSeamFinder("COST_COLOR" if finder == "gc_color" else "COST_COLOR_GRAD")
+        return cv.detail.SeamFinder_createDefault(cv.detail.SeamFinder_VORONOI_SEAM if finder == "voronoi" else cv.detail.SeamFinder_NO)
 
     def find(self, imgs, corners, masks):
-        raise StitchingError("seam estimation runs on ~0.1 Mpx images in OpenCV (outside the MI355X hot path); "
-                             "pass its masks to SeamFinder.resize")
+        """stitching/seam_finder.py:33-35: seam estimation on the ~0.1 Mpx images (graph cut / dynamic programming in
+        OpenCV: sequential, tiny, outside the MI355X hot path) — delegated; the masks it returns go to `resize`."""
+        if self.finder is None:
+            raise StitchingError("seam estimation needs OpenCV, which is not importable here: pass an estimator= object "
+                                 "or give seam masks found elsewhere to SeamFinder.resize")
+        host = lambda a: np.asarray(a.get() if hasattr(a, "get") else a)  # noqa: E731
+        imgs_float = [host(img).astype(np.float32) for img in imgs]
+        return self.finder.find(imgs_float, list(corners), [host(m) for m in masks])
 
     @staticmethod
     def resize(seam_mask, mask):
