@@ -132,6 +132,7 @@ static size_t bucket_of(size_t bytes)
 int stx_dev_alloc(stx_ctx* ctx, size_t bytes, void** out)
 {
     size_t b = bucket_of(bytes + 64);  // +64: kernels may over-read up to 12 bytes past a row
+    std::lock_guard<std::mutex> lock(ctx->alloc_mutex);
     auto it = ctx->free_blocks.find(b);
     if (it != ctx->free_blocks.end() && !it->second.empty()) {
         *out = it->second.back();
@@ -159,6 +160,7 @@ int stx_dev_alloc(stx_ctx* ctx, size_t bytes, void** out)
 void stx_dev_free(stx_ctx* ctx, void* p)
 {
     if (!p) return;
+    std::lock_guard<std::mutex> lock(ctx->alloc_mutex);
     auto it = ctx->block_size.find(p);
     if (it == ctx->block_size.end()) return;
     ctx->free_blocks[it->second].push_back(p);
@@ -552,6 +554,8 @@ static int resize_impl(stx_ctx* ctx, const stx_buf* src, int dw, int dh, bool di
     std::vector<int> xt, yt;
     linear_exact_table(src->w, dw, xt);
     linear_exact_table(src->h, dh, yt);
+    const size_t nx = xt.size();
+    xt.resize((nx + 7) & ~(size_t)7, 0);  // entries in whole groups of 4 columns (the 4-pixel seam kernel reads 4 at once), 32-byte rows
     std::vector<int> both(xt);
     both.insert(both.end(), yt.begin(), yt.end());
     void* d_tab = nullptr;
@@ -597,6 +601,8 @@ STX_EXPORT int stx_block_gain_apply(stx_ctx* ctx, stx_buf* img, const stx_buf* g
     std::vector<int> xt, yt;
     linear_f32_table(gain_map->w, img->w, true, xt);
     linear_f32_table(gain_map->h, img->h, false, yt);
+    const size_t nx = xt.size();
+    xt.resize((nx + 7) & ~(size_t)7, 0);  // entries in whole groups of 4 columns (the 4-pixel seam kernel reads 4 at once), 32-byte rows
     std::vector<int> both(xt);
     both.insert(both.end(), yt.begin(), yt.end());
     void* d_tab = nullptr;

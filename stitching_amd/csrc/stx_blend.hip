@@ -735,6 +735,63 @@ __global__ __launch_bounds__(256) void resize_exact_kernel(ResizeK P)
 }
 }  // namespace
 
+namespace {
+// SeamFinder.resize, fast form (the reference's default pipeline runs it once per image and panorama): the 3x3 dilation of
+// the small low-resolution mask is done once into a scratch image (a few tens of KB, L2 resident) instead of nine
+// bounds-checked byte loads per tap; a lane then produces 4 adjacent destination pixels (taps from the scratch, one
+// dword of the final warped mask, one dword store).  Same integer arithmetic as resize_exact_kernel<1, true>.
+__global__ __launch_bounds__(256) void dilate3x3_kernel(const uint8_t* __restrict__ src, long long sstride, int w, int h,
+                                                        uint8_t* __restrict__ dst, long long dstride)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    uint32_t m = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+            const int xx = x + dx, yy = y + dy;
+            if ((unsigned)xx < (unsigned)w && (unsigned)yy < (unsigned)h) m = max(m, (uint32_t)src[(long long)yy * sstride + xx]);
+        }
+    dst[(long long)y * dstride + x] = (uint8_t)m;
+}
+
+__global__ __launch_bounds__(256) void seam_resize4_kernel(ResizeK P)  // P.src: the dilated low-resolution mask
+{
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (x4 >= P.dw || y >= P.dh) return;
+    const int2 ty = P.yt[y];
+    const int oy = ty.x, oy1 = min(oy + 1, P.sh - 1);
+    const uint32_t cy1 = (uint32_t)ty.y & 0xffffu, cy0 = 256u - cy1;
+    const bool iy = (ty.y >> 16) != 0;
+    const uint8_t* r0 = P.src + (long long)oy * P.sstride;
+    const uint8_t* r1 = P.src + (long long)oy1 * P.sstride;
+    uint32_t out = 0;
+    // the table holds dw entries rounded up to 4 (host), so the four reads are always inside it
+    const int4 ta = *reinterpret_cast<const int4*>(P.xt + x4), tb = *reinterpret_cast<const int4*>(P.xt + x4 + 2);
+    const int ox[4] = {ta.x, ta.z, tb.x, tb.z}, cf[4] = {ta.y, ta.w, tb.y, tb.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int o0 = ox[j], o1 = min(o0 + 1, P.sw - 1);
+        const uint32_t cx1 = (uint32_t)cf[j] & 0xffffu, cx0 = 256u - cx1;
+        const uint32_t h0 = (uint32_t)r0[o0] * cx0 + (uint32_t)r0[o1] * cx1;
+        uint32_t v;
+        if (iy) {
+            const uint32_t h1 = (uint32_t)r1[o0] * cx0 + (uint32_t)r1[o1] * cx1;
+            v = (h0 * cy0 + h1 * cy1 + 32768u) >> 16;
+        } else {
+            v = (h0 + 128u) >> 8;
+        }
+        out |= min(v, 255u) << (8 * j);
+    }
+    out &= *reinterpret_cast<const uint32_t*>(P.andmask + (long long)y * P.amstride + x4);
+    uint8_t* d = P.dst + (long long)y * P.dstride + x4;
+    if (x4 + 4 <= P.dw) *reinterpret_cast<uint32_t*>(d) = out;
+    else for (int j = 0; x4 + j < P.dw; j++) d[j] = (uint8_t)(out >> (8 * j));
+}
+}  // namespace
+
 int stx_launch_resize_exact(stx_ctx* ctx, const stx_buf* src, stx_buf* dst, const int* d_xt, const int* d_yt, bool dilate,
                             const stx_buf* andmask)
 {
@@ -745,7 +802,20 @@ int stx_launch_resize_exact(stx_ctx* ctx, const stx_buf* src, stx_buf* dst, cons
     K.andmask = andmask ? andmask->ptr : nullptr; K.amstride = andmask ? (long long)andmask->stride : 0;
     const dim3 grid((dst->w + 63) / 64, (dst->h + 3) / 4);
     StxProfScope prof(ctx, dilate ? "seam_mask_resize" : "resize_linear_exact", (double)src->w * src->h * src->c + (double)dst->w * dst->h * dst->c * (andmask ? 2 : 1));
-    if (dilate) hipLaunchKernelGGL((resize_exact_kernel<1, true>), grid, dim3(256), 0, ctx->stream, K);
+    // dword access to the destination and to the final mask: 4-byte aligned rows (every stx_buf_new image; views may not be),
+    // and the mask rows must be readable up to the next multiple of 4 columns
+    const bool fast = dilate && andmask && ((uintptr_t)dst->ptr & 3) == 0 && (dst->stride & 3) == 0 && ((uintptr_t)andmask->ptr & 3) == 0 &&
+                      (andmask->stride & 3) == 0 && (size_t)((dst->w + 3) & ~3) <= andmask->stride && (size_t)((dst->w + 3) & ~3) <= dst->stride;
+    if (fast) {
+        void* tmp = nullptr;
+        const size_t tstride = ((size_t)src->w + 63) & ~(size_t)63;
+        STX_TRY(stx_dev_alloc(ctx, tstride * src->h, &tmp));
+        hipLaunchKernelGGL(dilate3x3_kernel, dim3((src->w + 63) / 64, (src->h + 3) / 4), dim3(256), 0, ctx->stream, src->ptr,
+                           (long long)src->stride, src->w, src->h, (uint8_t*)tmp, (long long)tstride);
+        K.src = (const uint8_t*)tmp; K.sstride = (long long)tstride;
+        hipLaunchKernelGGL(seam_resize4_kernel, dim3((dst->w + 255) / 256, (dst->h + 3) / 4), dim3(256), 0, ctx->stream, K);
+        stx_dev_free(ctx, tmp);  // stream-ordered reuse
+    } else if (dilate) hipLaunchKernelGGL((resize_exact_kernel<1, true>), grid, dim3(256), 0, ctx->stream, K);
     else if (src->c == 1) hipLaunchKernelGGL((resize_exact_kernel<1, false>), grid, dim3(256), 0, ctx->stream, K);
     else if (src->c == 3) hipLaunchKernelGGL((resize_exact_kernel<3, false>), grid, dim3(256), 0, ctx->stream, K);
     else return stx_fail(STX_ERR_UNSUPPORTED, "resize: 1 or 3 channels");

@@ -159,7 +159,11 @@ constexpr int LV_BAND = 4;  // same for the 512 x 8 tiles of the level kernels
 // level 0 (u8 BGR + u8 mask): 4 outputs from 11 input pixels
 // PK: every image of the launch is u8 with a 0 / 255 mask (decided on the host: no per-task branch in the kernel)
 template <bool PK>
-STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, short* hs1, short* hs2, float* hw)
+// hw_even / hw_odd: where the weight sums of outputs (4q, 4q+2) / (4q+1, 4q+3) go — the LDS row keeps even output columns
+// in its first half and odd ones in its second (column c at (c & 1) * 32 + (c >> 1)), so that the 32 lanes which later
+// read the pair (2p, 2p+1) as two dwords hit 32 consecutive banks each time (the natural order reads every other bank
+// twice: 1.1 conflict cycles per LDS instruction measured)
+STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, short* hs1, short* hs2, float* hw_even, float* hw_odd)
 {
     const int by = reflect101(row, im.fh) - im.top;  // bordered row -> image row
     const bool yin = (unsigned)by < (unsigned)im.ih;
@@ -218,10 +222,11 @@ STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, s
                                  (pk(pair_u8<1, 3>(mb)) + pk(pair_u8<3, 5>(mb))) * pk_splat(4);
                 const pk16 o23 = pk(pair_u8<4, 6>(mb)) + pk(pair_u8<8, 10>(mb)) + pk(pair_u8<6, 8>(mb)) * pk_splat(6) +
                                  (pk(pair_u8<5, 7>(mb)) + pk(pair_u8<7, 9>(mb))) * pk_splat(4);
-                *reinterpret_cast<float4*>(hw) = make_float4((float)(unpk(o01) & 0xffffu), (float)(unpk(o01) >> 16),
-                                                             (float)(unpk(o23) & 0xffffu), (float)(unpk(o23) >> 16));
+                *reinterpret_cast<float2*>(hw_even) = make_float2((float)(unpk(o01) & 0xffffu), (float)(unpk(o23) & 0xffffu));
+                *reinterpret_cast<float2*>(hw_odd) = make_float2((float)(unpk(o01) >> 16), (float)(unpk(o23) >> 16));
             } else {
-                *reinterpret_cast<float4*>(hw) = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float2*>(hw_even) = make_float2(0.f, 0.f);
+                *reinterpret_cast<float2*>(hw_odd) = make_float2(0.f, 0.f);
             }
             return;
         }
@@ -261,7 +266,7 @@ STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, s
         hs0[o] = (short)h5i(px[2 * o][0], px[2 * o + 1][0], px[2 * o + 2][0], px[2 * o + 3][0], px[2 * o + 4][0]);
         hs1[o] = (short)h5i(px[2 * o][1], px[2 * o + 1][1], px[2 * o + 2][1], px[2 * o + 3][1], px[2 * o + 4][1]);
         hs2[o] = (short)h5i(px[2 * o][2], px[2 * o + 1][2], px[2 * o + 2][2], px[2 * o + 3][2], px[2 * o + 4][2]);
-        hw[o] = h5f(f[2 * o], f[2 * o + 1], f[2 * o + 2], f[2 * o + 3], f[2 * o + 4]);
+        ((o & 1) ? hw_odd : hw_even)[o >> 1] = h5f(f[2 * o], f[2 * o + 1], f[2 * o + 2], f[2 * o + 3], f[2 * o + 4]);
     }
 }
 
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
     for (int task = tid; task < DN_ROWS * (DN_TOW / 4); task += 256) {
         const int r = task / (DN_TOW / 4), q = task % (DN_TOW / 4);
         dn_task_level0<PK>(im, 2 * Y0 - 2 + r, X0 + 4 * q, &s_h[0][r][4 * q], &s_h[1][r][4 * q], &s_h[2][r][4 * q],
-                           &s_w[r][4 * q]);
+                           &s_w[r][2 * q], &s_w[r][32 + 2 * q]);
     }
     __syncthreads();
     const int p = tid & 31, rg = tid >> 5;  // output pair, row group (2 rows)
@@ -306,9 +311,8 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
         float fa[5], fb[5];
 #pragma unroll
         for (int k = 0; k < 5; k++) {
-            float2 v = *reinterpret_cast<const float2*>(&s_w[2 * yl + k][2 * p]);
-            fa[k] = v.x;
-            fb[k] = v.y;
+            fa[k] = s_w[2 * yl + k][p];
+            fb[k] = s_w[2 * yl + k][32 + p];
         }
         const float wa = fmul(h5f(fa[0], fa[1], fa[2], fa[3], fa[4]), INV256);
         const float wb = fmul(h5f(fb[0], fb[1], fb[2], fb[3], fb[4]), INV256);
@@ -369,11 +373,13 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
             hi.y = h5i(s[10], s[11], s[12], s[13], s[14]);
             hi.z = h5i(s[12], s[13], s[14], s[15], s[16]);
             hi.w = h5i(s[14], s[15], s[16], s[17], s[18]);
-            // LDS column order: outputs 8q .. 8q+3 at 4q, outputs 8q+4 .. 8q+7 at 32 + 4q — the eight lanes of a
-            // 16-byte store group then write 128 contiguous bytes (natural order: 32-byte lane pitch, lanes q and
-            // q + 4 on the same banks, 3.5 conflict cycles per LDS instruction measured)
-            *reinterpret_cast<int4*>(&s_h[c][r][4 * q]) = lo;
-            *reinterpret_cast<int4*>(&s_h[c][r][32 + 4 * q]) = hi;
+            // LDS column order: even output columns in the first half of the row, odd ones in the second (column c at
+            // (c & 1) * 32 + (c >> 1)).  Stores: the eight lanes of a 16-byte store group write 128 contiguous bytes (natural
+            // order: 32-byte lane pitch, lanes q and q + 4 on the same banks); loads: the pair (2p, 2p+1) is two dword
+            // reads of 32 consecutive banks each (natural order: every other bank, twice).  3.5 conflict cycles per LDS
+            // instruction measured with the natural order.
+            *reinterpret_cast<int4*>(&s_h[c][r][4 * q]) = make_int4(lo.x, lo.z, hi.x, hi.z);
+            *reinterpret_cast<int4*>(&s_h[c][r][32 + 4 * q]) = make_int4(lo.y, lo.w, hi.y, hi.w);
         }
         const float* wq = im.wt[lv] + (long long)sy * im.wt_stride[lv];
         float f[19];
@@ -399,16 +405,14 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
         hi.y = h5f(f[10], f[11], f[12], f[13], f[14]);
         hi.z = h5f(f[12], f[13], f[14], f[15], f[16]);
         hi.w = h5f(f[14], f[15], f[16], f[17], f[18]);
-        *reinterpret_cast<float4*>(&s_w[r][4 * q]) = lo;
-        *reinterpret_cast<float4*>(&s_w[r][32 + 4 * q]) = hi;
+        *reinterpret_cast<float4*>(&s_w[r][4 * q]) = make_float4(lo.x, lo.z, hi.x, hi.z);
+        *reinterpret_cast<float4*>(&s_w[r][32 + 4 * q]) = make_float4(lo.y, lo.w, hi.y, hi.w);
     }
     __syncthreads();
     const int p = tid & 31, rg = tid >> 5;
     const int xo = X0 + 2 * p;
     if (xo >= ow) return;
     const bool two = xo + 1 < ow;
-    // outputs 2p, 2p + 1 in the permuted column order (the 32 lanes of a row still cover all 64 columns once)
-    const int lp = ((p & 2) ? 32 : 0) + 4 * (p >> 2) + 2 * (p & 1);
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
         const int yl = 2 * rg + rr, y = Y0 + yl;
@@ -418,9 +422,8 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
             int a[5], b[5];
 #pragma unroll
             for (int k = 0; k < 5; k++) {
-                int2 v = *reinterpret_cast<const int2*>(&s_h[c][2 * yl + k][lp]);
-                a[k] = v.x;
-                b[k] = v.y;
+                a[k] = s_h[c][2 * yl + k][p];
+                b[k] = s_h[c][2 * yl + k][32 + p];
             }
             const int va = (h5i(a[0], a[1], a[2], a[3], a[4]) + 128) >> 8;
             const int vb = (h5i(b[0], b[1], b[2], b[3], b[4]) + 128) >> 8;
@@ -431,9 +434,8 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
         float fa[5], fb[5];
 #pragma unroll
         for (int k = 0; k < 5; k++) {
-            float2 v = *reinterpret_cast<const float2*>(&s_w[2 * yl + k][lp]);
-            fa[k] = v.x;
-            fb[k] = v.y;
+            fa[k] = s_w[2 * yl + k][p];
+            fb[k] = s_w[2 * yl + k][32 + p];
         }
         const float wa = fmul(h5f(fa[0], fa[1], fa[2], fa[3], fa[4]), INV256);
         const float wb = fmul(h5f(fb[0], fb[1], fb[2], fb[3], fb[4]), INV256);

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -58,7 +59,8 @@ struct stx_ctx {
     // pipeline of panoramas can take its ROIs while the previous panorama is still blending
     hipStream_t aux_stream = nullptr;
     void* aux_scratch = nullptr;
-    // caching allocator: bucket size -> free blocks
+    // caching allocator: bucket size -> free blocks (alloc_mutex: Python finalizers may free buffers from any thread)
+    std::mutex alloc_mutex;
     std::map<size_t, std::vector<void*>> free_blocks;
     std::map<void*, size_t> block_size;
     size_t bytes_allocated = 0;
