@@ -159,11 +159,7 @@ constexpr int LV_BAND = 4;  // same for the 512 x 8 tiles of the level kernels
 // level 0 (u8 BGR + u8 mask): 4 outputs from 11 input pixels
 // PK: every image of the launch is u8 with a 0 / 255 mask (decided on the host: no per-task branch in the kernel)
 template <bool PK>
-// hw_even / hw_odd: where the weight sums of outputs (4q, 4q+2) / (4q+1, 4q+3) go — the LDS row keeps even output columns
-// in its first half and odd ones in its second (column c at (c & 1) * 32 + (c >> 1)), so that the 32 lanes which later
-// read the pair (2p, 2p+1) as two dwords hit 32 consecutive banks each time (the natural order reads every other bank
-// twice: 1.1 conflict cycles per LDS instruction measured)
-STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, short* hs1, short* hs2, float* hw_even, float* hw_odd)
+STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, short* hs1, short* hs2, float* hw)
 {
     const int by = reflect101(row, im.fh) - im.top;  // bordered row -> image row
     const bool yin = (unsigned)by < (unsigned)im.ih;
@@ -222,11 +218,10 @@ STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, s
                                  (pk(pair_u8<1, 3>(mb)) + pk(pair_u8<3, 5>(mb))) * pk_splat(4);
                 const pk16 o23 = pk(pair_u8<4, 6>(mb)) + pk(pair_u8<8, 10>(mb)) + pk(pair_u8<6, 8>(mb)) * pk_splat(6) +
                                  (pk(pair_u8<5, 7>(mb)) + pk(pair_u8<7, 9>(mb))) * pk_splat(4);
-                *reinterpret_cast<float2*>(hw_even) = make_float2((float)(unpk(o01) & 0xffffu), (float)(unpk(o23) & 0xffffu));
-                *reinterpret_cast<float2*>(hw_odd) = make_float2((float)(unpk(o01) >> 16), (float)(unpk(o23) >> 16));
+                *reinterpret_cast<float4*>(hw) = make_float4((float)(unpk(o01) & 0xffffu), (float)(unpk(o01) >> 16),
+                                                             (float)(unpk(o23) & 0xffffu), (float)(unpk(o23) >> 16));
             } else {
-                *reinterpret_cast<float2*>(hw_even) = make_float2(0.f, 0.f);
-                *reinterpret_cast<float2*>(hw_odd) = make_float2(0.f, 0.f);
+                *reinterpret_cast<float4*>(hw) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             return;
         }
@@ -266,7 +261,7 @@ STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, s
         hs0[o] = (short)h5i(px[2 * o][0], px[2 * o + 1][0], px[2 * o + 2][0], px[2 * o + 3][0], px[2 * o + 4][0]);
         hs1[o] = (short)h5i(px[2 * o][1], px[2 * o + 1][1], px[2 * o + 2][1], px[2 * o + 3][1], px[2 * o + 4][1]);
         hs2[o] = (short)h5i(px[2 * o][2], px[2 * o + 1][2], px[2 * o + 2][2], px[2 * o + 3][2], px[2 * o + 4][2]);
-        ((o & 1) ? hw_odd : hw_even)[o >> 1] = h5f(f[2 * o], f[2 * o + 1], f[2 * o + 2], f[2 * o + 3], f[2 * o + 4]);
+        hw[o] = h5f(f[2 * o], f[2 * o + 1], f[2 * o + 2], f[2 * o + 3], f[2 * o + 4]);
     }
 }
 
@@ -274,8 +269,8 @@ STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, s
 template <bool PK>
 __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __restrict__ images, StxTileMap M)
 {
-    __shared__ short s_h[3][DN_ROWS][DN_TOW];  // horizontal sums, <= 255*16
-    __shared__ float s_w[DN_ROWS][DN_TOW];
+    __shared__ __attribute__((aligned(16))) short s_h[3][DN_ROWS][DN_TOW];  // horizontal sums, <= 255*16
+    __shared__ __attribute__((aligned(16))) float s_w[DN_ROWS][DN_TOW];
     const StxMbImage& im = images[blockIdx.z];
     const int tid = threadIdx.x;
     const int ow = im.fw >> 1, oh = im.fh >> 1;
@@ -286,7 +281,7 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
     for (int task = tid; task < DN_ROWS * (DN_TOW / 4); task += 256) {
         const int r = task / (DN_TOW / 4), q = task % (DN_TOW / 4);
         dn_task_level0<PK>(im, 2 * Y0 - 2 + r, X0 + 4 * q, &s_h[0][r][4 * q], &s_h[1][r][4 * q], &s_h[2][r][4 * q],
-                           &s_w[r][2 * q], &s_w[r][32 + 2 * q]);
+                           &s_w[r][4 * q]);
     }
     __syncthreads();
     const int p = tid & 31, rg = tid >> 5;  // output pair, row group (2 rows)
@@ -309,10 +304,18 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
             else o[0] = (short)(unpk(v) & 0xffffu);
         }
         float fa[5], fb[5];
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            fa[k] = s_w[2 * yl + k][p];
-            fb[k] = s_w[2 * yl + k][32 + p];
+        {
+            // Five 8-byte LDS reads (rows 2 yl .. 2 yl + 4, row pitch 256 bytes).  Written as ds_read_b64 by hand: the compiler
+            // turns each float2 into two dword accesses (ds_read2_b32), whose 32 lanes then hit every other bank twice
+            // (1.1 conflict cycles per LDS instruction measured); the 8-byte form is conflict free.
+            typedef float v2 __attribute__((ext_vector_type(2)));
+            v2 r0, r1, r2, r3, r4;
+            const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)&s_w[2 * yl][2 * p];
+            asm volatile("ds_read_b64 %0, %5\n\tds_read_b64 %1, %5 offset:256\n\tds_read_b64 %2, %5 offset:512\n\t"
+                         "ds_read_b64 %3, %5 offset:768\n\tds_read_b64 %4, %5 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4) : "v"(a) : "memory");
+            fa[0] = r0.x; fb[0] = r0.y; fa[1] = r1.x; fb[1] = r1.y; fa[2] = r2.x; fb[2] = r2.y;
+            fa[3] = r3.x; fb[3] = r3.y; fa[4] = r4.x; fb[4] = r4.y;
         }
         const float wa = fmul(h5f(fa[0], fa[1], fa[2], fa[3], fa[4]), INV256);
         const float wb = fmul(h5f(fb[0], fb[1], fb[2], fb[3], fb[4]), INV256);
@@ -343,8 +346,8 @@ STX_DEV void dn_load19_s16(const short* __restrict__ p, int c0, int iw, bool fas
 
 __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __restrict__ images, int lv, StxTileMap M)
 {
-    __shared__ int s_h[3][DN_ROWS][DN_TOW];
-    __shared__ float s_w[DN_ROWS][DN_TOW];
+    __shared__ __attribute__((aligned(16))) int s_h[3][DN_ROWS][DN_TOW];
+    __shared__ __attribute__((aligned(16))) float s_w[DN_ROWS][DN_TOW];
     const StxMbImage& im = images[blockIdx.z];
     const int tid = threadIdx.x;
     const int iw = im.fw >> lv, ih = im.fh >> lv;

@@ -239,6 +239,11 @@ class RcclTransport:
 
     @staticmethod
     def unique_id():
+        import os
+
+        # all ranks live on one node: RCCL's bootstrap (ncclGetUniqueId opens a listening socket) stays on the loopback
+        # interface unless the caller chose another (interface discovery has been seen to stall on boxes without a network)
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         uid = (C.c_ubyte * 128)()
         _lib.check(_lib.lib().stx_comm_unique_id(uid))
         return bytes(uid)
