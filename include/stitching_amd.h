@@ -225,6 +225,17 @@ int stx_blend_feed_contrib(stx_blender* b, int order, const int rect_xywh[4], co
 int stx_blend_feed_contrib_ex(stx_blender* b, int order, const int rect_xywh[4], const stx_buf* packed, int flags);
 int stx_buf_flags(const stx_buf* buf, int* out_flags);
 
+/* image-strip form of the same exchange: the owner of an image ships the COLUMNS [x0, x1) of the warped
+ * image and mask that another band depends on (4 bytes per pixel, no export pass) and the receiver feeds them with
+ * stx_blend_feed_ex like an image of its own, at corner (tlx + x0, tly) and with the image's global `order`; its band
+ * comes out bit-identical.  stx_strip_rect: pure geometry (x0 == x1: nothing owed), columns relative to the image;
+ * stx_strip_pack: image rows then mask rows in one flat buffer (two 2-D device copies on the context stream);
+ * stx_strip_unpack: the two views of a received flat buffer (flags: STX_CONTRIB_U8_BINARY when the mask is 0 / 255). */
+int stx_strip_rect(const stx_blender* b, int img_w, int img_h, int tlx, int tly, int band_x0, int band_x1, int out_x0x1[2],
+                   size_t* out_bytes);
+int stx_strip_pack(stx_ctx* ctx, const stx_buf* img, const stx_buf* mask, int x0, int x1, stx_buf** out_packed);
+int stx_strip_unpack(const stx_buf* packed, int w, int h, int flags, stx_buf** out_img, stx_buf** out_mask);
+
 /* ---- RCCL strip exchange over xGMI ---------------------------------------------------------------
  * One communicator per rank (one process per GPU).  stx_comm_exchange issues every send / receive
  * of one step as a single RCCL group on the context's HIP stream: it is ordered after the kernels

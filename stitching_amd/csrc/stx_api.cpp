@@ -1444,6 +1444,107 @@ STX_EXPORT int stx_blend_contrib_rect(const stx_blender* b, int img_w, int img_h
     return STX_OK;
 }
 
+// ---- image-strip sharding -------------------------------------------------------------------------------------
+// Instead of per-level contributions ((short)(L W) and W: 13.3 bytes per strip pixel, plus an export pass on the sender)
+// a rank can ship the COLUMNS of its warped image and mask that the other band depends on (4 bytes per pixel, copied out
+// by the DMA engine) and let the receiver feed them like an image of its own.  The receiver's pyramids of the strip equal
+// the owner's wherever the band looks, provided the strip holds every source column that reaches the band's region:
+//   * [sx0, sx1): the level-0 columns where the band needs this image's contributions (mb_contrib_range);
+//   * + gap + 2^B on both sides: a Laplacian sample depends on the bordered image within 3 * 2^B = gap columns
+//     (pyrDown support 2 (2^B - 1), pyrUp of the next level 2^B more), one more 2^B for the grid snapping;
+//   * where that range runs into the image's own left / right edge the border is copyMakeBorder(REFLECT): the columns the
+//     reflection reads (as many as the range sticks out) must be in the strip as well.
+// A cut edge of the strip is then at least gap + 2^B away from everything the band reads; what the receiver computes
+// beyond it (it reflects where the owner had real pixels) is never looked at.  Rows are not cut.
+static bool mb_strip_range(const stx_blender* b, int img_w, int img_h, int tlx, int tly, int bx0, int bx1, int* x0, int* x1)
+{
+    int fx, fy, fw, fh, sx0, sx1;
+    mb_feed_rect(b, img_w, img_h, tlx, tly, &fx, &fy, &fw, &fh);
+    if (!mb_contrib_range(b, fx, fw, bx0, bx1, &sx0, &sx1)) return false;
+    const int nb = b->num_bands, reach = 3 * (1 << nb) + (1 << nb);
+    const int ix0 = tlx - b->rx, ix1 = ix0 + img_w;
+    const int qlo = std::max(sx0 - reach, fx), qhi = std::min(sx1 + reach, fx + fw);
+    int lo = std::max(ix0, qlo), hi = std::min(ix1, qhi);
+    if (qlo < ix0) hi = std::max(hi, std::min(ix1, 2 * ix0 - qlo));
+    if (qhi > ix1) lo = std::min(lo, std::max(ix0, 2 * ix1 - qhi));
+    if (img_w < 2 * reach) { lo = ix0; hi = ix1; }  // narrower than a border: several reflections, send it whole
+    lo = ix0 + ((lo - ix0) & ~7);                    // 8-pixel groups, as the rows of every image buffer
+    hi = std::min(ix1, ix0 + ((hi - ix0 + 7) & ~7));
+    *x0 = lo - ix0; *x1 = hi - ix0;
+    return hi > lo;
+}
+
+static void strip_layout(int w, int h, size_t* img_stride, size_t* mask_stride, size_t* bytes)
+{
+    *img_stride = align_up(align_up((size_t)w, 8) * 3, 64);
+    *mask_stride = align_up(align_up((size_t)w, 8), 64);
+    *bytes = (*img_stride + *mask_stride) * (size_t)h;
+}
+
+STX_EXPORT int stx_strip_rect(const stx_blender* b, int img_w, int img_h, int tlx, int tly, int band_x0, int band_x1, int out_x0x1[2],
+                              size_t* out_bytes)
+{
+    if (!b || !out_x0x1) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (b->kind != STX_BLEND_MULTIBAND) return stx_fail(STX_ERR_UNSUPPORTED, "multi-band blender only");
+    int x0 = 0, x1 = 0;
+    if (!mb_strip_range(b, img_w, img_h, tlx, tly, band_x0, band_x1, &x0, &x1)) x0 = x1 = 0;
+    out_x0x1[0] = x0; out_x0x1[1] = x1;
+    if (out_bytes) {
+        size_t si, sm, nb = 0;
+        if (x1 > x0) strip_layout(x1 - x0, img_h, &si, &sm, &nb);
+        *out_bytes = nb;
+    }
+    return STX_OK;
+}
+
+// columns [x0, x1) of a u8x3 image and of its u8 mask -> one flat buffer: the image rows (pitch as an image buffer of that
+// width has it), then the mask rows.  Two 2-D device copies on the context stream.
+STX_EXPORT int stx_strip_pack(stx_ctx* ctx, const stx_buf* img, const stx_buf* mask, int x0, int x1, stx_buf** out_packed)
+{
+    if (!ctx || !img || !mask || !out_packed) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (img->elem != STX_U8 || img->c != 3 || mask->elem != STX_U8 || mask->c != 1 || mask->w != img->w || mask->h != img->h)
+        return stx_fail(STX_ERR_INVALID, "strip: u8x3 image with a u8 mask of the same size");
+    if (x0 < 0 || x1 > img->w || x1 <= x0) return stx_fail(STX_ERR_INVALID, "strip columns [%d,%d) of %d", x0, x1, img->w);
+    STX_TRY(stx_set_device(ctx));
+    const int w = x1 - x0, h = img->h;
+    size_t si, sm, nbytes;
+    strip_layout(w, h, &si, &sm, &nbytes);
+    stx_buf* flat = nullptr;
+    STX_TRY(stx_buf_new(ctx, (int)std::min<size_t>(nbytes, (size_t)1 << 30), (int)((nbytes + ((size_t)1 << 30) - 1) >> 30), 1, STX_U8, &flat));
+    if (flat->h != 1) { stx_buf_release(flat); return stx_fail(STX_ERR_UNSUPPORTED, "strip larger than 1 GiB"); }
+    hipError_t e = hipMemcpy2DAsync(flat->ptr, si, img->ptr + (size_t)x0 * 3, img->stride, (size_t)w * 3, h, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(flat->ptr + si * h, sm, mask->ptr + x0, mask->stride, (size_t)w, h, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e != hipSuccess) { stx_buf_release(flat); return stx_fail(STX_ERR_HIP, "strip copy: %s", hipGetErrorString(e)); }
+    flat->mask_binary = mask->mask_binary;
+    *out_packed = flat;
+    return STX_OK;
+}
+
+// the image and mask of a received strip as views of the flat buffer (which they keep alive)
+STX_EXPORT int stx_strip_unpack(const stx_buf* packed, int w, int h, int flags, stx_buf** out_img, stx_buf** out_mask)
+{
+    if (!packed || !out_img || !out_mask) return stx_fail(STX_ERR_INVALID, "null argument");
+    size_t si, sm, nbytes;
+    if (w <= 0 || h <= 0) return stx_fail(STX_ERR_INVALID, "strip of %dx%d", w, h);
+    strip_layout(w, h, &si, &sm, &nbytes);
+    if (packed->elem != STX_U8 || packed->c != 1 || packed->h != 1 || (size_t)packed->w < nbytes)
+        return stx_fail(STX_ERR_INVALID, "packed strip of %d bytes, %zu needed for %dx%d", packed->w, nbytes, w, h);
+    stx_buf* root = const_cast<stx_buf*>(packed);
+    for (int k = 0; k < 2; k++) {
+        stx_buf* v = new stx_buf();
+        v->ctx = packed->ctx; v->base = packed->base;
+        v->ptr = packed->ptr + (k ? si * (size_t)h : 0);
+        v->w = w; v->h = h; v->c = k ? 1 : 3; v->elem = STX_U8;
+        v->stride = k ? sm : si;
+        v->parent = root;
+        v->mask_binary = k && (flags & STX_CONTRIB_U8_BINARY) ? 1 : 0;
+        stx_buf_retain(root);
+        *(k ? out_mask : out_img) = v;
+    }
+    return STX_OK;
+}
+
 STX_EXPORT int stx_blend_export_contrib(stx_blender* b, int order, int band_x0, int band_x1, stx_buf** out_packed,
                                         int out_rect_xywh[4])
 {

@@ -6,12 +6,14 @@ MI355X-first design of SURVEY.md §8(e) / DESIGN.md §6:
   * images are dealt to ranks as contiguous runs (ring panoramas: contiguous yaw);
   * rank g owns the panorama columns [b_g, b_{g+1}) (edges on multiples of max(8, 2^bands));
   * every rank warps and builds pyramids for ITS images only;
-  * an image whose 2^bands-aligned feed rectangle reaches another rank's columns sends that rank a
-    CONTRIBUTION strip: per level the products (short)(L*W) and the weights W.  This is the only
-    data-path communication — point-to-point over xGMI (RCCL send/recv on the compute stream), a
-    few tens of MB per neighbour, never an all-reduce of the panorama pyramid;
-  * the receiver adds contributions in global feed order, so the assembled panorama is
-    bit-identical to the single-GPU result.
+  * an image whose 2^bands-aligned feed rectangle reaches another rank's columns sends that rank a strip.
+    exchange="strips" (default): the COLUMNS of the warped image and mask the other band depends on (4 bytes per
+    pixel, copied out by the DMA engine); the receiver feeds them like an image of its own and builds their pyramids.
+    exchange="contribs" (round 1): per level the products (short)(L*W) and the weights W over the band's region
+    (13.3 bytes per pixel and an export pass on the sender).  Either way this is the only data-path communication —
+    point-to-point over xGMI (RCCL send/recv), never an all-reduce of the panorama pyramid;
+  * the receiver adds everything in global feed order, so the assembled panorama is bit-identical to the single-GPU
+    result.
 
 `ShardPlan` is pure geometry (every rank computes the same plan from the global camera list);
 `ShardedStitchJob` runs one rank; transports move packed contribution buffers:
@@ -65,6 +67,13 @@ class ShardBlender(_BlenderHandle):
         _lib.check(self.ctx._lib.stx_blend_export_contribs(self._h, n, orders, x0s, x1s, outs, rects))
         return [(DeviceImage(self.ctx, C.c_void_p(outs[i])), tuple(int(v) for v in rects[4 * i:4 * i + 4])) for i in range(n)]
 
+    def strip_rect(self, size, corner, band):
+        """-> ((x0, x1) columns of the image, packed bytes) that an image owes the owner of `band`; x0 == x1: nothing."""
+        xs, nbytes = (C.c_int * 2)(), C.c_size_t()
+        _lib.check(self.ctx._lib.stx_strip_rect(self._h, int(size[0]), int(size[1]), int(corner[0]), int(corner[1]), int(band[0]),
+                                                int(band[1]), xs, C.byref(nbytes)))
+        return (int(xs[0]), int(xs[1])), int(nbytes.value)
+
     def build(self):
         """Build the pyramids of everything fed so far (otherwise deferred to the first export / blend())."""
         _lib.check(self.ctx._lib.stx_blend_build(self._h))
@@ -83,6 +92,20 @@ class GeometryContext:
 
     def __init__(self):
         self._lib = _lib.lib()
+
+
+def strip_pack(ctx, img, mask, x0, x1):
+    """columns [x0, x1) of a warped image + mask -> one flat device buffer (stx_strip_pack)"""
+    out = C.c_void_p()
+    _lib.check(ctx._lib.stx_strip_pack(ctx.handle, img._h, mask._h, int(x0), int(x1), C.byref(out)))
+    return DeviceImage(ctx, out)
+
+
+def strip_unpack(packed, w, h, flags=_lib.CONTRIB_U8_BINARY):
+    """received flat buffer -> (image view, mask view)"""
+    oi, om = C.c_void_p(), C.c_void_p()
+    _lib.check(packed.ctx._lib.stx_strip_unpack(packed._h, int(w), int(h), int(flags), C.byref(oi), C.byref(om)))
+    return DeviceImage(packed.ctx, oi), DeviceImage(packed.ctx, om)
 
 
 def make_shard_blender(ctx, roi, num_bands):
@@ -131,7 +154,10 @@ class ShardPlan:
     """Who owns which columns and which contribution strips travel where.  Pure geometry: built from
     the global corner/size lists, identical on every rank."""
 
-    def __init__(self, corners, warped_sizes, owners, world, blender_probe):
+    def __init__(self, corners, warped_sizes, owners, world, blender_probe, exchange="strips"):
+        if exchange not in ("strips", "contribs"):
+            raise StitchingError(f"unknown exchange form {exchange!r}")
+        self.exchange = exchange
         self.corners = [tuple(int(v) for v in c) for c in corners]
         self.sizes = [tuple(int(v) for v in s) for s in warped_sizes]
         self.owners = list(owners)
@@ -140,11 +166,17 @@ class ShardPlan:
         self.num_bands = blender_probe.num_bands()
         self.edges = band_edges(self.corners, self.sizes, self.owners, self.world, self.roi, self.num_bands)
         # messages: (order k, src rank, dst rank, rect, bytes), sorted by (dst, k) so that every
-        # rank posts sends / receives in one global order
+        # rank posts sends / receives in one global order.  rect: contribs -> (x, y, w, h) relative to the roi;
+        # strips -> (x0, x1, w, h): columns of image k and the strip's size
         self.messages = []
         for k, (c, s) in enumerate(zip(self.corners, self.sizes)):
             for g in range(self.world):
                 if g == self.owners[k]:
+                    continue
+                if exchange == "strips":
+                    (x0, x1), nbytes = blender_probe.strip_rect(s, c, self.band(g))
+                    if x1 > x0:
+                        self.messages.append((k, self.owners[k], g, (x0, x1, x1 - x0, s[1]), nbytes))
                     continue
                 rect, nbytes = blender_probe.contrib_rect(s, c, self.band(g))
                 if rect[2] > 0:
@@ -307,7 +339,7 @@ class ShardedStitchJob:
 
     def __init__(self, frames, cameras, all_cameras, rank, world, all_sizes=None, warper_type="spherical",
                  blender_type="multiband", num_bands=5, blend_strength=None, ctx=None, dist=None, transport=None,
-                 split_boundary=True):
+                 split_boundary=True, exchange="strips"):
         """split_boundary: warp / feed the images that owe strips to other ranks first and the rest while the strips
         travel (lowest latency of ONE panorama).  A caller that keeps several panoramas in flight on several contexts
         passes False: all local images go through one warp launch and one pyramid build, and the other panorama's
@@ -332,6 +364,7 @@ class ShardedStitchJob:
         self.dist = dist
         self.transport = transport
         self.split_boundary = bool(split_boundary)
+        self.exchange = exchange
         self.plan_ = None
 
     @property
@@ -347,7 +380,7 @@ class ShardedStitchJob:
         self.req_bands = int((np.log(blend_width) / np.log(2.0) - 1.0))
         self.roi = roi
         probe = make_shard_blender(self.ctx, roi, self.req_bands)
-        self.plan_ = ShardPlan(corners, wsizes, self.owners, self.world, probe)
+        self.plan_ = ShardPlan(corners, wsizes, self.owners, self.world, probe, self.exchange)
         self.last_num_bands = self.plan_.num_bands
         if self.transport is None:
             self.transport = default_transport(self.ctx, self.rank, self.world, self.dist)
@@ -371,13 +404,19 @@ class ShardedStitchJob:
             recv_msgs = p.recvs(self.rank)
             # 1. the images that owe strips to other ranks: warp, feed, export, start the exchange
             senders = sorted({m[0] for m in send_msgs}) if self.split_boundary else list(self.my_orders)
-            self._warp_and_feed(blender, [k for k in self.my_orders if k in senders], p)
+            warped = self._warp_and_feed(blender, [k for k in self.my_orders if k in senders], p)
             sends = []
-            exported = blender.export_contribs([(k, p.band(dst)) for (k, _src, dst, _rect, _nbytes) in send_msgs])
-            for (k, _src, dst, rect, nbytes), (packed, r) in zip(send_msgs, exported):
-                if r != rect:
-                    raise StitchingError("contribution geometry differs from the plan")
-                sends.append((dst, packed, nbytes))
+            if p.exchange == "strips":
+                for (k, _src, dst, rect, nbytes) in send_msgs:
+                    img, mask = warped[k]
+                    sends.append((dst, strip_pack(self.ctx, img, mask, rect[0], rect[1]), nbytes))
+            else:
+                exported = blender.export_contribs([(k, p.band(dst)) for (k, _src, dst, _rect, _nbytes) in send_msgs])
+                for (k, _src, dst, rect, nbytes), (packed, r) in zip(send_msgs, exported):
+                    if r != rect:
+                        raise StitchingError("contribution geometry differs from the plan")
+                    sends.append((dst, packed, nbytes))
+            del warped
             self.transport.start(sends, [(m[1], m[4]) for m in recv_msgs], self.ctx)
             # 2. the other images of this rank are warped and fed while the strips travel
             self._warp_and_feed(blender, [k for k in self.my_orders if k not in senders], p)
@@ -386,15 +425,21 @@ class ShardedStitchJob:
             rbufs = self.transport.finish()
             # every strip of this job comes from a u8 warp with a 0 / 255 mask (warp_images_and_masks on all ranks)
             for m, buf in zip(recv_msgs, rbufs):
-                blender.feed_contrib(m[0], m[3], buf, _lib.CONTRIB_U8_BINARY)
+                if p.exchange == "strips":
+                    x0, _x1, w, h = m[3]
+                    simg, smask = strip_unpack(buf, w, h, _lib.CONTRIB_U8_BINARY)
+                    blender.feed_ex(simg, smask, (p.corners[m[0]][0] + x0, p.corners[m[0]][1]), m[0])
+                else:
+                    blender.feed_contrib(m[0], m[3], buf, _lib.CONTRIB_U8_BINARY)
             pano, mask = blender.blend()
         finally:
             config.set_device_resident(prev)
         return pano, mask
 
     def _warp_and_feed(self, blender, orders, p):
+        """-> {order: (warped image, mask)} of the images fed"""
         if not orders:
-            return
+            return {}
         local = {k: i for i, k in enumerate(self.my_orders)}
         frames = [self.frames[local[k]] for k in orders]
         cams = [self.cameras[local[k]] for k in orders]
@@ -403,6 +448,7 @@ class ShardedStitchJob:
             if roi[0:2] != p.corners[k]:
                 raise StitchingError("warp roi changed between plan() and run()")
             blender.feed_ex(img, mask, p.corners[k], k)
+        return {k: (img, mask) for k, img, mask in zip(orders, imgs, masks)}
 
     def gather(self, pano, mask):
         """Assemble the full panorama on rank 0 (host side, outside any timed region)."""
@@ -470,15 +516,21 @@ class _NullTransport:
         return []
 
 
+def _mask_is_binary(ctx, mask):
+    fl = C.c_int()
+    _lib.check(ctx._lib.stx_buf_flags(mask._h, C.byref(fl)))
+    return bool(fl.value & _lib.CONTRIB_U8_BINARY)
+
+
 # ------------------------------------------------------------------------------------ test helper
-def virtual_sharded_blend(ctx, warped, masks, corners, sizes, world, num_bands):
+def virtual_sharded_blend(ctx, warped, masks, corners, sizes, world, num_bands, exchange="strips"):
     """All `world` ranks simulated in ONE process on one GPU: same kernels, same geometry, the
     exchange is a pointer hand-over.  Returns (panorama, mask, plan) as numpy arrays."""
     n = len(warped)
     owners = owners_contiguous(n, world)
     roi = Blender.result_roi(corners, sizes)
     probe = make_shard_blender(ctx, roi, num_bands)
-    plan = ShardPlan(corners, sizes, owners, world, probe)
+    plan = ShardPlan(corners, sizes, owners, world, probe, exchange)
     blenders = []
     for g in range(world):
         b = make_shard_blender(ctx, roi, num_bands)
@@ -489,6 +541,12 @@ def virtual_sharded_blend(ctx, warped, masks, corners, sizes, world, num_bands):
     for k in range(n):
         blenders[owners[k]].feed_ex(d_imgs[k], d_masks[k], plan.corners[k], k)
     for (k, src, dst, rect, nbytes) in plan.messages:
+        if exchange == "strips":
+            packed = strip_pack(ctx, d_imgs[k], d_masks[k], rect[0], rect[1])
+            assert packed.width * packed.height >= nbytes
+            simg, smask = strip_unpack(packed, rect[2], rect[3], _lib.CONTRIB_U8_BINARY if _mask_is_binary(ctx, d_masks[k]) else 0)
+            blenders[dst].feed_ex(simg, smask, (plan.corners[k][0] + rect[0], plan.corners[k][1]), k)
+            continue
         packed, r = blenders[src].export_contrib(k, plan.band(dst))
         assert r == rect, (r, rect)
         fl = C.c_int()

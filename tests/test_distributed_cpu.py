@@ -44,15 +44,30 @@ def launch(world, case):
     return json.loads(outs[0][1].strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("world,n,req_bands", [(2, 4, 5), (3, 6, 4), (2, 8, 3)])
-def test_shard_plan_and_strip_exchange_over_gloo(oracle, world, n, req_bands):
+@pytest.mark.parametrize("world,n,req_bands,exchange", [(2, 4, 5, "strips"), (3, 6, 4, "strips"), (2, 8, 3, "contribs"), (3, 6, 4, "contribs")])
+def test_shard_plan_and_strip_exchange_over_gloo(oracle, world, n, req_bands, exchange):
     cams = synthetic.ring_cameras(n, 800, 600, span_deg=40.0 * n)
     w = oracle.Warper("spherical")
     w.set_scale(cams)
     corners, sizes = w.warp_rois([(800, 600)] * n, cams)
-    res = launch(world, {"corners": [list(c) for c in corners], "sizes": [list(s) for s in sizes], "req_bands": req_bands})
+    res = launch(world, {"corners": [list(c) for c in corners], "sizes": [list(s) for s in sizes], "req_bands": req_bands, "exchange": exchange})
     assert res["ok"] and res["messages"] >= world - 1 and res["bytes"] > 0
     assert len(res["edges"]) == world + 1
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_row_layout_over_gloo(oracle, world):
+    """BASELINE config 3's layout in small: `world` yaw columns x 4 pitch rows, one column (4 stacked images) per rank;
+    the +-56 degree rows are wide enough to owe strips to ranks that are not their neighbours."""
+    cams = synthetic.grid_cameras(world, 4, 800, 600, layout_yaw=8)
+    w = oracle.Warper("spherical")
+    w.set_scale(cams)
+    corners, sizes = w.warp_rois([(800, 600)] * len(cams), cams)
+    strips = launch(world, {"corners": [list(c) for c in corners], "sizes": [list(s) for s in sizes], "req_bands": 4, "exchange": "strips"})
+    contribs = launch(world, {"corners": [list(c) for c in corners], "sizes": [list(s) for s in sizes], "req_bands": 4, "exchange": "contribs"})
+    assert strips["ok"] and contribs["ok"] and strips["edges"] == contribs["edges"]
+    # 4 bytes per strip pixel against 13.3 per contribution pixel
+    assert strips["bytes"] < 0.6 * contribs["bytes"]
 
 
 def test_owners_are_contiguous_runs():

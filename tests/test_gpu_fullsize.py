@@ -219,8 +219,8 @@ def test_config3_vs_oracle_single_and_sharded(oracle, gpu_ctx):
         _assert_same(*b.blend(), o)
         roi = S.Blender.result_roi(job.corners, job.warped_sizes)
         req = int(np.log(np.sqrt(roi[2] * roi[3]) * job.blend_strength / 100) / np.log(2.0) - 1.0)
-        for world in (2, 8):
-            sp, sm, plan = virtual_sharded_blend(gpu_ctx, imgs, masks, job.corners, job.warped_sizes, world, req)
+        for world, exchange in ((2, "strips"), (8, "strips"), (8, "contribs")):
+            sp, sm, plan = virtual_sharded_blend(gpu_ctx, imgs, masks, job.corners, job.warped_sizes, world, req, exchange)
             assert plan.num_bands == 5 and plan.exchanged_bytes() > 0
             if world == 8:
                 # every rank owns one yaw column of 4 stacked frames; the wide +-56 degree rows reach past the neighbours

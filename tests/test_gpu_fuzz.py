@@ -84,10 +84,12 @@ def test_random_geometry_bit_exact(oracle, gpu_ctx, seed):
     assert np.array_equal(g["pano"], o["pano"]), (tag, int(np.count_nonzero(g["pano"] != o["pano"])))
 
 
-@pytest.mark.parametrize("seed", list(range(8)))
+@pytest.mark.parametrize("seed", list(range(14)))
 def test_random_sharded_blend_bit_exact(oracle, gpu_ctx, seed):
-    """The multi-GPU data path (column bands + contribution strips, all ranks simulated on this GPU) on random ring
-    geometries, rank counts and band counts: the assembled bands are the oracle's panorama bit for bit."""
+    """The multi-GPU data path (column bands + strips, all ranks simulated on this GPU) on random geometries — single-row
+    rings and, for seeds >= 8, grids of 2-3 pitch rows (several images of one rank stacked in its column band, wide
+    pitched rows reaching past the neighbouring band) — rank counts, band counts and both exchange forms: the assembled
+    bands are the oracle's panorama bit for bit."""
     from stitching_amd.distributed import virtual_sharded_blend
 
     rng = np.random.default_rng(5000 + seed)
@@ -96,15 +98,24 @@ def test_random_sharded_blend_bit_exact(oracle, gpu_ctx, seed):
     w, h = int(rng.integers(500, 1300)), int(rng.integers(300, 900))
     strength = float(rng.choice([3, 6, 12, 25]))
     wtype = str(rng.choice(["spherical", "cylindrical"]))
-    imgs, cams = helpers.small_ring(n, w, h, span=float(rng.uniform(28.0, 42.0)) * n)
+    exchange = "contribs" if seed % 4 == 1 else "strips"
+    if seed >= 8:
+        rows = int(rng.integers(2, 4))
+        cols = world * int(rng.integers(1, 3))
+        n = rows * cols
+        cams = synthetic.grid_cameras(cols, rows, w, h, span_deg=float(rng.uniform(30.0, 40.0)) * cols + 40.0,
+                                      max_edge_lat_deg=float(rng.uniform(55.0, 80.0)) if wtype == "spherical" else 45.0)
+        imgs = [synthetic.make_frame(i, w, h) for i in range(n)]
+    else:
+        imgs, cams = helpers.small_ring(n, w, h, span=float(rng.uniform(28.0, 42.0)) * n)
     masks_fn = synthetic.voronoi_seam_masks if seed % 3 == 2 else None
     o = helpers.run_pipeline(oracle.Warper, oracle.Blender, imgs, cams, warper_type=wtype, blend_strength=strength, masks_fn=masks_fn)
     feed_masks = masks_fn(o["w_masks"], o["corners"], o["sizes"]) if masks_fn else o["w_masks"]
     req = int(np.log(np.sqrt(o["pano"].shape[0] * o["pano"].shape[1]) * strength / 100) / np.log(2.0) - 1.0)
     if req < 0:
         pytest.skip("blend width below one band")
-    pano, mask, plan = virtual_sharded_blend(gpu_ctx, o["w_imgs"], feed_masks, o["corners"], o["sizes"], world, req)
-    tag = dict(world=world, n=n, w=w, h=h, strength=strength, wtype=wtype, bands=plan.num_bands, edges=plan.edges)
+    pano, mask, plan = virtual_sharded_blend(gpu_ctx, o["w_imgs"], feed_masks, o["corners"], o["sizes"], world, req, exchange)
+    tag = dict(world=world, n=n, w=w, h=h, strength=strength, wtype=wtype, bands=plan.num_bands, edges=plan.edges, exchange=exchange)
     assert pano.shape == o["pano"].shape, tag
     assert np.array_equal(mask, o["pmask"]), tag
     assert np.array_equal(pano, o["pano"]), (tag, int(np.count_nonzero(pano != o["pano"])))

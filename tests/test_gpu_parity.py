@@ -185,17 +185,18 @@ def test_error_paths(gpu_ctx):
         w.warp_image(np.zeros((10, 10), np.uint8), S.CameraParams(focal=100.0))
 
 
+@pytest.mark.parametrize("exchange", ["strips", "contribs"])
 @pytest.mark.parametrize("world,strength,n", [(2, 30, 4), (3, 12, 6), (2, 4, 4)])
-def test_sharded_blend_equals_single_gpu(oracle, gpu_ctx, world, strength, n):
-    """Column bands + contribution strips (the multi-GPU data path, all ranks simulated on one GPU)
-    give the bit-identical panorama of the single blender — and of the oracle."""
+def test_sharded_blend_equals_single_gpu(oracle, gpu_ctx, world, strength, n, exchange):
+    """Column bands + strips (the multi-GPU data path, all ranks simulated on one GPU; both exchange forms: warped image
+    strips, per-level contributions) give the bit-identical panorama of the single blender — and of the oracle."""
     from stitching_amd.distributed import virtual_sharded_blend
 
     imgs, cams = helpers.small_ring(n, 1203, 907, span=40.0 * n)
     o = helpers.run_pipeline(oracle.Warper, oracle.Blender, imgs, cams, blend_strength=strength)
     nb = o["blender"].blender.num_bands()
     req = int(np.log(np.sqrt(o["pano"].shape[0] * o["pano"].shape[1]) * strength / 100) / np.log(2.0) - 1.0)
-    pano, mask, plan = virtual_sharded_blend(gpu_ctx, o["w_imgs"], o["w_masks"], o["corners"], o["sizes"], world, req)
+    pano, mask, plan = virtual_sharded_blend(gpu_ctx, o["w_imgs"], o["w_masks"], o["corners"], o["sizes"], world, req, exchange)
     assert plan.num_bands == nb and len(plan.messages) >= world - 1
     assert pano.shape == o["pano"].shape
     assert np.array_equal(mask, o["pmask"])
@@ -255,8 +256,9 @@ def test_batched_warp_equals_per_image(oracle, gpu_ctx, wtype):
         assert np.array_equal(np.asarray(gm[i]), o.create_and_warp_mask(sizes[i], cams[i])), f"mask {i}"
 
 
+@pytest.mark.parametrize("exchange", ["strips", "contribs"])
 @pytest.mark.parametrize("split", [True, False])
-def test_sharded_job_bands_equal_single_job(oracle, gpu_ctx, split):
+def test_sharded_job_bands_equal_single_job(oracle, gpu_ctx, split, exchange):
     """ShardedStitchJob.run() as bench.py drives it for N > 1 (split: boundary images first, exchange in flight while
     the interior images are warped; not split: one warp launch and one pyramid build for all local images, as with
     several panoramas in flight), both ranks executed one after the other on this GPU: pass 1 records
@@ -302,7 +304,7 @@ def test_sharded_job_bands_equal_single_job(oracle, gpu_ctx, split):
     for r in range(world):
         rec = Recorder()
         job = ShardedStitchJob(frames[r * per:(r + 1) * per], cams[r * per:(r + 1) * per], cams, r, world, num_bands=4,
-                               ctx=gpu_ctx, transport=rec, split_boundary=split)
+                               ctx=gpu_ctx, transport=rec, split_boundary=split, exchange=exchange)
         job.plan()
         job.run()
         jobs.append(job)
