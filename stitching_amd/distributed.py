@@ -447,8 +447,11 @@ class ShardedStitchJob:
         for k, img, mask, roi in zip(orders, imgs, masks, rois):
             if roi[0:2] != p.corners[k]:
                 raise StitchingError("warp roi changed between plan() and run()")
-            blender.feed_ex(img, mask, p.corners[k], k)
+            self._feed_own(blender, p, k, img, mask)
         return {k: (img, mask) for k, img, mask in zip(orders, imgs, masks)}
+
+    def _feed_own(self, blender, p, k, img, mask):
+        feed_own_image(blender, p, self.rank, k, img, mask)
 
     def gather(self, pano, mask):
         """Assemble the full panorama on rank 0 (host side, outside any timed region)."""
@@ -516,6 +519,22 @@ class _NullTransport:
         return []
 
 
+def feed_own_image(blender, plan, rank, k, img, mask):
+    """An image of this rank joins its blender.  exchange="strips": only the columns its own band depends on — a view,
+    no copy — so that the pyramids of a wide image (the pitched rows of a multi-row panorama reach over several bands) are
+    not built where only other ranks look; they build those parts from the strips they receive."""
+    if plan.exchange != "strips":
+        blender.feed_ex(img, mask, plan.corners[k], k)
+        return
+    (x0, x1), _ = blender.strip_rect(plan.sizes[k], plan.corners[k], plan.band(rank))
+    if x1 <= x0:
+        return  # nothing of this image reaches the rank's own band
+    if x0 == 0 and x1 == plan.sizes[k][0]:
+        blender.feed_ex(img, mask, plan.corners[k], k)
+    else:
+        blender.feed_ex(img[:, x0:x1], mask[:, x0:x1], (plan.corners[k][0] + x0, plan.corners[k][1]), k)
+
+
 def _mask_is_binary(ctx, mask):
     fl = C.c_int()
     _lib.check(ctx._lib.stx_buf_flags(mask._h, C.byref(fl)))
@@ -539,7 +558,7 @@ def virtual_sharded_blend(ctx, warped, masks, corners, sizes, world, num_bands, 
     d_imgs = [as_device(w, ctx) for w in warped]
     d_masks = [as_device(m, ctx) for m in masks]
     for k in range(n):
-        blenders[owners[k]].feed_ex(d_imgs[k], d_masks[k], plan.corners[k], k)
+        feed_own_image(blenders[owners[k]], plan, owners[k], k, d_imgs[k], d_masks[k])
     for (k, src, dst, rect, nbytes) in plan.messages:
         if exchange == "strips":
             packed = strip_pack(ctx, d_imgs[k], d_masks[k], rect[0], rect[1])
