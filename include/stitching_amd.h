@@ -234,6 +234,12 @@ int stx_buf_flags(const stx_buf* buf, int* out_flags);
 int stx_strip_rect(const stx_blender* b, int img_w, int img_h, int tlx, int tly, int band_x0, int band_x1, int out_x0x1[2],
                    size_t* out_bytes);
 int stx_strip_pack(stx_ctx* ctx, const stx_buf* img, const stx_buf* mask, int x0, int x1, stx_buf** out_packed);
+/* all strips a rank owes in one call (one copy kernel per 16 strips); x0 multiples of 8, whole image buffers (no views) */
+int stx_strip_pack_batch(stx_ctx* ctx, int n, const stx_buf* const* imgs, const stx_buf* const* masks, const int* x0s, const int* x1s,
+                         stx_buf** out_packed);
+/* all received strips in one call: unpack + stx_blend_feed_ex(strip i at (tlxs[i], tlys[i]), orders[i]) */
+int stx_blend_feed_strips(stx_blender* b, int n, const stx_buf* const* packed, const int* ws, const int* hs, const int* tlxs,
+                          const int* tlys, const int* orders, int flags);
 int stx_strip_unpack(const stx_buf* packed, int w, int h, int flags, stx_buf** out_img, stx_buf** out_mask);
 
 /* ---- RCCL strip exchange over xGMI ---------------------------------------------------------------

@@ -1497,28 +1497,45 @@ STX_EXPORT int stx_strip_rect(const stx_blender* b, int img_w, int img_h, int tl
     return STX_OK;
 }
 
-// columns [x0, x1) of a u8x3 image and of its u8 mask -> one flat buffer: the image rows (pitch as an image buffer of that
-// width has it), then the mask rows.  Two 2-D device copies on the context stream.
+// columns [x0, x1) of u8x3 images and of their u8 masks -> one flat buffer each: the image rows (pitch as an image buffer
+// of that width has it), then the mask rows.  All strips of a call are copied by one kernel launch per 16 strips.
+STX_EXPORT int stx_strip_pack_batch(stx_ctx* ctx, int n, const stx_buf* const* imgs, const stx_buf* const* masks, const int* x0s,
+                                    const int* x1s, stx_buf** out_packed)
+{
+    if (!ctx || n < 0 || (n > 0 && (!imgs || !masks || !x0s || !x1s || !out_packed))) return stx_fail(STX_ERR_INVALID, "null argument");
+    STX_TRY(stx_set_device(ctx));
+    std::vector<stx_buf*> flats(n, nullptr);
+    std::vector<int> ws(n);
+    std::vector<size_t> si(n), sm(n);
+    int rc = STX_OK;
+    for (int i = 0; i < n && rc == STX_OK; i++) {
+        const stx_buf *img = imgs[i], *mask = masks[i];
+        if (!img || !mask || img->elem != STX_U8 || img->c != 3 || mask->elem != STX_U8 || mask->c != 1 || mask->w != img->w || mask->h != img->h)
+            rc = stx_fail(STX_ERR_INVALID, "strip: u8x3 image with a u8 mask of the same size");
+        else if (x0s[i] < 0 || x1s[i] > img->w || x1s[i] <= x0s[i] || (x0s[i] & 7))
+            rc = stx_fail(STX_ERR_INVALID, "strip columns [%d,%d) of %d (x0 must be a multiple of 8)", x0s[i], x1s[i], img->w);
+        else if (img->parent || mask->parent)
+            rc = stx_fail(STX_ERR_INVALID, "strip: whole image buffers only (rows of whole 8-pixel groups)");
+        if (rc != STX_OK) break;
+        ws[i] = x1s[i] - x0s[i];
+        size_t nbytes;
+        strip_layout(ws[i], img->h, &si[i], &sm[i], &nbytes);
+        if (nbytes > ((size_t)1 << 30)) { rc = stx_fail(STX_ERR_UNSUPPORTED, "strip larger than 1 GiB"); break; }
+        rc = stx_buf_new(ctx, (int)nbytes, 1, 1, STX_U8, &flats[i]);
+        if (rc == STX_OK) flats[i]->mask_binary = mask->mask_binary;
+    }
+    if (rc == STX_OK) rc = stx_launch_strip_pack(ctx, n, imgs, masks, x0s, ws.data(), flats.data(), si.data(), sm.data());
+    if (rc != STX_OK) {
+        for (stx_buf* f : flats) stx_buf_release(f);
+        return rc;
+    }
+    for (int i = 0; i < n; i++) out_packed[i] = flats[i];
+    return STX_OK;
+}
+
 STX_EXPORT int stx_strip_pack(stx_ctx* ctx, const stx_buf* img, const stx_buf* mask, int x0, int x1, stx_buf** out_packed)
 {
-    if (!ctx || !img || !mask || !out_packed) return stx_fail(STX_ERR_INVALID, "null argument");
-    if (img->elem != STX_U8 || img->c != 3 || mask->elem != STX_U8 || mask->c != 1 || mask->w != img->w || mask->h != img->h)
-        return stx_fail(STX_ERR_INVALID, "strip: u8x3 image with a u8 mask of the same size");
-    if (x0 < 0 || x1 > img->w || x1 <= x0) return stx_fail(STX_ERR_INVALID, "strip columns [%d,%d) of %d", x0, x1, img->w);
-    STX_TRY(stx_set_device(ctx));
-    const int w = x1 - x0, h = img->h;
-    size_t si, sm, nbytes;
-    strip_layout(w, h, &si, &sm, &nbytes);
-    stx_buf* flat = nullptr;
-    STX_TRY(stx_buf_new(ctx, (int)std::min<size_t>(nbytes, (size_t)1 << 30), (int)((nbytes + ((size_t)1 << 30) - 1) >> 30), 1, STX_U8, &flat));
-    if (flat->h != 1) { stx_buf_release(flat); return stx_fail(STX_ERR_UNSUPPORTED, "strip larger than 1 GiB"); }
-    hipError_t e = hipMemcpy2DAsync(flat->ptr, si, img->ptr + (size_t)x0 * 3, img->stride, (size_t)w * 3, h, hipMemcpyDeviceToDevice, ctx->stream);
-    if (e == hipSuccess)
-        e = hipMemcpy2DAsync(flat->ptr + si * h, sm, mask->ptr + x0, mask->stride, (size_t)w, h, hipMemcpyDeviceToDevice, ctx->stream);
-    if (e != hipSuccess) { stx_buf_release(flat); return stx_fail(STX_ERR_HIP, "strip copy: %s", hipGetErrorString(e)); }
-    flat->mask_binary = mask->mask_binary;
-    *out_packed = flat;
-    return STX_OK;
+    return stx_strip_pack_batch(ctx, 1, &img, &mask, &x0, &x1, out_packed);
 }
 
 // the image and mask of a received strip as views of the flat buffer (which they keep alive)
@@ -1541,6 +1558,23 @@ STX_EXPORT int stx_strip_unpack(const stx_buf* packed, int w, int h, int flags, 
         v->mask_binary = k && (flags & STX_CONTRIB_U8_BINARY) ? 1 : 0;
         stx_buf_retain(root);
         *(k ? out_mask : out_img) = v;
+    }
+    return STX_OK;
+}
+
+// feed n received strips (flat buffers of stx_strip_pack) in one call: strip i holds w[i] x h[i] pixels and belongs at
+// corner (tlx[i], tly[i]) with the global feed index orders[i]
+STX_EXPORT int stx_blend_feed_strips(stx_blender* b, int n, const stx_buf* const* packed, const int* ws, const int* hs, const int* tlxs,
+                                     const int* tlys, const int* orders, int flags)
+{
+    if (!b || n < 0 || (n > 0 && (!packed || !ws || !hs || !tlxs || !tlys || !orders))) return stx_fail(STX_ERR_INVALID, "null argument");
+    for (int i = 0; i < n; i++) {
+        stx_buf *img = nullptr, *mask = nullptr;
+        STX_TRY(stx_strip_unpack(packed[i], ws[i], hs[i], flags, &img, &mask));
+        const int rc = stx_blend_feed_ex(b, img, mask, tlxs[i], tlys[i], orders[i]);
+        stx_buf_release(img);  // the blender holds its own references
+        stx_buf_release(mask);
+        if (rc != STX_OK) return rc;
     }
     return STX_OK;
 }

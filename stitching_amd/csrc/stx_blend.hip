@@ -18,6 +18,8 @@
 // pixel, read-modify-written once per image) never exist in HBM.  Integer sums are exact in
 // any order (int16 wrap-around adds); fp32 weight sums are taken in ascending feed order, the
 // order OpenCV's += sees.
+#include <cstring>
+
 #include "stx_blend_kernels.h"
 #include "stx_device_math.h"
 #include "stx_internal.h"
@@ -677,6 +679,55 @@ int stx_launch_gain_apply(stx_ctx* ctx, stx_buf* img, const float g[3])
     StxProfScope prof(ctx, "gain_apply", 6.0 * img->w * img->h);
     hipLaunchKernelGGL(gain_apply_kernel, dim3((img->w + 255) / 256, (img->h + 3) / 4), dim3(256), 0, ctx->stream, K);
     return check_launch("gain_apply");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Strip packing (image-strip sharding): the columns [x0, x0 + w) of up to STRIP_BATCH warped images and of
+// their masks -> flat buffers (image rows at pitch si, then mask rows at pitch sm), one launch.  8 bytes per lane; w is
+// copied in whole 8-pixel groups (rows of every image buffer hold whole groups), x0 is a multiple of 8.
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int STRIP_BATCH = 16;
+struct StripK { const uint8_t* img; const uint8_t* mask; uint8_t* dst; long long istride, mstride, si, sm; int h, img_chunks, mask_chunks; };
+struct StripBatchK { StripK k[STRIP_BATCH]; };
+__global__ __launch_bounds__(256) void strip_pack_kernel(StripBatchK B)
+{
+    const StripK& P = B.k[blockIdx.z];
+    const int row = blockIdx.y;
+    if (row >= P.h) return;
+    const int per_row = P.img_chunks + P.mask_chunks;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < per_row; c += gridDim.x * 256) {
+        if (c < P.img_chunks)
+            *reinterpret_cast<uint2*>(P.dst + (long long)row * P.si + 8ll * c) = *reinterpret_cast<const uint2*>(P.img + (long long)row * P.istride + 8ll * c);
+        else
+            *reinterpret_cast<uint2*>(P.dst + P.si * P.h + (long long)row * P.sm + 8ll * (c - P.img_chunks)) =
+                *reinterpret_cast<const uint2*>(P.mask + (long long)row * P.mstride + 8ll * (c - P.img_chunks));
+    }
+}
+}  // namespace
+
+int stx_launch_strip_pack(stx_ctx* ctx, int n, const stx_buf* const* imgs, const stx_buf* const* masks, const int* x0, const int* w,
+                          stx_buf* const* dsts, const size_t* si, const size_t* sm)
+{
+    for (int base = 0; base < n; base += STRIP_BATCH) {
+        const int m = std::min(STRIP_BATCH, n - base);
+        StripBatchK B = {};
+        int max_h = 0, max_chunks = 0;
+        double bytes = 0.0;
+        for (int i = 0; i < m; i++) {
+            const int g = base + i, w8 = (w[g] + 7) & ~7;
+            StripK& K = B.k[i];
+            K.img = imgs[g]->ptr + (size_t)x0[g] * 3; K.mask = masks[g]->ptr + x0[g]; K.dst = dsts[g]->ptr;
+            K.istride = (long long)imgs[g]->stride; K.mstride = (long long)masks[g]->stride; K.si = (long long)si[g]; K.sm = (long long)sm[g];
+            K.h = imgs[g]->h; K.img_chunks = w8 * 3 / 8; K.mask_chunks = w8 / 8;
+            max_h = std::max(max_h, K.h);
+            max_chunks = std::max(max_chunks, K.img_chunks + K.mask_chunks);
+            bytes += 8.0 * (double)w[g] * K.h;
+        }
+        StxProfScope prof(ctx, "strip_pack", bytes);
+        hipLaunchKernelGGL(strip_pack_kernel, dim3((max_chunks + 255) / 256, max_h, m), dim3(256), 0, ctx->stream, B);
+    }
+    return check_launch("strip_pack");
 }
 
 // ---------------------------------------------------------------------------------------------

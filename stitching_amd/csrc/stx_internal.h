@@ -165,6 +165,10 @@ int stx_launch_block_gain(stx_ctx* ctx, stx_buf* img, const stx_buf* gmap, const
 int stx_launch_resize_exact(stx_ctx* ctx, const stx_buf* src, stx_buf* dst, const int* d_xt, const int* d_yt, bool dilate,
                             const stx_buf* andmask);
 
+// image-strip sharding: pack the columns [x0, x0 + w) of n images + masks into n flat buffers (one launch per 16 strips)
+int stx_launch_strip_pack(stx_ctx* ctx, int n, const stx_buf* const* imgs, const stx_buf* const* masks, const int* x0, const int* w,
+                          stx_buf* const* dsts, const size_t* si, const size_t* sm);
+
 // simple blenders --------------------------------------------------------------------------------
 int stx_launch_no_feed(stx_ctx* ctx, const stx_buf* img, const stx_buf* mask, short* dst, long long dst_stride,
                        uint8_t* dmask, long long dmask_stride, int dx, int dy);

@@ -67,6 +67,16 @@ class ShardBlender(_BlenderHandle):
         _lib.check(self.ctx._lib.stx_blend_export_contribs(self._h, n, orders, x0s, x1s, outs, rects))
         return [(DeviceImage(self.ctx, C.c_void_p(outs[i])), tuple(int(v) for v in rects[4 * i:4 * i + 4])) for i in range(n)]
 
+    def feed_strips(self, items, flags=_lib.CONTRIB_U8_BINARY):
+        """items: [(flat buffer, w, h, corner, order)]: all received strips in one call (stx_blend_feed_strips)"""
+        n = len(items)
+        if n == 0:
+            return
+        bufs = (C.c_void_p * n)(*[i[0]._h for i in items])
+        arr = lambda k: (C.c_int * n)(*[int(k(i)) for i in items])  # noqa: E731
+        _lib.check(self.ctx._lib.stx_blend_feed_strips(self._h, n, bufs, arr(lambda i: i[1]), arr(lambda i: i[2]), arr(lambda i: i[3][0]),
+                                                       arr(lambda i: i[3][1]), arr(lambda i: i[4]), int(flags)))
+
     def strip_rect(self, size, corner, band):
         """-> ((x0, x1) columns of the image, packed bytes) that an image owes the owner of `band`; x0 == x1: nothing."""
         xs, nbytes = (C.c_int * 2)(), C.c_size_t()
@@ -99,6 +109,20 @@ def strip_pack(ctx, img, mask, x0, x1):
     out = C.c_void_p()
     _lib.check(ctx._lib.stx_strip_pack(ctx.handle, img._h, mask._h, int(x0), int(x1), C.byref(out)))
     return DeviceImage(ctx, out)
+
+
+def strip_pack_batch(ctx, items):
+    """items: [(image, mask, x0, x1)] -> [flat device buffer]: every strip a rank owes, one copy kernel per 16 strips"""
+    n = len(items)
+    if n == 0:
+        return []
+    imgs = (C.c_void_p * n)(*[i[0]._h for i in items])
+    masks = (C.c_void_p * n)(*[i[1]._h for i in items])
+    x0s = (C.c_int * n)(*[int(i[2]) for i in items])
+    x1s = (C.c_int * n)(*[int(i[3]) for i in items])
+    outs = (C.c_void_p * n)()
+    _lib.check(ctx._lib.stx_strip_pack_batch(ctx.handle, n, imgs, masks, x0s, x1s, outs))
+    return [DeviceImage(ctx, C.c_void_p(outs[i])) for i in range(n)]
 
 
 def strip_unpack(packed, w, h, flags=_lib.CONTRIB_U8_BINARY):
@@ -407,9 +431,8 @@ class ShardedStitchJob:
             warped = self._warp_and_feed(blender, [k for k in self.my_orders if k in senders], p)
             sends = []
             if p.exchange == "strips":
-                for (k, _src, dst, rect, nbytes) in send_msgs:
-                    img, mask = warped[k]
-                    sends.append((dst, strip_pack(self.ctx, img, mask, rect[0], rect[1]), nbytes))
+                packed = strip_pack_batch(self.ctx, [(warped[k][0], warped[k][1], rect[0], rect[1]) for (k, _s, _d, rect, _n) in send_msgs])
+                sends = [(dst, buf, nbytes) for (_k, _src, dst, _rect, nbytes), buf in zip(send_msgs, packed)]
             else:
                 exported = blender.export_contribs([(k, p.band(dst)) for (k, _src, dst, _rect, _nbytes) in send_msgs])
                 for (k, _src, dst, rect, nbytes), (packed, r) in zip(send_msgs, exported):
@@ -420,16 +443,17 @@ class ShardedStitchJob:
             self.transport.start(sends, [(m[1], m[4]) for m in recv_msgs], self.ctx)
             # 2. the other images of this rank are warped and fed while the strips travel
             self._warp_and_feed(blender, [k for k in self.my_orders if k not in senders], p)
-            blender.build()  # ... and so are their pyramids, before this stream starts waiting for the exchange
+            if self.split_boundary:
+                blender.build()  # ... and so are their pyramids, before this stream starts waiting for the exchange
+            # (not split: another panorama in flight covers the exchange; everything is built by ONE set of launches in blend())
             # 3. received strips join the image table in global feed order; blend this rank's band
             rbufs = self.transport.finish()
             # every strip of this job comes from a u8 warp with a 0 / 255 mask (warp_images_and_masks on all ranks)
-            for m, buf in zip(recv_msgs, rbufs):
-                if p.exchange == "strips":
-                    x0, _x1, w, h = m[3]
-                    simg, smask = strip_unpack(buf, w, h, _lib.CONTRIB_U8_BINARY)
-                    blender.feed_ex(simg, smask, (p.corners[m[0]][0] + x0, p.corners[m[0]][1]), m[0])
-                else:
+            if p.exchange == "strips":
+                blender.feed_strips([(buf, m[3][2], m[3][3], (p.corners[m[0]][0] + m[3][0], p.corners[m[0]][1]), m[0])
+                                     for m, buf in zip(recv_msgs, rbufs)], _lib.CONTRIB_U8_BINARY)
+            else:
+                for m, buf in zip(recv_msgs, rbufs):
                     blender.feed_contrib(m[0], m[3], buf, _lib.CONTRIB_U8_BINARY)
             pano, mask = blender.blend()
         finally:
