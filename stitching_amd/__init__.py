@@ -7,13 +7,14 @@ from .camera import CameraParams
 from .config import device_resident, set_device_resident
 from .device import Context, DeviceImage, as_device, device_count, get_context, pinned_empty, set_default_device
 from .exposure_error_compensator import ExposureErrorCompensator
+from .images import Images, MegapixDownscaler, MegapixScaler
 from .seam_finder import SeamFinder, resize_linear_exact
 from .stitching_error import StitchingError, StitchingWarning
 from .timelapser import Timelapser
 from .warper import Warper
 
 __all__ = [
-    "Blender", "CameraParams", "Context", "DeviceImage", "ExposureErrorCompensator", "StitchingError", "StitchingWarning",
+    "Blender", "CameraParams", "Context", "DeviceImage", "ExposureErrorCompensator", "Images", "MegapixDownscaler", "MegapixScaler", "StitchingError", "StitchingWarning",
     "SeamFinder", "Timelapser", "Warper", "resize_linear_exact",
     "as_device", "device_count", "pinned_empty", "device_resident", "get_context", "set_default_device", "set_device_resident",
 ]

@@ -1,0 +1,304 @@
+"""`Images` with the reference's surface (stitching/images.py:13-207) and the staging in front of the hot path
+(SURVEY.md §8f row N3): decode -> page-locked buffer -> queued upload -> `cv.resize(INTER_LINEAR_EXACT)` on the device.
+
+The reference reads every file with `cv.imread` and resizes it on the host three times (MEDIUM for the features, LOW for
+seams / exposure, FINAL for the composition: `stitcher.py:131,168,217`).  Here
+
+  * `Images.resize(resolution)` keeps the generator contract and runs the bit-exact `INTER_LINEAR_EXACT` kernel
+    (`stx_resize_linear_exact`) — numpy out by default, `DeviceImage` out after `set_device_resident(True)`;
+  * `Images.stage(resolution)` is the streaming form for FINAL: a small thread pool decodes ahead (cv2 when it is
+    importable, else Pillow — both are libjpeg-turbo underneath and release the GIL while decoding) into page-locked
+    buffers, uploads are queued on the context's stream and the resize runs in HBM, so the frame that
+    `Warper.warp_images` consumes next is already resident while the following ones are still being decoded.
+
+Decoding itself stays on the host (no JPEG decoder on the device); what this row removes is the pageable copy and the
+serialisation of decode, upload and resize.
+"""
+import os
+import threading
+from collections import deque
+from concurrent.futures import ThreadPoolExecutor
+from enum import Enum
+from glob import glob
+
+import numpy as np
+
+from . import config
+from .device import DeviceImage, get_context, pinned_empty
+from .seam_finder import resize_linear_exact
+from .stitching_error import StitchingError
+
+
+class MegapixScaler:
+    """stitching/megapix_scaler.py:4-26: scale = sqrt(megapix * 1e6 / pixels) (1.0 when megapix <= 0)."""
+
+    def __init__(self, megapix):
+        self.megapix = megapix
+        self.is_scale_set = False
+        self.scale = None
+
+    def get_scale_by_resolution(self, resolution):
+        return float(np.sqrt(self.megapix * 1e6 / resolution)) if self.megapix > 0 else 1.0
+
+    def set_scale(self, scale):
+        self.scale, self.is_scale_set = scale, True
+
+    def set_scale_by_img_size(self, img_size):
+        self.set_scale(self.get_scale_by_resolution(img_size[0] * img_size[1]))
+
+    def get_scaled_img_size(self, img_size):
+        return (int(round(img_size[0] * self.scale)), int(round(img_size[1] * self.scale)))
+
+
+class MegapixDownscaler(MegapixScaler):
+    """stitching/megapix_scaler.py:29-37: never enlarges."""
+
+    @staticmethod
+    def force_downscale(scale):
+        return min(1.0, scale)
+
+    def set_scale(self, scale):
+        super().set_scale(self.force_downscale(scale))
+
+
+def _decode(name):
+    """u8 BGR HWC, as cv.imread(name) returns it."""
+    try:
+        import cv2 as cv
+    except ImportError:
+        cv = None
+    if cv is not None:
+        return cv.imread(name)
+    try:
+        from PIL import Image
+    except ImportError as e:
+        raise StitchingError("reading image files needs cv2 or Pillow") from e
+    try:
+        with Image.open(name) as im:
+            rgb = np.asarray(im.convert("RGB"))
+    except (OSError, ValueError):
+        return None
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
+class Images:
+    """stitching/images.py:13-161 — construct with Images.of(list of numpy images or of file names, ...)."""
+
+    class Resolution(Enum):
+        MEDIUM = 0.6
+        LOW = 0.1
+        FINAL = -1
+
+    @staticmethod
+    def of(images, medium_megapix=Resolution.MEDIUM.value, low_megapix=Resolution.LOW.value, final_megapix=Resolution.FINAL.value):
+        if not isinstance(images, list):
+            raise StitchingError("images must be a list of images or filenames")
+        if len(images) == 0:
+            raise StitchingError("images must not be an empty list")
+        if Images.check_list_element_types(images, (np.ndarray, DeviceImage)):
+            return _ArrayImages(images, medium_megapix, low_megapix, final_megapix)
+        if Images.check_list_element_types(images, str):
+            return _FilenameImages(images, medium_megapix, low_megapix, final_megapix)
+        raise StitchingError("invalid images list: must be numpy arrays (loaded images) or filename strings")
+
+    def __init__(self, images, medium_megapix, low_megapix, final_megapix):
+        if medium_megapix < low_megapix:
+            raise StitchingError("Medium resolution megapix need to be greater or equal than low resolution megapix")
+        self._scalers = {"MEDIUM": MegapixDownscaler(medium_megapix), "LOW": MegapixDownscaler(low_megapix),
+                         "FINAL": MegapixDownscaler(final_megapix)}
+        self._scales_set = self._sizes_set = self._names_set = False
+
+    # ---- the reference's properties / helpers
+    @property
+    def sizes(self):
+        assert self._sizes_set
+        return self._sizes
+
+    @property
+    def names(self):
+        assert self._names_set
+        return self._names
+
+    def subset(self, indices):
+        self._sizes = [self._sizes[i] for i in indices]
+        self._names = [self._names[i] for i in indices]
+
+    def resize(self, resolution, imgs=None):
+        """generator, stitching/images.py:72-77: every image at `resolution` (cv.resize INTER_LINEAR_EXACT, on the device)"""
+        for idx, img in enumerate(iter(self) if imgs is None else imgs):
+            yield Images.resize_img_by_scaler(self._get_scaler(resolution), self._sizes[idx], img)
+
+    def _set_scales(self, size):
+        if not self._scales_set:
+            for s in self._scalers.values():
+                s.set_scale_by_img_size(size)
+            self._scales_set = True
+
+    def _get_scaler(self, resolution):
+        Images.check_resolution(resolution)
+        return self._scalers[resolution.name]
+
+    def get_ratio(self, from_resolution, to_resolution):
+        assert self._scales_set
+        return self._get_scaler(to_resolution).scale / self._get_scaler(from_resolution).scale
+
+    def get_scaled_img_sizes(self, resolution):
+        assert self._scales_set and self._sizes_set
+        return [self._get_scaler(resolution).get_scaled_img_size(sz) for sz in self._sizes]
+
+    @staticmethod
+    def read_image(img_name):
+        img = _decode(img_name)
+        if img is None:
+            raise StitchingError("Cannot read image " + img_name)
+        return img
+
+    @staticmethod
+    def get_image_size(img):
+        """(width, height)"""
+        return (img.shape[1], img.shape[0])
+
+    @staticmethod
+    def resize_img_by_scaler(scaler, size, img):
+        desired = scaler.get_scaled_img_size(size)
+        if desired == Images.get_image_size(img):  # INTER_LINEAR_EXACT to the same size is the identity
+            if isinstance(img, DeviceImage) or not config.device_resident():
+                return img
+            return DeviceImage.from_numpy(img)
+        return resize_linear_exact(img, desired, ctx=img.ctx if isinstance(img, DeviceImage) else None)
+
+    @staticmethod
+    def check_resolution(resolution):
+        assert isinstance(resolution, Enum) and resolution in Images.Resolution
+
+    @staticmethod
+    def resolve_wildcards(img_names):
+        if len(img_names) == 1:
+            img_names = [i for i in glob(img_names[0]) if not os.path.isdir(i)]
+        return img_names
+
+    @staticmethod
+    def check_list_element_types(list_, type_):
+        return all(isinstance(e, type_) for e in list_)
+
+    @staticmethod
+    def to_binary(img):
+        """stitching/images.py:153-158: BGR2GRAY (Y = (R 4899 + G 9617 + B 1868 + 8192) >> 14, cv::cvtColor's 8-bit path),
+        then 255 where the value exceeds 0.5."""
+        img = np.asarray(img)
+        if img.ndim == 3:
+            b, g, r = (img[:, :, k].astype(np.uint32) for k in range(3))
+            img = ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8)
+        return np.where(img > 0.5, 255, 0).astype(np.uint8)
+
+    # ---- staging (no counterpart in the reference: it reads and resizes one image at a time on the host)
+    def stage(self, resolution=None, ctx=None, depth=2, workers=2):
+        """Generator of device-resident images at `resolution` (default FINAL), decoded `depth` images ahead on `workers`
+        threads into page-locked buffers and uploaded with queued copies.  Order and contents equal
+        `resize(resolution)`; sizes / scales are set on the way exactly as iterating does."""
+        resolution = resolution or Images.Resolution.FINAL
+        ctx = ctx or get_context()
+        n = len(self._staging_sources())
+        if n == 0:
+            return
+        self._pin_pool, self._pin_lock = {}, threading.Lock()
+        with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
+            pending = deque()
+            nxt = 0
+
+            def submit():
+                nonlocal nxt
+                if nxt < n:
+                    pending.append(pool.submit(self._load_pinned, nxt))
+                    nxt += 1
+
+            for _ in range(max(1, depth)):
+                submit()
+            idx = 0
+            in_flight = deque()  # page-locked buffers whose queued upload may still be running
+            while pending:
+                host = pending.popleft().result()
+                submit()
+                self._note_size(idx, Images.get_image_size(host))
+                dev = DeviceImage.from_numpy(host, ctx, wait=False)
+                in_flight.append(host)
+                if len(in_flight) > max(1, depth):
+                    ctx.sync()  # page-locked buffers go back to the decoders only after their queued copies have landed
+                    with self._pin_lock:
+                        for b in in_flight:
+                            self._pin_pool.setdefault((b.shape, b.dtype.str), []).append(b)
+                    in_flight.clear()
+                prev = config.device_resident()
+                config.set_device_resident(True)
+                try:
+                    out = Images.resize_img_by_scaler(self._get_scaler(resolution), self._sizes[idx], dev)
+                finally:
+                    config.set_device_resident(prev)
+                yield out
+                idx += 1
+            ctx.sync()
+
+    def _load_pinned(self, i):
+        src = self._staging_sources()[i]
+        a = Images.read_image(src) if isinstance(src, str) else np.asarray(src)
+        with self._pin_lock:
+            free = self._pin_pool.get((a.shape, a.dtype.str))
+            buf = free.pop() if free else None
+        if buf is None:
+            buf = pinned_empty(a.shape, a.dtype)
+        np.copyto(buf, a)
+        return buf
+
+
+class _ArrayImages(Images):
+    def __init__(self, images, medium_megapix, low_megapix, final_megapix):
+        super().__init__(images, medium_megapix, low_megapix, final_megapix)
+        if len(images) < 2:
+            raise StitchingError("2 or more Images needed")
+        self._images = images
+        self._sizes = [Images.get_image_size(img) for img in images]
+        self._sizes_set = True
+        self._names = [str(i + 1) for i in range(len(images))]
+        self._names_set = True
+        self._set_scales(self._sizes[0])
+
+    def subset(self, indices):
+        super().subset(indices)
+        self._images = [self._images[i] for i in indices]
+
+    def __iter__(self):
+        yield from self._images
+
+    def _staging_sources(self):
+        return self._images
+
+    def _note_size(self, idx, size):
+        pass
+
+
+class _FilenameImages(Images):
+    def __init__(self, images, medium_megapix, low_megapix, final_megapix):
+        super().__init__(images, medium_megapix, low_megapix, final_megapix)
+        self._names = Images.resolve_wildcards(images)
+        self._names_set = True
+        if len(self.names) < 2:
+            raise StitchingError("2 or more Images needed")
+        self._sizes = []
+
+    def __iter__(self):
+        for idx, name in enumerate(self.names):
+            img = Images.read_image(name)
+            self._note_size(idx, Images.get_image_size(img))
+            yield img
+
+    def _staging_sources(self):
+        return self._names
+
+    def _note_size(self, idx, size):
+        # the reference's side effects of the first iteration (images.py:190-201): scales from the first image, sizes recorded once
+        self._set_scales(size)
+        if not self._sizes_set:
+            if idx == len(self._sizes):
+                self._sizes.append(size)
+            if len(self._sizes) == len(self.names):
+                self._sizes_set = True
