@@ -8,6 +8,8 @@
 
 #include <cstring>
 
+#include <map>
+
 #include "stx_internal.h"
 
 namespace {
@@ -72,8 +74,10 @@ struct stx_comm {
     // exchanges run on their own stream so that independent kernels queued on the context stream after
     // stx_comm_exchange_begin overlap with the transfer
     hipStream_t stream = nullptr;
-    hipEvent_t ready = nullptr, done = nullptr;
-    bool in_flight = false;
+    // one (ready, done) event pair per context that exchanges through this communicator: several panoramas in flight
+    // each wait for their OWN transfer only
+    struct Slot { hipEvent_t ready = nullptr, done = nullptr; bool in_flight = false; };
+    std::map<stx_ctx*, Slot> slots;
 };
 
 STX_EXPORT int stx_comm_unique_id(unsigned char out[128])
@@ -119,20 +123,21 @@ STX_EXPORT int stx_comm_exchange_begin_on(stx_comm* comm, stx_ctx* on, int n_ops
     if (!comm || !on || n_ops < 0 || (n_ops && (!peers || !is_send || !dev_ptrs || !bytes)))
         return stx_fail(STX_ERR_INVALID, "bad argument");
     if (on->device != comm->ctx->device) return stx_fail(STX_ERR_INVALID, "context lives on another device than the communicator");
-    if (comm->in_flight) return stx_fail(STX_ERR_STATE, "an exchange is already in flight on this communicator");
+    stx_comm::Slot& slot = comm->slots[on];
+    if (slot.in_flight) return stx_fail(STX_ERR_STATE, "an exchange of this context is already in flight on this communicator");
     STX_TRY(stx_set_device(comm->ctx));
     for (int i = 0; i < n_ops; i++)
         if (peers[i] < 0 || peers[i] >= comm->nranks || !dev_ptrs[i])
             return stx_fail(STX_ERR_INVALID, "exchange op %d: peer %d / null buffer", i, peers[i]);
-    if (!comm->stream) {
-        STX_HIP(hipStreamCreateWithFlags(&comm->stream, hipStreamNonBlocking));
-        STX_HIP(hipEventCreateWithFlags(&comm->ready, hipEventDisableTiming));
-        STX_HIP(hipEventCreateWithFlags(&comm->done, hipEventDisableTiming));
+    if (!comm->stream) STX_HIP(hipStreamCreateWithFlags(&comm->stream, hipStreamNonBlocking));
+    if (!slot.ready) {
+        STX_HIP(hipEventCreateWithFlags(&slot.ready, hipEventDisableTiming));
+        STX_HIP(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
     }
     // the transfer starts after everything queued so far on the context stream (the kernels that filled the
     // send buffers, the last users of the memory behind the receive buffers) ...
-    STX_HIP(hipEventRecord(comm->ready, on->stream));
-    STX_HIP(hipStreamWaitEvent(comm->stream, comm->ready, 0));
+    STX_HIP(hipEventRecord(slot.ready, on->stream));
+    STX_HIP(hipStreamWaitEvent(comm->stream, slot.ready, 0));
     if (n_ops > 0) {
         STX_RCCL(g_rccl.GroupStart());
         for (int i = 0; i < n_ops; i++) {
@@ -146,8 +151,8 @@ STX_EXPORT int stx_comm_exchange_begin_on(stx_comm* comm, stx_ctx* on, int n_ops
         }
         STX_RCCL(g_rccl.GroupEnd());
     }
-    STX_HIP(hipEventRecord(comm->done, comm->stream));
-    comm->in_flight = true;
+    STX_HIP(hipEventRecord(slot.done, comm->stream));
+    slot.in_flight = true;
     return STX_OK;
 }
 
@@ -155,10 +160,11 @@ STX_EXPORT int stx_comm_exchange_begin_on(stx_comm* comm, stx_ctx* on, int n_ops
 STX_EXPORT int stx_comm_exchange_end_on(stx_comm* comm, stx_ctx* on)
 {
     if (!comm || !on) return stx_fail(STX_ERR_INVALID, "null argument");
-    if (!comm->in_flight) return STX_OK;
+    auto it = comm->slots.find(on);
+    if (it == comm->slots.end() || !it->second.in_flight) return STX_OK;
     STX_TRY(stx_set_device(comm->ctx));
-    STX_HIP(hipStreamWaitEvent(on->stream, comm->done, 0));
-    comm->in_flight = false;
+    STX_HIP(hipStreamWaitEvent(on->stream, it->second.done, 0));
+    it->second.in_flight = false;
     return STX_OK;
 }
 
@@ -178,8 +184,10 @@ STX_EXPORT int stx_comm_destroy(stx_comm* comm)
         hipStreamSynchronize(comm->ctx->stream);
         g_rccl.CommDestroy(comm->comm);
     }
-    if (comm->ready) hipEventDestroy(comm->ready);
-    if (comm->done) hipEventDestroy(comm->done);
+    for (auto& kv : comm->slots) {
+        if (kv.second.ready) hipEventDestroy(kv.second.ready);
+        if (kv.second.done) hipEventDestroy(kv.second.done);
+    }
     if (comm->stream) hipStreamDestroy(comm->stream);
     delete comm;
     return STX_OK;

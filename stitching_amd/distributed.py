@@ -241,7 +241,7 @@ class GlooHostTransport:
     def start(self, sends, recvs, ctx=None):
         self._pending = (sends, recvs, ctx)
 
-    def finish(self):
+    def finish(self, ctx=None):
         sends, recvs, ctx = self._pending
         self._pending = None
         return self.exchange(sends, recvs, ctx)
@@ -291,7 +291,7 @@ class RcclTransport:
         uid = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
         _lib.check(ctx._lib.stx_comm_create(ctx.handle, int(world), int(rank), uid, C.byref(h)))
         self._h = h
-        self._inflight = self._sent = None
+        self._inflight, self._last, self._sent = {}, None, None
 
     @staticmethod
     def unique_id():
@@ -328,16 +328,17 @@ class RcclTransport:
             peers[i], is_send[i], ptrs[i], sizes[i] = dst, 1, packed.device_ptr(), nbytes
             i += 1
         _lib.check(lib.stx_comm_exchange_begin_on(self._h, ctx.handle, n, peers, is_send, ptrs, sizes))
-        self._inflight = (rbufs, [p for _, p, _ in sends], ctx)  # both sides stay alive until finish()
+        self._inflight[id(ctx)] = (rbufs, [p for _, p, _ in sends], ctx)  # both sides stay alive until finish()
+        self._last = ctx
 
-    def finish(self):
-        """Order the context stream after the transfer; returns the received strips."""
-        rbufs, sent, ctx = self._inflight
+    def finish(self, ctx=None):
+        """Order the stream of `ctx` (default: the context of the latest start) after ITS transfer — exchanges of
+        other contexts that were started in between are not waited for; returns the received strips."""
+        rbufs, sent, ctx = self._inflight.pop(id(ctx or self._last))
         _lib.check(ctx._lib.stx_comm_exchange_end_on(self._h, ctx.handle))
         # the sent strips must outlive the transfer: they are released only after a later exchange of the same
         # context has been ordered behind this one (two generations are kept)
         self._sent = (self._sent or [])[-2:] + [sent]
-        self._inflight = None
         return rbufs
 
     def exchange(self, sends, recvs, ctx=None):
@@ -447,7 +448,7 @@ class ShardedStitchJob:
                 blender.build()  # ... and so are their pyramids, before this stream starts waiting for the exchange
             # (not split: another panorama in flight covers the exchange; everything is built by ONE set of launches in blend())
             # 3. received strips join the image table in global feed order; blend this rank's band
-            rbufs = self.transport.finish()
+            rbufs = self.transport.finish(self.ctx)
             # every strip of this job comes from a u8 warp with a 0 / 255 mask (warp_images_and_masks on all ranks)
             if p.exchange == "strips":
                 blender.feed_strips([(buf, m[3][2], m[3][3], (p.corners[m[0]][0] + m[3][0], p.corners[m[0]][1]), m[0])
@@ -539,7 +540,7 @@ class _NullTransport:
     def start(self, sends, recvs, ctx=None):
         self.exchange(sends, recvs)
 
-    def finish(self):
+    def finish(self, ctx=None):
         return []
 
 

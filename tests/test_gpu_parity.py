@@ -229,6 +229,14 @@ def test_rccl_transport_self_exchange(gpu_ctx):
                 (d2,) = tr.finish()
                 assert d2.ctx is c and np.array_equal(np.asarray(d2), h2)
                 del s2, d2
+        # two exchanges in flight at once, one per context, finished in the opposite order: each context waits for its own
+        ha, hb = (rng.integers(0, 256, size=(1, 500000 + 7 * i), dtype=np.uint8) for i in range(2))
+        sa, sb = DeviceImage.from_numpy(ha, gpu_ctx), DeviceImage.from_numpy(hb, ctx2)
+        tr.start([(0, sa, ha.size)], [(0, ha.size)], gpu_ctx)
+        tr.start([(0, sb, hb.size)], [(0, hb.size)], ctx2)
+        (db,) = tr.finish(ctx2)
+        (da,) = tr.finish(gpu_ctx)
+        assert np.array_equal(np.asarray(da), ha) and np.array_equal(np.asarray(db), hb)
     finally:
         tr.close()
         ctx2.sync()
@@ -281,7 +289,7 @@ def test_sharded_job_bands_equal_single_job(oracle, gpu_ctx, split, exchange):
             self.sent = [(dst, np.asarray(p).reshape(-1)[:nb].copy()) for dst, p, nb in sends]
             self.recvs = recvs
 
-        def finish(self):
+        def finish(self, ctx=None):
             return [flat_device_buffer(gpu_ctx, np.zeros(nb, np.uint8)) for _, nb in self.recvs]
 
     class Replay:
@@ -291,7 +299,7 @@ def test_sharded_job_bands_equal_single_job(oracle, gpu_ctx, split, exchange):
         def start(self, sends, recvs, ctx=None):
             self.recvs = recvs
 
-        def finish(self):
+        def finish(self, ctx=None):
             out = []
             for src, nb in self.recvs:
                 a = self.inbox[src].pop(0)

@@ -26,7 +26,7 @@ class ZeroStrips:
     def start(self, sends, recvs, ctx=None):
         self.ctx, self.recvs = ctx, recvs
 
-    def finish(self):
+    def finish(self, ctx=None):
         out = []
         for i, (src, nb) in enumerate(self.recvs):
             key = (id(self.ctx), i, nb)
