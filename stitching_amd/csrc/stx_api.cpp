@@ -1066,7 +1066,9 @@ struct stx_blender {
     std::vector<void*> pyr_allocs;
     int band_x0 = 0, band_x1 = 0;     // columns of the final roi this blender produces (sharded blending)
     int next_order = 0;
-    // no / feather (accumulate per feed, as OpenCV)
+    // no: deferred gather over the fed images (stx_launch_no_gather)
+    std::vector<NoImg> no_images;
+    // feather (accumulate per feed, as OpenCV)
     void* dst = nullptr; long long dst_stride = 0;      // s16 HWC
     void* dmask = nullptr; long long dmask_stride = 0;  // u8
     void* dw = nullptr; long long dw_stride = 0;        // f32
@@ -1083,6 +1085,7 @@ static void blender_release(stx_blender* b)
     stx_dev_free(b->ctx, b->dw); b->dw = nullptr;
     b->images.clear();
     b->built.clear();
+    b->no_images.clear();
 }
 
 STX_EXPORT int stx_blend_create(stx_ctx* ctx, int kind, int num_bands, float sharpness, const int roi_xywh[4],
@@ -1113,7 +1116,7 @@ STX_EXPORT int stx_blend_create(stx_ctx* ctx, int kind, int num_bands, float sha
     }
     b->rx = roi_xywh[0]; b->ry = roi_xywh[1]; b->rw = w; b->rh = h;
     b->band_x0 = 0; b->band_x1 = b->fw;
-    if (kind != STX_BLEND_MULTIBAND) {
+    if (kind == STX_BLEND_FEATHER) {
         b->dst_stride = (long long)align_up((size_t)w * 6, 64);
         b->dmask_stride = (long long)align_up((size_t)w, 64);
         STX_TRY(stx_dev_alloc(ctx, (size_t)b->dst_stride * h, &b->dst));
@@ -1342,9 +1345,20 @@ STX_EXPORT int stx_blend_feed_ex(stx_blender* b, const stx_buf* img, const stx_b
     if (order < 0) order = b->next_order;
     b->next_order = std::max(b->next_order, order + 1);
     if (b->kind == STX_BLEND_MULTIBAND) return mb_feed(b, img, mask, tlx, tly, order);
-    if (b->kind == STX_BLEND_NO)
-        return stx_launch_no_feed(b->ctx, img, mask, (short*)b->dst, b->dst_stride, (uint8_t*)b->dmask, b->dmask_stride,
-                                  tlx - b->rx, tly - b->ry);
+    if (b->kind == STX_BLEND_NO) {  // deferred: the image joins the table, the gather runs in blend()
+        NoImg im;
+        memset(&im, 0, sizeof(im));
+        im.img = img->ptr; im.istride = (long long)img->stride; im.is_s16 = img->elem == STX_S16;
+        im.mask = mask->ptr; im.mstride = (long long)mask->stride;
+        im.x = tlx - b->rx; im.y = tly - b->ry; im.w = img->w; im.h = img->h;
+        im.pad = mask->mask_binary;
+        b->no_images.push_back(im);
+        stx_buf_retain(const_cast<stx_buf*>(img));
+        stx_buf_retain(const_cast<stx_buf*>(mask));
+        b->held.push_back(const_cast<stx_buf*>(img));
+        b->held.push_back(const_cast<stx_buf*>(mask));
+        return STX_OK;
+    }
     return stx_launch_feather_feed(b->ctx, img, mask, b->sharpness, (short*)b->dst, b->dst_stride, (float*)b->dw,
                                    b->dw_stride, tlx - b->rx, tly - b->ry);
 }
@@ -1715,6 +1729,45 @@ STX_EXPORT int stx_blend_feed_contrib_ex(stx_blender* b, int order, const int re
     return STX_OK;
 }
 
+// Blender::blend of the "no" blender: one gather over the panorama (stx_blend.hip: no_gather_kernel)
+static int no_finish(stx_blender* b, stx_buf* pano, stx_buf* pmask, stx_buf* p16)
+{
+    stx_ctx* ctx = b->ctx;
+    const int n = (int)b->no_images.size();
+    void* d_tab = nullptr;
+    STX_TRY(stx_dev_alloc(ctx, sizeof(NoImg) * std::max(n, 1), &d_tab));
+    b->pyr_allocs.push_back(d_tab);
+    bool all_binary = true;
+    double bytes = 4.0 * pano->w * pano->h + (p16 ? 6.0 * pano->w * pano->h : 0.0);
+    for (const NoImg& im : b->no_images) {
+        all_binary = all_binary && im.pad;
+        bytes += (double)im.w * im.h;  // every mask once; the image bytes of the winners are counted with the output
+    }
+    bytes += 3.0 * pano->w * pano->h;
+    if (n > 0) {
+        const size_t nbytes = sizeof(NoImg) * (size_t)n;
+        if (nbytes > ctx->stage_bytes) {
+            STX_HIP(hipMemcpyAsync(d_tab, b->no_images.data(), nbytes, hipMemcpyHostToDevice, ctx->stream));
+            STX_HIP(hipStreamSynchronize(ctx->stream));
+        } else {
+            if (ctx->stage_off + nbytes > ctx->stage_bytes) {
+                STX_HIP(hipStreamSynchronize(ctx->stream));
+                ctx->stage_off = 0;
+            }
+            uint8_t* slot = ctx->stage + ctx->stage_off;
+            memcpy(slot, b->no_images.data(), nbytes);
+            ctx->stage_off += (nbytes + 255) & ~(size_t)255;
+            STX_HIP(hipMemcpyAsync(d_tab, slot, nbytes, hipMemcpyHostToDevice, ctx->stream));
+        }
+    }
+    NoGatherK K;
+    K.imgs = (const NoImg*)d_tab; K.n = n; K.all_binary = all_binary ? 1 : 0;
+    K.w = pano->w; K.h = pano->h;
+    K.pano = pano->ptr; K.pano_stride = (long long)pano->stride; K.pmask = pmask->ptr; K.pmask_stride = (long long)pmask->stride;
+    K.pano16 = p16 ? (short*)p16->ptr : nullptr; K.pano16_stride = p16 ? (long long)p16->stride : 0;
+    return stx_launch_no_gather(ctx, K, bytes);
+}
+
 STX_EXPORT int stx_blend_finish_ex(stx_blender* b, stx_buf** out_pano_u8, stx_buf** out_mask_u8, stx_buf** out_pano_s16)
 {
     if (!b) return stx_fail(STX_ERR_INVALID, "null argument");
@@ -1729,12 +1782,13 @@ STX_EXPORT int stx_blend_finish_ex(stx_blender* b, stx_buf** out_pano_u8, stx_bu
     if (rc == STX_OK && out_pano_s16) rc = stx_buf_new(ctx, ow, oh, 3, STX_S16, &p16);
     if (rc == STX_OK) {
         if (b->kind == STX_BLEND_MULTIBAND) rc = mb_finish(b, pano, pmask, p16);
+        else if (b->kind == STX_BLEND_NO) rc = no_finish(b, pano, pmask, p16);
         else
             rc = stx_launch_simple_finish(ctx, b->kind, (short*)b->dst, b->dst_stride, (const float*)b->dw, b->dw_stride,
                                           (uint8_t*)b->dmask, b->dmask_stride, ow, oh, pano->ptr, (long long)pano->stride,
                                           p16 ? (short*)p16->ptr : nullptr, p16 ? (long long)p16->stride : 0);
     }
-    if (rc == STX_OK && b->kind != STX_BLEND_MULTIBAND) {
+    if (rc == STX_OK && b->kind == STX_BLEND_FEATHER) {
         // hand out dst_mask_ (Blender::blend: dst_mask.assign(dst_mask_))
         hipError_t e = hipMemcpy2DAsync(pmask->ptr, pmask->stride, b->dmask, b->dmask_stride, ow, oh,
                                         hipMemcpyDeviceToDevice, ctx->stream);

@@ -639,6 +639,115 @@ int stx_launch_simple_finish(stx_ctx* ctx, int kind, short* dst, long long dst_s
 }
 
 // ---------------------------------------------------------------------------------------------
+// "no" blender as a deferred gather (Blender::feed: dst = src where mask != 0, dst_mask |= mask; Blender::blend: zero
+// where dst_mask == 0; then convertScaleAbs).  OpenCV keeps an int16 panorama and overwrites it once per image — 10 bytes
+// per panorama pixel zeroed, (3 + 1) read and 7 written per image pixel, 7 read + 4 written at the end.  Fed images
+// stay resident here; one pass over the panorama finds, per pixel, the LAST fed image whose mask is set (walking the
+// image table backwards), ORs the masks of all of them and writes the u8 panorama (+ mask, + int16 on request) once.
+// A lane owns 4 adjacent pixels; inside an image the four mask bytes / the twelve image bytes come from aligned dword
+// loads + v_alignbyte.
+// ---------------------------------------------------------------------------------------------
+namespace {
+STX_DEV uint32_t ld_u32_unaligned(const uint8_t* p)  // 4 bytes at any address, as two aligned dword loads
+{
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)3);
+    return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u));
+}
+
+template <bool WITH16>
+__global__ __launch_bounds__(256) void no_gather_kernel(NoGatherK P)
+{
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xw0 = blockIdx.x * 256;  // first column of the wavefront
+    if (y >= P.h || xw0 >= P.w) return;
+    int v[4][3];
+    uint32_t macc = 0, decided = 0;  // per pixel byte: OR of the masks / 0xff once a value is chosen
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j][0] = v[j][1] = v[j][2] = 0;
+    for (int i = P.n - 1; i >= 0; i--) {
+        const NoImg& im = P.imgs[i];
+        // wave-uniform rejection
+        if (y < im.y || y >= im.y + im.h || xw0 + 256 <= im.x || xw0 >= im.x + im.w) continue;
+        if (P.all_binary && __builtin_amdgcn_ballot_w64(decided != 0xffffffffu && x4 < P.w) == 0) break;  // every pixel of the wavefront has its value and 255
+        const int lx = x4 - im.x, ly = y - im.y;
+        if (lx + 3 < 0 || lx >= im.w) continue;
+        const uint8_t* mrow = im.mask + (long long)ly * im.mstride;
+        uint32_t m4;
+        const bool quad = lx >= 0 && lx + 3 < im.w;
+        if (quad) m4 = ld_u32_unaligned(mrow + lx);
+        else {
+            m4 = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (lx + j >= 0 && lx + j < im.w) m4 |= (uint32_t)mrow[lx + j] << (8 * j);
+        }
+        macc |= m4;
+        // bytes of pixels this image gives their value: mask != 0 and not decided yet
+        uint32_t nz = (m4 | (m4 >> 4)) & 0x0f0f0f0fu; nz = (nz | (nz >> 2)) & 0x03030303u; nz = (nz | (nz >> 1)) & 0x01010101u;
+        const uint32_t take = (nz * 255u) & ~decided;
+        if (take) {
+            if (im.is_s16) {
+                const short* irow = reinterpret_cast<const short*>(im.img + (long long)ly * im.istride);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if ((take >> (8 * j)) & 1u) { v[j][0] = irow[(lx + j) * 3]; v[j][1] = irow[(lx + j) * 3 + 1]; v[j][2] = irow[(lx + j) * 3 + 2]; }
+            } else {
+                const uint8_t* irow = im.img + (long long)ly * im.istride;
+                if (quad) {
+                    const uint32_t w0 = ld_u32_unaligned(irow + lx * 3), w1 = ld_u32_unaligned(irow + lx * 3 + 4), w2 = ld_u32_unaligned(irow + lx * 3 + 8);
+                    const uint32_t w[3] = {w0, w1, w2};
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if ((take >> (8 * j)) & 1u) {
+#pragma unroll
+                            for (int c = 0; c < 3; c++) v[j][c] = (int)((w[(3 * j + c) >> 2] >> (8 * ((3 * j + c) & 3))) & 255u);
+                        }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if ((take >> (8 * j)) & 1u) { v[j][0] = irow[(lx + j) * 3]; v[j][1] = irow[(lx + j) * 3 + 1]; v[j][2] = irow[(lx + j) * 3 + 2]; }
+                }
+            }
+            decided |= take;
+        }
+    }
+    if (x4 >= P.w) return;
+    // Blender::blend zeroes where dst_mask == 0 (those pixels never took a value: v is 0 already); convertScaleAbs
+    uint32_t o[3] = {0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) o[(3 * j + c) >> 2] |= (uint32_t)min(abs(v[j][c]), 255) << (8 * ((3 * j + c) & 3));
+    uint8_t* po = P.pano + (long long)y * P.pano_stride + (long long)x4 * 3;
+    uint8_t* pm = P.pmask + (long long)y * P.pmask_stride + x4;
+    if (x4 + 4 <= P.w) {
+        reinterpret_cast<uint32_t*>(po)[0] = o[0]; reinterpret_cast<uint32_t*>(po)[1] = o[1]; reinterpret_cast<uint32_t*>(po)[2] = o[2];
+        *reinterpret_cast<uint32_t*>(pm) = macc;
+    } else {
+        for (int j = 0; x4 + j < P.w; j++) {
+            for (int c = 0; c < 3; c++) po[3 * j + c] = (uint8_t)(o[(3 * j + c) >> 2] >> (8 * ((3 * j + c) & 3)));
+            pm[j] = (uint8_t)(macc >> (8 * j));
+        }
+    }
+    if (WITH16) {
+        short* p16 = reinterpret_cast<short*>(reinterpret_cast<uint8_t*>(P.pano16) + (long long)y * P.pano16_stride) + (long long)x4 * 3;
+        for (int j = 0; j < 4 && x4 + j < P.w; j++)
+            for (int c = 0; c < 3; c++) p16[3 * j + c] = (short)v[j][c];
+    }
+}
+}  // namespace
+
+int stx_launch_no_gather(stx_ctx* ctx, const NoGatherK& K, double algo_bytes)
+{
+    StxProfScope prof(ctx, "no_gather", algo_bytes);
+    const dim3 grid((K.w + 255) / 256, (K.h + 3) / 4);
+    if (K.pano16) hipLaunchKernelGGL(no_gather_kernel<true>, grid, dim3(256), 0, ctx->stream, K);
+    else hipLaunchKernelGGL(no_gather_kernel<false>, grid, dim3(256), 0, ctx->stream, K);
+    return check_launch("no_gather");
+}
+
+// ---------------------------------------------------------------------------------------------
 // "next" rows of the scope table: consumers / producers either side of the path
 // ---------------------------------------------------------------------------------------------
 namespace {

@@ -169,6 +169,15 @@ int stx_launch_resize_exact(stx_ctx* ctx, const stx_buf* src, stx_buf* dst, cons
 int stx_launch_strip_pack(stx_ctx* ctx, int n, const stx_buf* const* imgs, const stx_buf* const* masks, const int* x0, const int* w,
                           stx_buf* const* dsts, const size_t* si, const size_t* sm);
 
+// "no" blender as a deferred gather: device table of the fed images, in feed order
+struct NoImg { const uint8_t* img; long long istride; const uint8_t* mask; long long mstride; int is_s16; int x, y, w, h; int pad; };
+struct NoGatherK {
+    const NoImg* imgs; int n; int all_binary;  // all_binary: every mask holds only 0 / 255
+    int w, h;
+    uint8_t* pano; long long pano_stride; uint8_t* pmask; long long pmask_stride; short* pano16; long long pano16_stride;
+};
+int stx_launch_no_gather(stx_ctx* ctx, const NoGatherK& K, double algo_bytes);
+
 // simple blenders --------------------------------------------------------------------------------
 int stx_launch_no_feed(stx_ctx* ctx, const stx_buf* img, const stx_buf* mask, short* dst, long long dst_stride,
                        uint8_t* dmask, long long dmask_stride, int dx, int dy);
