@@ -1068,10 +1068,8 @@ struct stx_blender {
     int next_order = 0;
     // no: deferred gather over the fed images (stx_launch_no_gather)
     std::vector<NoImg> no_images;
-    // feather (accumulate per feed, as OpenCV)
-    void* dst = nullptr; long long dst_stride = 0;      // s16 HWC
-    void* dmask = nullptr; long long dmask_stride = 0;  // u8
-    void* dw = nullptr; long long dw_stride = 0;        // f32
+    // feather: deferred gather as well (stx_launch_feather_weights / _gather)
+    std::vector<FeatherImg> feather_images;
 };
 
 static void blender_release(stx_blender* b)
@@ -1080,12 +1078,10 @@ static void blender_release(stx_blender* b)
     b->held.clear();
     for (void* p : b->pyr_allocs) stx_dev_free(b->ctx, p);
     b->pyr_allocs.clear();
-    stx_dev_free(b->ctx, b->dst); b->dst = nullptr;
-    stx_dev_free(b->ctx, b->dmask); b->dmask = nullptr;
-    stx_dev_free(b->ctx, b->dw); b->dw = nullptr;
     b->images.clear();
     b->built.clear();
     b->no_images.clear();
+    b->feather_images.clear();
 }
 
 STX_EXPORT int stx_blend_create(stx_ctx* ctx, int kind, int num_bands, float sharpness, const int roi_xywh[4],
@@ -1116,21 +1112,6 @@ STX_EXPORT int stx_blend_create(stx_ctx* ctx, int kind, int num_bands, float sha
     }
     b->rx = roi_xywh[0]; b->ry = roi_xywh[1]; b->rw = w; b->rh = h;
     b->band_x0 = 0; b->band_x1 = b->fw;
-    if (kind == STX_BLEND_FEATHER) {
-        b->dst_stride = (long long)align_up((size_t)w * 6, 64);
-        b->dmask_stride = (long long)align_up((size_t)w, 64);
-        STX_TRY(stx_dev_alloc(ctx, (size_t)b->dst_stride * h, &b->dst));
-        int rc = stx_dev_alloc(ctx, (size_t)b->dmask_stride * h, &b->dmask);
-        if (rc == STX_OK && kind == STX_BLEND_FEATHER) {
-            b->dw_stride = (long long)align_up((size_t)w * 4, 64);
-            rc = stx_dev_alloc(ctx, (size_t)b->dw_stride * h, &b->dw);
-        }
-        if (rc != STX_OK) { blender_release(b.get()); return rc; }
-        hipError_t e = hipMemsetAsync(b->dst, 0, (size_t)b->dst_stride * h, ctx->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(b->dmask, 0, (size_t)b->dmask_stride * h, ctx->stream);
-        if (e == hipSuccess && b->dw) e = hipMemsetAsync(b->dw, 0, (size_t)b->dw_stride * h, ctx->stream);
-        if (e != hipSuccess) { blender_release(b.get()); return stx_fail(STX_ERR_HIP, "memset: %s", hipGetErrorString(e)); }
-    }
     *out = b.release();
     return STX_OK;
 }
@@ -1359,8 +1340,27 @@ STX_EXPORT int stx_blend_feed_ex(stx_blender* b, const stx_buf* img, const stx_b
         b->held.push_back(const_cast<stx_buf*>(mask));
         return STX_OK;
     }
-    return stx_launch_feather_feed(b->ctx, img, mask, b->sharpness, (short*)b->dst, b->dst_stride, (float*)b->dw,
-                                   b->dw_stride, tlx - b->rx, tly - b->ry);
+    // feather, deferred: the image joins the table; distance transforms, weights and the gather run in blend()
+    FeatherImg im;
+    memset(&im, 0, sizeof(im));
+    im.img = img->ptr; im.istride = (long long)img->stride; im.is_s16 = img->elem == STX_S16;
+    im.mask = mask->ptr; im.mstride = (long long)mask->stride;
+    im.x = tlx - b->rx; im.y = tly - b->ry; im.w = img->w; im.h = img->h;
+    im.dstride = ((long long)img->w + 15) & ~15ll;
+    im.n_chunks = (img->h + STX_DT_RC - 1) / STX_DT_RC;
+    void *wm = nullptr, *summ = nullptr;
+    STX_TRY(stx_dev_alloc(b->ctx, sizeof(float) * (size_t)im.dstride * img->h, &wm));
+    b->pyr_allocs.push_back(wm);
+    STX_TRY(stx_dev_alloc(b->ctx, sizeof(int) * 2 * (size_t)im.dstride * im.n_chunks, &summ));
+    b->pyr_allocs.push_back(summ);
+    im.wmap = (float*)wm;
+    im.first = (int*)summ; im.last = im.first + (size_t)im.dstride * im.n_chunks;
+    b->feather_images.push_back(im);
+    stx_buf_retain(const_cast<stx_buf*>(img));
+    stx_buf_retain(const_cast<stx_buf*>(mask));
+    b->held.push_back(const_cast<stx_buf*>(img));
+    b->held.push_back(const_cast<stx_buf*>(mask));
+    return STX_OK;
 }
 
 STX_EXPORT int stx_blend_feed(stx_blender* b, const stx_buf* img, const stx_buf* mask, int tlx, int tly)
@@ -1729,6 +1729,24 @@ STX_EXPORT int stx_blend_feed_contrib_ex(stx_blender* b, int order, const int re
     return STX_OK;
 }
 
+// FeatherBlender::blend: weights of all fed images (batched distance transforms), then one gather over the panorama
+static int feather_finish(stx_blender* b, stx_buf* pano, stx_buf* pmask, stx_buf* p16)
+{
+    stx_ctx* ctx = b->ctx;
+    const int n = (int)b->feather_images.size();
+    void* d_tab = nullptr;
+    STX_TRY(upload_small(ctx, b->feather_images.data(), sizeof(FeatherImg) * (size_t)n, &d_tab));
+    b->pyr_allocs.push_back(d_tab);
+    STX_TRY(stx_launch_feather_weights(ctx, (const FeatherImg*)d_tab, b->feather_images.data(), n, b->sharpness));
+    double bytes = 4.0 * pano->w * pano->h + (p16 ? 6.0 * pano->w * pano->h : 0.0);
+    for (const FeatherImg& im : b->feather_images) bytes += (double)im.w * im.h * ((im.is_s16 ? 6 : 3) + 4);
+    FeatherGatherK K;
+    K.imgs = (const FeatherImg*)d_tab; K.n = n; K.w = pano->w; K.h = pano->h;
+    K.pano = pano->ptr; K.pano_stride = (long long)pano->stride; K.pmask = pmask->ptr; K.pmask_stride = (long long)pmask->stride;
+    K.pano16 = p16 ? (short*)p16->ptr : nullptr; K.pano16_stride = p16 ? (long long)p16->stride : 0;
+    return stx_launch_feather_gather(ctx, K, bytes);
+}
+
 // Blender::blend of the "no" blender: one gather over the panorama (stx_blend.hip: no_gather_kernel)
 static int no_finish(stx_blender* b, stx_buf* pano, stx_buf* pmask, stx_buf* p16)
 {
@@ -1783,16 +1801,7 @@ STX_EXPORT int stx_blend_finish_ex(stx_blender* b, stx_buf** out_pano_u8, stx_bu
     if (rc == STX_OK) {
         if (b->kind == STX_BLEND_MULTIBAND) rc = mb_finish(b, pano, pmask, p16);
         else if (b->kind == STX_BLEND_NO) rc = no_finish(b, pano, pmask, p16);
-        else
-            rc = stx_launch_simple_finish(ctx, b->kind, (short*)b->dst, b->dst_stride, (const float*)b->dw, b->dw_stride,
-                                          (uint8_t*)b->dmask, b->dmask_stride, ow, oh, pano->ptr, (long long)pano->stride,
-                                          p16 ? (short*)p16->ptr : nullptr, p16 ? (long long)p16->stride : 0);
-    }
-    if (rc == STX_OK && b->kind == STX_BLEND_FEATHER) {
-        // hand out dst_mask_ (Blender::blend: dst_mask.assign(dst_mask_))
-        hipError_t e = hipMemcpy2DAsync(pmask->ptr, pmask->stride, b->dmask, b->dmask_stride, ow, oh,
-                                        hipMemcpyDeviceToDevice, ctx->stream);
-        if (e != hipSuccess) rc = stx_fail(STX_ERR_HIP, "mask copy: %s", hipGetErrorString(e));
+        else rc = feather_finish(b, pano, pmask, p16);
     }
     b->finished = true;
     blender_release(b);  // stream-ordered: the kernels above were enqueued before any reuse

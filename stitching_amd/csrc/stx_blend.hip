@@ -268,42 +268,6 @@ __global__ __launch_bounds__(256) void mb_level_multi_kernel(const MbLevelK* __r
 // ---------------------------------------------------------------------------------------------
 // "no" blender (base cv::detail::Blender) and feather blender
 // ---------------------------------------------------------------------------------------------
-struct SimpleFeedK {
-    const uint8_t* img; long long img_stride; int img_is_s16;
-    const uint8_t* mask; long long mask_stride;
-    int w, h, dx, dy;
-    short* dst; long long dst_stride;       // int16 HWC accumulator (bytes stride)
-    uint8_t* dmask; long long dmask_stride;
-    float* dw; long long dw_stride;         // fp32 weight accumulator (feather), bytes stride
-    const float* wmap; long long wmap_stride;  // feather weight map of this image (elements stride)
-};
-
-STX_DEV void load_src(const SimpleFeedK& P, int x, int y, int& b, int& g, int& r)
-{
-    if (P.img_is_s16) {
-        const short* p = reinterpret_cast<const short*>(P.img + (long long)y * P.img_stride) + x * 3;
-        b = p[0]; g = p[1]; r = p[2];
-    } else {
-        const uint8_t* p = P.img + (long long)y * P.img_stride + x * 3;
-        b = p[0]; g = p[1]; r = p[2];
-    }
-}
-
-// Blender::feed: dst = src where mask; dst_mask |= mask
-__global__ __launch_bounds__(256) void no_feed_kernel(SimpleFeedK P)
-{
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= P.w || y >= P.h) return;
-    uint8_t m = P.mask[(long long)y * P.mask_stride + x];
-    if (!m) return;
-    int b, g, r;
-    load_src(P, x, y, b, g, r);
-    short* d = reinterpret_cast<short*>(reinterpret_cast<uint8_t*>(P.dst) + (long long)(y + P.dy) * P.dst_stride) + (x + P.dx) * 3;
-    d[0] = (short)b; d[1] = (short)g; d[2] = (short)r;
-    P.dmask[(long long)(y + P.dy) * P.dmask_stride + x + P.dx] |= m;
-}
-
 // distanceTransform(mask, DIST_L1, 3): exact city-block distance to the nearest zero pixel, as two separable passes
 // that are plain prefix / suffix minima and therefore parallel:
 //   columns: g(x, y) = min(y - last zero row <= y, first zero row >= y - y), INF when the column has no zero.
@@ -316,43 +280,7 @@ __global__ __launch_bounds__(256) void no_feed_kernel(SimpleFeedK P)
 //            (distanceTransform_3x3's 16.16 fixed point saturates at INT_MAX >> 2, i.e. 8192.0f).
 // Same integers as the serial recurrences cur = min(v, cur + 1) of the reference.
 constexpr int DT_INF = 1 << 28;
-constexpr int DT_RC = 64;
-__global__ __launch_bounds__(64) void dt_col_summary_kernel(const uint8_t* __restrict__ mask, long long mstride, int w, int h,
-                                                           int* __restrict__ first, int* __restrict__ last, long long sstride)
-{
-    const int x = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y;
-    if (x >= w) return;
-    const int y0 = c * DT_RC, y1 = min(h, y0 + DT_RC);
-    int f = DT_INF, l = -DT_INF;
-    for (int y = y0; y < y1; y++)
-        if (mask[(long long)y * mstride + x] == 0) {
-            if (f == DT_INF) f = y;
-            l = y;
-        }
-    first[(long long)c * sstride + x] = f;
-    last[(long long)c * sstride + x] = l;
-}
-__global__ __launch_bounds__(64) void dt_col_fill_kernel(const uint8_t* __restrict__ mask, long long mstride, int w, int h,
-                                                        const int* __restrict__ first, const int* __restrict__ last, long long sstride,
-                                                        int n_chunks, int* __restrict__ d, long long dstride)
-{
-    const int x = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y;
-    if (x >= w) return;
-    int prev = -DT_INF, next = DT_INF;
-    for (int k = 0; k < c; k++) prev = max(prev, last[(long long)k * sstride + x]);
-    for (int k = n_chunks - 1; k > c; k--) next = min(next, first[(long long)k * sstride + x]);
-    const int y0 = c * DT_RC, y1 = min(h, y0 + DT_RC);
-    for (int y = y0; y < y1; y++) {
-        if (mask[(long long)y * mstride + x] == 0) prev = y;
-        d[(long long)y * dstride + x] = prev == -DT_INF ? DT_INF : y - prev;
-    }
-    for (int y = y1 - 1; y >= y0; y--) {
-        const int v = d[(long long)y * dstride + x];
-        if (v == 0) next = y;
-        d[(long long)y * dstride + x] = min(v, next == DT_INF ? DT_INF : next - y);
-    }
-}
-
+constexpr int DT_RC = STX_DT_RC;
 STX_DEV int wave_excl_prefix_min(int v, int lane)  // min over lanes < lane (INT_MAX for lane 0)
 {
 #pragma unroll
@@ -372,110 +300,6 @@ STX_DEV int wave_excl_suffix_min(int v, int lane)  // min over lanes > lane
     }
     const int e = __shfl_down(v, 1);
     return lane == 63 ? 0x7fffffff : e;
-}
-
-__global__ __launch_bounds__(256) void dt_rows_kernel(int* __restrict__ d, long long dstride, int w, int h, float sharpness,
-                                                     float* __restrict__ wmap, long long wstride)
-{
-    const int lane = threadIdx.x & 63;
-    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (y >= h) return;
-    int* row = d + (long long)y * dstride;       // dstride is a multiple of 16: every 4-pixel group is 16-byte aligned
-    float* wr = wmap + (long long)y * wstride;
-    const int nseg = (w + 255) / 256;
-    int carry = 1 << 29;
-    for (int s = 0; s < nseg; s++) {             // forward: F(x) = x + min_{x' <= x} (g(x') - x')
-        const int x0 = s * 256 + lane * 4;
-        int4 g = make_int4(DT_INF, DT_INF, DT_INF, DT_INF);
-        if (x0 < w) g = *reinterpret_cast<const int4*>(row + x0);
-        int p0 = (x0 + 0 < w ? g.x : DT_INF) - (x0 + 0), p1 = (x0 + 1 < w ? g.y : DT_INF) - (x0 + 1);
-        int p2 = (x0 + 2 < w ? g.z : DT_INF) - (x0 + 2), p3 = (x0 + 3 < w ? g.w : DT_INF) - (x0 + 3);
-        p1 = min(p1, p0); p2 = min(p2, p1); p3 = min(p3, p2);
-        const int before = min(carry, wave_excl_prefix_min(p3, lane));
-        p0 = min(p0, before); p1 = min(p1, before); p2 = min(p2, before); p3 = min(p3, before);
-        if (x0 < w) *reinterpret_cast<int4*>(row + x0) = make_int4(p0 + x0, p1 + x0 + 1, p2 + x0 + 2, p3 + x0 + 3);
-        carry = __shfl(p3, 63);  // includes the old carry
-    }
-    carry = 1 << 29;
-    for (int s = nseg - 1; s >= 0; s--) {        // backward: f(x) = -x + min_{x' >= x} (F(x') + x'), then the weight
-        const int x0 = s * 256 + lane * 4;
-        int4 g = make_int4(DT_INF, DT_INF, DT_INF, DT_INF);
-        if (x0 < w) g = *reinterpret_cast<const int4*>(row + x0);
-        int p0 = (x0 + 0 < w ? g.x : DT_INF) + (x0 + 0), p1 = (x0 + 1 < w ? g.y : DT_INF) + (x0 + 1);
-        int p2 = (x0 + 2 < w ? g.z : DT_INF) + (x0 + 2), p3 = (x0 + 3 < w ? g.w : DT_INF) + (x0 + 3);
-        p2 = min(p2, p3); p1 = min(p1, p2); p0 = min(p0, p1);
-        const int after = min(carry, wave_excl_suffix_min(p0, lane));
-        p0 = min(p0, after); p1 = min(p1, after); p2 = min(p2, after); p3 = min(p3, after);
-        carry = __shfl(p0, 0);
-        if (x0 < w) {
-            const int f[4] = {p0 - x0, p1 - (x0 + 1), p2 - (x0 + 2), p3 - (x0 + 3)};
-            float o[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float dist = f[j] >= 8192 ? 8192.f : (float)f[j];
-                const float t = fmul(dist, sharpness);
-                o[j] = t > 1.f ? 1.f : t;
-            }
-            *reinterpret_cast<float4*>(wr + x0) = make_float4(o[0], o[1], o[2], o[3]);
-        }
-    }
-}
-
-// FeatherBlender::feed: dst += (short)(src * w); dst_weight += w
-__global__ __launch_bounds__(256) void feather_feed_kernel(SimpleFeedK P)
-{
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= P.w || y >= P.h) return;
-    const float w = P.wmap[(long long)y * P.wmap_stride + x];
-    int b, g, r;
-    load_src(P, x, y, b, g, r);
-    short* d = reinterpret_cast<short*>(reinterpret_cast<uint8_t*>(P.dst) + (long long)(y + P.dy) * P.dst_stride) + (x + P.dx) * 3;
-    d[0] = (short)(d[0] + trunc_s16(fmul((float)b, w)));
-    d[1] = (short)(d[1] + trunc_s16(fmul((float)g, w)));
-    d[2] = (short)(d[2] + trunc_s16(fmul((float)r, w)));
-    float* dw = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(P.dw) + (long long)(y + P.dy) * P.dw_stride) + x + P.dx;
-    *dw = fadd(*dw, w);
-}
-
-struct SimpleFinishK {
-    int kind, w, h;
-    short* dst; long long dst_stride;
-    const float* dw; long long dw_stride;
-    uint8_t* dmask; long long dmask_stride;
-    uint8_t* pano; long long pano_stride;
-    short* pano16; long long pano16_stride;
-};
-// FeatherBlender::blend (normalizeUsingWeightMap, compare GT) / Blender::blend (zero outside mask),
-// then convertScaleAbs
-__global__ __launch_bounds__(256) void simple_finish_kernel(SimpleFinishK P)
-{
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= P.w || y >= P.h) return;
-    short* d = reinterpret_cast<short*>(reinterpret_cast<uint8_t*>(P.dst) + (long long)y * P.dst_stride) + x * 3;
-    int v[3] = {d[0], d[1], d[2]};
-    uint8_t m;
-    if (P.kind == STX_BLEND_FEATHER) {
-        const float ws = *(reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(P.dw) + (long long)y * P.dw_stride) + x);
-        const float den = fadd(ws, WEIGHT_EPS);
-        v[0] = trunc_s16(fdiv((float)v[0], den));
-        v[1] = trunc_s16(fdiv((float)v[1], den));
-        v[2] = trunc_s16(fdiv((float)v[2], den));
-        m = ws > WEIGHT_EPS ? 255 : 0;
-        P.dmask[(long long)y * P.dmask_stride + x] = m;
-    } else {
-        m = P.dmask[(long long)y * P.dmask_stride + x];
-    }
-    if (!m) v[0] = v[1] = v[2] = 0;
-    uint8_t* o = P.pano + (long long)y * P.pano_stride + x * 3;
-    o[0] = (uint8_t)min(abs(v[0]), 255);
-    o[1] = (uint8_t)min(abs(v[1]), 255);
-    o[2] = (uint8_t)min(abs(v[2]), 255);
-    if (P.pano16) {
-        short* o16 = reinterpret_cast<short*>(reinterpret_cast<uint8_t*>(P.pano16) + (long long)y * P.pano16_stride) + x * 3;
-        o16[0] = (short)v[0]; o16[1] = (short)v[1]; o16[2] = (short)v[2];
-    }
 }
 
 int check_launch(const char* what)
@@ -558,84 +382,184 @@ int stx_launch_mb_emit_batch(stx_ctx* ctx, const MbLevelK* d_Ks, const MbLevelK*
     return check_launch("mb_contrib");
 }
 
-static void fill_feed(SimpleFeedK& K, const stx_buf* img, const stx_buf* mask, int dx, int dy)
+// ---------------------------------------------------------------------------------------------
+// Feather blender as a deferred gather.  FeatherBlender::feed: weight = min(distanceTransform(mask, L1, 3) * sharpness, 1);
+// dst += (short)(src * weight); dst_weight += weight.  blend: dst = (short)(dst / (dst_weight + 1e-5)), mask = weight sum >
+// 1e-5, zero outside, then convertScaleAbs.  Fed images stay resident; at blend() the distance transforms of ALL images run
+// as three launches (blockIdx.z = image; the two column kernels and the row kernel above, same integers), the weight map
+// replaces the distances in place, and one pass over the panorama adds the products of the covering images in feed order
+// (int16 wrap-around adds, fp32 weight sums in OpenCV's += order), normalises and writes the u8 panorama once.  The int16 /
+// fp32 accumulators of OpenCV (10 bytes per panorama pixel, read-modify-written per image) never exist.
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(64) void dt_col_summary_batch_kernel(const FeatherImg* __restrict__ imgs)
 {
-    K.img = img->ptr; K.img_stride = (long long)img->stride; K.img_is_s16 = img->elem == STX_S16;
-    K.mask = mask->ptr; K.mask_stride = (long long)mask->stride;
-    K.w = img->w; K.h = img->h; K.dx = dx; K.dy = dy;
-    K.dst = nullptr; K.dst_stride = 0; K.dmask = nullptr; K.dmask_stride = 0;
-    K.dw = nullptr; K.dw_stride = 0; K.wmap = nullptr; K.wmap_stride = 0;
+    const FeatherImg& P = imgs[blockIdx.z];
+    const int x = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y;
+    if (x >= P.w || c >= P.n_chunks) return;
+    const int y0 = c * DT_RC, y1 = min(P.h, y0 + DT_RC);
+    int f = DT_INF, l = -DT_INF;
+    for (int y = y0; y < y1; y++)
+        if (P.mask[(long long)y * P.mstride + x] == 0) {
+            if (f == DT_INF) f = y;
+            l = y;
+        }
+    P.first[(long long)c * P.dstride + x] = f;
+    P.last[(long long)c * P.dstride + x] = l;
+}
+__global__ __launch_bounds__(64) void dt_col_fill_batch_kernel(const FeatherImg* __restrict__ imgs)
+{
+    const FeatherImg& P = imgs[blockIdx.z];
+    const int x = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y;
+    if (x >= P.w || c >= P.n_chunks) return;
+    int* d = reinterpret_cast<int*>(P.wmap);
+    int prev = -DT_INF, next = DT_INF;
+    for (int k = 0; k < c; k++) prev = max(prev, P.last[(long long)k * P.dstride + x]);
+    for (int k = P.n_chunks - 1; k > c; k--) next = min(next, P.first[(long long)k * P.dstride + x]);
+    const int y0 = c * DT_RC, y1 = min(P.h, y0 + DT_RC);
+    for (int y = y0; y < y1; y++) {
+        if (P.mask[(long long)y * P.mstride + x] == 0) prev = y;
+        d[(long long)y * P.dstride + x] = prev == -DT_INF ? DT_INF : y - prev;
+    }
+    for (int y = y1 - 1; y >= y0; y--) {
+        const int v = d[(long long)y * P.dstride + x];
+        if (v == 0) next = y;
+        d[(long long)y * P.dstride + x] = min(v, next == DT_INF ? DT_INF : next - y);
+    }
+}
+// rows: the row kernel above with the weights written over the distances (a lane reads its 4-pixel group before it writes it)
+__global__ __launch_bounds__(256) void dt_rows_batch_kernel(const FeatherImg* __restrict__ imgs, float sharpness)
+{
+    const FeatherImg& P = imgs[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (y >= P.h) return;
+    const int w = P.w;
+    int* row = reinterpret_cast<int*>(P.wmap) + (long long)y * P.dstride;
+    float* wr = P.wmap + (long long)y * P.dstride;
+    const int nseg = (w + 255) / 256;
+    int carry = 1 << 29;
+    for (int s = 0; s < nseg; s++) {
+        const int x0 = s * 256 + lane * 4;
+        int4 g = make_int4(DT_INF, DT_INF, DT_INF, DT_INF);
+        if (x0 < w) g = *reinterpret_cast<const int4*>(row + x0);
+        int p0 = (x0 + 0 < w ? g.x : DT_INF) - (x0 + 0), p1 = (x0 + 1 < w ? g.y : DT_INF) - (x0 + 1);
+        int p2 = (x0 + 2 < w ? g.z : DT_INF) - (x0 + 2), p3 = (x0 + 3 < w ? g.w : DT_INF) - (x0 + 3);
+        p1 = min(p1, p0); p2 = min(p2, p1); p3 = min(p3, p2);
+        const int before = min(carry, wave_excl_prefix_min(p3, lane));
+        p0 = min(p0, before); p1 = min(p1, before); p2 = min(p2, before); p3 = min(p3, before);
+        if (x0 < w) *reinterpret_cast<int4*>(row + x0) = make_int4(p0 + x0, p1 + x0 + 1, p2 + x0 + 2, p3 + x0 + 3);
+        carry = __shfl(p3, 63);
+    }
+    carry = 1 << 29;
+    for (int s = nseg - 1; s >= 0; s--) {
+        const int x0 = s * 256 + lane * 4;
+        int4 g = make_int4(DT_INF, DT_INF, DT_INF, DT_INF);
+        if (x0 < w) g = *reinterpret_cast<const int4*>(row + x0);
+        int p0 = (x0 + 0 < w ? g.x : DT_INF) + (x0 + 0), p1 = (x0 + 1 < w ? g.y : DT_INF) + (x0 + 1);
+        int p2 = (x0 + 2 < w ? g.z : DT_INF) + (x0 + 2), p3 = (x0 + 3 < w ? g.w : DT_INF) + (x0 + 3);
+        p2 = min(p2, p3); p1 = min(p1, p2); p0 = min(p0, p1);
+        const int after = min(carry, wave_excl_suffix_min(p0, lane));
+        p0 = min(p0, after); p1 = min(p1, after); p2 = min(p2, after); p3 = min(p3, after);
+        carry = __shfl(p0, 0);
+        if (x0 < w) {
+            const int f[4] = {p0 - x0, p1 - (x0 + 1), p2 - (x0 + 2), p3 - (x0 + 3)};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float dist = f[j] >= 8192 ? 8192.f : (float)f[j];
+                const float t = fmul(dist, sharpness);
+                o[j] = t > 1.f ? 1.f : t;
+            }
+            *reinterpret_cast<float4*>(wr + x0) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
 }
 
-int stx_launch_no_feed(stx_ctx* ctx, const stx_buf* img, const stx_buf* mask, short* dst, long long dst_stride,
-                       uint8_t* dmask, long long dmask_stride, int dx, int dy)
+template <bool WITH16>
+__global__ __launch_bounds__(256) void feather_gather_kernel(FeatherGatherK P)
 {
-    SimpleFeedK K;
-    fill_feed(K, img, mask, dx, dy);
-    K.dst = dst; K.dst_stride = dst_stride; K.dmask = dmask; K.dmask_stride = dmask_stride;
-    double px = (double)img->w * img->h;
-    StxProfScope prof(ctx, "no_feed", px * ((K.img_is_s16 ? 6 : 3) + 1 + 6 + 2));
-    hipLaunchKernelGGL(no_feed_kernel, grid64x4(img->w, img->h), dim3(256), 0, ctx->stream, K);
-    return check_launch("no_feed");
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xw0 = blockIdx.x * 256;
+    if (y >= P.h || xw0 >= P.w) return;
+    int acc[4][3];
+    float ws[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[j][0] = acc[j][1] = acc[j][2] = 0;
+    for (int i = 0; i < P.n; i++) {  // ascending feed order: the order of OpenCV's += on the fp32 weights
+        const FeatherImg& im = P.imgs[i];
+        if (y < im.y || y >= im.y + im.h || xw0 + 256 <= im.x || xw0 >= im.x + im.w) continue;  // wave-uniform
+        const int lx = x4 - im.x, ly = y - im.y;
+        if (lx + 3 < 0 || lx >= im.w) continue;
+        const float* wrow = im.wmap + (long long)ly * im.dstride;
+        const uint8_t* irow = im.img + (long long)ly * im.istride;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (lx + j < 0 || lx + j >= im.w) continue;
+            const float w = wrow[lx + j];
+            int b, g, r;
+            if (im.is_s16) {
+                const short* p = reinterpret_cast<const short*>(irow) + (lx + j) * 3;
+                b = p[0]; g = p[1]; r = p[2];
+            } else {
+                const uint8_t* p = irow + (lx + j) * 3;
+                b = p[0]; g = p[1]; r = p[2];
+            }
+            acc[j][0] = (short)(acc[j][0] + trunc_s16(fmul((float)b, w)));
+            acc[j][1] = (short)(acc[j][1] + trunc_s16(fmul((float)g, w)));
+            acc[j][2] = (short)(acc[j][2] + trunc_s16(fmul((float)r, w)));
+            ws[j] = fadd(ws[j], w);
+        }
+    }
+    if (x4 >= P.w) return;
+    uint8_t* po = P.pano + (long long)y * P.pano_stride + (long long)x4 * 3;
+    uint8_t* pm = P.pmask + (long long)y * P.pmask_stride + x4;
+    for (int j = 0; j < 4 && x4 + j < P.w; j++) {
+        const float den = fadd(ws[j], WEIGHT_EPS);
+        const bool in = ws[j] > WEIGHT_EPS;
+        int v[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) v[c] = in ? trunc_s16(fdiv((float)acc[j][c], den)) : 0;
+        po[3 * j] = (uint8_t)min(abs(v[0]), 255); po[3 * j + 1] = (uint8_t)min(abs(v[1]), 255); po[3 * j + 2] = (uint8_t)min(abs(v[2]), 255);
+        pm[j] = in ? 255 : 0;
+        if (WITH16) {
+            short* p16 = reinterpret_cast<short*>(reinterpret_cast<uint8_t*>(P.pano16) + (long long)y * P.pano16_stride) + (long long)(x4 + j) * 3;
+            p16[0] = (short)v[0]; p16[1] = (short)v[1]; p16[2] = (short)v[2];
+        }
+    }
 }
+}  // namespace
 
-int stx_launch_feather_feed(stx_ctx* ctx, const stx_buf* img, const stx_buf* mask, float sharpness, short* dst,
-                            long long dst_stride, float* dw, long long dw_stride, int dx, int dy)
+// distance transforms + weight maps of n fed images (device table d_imgs, host copy h_imgs for the grid sizes)
+int stx_launch_feather_weights(stx_ctx* ctx, const FeatherImg* d_imgs, const FeatherImg* h_imgs, int n, float sharpness)
 {
-    const int w = img->w, h = img->h;
-    const long long dstride = (w + 15) & ~15;
-    void* dist = nullptr;
-    void* wmap = nullptr;
-    STX_TRY(stx_dev_alloc(ctx, sizeof(int) * dstride * h, &dist));
-    int rc = stx_dev_alloc(ctx, sizeof(float) * dstride * h, &wmap);
-    if (rc != STX_OK) { stx_dev_free(ctx, dist); return rc; }
-    double px = (double)w * h;
-    const int n_chunks = (h + DT_RC - 1) / DT_RC;
-    void* summ = nullptr;
-    rc = stx_dev_alloc(ctx, sizeof(int) * 2 * (size_t)dstride * n_chunks, &summ);
-    if (rc != STX_OK) { stx_dev_free(ctx, dist); stx_dev_free(ctx, wmap); return rc; }
-    int* first = (int*)summ;
-    int* last = first + (size_t)dstride * n_chunks;
+    if (n <= 0) return STX_OK;
+    int max_w = 0, max_h = 0, max_chunks = 0;
+    double px = 0.0;
+    for (int i = 0; i < n; i++) {
+        max_w = std::max(max_w, h_imgs[i].w); max_h = std::max(max_h, h_imgs[i].h); max_chunks = std::max(max_chunks, h_imgs[i].n_chunks);
+        px += (double)h_imgs[i].w * h_imgs[i].h;
+    }
     {
         StxProfScope prof(ctx, "feather_dt_cols", px * (1 + 1 + 4 + 4));
-        hipLaunchKernelGGL(dt_col_summary_kernel, dim3((w + 63) / 64, n_chunks), dim3(64), 0, ctx->stream, mask->ptr,
-                           (long long)mask->stride, w, h, first, last, dstride);
-        hipLaunchKernelGGL(dt_col_fill_kernel, dim3((w + 63) / 64, n_chunks), dim3(64), 0, ctx->stream, mask->ptr,
-                           (long long)mask->stride, w, h, (const int*)first, (const int*)last, dstride, n_chunks, (int*)dist, dstride);
+        hipLaunchKernelGGL(dt_col_summary_batch_kernel, dim3((max_w + 63) / 64, max_chunks, n), dim3(64), 0, ctx->stream, d_imgs);
+        hipLaunchKernelGGL(dt_col_fill_batch_kernel, dim3((max_w + 63) / 64, max_chunks, n), dim3(64), 0, ctx->stream, d_imgs);
     }
     {
         StxProfScope prof(ctx, "feather_dt_rows", px * (4 + 4 + 4 + 4));
-        hipLaunchKernelGGL(dt_rows_kernel, dim3((h + 3) / 4), dim3(256), 0, ctx->stream, (int*)dist, dstride, w, h,
-                           sharpness, (float*)wmap, dstride);
+        hipLaunchKernelGGL(dt_rows_batch_kernel, dim3((max_h + 3) / 4, n), dim3(256), 0, ctx->stream, d_imgs, sharpness);
     }
-    stx_dev_free(ctx, summ);
-    SimpleFeedK K;
-    fill_feed(K, img, mask, dx, dy);
-    K.dst = dst; K.dst_stride = dst_stride; K.dw = dw; K.dw_stride = dw_stride;
-    K.wmap = (const float*)wmap; K.wmap_stride = dstride;
-    {
-        StxProfScope prof(ctx, "feather_feed", px * ((K.img_is_s16 ? 6 : 3) + 4 + 12 + 8));
-        hipLaunchKernelGGL(feather_feed_kernel, grid64x4(w, h), dim3(256), 0, ctx->stream, K);
-    }
-    rc = check_launch("feather_feed");
-    stx_dev_free(ctx, dist);  // stream-ordered reuse: later kernels on this stream run after the ones above
-    stx_dev_free(ctx, wmap);
-    return rc;
+    return check_launch("feather_weights");
 }
 
-int stx_launch_simple_finish(stx_ctx* ctx, int kind, short* dst, long long dst_stride, const float* dw,
-                             long long dw_stride, uint8_t* dmask, long long dmask_stride, int w, int h, uint8_t* pano,
-                             long long pano_stride, short* pano16, long long pano16_stride)
+int stx_launch_feather_gather(stx_ctx* ctx, const FeatherGatherK& K, double algo_bytes)
 {
-    SimpleFinishK K;
-    K.kind = kind; K.w = w; K.h = h;
-    K.dst = dst; K.dst_stride = dst_stride; K.dw = dw; K.dw_stride = dw_stride;
-    K.dmask = dmask; K.dmask_stride = dmask_stride; K.pano = pano; K.pano_stride = pano_stride;
-    K.pano16 = pano16; K.pano16_stride = pano16_stride;
-    double px = (double)w * h;
-    StxProfScope prof(ctx, "simple_finish", px * (6 + (kind == STX_BLEND_FEATHER ? 4 : 1) + 3 + 1));
-    hipLaunchKernelGGL(simple_finish_kernel, grid64x4(w, h), dim3(256), 0, ctx->stream, K);
-    return check_launch("simple_finish");
+    StxProfScope prof(ctx, "feather_gather", algo_bytes);
+    const dim3 grid((K.w + 255) / 256, (K.h + 3) / 4);
+    if (K.pano16) hipLaunchKernelGGL(feather_gather_kernel<true>, grid, dim3(256), 0, ctx->stream, K);
+    else hipLaunchKernelGGL(feather_gather_kernel<false>, grid, dim3(256), 0, ctx->stream, K);
+    return check_launch("feather_gather");
 }
 
 // ---------------------------------------------------------------------------------------------

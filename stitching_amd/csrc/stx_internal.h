@@ -169,6 +169,22 @@ int stx_launch_resize_exact(stx_ctx* ctx, const stx_buf* src, stx_buf* dst, cons
 int stx_launch_strip_pack(stx_ctx* ctx, int n, const stx_buf* const* imgs, const stx_buf* const* masks, const int* x0, const int* w,
                           stx_buf* const* dsts, const size_t* si, const size_t* sm);
 
+constexpr int STX_DT_RC = 64;  // rows per chunk of the distance transform's column pass (stx_blend.hip: DT_RC)
+// feather blender as a deferred gather: device table of the fed images, in feed order
+struct FeatherImg {
+    const uint8_t* img; long long istride; int is_s16;
+    const uint8_t* mask; long long mstride;
+    int x, y, w, h;                 // rectangle inside the panorama roi
+    float* wmap; long long dstride; // weight map (the L1 distances first, in place), elements per row (multiple of 16)
+    int* first; int* last; int n_chunks;  // column-pass summaries (DT_RC rows per chunk)
+};
+struct FeatherGatherK {
+    const FeatherImg* imgs; int n; int w, h;
+    uint8_t* pano; long long pano_stride; uint8_t* pmask; long long pmask_stride; short* pano16; long long pano16_stride;
+};
+int stx_launch_feather_weights(stx_ctx* ctx, const FeatherImg* d_imgs, const FeatherImg* h_imgs, int n, float sharpness);
+int stx_launch_feather_gather(stx_ctx* ctx, const FeatherGatherK& K, double algo_bytes);
+
 // "no" blender as a deferred gather: device table of the fed images, in feed order
 struct NoImg { const uint8_t* img; long long istride; const uint8_t* mask; long long mstride; int is_s16; int x, y, w, h; int pad; };
 struct NoGatherK {
@@ -179,10 +195,4 @@ struct NoGatherK {
 int stx_launch_no_gather(stx_ctx* ctx, const NoGatherK& K, double algo_bytes);
 
 // simple blenders --------------------------------------------------------------------------------
-int stx_launch_no_feed(stx_ctx* ctx, const stx_buf* img, const stx_buf* mask, short* dst, long long dst_stride,
-                       uint8_t* dmask, long long dmask_stride, int dx, int dy);
-int stx_launch_feather_feed(stx_ctx* ctx, const stx_buf* img, const stx_buf* mask, float sharpness, short* dst,
-                            long long dst_stride, float* dw, long long dw_stride, int dx, int dy);
-int stx_launch_simple_finish(stx_ctx* ctx, int kind, short* dst, long long dst_stride, const float* dw,
-                             long long dw_stride, uint8_t* dmask, long long dmask_stride, int w, int h, uint8_t* pano,
-                             long long pano_stride, short* pano16, long long pano16_stride);
+
