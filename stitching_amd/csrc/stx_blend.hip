@@ -392,39 +392,78 @@ int stx_launch_mb_emit_batch(stx_ctx* ctx, const MbLevelK* d_Ks, const MbLevelK*
 // fp32 accumulators of OpenCV (10 bytes per panorama pixel, read-modify-written per image) never exist.
 // ---------------------------------------------------------------------------------------------
 namespace {
+STX_DEV uint32_t ld_u32_unaligned(const uint8_t* p)  // 4 bytes at any address, as two aligned dword loads
+{
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)3);
+    return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u));
+}
+
+// Column passes: a lane owns 4 adjacent columns (one mask dword per row, 16-byte stores of the distances), a workgroup
+// of 64 lanes 256 columns of one chunk of DT_RC rows.  Columns >= w inside the last group are computed on whatever the
+// row padding holds and land in the padding of the distance rows (dstride is a multiple of 16), where nothing reads them.
+STX_DEV uint32_t dt_mask4(const FeatherImg& P, int x, int y)
+{
+    const uint8_t* p = P.mask + (long long)y * P.mstride + x;
+    if ((reinterpret_cast<uintptr_t>(p) & 3u) == 0) return *reinterpret_cast<const uint32_t*>(p);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)3);
+    return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u));
+}
 __global__ __launch_bounds__(64) void dt_col_summary_batch_kernel(const FeatherImg* __restrict__ imgs)
 {
     const FeatherImg& P = imgs[blockIdx.z];
-    const int x = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y;
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4, c = blockIdx.y;
     if (x >= P.w || c >= P.n_chunks) return;
     const int y0 = c * DT_RC, y1 = min(P.h, y0 + DT_RC);
-    int f = DT_INF, l = -DT_INF;
-    for (int y = y0; y < y1; y++)
-        if (P.mask[(long long)y * P.mstride + x] == 0) {
-            if (f == DT_INF) f = y;
-            l = y;
-        }
-    P.first[(long long)c * P.dstride + x] = f;
-    P.last[(long long)c * P.dstride + x] = l;
+    int f[4] = {DT_INF, DT_INF, DT_INF, DT_INF}, l[4] = {-DT_INF, -DT_INF, -DT_INF, -DT_INF};
+    for (int y = y0; y < y1; y++) {
+        const uint32_t m = dt_mask4(P, x, y);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (((m >> (8 * j)) & 255u) == 0) {
+                if (f[j] == DT_INF) f[j] = y;
+                l[j] = y;
+            }
+    }
+    *reinterpret_cast<int4*>(P.first + (long long)c * P.dstride + x) = make_int4(f[0], f[1], f[2], f[3]);
+    *reinterpret_cast<int4*>(P.last + (long long)c * P.dstride + x) = make_int4(l[0], l[1], l[2], l[3]);
 }
 __global__ __launch_bounds__(64) void dt_col_fill_batch_kernel(const FeatherImg* __restrict__ imgs)
 {
     const FeatherImg& P = imgs[blockIdx.z];
-    const int x = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y;
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4, c = blockIdx.y;
     if (x >= P.w || c >= P.n_chunks) return;
     int* d = reinterpret_cast<int*>(P.wmap);
-    int prev = -DT_INF, next = DT_INF;
-    for (int k = 0; k < c; k++) prev = max(prev, P.last[(long long)k * P.dstride + x]);
-    for (int k = P.n_chunks - 1; k > c; k--) next = min(next, P.first[(long long)k * P.dstride + x]);
+    int prev[4] = {-DT_INF, -DT_INF, -DT_INF, -DT_INF}, next[4] = {DT_INF, DT_INF, DT_INF, DT_INF};
+    for (int k = 0; k < c; k++) {
+        const int4 v = *reinterpret_cast<const int4*>(P.last + (long long)k * P.dstride + x);
+        prev[0] = max(prev[0], v.x); prev[1] = max(prev[1], v.y); prev[2] = max(prev[2], v.z); prev[3] = max(prev[3], v.w);
+    }
+    for (int k = P.n_chunks - 1; k > c; k--) {
+        const int4 v = *reinterpret_cast<const int4*>(P.first + (long long)k * P.dstride + x);
+        next[0] = min(next[0], v.x); next[1] = min(next[1], v.y); next[2] = min(next[2], v.z); next[3] = min(next[3], v.w);
+    }
     const int y0 = c * DT_RC, y1 = min(P.h, y0 + DT_RC);
     for (int y = y0; y < y1; y++) {
-        if (P.mask[(long long)y * P.mstride + x] == 0) prev = y;
-        d[(long long)y * P.dstride + x] = prev == -DT_INF ? DT_INF : y - prev;
+        const uint32_t m = dt_mask4(P, x, y);
+        int o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (((m >> (8 * j)) & 255u) == 0) prev[j] = y;
+            o[j] = prev[j] == -DT_INF ? DT_INF : y - prev[j];
+        }
+        *reinterpret_cast<int4*>(d + (long long)y * P.dstride + x) = make_int4(o[0], o[1], o[2], o[3]);
     }
     for (int y = y1 - 1; y >= y0; y--) {
-        const int v = d[(long long)y * P.dstride + x];
-        if (v == 0) next = y;
-        d[(long long)y * P.dstride + x] = min(v, next == DT_INF ? DT_INF : next - y);
+        int4* q = reinterpret_cast<int4*>(d + (long long)y * P.dstride + x);
+        const int4 v = *q;
+        const int vv[4] = {v.x, v.y, v.z, v.w};
+        int o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (vv[j] == 0) next[j] = y;
+            o[j] = min(vv[j], next[j] == DT_INF ? DT_INF : next[j] - y);
+        }
+        *q = make_int4(o[0], o[1], o[2], o[3]);
     }
 }
 // rows: the row kernel above with the weights written over the distances (a lane reads its 4-pixel group before it writes it)
@@ -494,6 +533,21 @@ __global__ __launch_bounds__(256) void feather_gather_kernel(FeatherGatherK P)
         if (lx + 3 < 0 || lx >= im.w) continue;
         const float* wrow = im.wmap + (long long)ly * im.dstride;
         const uint8_t* irow = im.img + (long long)ly * im.istride;
+        if (!im.is_s16 && lx >= 0 && lx + 3 < im.w) {
+            // whole group inside a u8 image: the four weights and the twelve image bytes as wide loads
+            const float w4[4] = {wrow[lx], wrow[lx + 1], wrow[lx + 2], wrow[lx + 3]};
+            const uint32_t b3[3] = {ld_u32_unaligned(irow + lx * 3), ld_u32_unaligned(irow + lx * 3 + 4), ld_u32_unaligned(irow + lx * 3 + 8)};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const int px = (int)((b3[(3 * j + c) >> 2] >> (8 * ((3 * j + c) & 3))) & 255u);
+                    acc[j][c] = (short)(acc[j][c] + trunc_s16(fmul((float)px, w4[j])));
+                }
+                ws[j] = fadd(ws[j], w4[j]);
+            }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (lx + j < 0 || lx + j >= im.w) continue;
@@ -515,17 +569,32 @@ __global__ __launch_bounds__(256) void feather_gather_kernel(FeatherGatherK P)
     if (x4 >= P.w) return;
     uint8_t* po = P.pano + (long long)y * P.pano_stride + (long long)x4 * 3;
     uint8_t* pm = P.pmask + (long long)y * P.pmask_stride + x4;
-    for (int j = 0; j < 4 && x4 + j < P.w; j++) {
+    uint32_t o[3] = {0, 0, 0}, mo = 0;
+    int vv[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
         const float den = fadd(ws[j], WEIGHT_EPS);
         const bool in = ws[j] > WEIGHT_EPS;
-        int v[3];
 #pragma unroll
-        for (int c = 0; c < 3; c++) v[c] = in ? trunc_s16(fdiv((float)acc[j][c], den)) : 0;
-        po[3 * j] = (uint8_t)min(abs(v[0]), 255); po[3 * j + 1] = (uint8_t)min(abs(v[1]), 255); po[3 * j + 2] = (uint8_t)min(abs(v[2]), 255);
-        pm[j] = in ? 255 : 0;
-        if (WITH16) {
+        for (int c = 0; c < 3; c++) {
+            vv[j][c] = in ? trunc_s16(fdiv((float)acc[j][c], den)) : 0;
+            o[(3 * j + c) >> 2] |= (uint32_t)min(abs(vv[j][c]), 255) << (8 * ((3 * j + c) & 3));
+        }
+        mo |= (in ? 255u : 0u) << (8 * j);
+    }
+    if (x4 + 4 <= P.w) {
+        reinterpret_cast<uint32_t*>(po)[0] = o[0]; reinterpret_cast<uint32_t*>(po)[1] = o[1]; reinterpret_cast<uint32_t*>(po)[2] = o[2];
+        *reinterpret_cast<uint32_t*>(pm) = mo;
+    } else {
+        for (int j = 0; x4 + j < P.w; j++) {
+            for (int c = 0; c < 3; c++) po[3 * j + c] = (uint8_t)(o[(3 * j + c) >> 2] >> (8 * ((3 * j + c) & 3)));
+            pm[j] = (uint8_t)(mo >> (8 * j));
+        }
+    }
+    if (WITH16) {
+        for (int j = 0; j < 4 && x4 + j < P.w; j++) {
             short* p16 = reinterpret_cast<short*>(reinterpret_cast<uint8_t*>(P.pano16) + (long long)y * P.pano16_stride) + (long long)(x4 + j) * 3;
-            p16[0] = (short)v[0]; p16[1] = (short)v[1]; p16[2] = (short)v[2];
+            p16[0] = (short)vv[j][0]; p16[1] = (short)vv[j][1]; p16[2] = (short)vv[j][2];
         }
     }
 }
@@ -543,8 +612,8 @@ int stx_launch_feather_weights(stx_ctx* ctx, const FeatherImg* d_imgs, const Fea
     }
     {
         StxProfScope prof(ctx, "feather_dt_cols", px * (1 + 1 + 4 + 4));
-        hipLaunchKernelGGL(dt_col_summary_batch_kernel, dim3((max_w + 63) / 64, max_chunks, n), dim3(64), 0, ctx->stream, d_imgs);
-        hipLaunchKernelGGL(dt_col_fill_batch_kernel, dim3((max_w + 63) / 64, max_chunks, n), dim3(64), 0, ctx->stream, d_imgs);
+        hipLaunchKernelGGL(dt_col_summary_batch_kernel, dim3((max_w + 255) / 256, max_chunks, n), dim3(64), 0, ctx->stream, d_imgs);
+        hipLaunchKernelGGL(dt_col_fill_batch_kernel, dim3((max_w + 255) / 256, max_chunks, n), dim3(64), 0, ctx->stream, d_imgs);
     }
     {
         StxProfScope prof(ctx, "feather_dt_rows", px * (4 + 4 + 4 + 4));
@@ -572,12 +641,6 @@ int stx_launch_feather_gather(stx_ctx* ctx, const FeatherGatherK& K, double algo
 // loads + v_alignbyte.
 // ---------------------------------------------------------------------------------------------
 namespace {
-STX_DEV uint32_t ld_u32_unaligned(const uint8_t* p)  // 4 bytes at any address, as two aligned dword loads
-{
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)3);
-    return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u));
-}
-
 template <bool WITH16>
 __global__ __launch_bounds__(256) void no_gather_kernel(NoGatherK P)
 {
