@@ -286,6 +286,9 @@ class RcclTransport:
     name = "rccl"
 
     def __init__(self, ctx, rank, world, unique_id):
+        import os
+
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # one node: every rank bootstraps over loopback (see unique_id)
         self.ctx, self.rank, self.world = ctx, rank, world
         h = C.c_void_p()
         uid = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
