@@ -53,6 +53,11 @@ struct WarpK {
     //   zone    : s >> 5 in [-n, 2n-2] and inside int16    <=>  pattern in [u*_zlo, u*_zhi]  (one mirror image away)
     uint32_t ux_int, uy_int;
     uint32_t ux_zlo, ux_zhi, uy_zlo, uy_zhi;
+    //   periodic: |s| < 2^21 (any number of mirror images away): BORDER_REFLECT has the period 2n pixels = 64n units, so
+    //             s (after the int16 saturation of its pixel part) is reduced into [-32n, 32n) first: per_* = 64 n,
+    //             inv_* = 1 / per_* (fp32 quotient estimate, corrected by one step either way), bias_* = 32 n + k per_* >= 2^20
+    int per_x, per_y, bias_x, bias_y;
+    float inv_x, inv_y;
     // nearest-neighbour inside test on 32 v: cvRound(v) in [0, n-1]  <=>  -16 <= 32 v < m32_hi (ties go to even)
     float mx32_hi, my32_hi;
     float c2, c5, c8;  // plane: kr2 (1 - t2), kr5 (1 - t2), kr8 (1 - t2), each rounded once (host fp32 = device fp32)
@@ -251,7 +256,10 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpK P, const float2* __rest
 //                  position (s -> -s - 32 below, s -> 64 n - 32 - s above, clamped at the edges where both taps fall on
 //                  the edge pixel) turns the two reflected taps into an adjacent pixel pair again, weights in [0, 32]:
 //                  the interior code with 7 more integer ops per axis.  Masks by the nearest-neighbour range test;
-//       generic  : anything else (several mirror images away, divisions that need rescaling): per-tap borderInterpolate.
+//       periodic : |s| < 2^21, any number of mirror images away: s is reduced modulo the period of BORDER_REFLECT (2 n
+//                  pixels) into the mirror zone first (13 more ops per axis) — the pitched rows of a multi-row panorama
+//                  have large parts of their ROI there;
+//       generic  : anything else (|32 v| >= 2^21, NaN, divisions that need rescaling): per-tap borderInterpolate.
 // Preconditions (host): source < 2^31 bytes, 2 <= sw, sh <= 32767, no nearest-neighbour source image.
 // ---------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -345,6 +353,19 @@ STX_DEV void mirror_axis(int s, int n, uint32_t& ip, uint32_t& fp)
     const int i = min(m >> 5, n - 2);
     ip = (uint32_t)i;
     fp = (uint32_t)(m - (i << 5));                      // 0..32
+}
+
+// any position with |s| < 2^21 -> the position inside [-32 n, 32 n) that BORDER_REFLECT maps to the same two taps:
+// the pixel part saturates to int16 as remap's saturate_cast<short> does, then s is reduced modulo the period 64 n
+STX_DEV int periodic_axis(int s, int n, int period, float inv_period, int bias)
+{
+    const int se = (min(max(s >> 5, -32768), 32767) << 5) | (s & 31);
+    const uint32_t a = (uint32_t)(se + bias);                          // >= 0, < 2^23: exact in fp32
+    const uint32_t q = (uint32_t)(int)__fmul_rn((float)a, inv_period);  // floor(a / period), or one off
+    uint32_t r = a - __umul24(q, (uint32_t)period);
+    r = min(r, r + (uint32_t)period);  // the estimate was one too high: r < 0 wrapped around
+    r = min(r, r - (uint32_t)period);  // ... or one too low
+    return (int)r - 32 * n;
 }
 
 template <int TYPE, bool IMG, bool MASK>
@@ -522,6 +543,17 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
                     uint32_t ix, iy, fx, fy;
                     mirror_axis((int)(ux[j] - RND_U0), sw, ix, fx);
                     mirror_axis((int)(uy[j] - RND_U0), sh, iy, fy);
+                    blend_pair_to_lds(src, sstride, ix, iy, fx, fy, lpx + 192 * j);
+                }
+            } else if (__builtin_amdgcn_ballot_w64(min(uxmn, uymn) < RND_U0 - (1u << 21) || max(uxmx, uymx) >= RND_U0 + (1u << 21)) == 0) {
+                // several mirror images away somewhere in the wavefront: reduce by the period, then mirror as above
+                const int per_x = P.per_x, per_y = P.per_y, bias_x = P.bias_x, bias_y = P.bias_y;
+                const float inv_x = P.inv_x, inv_y = P.inv_y;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    uint32_t ix, iy, fx, fy;
+                    mirror_axis(periodic_axis((int)(ux[j] - RND_U0), sw, per_x, inv_x, bias_x), sw, ix, fx);
+                    mirror_axis(periodic_axis((int)(uy[j] - RND_U0), sh, per_y, inv_y, bias_y), sh, iy, fy);
                     blend_pair_to_lds(src, sstride, ix, iy, fx, fy, lpx + 192 * j);
                 }
             } else {
@@ -942,6 +974,10 @@ void fill_warpk(const StxWarpLaunch& L, WarpK* Kp, double* bytes)
     const int zy_lo = std::max(-32 * L.sh, -32768 * 32), zy_hi = std::min(64 * L.sh - 33, 32767 * 32 + 31);
     K.ux_int = RND_U0 + (uint32_t)(32 * (L.sw - 1) - 1);
     K.uy_int = RND_U0 + (uint32_t)(32 * (L.sh - 1) - 1);
+    K.per_x = 64 * L.sw; K.per_y = 64 * L.sh;
+    K.inv_x = 1.0f / (float)K.per_x; K.inv_y = 1.0f / (float)K.per_y;
+    K.bias_x = 32 * L.sw + K.per_x * (((1 << 20) + K.per_x - 1) / K.per_x);
+    K.bias_y = 32 * L.sh + K.per_y * (((1 << 20) + K.per_y - 1) / K.per_y);
     K.ux_zlo = RND_U0 + (uint32_t)zx_lo; K.ux_zhi = RND_U0 + (uint32_t)zx_hi;
     K.uy_zlo = RND_U0 + (uint32_t)zy_lo; K.uy_zhi = RND_U0 + (uint32_t)zy_hi;
     // cvRound(v) <= n - 1: v <= n - 0.5 when n - 1 is even (the tie rounds down to it), v < n - 0.5 otherwise; times 32 (exact)

@@ -377,3 +377,23 @@ def test_panorama_vs_libm_trig_oracle(oracle, gpu_ctx):
     assert d.max() <= 3
     assert np.count_nonzero(d > 1) <= 1e-5 * d.size
     assert np.count_nonzero(d) < 1e-3 * d.size
+
+
+@pytest.mark.parametrize("wtype,pitch", [("spherical", 62.0), ("spherical", -75.0), ("cylindrical", 40.0)])
+def test_warp_far_outside_the_source(oracle, gpu_ctx, wtype, pitch):
+    """A steeply pitched frame: large parts of its ROI lie several mirror images (BORDER_REFLECT periods) away from the
+    source — the warp kernel's periodic path (position reduced modulo 2 n pixels, then mirrored) — and, close to the
+    horizon of the camera, beyond 2^21 / 32 pixels (generic path).  Image and mask bit for bit."""
+    w, h = 331, 207
+    img = synthetic.make_frame(77, w, h)
+    R = (synthetic.rot_y(np.radians(20.0)) @ synthetic.rot_x(np.radians(pitch)) @ synthetic.rot_z(np.radians(7.0))).astype(np.float32)
+    cam = S.CameraParams(focal=0.55 * w, aspect=1.0, ppx=w / 2.0, ppy=h / 2.0, R=R)
+    g, o = S.Warper(wtype), oracle.Warper(wtype)
+    g.set_scale([cam])
+    o.set_scale([cam])
+    roi = o.warp_roi((w, h), cam)
+    assert g.warp_roi((w, h), cam) == roi and roi[2] * roi[3] > 2 * w * h
+    gi, oi = g.warp_image(img, cam), o.warp_image(img, cam)
+    assert np.array_equal(gi, oi), f"{np.count_nonzero(gi != oi)} differing bytes"
+    gm = g.create_and_warp_mask((w, h), cam)
+    assert np.array_equal(gm, o.create_and_warp_mask((w, h), cam)) and 0 < np.count_nonzero(gm) < gm.size
