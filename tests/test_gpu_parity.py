@@ -397,3 +397,35 @@ def test_warp_far_outside_the_source(oracle, gpu_ctx, wtype, pitch):
     assert np.array_equal(gi, oi), f"{np.count_nonzero(gi != oi)} differing bytes"
     gm = g.create_and_warp_mask((w, h), cam)
     assert np.array_equal(gm, o.create_and_warp_mask((w, h), cam)) and 0 < np.count_nonzero(gm) < gm.size
+
+
+@pytest.mark.parametrize("btype", ["no", "feather"])
+@pytest.mark.parametrize("s16", [False, True])
+def test_simple_blenders_gather_int16_and_grey_masks(oracle, gpu_ctx, btype, s16):
+    """The "no" / feather blenders are deferred gathers over the fed images: int16 inputs outside 0..255 (negative values
+    go through |x| of convertScaleAbs), masks with values other than 0 / 255 (the "no" blender ORs them), widths that are no
+    multiple of 4, an image fed twice, and the int16 result of blender.blend()."""
+    imgs, cams = helpers.small_ring(4, 301, 227, span=130.0)
+    ow = oracle.Warper("spherical")
+    ow.set_scale(cams)
+    sizes = [(301, 227)] * 4
+    wi = [ow.warp_image(i, c) for i, c in zip(imgs, cams)]
+    if s16:
+        wi = [a.astype(np.int16) * 2 - 180 for a in wi]
+    wm = [ow.create_and_warp_mask(s, c) for s, c in zip(sizes, cams)]
+    rng = np.random.default_rng(3)
+    wm[1] = np.where(wm[1] > 0, rng.integers(1, 256, wm[1].shape), 0).astype(np.uint8)  # grey values
+    wm[2][::3, ::5] = 0                                                                   # holes
+    corners, wsz = ow.warp_rois(sizes, cams)
+    order = [0, 1, 2, 3, 1]
+    ob, gb = oracle.Blender(btype, 7), S.Blender(btype, 7)
+    ob.prepare(corners, wsz)
+    gb.prepare(corners, wsz)
+    for k in order:
+        ob.blender.feed(wi[k].astype(np.int16), wm[k], corners[k])
+        gb.feed(wi[k], wm[k], corners[k])
+    o16, omask = ob.blender.blend()
+    pano, mask, p16 = gb.blender.blend(want_s16=True)
+    assert np.array_equal(np.asarray(mask), omask)
+    assert np.array_equal(np.asarray(p16), o16)
+    assert np.array_equal(np.asarray(pano), oracle.convert_scale_abs(o16))
