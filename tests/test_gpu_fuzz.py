@@ -3,6 +3,7 @@ tests CPU oracle <-> GPU, bit-exact on u8 / int16).  Every case draws the image 
 of cameras, their yaw / pitch / roll and focal length, the warper, the blender and its strength, and the mask kind
 (full warped masks, Voronoi seams, random rectangular holes, or non-binary values)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -15,7 +16,11 @@ from tests import helpers
 pytestmark = pytest.mark.gpu
 
 
-def _random_case(seed):
+# STX_FUZZ_EXTRA=n adds n more seeds to every seeded test of this file (an offline soak; the committed runs use the defaults)
+EXTRA = int(os.environ.get("STX_FUZZ_EXTRA", "0"))
+
+
+def _random_case(seed, pitched=False):
     rng = np.random.default_rng(seed)
     w = int(rng.integers(97, 420))
     h = int(rng.integers(71, 330))
@@ -31,6 +36,12 @@ def _random_case(seed):
         yaw = (i - (n - 1) / 2.0) * step + float(rng.uniform(-2, 2))
         pitch = float(rng.uniform(-8, 8))
         roll = float(rng.uniform(-5, 5))
+        if pitched and wtype != "plane":
+            # steeply pitched and rolled frames: ROIs several times the source, samples many mirror images away (the warp
+            # kernel's mirror / periodic / generic paths), masks that are a small part of the ROI
+            lim = {"spherical": 70.0, "fisheye": 50.0, "mercator": 45.0}.get(wtype, 38.0)
+            pitch = float(rng.uniform(-lim, lim))
+            roll = float(rng.uniform(-25, 25))
         R = synthetic.rot_y(math.radians(yaw)) @ synthetic.rot_x(math.radians(pitch)) @ synthetic.rot_z(math.radians(roll))
         cams.append(CameraParams(focal=focal * float(rng.uniform(0.97, 1.03)), aspect=1.0, ppx=w / 2.0 + float(rng.uniform(-3, 3)),
                                  ppy=h / 2.0 + float(rng.uniform(-3, 3)), R=R.astype(np.float32)))
@@ -65,9 +76,9 @@ def _masks_fn(kind, seed):
     return fn
 
 
-@pytest.mark.parametrize("seed", list(range(24)))
+@pytest.mark.parametrize("seed", list(range(24 + EXTRA)) + [100000 + i for i in range(10 + EXTRA)])
 def test_random_geometry_bit_exact(oracle, gpu_ctx, seed):
-    c = _random_case(1000 + seed)
+    c = _random_case(1000 + seed % 100000, pitched=seed >= 100000)
     if c["aspect"] != 1.0:  # the reference warps the final images with aspect != 1 (stitching/warper.py:44,86-94)
         c["imgs"] = [np.ascontiguousarray(im[: max(8, int(c["h"] * c["aspect"])), : max(8, int(c["w"] * c["aspect"]))]) for im in c["imgs"]]
     kw = dict(warper_type=c["wtype"], blender_type=c["btype"], blend_strength=c["strength"], masks_fn=_masks_fn(c["mask_kind"], c["seed"]),
@@ -84,7 +95,7 @@ def test_random_geometry_bit_exact(oracle, gpu_ctx, seed):
     assert np.array_equal(g["pano"], o["pano"]), (tag, int(np.count_nonzero(g["pano"] != o["pano"])))
 
 
-@pytest.mark.parametrize("seed", list(range(14)))
+@pytest.mark.parametrize("seed", list(range(14 + EXTRA)))
 def test_random_sharded_blend_bit_exact(oracle, gpu_ctx, seed):
     """The multi-GPU data path (column bands + strips, all ranks simulated on this GPU) on random geometries — single-row
     rings and, for seeds >= 8, grids of 2-3 pitch rows (several images of one rank stacked in its column band, wide
