@@ -51,7 +51,7 @@ def parse():
     p.add_argument("--blender", default="")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the extra legs (seam masks, configs 4 / 5, latency)")
-    p.add_argument("--cpu-frames", type=int, default=8, help="frames in the CPU-baseline sample")
+    p.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU-baseline sample (0: all frames of the step, which also gives `parity`)")
     p.add_argument("--profile-steps", type=int, default=3)
     p.add_argument("--min-seconds", type=float, default=MIN_TIMED_S)
     p.add_argument("--streams", type=int, default=2, help="panoramas in flight per GPU (contexts = HIP streams); N = 1 "
@@ -450,9 +450,10 @@ def main():
     if world == 1 and args.e2e_steps > 0:
         result["pcie_inclusive"] = pcie_legs(args, S, StitchJob, ctxs, wl, frames, cams, src_mpix, nb)
     if world == 1 and not args.no_cpu_baseline:
-        cb, o_pano, o_mask = cpu_baseline(wl, frames, cams, all_cams, args.cpu_frames)
+        n_cpu = args.cpu_frames or len(frames)
+        cb, o_pano, o_mask = cpu_baseline(wl, frames, cams, all_cams, n_cpu)
         result["cpu_baseline"] = cb
-        if args.cpu_frames >= len(frames):
+        if n_cpu >= len(frames):
             # the panorama of the timed path (same job object, same kernels) against the oracle's, byte for byte
             g_pano, g_mask = (np.asarray(a) for a in jobs[0].run())
             if g_pano.shape == o_pano.shape:
