@@ -190,6 +190,10 @@ int stx_block_gain_apply(stx_ctx* ctx, stx_buf* img_u8x3, const stx_buf* gain_ma
  *                            one fused kernel, the result is what Blender.feed receives (stitching/stitcher.py:124,127) */
 int stx_resize_linear_exact(stx_ctx* ctx, const stx_buf* src_u8, int dst_w, int dst_h, stx_buf** out);
 int stx_seam_mask_resize(stx_ctx* ctx, const stx_buf* seam_mask_u8x1, const stx_buf* final_mask_u8x1, stx_buf** out);
+/* the same for all n images of a panorama (the generator loop stitching/stitcher.py:223-225): one table upload, one dilate
+ * and one resize launch per 16 images */
+int stx_seam_mask_resize_batch(stx_ctx* ctx, int n, const stx_buf* const* seam_masks, const stx_buf* const* final_masks,
+                               stx_buf** outs);
 int stx_timelapse_frame(stx_ctx* ctx, const stx_buf* img, int tlx, int tly, const int dst_roi_xywh[4], stx_buf** out_frame);
 
 /* ---- sharded multi-band blending: one process per GPU, one stx_blender per rank ------------------

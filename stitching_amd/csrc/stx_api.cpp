@@ -628,6 +628,66 @@ STX_EXPORT int stx_seam_mask_resize(stx_ctx* ctx, const stx_buf* seam_mask, cons
     return resize_impl(ctx, seam_mask, final_mask->w, final_mask->h, true, final_mask, out);
 }
 
+// SeamFinder.resize for all images of a panorama: one table upload, one dilate launch and one resize launch per 16 images.
+// Falls back to the per-image call when a buffer does not meet the 4-pixel kernel's alignment needs.
+STX_EXPORT int stx_seam_mask_resize_batch(stx_ctx* ctx, int n, const stx_buf* const* seam_masks, const stx_buf* const* final_masks,
+                                          stx_buf** outs)
+{
+    if (!ctx || n < 0 || (n > 0 && (!seam_masks || !final_masks || !outs))) return stx_fail(STX_ERR_INVALID, "null argument");
+    STX_TRY(stx_set_device(ctx));
+    bool fast = true;
+    for (int i = 0; i < n; i++) {
+        const stx_buf *s = seam_masks[i], *m = final_masks[i];
+        if (!s || !m) return stx_fail(STX_ERR_INVALID, "null argument");
+        if (s->c != 1 || s->elem != STX_U8 || m->c != 1 || m->elem != STX_U8) return stx_fail(STX_ERR_INVALID, "seam masks are u8x1");
+        if (s->ctx->device != ctx->device || m->ctx->device != ctx->device) return stx_fail(STX_ERR_INVALID, "image lives on another device");
+        fast = fast && ((uintptr_t)m->ptr & 3) == 0 && (m->stride & 3) == 0 && (size_t)((m->w + 3) & ~3) <= m->stride;
+    }
+    if (!fast || n == 0) {
+        for (int i = 0; i < n; i++) STX_TRY(stx_seam_mask_resize(ctx, seam_masks[i], final_masks[i], &outs[i]));
+        return STX_OK;
+    }
+    // tables of all images in one upload: per image xt (dw rounded up to 4 entries) then yt
+    std::vector<int> all;
+    std::vector<size_t> xoff(n), yoff(n);
+    for (int i = 0; i < n; i++) {
+        std::vector<int> xt, yt;
+        linear_exact_table(seam_masks[i]->w, final_masks[i]->w, xt);
+        linear_exact_table(seam_masks[i]->h, final_masks[i]->h, yt);
+        xt.resize((xt.size() + 7) & ~(size_t)7, 0);
+        xoff[i] = all.size();
+        all.insert(all.end(), xt.begin(), xt.end());
+        yoff[i] = all.size();
+        all.insert(all.end(), yt.begin(), yt.end());
+        all.resize((all.size() + 7) & ~(size_t)7, 0);  // keep every table 32-byte aligned
+    }
+    void* d_tab = nullptr;
+    STX_TRY(upload_small(ctx, all.data(), all.size() * sizeof(int), &d_tab));
+    std::vector<stx_buf*> dsts(n, nullptr);
+    std::vector<void*> tmps(n, nullptr);
+    std::vector<uint8_t*> tptr(n);
+    std::vector<size_t> tstride(n);
+    std::vector<const int*> dx(n), dy(n);
+    int rc = STX_OK;
+    for (int i = 0; i < n && rc == STX_OK; i++) {
+        rc = stx_buf_new(ctx, final_masks[i]->w, final_masks[i]->h, 1, STX_U8, &dsts[i]);
+        tstride[i] = ((size_t)seam_masks[i]->w + 63) & ~(size_t)63;
+        if (rc == STX_OK) rc = stx_dev_alloc(ctx, tstride[i] * seam_masks[i]->h, &tmps[i]);
+        tptr[i] = (uint8_t*)tmps[i];
+        dx[i] = (const int*)d_tab + xoff[i];
+        dy[i] = (const int*)d_tab + yoff[i];
+    }
+    if (rc == STX_OK) rc = stx_launch_seam_resize_batch(ctx, n, seam_masks, final_masks, dsts.data(), dx.data(), dy.data(), tptr.data(), tstride.data());
+    for (void* t : tmps) stx_dev_free(ctx, t);  // stream-ordered reuse
+    stx_dev_free(ctx, d_tab);
+    if (rc != STX_OK) {
+        for (stx_buf* d : dsts) stx_buf_release(d);
+        return rc;
+    }
+    for (int i = 0; i < n; i++) outs[i] = dsts[i];
+    return STX_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // projector: ProjectorBase::setCameraParams, AffineWarper::getRTfromHomogeneous
 // ---------------------------------------------------------------------------------------------

@@ -903,7 +903,30 @@ __global__ __launch_bounds__(256) void dilate3x3_kernel(const uint8_t* __restric
     dst[(long long)y * dstride + x] = (uint8_t)m;
 }
 
-__global__ __launch_bounds__(256) void seam_resize4_kernel(ResizeK P)  // P.src: the dilated low-resolution mask
+STX_DEV void seam_resize4_body(const ResizeK& P);
+__global__ __launch_bounds__(256) void seam_resize4_kernel(ResizeK P) { seam_resize4_body(P); }  // P.src: the dilated low-resolution mask
+// all seam masks of a panorama in one launch each (blockIdx.z = image); the argument blocks travel as kernel arguments
+constexpr int SEAM_BATCH = 16;
+struct SeamBatchK { ResizeK k[SEAM_BATCH]; const uint8_t* raw[SEAM_BATCH]; long long raw_stride[SEAM_BATCH]; };
+__global__ __launch_bounds__(256) void seam_resize4_batch_kernel(SeamBatchK B) { seam_resize4_body(B.k[blockIdx.z]); }
+__global__ __launch_bounds__(256) void dilate3x3_batch_kernel(SeamBatchK B)
+{
+    const ResizeK& P = B.k[blockIdx.z];
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.sw || y >= P.sh) return;
+    const uint8_t* src = B.raw[blockIdx.z];
+    const long long ss = B.raw_stride[blockIdx.z];
+    uint32_t m = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+            const int xx = x + dx, yy = y + dy;
+            if ((unsigned)xx < (unsigned)P.sw && (unsigned)yy < (unsigned)P.sh) m = max(m, (uint32_t)src[(long long)yy * ss + xx]);
+        }
+    const_cast<uint8_t*>(P.src)[(long long)y * P.sstride + x] = (uint8_t)m;
+}
+STX_DEV void seam_resize4_body(const ResizeK& P)
 {
     const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     const int y = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -938,6 +961,33 @@ __global__ __launch_bounds__(256) void seam_resize4_kernel(ResizeK P)  // P.src:
     else for (int j = 0; x4 + j < P.dw; j++) d[j] = (uint8_t)(out >> (8 * j));
 }
 }  // namespace
+
+// SeamFinder.resize for n images: tmp[i] = scratch of the dilated low-resolution mask (pitch tstride[i]), d_xt / d_yt per image
+int stx_launch_seam_resize_batch(stx_ctx* ctx, int n, const stx_buf* const* seams, const stx_buf* const* masks, stx_buf* const* dsts,
+                                 const int* const* d_xt, const int* const* d_yt, uint8_t* const* tmp, const size_t* tstride)
+{
+    for (int base = 0; base < n; base += SEAM_BATCH) {
+        const int m = std::min(SEAM_BATCH, n - base);
+        SeamBatchK B = {};
+        int msw = 0, msh = 0, mdw = 0, mdh = 0;
+        double bytes = 0.0;
+        for (int i = 0; i < m; i++) {
+            const int g = base + i;
+            ResizeK& K = B.k[i];
+            K.src = tmp[g]; K.sstride = (long long)tstride[g]; K.sw = seams[g]->w; K.sh = seams[g]->h;
+            K.dst = dsts[g]->ptr; K.dstride = (long long)dsts[g]->stride; K.dw = dsts[g]->w; K.dh = dsts[g]->h;
+            K.xt = (const int2*)d_xt[g]; K.yt = (const int2*)d_yt[g];
+            K.andmask = masks[g]->ptr; K.amstride = (long long)masks[g]->stride;
+            B.raw[i] = seams[g]->ptr; B.raw_stride[i] = (long long)seams[g]->stride;
+            msw = std::max(msw, K.sw); msh = std::max(msh, K.sh); mdw = std::max(mdw, K.dw); mdh = std::max(mdh, K.dh);
+            bytes += (double)K.sw * K.sh + 2.0 * K.dw * K.dh;
+        }
+        StxProfScope prof(ctx, "seam_mask_resize", bytes);
+        hipLaunchKernelGGL(dilate3x3_batch_kernel, dim3((msw + 63) / 64, (msh + 3) / 4, m), dim3(256), 0, ctx->stream, B);
+        hipLaunchKernelGGL(seam_resize4_batch_kernel, dim3((mdw + 255) / 256, (mdh + 3) / 4, m), dim3(256), 0, ctx->stream, B);
+    }
+    return check_launch("seam_mask_resize");
+}
 
 int stx_launch_resize_exact(stx_ctx* ctx, const stx_buf* src, stx_buf* dst, const int* d_xt, const int* d_yt, bool dilate,
                             const stx_buf* andmask)

@@ -165,6 +165,8 @@ int stx_launch_block_gain(stx_ctx* ctx, stx_buf* img, const stx_buf* gmap, const
 int stx_launch_resize_exact(stx_ctx* ctx, const stx_buf* src, stx_buf* dst, const int* d_xt, const int* d_yt, bool dilate,
                             const stx_buf* andmask);
 
+int stx_launch_seam_resize_batch(stx_ctx* ctx, int n, const stx_buf* const* seams, const stx_buf* const* masks, stx_buf* const* dsts,
+                                 const int* const* d_xt, const int* const* d_yt, uint8_t* const* tmp, const size_t* tstride);
 // image-strip sharding: pack the columns [x0, x0 + w) of n images + masks into n flat buffers (one launch per 16 strips)
 int stx_launch_strip_pack(stx_ctx* ctx, int n, const stx_buf* const* imgs, const stx_buf* const* masks, const int* x0, const int* w,
                           stx_buf* const* dsts, const size_t* si, const size_t* sm);

@@ -74,7 +74,7 @@ class StitchJob:
             elif self.seam_masks is not None:
                 from .seam_finder import SeamFinder
 
-                masks = [SeamFinder.resize(s, m) for s, m in zip(self.seam_masks, masks)]
+                masks = SeamFinder.resize_all(self.seam_masks, masks)
             for img, mask, roi, corner in zip(imgs, masks, rois, self.corners):
                 if roi[0:2] != tuple(corner):
                     raise StitchingError("warp roi changed between plan() and run()")
@@ -111,7 +111,7 @@ def compose(frames, cameras, warper_type="spherical", blender_type="multiband", 
         if seam_masks is not None:
             from .seam_finder import SeamFinder
 
-            masks = [SeamFinder.resize(s, m) for s, m in zip(seam_masks, masks)]
+            masks = SeamFinder.resize_all(seam_masks, masks)
         blender = Blender(blender_type, blend_strength, ctx=ctx)
         blender.prepare(corners, sizes)
         for img, mask, corner in zip(imgs, masks, corners):

@@ -62,6 +62,23 @@ class SeamFinder:
         return self.finder.find(imgs_float, list(corners), [host(m) for m in masks])
 
     @staticmethod
+    def resize_all(seam_masks, masks):
+        """`resize` for all images of a panorama in one call (one dilate + one resize launch per 16 images); device-resident
+        inputs of one context.  Same results as [SeamFinder.resize(s, m) for s, m in zip(seam_masks, masks)]."""
+        masks = list(masks)
+        ctx = masks[0].ctx if masks and isinstance(masks[0], DeviceImage) else get_context()
+        host = lambda a: a if isinstance(a, DeviceImage) else np.asarray(a.get() if hasattr(a, "get") else a)  # noqa: E731
+        s = [as_device(host(a), ctx) for a in seam_masks]
+        m = [as_device(host(a), ctx) for a in masks]
+        n = len(m)
+        if n == 0:
+            return []
+        sa, ma, outs = (C.c_void_p * n)(*[a._h for a in s]), (C.c_void_p * n)(*[a._h for a in m]), (C.c_void_p * n)()
+        _lib.check(ctx._lib.stx_seam_mask_resize_batch(ctx.handle, n, sa, ma, outs))
+        res = [DeviceImage(ctx, C.c_void_p(outs[i])) for i in range(n)]
+        return res if config.device_resident() else [r.numpy() for r in res]
+
+    @staticmethod
     def resize(seam_mask, mask):
         """stitching/seam_finder.py:37-43 — returns the final-resolution seam mask for Blender.feed.  `seam_mask` may be
         what cv2's finders return (a cv.UMat: `.get()` is called), a numpy array or a DeviceImage."""

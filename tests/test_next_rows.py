@@ -212,6 +212,19 @@ def test_block_gain_apply_bit_exact(oracle, gpu_ctx, w, h, bs):
 
 
 @pytest.mark.gpu
+def test_seam_mask_resize_batch_equals_per_image(oracle, gpu_ctx):
+    """SeamFinder.resize_all (one dilate + one resize launch for all images, mixed sizes) against the oracle per image."""
+    rng = np.random.default_rng(17)
+    finals = [(rng.integers(0, 2, size=(h, w)) * 255).astype(np.uint8) for w, h in ((803, 601), (640, 480), (97, 1201), (1200, 37))]
+    lows = [(rng.integers(0, 2, size=(max(2, m.shape[0] // k), max(2, m.shape[1] // k))) * 255).astype(np.uint8)
+            for m, k in zip(finals, (11, 7, 9, 5))]
+    out = S.SeamFinder.resize_all([DeviceImageOrArray for DeviceImageOrArray in lows], finals)
+    assert len(out) == 4
+    for o, l, f in zip(out, lows, finals):
+        assert np.array_equal(np.asarray(o), oracle.seam_resize(l, f))
+
+
+@pytest.mark.gpu
 def test_compose_final_resolution_pipeline(oracle, gpu_ctx):
     """pipeline.compose = the final-resolution half of Stitcher.stitch (stitching/stitcher.py:117-128): warp ->
     gain_blocks apply -> seam-mask resize -> multi-band blend, all in HBM, against the same chain of oracle calls."""
