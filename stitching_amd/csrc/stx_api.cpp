@@ -1204,14 +1204,18 @@ static void mb_feed_rect(const stx_blender* b, int w, int h, int tlx, int tly, i
 }
 
 // Region of every level that the columns [bx0, bx1) of the final panorama depend on (pyrUp halo:
-// level i needs level i+1 at (x >> 1) +- 1).  Origins are multiples of 8 for the vector kernels.
+// level i needs level i+1 at (x >> 1) +- 1).  Origins are multiples of 8 for the levels of the vector kernels
+// (<= B - 3: a lane owns 8 adjacent samples) and multiples of 2 for the coarser levels of the per-sample kernel (the finer
+// level reads them through dword-aligned windows): 8 samples of the coarsest level are 8 * 2^B panorama columns, which used
+// to widen every band's region — and with it every strip another rank has to supply — by up to 256 columns at 5 bands.
 static void mb_level_regions(const stx_blender* b, int bx0, int bx1, int* xb, int* xe)
 {
     xb[0] = bx0; xe[0] = bx1;
     for (int i = 1; i <= b->num_bands; i++) {
         const int pw = b->rw >> i;
-        xb[i] = std::max(0, (xb[i - 1] >> 1) - 1) & ~7;
-        xe[i] = std::min(pw, ((((xe[i - 1] - 1) >> 1) + 2) + 7) & ~7);
+        const int al = i <= b->num_bands - 3 ? 7 : 1;
+        xb[i] = std::max(0, (xb[i - 1] >> 1) - 1) & ~al;
+        xe[i] = std::min(pw, ((((xe[i - 1] - 1) >> 1) + 2) + al) & ~al);
     }
 }
 
