@@ -285,9 +285,10 @@ def main():
         if world > 1:
             from stitching_amd.distributed import ShardedStitchJob
 
-            # with two panoramas in flight the other panorama's kernels cover the exchange: no boundary / interior split
+            # split: the pyramids of the rank's own images are built while its strips travel (measured on one rank of the
+            # 8-rank config-3 job, tools/sim_rank.py: 1.03 ms per step against 1.34 ms with everything built after the exchange)
             return ShardedStitchJob(frames_, cams, all_cams, rank, world, warper_type=wl["warper"], blender_type=wl["blender"],
-                                    num_bands=nb, ctx=c, dist=dist, split_boundary=max(1, args.streams) < 2,
+                                    num_bands=nb, ctx=c, dist=dist, split_boundary=True,
                                     transport=(jobs[0].transport if jobs else None))
         j = StitchJob(frames_, cams, warper_type=wl["warper"], blender_type=wl["blender"], num_bands=nb, ctx=c)
         j.warper.set_scale(all_cams)
