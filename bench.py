@@ -63,10 +63,11 @@ def parse():
 
 
 def kernel_source_hash():
-    """sha256 over the kernel sources: a traffic profile is only quoted for the build it was measured on."""
+    """sha256 over the device sources (.hip files and the device headers): a traffic profile is only quoted for the
+    kernels it was measured on (host-side API changes do not move bytes)."""
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "stitching_amd", "csrc", "*"))):
-        if f.endswith((".hip", ".h", ".cpp")):
+        if f.endswith(".hip") or os.path.basename(f) in ("stx_device_math.h", "stx_blend_kernels.h"):  # device code only
             h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 

@@ -19,7 +19,7 @@ def kernel_source_hash():
     """as bench.py: the profile is quoted only for the kernel sources it was measured on"""
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "stitching_amd", "csrc", "*"))):
-        if f.endswith((".hip", ".h", ".cpp")):
+        if f.endswith(".hip") or os.path.basename(f) in ("stx_device_math.h", "stx_blend_kernels.h"):  # device code only
             h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
