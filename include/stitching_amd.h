@@ -154,7 +154,10 @@ int stx_warp_mask(stx_ctx* ctx, int type, float scale, const float K[9], const f
  *                      + setNumBands | detail_FeatherBlender() + setSharpness, then .prepare(dst_sz)
  *                      (Blender/FeatherBlender/MultiBandBlender::prepare)
  * stx_blend_feed    <- stitching/blender.py:40-41 blender.feed(UMat(int16 img), mask, corner)
- *                      img: u8x3 (converted on load) or s16x3; mask u8x1
+ *                      img: u8x3 (converted on load) or s16x3; mask u8x1.  DEFERRED for all three kinds: the blender
+ *                      keeps a reference to img and mask and reads them in stx_blend_finish (one gather over the
+ *                      panorama), so the two buffers must not be modified between feed and finish (OpenCV consumes
+ *                      them inside feed)
  * stx_blend_finish  <- stitching/blender.py:43-48 blender.blend() + cv.convertScaleAbs(result)
  *                      returns the u8x3 panorama and the u8 mask; consumes the blender
  *                      (a second finish is STX_ERR_STATE; OpenCV releases dst_ in blend). */

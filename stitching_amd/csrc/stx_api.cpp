@@ -1396,7 +1396,7 @@ STX_EXPORT int stx_blend_feed_ex(stx_blender* b, const stx_buf* img, const stx_b
         im.img = img->ptr; im.istride = (long long)img->stride; im.is_s16 = img->elem == STX_S16;
         im.mask = mask->ptr; im.mstride = (long long)mask->stride;
         im.x = tlx - b->rx; im.y = tly - b->ry; im.w = img->w; im.h = img->h;
-        im.pad = mask->mask_binary;
+        im.mask_binary = mask->mask_binary;
         b->no_images.push_back(im);
         stx_buf_retain(const_cast<stx_buf*>(img));
         stx_buf_retain(const_cast<stx_buf*>(mask));
@@ -1822,7 +1822,7 @@ static int no_finish(stx_blender* b, stx_buf* pano, stx_buf* pmask, stx_buf* p16
     bool all_binary = true;
     double bytes = 4.0 * pano->w * pano->h + (p16 ? 6.0 * pano->w * pano->h : 0.0);
     for (const NoImg& im : b->no_images) {
-        all_binary = all_binary && im.pad;
+        all_binary = all_binary && im.mask_binary;
         bytes += (double)im.w * im.h;  // every mask once; the image bytes of the winners are counted with the output
     }
     bytes += 3.0 * pano->w * pano->h;

@@ -188,7 +188,7 @@ int stx_launch_feather_weights(stx_ctx* ctx, const FeatherImg* d_imgs, const Fea
 int stx_launch_feather_gather(stx_ctx* ctx, const FeatherGatherK& K, double algo_bytes);
 
 // "no" blender as a deferred gather: device table of the fed images, in feed order
-struct NoImg { const uint8_t* img; long long istride; const uint8_t* mask; long long mstride; int is_s16; int x, y, w, h; int pad; };
+struct NoImg { const uint8_t* img; long long istride; const uint8_t* mask; long long mstride; int is_s16; int x, y, w, h; int mask_binary; };
 struct NoGatherK {
     const NoImg* imgs; int n; int all_binary;  // all_binary: every mask holds only 0 / 255
     int w, h;
