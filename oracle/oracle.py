@@ -374,7 +374,7 @@ class Blender:
             self.blender = _OracleBlenderHandle(_OracleBlenderHandle.NO)
         elif self.blender_type == "multiband":
             self.blender = _OracleBlenderHandle(
-                _OracleBlenderHandle.MULTI_BAND, num_bands=int((np.log(blend_width) / np.log(2.0) - 1.0)))
+                _OracleBlenderHandle.MULTI_BAND, num_bands=max(0, int((np.log(blend_width) / np.log(2.0) - 1.0))))  # -1 at blend_width == 1: UB in cv2
         elif self.blender_type == "feather":
             self.blender = _OracleBlenderHandle(_OracleBlenderHandle.FEATHER, sharpness=1.0 / blend_width)
         self.blender.prepare(dst_sz)

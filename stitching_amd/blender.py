@@ -94,7 +94,9 @@ class Blender:
 
         elif self.blender_type == "multiband":
             num_bands = int((np.log(blend_width) / np.log(2.0) - 1.0))
-            self.blender = _BlenderHandle(ctx, _lib.BLEND_MULTIBAND, num_bands, 0.0, dst_sz)
+            # blend_width == 1 exactly gives -1: cv2's setNumBands(-1) then shifts by a negative count in prepare()
+            # (undefined behaviour in the reference); 0 bands — the single-level blend of blend_width in (1, 4) — is the limit
+            self.blender = _BlenderHandle(ctx, _lib.BLEND_MULTIBAND, max(num_bands, 0), 0.0, dst_sz)
 
         elif self.blender_type == "feather":
             self.blender = _BlenderHandle(ctx, _lib.BLEND_FEATHER, 0, 1.0 / blend_width, dst_sz)
