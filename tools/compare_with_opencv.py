@@ -4,12 +4,18 @@ OpenCV, wherever `cv2` is importable.  Not runnable in the build container or on
 (no cv2 there — DESIGN.md §2: parity unpinned); this is the hook a maintainer with opencv-python
 installed uses to pin it:
 
-    python tools/compare_with_opencv.py
+    python tools/compare_with_opencv.py [--json report.json] [--write-golden tests/golden/opencv_golden.npz]
+
+--write-golden stores what REAL OpenCV returns for the seeded cases (ROIs, warped images and masks, panoramas, the cv2
+version) next to the oracle model that matched best; tests/test_opencv_golden.py then pins the oracle against that file
+on every run — commit it and the "parity unpinned" caveat goes away for the cases it holds.
 
 Drives both through the reference's own call sequence (stitching/warper.py:43-82,
 stitching/blender.py:23-48) on the seeded synthetic cases of tools/make_golden.py and prints, per
 case, ROI equality, max |Δ| of warped pixels / masks / panorama and the count of differing bytes.
 """
+import argparse
+import json
 import os
 import sys
 
@@ -19,7 +25,97 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def model_sweep(cv, O, G, report, golden):
+    """Which of the oracle's arithmetic models (oracle.set_model; trig) is the one this OpenCV build follows?  Every
+    combination on every seeded case: count of differing bytes of the warped images (remap x trig) and of the panorama
+    (pyrDown order, with the warp inputs taken from the oracle so that only the blender differs)."""
+    from stitching_amd import synthetic
+
+    warp_models = [(t, r) for t in ("libm", "exact") for r in O.REMAP_MODELS]
+    pyr_models = [(m, l) for m in O.PYRDOWN32F_MODELS for l in ((4,) if m == "scalar" else (4, 8))]
+    warp_score = {m: 0 for m in warp_models}
+    pyr_score = {m: 0 for m in pyr_models}
+    for name, p in G.CASES.items():
+        imgs, cams = G.inputs_for(p)
+        aspect = p.get("aspect", 1)
+        base = O.Warper(p["warper"])
+        base.set_scale(cams)
+        refs = []
+        for img, c in zip(imgs, cams):
+            K, R = O.Warper.get_K(c, aspect), np.asarray(c.R, np.float32)
+            w = cv.PyRotationWarper(p["warper"], base.scale * aspect)
+            _, ref = w.warp(img, K, R, cv.INTER_LINEAR, cv.BORDER_REFLECT)
+            _, refm = w.warp(255 * np.ones(img.shape[:2], np.uint8), K, R, cv.INTER_NEAREST, cv.BORDER_CONSTANT)
+            roi = tuple(int(v) for v in w.warpRoi((img.shape[1], img.shape[0]), K, R))
+            refs.append((ref, refm, roi))
+        for (t, r) in warp_models:
+            O.set_model(remap=r)
+            ow = O.Warper(p["warper"], trig=O.TRIG_LIBM if t == "libm" else O.TRIG_EXACT)
+            ow.set_scale(cams)
+            for (ref, refm, roi), img, c in zip(refs, imgs, cams):
+                mine = ow.warp_image(img, c, aspect)
+                warp_score[(t, r)] += int(np.count_nonzero(mine != ref)) if mine.shape == ref.shape else ref.size
+        O.set_model()
+        if golden is not None:
+            for i, (ref, refm, roi) in enumerate(refs):
+                golden[f"{name}/roi/{i}"] = np.asarray(roi, np.int32)
+                golden[f"{name}/warp/{i}"] = ref
+                golden[f"{name}/mask/{i}"] = refm
+        # blender: cv2 fed with cv2's own warps; the oracle under every pyrDown model fed with the same arrays
+        sizes0 = [(im.shape[1], im.shape[0]) for im in imgs]
+        corners = [r[2][0:2] for r in refs]
+        sizes = [r[2][2:4] for r in refs]
+        wi, wm = [r[0] for r in refs], [r[1] for r in refs]
+        if p.get("voronoi"):
+            wm = synthetic.voronoi_seam_masks(wm, corners, sizes)
+        strength = p.get("strength", 5)
+        dst_sz = cv.detail.resultRoi(corners=corners, sizes=sizes)
+        bw = np.sqrt(dst_sz[2] * dst_sz[3]) * strength / 100
+        if p["blender"] == "no" or bw < 1:
+            cb = cv.detail.Blender_createDefault(cv.detail.Blender_NO)
+        elif p["blender"] == "multiband":
+            cb = cv.detail_MultiBandBlender()
+            cb.setNumBands(max(0, int((np.log(bw) / np.log(2.0) - 1.0))))
+        else:
+            cb = cv.detail_FeatherBlender()
+            cb.setSharpness(1.0 / bw)
+        cb.prepare(dst_sz)
+        for a, m, c in zip(wi, wm, corners):
+            cb.feed(cv.UMat(a.astype(np.int16)), m, c)
+        cp, cm = cb.blend(None, None)
+        cp = cv.convertScaleAbs(cp)
+        cp, cm = (x.get() if hasattr(x, "get") else x for x in (cp, cm))
+        if golden is not None:
+            golden[f"{name}/pano"] = cp
+            golden[f"{name}/pmask"] = cm
+        for (m_, l_) in pyr_models:
+            O.set_model(pyrdown32f=m_, lanes=l_)
+            ob = O.Blender(p["blender"], strength)
+            ob.prepare(corners, sizes)
+            for a, m, c in zip(wi, wm, corners):
+                ob.feed(a, m, c)
+            op, om = ob.blend()
+            pyr_score[(m_, l_)] += int(np.count_nonzero(op != cp)) if op.shape == cp.shape else cp.size
+        O.set_model()
+    print("\nmodel sweep (differing bytes over all cases; 0 = this build follows that model):")
+    for k, v in sorted(warp_score.items(), key=lambda kv: kv[1]):
+        print(f"  warp: trig={k[0]:5s} remap={k[1]:9s} {v}")
+    for k, v in sorted(pyr_score.items(), key=lambda kv: kv[1]):
+        print(f"  blend: pyrdown32f={k[0]:12s} lanes={k[1]} {v}")
+    bw_, bp_ = min(warp_score, key=warp_score.get), min(pyr_score, key=pyr_score.get)
+    report["model_sweep"] = {"warp": {f"{k[0]}/{k[1]}": v for k, v in warp_score.items()},
+                             "blend": {f"{k[0]}/{k[1]}": v for k, v in pyr_score.items()},
+                             "best": {"trig": bw_[0], "remap": bw_[1], "pyrdown32f": bp_[0], "lanes": bp_[1]}}
+    if golden is not None:
+        golden["__meta__"] = np.frombuffer(json.dumps({"cv2": cv.__version__, "best": report["model_sweep"]["best"],
+                                                      "warp_diff": warp_score[bw_], "blend_diff": pyr_score[bp_]}).encode(), np.uint8)
+
+
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--json", default="")
+    ap.add_argument("--write-golden", default="")
+    args = ap.parse_args()
     try:
         import cv2 as cv
     except ImportError:
@@ -29,6 +125,13 @@ def main():
     from tools import make_golden as G
 
     O.build()
+    report = {"cv2": cv.__version__}
+    golden = {} if args.write_golden else None
+    print("OpenCV", cv.__version__)
+    model_sweep(cv, O, G, report, golden)
+    if args.write_golden:
+        np.savez_compressed(args.write_golden, **golden)
+        print("wrote", args.write_golden)
 
     def cam_cv(c):
         p = cv.detail.CameraParams()
@@ -128,6 +231,9 @@ def main():
     d = np.abs(O.block_gain_apply(img, gm).astype(int) - ref.astype(int))
     print(f"BlocksCompensator::apply: max|d|={int(d.max())}")
     worst_next = max(worst_next, int(d.max()))
+    report.update(worst_warp=worst, worst_blend=worst_blend, worst_next_rows=worst_next)
+    if args.json:
+        json.dump(report, open(args.json, "w"), indent=1)
     return 0 if max(worst, worst_blend, worst_next) <= 1 else 1
 
 
