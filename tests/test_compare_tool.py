@@ -1,0 +1,34 @@
+"""tools/compare_with_opencv.py end to end against a stand-in `cv2` (tests/fake_cv2.py: the oracle under libm trig +
+SIMD-order pyrDown): the model sweep must name exactly that model with 0 differing bytes, --write-golden must produce a
+file, and tests/test_opencv_golden.py must accept it.  Proves the pinning machinery; says nothing about real OpenCV."""
+import json
+import sys
+
+import numpy as np
+
+
+def test_model_sweep_and_golden_roundtrip(oracle, tmp_path, monkeypatch):
+    from tests import fake_cv2, test_opencv_golden
+    from tools import compare_with_opencv as tool
+    from tools import make_golden as G
+
+    # a subset of the seeded cases keeps the CPU suite short: one multi-band, one per-pixel projector, the affine pair
+    keep = ("spherical_mb_default", "plane_mb3", "affine_feather", "affine_no", "spherical_mb_voronoi", "fisheye_mb")
+    monkeypatch.setattr(G, "CASES", {k: G.CASES[k] for k in keep})
+    monkeypatch.setitem(sys.modules, "cv2", fake_cv2)
+    golden, report = str(tmp_path / "opencv_golden.npz"), str(tmp_path / "report.json")
+    monkeypatch.setattr(sys, "argv", ["compare_with_opencv.py", "--json", report, "--write-golden", golden])
+    rc = tool.main()
+    rep = json.load(open(report))
+    best = rep["model_sweep"]["best"]
+    assert best == {"trig": "libm", "remap": "q15", "pyrdown32f": best["pyrdown32f"], "lanes": best["lanes"]}
+    assert rep["model_sweep"]["warp"]["libm/q15"] == 0 and rep["model_sweep"]["warp"]["exact/float"] > 0
+    assert rep["model_sweep"]["blend"]["simd_hv/4"] == 0
+    # the tool's main comparison runs the DEFAULT oracle model against the stand-in: within the measured bounds, not exact
+    assert rc in (0, 1) and rep["worst_next_rows"] == 0
+    z = np.load(golden)
+    meta = json.loads(bytes(z["__meta__"]).decode())
+    assert meta["cv2"] == fake_cv2.__version__ and meta["warp_diff"] == 0 and meta["blend_diff"] == 0
+    # ... and the pin test accepts the file (and would fail on a regression of the oracle)
+    monkeypatch.setattr(test_opencv_golden, "GOLDEN", golden)
+    test_opencv_golden.test_oracle_reproduces_opencv_goldens(oracle)
