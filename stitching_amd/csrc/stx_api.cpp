@@ -8,6 +8,7 @@
 #include <limits>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -1338,6 +1339,34 @@ static int mb_ensure_pyramids(stx_blender* b)
     for (size_t i = 0; i < b->images.size(); i++)
         if (b->images[i].kind == 0 && !b->built[i]) todo.push_back(b->images[i]);
     if (todo.empty()) return STX_OK;
+    // occupancy maps of the weight pyramids (StxMbImage::occ): one arena for this batch.  Only where every level is built by
+    // the batched LDS kernels, which write them (int16 sources take the generic level-0 kernel).
+    static const bool occ_off = getenv("STITCHING_AMD_NO_OCC") != nullptr;  // diagnostic: A/B of the bookkeeping
+    if (todo.size() <= 65535 && !occ_off) {
+        const int nl = b->num_bands + 1;
+        std::vector<size_t> off(todo.size() * (size_t)nl, 0);
+        size_t bytes = 0;
+        for (size_t t = 0; t < todo.size(); t++) {
+            if (todo[t].img0_is_s16) continue;
+            for (int i = 1; i < nl; i++) {
+                off[t * nl + i] = bytes;
+                // rows of ((fw >> i) / 64 rounded up, then to a multiple of 4) bytes; one more row = slack for the 12-byte reads
+                bytes += (size_t)((((todo[t].fh >> i) + 1) >> 1) + 1) * (size_t)(((((todo[t].fw >> i) + 63) >> 6) + 3) & ~3);
+            }
+        }
+        if (bytes > 0) {
+            void* arena = nullptr;
+            STX_TRY(stx_dev_alloc(b->ctx, bytes + 16, &arena));
+            b->pyr_allocs.push_back(arena);
+            size_t t = 0;
+            for (size_t i = 0; i < b->images.size(); i++) {
+                if (!(b->images[i].kind == 0 && !b->built[i])) continue;
+                if (!todo[t].img0_is_s16)
+                    for (int l = 1; l < nl; l++) todo[t].occ[l] = b->images[i].occ[l] = (uint8_t*)arena + off[t * nl + l];
+                t++;
+            }
+        }
+    }
     StxMbImage* d = nullptr;
     STX_TRY(mb_upload(b, todo.data(), (int)todo.size(), &d));
     STX_TRY(stx_launch_mb_pyramids(b->ctx, d, todo.data(), (int)todo.size(), b->num_bands));

@@ -786,18 +786,25 @@ namespace {
 constexpr int STRIP_BATCH = 16;
 struct StripK { const uint8_t* img; const uint8_t* mask; uint8_t* dst; long long istride, mstride, si, sm; int h, img_chunks, mask_chunks; };
 struct StripBatchK { StripK k[STRIP_BATCH]; };
+constexpr int STRIP_ROWS = 4;  // rows per workgroup: four independent 8-byte copies in flight per lane
 __global__ __launch_bounds__(256) void strip_pack_kernel(StripBatchK B)
 {
     const StripK& P = B.k[blockIdx.z];
-    const int row = blockIdx.y;
-    if (row >= P.h) return;
+    const int row0 = blockIdx.y * STRIP_ROWS;
+    if (row0 >= P.h) return;
     const int per_row = P.img_chunks + P.mask_chunks;
     for (int c = blockIdx.x * 256 + threadIdx.x; c < per_row; c += gridDim.x * 256) {
-        if (c < P.img_chunks)
-            *reinterpret_cast<uint2*>(P.dst + (long long)row * P.si + 8ll * c) = *reinterpret_cast<const uint2*>(P.img + (long long)row * P.istride + 8ll * c);
-        else
-            *reinterpret_cast<uint2*>(P.dst + P.si * P.h + (long long)row * P.sm + 8ll * (c - P.img_chunks)) =
-                *reinterpret_cast<const uint2*>(P.mask + (long long)row * P.mstride + 8ll * (c - P.img_chunks));
+        const bool im = c < P.img_chunks;
+        const uint8_t* src = im ? P.img + 8ll * c : P.mask + 8ll * (c - P.img_chunks);
+        uint8_t* dst = im ? P.dst + 8ll * c : P.dst + P.si * P.h + 8ll * (c - P.img_chunks);
+        const long long ss = im ? P.istride : P.mstride, ds = im ? P.si : P.sm;
+        uint2 v[STRIP_ROWS];
+#pragma unroll
+        for (int r = 0; r < STRIP_ROWS; r++)
+            if (row0 + r < P.h) v[r] = *reinterpret_cast<const uint2*>(src + (long long)(row0 + r) * ss);
+#pragma unroll
+        for (int r = 0; r < STRIP_ROWS; r++)
+            if (row0 + r < P.h) *reinterpret_cast<uint2*>(dst + (long long)(row0 + r) * ds) = v[r];
     }
 }
 }  // namespace
@@ -821,7 +828,7 @@ int stx_launch_strip_pack(stx_ctx* ctx, int n, const stx_buf* const* imgs, const
             bytes += 8.0 * (double)w[g] * K.h;
         }
         StxProfScope prof(ctx, "strip_pack", bytes);
-        hipLaunchKernelGGL(strip_pack_kernel, dim3((max_chunks + 255) / 256, max_h, m), dim3(256), 0, ctx->stream, B);
+        hipLaunchKernelGGL(strip_pack_kernel, dim3((max_chunks + 255) / 256, (max_h + STRIP_ROWS - 1) / STRIP_ROWS, m), dim3(256), 0, ctx->stream, B);
     }
     return check_launch("strip_pack");
 }

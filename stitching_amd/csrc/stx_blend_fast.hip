@@ -265,6 +265,20 @@ STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, s
     }
 }
 
+// Occupancy map of the level the pyrDown kernels write (StxMbImage::occ): called by every lane that reached the end of phase 2
+// with the OR of the bit patterns of its weights (lane = column pair p = tid & 31 of row pair rg = tid >> 5 of the 64 x 14 tile
+// at (X0, Y0)); lane p = 0 — never beyond the image — stores the half-wavefront's verdict.
+// bytes per row of an occupancy map over a level `lw` columns wide: one per 64 columns, rows on dword boundaries
+STX_DEV int occ_pitch(int lw) { return (((lw + 63) >> 6) + 3) & ~3; }
+STX_DEV void dn_note_occ(uint8_t* __restrict__ occ, uint32_t nzbits, int tid, int X0, int Y0, int ow, int oh)
+{
+    const unsigned long long bal = __ballot(nzbits != 0u);
+    const int rg = tid >> 5;
+    if (occ == nullptr || (tid & 31) != 0 || 2 * rg >= DN_TOH || Y0 + 2 * rg >= oh) return;
+    const uint32_t half = (tid & 32) ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+    occ[(long long)((Y0 >> 1) + rg) * occ_pitch(ow) + (X0 >> 6)] = half != 0u ? 1 : 0;
+}
+
 // blockIdx.z = image: all fed images are processed by one launch (deferred pyramid build)
 template <bool PK>
 __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __restrict__ images, StxTileMap M)
@@ -278,8 +292,14 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
     if (!xcd_tile(M, blockIdx.x, tile_tx, tile_ty)) return;
     const int X0 = tile_tx * DN_TOW, Y0 = tile_ty * DN_TOH;
     if (im.img0_is_s16 || X0 >= ow || Y0 >= oh) return;  // int16 sources take the generic kernel
+    uint8_t* const occ = im.occ[1];
+    asm volatile("" ::"s"(occ));  // fetched with the other descriptor fields, not at the tail where nothing hides the round trip
+    // rows / columns of the tile past the image's last output feed nothing (narrow exchange strips and the right / bottom
+    // edge tiles would otherwise run the reflecting slow path for them)
+    const int r_end = 2 * min(DN_TOH, oh - Y0) + 3;
     for (int task = tid; task < DN_ROWS * (DN_TOW / 4); task += 256) {
         const int r = task / (DN_TOW / 4), q = task % (DN_TOW / 4);
+        if (X0 + 4 * q >= ow || r >= r_end) continue;
         dn_task_level0<PK>(im, 2 * Y0 - 2 + r, X0 + 4 * q, &s_h[0][r][4 * q], &s_h[1][r][4 * q], &s_h[2][r][4 * q],
                            &s_w[r][4 * q]);
     }
@@ -288,6 +308,7 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
     const int xo = X0 + 2 * p;
     if (xo >= ow) return;
     const bool two = xo + 1 < ow;
+    uint32_t nz = 0u;
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
         const int yl = 2 * rg + rr, y = Y0 + yl;
@@ -322,7 +343,9 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
         float* o = im.wt[1] + (long long)y * im.wt_stride[1] + xo;
         if (two) *reinterpret_cast<float2*>(o) = make_float2(wa, wb);
         else o[0] = wa;
+        nz |= __float_as_uint(wa) | (two ? __float_as_uint(wb) : 0u);
     }
+    dn_note_occ(occ, nz, tid, X0, Y0, ow, oh);
 }
 
 // level >= 1 (planar int16 x3 + fp32): 8 outputs from 19 input elements per plane
@@ -358,8 +381,12 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
     if (X0 >= ow || Y0 >= oh) return;
     const short* G = im.g[lv];
     const long long gs = im.g_stride[lv], gp = im.g_plane[lv];
+    uint8_t* const occ = im.occ[lv + 1];
+    asm volatile("" ::"s"(occ));  // as in the level-0 kernel
+    const int r_end = 2 * min(DN_TOH, oh - Y0) + 3;  // as in the level-0 kernel
     for (int task = tid; task < DN_ROWS * (DN_TOW / 8); task += 256) {
         const int r = task / (DN_TOW / 8), q = task % (DN_TOW / 8);
+        if (X0 + 8 * q >= ow || r >= r_end) continue;
         const int sy = reflect101(2 * Y0 - 2 + r, ih);
         const int c0 = 2 * (X0 + 8 * q) - 2;
         const bool fast = c0 >= 0 && c0 + 18 < iw;
@@ -416,6 +443,7 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
     const int xo = X0 + 2 * p;
     if (xo >= ow) return;
     const bool two = xo + 1 < ow;
+    uint32_t nz = 0u;
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
         const int yl = 2 * rg + rr, y = Y0 + yl;
@@ -445,7 +473,9 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
         float* o = im.wt[lv + 1] + (long long)y * im.wt_stride[lv + 1] + xo;
         if (two) *reinterpret_cast<float2*>(o) = make_float2(wa, wb);
         else o[0] = wa;
+        nz |= __float_as_uint(wa) | (two ? __float_as_uint(wb) : 0u);
     }
+    dn_note_occ(occ, nz, tid, X0, Y0, ow, oh);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -590,6 +620,40 @@ STX_DEV void level_epilogue(const MbLevelK& P, int X0, int Y0, int (&acc)[2][8][
     }
 }
 
+// Does image `im` have a non-zero weight in the rows Y0, Y0 + 1 of level lv under the 512 columns from tile_x on?  (Occupancy
+// map written by the pyramid kernels; true when there is none.)  Level 0 has no map of its own: a non-zero mask value at the
+// frame position (x, y) makes W_1(x >> 1, y >> 1) non-zero (the taps 2 x', 2 x' + 1 of the 5-tap kernel are direct, the weights
+// are non-negative and far above underflow), so the level-1 entries over (x >> 1, y >> 1) bound it.  Passing over an image whose
+// weights are all exactly 0 changes nothing: (short)(L * 0.f) = 0 and w + 0.f = w.
+template <bool L0>
+STX_DEV bool occ_hit(const StxMbImage& im, int lv, int tile_x, int Y0)
+{
+    const int sl = L0 ? 1 : lv;
+    const uint8_t* occ = im.occ[sl];
+    if (occ == nullptr) return true;
+    const int lw = im.fw >> sl, lh = im.fh >> sl;
+    const int fr = L0 ? (Y0 - im.fy) >> 1 : Y0 - (im.fy >> lv);  // row of level sl, frame coordinates
+    int x0 = L0 ? (tile_x - im.fx) >> 1 : tile_x - (im.fx >> lv);
+    int x1 = L0 ? (tile_x + 511 - im.fx) >> 1 : x0 + 511;
+    x0 = max(x0, 0); x1 = min(x1, lw - 1);
+    if (fr < 0 || fr >= lh || x0 > x1) return true;
+    // entries t0 .. t1 (at most 5 at level 0: 256 columns of level 1; 9 otherwise) from one dword-aligned 8 / 12-byte load (rows
+    // start on dword boundaries and the arena ends with slack); entries outside the range are masked off
+    const int t0 = x0 >> 6, n = (x1 >> 6) - t0 + 1;
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(occ + (long long)(fr >> 1) * occ_pitch(lw) + (t0 & ~3));
+    const uint32_t sh = (uint32_t)t0 & 3u;
+    if (L0) {
+        const uint2 d = *reinterpret_cast<const uint2*>(q);
+        const uint32_t w0 = __builtin_amdgcn_alignbyte(d.y, d.x, sh), w1 = d.y >> (8u * sh);
+        return ((w0 & (n >= 4 ? 0xffffffffu : (1u << (8 * n)) - 1u)) | (n > 4 ? w1 & 0xffu : 0u)) != 0u;
+    }
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+    const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh), w2 = d2 >> (8u * sh);
+    const uint32_t m0 = n >= 4 ? 0xffffffffu : (1u << (8 * n)) - 1u;
+    const uint32_t m1 = n >= 8 ? 0xffffffffu : (n > 4 ? (1u << (8 * (n - 4))) - 1u : 0u);
+    return ((w0 & m0) | (w1 & m1) | (n > 8 ? w2 & 0xffu : 0u)) != 0u;
+}
+
 // CONTRIB: the image table may hold received contribution strips (kind 1); EMIT: write un-normalised sums.
 // Both are compile-time so that the common single-GPU instantiation carries neither path.
 // U8SRC (levels >= 1): every image was fed as u8, so G_i is 0..255 and pyrUp / the Laplacian run in packed 16-bit lanes
@@ -626,6 +690,7 @@ STX_DEV void mb_level_fast_body(const MbLevelK& P)
                 if (L0 && !(CONTRIB && im.kind == 1)) { rx = im.ix; ry = im.iy; rw = im.iw; rh = im.ih; }
                 else { rx = im.fx >> lv; ry = im.fy >> lv; rw = im.fw >> lv; rh = im.fh >> lv; }
                 hit = rx < tile_x + 512 && rx + rw > tile_x && ry < Y0 + 2 && ry + rh > Y0;
+                if (hit) hit = occ_hit<L0>(im, lv, tile_x, Y0);
             }
         }
         unsigned long long todo = __ballot(hit);
@@ -1011,6 +1076,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVE
                 int rx = im.ix, ry = im.iy, rw = im.iw, rh = im.ih;
                 if (CONTRIB && im.kind == 1) { rx = im.fx; ry = im.fy; rw = im.fw; rh = im.fh; }
                 hit = rx < tile_x + 512 && rx + rw > tile_x && ry < Y0 + 2 && ry + rh > Y0;
+                if (hit) hit = occ_hit<true>(im, 0, tile_x, Y0);
             }
         }
         unsigned long long todo = __ballot(hit);

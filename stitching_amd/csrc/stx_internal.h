@@ -153,6 +153,12 @@ struct StxMbImage {  // device-visible descriptor of one fed image (all levels)
     // levels 1..B: planar int16 Gaussian pyramid (3 planes) and fp32 weight pyramid
     short* g[STX_MAX_BANDS + 1]; long long g_stride[STX_MAX_BANDS + 1]; long long g_plane[STX_MAX_BANDS + 1];
     float* wt[STX_MAX_BANDS + 1]; long long wt_stride[STX_MAX_BANDS + 1];
+    // occupancy of the weight pyramid (null: not recorded): occ[i][p * nt + t] != 0 iff W_i has a non-zero value in the rows
+    // 2 p, 2 p + 1 and the columns 64 t .. 64 t + 63 of level i (frame coordinates), nt = ((fw >> i) + 63) / 64 rounded up to 4.  Every entry is
+    // written by the pyramid kernel that produces the level (one byte store per half-wavefront: no atomics, no clearing);
+    // the gather kernels read it to pass over the empty parts of a feed rectangle (bounding boxes of pitched / rolled frames,
+    // seam masks, exchange strips) a wavefront at a time.
+    uint8_t* occ[STX_MAX_BANDS + 1];
 };
 int stx_launch_mb_pyramids(stx_ctx* ctx, const StxMbImage* d_images, const StxMbImage* h_images, int n, int num_bands);
 struct MbLevelK;

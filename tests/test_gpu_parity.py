@@ -429,3 +429,42 @@ def test_simple_blenders_gather_int16_and_grey_masks(oracle, gpu_ctx, btype, s16
     assert np.array_equal(np.asarray(mask), omask)
     assert np.array_equal(np.asarray(p16), o16)
     assert np.array_equal(np.asarray(pano), oracle.convert_scale_abs(o16))
+
+
+@pytest.mark.parametrize("kind", ["islands", "empty_and_dots", "grey_islands", "edges"])
+def test_blend_sparse_masks_bit_exact(oracle, gpu_ctx, kind):
+    """Masks that are zero over most of their feed rectangle: the gather kernels pass over an image wherever the recorded
+    row spans of its weight pyramid (StxMbImage::span) say that nothing of it is under a wavefront's 512 x 2 pixels.
+    Islands at the 512-column tile seams, single pixels in the corners, one mask entirely zero, grey (non-binary) values
+    and one-pixel lines along the rectangle's edges — every panorama is the oracle's bit for bit."""
+    imgs, cams = helpers.small_ring(4, 1500, 420, span=150.0)
+    rng = np.random.default_rng(31)
+
+    def fn(masks, corners, sizes):
+        out = []
+        for k, m in enumerate(masks):
+            hh, ww = m.shape
+            z = np.zeros_like(m)
+            if kind == "islands":
+                for x in (0, 500, 1016, ww - 40):
+                    y = int(rng.integers(0, hh - 30))
+                    z[y:y + 24, x:x + 33] = m[y:y + 24, x:x + 33]
+            elif kind == "empty_and_dots":
+                if k != 1:  # image 1: nothing at all
+                    for (y, x) in ((0, 0), (hh - 1, ww - 1), (hh // 2, 511), (hh // 2 + 1, 512), (3, ww // 3)):
+                        z[y, x] = 255
+            elif kind == "grey_islands":
+                for _ in range(5):
+                    y, x = int(rng.integers(0, hh - 20)), int(rng.integers(0, ww - 80))
+                    z[y:y + 17, x:x + 70] = rng.integers(0, 256, (17, 70), dtype=np.uint8)
+            else:
+                z[0, :] = 255; z[hh - 1, :] = 255; z[:, 0] = 255; z[:, ww - 1] = 255
+                z &= m if k % 2 else z
+            out.append(z)
+        return out
+
+    o = helpers.run_pipeline(oracle.Warper, oracle.Blender, imgs, cams, blend_strength=6, masks_fn=fn)
+    rng = np.random.default_rng(31)
+    g = helpers.run_pipeline(S.Warper, S.Blender, imgs, cams, blend_strength=6, masks_fn=fn)
+    assert np.array_equal(g["pmask"], o["pmask"])
+    assert np.array_equal(g["pano"], o["pano"]), int(np.count_nonzero(g["pano"] != o["pano"]))
