@@ -101,6 +101,7 @@ STX_DEV uint32_t bil(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, uin
 
 // Separable part of mapBackward, evaluated once per destination column / row (fp64 "exact" trig):
 //   spherical  : col = (sin u', cos u'),           row: ra = sin(pi - v'), rb = cos(pi - v')
+//   mercator   : col = (sin u', cos u'),           row: ra = cos v_, rb = sin v_ with v_ = atan(sinh v')   (typed as spherical)
 //   cylindrical: col = (sin u', cos u'),           row: ra = v'
 //   plane      : col = (u'/scale - t0, -),         row: ra = v'/scale - t1
 // plus the products of the projector that depend on the row only, each rounded once exactly as the per-pixel
@@ -126,7 +127,11 @@ __global__ __launch_bounds__(256) void warp_tables_kernel(WarpBatchK B)
         const int slot = i - P.dw, r = min(slot, P.dh - 1);  // the padding rows repeat the last row
         const float vv = (float)(P.tly + r);
         float ra = 0.f, rb = 0.f;
-        if (TYPE == STX_WARP_SPHERICAL) sincosf_x(fsub(PI_F, fdiv(vv, P.scale)), &ra, &rb);
+        if (TYPE == STX_WARP_SPHERICAL && P.family == STX_F_MERCATOR) {
+            // MercatorProjector::mapBackward is the sphere's with another latitude: v_ = atan(sinh(v')), x_ = cos v_ sin u',
+            // y_ = sin v_, z_ = cos v_ cos u' — the same per-pixel arithmetic from a different row table
+            sincosf_x(atanf_x(sinhf_x(fdiv(vv, P.scale))), &rb, &ra);
+        } else if (TYPE == STX_WARP_SPHERICAL) sincosf_x(fsub(PI_F, fdiv(vv, P.scale)), &ra, &rb);
         else if (TYPE == STX_WARP_CYLINDRICAL) ra = fdiv(vv, P.scale);
         else ra = fsub(fdiv(vv, P.scale), P.t[1]);
         const float y_ = TYPE == STX_WARP_SPHERICAL ? rb : ra;
@@ -647,88 +652,130 @@ STX_DEV void put_px(uint32_t (&out)[3], int j, uint32_t px)
     else out[2] |= px << 8;
 }
 
-__device__ __noinline__ void backward_dir(int family, float a, float b, float scale, float u, float v, float* out3)
+// Family groups of the per-pixel kernel.  What depends on the destination column alone (u') or on the row alone (v') is
+// evaluated once per workgroup tile (256 columns x 16 rows) into LDS; a pixel pays only for the inseparable rest:
+//   fisheye / stereographic : nothing separable                      pixel: atan2, sqrt (+ atan), 2 sincos
+//   compressed rectilinear  : col u_ = a atan(u'/a), sincos(u_)      pixel: atan, sincos
+//   panini                  : col u_, sincos(u_), b a tan(u_/a)      pixel: atan, sincos
+//   transverse mercator     : col sinh u', cosh u'; row sincos(v')   pixel: asin, atan2, 2 sincos
+// Every fp32 step is OpenCV's mapBackward step (warpers_inl.hpp: same operands, same order, each rounded to fp32 separately):
+//   u' = u / scale (portrait: / -scale), v' = v / scale, then per family as in gen_col / gen_row / gen_dir below; the portrait
+//   variants swap x_ and y_ at the end.
+enum { GEN_FISH = 0, GEN_CRECT, GEN_PANINI, GEN_TMERC };
+constexpr int GEN_TH = 16;  // tile rows
+
+template <int G>
+STX_DEV float4 gen_col(const WarpK& P, float upx)
 {
-    float x_, y_, z_;
-    const bool portrait = family == STX_F_CRECT_PORTRAIT || family == STX_F_PANINI_PORTRAIT;
-    u = fdiv(u, portrait ? -scale : scale);
-    v = fdiv(v, scale);
-    if (family == STX_F_FISHEYE || family == STX_F_STEREOGRAPHIC) {
+    const bool portrait = P.family == STX_F_CRECT_PORTRAIT || P.family == STX_F_PANINI_PORTRAIT;
+    const float u = fdiv(upx, portrait ? -P.scale : P.scale);
+    float4 o = make_float4(u, 0.f, 0.f, 0.f);
+    if (G == GEN_CRECT || G == GEN_PANINI) {
+        const float u_ = fmul(P.pa, atanf_x(fdiv(u, P.pa)));
+        sincosf_x(u_, &o.x, &o.y);  // sinf_x(u_) / cosf_x(u_) are these very values
+        if (G == GEN_PANINI) {
+            o.z = fmul(fmul(P.pb, P.pa), tanf_x(fdiv(u_, P.pa)));
+            o.w = u_ == u_ ? 1.f : 0.f;
+        }
+    } else if (G == GEN_TMERC) {
+        o.x = sinhf_x(u);
+        o.y = coshf_x(u);
+    }
+    return o;
+}
+
+template <int G>
+STX_DEV float2 gen_row(const WarpK& P, float vpx)
+{
+    const float v = fdiv(vpx, P.scale);
+    float2 o = make_float2(v, 0.f);
+    if (G == GEN_TMERC) sincosf_x(v, &o.x, &o.y);
+    return o;
+}
+
+template <int G>
+STX_DEV void gen_dir(const WarpK& P, const float4 c, const float2 r, float& x_, float& y_, float& z_)
+{
+    if (G == GEN_FISH) {
+        const float u = c.x, v = r.x;
         const float u_ = atan2f_x(v, u);
-        const float r = fsqrt(fadd(fmul(u, u), fmul(v, v)));
-        const float v_ = family == STX_F_FISHEYE ? r : fmul(2.f, atanf_x(fdiv(1.f, r)));
+        const float rad = fsqrt(fadd(fmul(u, u), fmul(v, v)));
+        const float v_ = P.family == STX_F_FISHEYE ? rad : fmul(2.f, atanf_x(fdiv(1.f, rad)));
         float sinv, cosv, su, cu;
         sincosf_x(fsub(PI_F, v_), &sinv, &cosv);
         sincosf_x(u_, &su, &cu);
         x_ = fmul(sinv, su);
         y_ = cosv;
         z_ = fmul(sinv, cu);
-    } else {
-        float u_, v_;
-        if (family == STX_F_CRECT || family == STX_F_CRECT_PORTRAIT) {
-            u_ = fmul(a, atanf_x(fdiv(u, a)));
-            v_ = atanf_x(fdiv(fmul(v, cosf_x(u_)), b));
-        } else if (family == STX_F_PANINI || family == STX_F_PANINI_PORTRAIT) {
-            u_ = fmul(a, atanf_x(fdiv(u, a)));
-            if (u_ == u_) v_ = atanf_x(fdiv(fmul(v, sinf_x(u_)), fmul(fmul(b, a), tanf_x(fdiv(u_, a)))));
-            else v_ = 0.f;
-        } else if (family == STX_F_MERCATOR) {
-            v_ = atanf_x(sinhf_x(v));
-            u_ = u;
-        } else {  // transverse mercator
-            v_ = asinf_x(fdiv(sinf_x(v), coshf_x(u)));
-            u_ = atan2f_x(sinhf_x(u), cosf_x(v));
-        }
-        float sv, cv, su, cu;
-        sincosf_x(v_, &sv, &cv);
-        sincosf_x(u_, &su, &cu);
-        x_ = fmul(cv, su);
-        y_ = sv;
-        z_ = fmul(cv, cu);
-        if (portrait) { const float t = x_; x_ = y_; y_ = t; }
+        return;
     }
-    out3[0] = x_; out3[1] = y_; out3[2] = z_;
+    float su, cu, v_;
+    if (G == GEN_CRECT) {
+        su = c.x; cu = c.y;
+        v_ = atanf_x(fdiv(fmul(r.x, cu), P.pb));
+    } else if (G == GEN_PANINI) {
+        su = c.x; cu = c.y;
+        v_ = c.w != 0.f ? atanf_x(fdiv(fmul(r.x, su), c.z)) : 0.f;
+    } else {
+        v_ = asinf_x(fdiv(r.x, c.y));
+        sincosf_x(atan2f_x(c.x, r.y), &su, &cu);
+    }
+    float sv, cv;
+    sincosf_x(v_, &sv, &cv);
+    x_ = fmul(cv, su);
+    y_ = sv;
+    z_ = fmul(cv, cu);
+    if (P.family == STX_F_CRECT_PORTRAIT || P.family == STX_F_PANINI_PORTRAIT) { const float t = x_; x_ = y_; y_ = t; }
 }
 
-template <bool IMG, bool MASK>
+template <int G, bool IMG, bool MASK>
 __global__ __launch_bounds__(256) void warp_general_kernel(WarpK P)
 {
-    const int lane = threadIdx.x & 63;
-    const int x0 = blockIdx.x * WARP_TW + lane * 4;
-    const int y = blockIdx.y * WARP_TH + (threadIdx.x >> 6);
-    if (x0 >= P.dw || y >= P.dh) return;
-    uint32_t out[3] = {0, 0, 0};
-    uint32_t mout = 0;
-    const float vv = (float)(P.tly + y);
+    __shared__ float4 s_col[WARP_TW];
+    __shared__ float2 s_row[GEN_TH];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tx0 = blockIdx.x * WARP_TW, ty0 = blockIdx.y * GEN_TH;
+    s_col[tid] = gen_col<G>(P, (float)(P.tlx + min(tx0 + tid, P.dw - 1)));
+    if (tid < GEN_TH) s_row[tid] = gen_row<G>(P, (float)(P.tly + min(ty0 + tid, P.dh - 1)));
+    __syncthreads();
+    const int x0 = tx0 + lane * 4;
+    if (x0 >= P.dw) return;
+    for (int it = 0; it < GEN_TH / 4; it++) {
+        const int yl = it * 4 + wv, y = ty0 + yl;
+        if (y >= P.dh) break;
+        const float2 rw = s_row[yl];
+        uint32_t out[3] = {0, 0, 0};
+        uint32_t mout = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        float d[3];
-        backward_dir(P.family, P.pa, P.pb, P.scale, (float)(P.tlx + x0 + j), vv, d);
-        float x = dot3(P.kr[0], d[0], P.kr[1], d[1], P.kr[2], d[2]);
-        float yy = dot3(P.kr[3], d[0], P.kr[4], d[1], P.kr[5], d[2]);
-        const float z = dot3(P.kr[6], d[0], P.kr[7], d[1], P.kr[8], d[2]);
-        if (z > 0) {
-            x = fdiv(x, z);
-            yy = fdiv(yy, z);
-        } else {
-            x = yy = -1.f;
+        for (int j = 0; j < 4; j++) {
+            float d0, d1, d2;
+            gen_dir<G>(P, s_col[lane * 4 + j], rw, d0, d1, d2);
+            float x = dot3(P.kr[0], d0, P.kr[1], d1, P.kr[2], d2);
+            float yy = dot3(P.kr[3], d0, P.kr[4], d1, P.kr[5], d2);
+            const float z = dot3(P.kr[6], d0, P.kr[7], d1, P.kr[8], d2);
+            if (z > 0) {
+                x = fdiv(x, z);
+                yy = fdiv(yy, z);
+            } else {
+                x = yy = -1.f;
+            }
+            if (IMG) put_px(out, j, sample_generic(P, x, yy));
+            if (MASK) {
+                int nx = sat_s16(cv_round(x)), ny = sat_s16(cv_round(yy));
+                uint32_t m = 0;
+                if ((unsigned)nx < (unsigned)P.sw && (unsigned)ny < (unsigned)P.sh)
+                    m = P.msrc ? (uint32_t)P.msrc[(long long)ny * P.msstride + nx] : 255u;
+                mout |= m << (8 * j);
+            }
         }
-        if (IMG) put_px(out, j, sample_generic(P, x, yy));
-        if (MASK) {
-            int nx = sat_s16(cv_round(x)), ny = sat_s16(cv_round(yy));
-            uint32_t m = 0;
-            if ((unsigned)nx < (unsigned)P.sw && (unsigned)ny < (unsigned)P.sh)
-                m = P.msrc ? (uint32_t)P.msrc[(long long)ny * P.msstride + nx] : 255u;
-            mout |= m << (8 * j);
+        if (IMG) {
+            uint32_t* d = reinterpret_cast<uint32_t*>(P.dimg + (long long)y * P.dimg_stride + (long long)x0 * 3);
+            d[0] = out[0];
+            d[1] = out[1];
+            d[2] = out[2];
         }
+        if (MASK) *reinterpret_cast<uint32_t*>(P.dmask + (long long)y * P.dmask_stride + x0) = mout;
     }
-    if (IMG) {
-        uint32_t* d = reinterpret_cast<uint32_t*>(P.dimg + (long long)y * P.dimg_stride + (long long)x0 * 3);
-        d[0] = out[0];
-        d[1] = out[1];
-        d[2] = out[2];
-    }
-    if (MASK) *reinterpret_cast<uint32_t*>(P.dmask + (long long)y * P.dmask_stride + x0) = mout;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -937,15 +984,30 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
 }
 
 // per-pixel projector warpers: one launch per image
+template <int G>
+void launch_general_group(stx_ctx* ctx, const WarpK& K, bool img, bool mask)
+{
+    const dim3 grid((K.dw + WARP_TW - 1) / WARP_TW, (K.dh + GEN_TH - 1) / GEN_TH);
+    if (img && mask) hipLaunchKernelGGL((warp_general_kernel<G, true, true>), grid, dim3(256), 0, ctx->stream, K);
+    else if (img) hipLaunchKernelGGL((warp_general_kernel<G, true, false>), grid, dim3(256), 0, ctx->stream, K);
+    else hipLaunchKernelGGL((warp_general_kernel<G, false, true>), grid, dim3(256), 0, ctx->stream, K);
+}
+
 int launch_general(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, const char* prof_name, const double* algo_bytes)
 {
     for (int i = 0; i < n; i++) {
         StxProfScope prof(ctx, prof_name, algo_bytes[i]);
         const WarpK& K = Ks[i];
-        const dim3 grid((K.dw + WARP_TW - 1) / WARP_TW, (K.dh + WARP_TH - 1) / WARP_TH);
-        if (img && mask) hipLaunchKernelGGL((warp_general_kernel<true, true>), grid, dim3(256), 0, ctx->stream, K);
-        else if (img) hipLaunchKernelGGL((warp_general_kernel<true, false>), grid, dim3(256), 0, ctx->stream, K);
-        else hipLaunchKernelGGL((warp_general_kernel<false, true>), grid, dim3(256), 0, ctx->stream, K);
+        switch (K.family) {
+        case STX_F_FISHEYE:
+        case STX_F_STEREOGRAPHIC: launch_general_group<GEN_FISH>(ctx, K, img, mask); break;
+        case STX_F_CRECT:
+        case STX_F_CRECT_PORTRAIT: launch_general_group<GEN_CRECT>(ctx, K, img, mask); break;
+        case STX_F_PANINI:
+        case STX_F_PANINI_PORTRAIT: launch_general_group<GEN_PANINI>(ctx, K, img, mask); break;
+        case STX_F_TRANSVERSE_MERCATOR: launch_general_group<GEN_TMERC>(ctx, K, img, mask); break;
+        default: return stx_fail(STX_ERR_INVALID, "no per-pixel kernel for projector family %d", K.family);
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return stx_fail(STX_ERR_HIP, "warp kernel launch failed: %s", hipGetErrorString(e));
@@ -993,7 +1055,7 @@ void fill_warpk(const StxWarpLaunch& L, WarpK* Kp, double* bytes)
         const double umax = std::max(std::fabs((double)L.tlx), std::fabs((double)L.tlx + L.dw)) / std::max(sc, 1e-30);
         const double vmax = std::max(std::fabs((double)L.tly), std::fabs((double)L.tly + L.dh)) / std::max(sc, 1e-30);
         double bx = 1.0001, by = 1.0001, bz = 1.0001;
-        if (L.proj.family == STX_F_SPHERICAL) ok = ok && umax < 5e5 && vmax < 5e5;
+        if (L.proj.family == STX_F_SPHERICAL || L.proj.family == STX_F_MERCATOR) ok = ok && umax < 5e5 && vmax < 5e5;
         else if (L.proj.family == STX_F_CYLINDRICAL) { ok = ok && umax < 5e5; by = vmax * 1.0001; }
         else { bx = (umax + std::fabs((double)K.t[0])) * 1.0001; by = (vmax + std::fabs((double)K.t[1])) * 1.0001; bz = (1.0 + std::fabs((double)K.t[2])) * 1.0001; }
         for (int r = 0; r < 2; r++)
@@ -1023,7 +1085,9 @@ int stx_launch_warp_batch(stx_ctx* ctx, const StxWarpLaunch* Ls, int n)
     switch (Ls[0].proj.family) {
     case STX_F_PLANE: return launch_typed<STX_WARP_PLANE>(ctx, Ks.data(), n, img, mask, name, bytes.data());
     case STX_F_CYLINDRICAL: return launch_typed<STX_WARP_CYLINDRICAL>(ctx, Ks.data(), n, img, mask, name, bytes.data());
-    case STX_F_SPHERICAL: return launch_typed<STX_WARP_SPHERICAL>(ctx, Ks.data(), n, img, mask, name, bytes.data());
+    case STX_F_SPHERICAL:
+    case STX_F_MERCATOR:  // separable like the sphere (row table: warp_tables_kernel)
+        return launch_typed<STX_WARP_SPHERICAL>(ctx, Ks.data(), n, img, mask, name, bytes.data());
     default: return launch_general(ctx, Ks.data(), n, img, mask, name, bytes.data());
     }
 }
