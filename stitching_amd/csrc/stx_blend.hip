@@ -910,6 +910,7 @@ __global__ __launch_bounds__(256) void dilate3x3_kernel(const uint8_t* __restric
     dst[(long long)y * dstride + x] = (uint8_t)m;
 }
 
+constexpr int SEAM_ROWS = 16;  // destination rows per lane (seam_resize4_body)
 STX_DEV void seam_resize4_body(const ResizeK& P);
 __global__ __launch_bounds__(256) void seam_resize4_kernel(ResizeK P) { seam_resize4_body(P); }  // P.src: the dilated low-resolution mask
 // all seam masks of a panorama in one launch each (blockIdx.z = image); the argument blocks travel as kernel arguments
@@ -933,39 +934,49 @@ __global__ __launch_bounds__(256) void dilate3x3_batch_kernel(SeamBatchK B)
         }
     const_cast<uint8_t*>(P.src)[(long long)y * P.sstride + x] = (uint8_t)m;
 }
+// One lane = 4 adjacent columns of SEAM_ROWS consecutive destination rows.  The seam masks are enlarged (0.1 Mpix -> final
+// size, about 11 x): consecutive destination rows interpolate between the same two source rows, so the horizontal sums
+// (8.8 fixed point) are kept in registers and recomputed only when the source row changes (a wave-uniform test: the row is);
+// a destination pixel then costs the vertical blend, the AND and a quarter of a dword store.
 STX_DEV void seam_resize4_body(const ResizeK& P)
 {
     const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int y = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (x4 >= P.dw || y >= P.dh) return;
-    const int2 ty = P.yt[y];
-    const int oy = ty.x, oy1 = min(oy + 1, P.sh - 1);
-    const uint32_t cy1 = (uint32_t)ty.y & 0xffffu, cy0 = 256u - cy1;
-    const bool iy = (ty.y >> 16) != 0;
-    const uint8_t* r0 = P.src + (long long)oy * P.sstride;
-    const uint8_t* r1 = P.src + (long long)oy1 * P.sstride;
-    uint32_t out = 0;
+    const int yb = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * SEAM_ROWS;
+    if (x4 >= P.dw || yb >= P.dh) return;
     // the table holds dw entries rounded up to 4 (host), so the four reads are always inside it
     const int4 ta = *reinterpret_cast<const int4*>(P.xt + x4), tb = *reinterpret_cast<const int4*>(P.xt + x4 + 2);
     const int ox[4] = {ta.x, ta.z, tb.x, tb.z}, cf[4] = {ta.y, ta.w, tb.y, tb.w};
+    uint32_t h0[4] = {0, 0, 0, 0}, h1[4] = {0, 0, 0, 0};
+    int cur = -1;
+    for (int r = 0; r < SEAM_ROWS; r++) {
+        const int y = yb + r;
+        if (y >= P.dh) break;
+        const int2 ty = P.yt[y];
+        if (ty.x != cur) {
+            cur = ty.x;
+            const uint8_t* r0 = P.src + (long long)cur * P.sstride;
+            const uint8_t* r1 = P.src + (long long)min(cur + 1, P.sh - 1) * P.sstride;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int o0 = ox[j], o1 = min(o0 + 1, P.sw - 1);
-        const uint32_t cx1 = (uint32_t)cf[j] & 0xffffu, cx0 = 256u - cx1;
-        const uint32_t h0 = (uint32_t)r0[o0] * cx0 + (uint32_t)r0[o1] * cx1;
-        uint32_t v;
-        if (iy) {
-            const uint32_t h1 = (uint32_t)r1[o0] * cx0 + (uint32_t)r1[o1] * cx1;
-            v = (h0 * cy0 + h1 * cy1 + 32768u) >> 16;
-        } else {
-            v = (h0 + 128u) >> 8;
+            for (int j = 0; j < 4; j++) {
+                const int o0 = ox[j], o1 = min(o0 + 1, P.sw - 1);
+                const uint32_t cx1 = (uint32_t)cf[j] & 0xffffu, cx0 = 256u - cx1;
+                h0[j] = (uint32_t)r0[o0] * cx0 + (uint32_t)r0[o1] * cx1;
+                h1[j] = (uint32_t)r1[o0] * cx0 + (uint32_t)r1[o1] * cx1;
+            }
         }
-        out |= min(v, 255u) << (8 * j);
+        const uint32_t cy1 = (uint32_t)ty.y & 0xffffu, cy0 = 256u - cy1;
+        const bool iy = (ty.y >> 16) != 0;
+        uint32_t out = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t v = iy ? (h0[j] * cy0 + h1[j] * cy1 + 32768u) >> 16 : (h0[j] + 128u) >> 8;
+            out |= min(v, 255u) << (8 * j);
+        }
+        out &= *reinterpret_cast<const uint32_t*>(P.andmask + (long long)y * P.amstride + x4);
+        uint8_t* d = P.dst + (long long)y * P.dstride + x4;
+        if (x4 + 4 <= P.dw) *reinterpret_cast<uint32_t*>(d) = out;
+        else for (int j = 0; x4 + j < P.dw; j++) d[j] = (uint8_t)(out >> (8 * j));
     }
-    out &= *reinterpret_cast<const uint32_t*>(P.andmask + (long long)y * P.amstride + x4);
-    uint8_t* d = P.dst + (long long)y * P.dstride + x4;
-    if (x4 + 4 <= P.dw) *reinterpret_cast<uint32_t*>(d) = out;
-    else for (int j = 0; x4 + j < P.dw; j++) d[j] = (uint8_t)(out >> (8 * j));
 }
 }  // namespace
 
@@ -991,7 +1002,7 @@ int stx_launch_seam_resize_batch(stx_ctx* ctx, int n, const stx_buf* const* seam
         }
         StxProfScope prof(ctx, "seam_mask_resize", bytes);
         hipLaunchKernelGGL(dilate3x3_batch_kernel, dim3((msw + 63) / 64, (msh + 3) / 4, m), dim3(256), 0, ctx->stream, B);
-        hipLaunchKernelGGL(seam_resize4_batch_kernel, dim3((mdw + 255) / 256, (mdh + 3) / 4, m), dim3(256), 0, ctx->stream, B);
+        hipLaunchKernelGGL(seam_resize4_batch_kernel, dim3((mdw + 255) / 256, (mdh + 4 * SEAM_ROWS - 1) / (4 * SEAM_ROWS), m), dim3(256), 0, ctx->stream, B);
     }
     return check_launch("seam_mask_resize");
 }
@@ -1017,7 +1028,7 @@ int stx_launch_resize_exact(stx_ctx* ctx, const stx_buf* src, stx_buf* dst, cons
         hipLaunchKernelGGL(dilate3x3_kernel, dim3((src->w + 63) / 64, (src->h + 3) / 4), dim3(256), 0, ctx->stream, src->ptr,
                            (long long)src->stride, src->w, src->h, (uint8_t*)tmp, (long long)tstride);
         K.src = (const uint8_t*)tmp; K.sstride = (long long)tstride;
-        hipLaunchKernelGGL(seam_resize4_kernel, dim3((dst->w + 255) / 256, (dst->h + 3) / 4), dim3(256), 0, ctx->stream, K);
+        hipLaunchKernelGGL(seam_resize4_kernel, dim3((dst->w + 255) / 256, (dst->h + 4 * SEAM_ROWS - 1) / (4 * SEAM_ROWS)), dim3(256), 0, ctx->stream, K);
         stx_dev_free(ctx, tmp);  // stream-ordered reuse
     } else if (dilate) hipLaunchKernelGGL((resize_exact_kernel<1, true>), grid, dim3(256), 0, ctx->stream, K);
     else if (src->c == 1) hipLaunchKernelGGL((resize_exact_kernel<1, false>), grid, dim3(256), 0, ctx->stream, K);
