@@ -1442,12 +1442,14 @@ STX_EXPORT int stx_blend_feed_ex(stx_blender* b, const stx_buf* img, const stx_b
     im.dstride = ((long long)img->w + 15) & ~15ll;
     im.n_chunks = (img->h + STX_DT_RC - 1) / STX_DT_RC;
     void *wm = nullptr, *summ = nullptr;
-    STX_TRY(stx_dev_alloc(b->ctx, sizeof(float) * (size_t)im.dstride * img->h, &wm));
+    STX_TRY(stx_dev_alloc(b->ctx, sizeof(uint16_t) * (size_t)im.dstride * img->h, &wm));
     b->pyr_allocs.push_back(wm);
-    STX_TRY(stx_dev_alloc(b->ctx, sizeof(int) * 2 * (size_t)im.dstride * im.n_chunks, &summ));
+    // per (chunk, column): the zero rows as a 64-bit set, then the first and the last of them
+    STX_TRY(stx_dev_alloc(b->ctx, (sizeof(unsigned long long) + 2 * sizeof(int)) * (size_t)im.dstride * im.n_chunks, &summ));
     b->pyr_allocs.push_back(summ);
-    im.wmap = (float*)wm;
-    im.first = (int*)summ; im.last = im.first + (size_t)im.dstride * im.n_chunks;
+    im.dist = (uint16_t*)wm;
+    im.zbits = (unsigned long long*)summ;
+    im.first = (int*)(im.zbits + (size_t)im.dstride * im.n_chunks); im.last = im.first + (size_t)im.dstride * im.n_chunks;
     b->feather_images.push_back(im);
     stx_buf_retain(const_cast<stx_buf*>(img));
     stx_buf_retain(const_cast<stx_buf*>(mask));
@@ -1830,11 +1832,11 @@ static int feather_finish(stx_blender* b, stx_buf* pano, stx_buf* pmask, stx_buf
     void* d_tab = nullptr;
     STX_TRY(upload_small(ctx, b->feather_images.data(), sizeof(FeatherImg) * (size_t)n, &d_tab));
     b->pyr_allocs.push_back(d_tab);
-    STX_TRY(stx_launch_feather_weights(ctx, (const FeatherImg*)d_tab, b->feather_images.data(), n, b->sharpness));
+    STX_TRY(stx_launch_feather_weights(ctx, (const FeatherImg*)d_tab, b->feather_images.data(), n));
     double bytes = 4.0 * pano->w * pano->h + (p16 ? 6.0 * pano->w * pano->h : 0.0);
-    for (const FeatherImg& im : b->feather_images) bytes += (double)im.w * im.h * ((im.is_s16 ? 6 : 3) + 4);
+    for (const FeatherImg& im : b->feather_images) bytes += (double)im.w * im.h * ((im.is_s16 ? 6 : 3) + 2);
     FeatherGatherK K;
-    K.imgs = (const FeatherImg*)d_tab; K.n = n; K.w = pano->w; K.h = pano->h;
+    K.imgs = (const FeatherImg*)d_tab; K.n = n; K.w = pano->w; K.h = pano->h; K.sharpness = b->sharpness;
     K.pano = pano->ptr; K.pano_stride = (long long)pano->stride; K.pmask = pmask->ptr; K.pmask_stride = (long long)pmask->stride;
     K.pano16 = p16 ? (short*)p16->ptr : nullptr; K.pano16_stride = p16 ? (long long)p16->stride : 0;
     return stx_launch_feather_gather(ctx, K, bytes);

@@ -271,35 +271,34 @@ __global__ __launch_bounds__(256) void mb_level_multi_kernel(const MbLevelK* __r
 // distanceTransform(mask, DIST_L1, 3): exact city-block distance to the nearest zero pixel, as two separable passes
 // that are plain prefix / suffix minima and therefore parallel:
 //   columns: g(x, y) = min(y - last zero row <= y, first zero row >= y - y), INF when the column has no zero.
-//            Chunks of DT_RC rows: kernel 1 records each chunk's first / last zero row, kernel 2 folds the summaries of
-//            the chunks above / below (<= h / DT_RC coalesced loads) and sweeps its own rows.  Lanes run along x.
+//            Chunks of DT_RC = 64 rows.  Kernel 1 reads the mask once and keeps, per (chunk, column), the zero rows as a
+//            64-bit set plus its first / last member.  Kernel 2 folds the summaries of the chunks above / below (<= h / 64
+//            coalesced loads) and writes its 64 rows straight from the bit set: distance up = a running counter, distance
+//            down = count-trailing-zeros of the shifted set.  Lanes run along x, 4 columns each.
 //   rows:    f(x) = min_x' (|x - x'| + g(x')) = min( x + min_{x'<=x} (g(x') - x'),  -x + min_{x'>=x} (g(x') + x') ):
-//            one wavefront per row, 256 pixels per step (16-byte loads), wave-level min scans, a scalar carry between
-//            steps; the backward sweep also produces the weight map
+//            one wavefront per row, 256 pixels per step, wave-level min scans, a scalar carry between steps; the forward
+//            sweep parks its result in LDS (lane-private slots), the backward sweep overwrites the row in place.
+// Distances are stored as 16 bits, saturated at 8192: the weight is
 //            weight = min(dist * sharpness, 1), dist = (L1 >= 8192 or no zero) ? 8192.f : (float)L1
-//            (distanceTransform_3x3's 16.16 fixed point saturates at INT_MAX >> 2, i.e. 8192.0f).
+//            (distanceTransform_3x3's 16.16 fixed point saturates at INT_MAX >> 2, i.e. 8192.0f), min commutes with the
+//            saturation, and the gather kernel makes the weight from the distance on the fly.
+// HBM traffic per mask pixel: 1 (mask) + 1/8 + 1/8 (bit sets) + 2 (g) + 2 + 2 (f in place) — it was 30 with fp32 maps, a
+// second mask read and both sweeps of both passes through memory.
 // Same integers as the serial recurrences cur = min(v, cur + 1) of the reference.
 constexpr int DT_INF = 1 << 28;
 constexpr int DT_RC = STX_DT_RC;
-STX_DEV int wave_excl_prefix_min(int v, int lane)  // min over lanes < lane (INT_MAX for lane 0)
+// min over the lanes below this one (INT_MAX for lane 0): a DPP scan — shifts inside the 16-lane rows, then the row_bcast steps
+// of the wave64 scan idiom, then one wave_shr to make it exclusive.  (The shuffle form costs 7 LDS-crossbar permutes.)
+STX_DEV int wave_excl_prefix_min(int v)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(v, o);
-        if (lane >= o) v = min(v, t);
-    }
-    const int e = __shfl_up(v, 1);
-    return lane == 0 ? 0x7fffffff : e;
-}
-STX_DEV int wave_excl_suffix_min(int v, int lane)  // min over lanes > lane
-{
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_down(v, o);
-        if (lane + o < 64) v = min(v, t);
-    }
-    const int e = __shfl_down(v, 1);
-    return lane == 63 ? 0x7fffffff : e;
+    constexpr int ID = 0x7fffffff;
+    v = min(v, __builtin_amdgcn_update_dpp(ID, v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = min(v, __builtin_amdgcn_update_dpp(ID, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = min(v, __builtin_amdgcn_update_dpp(ID, v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = min(v, __builtin_amdgcn_update_dpp(ID, v, 0x118, 0xf, 0xf, false));  // row_shr:8
+    v = min(v, __builtin_amdgcn_update_dpp(ID, v, 0x142, 0xa, 0xf, false));  // row_bcast:15 -> rows 1, 3
+    v = min(v, __builtin_amdgcn_update_dpp(ID, v, 0x143, 0xc, 0xf, false));  // row_bcast:31 -> rows 2, 3
+    return __builtin_amdgcn_update_dpp(ID, v, 0x138, 0xf, 0xf, false);       // wave_shr:1
 }
 
 int check_launch(const char* what)
@@ -414,105 +413,163 @@ __global__ __launch_bounds__(64) void dt_col_summary_batch_kernel(const FeatherI
     const int x = (blockIdx.x * 64 + threadIdx.x) * 4, c = blockIdx.y;
     if (x >= P.w || c >= P.n_chunks) return;
     const int y0 = c * DT_RC, y1 = min(P.h, y0 + DT_RC);
-    int f[4] = {DT_INF, DT_INF, DT_INF, DT_INF}, l[4] = {-DT_INF, -DT_INF, -DT_INF, -DT_INF};
-    for (int y = y0; y < y1; y++) {
-        const uint32_t m = dt_mask4(P, x, y);
+    uint32_t zb[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};  // zero rows of the chunk: rows 0..31, 32..63
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (((m >> (8 * j)) & 255u) == 0) {
-                if (f[j] == DT_INF) f[j] = y;
-                l[j] = y;
-            }
+    for (int hf = 0; hf < 2; hf++) {
+        if (y0 + 32 * hf >= y1) break;
+#pragma unroll 8
+        for (int r = 0; r < 32; r++) {
+            const int y = y0 + 32 * hf + r;
+            if (y >= y1) break;
+            const uint32_t m = dt_mask4(P, x, y);
+#pragma unroll
+            for (int j = 0; j < 4; j++) zb[hf][j] |= (((m >> (8 * j)) & 255u) == 0 ? 1u : 0u) << r;
+        }
+    }
+    int f[4], l[4];
+    unsigned long long bits[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        bits[j] = (unsigned long long)zb[0][j] | ((unsigned long long)zb[1][j] << 32);
+        f[j] = bits[j] ? y0 + (int)__builtin_ctzll(bits[j]) : DT_INF;
+        l[j] = bits[j] ? y0 + 63 - (int)__builtin_clzll(bits[j]) : -DT_INF;
     }
     *reinterpret_cast<int4*>(P.first + (long long)c * P.dstride + x) = make_int4(f[0], f[1], f[2], f[3]);
     *reinterpret_cast<int4*>(P.last + (long long)c * P.dstride + x) = make_int4(l[0], l[1], l[2], l[3]);
+    unsigned long long* zo = P.zbits + (long long)c * P.dstride + x;
+    *reinterpret_cast<ulonglong2*>(zo) = make_ulonglong2(bits[0], bits[1]);
+    *reinterpret_cast<ulonglong2*>(zo + 2) = make_ulonglong2(bits[2], bits[3]);
+}
+// first[c] <- first zero row below chunk c, last[c] <- last zero row above it (in place, one lane per 4 columns, chunks in turn)
+__global__ __launch_bounds__(64) void dt_col_link_batch_kernel(const FeatherImg* __restrict__ imgs)
+{
+    const FeatherImg& P = imgs[blockIdx.y];
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (x >= P.w) return;
+    int4 run = make_int4(-DT_INF, -DT_INF, -DT_INF, -DT_INF);
+    for (int c = 0; c < P.n_chunks; c++) {
+        int4* q = reinterpret_cast<int4*>(P.last + (long long)c * P.dstride + x);
+        const int4 v = *q;
+        *q = run;
+        run = make_int4(max(run.x, v.x), max(run.y, v.y), max(run.z, v.z), max(run.w, v.w));
+    }
+    run = make_int4(DT_INF, DT_INF, DT_INF, DT_INF);
+    for (int c = P.n_chunks - 1; c >= 0; c--) {
+        int4* q = reinterpret_cast<int4*>(P.first + (long long)c * P.dstride + x);
+        const int4 v = *q;
+        *q = run;
+        run = make_int4(min(run.x, v.x), min(run.y, v.y), min(run.z, v.z), min(run.w, v.w));
+    }
 }
 __global__ __launch_bounds__(64) void dt_col_fill_batch_kernel(const FeatherImg* __restrict__ imgs)
 {
     const FeatherImg& P = imgs[blockIdx.z];
     const int x = (blockIdx.x * 64 + threadIdx.x) * 4, c = blockIdx.y;
-    if (x >= P.w || c >= P.n_chunks) return;
-    int* d = reinterpret_cast<int*>(P.wmap);
-    int prev[4] = {-DT_INF, -DT_INF, -DT_INF, -DT_INF}, next[4] = {DT_INF, DT_INF, DT_INF, DT_INF};
-    for (int k = 0; k < c; k++) {
-        const int4 v = *reinterpret_cast<const int4*>(P.last + (long long)k * P.dstride + x);
-        prev[0] = max(prev[0], v.x); prev[1] = max(prev[1], v.y); prev[2] = max(prev[2], v.z); prev[3] = max(prev[3], v.w);
+    if (x >= P.dstride || c >= P.n_chunks) return;
+    if (x >= P.w) {  // row padding: "no zero anywhere near" for the 8-pixel groups of the row pass
+        for (int y = c * DT_RC; y < min(P.h, c * DT_RC + DT_RC); y++)
+            *reinterpret_cast<uint2*>(P.dist + (long long)y * P.dstride + x) = make_uint2(0x20002000u, 0x20002000u);
+        return;
     }
-    for (int k = P.n_chunks - 1; k > c; k--) {
-        const int4 v = *reinterpret_cast<const int4*>(P.first + (long long)k * P.dstride + x);
-        next[0] = min(next[0], v.x); next[1] = min(next[1], v.y); next[2] = min(next[2], v.z); next[3] = min(next[3], v.w);
-    }
+    const int4 pv = *reinterpret_cast<const int4*>(P.last + (long long)c * P.dstride + x);
+    const int4 nv = *reinterpret_cast<const int4*>(P.first + (long long)c * P.dstride + x);
+    const int prev[4] = {pv.x, pv.y, pv.z, pv.w}, next[4] = {nv.x, nv.y, nv.z, nv.w};
     const int y0 = c * DT_RC, y1 = min(P.h, y0 + DT_RC);
-    for (int y = y0; y < y1; y++) {
-        const uint32_t m = dt_mask4(P, x, y);
-        int o[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (((m >> (8 * j)) & 255u) == 0) prev[j] = y;
-            o[j] = prev[j] == -DT_INF ? DT_INF : y - prev[j];
-        }
-        *reinterpret_cast<int4*>(d + (long long)y * P.dstride + x) = make_int4(o[0], o[1], o[2], o[3]);
+    unsigned long long bits[4];
+    {
+        const unsigned long long* zi = P.zbits + (long long)c * P.dstride + x;
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(zi), b = *reinterpret_cast<const ulonglong2*>(zi + 2);
+        bits[0] = a.x; bits[1] = a.y; bits[2] = b.x; bits[3] = b.y;
     }
-    for (int y = y1 - 1; y >= y0; y--) {
-        int4* q = reinterpret_cast<int4*>(d + (long long)y * P.dstride + x);
-        const int4 v = *q;
-        const int vv[4] = {v.x, v.y, v.z, v.w};
-        int o[4];
+    int up[4];  // distance to the last zero row above the chunk (as seen from row y0 - 1)
+#pragma unroll
+    for (int j = 0; j < 4; j++) up[j] = prev[j] == -DT_INF ? DT_INF : y0 - 1 - prev[j];
+#pragma unroll 8
+    for (int r = 0; r < DT_RC; r++) {
+        const int y = y0 + r;
+        if (y >= y1) break;
+        uint32_t o[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            if (vv[j] == 0) next[j] = y;
-            o[j] = min(vv[j], next[j] == DT_INF ? DT_INF : next[j] - y);
+            const unsigned long long t = bits[j] >> r;  // the zero rows from this one on
+            up[j] = (t & 1ull) ? 0 : min(up[j] + 1, DT_INF);
+            const int dn = t ? (int)__builtin_ctzll(t) : (next[j] == DT_INF ? DT_INF : next[j] - y);
+            o[j] = x + j < P.w ? (uint32_t)min(min(up[j], dn), 8192) : 8192u;  // the row pass reads whole 8-pixel groups
         }
-        *q = make_int4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint2*>(P.dist + (long long)y * P.dstride + x) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
     }
 }
-// rows: the row kernel above with the weights written over the distances (a lane reads its 4-pixel group before it writes it)
-__global__ __launch_bounds__(256) void dt_rows_batch_kernel(const FeatherImg* __restrict__ imgs, float sharpness)
+// rows: one wavefront per row; s_mid: the forward sweep's result, one 8-byte slot per lane and step (lane-private: a lane
+// reads back exactly what it wrote, no barrier)
+// A lane owns 8 adjacent pixels (16-byte loads), a step 512.  Columns past the row's end hold 8192 (dt_col_fill) or are
+// replaced by it here: a candidate of 8192 or more never survives the final saturation, so it stands for "no zero".
+constexpr int DT_RW = 8;
+STX_DEV void dt_unpack8(const uint4 g, int (&v)[8])
 {
+    v[0] = (int)(g.x & 0xffffu); v[1] = (int)(g.x >> 16); v[2] = (int)(g.y & 0xffffu); v[3] = (int)(g.y >> 16);
+    v[4] = (int)(g.z & 0xffffu); v[5] = (int)(g.z >> 16); v[6] = (int)(g.w & 0xffffu); v[7] = (int)(g.w >> 16);
+}
+STX_DEV uint4 dt_pack8(const int (&v)[8])
+{
+    return make_uint4((uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16),
+                      (uint32_t)v[4] | ((uint32_t)v[5] << 16), (uint32_t)v[6] | ((uint32_t)v[7] << 16));
+}
+__global__ __launch_bounds__(256) void dt_rows_batch_kernel(const FeatherImg* __restrict__ imgs, int rows_per_block, int lds_pitch)
+{
+    extern __shared__ uint4 s_mid[];
     const FeatherImg& P = imgs[blockIdx.y];
-    const int lane = threadIdx.x & 63;
-    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (y >= P.h) return;
-    const int w = P.w;
-    int* row = reinterpret_cast<int*>(P.wmap) + (long long)y * P.dstride;
-    float* wr = P.wmap + (long long)y * P.dstride;
-    const int nseg = (w + 255) / 256;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int y = blockIdx.x * rows_per_block + wv;
+    if (wv >= rows_per_block || y >= P.h) return;
+    const int wpad = (int)P.dstride;  // multiple of 16: whole 8-pixel groups, the columns >= w hold 8192
+    uint16_t* row = P.dist + (long long)y * P.dstride;
+    uint4* mid = s_mid + (long long)wv * lds_pitch;
+    const int nseg = (P.w + 64 * DT_RW - 1) / (64 * DT_RW);
+    const uint4 FAR = make_uint4(0x20002000u, 0x20002000u, 0x20002000u, 0x20002000u);
     int carry = 1 << 29;
+    uint4 g = lane * DT_RW < wpad ? *reinterpret_cast<const uint4*>(row + lane * DT_RW) : FAR;
     for (int s = 0; s < nseg; s++) {
-        const int x0 = s * 256 + lane * 4;
-        int4 g = make_int4(DT_INF, DT_INF, DT_INF, DT_INF);
-        if (x0 < w) g = *reinterpret_cast<const int4*>(row + x0);
-        int p0 = (x0 + 0 < w ? g.x : DT_INF) - (x0 + 0), p1 = (x0 + 1 < w ? g.y : DT_INF) - (x0 + 1);
-        int p2 = (x0 + 2 < w ? g.z : DT_INF) - (x0 + 2), p3 = (x0 + 3 < w ? g.w : DT_INF) - (x0 + 3);
-        p1 = min(p1, p0); p2 = min(p2, p1); p3 = min(p3, p2);
-        const int before = min(carry, wave_excl_prefix_min(p3, lane));
-        p0 = min(p0, before); p1 = min(p1, before); p2 = min(p2, before); p3 = min(p3, before);
-        if (x0 < w) *reinterpret_cast<int4*>(row + x0) = make_int4(p0 + x0, p1 + x0 + 1, p2 + x0 + 2, p3 + x0 + 3);
-        carry = __shfl(p3, 63);
+        const int x0 = (s * 64 + lane) * DT_RW;
+        // the next step's distances are on their way while this step is scanned
+        const uint4 gn = x0 + 64 * DT_RW < wpad ? *reinterpret_cast<const uint4*>(row + x0 + 64 * DT_RW) : FAR;
+        int v[8];
+        dt_unpack8(g, v);
+        // p_j = g_j - (x0 + j) as q_j = g_j - j relative to x0; running minimum along the lane, then across the lanes below
+#pragma unroll
+        for (int j = 1; j < 8; j++) v[j] = min(v[j] - j, v[j - 1]);
+        const int before = min(carry, wave_excl_prefix_min(v[7] - x0)) + x0;  // everything to the left, in this lane's frame
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = min(min(v[j], before) + j, 65535);  // back to a distance: <= g_j <= 8192 inside the row
+        mid[s * 64 + lane] = dt_pack8(v);
+        carry = __builtin_amdgcn_readlane(v[7] - 7 - x0, 63);
+        g = gn;
     }
+    // Backward sweep with the lanes mirrored (lane L owns the group of lane 63 - L): "every pixel to the right" is then
+    // "every lane below", the same prefix scan.  The slots are read by another lane of the same wavefront than wrote them.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     carry = 1 << 29;
     for (int s = nseg - 1; s >= 0; s--) {
-        const int x0 = s * 256 + lane * 4;
-        int4 g = make_int4(DT_INF, DT_INF, DT_INF, DT_INF);
-        if (x0 < w) g = *reinterpret_cast<const int4*>(row + x0);
-        int p0 = (x0 + 0 < w ? g.x : DT_INF) + (x0 + 0), p1 = (x0 + 1 < w ? g.y : DT_INF) + (x0 + 1);
-        int p2 = (x0 + 2 < w ? g.z : DT_INF) + (x0 + 2), p3 = (x0 + 3 < w ? g.w : DT_INF) + (x0 + 3);
-        p2 = min(p2, p3); p1 = min(p1, p2); p0 = min(p0, p1);
-        const int after = min(carry, wave_excl_suffix_min(p0, lane));
-        p0 = min(p0, after); p1 = min(p1, after); p2 = min(p2, after); p3 = min(p3, after);
-        carry = __shfl(p0, 0);
-        if (x0 < w) {
-            const int f[4] = {p0 - x0, p1 - (x0 + 1), p2 - (x0 + 2), p3 - (x0 + 3)};
-            float o[4];
+        const int x0 = (s * 64 + 63 - lane) * DT_RW;
+        int v[8];
+        dt_unpack8(mid[s * 64 + 63 - lane], v);
+        // p_j = v_j + (x0 + j); running minimum from the right
+        v[7] += 7;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float dist = f[j] >= 8192 ? 8192.f : (float)f[j];
-                const float t = fmul(dist, sharpness);
-                o[j] = t > 1.f ? 1.f : t;
-            }
-            *reinterpret_cast<float4*>(wr + x0) = make_float4(o[0], o[1], o[2], o[3]);
-        }
+        for (int j = 6; j >= 0; j--) v[j] = min(v[j] + j, v[j + 1]);
+        const int after = min(carry, wave_excl_prefix_min(v[0] + x0)) - x0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = min(min(v[j], after) - j, 8192);
+        carry = __builtin_amdgcn_readlane(v[0] + x0, 63);  // the leftmost group of the step (before the saturation matters: see below)
+        if (x0 < wpad) *reinterpret_cast<uint4*>(row + x0) = dt_pack8(v);
     }
+}
+
+// FeatherBlender's weight from the stored distance: min(dist * sharpness, 1)
+STX_DEV float feather_weight(uint32_t dist, float sharpness)
+{
+    const float t = fmul((float)dist, sharpness);
+    return t > 1.f ? 1.f : t;
 }
 
 template <bool WITH16>
@@ -531,12 +588,27 @@ __global__ __launch_bounds__(256) void feather_gather_kernel(FeatherGatherK P)
         if (y < im.y || y >= im.y + im.h || xw0 + 256 <= im.x || xw0 >= im.x + im.w) continue;  // wave-uniform
         const int lx = x4 - im.x, ly = y - im.y;
         if (lx + 3 < 0 || lx >= im.w) continue;
-        const float* wrow = im.wmap + (long long)ly * im.dstride;
+        const uint16_t* wrow = im.dist + (long long)ly * im.dstride;
         const uint8_t* irow = im.img + (long long)ly * im.istride;
         if (!im.is_s16 && lx >= 0 && lx + 3 < im.w) {
             // whole group inside a u8 image: the four weights and the twelve image bytes as wide loads
-            const float w4[4] = {wrow[lx], wrow[lx + 1], wrow[lx + 2], wrow[lx + 3]};
+            const uint32_t d01 = ld_u32_unaligned(reinterpret_cast<const uint8_t*>(wrow + lx)), d23 = ld_u32_unaligned(reinterpret_cast<const uint8_t*>(wrow + lx + 2));
+            const float w4[4] = {feather_weight(d01 & 0xffffu, P.sharpness), feather_weight(d01 >> 16, P.sharpness),
+                                 feather_weight(d23 & 0xffffu, P.sharpness), feather_weight(d23 >> 16, P.sharpness)};
             const uint32_t b3[3] = {ld_u32_unaligned(irow + lx * 3), ld_u32_unaligned(irow + lx * 3 + 4), ld_u32_unaligned(irow + lx * 3 + 8)};
+            // away from the mask's edge every weight is exactly 1.f (distance * sharpness >= 1) and (short)(px * 1.f) = px:
+            // a wavefront in which that holds for all lanes adds the bytes as integers
+            const bool ones = __builtin_amdgcn_ballot_w64(!(w4[0] == 1.f && w4[1] == 1.f && w4[2] == 1.f && w4[3] == 1.f)) == 0;
+            if (ones) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++)
+                        acc[j][c] = (short)(acc[j][c] + (int)((b3[(3 * j + c) >> 2] >> (8 * ((3 * j + c) & 3))) & 255u));
+                    ws[j] = fadd(ws[j], 1.f);
+                }
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
 #pragma unroll
@@ -551,7 +623,7 @@ __global__ __launch_bounds__(256) void feather_gather_kernel(FeatherGatherK P)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (lx + j < 0 || lx + j >= im.w) continue;
-            const float w = wrow[lx + j];
+            const float w = feather_weight(wrow[lx + j], P.sharpness);
             int b, g, r;
             if (im.is_s16) {
                 const short* p = reinterpret_cast<const short*>(irow) + (lx + j) * 3;
@@ -575,9 +647,11 @@ __global__ __launch_bounds__(256) void feather_gather_kernel(FeatherGatherK P)
     for (int j = 0; j < 4; j++) {
         const float den = fadd(ws[j], WEIGHT_EPS);
         const bool in = ws[j] > WEIGHT_EPS;
+        float q[3];  // the three quotients share one refined reciprocal (bit-identical to the IEEE division for these operands)
+        div3_shared(den, (float)acc[j][0], (float)acc[j][1], (float)acc[j][2], q[0], q[1], q[2]);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            vv[j][c] = in ? trunc_s16(fdiv((float)acc[j][c], den)) : 0;
+            vv[j][c] = in ? trunc_s16(q[c]) : 0;
             o[(3 * j + c) >> 2] |= (uint32_t)min(abs(vv[j][c]), 255) << (8 * ((3 * j + c) & 3));
         }
         mo |= (in ? 255u : 0u) << (8 * j);
@@ -601,7 +675,7 @@ __global__ __launch_bounds__(256) void feather_gather_kernel(FeatherGatherK P)
 }  // namespace
 
 // distance transforms + weight maps of n fed images (device table d_imgs, host copy h_imgs for the grid sizes)
-int stx_launch_feather_weights(stx_ctx* ctx, const FeatherImg* d_imgs, const FeatherImg* h_imgs, int n, float sharpness)
+int stx_launch_feather_weights(stx_ctx* ctx, const FeatherImg* d_imgs, const FeatherImg* h_imgs, int n)
 {
     if (n <= 0) return STX_OK;
     int max_w = 0, max_h = 0, max_chunks = 0;
@@ -611,13 +685,18 @@ int stx_launch_feather_weights(stx_ctx* ctx, const FeatherImg* d_imgs, const Fea
         px += (double)h_imgs[i].w * h_imgs[i].h;
     }
     {
-        StxProfScope prof(ctx, "feather_dt_cols", px * (1 + 1 + 4 + 4));
+        StxProfScope prof(ctx, "feather_dt_cols", px * (1 + 0.25 + 2));
         hipLaunchKernelGGL(dt_col_summary_batch_kernel, dim3((max_w + 255) / 256, max_chunks, n), dim3(64), 0, ctx->stream, d_imgs);
+        hipLaunchKernelGGL(dt_col_link_batch_kernel, dim3((max_w + 255) / 256, n), dim3(64), 0, ctx->stream, d_imgs);
         hipLaunchKernelGGL(dt_col_fill_batch_kernel, dim3((max_w + 255) / 256, max_chunks, n), dim3(64), 0, ctx->stream, d_imgs);
     }
     {
-        StxProfScope prof(ctx, "feather_dt_rows", px * (4 + 4 + 4 + 4));
-        hipLaunchKernelGGL(dt_rows_batch_kernel, dim3((max_h + 3) / 4, n), dim3(256), 0, ctx->stream, d_imgs, sharpness);
+        StxProfScope prof(ctx, "feather_dt_rows", px * (2 + 2));
+        // LDS: 2 bytes per pixel and row, at most 64 KB per workgroup (1 / 2 / 4 rows)
+        const int lds_pitch = ((max_w + 511) / 512) * 64;  // 16-byte slots per row
+        const int rows = lds_pitch * 16 * 4 <= 65536 ? 4 : (lds_pitch * 16 * 2 <= 65536 ? 2 : 1);
+        hipLaunchKernelGGL(dt_rows_batch_kernel, dim3((max_h + rows - 1) / rows, n), dim3(256), (size_t)lds_pitch * 16 * rows, ctx->stream,
+                           d_imgs, rows, lds_pitch);
     }
     return check_launch("feather_weights");
 }
@@ -948,6 +1027,11 @@ STX_DEV void seam_resize4_body(const ResizeK& P)
     const int ox[4] = {ta.x, ta.z, tb.x, tb.z}, cf[4] = {ta.y, ta.w, tb.y, tb.w};
     uint32_t h0[4] = {0, 0, 0, 0}, h1[4] = {0, 0, 0, 0};
     int cur = -1;
+    uint32_t am[SEAM_ROWS];  // the final-size masks of all rows first: SEAM_ROWS loads in flight instead of one per iteration
+#pragma unroll
+    for (int r = 0; r < SEAM_ROWS; r++)
+        am[r] = yb + r < P.dh ? *reinterpret_cast<const uint32_t*>(P.andmask + (long long)(yb + r) * P.amstride + x4) : 0u;
+#pragma unroll
     for (int r = 0; r < SEAM_ROWS; r++) {
         const int y = yb + r;
         if (y >= P.dh) break;
@@ -972,7 +1056,7 @@ STX_DEV void seam_resize4_body(const ResizeK& P)
             const uint32_t v = iy ? (h0[j] * cy0 + h1[j] * cy1 + 32768u) >> 16 : (h0[j] + 128u) >> 8;
             out |= min(v, 255u) << (8 * j);
         }
-        out &= *reinterpret_cast<const uint32_t*>(P.andmask + (long long)y * P.amstride + x4);
+        out &= am[r];
         uint8_t* d = P.dst + (long long)y * P.dstride + x4;
         if (x4 + 4 <= P.dw) *reinterpret_cast<uint32_t*>(d) = out;
         else for (int j = 0; x4 + j < P.dw; j++) d[j] = (uint8_t)(out >> (8 * j));

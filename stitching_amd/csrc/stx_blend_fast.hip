@@ -489,21 +489,6 @@ STX_DEV int s6(int v) { return (v + 32) >> 6; }
 // DESIGN.md §4.4): v_cvt_i32_f32 truncates toward zero like cvttss2si and no wrap can occur.
 STX_DEV int trunc_small(float v) { return (int)v; }
 
-// n[c] / d for three numerators sharing one denominator, bit-identical to IEEE-754 division
-// (__fdiv_rn) whenever v_div_scale would not rescale — true here: d in [1e-5, #images], |n| <= 32768.
-// It is LLVM's own f32 fdiv expansion (rcp, 2 Newton fmas; then mul + 4 fmas per quotient) with the
-// reciprocal refinement shared.
-STX_DEV void div3_shared(float d, float n0, float n1, float n2, float& q0, float& q1, float& q2)
-{
-    float r = __builtin_amdgcn_rcpf(d);
-    const float e = __fmaf_rn(-d, r, 1.0f);
-    r = __fmaf_rn(e, r, r);
-    float t, u;
-    t = __fmul_rn(n0, r); u = __fmaf_rn(-d, t, n0); t = __fmaf_rn(u, r, t); u = __fmaf_rn(-d, t, n0); q0 = __fmaf_rn(u, r, t);
-    t = __fmul_rn(n1, r); u = __fmaf_rn(-d, t, n1); t = __fmaf_rn(u, r, t); u = __fmaf_rn(-d, t, n1); q1 = __fmaf_rn(u, r, t);
-    t = __fmul_rn(n2, r); u = __fmaf_rn(-d, t, n2); t = __fmaf_rn(u, r, t); u = __fmaf_rn(-d, t, n2); q2 = __fmaf_rn(u, r, t);
-}
-
 // pyrUp_<FixPtCast<short,6>> of one plane for the 8x2 patch whose coarse origin is (cx, cy);
 // cx is a multiple of 4 and cx+3 < cw
 STX_DEV void up_patch(const short* __restrict__ plane, long long stride, int cw, int ch, int cx, int cy, int up[2][8])

@@ -288,4 +288,19 @@ STX_DEV int reflect101(int p, int len)
 // pyrUp_ index rule on both axes: -1 -> 1 (0 when n == 1), n -> n-1
 STX_DEV int up_idx(int i, int n) { return i < 0 ? (n > 1 ? 1 : 0) : (i >= n ? n - 1 : i); }
 
+// n[c] / d for three numerators sharing one denominator, bit-identical to IEEE-754 division
+// (__fdiv_rn) whenever v_div_scale would not rescale — true here: d in [1e-5, #images], |n| <= 32768.
+// It is LLVM's own f32 fdiv expansion (rcp, 2 Newton fmas; then mul + 4 fmas per quotient) with the
+// reciprocal refinement shared.
+STX_DEV void div3_shared(float d, float n0, float n1, float n2, float& q0, float& q1, float& q2)
+{
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __fmaf_rn(-d, r, 1.0f);
+    r = __fmaf_rn(e, r, r);
+    float t, u;
+    t = __fmul_rn(n0, r); u = __fmaf_rn(-d, t, n0); t = __fmaf_rn(u, r, t); u = __fmaf_rn(-d, t, n0); q0 = __fmaf_rn(u, r, t);
+    t = __fmul_rn(n1, r); u = __fmaf_rn(-d, t, n1); t = __fmaf_rn(u, r, t); u = __fmaf_rn(-d, t, n1); q1 = __fmaf_rn(u, r, t);
+    t = __fmul_rn(n2, r); u = __fmaf_rn(-d, t, n2); t = __fmaf_rn(u, r, t); u = __fmaf_rn(-d, t, n2); q2 = __fmaf_rn(u, r, t);
+}
+
 }  // namespace stxd

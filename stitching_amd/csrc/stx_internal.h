@@ -183,14 +183,14 @@ struct FeatherImg {
     const uint8_t* img; long long istride; int is_s16;
     const uint8_t* mask; long long mstride;
     int x, y, w, h;                 // rectangle inside the panorama roi
-    float* wmap; long long dstride; // weight map (the L1 distances first, in place), elements per row (multiple of 16)
-    int* first; int* last; int n_chunks;  // column-pass summaries (DT_RC rows per chunk)
+    uint16_t* dist; long long dstride; // L1 distance to the nearest zero of the mask, saturated at 8192; elements per row (multiple of 16)
+    int* first; int* last; unsigned long long* zbits; int n_chunks;  // column-pass summaries (DT_RC rows per chunk): first / last zero row, zero rows as a bit set
 };
 struct FeatherGatherK {
-    const FeatherImg* imgs; int n; int w, h;
+    const FeatherImg* imgs; int n; int w, h; float sharpness;
     uint8_t* pano; long long pano_stride; uint8_t* pmask; long long pmask_stride; short* pano16; long long pano16_stride;
 };
-int stx_launch_feather_weights(stx_ctx* ctx, const FeatherImg* d_imgs, const FeatherImg* h_imgs, int n, float sharpness);
+int stx_launch_feather_weights(stx_ctx* ctx, const FeatherImg* d_imgs, const FeatherImg* h_imgs, int n);
 int stx_launch_feather_gather(stx_ctx* ctx, const FeatherGatherK& K, double algo_bytes);
 
 // "no" blender as a deferred gather: device table of the fed images, in feed order

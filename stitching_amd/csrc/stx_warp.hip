@@ -62,6 +62,7 @@ struct WarpK {
     float mx32_hi, my32_hi;
     float c2, c5, c8;  // plane: kr2 (1 - t2), kr5 (1 - t2), kr8 (1 - t2), each rounded once (host fp32 = device fp32)
     int num_ok;  // host-proved: |numerators| <= 2^60 and finite tables, the per-lane magnitude test is skipped
+    int z_one;   // host-proved (plane / affine): z = 1.f for every pixel, the quotients are the numerators
 };
 
 // Up to WARP_BATCH images per launch: the per-image argument blocks travel in the kernel-argument segment
@@ -457,50 +458,54 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
     // float bit patterns of z (a NaN z is "too big" or negative there, so it cannot slip through a NaN-dropping
     // fp min) and one fp max over |x|, |y| (a NaN numerator gives NaN on both division paths) — the latter only when
     // the host could not bound the numerators from the camera (num_ok: a wave-uniform branch).
-    int zb[4] = {__float_as_int(Z[0].x), __float_as_int(Z[0].y), __float_as_int(Z[1].x), __float_as_int(Z[1].y)};
-    if (TYPE == STX_WARP_PLANE || TYPE == STX_WARP_AFFINE) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) zb[j] &= 0x7fffffff;
-    }
-    const int zlo = min(min(zb[0], zb[1]), min(zb[2], zb[3])), zhi = max(max(zb[0], zb[1]), max(zb[2], zb[3]));
-    bool easy = zlo >= 0x21800000 /* 2^-60 */ && zhi <= 0x5d800000 /* 2^60 */;
-    if (!num_ok) {
-        const float nmax = fmaxf(fmaxf(fmaxf(fabsf(X[0].x), fabsf(Y[0].x)), fmaxf(fabsf(X[0].y), fabsf(Y[0].y))),
-                                 fmaxf(fmaxf(fabsf(X[1].x), fabsf(Y[1].x)), fmaxf(fabsf(X[1].y), fabsf(Y[1].y))));
-        easy = easy && nmax <= 0x1p60f;
-    }
-    if (easy) {
-        // x/z and y/z of a row pair: Newton-refined reciprocals, then the fma sequence of the IEEE division expansion
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const v2f d = Z[h], nd = -d;
-            v2f r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-            const v2f one = {1.0f, 1.0f};
-            const v2f e = __builtin_elementwise_fma(nd, r, one);
-            r = __builtin_elementwise_fma(e, r, r);
-            v2f t = X[h] * r;
-            v2f u = __builtin_elementwise_fma(nd, t, X[h]);
-            t = __builtin_elementwise_fma(u, r, t);
-            u = __builtin_elementwise_fma(nd, t, X[h]);
-            X[h] = __builtin_elementwise_fma(u, r, t);
-            t = Y[h] * r;
-            u = __builtin_elementwise_fma(nd, t, Y[h]);
-            t = __builtin_elementwise_fma(u, r, t);
-            u = __builtin_elementwise_fma(nd, t, Y[h]);
-            Y[h] = __builtin_elementwise_fma(u, r, t);
+    // An affine map (AffineWarper: third row of K R^-1 = (0 0 1), t2 = 0) has z = (0 v' + 0 u') + 1 = 1.f exactly and x / 1.f = x:
+    // no division at all (host-proved together with the finiteness of the tables, WarpK::z_one).
+    if (!((TYPE == STX_WARP_PLANE || TYPE == STX_WARP_AFFINE) && P.z_one)) {
+        int zb[4] = {__float_as_int(Z[0].x), __float_as_int(Z[0].y), __float_as_int(Z[1].x), __float_as_int(Z[1].y)};
+        if (TYPE == STX_WARP_PLANE || TYPE == STX_WARP_AFFINE) {
+    #pragma unroll
+            for (int j = 0; j < 4; j++) zb[j] &= 0x7fffffff;
         }
-    } else {
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                const float z = e ? Z[h].y : Z[h].x, x = e ? X[h].y : X[h].x, y = e ? Y[h].y : Y[h].x;
-                float qx = -1.f, qy = -1.f;
-                if (TYPE == STX_WARP_PLANE || TYPE == STX_WARP_AFFINE || z > 0) {
-                    qx = fdiv(x, z);
-                    qy = fdiv(y, z);
+        const int zlo = min(min(zb[0], zb[1]), min(zb[2], zb[3])), zhi = max(max(zb[0], zb[1]), max(zb[2], zb[3]));
+        bool easy = zlo >= 0x21800000 /* 2^-60 */ && zhi <= 0x5d800000 /* 2^60 */;
+        if (!num_ok) {
+            const float nmax = fmaxf(fmaxf(fmaxf(fabsf(X[0].x), fabsf(Y[0].x)), fmaxf(fabsf(X[0].y), fabsf(Y[0].y))),
+                                     fmaxf(fmaxf(fabsf(X[1].x), fabsf(Y[1].x)), fmaxf(fabsf(X[1].y), fabsf(Y[1].y))));
+            easy = easy && nmax <= 0x1p60f;
+        }
+        if (easy) {
+            // x/z and y/z of a row pair: Newton-refined reciprocals, then the fma sequence of the IEEE division expansion
+    #pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const v2f d = Z[h], nd = -d;
+                v2f r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+                const v2f one = {1.0f, 1.0f};
+                const v2f e = __builtin_elementwise_fma(nd, r, one);
+                r = __builtin_elementwise_fma(e, r, r);
+                v2f t = X[h] * r;
+                v2f u = __builtin_elementwise_fma(nd, t, X[h]);
+                t = __builtin_elementwise_fma(u, r, t);
+                u = __builtin_elementwise_fma(nd, t, X[h]);
+                X[h] = __builtin_elementwise_fma(u, r, t);
+                t = Y[h] * r;
+                u = __builtin_elementwise_fma(nd, t, Y[h]);
+                t = __builtin_elementwise_fma(u, r, t);
+                u = __builtin_elementwise_fma(nd, t, Y[h]);
+                Y[h] = __builtin_elementwise_fma(u, r, t);
+            }
+        } else {
+    #pragma unroll
+            for (int h = 0; h < 2; h++) {
+    #pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const float z = e ? Z[h].y : Z[h].x, x = e ? X[h].y : X[h].x, y = e ? Y[h].y : Y[h].x;
+                    float qx = -1.f, qy = -1.f;
+                    if (TYPE == STX_WARP_PLANE || TYPE == STX_WARP_AFFINE || z > 0) {
+                        qx = fdiv(x, z);
+                        qy = fdiv(y, z);
+                    }
+                    if (e) { X[h].y = qx; Y[h].y = qy; } else { X[h].x = qx; Y[h].x = qy; }
                 }
-                if (e) { X[h].y = qx; Y[h].y = qy; } else { X[h].x = qx; Y[h].x = qy; }
             }
         }
     }
@@ -1067,6 +1072,8 @@ void fill_warpk(const StxWarpLaunch& L, WarpK* Kp, double* bytes)
         volatile float c2 = K.kr[2] * omt, c5 = K.kr[5] * omt, c8 = K.kr[8] * omt;
         K.c2 = c2; K.c5 = c5; K.c8 = c8;
     }
+    // plane / affine: z = (kr7 v' + kr6 u') + c8; with kr6 = kr7 = 0 and finite tables (num_ok) that is c8 for every pixel
+    K.z_one = K.num_ok && L.proj.family == STX_F_PLANE && K.kr[6] == 0.f && K.kr[7] == 0.f && K.c8 == 1.0f ? 1 : 0;
     // algorithmic bytes: read the source once, write the warped image + mask once
     *bytes = (img ? 3.0 * L.sw * L.sh + 3.0 * L.dw * L.dh : 0.0) + (mask ? 1.0 * L.dw * L.dh : 0.0);
 }
