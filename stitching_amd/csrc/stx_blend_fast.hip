@@ -747,6 +747,96 @@ STX_DEV void mb_level_fast_body(const MbLevelK& P)
                 for (int r = 0; r < 2; r++)
 #pragma unroll
                     for (int j = 0; j < 8; j++) ws[r][j] = fadd(ws[r][j], w[r][j]);
+            } else if (U8SRC) {
+                // level 0 of u8 images with fp32 weights (masks that may be grey: resized seam masks): G_1 is 0..255, so pyrUp
+                // and the Laplacian run in packed 16-bit lanes exactly as in mb_level0_pk_kernel (pair order (0,2)(4,6)(1,3)(5,7));
+                // only the product with the weight and the weight sum are per pixel in fp32.  Pixels outside the image have
+                // weight 0 and add nothing.  (num_bands > 0: the launcher's condition.)
+                const int lx0 = X0 - im.ix, ly0 = Y0 - im.iy;
+                if (lx0 + 8 <= 0 || lx0 >= im.iw || ly0 + 2 <= 0 || ly0 >= im.ih) continue;
+                const bool fastx = lx0 >= 0 && lx0 + 8 <= im.iw;
+                uint32_t pw_[2][6], mw[2][2];
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const int ly = ly0 + r;
+#pragma unroll
+                    for (int q = 0; q < 6; q++) pw_[r][q] = 0;
+                    mw[r][0] = mw[r][1] = 0;
+                    if ((unsigned)ly >= (unsigned)im.ih) continue;
+                    if (fastx) {
+                        const uint32_t off = (uint32_t)ly * (uint32_t)im.img0_stride + (uint32_t)lx0 * 3u;
+                        const STX_GAS uint8_t* q = gp(im.img0) + (off & ~3u);
+                        const uint32_t s = off & 3u;
+                        const v4u d0 = *reinterpret_cast<const STX_GAS v4u_a4*>(q);
+                        const v4u d1 = *reinterpret_cast<const STX_GAS v4u_a4*>(q + 16);
+                        pw_[r][0] = __builtin_amdgcn_alignbyte(d0.y, d0.x, s);
+                        pw_[r][1] = __builtin_amdgcn_alignbyte(d0.z, d0.y, s);
+                        pw_[r][2] = __builtin_amdgcn_alignbyte(d0.w, d0.z, s);
+                        pw_[r][3] = __builtin_amdgcn_alignbyte(d1.x, d0.w, s);
+                        pw_[r][4] = __builtin_amdgcn_alignbyte(d1.y, d1.x, s);
+                        pw_[r][5] = __builtin_amdgcn_alignbyte(d1.z, d1.y, s);
+                        const uint32_t moff = (uint32_t)ly * (uint32_t)im.mask0_stride + (uint32_t)lx0;
+                        const STX_GAS uint8_t* mq = gp(im.mask0) + (moff & ~3u);
+                        const uint32_t ms = moff & 3u;
+                        const uint32_t m0 = *reinterpret_cast<const STX_GAS uint32_t*>(mq), m1 = *reinterpret_cast<const STX_GAS uint32_t*>(mq + 4),
+                                       m2 = *reinterpret_cast<const STX_GAS uint32_t*>(mq + 8);
+                        mw[r][0] = __builtin_amdgcn_alignbyte(m1, m0, ms);
+                        mw[r][1] = __builtin_amdgcn_alignbyte(m2, m1, ms);
+                    } else {
+                        const STX_GAS uint8_t* irow = gp(im.img0) + (uint32_t)ly * (uint32_t)im.img0_stride;
+                        const STX_GAS uint8_t* mrow = gp(im.mask0) + (uint32_t)ly * (uint32_t)im.mask0_stride;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const int lx = lx0 + j;
+                            if ((unsigned)lx < (unsigned)im.iw) {
+                                const STX_GAS uint8_t* p = irow + lx * 3;
+                                const uint32_t v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+                                const int bo = 3 * j;
+                                pw_[r][bo >> 2] |= v << (8 * (bo & 3));
+                                if ((bo & 3) > 1) pw_[r][(bo >> 2) + 1] |= v >> (32 - 8 * (bo & 3));
+                                mw[r][j >> 2] |= (uint32_t)mrow[lx] << (8 * (j & 3));
+                            }
+                        }
+                    }
+                }
+                float w[2][8];
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) w[r][j] = fmul((float)byte_of(mw[r], j), INV255);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    pk16 upk[2][4];
+                    up_patch_pk(gp(im.g[1]) + c * im.g_plane[1], (uint32_t)im.g_stride[1], im.fw >> 1, im.fh >> 1, (X0 - im.fx) >> 1,
+                                (Y0 - im.fy) >> 1, upk);
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        uint32_t px[4];
+                        if (c == 0) {
+                            px[0] = pair_u8<0, 6>(pw_[r]); px[1] = pair_u8<12, 18>(pw_[r]);
+                            px[2] = pair_u8<3, 9>(pw_[r]); px[3] = pair_u8<15, 21>(pw_[r]);
+                        } else if (c == 1) {
+                            px[0] = pair_u8<1, 7>(pw_[r]); px[1] = pair_u8<13, 19>(pw_[r]);
+                            px[2] = pair_u8<4, 10>(pw_[r]); px[3] = pair_u8<16, 22>(pw_[r]);
+                        } else {
+                            px[0] = pair_u8<2, 8>(pw_[r]); px[1] = pair_u8<14, 20>(pw_[r]);
+                            px[2] = pair_u8<5, 11>(pw_[r]); px[3] = pair_u8<17, 23>(pw_[r]);
+                        }
+                        uint32_t Lq[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) Lq[q] = unpk(pk(px[q]) - upk[r][q]);  // in [-255, 255]
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const int q = (j & 1) ? 2 + (j >> 2) : (j >> 2);
+                            const int L = ((j >> 1) & 1) ? s16hi(Lq[q]) : s16lo(Lq[q]);
+                            acc[r][j][c] += trunc_small(fmul((float)L, w[r][j]));
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) ws[r][j] = fadd(ws[r][j], w[r][j]);
             } else {
                 const int lx0 = X0 - im.ix, ly0 = Y0 - im.iy;
                 if (lx0 + 8 <= 0 || lx0 >= im.iw || ly0 + 2 <= 0 || ly0 >= im.ih) continue;
@@ -1275,7 +1365,8 @@ bool stx_fast_mb_level(stx_ctx* ctx, const MbLevelK& K)
         else if (K.all_u8) hipLaunchKernelGGL((mb_level_fast_kernel<false, true, false, true>), grid, dim3(256), 0, st, KT);
         else hipLaunchKernelGGL((mb_level_fast_kernel<false, true, false, false>), grid, dim3(256), 0, st, KT);
     } else {
-        if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, false, false>), grid, dim3(256), 0, st, KT);
+        if (K.level == 0 && K.all_u8 && K.num_bands > 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, false, true>), grid, dim3(256), 0, st, KT);
+        else if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, false, false>), grid, dim3(256), 0, st, KT);
         else if (K.all_u8) hipLaunchKernelGGL((mb_level_fast_kernel<false, false, false, true>), grid, dim3(256), 0, st, KT);
         else hipLaunchKernelGGL((mb_level_fast_kernel<false, false, false, false>), grid, dim3(256), 0, st, KT);
     }
