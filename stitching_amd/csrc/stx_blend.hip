@@ -487,21 +487,31 @@ __global__ __launch_bounds__(64) void dt_col_fill_batch_kernel(const FeatherImg*
         bits[0] = a.x; bits[1] = a.y; bits[2] = b.x; bits[3] = b.y;
     }
     int up[4];  // distance to the last zero row above the chunk (as seen from row y0 - 1)
+    uint32_t lo[4], hi[4];
+    int far0[4], far1[4];  // distance from the chunk's row 0 to the first zero in rows >= 32 / below the chunk (32-bit work only)
 #pragma unroll
-    for (int j = 0; j < 4; j++) up[j] = prev[j] == -DT_INF ? DT_INF : y0 - 1 - prev[j];
+    for (int j = 0; j < 4; j++) {
+        up[j] = prev[j] == -DT_INF ? DT_INF : y0 - 1 - prev[j];
+        lo[j] = (uint32_t)bits[j]; hi[j] = (uint32_t)(bits[j] >> 32);
+        far1[j] = next[j] == DT_INF ? DT_INF : next[j] - y0;
+        far0[j] = hi[j] ? 32 + (int)__builtin_ctz(hi[j]) : far1[j];
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
 #pragma unroll 8
-    for (int r = 0; r < DT_RC; r++) {
-        const int y = y0 + r;
-        if (y >= y1) break;
-        uint32_t o[4];
+        for (int rr = 0; rr < 32; rr++) {
+            const int r = 32 * hf + rr, y = y0 + r;
+            if (y >= y1) break;
+            uint32_t o[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const unsigned long long t = bits[j] >> r;  // the zero rows from this one on
-            up[j] = (t & 1ull) ? 0 : min(up[j] + 1, DT_INF);
-            const int dn = t ? (int)__builtin_ctzll(t) : (next[j] == DT_INF ? DT_INF : next[j] - y);
-            o[j] = x + j < P.w ? (uint32_t)min(min(up[j], dn), 8192) : 8192u;  // the row pass reads whole 8-pixel groups
+            for (int j = 0; j < 4; j++) {
+                const uint32_t t = (hf ? hi[j] : lo[j]) >> rr;  // the zero rows of this half from this one on
+                up[j] = (t & 1u) ? 0 : min(up[j] + 1, DT_INF);
+                const int dn = t ? (int)__builtin_ctz(t) : (hf ? far1[j] : far0[j]) - r;
+                o[j] = x + j < P.w ? (uint32_t)min(min(up[j], dn), 8192) : 8192u;  // the row pass reads whole 8-pixel groups
+            }
+            *reinterpret_cast<uint2*>(P.dist + (long long)y * P.dstride + x) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
         }
-        *reinterpret_cast<uint2*>(P.dist + (long long)y * P.dstride + x) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
     }
 }
 // rows: one wavefront per row; s_mid: the forward sweep's result, one 8-byte slot per lane and step (lane-private: a lane
