@@ -504,21 +504,22 @@ def extra_legs(args, S, synthetic, StitchJob, ctxs, wl, job, all_cams):
         seams = synthetic.voronoi_seam_masks(h_masks, job.corners, job.warped_sizes)
         js = []
         for c in ctxs:
-            j = StitchJob(job.frames, job.cameras, num_bands=wl["bands"], ctx=c, feed_masks=[S.DeviceImage.from_numpy(m, c) for m in seams])
+            j = StitchJob(job.frames, job.cameras, num_bands=wl["bands"], ctx=c, feed_masks=seams)  # host arrays: the job sees the cells
             j.warper.set_scale(all_cams)
             js.append(j)
-        out["voronoi_seam_masks"] = dict(quick_rate(js, ctxs, src_mpix), note="full-resolution 0/255 seam masks fed instead of the warped masks")
+        out["voronoi_seam_masks"] = dict(quick_rate(js, ctxs, src_mpix), note="full-resolution 0/255 seam masks fed instead of the warped masks; "
+                                         "every image warped and fed only over the columns its seam cell can reach (StitchJob crop_to_masks)")
         # the reference's default pipeline: low-resolution seam masks resized per panorama (SeamFinder.resize) -> grey edges,
         # non-binary masks -> the fp32-weight level-0 kernel
         low = [np.ascontiguousarray(m[::11, ::11]) for m in seams]
         js = []
         for c in ctxs:
-            j = StitchJob(job.frames, job.cameras, num_bands=wl["bands"], ctx=c, seam_masks=[S.DeviceImage.from_numpy(m, c) for m in low])
+            j = StitchJob(job.frames, job.cameras, num_bands=wl["bands"], ctx=c, seam_masks=low)
             j.warper.set_scale(all_cams)
             js.append(j)
         out["resized_seam_masks"] = dict(quick_rate(js, ctxs, src_mpix),
                                          note="0.09-scale seam masks -> SeamFinder.resize on the device every step (dilate, "
-                                              "INTER_LINEAR_EXACT, AND): non-binary masks, fp32-weight level-0 gather")
+                                              "INTER_LINEAR_EXACT, AND): non-binary masks, fp32-weight level-0 gather; cropped to the seam cells' reach")
         del js
     if wl["cfg"] == 2:
         # BASELINE configs[3] (config 4), one GPU's share: 8 x 8000x6000, cylindrical, 7 bands

@@ -144,6 +144,12 @@ int stx_warp_image_and_mask(stx_ctx* ctx, int type, float scale, const float K[9
  * no host synchronisation).  out_imgs / out_masks are arrays of n handles (either may be NULL). */
 int stx_warp_batch(stx_ctx* ctx, int type, float scale, int n, const float* K9s, const float* R9s,
                    const stx_buf* const* srcs, stx_buf** out_imgs, stx_buf** out_masks, int* out_xywh);
+/* stx_warp_batch over caller-given destination rectangles (x, y, w, h in warp coordinates, normally sub-rectangles of the
+ * ROIs of stx_warp_rois): the pixels are exactly those of the full warp inside the rectangle.  For pipelines that know
+ * which part of a warped image the blender can see (seam masks: stitching/stitcher.py:124 cuts every image down to its
+ * seam cell AFTER warping all of it, :119-121). */
+int stx_warp_batch_rects(stx_ctx* ctx, int type, float scale, int n, const float* K9s, const float* R9s,
+                         const stx_buf* const* srcs, const int* rects_xywh, stx_buf** out_imgs, stx_buf** out_masks);
 /* stitching/warper.py:58-68 without allocating the 255-filled source (size only) */
 int stx_warp_mask(stx_ctx* ctx, int type, float scale, const float K[9], const float R[9], int w, int h,
                   stx_buf** out_mask, int out_xywh[4]);
@@ -197,6 +203,11 @@ int stx_seam_mask_resize(stx_ctx* ctx, const stx_buf* seam_mask_u8x1, const stx_
  * and one resize launch per 16 images */
 int stx_seam_mask_resize_batch(stx_ctx* ctx, int n, const stx_buf* const* seam_masks, const stx_buf* const* final_masks,
                                stx_buf** outs);
+/* the same for rectangles of the final masks: final_masks[i] is the w x h rectangle at (x0, y0) of image i's warped mask of
+ * size full_w x full_h; full_wh_xy0 = {full_w, full_h, x0, y0} per image (x0 a multiple of 4).  Output i equals that
+ * rectangle of stx_seam_mask_resize_batch's output for the whole mask. */
+int stx_seam_mask_resize_batch_sub(stx_ctx* ctx, int n, const stx_buf* const* seam_masks, const stx_buf* const* final_masks,
+                                   const int* full_wh_xy0, stx_buf** outs);
 int stx_timelapse_frame(stx_ctx* ctx, const stx_buf* img, int tlx, int tly, const int dst_roi_xywh[4], stx_buf** out_frame);
 
 /* ---- sharded multi-band blending: one process per GPU, one stx_blender per rank ------------------

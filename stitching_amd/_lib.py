@@ -28,8 +28,8 @@ CONTRIB_U8_BINARY = 1
 EXPORTS = (
     "stx_version stx_last_error stx_device_count stx_ctx_create stx_ctx_destroy stx_ctx_sync "
     "stx_host_alloc stx_host_free stx_buf_from_host stx_buf_from_host_async stx_buf_alloc stx_buf_to_host stx_buf_to_host_async stx_buf_view stx_buf_info stx_buf_device_ptr stx_buf_free "
-    "stx_warp_roi stx_warp_rois stx_warp stx_warp_image_and_mask stx_warp_batch stx_warp_mask "
-    "stx_gain_apply stx_block_gain_apply stx_resize_linear_exact stx_seam_mask_resize stx_seam_mask_resize_batch stx_timelapse_frame stx_result_roi stx_blend_create stx_blend_num_bands stx_blend_feed stx_blend_finish stx_blend_finish_ex "
+    "stx_warp_roi stx_warp_rois stx_warp stx_warp_image_and_mask stx_warp_batch stx_warp_batch_rects stx_warp_mask "
+    "stx_gain_apply stx_block_gain_apply stx_resize_linear_exact stx_seam_mask_resize stx_seam_mask_resize_batch stx_seam_mask_resize_batch_sub stx_timelapse_frame stx_result_roi stx_blend_create stx_blend_num_bands stx_blend_feed stx_blend_finish stx_blend_finish_ex "
     "stx_blend_destroy stx_blend_set_band stx_blend_feed_ex stx_blend_contrib_rect stx_blend_export_contrib stx_blend_export_contribs "
     "stx_blend_build stx_blend_feed_contrib stx_blend_feed_contrib_ex stx_buf_flags stx_strip_rect stx_strip_pack stx_strip_pack_batch stx_strip_unpack stx_blend_feed_strips stx_comm_unique_id stx_comm_create stx_comm_exchange stx_comm_exchange_begin stx_comm_exchange_end stx_comm_exchange_begin_on stx_comm_exchange_end_on stx_comm_destroy stx_prof_enable stx_prof_reset stx_prof_count stx_prof_get stx_mark stx_mark_elapsed_ms"
 ).split()
@@ -74,12 +74,14 @@ def lib():
     L.stx_warp.argtypes = [vp, C.c_int, C.c_float, fp, fp, vp, C.c_int, C.c_int, vpp, ip]
     L.stx_warp_image_and_mask.argtypes = [vp, C.c_int, C.c_float, fp, fp, vp, vpp, vpp, ip]
     L.stx_warp_batch.argtypes = [vp, C.c_int, C.c_float, C.c_int, fp, fp, vpp, vpp, vpp, ip]
+    L.stx_warp_batch_rects.argtypes = [vp, C.c_int, C.c_float, C.c_int, fp, fp, vpp, ip, vpp, vpp]
     L.stx_warp_mask.argtypes = [vp, C.c_int, C.c_float, fp, fp, C.c_int, C.c_int, vpp, ip]
     L.stx_gain_apply.argtypes = [vp, vp, fp]
     L.stx_block_gain_apply.argtypes = [vp, vp, vp]
     L.stx_resize_linear_exact.argtypes = [vp, vp, C.c_int, C.c_int, vpp]
     L.stx_seam_mask_resize.argtypes = [vp, vp, vp, vpp]
     L.stx_seam_mask_resize_batch.argtypes = [vp, C.c_int, vpp, vpp, vpp]
+    L.stx_seam_mask_resize_batch_sub.argtypes = [vp, C.c_int, vpp, vpp, ip, vpp]
     L.stx_timelapse_frame.argtypes = [vp, vp, C.c_int, C.c_int, ip, vpp]
     L.stx_result_roi.argtypes = [C.c_int, ip, ip, ip]
     L.stx_blend_create.argtypes = [vp, C.c_int, C.c_int, C.c_float, ip, vpp]

@@ -631,12 +631,20 @@ STX_EXPORT int stx_seam_mask_resize(stx_ctx* ctx, const stx_buf* seam_mask, cons
 
 // SeamFinder.resize for all images of a panorama: one table upload, one dilate launch and one resize launch per 16 images.
 // Falls back to the per-image call when a buffer does not meet the 4-pixel kernel's alignment needs.
-STX_EXPORT int stx_seam_mask_resize_batch(stx_ctx* ctx, int n, const stx_buf* const* seam_masks, const stx_buf* const* final_masks,
-                                          stx_buf** outs)
+// sub: null -> final_masks[i] is the whole final mask; else {full_w, full_h, x0, y0} per image: final_masks[i] is the
+// rectangle at (x0, y0) of a final mask of size full_w x full_h (the seam mask is enlarged to THAT size, only the
+// rectangle is produced; x0 a multiple of 4)
+static int seam_resize_batch_impl(stx_ctx* ctx, int n, const stx_buf* const* seam_masks, const stx_buf* const* final_masks,
+                                  const int* sub, stx_buf** outs)
 {
     if (!ctx || n < 0 || (n > 0 && (!seam_masks || !final_masks || !outs))) return stx_fail(STX_ERR_INVALID, "null argument");
     STX_TRY(stx_set_device(ctx));
     bool fast = true;
+    for (int i = 0; i < n && sub; i++) {
+        const int* q = sub + 4 * i;
+        if (!final_masks[i] || q[2] < 0 || q[3] < 0 || (q[2] & 3) || q[2] + final_masks[i]->w > q[0] || q[3] + final_masks[i]->h > q[1])
+            return stx_fail(STX_ERR_INVALID, "seam mask rectangle %d outside its final mask (or x0 not a multiple of 4)", i);
+    }
     for (int i = 0; i < n; i++) {
         const stx_buf *s = seam_masks[i], *m = final_masks[i];
         if (!s || !m) return stx_fail(STX_ERR_INVALID, "null argument");
@@ -644,7 +652,9 @@ STX_EXPORT int stx_seam_mask_resize_batch(stx_ctx* ctx, int n, const stx_buf* co
         if (s->ctx->device != ctx->device || m->ctx->device != ctx->device) return stx_fail(STX_ERR_INVALID, "image lives on another device");
         fast = fast && ((uintptr_t)m->ptr & 3) == 0 && (m->stride & 3) == 0 && (size_t)((m->w + 3) & ~3) <= m->stride;
     }
-    if (!fast || n == 0) {
+    if (n == 0) return STX_OK;
+    if (!fast) {
+        if (sub) return stx_fail(STX_ERR_UNSUPPORTED, "seam mask rectangles need dword-aligned final masks");
         for (int i = 0; i < n; i++) STX_TRY(stx_seam_mask_resize(ctx, seam_masks[i], final_masks[i], &outs[i]));
         return STX_OK;
     }
@@ -653,8 +663,13 @@ STX_EXPORT int stx_seam_mask_resize_batch(stx_ctx* ctx, int n, const stx_buf* co
     std::vector<size_t> xoff(n), yoff(n);
     for (int i = 0; i < n; i++) {
         std::vector<int> xt, yt;
-        linear_exact_table(seam_masks[i]->w, final_masks[i]->w, xt);
-        linear_exact_table(seam_masks[i]->h, final_masks[i]->h, yt);
+        linear_exact_table(seam_masks[i]->w, sub ? sub[4 * i] : final_masks[i]->w, xt);
+        linear_exact_table(seam_masks[i]->h, sub ? sub[4 * i + 1] : final_masks[i]->h, yt);
+        if (sub) {  // the rectangle's slice of the tables (2 ints per destination column / row)
+            const int x0 = sub[4 * i + 2], y0 = sub[4 * i + 3];
+            xt = std::vector<int>(xt.begin() + 2 * (size_t)x0, xt.begin() + 2 * (size_t)(x0 + final_masks[i]->w));
+            yt = std::vector<int>(yt.begin() + 2 * (size_t)y0, yt.begin() + 2 * (size_t)(y0 + final_masks[i]->h));
+        }
         xt.resize((xt.size() + 7) & ~(size_t)7, 0);
         xoff[i] = all.size();
         all.insert(all.end(), xt.begin(), xt.end());
@@ -687,6 +702,19 @@ STX_EXPORT int stx_seam_mask_resize_batch(stx_ctx* ctx, int n, const stx_buf* co
     }
     for (int i = 0; i < n; i++) outs[i] = dsts[i];
     return STX_OK;
+}
+
+STX_EXPORT int stx_seam_mask_resize_batch(stx_ctx* ctx, int n, const stx_buf* const* seam_masks, const stx_buf* const* final_masks,
+                                          stx_buf** outs)
+{
+    return seam_resize_batch_impl(ctx, n, seam_masks, final_masks, nullptr, outs);
+}
+
+STX_EXPORT int stx_seam_mask_resize_batch_sub(stx_ctx* ctx, int n, const stx_buf* const* seam_masks, const stx_buf* const* final_masks,
+                                              const int* full_wh_xy0, stx_buf** outs)
+{
+    if (!full_wh_xy0 && n > 0) return stx_fail(STX_ERR_INVALID, "null argument");
+    return seam_resize_batch_impl(ctx, n, seam_masks, final_masks, full_wh_xy0, outs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1003,8 +1031,10 @@ STX_EXPORT int stx_warp(stx_ctx* ctx, int type, float scale, const float K[9], c
     return STX_OK;
 }
 
-STX_EXPORT int stx_warp_batch(stx_ctx* ctx, int type, float scale, int n, const float* K9s, const float* R9s,
-                              const stx_buf* const* srcs, stx_buf** out_imgs, stx_buf** out_masks, int* out_xywh)
+// rects: null -> the destination rectangle of image i is its ROI (found here, cached); else the caller's rectangle in warp
+// coordinates (any sub-rectangle of the ROI gives exactly the ROI warp's pixels there: every pixel is mapped on its own)
+static int warp_batch_impl(stx_ctx* ctx, int type, float scale, int n, const float* K9s, const float* R9s,
+                           const stx_buf* const* srcs, const int* rects, stx_buf** out_imgs, stx_buf** out_masks, int* out_xywh)
 {
     if (!ctx || !K9s || !R9s || !srcs || n < 0) return stx_fail(STX_ERR_INVALID, "bad argument");
     if (!out_imgs && !out_masks) return stx_fail(STX_ERR_INVALID, "nothing requested");
@@ -1023,7 +1053,8 @@ STX_EXPORT int stx_warp_batch(stx_ctx* ctx, int type, float scale, int n, const 
     // ROIs: cached ones as they are, all missing ones in ONE device pass (one synchronisation)
     if (!g_roi_cache) g_roi_cache = new std::map<RoiKey, std::array<int, 4>>();
     std::vector<int> miss;
-    for (int i = 0; i < n; i++) {
+    if (rects) memcpy(rois.data(), rects, sizeof(int) * 4 * (size_t)n);
+    for (int i = 0; i < n && !rects; i++) {
         auto it = g_roi_cache->find(make_key(type, scale, K9s + 9 * i, R9s + 9 * i, sizes[2 * i], sizes[2 * i + 1]));
         if (it != g_roi_cache->end()) memcpy(&rois[4 * i], it->second.data(), 16);
         else miss.push_back(i);
@@ -1072,6 +1103,19 @@ STX_EXPORT int stx_warp_batch(stx_ctx* ctx, int type, float scale, int n, const 
     }
     if (out_xywh) memcpy(out_xywh, rois.data(), sizeof(int) * 4 * (size_t)n);
     return STX_OK;
+}
+
+STX_EXPORT int stx_warp_batch(stx_ctx* ctx, int type, float scale, int n, const float* K9s, const float* R9s,
+                              const stx_buf* const* srcs, stx_buf** out_imgs, stx_buf** out_masks, int* out_xywh)
+{
+    return warp_batch_impl(ctx, type, scale, n, K9s, R9s, srcs, nullptr, out_imgs, out_masks, out_xywh);
+}
+
+STX_EXPORT int stx_warp_batch_rects(stx_ctx* ctx, int type, float scale, int n, const float* K9s, const float* R9s,
+                                    const stx_buf* const* srcs, const int* rects_xywh, stx_buf** out_imgs, stx_buf** out_masks)
+{
+    if (!rects_xywh) return stx_fail(STX_ERR_INVALID, "null argument");
+    return warp_batch_impl(ctx, type, scale, n, K9s, R9s, srcs, rects_xywh, out_imgs, out_masks, nullptr);
 }
 
 STX_EXPORT int stx_warp_image_and_mask(stx_ctx* ctx, int type, float scale, const float K[9], const float R[9],

@@ -7,9 +7,11 @@ One image is in flight on the host side exactly as in the reference
 builds and the final gather are enqueued on one HIP stream; the only host syncs are the batched
 ROI read-back at the start and whatever the caller does with the result.
 """
+import ctypes as C
+
 import numpy as np
 
-from . import config
+from . import _lib, config
 from .blender import Blender
 from .device import DeviceImage, as_device, get_context
 from .stitching_error import StitchingError
@@ -21,13 +23,18 @@ class StitchJob:
     """Pre-staged inputs of one panorama: device-resident source frames + cameras."""
 
     def __init__(self, frames, cameras, warper_type="spherical", blender_type="multiband", num_bands=None,
-                 blend_strength=Blender.DEFAULT_BLEND_STRENGTH, ctx=None, async_upload=False, feed_masks=None, seam_masks=None):
+                 blend_strength=Blender.DEFAULT_BLEND_STRENGTH, ctx=None, async_upload=False, feed_masks=None, seam_masks=None,
+                 crop_to_masks=True):
         """async_upload: numpy frames in page-locked memory (pinned_empty) are only queued for upload; they must stay
         untouched until ctx.sync() (a streaming caller alternates two contexts).
         feed_masks: final-resolution u8 masks fed to the blender instead of the warped masks (seam masks already at the
         warped size); seam_masks: LOW-resolution seam masks, resized on the device every run exactly as the reference
         does per panorama (SeamFinder.resize, stitching/stitcher.py:124: dilate, INTER_LINEAR_EXACT, AND with the warped
-        mask) — its grey edges make the masks non-binary."""
+        mask) — its grey edges make the masks non-binary.
+        crop_to_masks (multi-band blender, feed_masks / seam_masks given as host arrays): a seam mask keeps one cell of its
+        image, and nothing farther than the pyramids reach from that cell can touch the panorama.  The reference warps
+        every image whole and cuts afterwards (stitching/stitcher.py:119-127); here only the columns the blender can see
+        are warped, masked and fed — the same panorama bit for bit (`_crop_columns`)."""
         if len(frames) != len(cameras) or not frames:
             raise StitchingError("need one camera per frame and at least one frame")
         self.ctx = ctx or get_context()
@@ -40,6 +47,15 @@ class StitchJob:
         self.num_bands = num_bands
         self.blend_strength = blend_strength
         self.corners = self.warped_sizes = None
+        # per mask the columns [a, b) that hold a non-zero value and the mask's width (host arrays only: no read-back here)
+        self._mask_cols = None
+        given = feed_masks if feed_masks is not None else seam_masks
+        if crop_to_masks and given is not None and all(isinstance(m, np.ndarray) for m in given):
+            self._mask_cols = []
+            for m in given:
+                nz = np.flatnonzero(m.reshape(m.shape[0], m.shape[1], -1).any(axis=(0, 2)))
+                self._mask_cols.append((int(nz[0]), int(nz[-1]) + 1, int(m.shape[1])) if nz.size else None)
+        self._crop_cache = None
         self.feed_masks = None if feed_masks is None else [as_device(m, self.ctx) for m in feed_masks]
         self.seam_masks = None if seam_masks is None else [as_device(m, self.ctx) for m in seam_masks]
 
@@ -58,6 +74,47 @@ class StitchJob:
             self.blend_strength = blend_strength_for_bands(self.num_bands, roi[2], roi[3])
         return self.corners, self.warped_sizes
 
+    def _crop_columns(self, handle):
+        """Per image the columns [x0, x1) of its warped image that can influence the panorama, or None (all of them).
+
+        The fed mask of image k is non-zero in the columns [m0, m1) only.  Its weight pyramid W_l is then non-zero within
+        2^(l+1) - 2 level-0 columns of them, at most 2^(B+1) — call that range, snapped outwards to the band grid, the
+        image's band.  Outside its band the image adds (short)(L * 0.f) = 0 and 0.f whatever its pixels are; inside it, L
+        and W are what the whole image gives as long as every column within the pyramids' reach of the band is present:
+        exactly the guarantee of the strips of the sharded blender (`stx_strip_rect`), whose cut edges are
+        farther from the band than any pyramid tap.  So the strip for its own band is all of image k that has to exist.
+        Seam masks given at low resolution: the final mask is dilate(3x3) -> INTER_LINEAR_EXACT -> AND, non-zero at x only
+        if a dilated low-resolution column floor(sx) or floor(sx) + 1 is, sx = (x + 0.5) * lw / w - 0.5."""
+        key = (tuple(self.corners), tuple(self.warped_sizes), self.blend_strength)
+        if self._crop_cache is not None and self._crop_cache[0] == key:
+            return self._crop_cache[1]
+        B = handle.num_bands()
+        roi = Blender.result_roi(self.corners, self.warped_sizes)
+        out = None
+        if B > 0:
+            align, reach = max(8, 1 << B), 2 << B
+            out = []
+            for (cx, cy), (w, h), cols in zip(self.corners, self.warped_sizes, self._mask_cols):
+                if cols is None:
+                    out.append(None)
+                    continue
+                a, b, mw = cols
+                if mw != w:  # low-resolution seam mask: the columns of the final mask that can be non-zero
+                    a = int(np.floor((a - 2 + 0.5) * w / mw - 0.5)) - 1
+                    b = int(np.ceil((b + 2 + 0.5) * w / mw - 0.5)) + 1
+                a, b = max(a, 0), min(b, w)
+                lo = max(((cx - roi[0] + a - reach) // align) * align, 0)
+                hi = -((-(cx - roi[0] + b + reach)) // align) * align
+                xs, nbytes = (C.c_int * 2)(), C.c_size_t()
+                _lib.check(self.ctx._lib.stx_strip_rect(handle._h, int(w), int(h), int(cx), int(cy), int(lo), int(hi), xs,
+                                                        C.byref(nbytes)))
+                x0, x1 = int(xs[0]), int(xs[1])
+                out.append((x0, x1) if 0 < x1 - x0 <= 0.9 * w else None)
+            if all(o is None for o in out):
+                out = None
+        self._crop_cache = (key, out)
+        return out
+
     def run(self):
         """warp every frame, feed it, blend.  Returns device-resident (panorama u8x3, mask u8)."""
         # one panorama = one ROI pass (the reference's eager Warper.warp_rois, stitching/stitcher.py:188):
@@ -68,16 +125,35 @@ class StitchJob:
         try:
             blender = Blender(self.blender_type, self.blend_strength, ctx=self.ctx)
             blender.prepare(self.corners, self.warped_sizes)
-            imgs, masks, rois = self.warper.warp_images_and_masks(self.frames, self.cameras)
-            if self.feed_masks is not None:
-                masks = self.feed_masks
-            elif self.seam_masks is not None:
-                from .seam_finder import SeamFinder
+            crop = None
+            if self._mask_cols is not None and blender.blender.kind == _lib.BLEND_MULTIBAND:
+                crop = self._crop_columns(blender.blender)
+            if crop is not None:
+                cols = [c if c is not None else (0, w) for c, (w, h) in zip(crop, self.warped_sizes)]
+                rects = [(cx + x0, cy, x1 - x0, h) for (x0, x1), (cx, cy), (w, h) in zip(cols, self.corners, self.warped_sizes)]
+                imgs, masks, rois = self.warper.warp_images_and_masks(self.frames, self.cameras, rects=rects)
+                if self.feed_masks is not None:
+                    masks = [m[:, x0:x1] for m, (x0, x1) in zip(self.feed_masks, cols)]
+                else:
+                    from .seam_finder import SeamFinder
 
-                masks = SeamFinder.resize_all(self.seam_masks, masks)
-            for img, mask, roi, corner in zip(imgs, masks, rois, self.corners):
-                if roi[0:2] != tuple(corner):
-                    raise StitchingError("warp roi changed between plan() and run()")
+                    masks = SeamFinder.resize_all(self.seam_masks, masks,
+                                                  sub=[(w, h, x0, 0) for (x0, x1), (w, h) in zip(cols, self.warped_sizes)])
+                corners = [(r[0], r[1]) for r in rects]
+            else:
+                imgs, masks, rois = self.warper.warp_images_and_masks(self.frames, self.cameras)
+                if self.feed_masks is not None:
+                    masks = self.feed_masks
+                elif self.seam_masks is not None:
+                    from .seam_finder import SeamFinder
+
+                    masks = SeamFinder.resize_all(self.seam_masks, masks)
+                corners = self.corners
+                for roi, corner in zip(rois, self.corners):
+                    if roi[0:2] != tuple(corner):
+                        raise StitchingError("warp roi changed between plan() and run()")
+            self.last_crop = crop
+            for img, mask, corner in zip(imgs, masks, corners):
                 blender.feed(img, mask, corner)
             self.last_num_bands = blender.blender.num_bands()
             pano, pmask = blender.blend()
@@ -99,6 +175,10 @@ def compose(frames, cameras, warper_type="spherical", blender_type="multiband", 
     masks (one per image, e.g. from cv2's seam finder), or None for the full warped masks.
     Returns device-resident (panorama u8x3, mask u8)."""
     ctx = ctx or get_context()
+    if compensator is None and seam_masks is not None and blender_type == "multiband":
+        # nothing between the warp and the blender needs whole images: warp and feed only what the seam cells can reach
+        return StitchJob(frames, cameras, warper_type=warper_type, blender_type=blender_type, blend_strength=blend_strength, ctx=ctx,
+                         seam_masks=[np.asarray(m.get() if hasattr(m, "get") else m) for m in seam_masks]).run()
     prev = config.device_resident()
     config.set_device_resident(True)
     try:

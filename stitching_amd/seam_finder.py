@@ -62,9 +62,11 @@ class SeamFinder:
         return self.finder.find(imgs_float, list(corners), [host(m) for m in masks])
 
     @staticmethod
-    def resize_all(seam_masks, masks):
+    def resize_all(seam_masks, masks, sub=None):
         """`resize` for all images of a panorama in one call (one dilate + one resize launch per 16 images); device-resident
-        inputs of one context.  Same results as [SeamFinder.resize(s, m) for s, m in zip(seam_masks, masks)]."""
+        inputs of one context.  Same results as [SeamFinder.resize(s, m) for s, m in zip(seam_masks, masks)].
+        sub: optional (full_w, full_h, x0, y0) per image — masks[i] is then the rectangle at (x0, y0) of a warped mask of
+        size full_w x full_h and the result is that rectangle of the full result (x0 a multiple of 4)."""
         masks = list(masks)
         ctx = masks[0].ctx if masks and isinstance(masks[0], DeviceImage) else get_context()
         host = lambda a: a if isinstance(a, DeviceImage) else np.asarray(a.get() if hasattr(a, "get") else a)  # noqa: E731
@@ -74,7 +76,11 @@ class SeamFinder:
         if n == 0:
             return []
         sa, ma, outs = (C.c_void_p * n)(*[a._h for a in s]), (C.c_void_p * n)(*[a._h for a in m]), (C.c_void_p * n)()
-        _lib.check(ctx._lib.stx_seam_mask_resize_batch(ctx.handle, n, sa, ma, outs))
+        if sub is not None:
+            q = np.ascontiguousarray(np.asarray(sub, np.int32).reshape(n, 4))
+            _lib.check(ctx._lib.stx_seam_mask_resize_batch_sub(ctx.handle, n, sa, ma, q.ctypes.data_as(C.POINTER(C.c_int)), outs))
+        else:
+            _lib.check(ctx._lib.stx_seam_mask_resize_batch(ctx.handle, n, sa, ma, outs))
         res = [DeviceImage(ctx, C.c_void_p(outs[i])) for i in range(n)]
         return res if config.device_resident() else [r.numpy() for r in res]
 

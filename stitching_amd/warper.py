@@ -148,10 +148,12 @@ class Warper:
                                                     src._h, C.byref(oi), C.byref(om), roi))
         return (self._result(DeviceImage(ctx, oi)), self._result(DeviceImage(ctx, om)), tuple(int(v) for v in roi))
 
-    def warp_images_and_masks(self, imgs, cameras, aspect=1):
+    def warp_images_and_masks(self, imgs, cameras, aspect=1, rects=None):
         """Batched form of warp_images + create_and_warp_masks (stitching/warper.py:39-41, 54-56) for a list of
         images: one ROI pass, one table launch and one remap launch for all of them (stx_warp_batch).
-        Returns (warped_images, warped_masks, rois)."""
+        Returns (warped_images, warped_masks, rois).
+        rects: optional (x, y, w, h) per image in warp coordinates — only that rectangle of each warped image / mask is
+        produced (pixel for pixel what the full warp holds there); the returned rois are then these rectangles."""
         ctx = self._ctx()
         srcs = [as_device(img, ctx) for img in imgs]
         cameras = list(cameras)
@@ -167,8 +169,13 @@ class Warper:
         h_src = (C.c_void_p * n)(*[s._h for s in srcs[:n]])
         h_img, h_mask = (C.c_void_p * n)(), (C.c_void_p * n)()
         rois = np.zeros((n, 4), np.int32)
-        _lib.check(ctx._lib.stx_warp_batch(ctx.handle, self._type_id(), self._scale(aspect), n, _fp(Ks), _fp(Rs), h_src,
-                                           h_img, h_mask, rois.ctypes.data_as(C.POINTER(C.c_int))))
+        if rects is not None:
+            rois = np.ascontiguousarray(np.asarray(rects, np.int32).reshape(n, 4))
+            _lib.check(ctx._lib.stx_warp_batch_rects(ctx.handle, self._type_id(), self._scale(aspect), n, _fp(Ks), _fp(Rs), h_src,
+                                                     rois.ctypes.data_as(C.POINTER(C.c_int)), h_img, h_mask))
+        else:
+            _lib.check(ctx._lib.stx_warp_batch(ctx.handle, self._type_id(), self._scale(aspect), n, _fp(Ks), _fp(Rs), h_src,
+                                               h_img, h_mask, rois.ctypes.data_as(C.POINTER(C.c_int))))
         imgs_out = [self._result(DeviceImage(ctx, C.c_void_p(h_img[i]))) for i in range(n)]
         masks_out = [self._result(DeviceImage(ctx, C.c_void_p(h_mask[i]))) for i in range(n)]
         return imgs_out, masks_out, [tuple(int(v) for v in r) for r in rois]
