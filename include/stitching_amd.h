@@ -243,6 +243,11 @@ int stx_blend_feed_contrib(stx_blender* b, int order, const int rect_xywh[4], co
 int stx_blend_feed_contrib_ex(stx_blender* b, int order, const int rect_xywh[4], const stx_buf* packed, int flags);
 int stx_buf_flags(const stx_buf* buf, int* out_flags);
 
+/* Rectangle {x0, x1, y0, y1} of an image that the panorama rectangle [band_x0, band_x1) x [band_y0, band_y1) (roi-relative)
+ * depends on through the pyramids: stx_strip_rect's column range and the same range along y.  A pipeline that knows where an
+ * image's fed mask is non-zero (its seam cell) needs no more of the image than this; all zeros: nothing. */
+int stx_view_rect(const stx_blender* b, int img_w, int img_h, int tlx, int tly, int band_x0, int band_x1, int band_y0, int band_y1,
+                  int out_x0x1y0y1[4]);
 /* image-strip form of the same exchange: the owner of an image ships the COLUMNS [x0, x1) of the warped
  * image and mask that another band depends on (4 bytes per pixel, no export pass) and the receiver feeds them with
  * stx_blend_feed_ex like an image of its own, at corner (tlx + x0, tly) and with the image's global `order`; its band

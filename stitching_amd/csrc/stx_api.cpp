@@ -1634,6 +1634,61 @@ static void strip_layout(int w, int h, size_t* img_stride, size_t* mask_stride, 
     *bytes = (*img_stride + *mask_stride) * (size_t)h;
 }
 
+// The same range along y (rows [y0, y1) of an image that the rows [by0, by1) of the panorama depend on): pyrDown / pyrUp and
+// the feed geometry are the same along both axes, so this is mb_level_regions + mb_contrib_range + mb_strip_range with
+// (ry, rh, fy, fh, tly, img_h) in the places of (rx, rw, fx, fw, tlx, img_w).  The column version's 8-sample region alignment
+// (vector lanes of the kernels) is kept: a wider region is a superset.  Rows are cut to even positions only.
+static bool mb_strip_range_y(const stx_blender* b, int img_w, int img_h, int tlx, int tly, int by0, int by1, int* y0, int* y1)
+{
+    int fx, fy, fw, fh;
+    mb_feed_rect(b, img_w, img_h, tlx, tly, &fx, &fy, &fw, &fh);
+    const int nb = b->num_bands;
+    int yb[STX_MAX_BANDS + 1], ye[STX_MAX_BANDS + 1];
+    yb[0] = by0; ye[0] = by1;
+    for (int i = 1; i <= nb; i++) {
+        const int ph = b->rh >> i;
+        const int al = i <= nb - 3 ? 7 : 1;
+        yb[i] = std::max(0, (yb[i - 1] >> 1) - 1) & ~al;
+        ye[i] = std::min(ph, ((((ye[i - 1] - 1) >> 1) + 2) + al) & ~al);
+    }
+    const int al = (1 << nb) - 1;
+    long long lo = yb[0], hi = ye[0];
+    for (int i = 1; i <= nb; i++) {
+        lo = std::min(lo, (long long)yb[i] << i);
+        hi = std::max(hi, (long long)ye[i] << i);
+    }
+    lo = lo & ~(long long)al;
+    hi = (hi + al) & ~(long long)al;
+    lo = std::max(lo, (long long)fy);
+    hi = std::min(hi, (long long)fy + fh);
+    if (hi <= lo) return false;
+    const int sy0 = (int)lo, sy1 = (int)hi;
+    const int reach = 3 * (1 << nb) + (1 << nb);
+    const int iy0 = tly - b->ry, iy1 = iy0 + img_h;
+    const int qlo = std::max(sy0 - reach, fy), qhi = std::min(sy1 + reach, fy + fh);
+    int l = std::max(iy0, qlo), h = std::min(iy1, qhi);
+    if (qlo < iy0) h = std::max(h, std::min(iy1, 2 * iy0 - qlo));
+    if (qhi > iy1) l = std::min(l, std::max(iy0, 2 * iy1 - qhi));
+    if (img_h < 2 * reach) { l = iy0; h = iy1; }
+    l = iy0 + ((l - iy0) & ~1);
+    h = std::min(iy1, iy0 + ((h - iy0 + 1) & ~1));
+    *y0 = l - iy0; *y1 = h - iy0;
+    return h > l;
+}
+
+STX_EXPORT int stx_view_rect(const stx_blender* b, int img_w, int img_h, int tlx, int tly, int band_x0, int band_x1, int band_y0,
+                             int band_y1, int out_x0x1y0y1[4])
+{
+    if (!b || !out_x0x1y0y1) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (b->kind != STX_BLEND_MULTIBAND) return stx_fail(STX_ERR_UNSUPPORTED, "multi-band blender only");
+    int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+    if (!mb_strip_range(b, img_w, img_h, tlx, tly, band_x0, band_x1, &x0, &x1) ||
+        !mb_strip_range_y(b, img_w, img_h, tlx, tly, band_y0, band_y1, &y0, &y1))
+        x0 = x1 = y0 = y1 = 0;
+    out_x0x1y0y1[0] = x0; out_x0x1y0y1[1] = x1; out_x0x1y0y1[2] = y0; out_x0x1y0y1[3] = y1;
+    return STX_OK;
+}
+
 STX_EXPORT int stx_strip_rect(const stx_blender* b, int img_w, int img_h, int tlx, int tly, int band_x0, int band_x1, int out_x0x1[2],
                               size_t* out_bytes)
 {

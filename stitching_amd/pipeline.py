@@ -33,8 +33,8 @@ class StitchJob:
         mask) — its grey edges make the masks non-binary.
         crop_to_masks (multi-band blender, feed_masks / seam_masks given as host arrays): a seam mask keeps one cell of its
         image, and nothing farther than the pyramids reach from that cell can touch the panorama.  The reference warps
-        every image whole and cuts afterwards (stitching/stitcher.py:119-127); here only the columns the blender can see
-        are warped, masked and fed — the same panorama bit for bit (`_crop_columns`)."""
+        every image whole and cuts afterwards (stitching/stitcher.py:119-127); here only the rectangle the blender can see
+        are warped, masked and fed — the same panorama bit for bit (`_crop_rects`)."""
         if len(frames) != len(cameras) or not frames:
             raise StitchingError("need one camera per frame and at least one frame")
         self.ctx = ctx or get_context()
@@ -47,14 +47,17 @@ class StitchJob:
         self.num_bands = num_bands
         self.blend_strength = blend_strength
         self.corners = self.warped_sizes = None
-        # per mask the columns [a, b) that hold a non-zero value and the mask's width (host arrays only: no read-back here)
+        # per mask the columns [a, b) and rows [c, d) that hold a non-zero value, and the mask's size (host arrays only: no
+        # read-back here)
         self._mask_cols = None
         given = feed_masks if feed_masks is not None else seam_masks
         if crop_to_masks and given is not None and all(isinstance(m, np.ndarray) for m in given):
             self._mask_cols = []
             for m in given:
-                nz = np.flatnonzero(m.reshape(m.shape[0], m.shape[1], -1).any(axis=(0, 2)))
-                self._mask_cols.append((int(nz[0]), int(nz[-1]) + 1, int(m.shape[1])) if nz.size else None)
+                m2 = m.reshape(m.shape[0], m.shape[1], -1).any(axis=2)
+                nx, ny = np.flatnonzero(m2.any(axis=0)), np.flatnonzero(m2.any(axis=1))
+                self._mask_cols.append((int(nx[0]), int(nx[-1]) + 1, int(m.shape[1]), int(ny[0]), int(ny[-1]) + 1, int(m.shape[0]))
+                                       if nx.size else None)
         self._crop_cache = None
         self.feed_masks = None if feed_masks is None else [as_device(m, self.ctx) for m in feed_masks]
         self.seam_masks = None if seam_masks is None else [as_device(m, self.ctx) for m in seam_masks]
@@ -74,17 +77,18 @@ class StitchJob:
             self.blend_strength = blend_strength_for_bands(self.num_bands, roi[2], roi[3])
         return self.corners, self.warped_sizes
 
-    def _crop_columns(self, handle):
-        """Per image the columns [x0, x1) of its warped image that can influence the panorama, or None (all of them).
+    def _crop_rects(self, handle):
+        """Per image the rectangle (x0, x1, y0, y1) of its warped image that can influence the panorama, or None (all of it).
 
-        The fed mask of image k is non-zero in the columns [m0, m1) only.  Its weight pyramid W_l is then non-zero within
-        2^(l+1) - 2 level-0 columns of them, at most 2^(B+1) — call that range, snapped outwards to the band grid, the
-        image's band.  Outside its band the image adds (short)(L * 0.f) = 0 and 0.f whatever its pixels are; inside it, L
-        and W are what the whole image gives as long as every column within the pyramids' reach of the band is present:
-        exactly the guarantee of the strips of the sharded blender (`stx_strip_rect`), whose cut edges are
-        farther from the band than any pyramid tap.  So the strip for its own band is all of image k that has to exist.
-        Seam masks given at low resolution: the final mask is dilate(3x3) -> INTER_LINEAR_EXACT -> AND, non-zero at x only
-        if a dilated low-resolution column floor(sx) or floor(sx) + 1 is, sx = (x + 0.5) * lw / w - 0.5."""
+        The fed mask of image k is non-zero inside the columns [m0, m1) and rows [n0, n1) only.  Its weight pyramid W_l is then
+        non-zero within 2^(l+1) - 2 level-0 pixels of that box, at most 2^(B+1) — call that box, snapped outwards to the band
+        grid, the image's band.  Outside its band the image adds (short)(L * 0.f) = 0 and 0.f whatever its pixels are; inside
+        it, L and W are what the whole image gives as long as everything within the pyramids' reach of the band is present:
+        exactly the guarantee of the strips of the sharded blender (`stx_strip_rect`; `stx_view_rect` adds the
+        same range along y), whose cut edges are farther from the band than any pyramid tap.  So the view for its own band is
+        all of image k that has to exist.  Seam masks given at low resolution: the final mask is dilate(3x3) ->
+        INTER_LINEAR_EXACT -> AND, non-zero at x only if a dilated low-resolution column floor(sx) or floor(sx) + 1 is,
+        sx = (x + 0.5) * lw / w - 0.5 (rows alike)."""
         key = (tuple(self.corners), tuple(self.warped_sizes), self.blend_strength)
         if self._crop_cache is not None and self._crop_cache[0] == key:
             return self._crop_cache[1]
@@ -93,23 +97,33 @@ class StitchJob:
         out = None
         if B > 0:
             align, reach = max(8, 1 << B), 2 << B
+
+            def band(lo, hi, size, msize, origin):
+                if msize != size:  # low-resolution seam mask: the final-mask positions that can be non-zero
+                    lo = int(np.floor((lo - 2 + 0.5) * size / msize - 0.5)) - 1
+                    hi = int(np.ceil((hi + 2 + 0.5) * size / msize - 0.5)) + 1
+                lo, hi = max(lo, 0), min(hi, size)
+                return max(((origin + lo - reach) // align) * align, 0), -((-(origin + hi + reach)) // align) * align
+
             out = []
-            for (cx, cy), (w, h), cols in zip(self.corners, self.warped_sizes, self._mask_cols):
-                if cols is None:
+            for (cx, cy), (w, h), box in zip(self.corners, self.warped_sizes, self._mask_cols):
+                if box is None:
                     out.append(None)
                     continue
-                a, b, mw = cols
-                if mw != w:  # low-resolution seam mask: the columns of the final mask that can be non-zero
-                    a = int(np.floor((a - 2 + 0.5) * w / mw - 0.5)) - 1
-                    b = int(np.ceil((b + 2 + 0.5) * w / mw - 0.5)) + 1
-                a, b = max(a, 0), min(b, w)
-                lo = max(((cx - roi[0] + a - reach) // align) * align, 0)
-                hi = -((-(cx - roi[0] + b + reach)) // align) * align
-                xs, nbytes = (C.c_int * 2)(), C.c_size_t()
-                _lib.check(self.ctx._lib.stx_strip_rect(handle._h, int(w), int(h), int(cx), int(cy), int(lo), int(hi), xs,
-                                                        C.byref(nbytes)))
-                x0, x1 = int(xs[0]), int(xs[1])
-                out.append((x0, x1) if 0 < x1 - x0 <= 0.9 * w else None)
+                bx0, bx1 = band(box[0], box[1], w, box[2], cx - roi[0])
+                by0, by1 = band(box[3], box[4], h, box[5], cy - roi[1])
+                r = (C.c_int * 4)()
+                _lib.check(self.ctx._lib.stx_view_rect(handle._h, int(w), int(h), int(cx), int(cy), int(bx0), int(bx1), int(by0),
+                                                       int(by1), r))
+                x0, x1, y0, y1 = (int(v) for v in r)
+                if x1 <= x0 or y1 <= y0:
+                    out.append(None)
+                    continue
+                if x1 - x0 > 0.9 * w:
+                    x0, x1 = 0, w
+                if y1 - y0 > 0.9 * h:
+                    y0, y1 = 0, h
+                out.append((x0, x1, y0, y1) if (x1 - x0) * (y1 - y0) < w * h else None)
             if all(o is None for o in out):
                 out = None
         self._crop_cache = (key, out)
@@ -127,18 +141,18 @@ class StitchJob:
             blender.prepare(self.corners, self.warped_sizes)
             crop = None
             if self._mask_cols is not None and blender.blender.kind == _lib.BLEND_MULTIBAND:
-                crop = self._crop_columns(blender.blender)
+                crop = self._crop_rects(blender.blender)
             if crop is not None:
-                cols = [c if c is not None else (0, w) for c, (w, h) in zip(crop, self.warped_sizes)]
-                rects = [(cx + x0, cy, x1 - x0, h) for (x0, x1), (cx, cy), (w, h) in zip(cols, self.corners, self.warped_sizes)]
+                box = [c if c is not None else (0, w, 0, h) for c, (w, h) in zip(crop, self.warped_sizes)]
+                rects = [(cx + x0, cy + y0, x1 - x0, y1 - y0) for (x0, x1, y0, y1), (cx, cy) in zip(box, self.corners)]
                 imgs, masks, rois = self.warper.warp_images_and_masks(self.frames, self.cameras, rects=rects)
                 if self.feed_masks is not None:
-                    masks = [m[:, x0:x1] for m, (x0, x1) in zip(self.feed_masks, cols)]
+                    masks = [m[y0:y1, x0:x1] for m, (x0, x1, y0, y1) in zip(self.feed_masks, box)]
                 else:
                     from .seam_finder import SeamFinder
 
                     masks = SeamFinder.resize_all(self.seam_masks, masks,
-                                                  sub=[(w, h, x0, 0) for (x0, x1), (w, h) in zip(cols, self.warped_sizes)])
+                                                  sub=[(w, h, x0, y0) for (x0, x1, y0, y1), (w, h) in zip(box, self.warped_sizes)])
                 corners = [(r[0], r[1]) for r in rects]
             else:
                 imgs, masks, rois = self.warper.warp_images_and_masks(self.frames, self.cameras)

@@ -1,5 +1,5 @@
-"""StitchJob(crop_to_masks=True): with seam masks only the columns of every warped image that the blender can see are
-warped, masked and fed (stitching_amd/pipeline.py: _crop_columns).  The reference warps every image whole and cuts
+"""StitchJob(crop_to_masks=True): with seam masks only the rectangle of every warped image that the blender can see is
+warped, masked and fed (stitching_amd/pipeline.py: _crop_rects).  The reference warps every image whole and cuts
 afterwards (stitching/stitcher.py:119-127); the panorama must be the same bit for bit — against the oracle's whole-image
 chain and against the uncropped job."""
 import numpy as np
@@ -104,3 +104,31 @@ def test_warp_rects_and_seam_resize_rects_equal_the_whole(oracle, gpu_ctx):
             assert np.array_equal(np.asarray(part[k]), np.asarray(whole[k])[:, x0:x0 + rects[k][2]])
     finally:
         S.set_device_resident(False)
+
+
+@pytest.mark.parametrize("low", [False, True])
+@pytest.mark.parametrize("wtype", ["spherical", "cylindrical"])
+def test_crop_rows_and_columns_of_a_multi_row_panorama(oracle, gpu_ctx, wtype, low):
+    """3 yaw columns x 3 pitch rows: the seam cell of the middle frame touches none of its edges, the rectangle that is warped
+    is cut on all four sides (rows through stx_view_rect's y range)."""
+    cols, rows, w, h = 3, 3, 900, 700
+    cams = synthetic.grid_cameras(cols, rows, w, h, span_deg=95.0, max_edge_lat_deg=42.0)
+    imgs = [synthetic.make_frame(i, w, h) for i in range(cols * rows)]
+
+    def fed_fn(wmasks, corners, sizes):
+        v = synthetic.voronoi_seam_masks(wmasks, corners, sizes)
+        if not low:
+            return v
+        fed_fn.low = [np.ascontiguousarray(m[::6, ::6]) for m in v]
+        return [oracle.seam_resize(l, m) for l, m in zip(fed_fn.low, wmasks)]
+
+    opano, omask, fed, _, _, wsizes = _oracle_chain(oracle, imgs, cams, wtype, 2, fed_fn)
+    kw = dict(seam_masks=fed_fn.low) if low else dict(feed_masks=fed)
+    job = StitchJob(imgs, cams, warper_type=wtype, blend_strength=2, ctx=gpu_ctx, **kw)
+    pano, mask = job.run()
+    assert job.last_crop is not None
+    cut_rows = [c for c, (ww, hh) in zip(job.last_crop, wsizes) if c is not None and (c[2] > 0 or c[3] < hh)]
+    cut_cols = [c for c, (ww, hh) in zip(job.last_crop, wsizes) if c is not None and (c[0] > 0 or c[1] < ww)]
+    assert cut_rows and cut_cols, job.last_crop
+    assert np.array_equal(np.asarray(mask), omask)
+    assert np.array_equal(np.asarray(pano), opano), int(np.count_nonzero(np.asarray(pano) != opano))
