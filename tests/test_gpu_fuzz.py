@@ -130,3 +130,49 @@ def test_random_sharded_blend_bit_exact(oracle, gpu_ctx, seed):
     assert pano.shape == o["pano"].shape, tag
     assert np.array_equal(mask, o["pmask"]), tag
     assert np.array_equal(pano, o["pano"]), (tag, int(np.count_nonzero(pano != o["pano"])))
+
+
+@pytest.mark.parametrize("seed", list(range(16 + EXTRA)))
+def test_random_crop_to_masks_bit_exact(oracle, gpu_ctx, seed):
+    """StitchJob(crop_to_masks): rings and multi-row grids with Voronoi seam masks at full or low resolution, random sizes,
+    overlaps and band counts — the panorama of the job that warps and feeds only what each seam cell can reach is the one the
+    oracle gets from whole images."""
+    from stitching_amd.pipeline import StitchJob
+
+    rng = np.random.default_rng(9000 + seed)
+    wtype = str(rng.choice(["spherical", "cylindrical", "spherical", "plane"]))
+    w, h = int(rng.integers(500, 1500)), int(rng.integers(300, 800))
+    strength = float(rng.choice([1, 2, 3, 5, 8]))
+    if seed % 3 == 2 and wtype != "plane":
+        cols, rows = int(rng.integers(2, 4)), int(rng.integers(2, 4))
+        cams = synthetic.grid_cameras(cols, rows, w, h, span_deg=float(rng.uniform(24.0, 34.0)) * cols + 30.0,
+                                      max_edge_lat_deg=float(rng.uniform(35.0, 55.0)) if wtype == "spherical" else 40.0)
+        n = cols * rows
+    else:
+        n = int(rng.integers(3, 7))
+        span = float(rng.uniform(14.0, 34.0)) * n
+        if wtype == "plane":
+            span = min(span, 75.0)
+        cams = synthetic.ring_cameras(n, w, h, span_deg=span)
+    imgs = [synthetic.make_frame(int(rng.integers(0, 1000)), w, h) for _ in range(n)]
+    scale = int(rng.choice([0, 0, 4, 7, 10]))  # 0: full-resolution masks
+    ow = oracle.Warper(wtype)
+    ow.set_scale(cams)
+    sizes = [(w, h)] * n
+    corners, wsizes = ow.warp_rois(sizes, cams)
+    wimgs = [ow.warp_image(im, c) for im, c in zip(imgs, cams)]
+    wmasks = [ow.create_and_warp_mask(s, c) for s, c in zip(sizes, cams)]
+    seams = synthetic.voronoi_seam_masks(wmasks, corners, wsizes)
+    low = [np.ascontiguousarray(m[::scale, ::scale]) for m in seams] if scale else None
+    fed = [oracle.seam_resize(l, m) for l, m in zip(low, wmasks)] if scale else seams
+    ob = oracle.Blender("multiband", strength)
+    ob.prepare(corners, wsizes)
+    for im, m, c in zip(wimgs, fed, corners):
+        ob.feed(im, m, c)
+    opano, omask = (np.asarray(a) for a in ob.blend())
+    kw = dict(seam_masks=low) if scale else dict(feed_masks=fed)
+    job = StitchJob(imgs, cams, warper_type=wtype, blend_strength=strength, ctx=gpu_ctx, **kw)
+    pano, mask = job.run()
+    tag = dict(wtype=wtype, n=n, w=w, h=h, strength=strength, scale=scale, crop=job.last_crop)
+    assert np.array_equal(np.asarray(mask), omask), tag
+    assert np.array_equal(np.asarray(pano), opano), (tag, int(np.count_nonzero(np.asarray(pano) != opano)))
