@@ -240,6 +240,9 @@ int stx_blend_feed_contrib(stx_blender* b, int order, const int rect_xywh[4], co
  * receiver may keep the packed 16-bit level-0 kernel).  stx_buf_flags reads it off an exported strip (or a mask:
  * the same bit says "only 0 / 255"). */
 #define STX_CONTRIB_U8_BINARY 1
+/* STX_STRIP_MASK_BITS (strips only): the mask rows of the flat buffer hold one bit per pixel instead of a byte (a 0 / 255 mask:
+ * 3.125 instead of 4 bytes per pixel on the link); stx_strip_unpack / stx_blend_feed_strips expand them into a mask buffer. */
+#define STX_STRIP_MASK_BITS 2
 int stx_blend_feed_contrib_ex(stx_blender* b, int order, const int rect_xywh[4], const stx_buf* packed, int flags);
 int stx_buf_flags(const stx_buf* buf, int* out_flags);
 
@@ -260,6 +263,10 @@ int stx_strip_pack(stx_ctx* ctx, const stx_buf* img, const stx_buf* mask, int x0
 /* all strips a rank owes in one call (one copy kernel per 16 strips); x0 multiples of 8, whole image buffers (no views) */
 int stx_strip_pack_batch(stx_ctx* ctx, int n, const stx_buf* const* imgs, const stx_buf* const* masks, const int* x0s, const int* x1s,
                          stx_buf** out_packed);
+/* the same with flags (STX_STRIP_MASK_BITS); stx_strip_bytes: size of the flat buffer of a w x h strip under these flags */
+int stx_strip_pack_batch_ex(stx_ctx* ctx, int n, const stx_buf* const* imgs, const stx_buf* const* masks, const int* x0s, const int* x1s,
+                            int flags, stx_buf** out_packed);
+int stx_strip_bytes(int w, int h, int flags, size_t* out_bytes);
 /* all received strips in one call: unpack + stx_blend_feed_ex(strip i at (tlxs[i], tlys[i]), orders[i]) */
 int stx_blend_feed_strips(stx_blender* b, int n, const stx_buf* const* packed, const int* ws, const int* hs, const int* tlxs,
                           const int* tlys, const int* orders, int flags);

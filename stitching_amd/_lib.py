@@ -24,6 +24,7 @@ BORDER_CONSTANT, BORDER_REFLECT = 0, 2
 BLEND_NO, BLEND_FEATHER, BLEND_MULTIBAND = 0, 1, 2
 U8, S16, F32 = 0, 1, 2
 CONTRIB_U8_BINARY = 1
+STRIP_MASK_BITS = 2
 
 EXPORTS = (
     "stx_version stx_last_error stx_device_count stx_ctx_create stx_ctx_destroy stx_ctx_sync "
@@ -31,7 +32,7 @@ EXPORTS = (
     "stx_warp_roi stx_warp_rois stx_warp stx_warp_image_and_mask stx_warp_batch stx_warp_batch_rects stx_warp_mask "
     "stx_gain_apply stx_block_gain_apply stx_resize_linear_exact stx_seam_mask_resize stx_seam_mask_resize_batch stx_seam_mask_resize_batch_sub stx_timelapse_frame stx_result_roi stx_blend_create stx_blend_num_bands stx_blend_feed stx_blend_finish stx_blend_finish_ex "
     "stx_blend_destroy stx_blend_set_band stx_blend_feed_ex stx_blend_contrib_rect stx_blend_export_contrib stx_blend_export_contribs "
-    "stx_blend_build stx_blend_feed_contrib stx_blend_feed_contrib_ex stx_buf_flags stx_strip_rect stx_view_rect stx_strip_pack stx_strip_pack_batch stx_strip_unpack stx_blend_feed_strips stx_comm_unique_id stx_comm_create stx_comm_exchange stx_comm_exchange_begin stx_comm_exchange_end stx_comm_exchange_begin_on stx_comm_exchange_end_on stx_comm_destroy stx_prof_enable stx_prof_reset stx_prof_count stx_prof_get stx_mark stx_mark_elapsed_ms"
+    "stx_blend_build stx_blend_feed_contrib stx_blend_feed_contrib_ex stx_buf_flags stx_strip_rect stx_view_rect stx_strip_pack stx_strip_pack_batch stx_strip_pack_batch_ex stx_strip_bytes stx_strip_unpack stx_blend_feed_strips stx_comm_unique_id stx_comm_create stx_comm_exchange stx_comm_exchange_begin stx_comm_exchange_end stx_comm_exchange_begin_on stx_comm_exchange_end_on stx_comm_destroy stx_prof_enable stx_prof_reset stx_prof_count stx_prof_get stx_mark stx_mark_elapsed_ms"
 ).split()
 
 _lib = None
@@ -105,6 +106,8 @@ def lib():
     L.stx_strip_pack.argtypes = [vp, vp, vp, C.c_int, C.c_int, vpp]
     L.stx_strip_unpack.argtypes = [vp, C.c_int, C.c_int, C.c_int, vpp, vpp]
     L.stx_strip_pack_batch.argtypes = [vp, C.c_int, vpp, vpp, ip, ip, vpp]
+    L.stx_strip_pack_batch_ex.argtypes = [vp, C.c_int, vpp, vpp, ip, ip, C.c_int, vpp]
+    L.stx_strip_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
     L.stx_blend_feed_strips.argtypes = [vp, C.c_int, vpp, ip, ip, ip, ip, ip, C.c_int]
     L.stx_comm_unique_id.argtypes = [C.POINTER(C.c_ubyte)]
     L.stx_comm_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte), vpp]

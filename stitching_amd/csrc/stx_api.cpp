@@ -112,6 +112,7 @@ STX_EXPORT int stx_ctx_destroy(stx_ctx* ctx)
     for (auto e : ctx->marks) if (e) hipEventDestroy(e);
     if (ctx->pinned) hipHostFree(ctx->pinned);
     if (ctx->stage) hipHostFree(ctx->stage);
+    for (hipEvent_t e : ctx->stage_ev) if (e) hipEventDestroy(e);
     if (ctx->aux_scratch) hipFree(ctx->aux_scratch);
     if (ctx->aux_stream) hipStreamDestroy(ctx->aux_stream);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -165,6 +166,34 @@ void stx_dev_free(stx_ctx* ctx, void* p)
     auto it = ctx->block_size.find(p);
     if (it == ctx->block_size.end()) return;
     ctx->free_blocks[it->second].push_back(p);
+}
+
+int stx_stage_upload(stx_ctx* ctx, void* d, const void* h, size_t bytes)
+{
+    if (bytes == 0) return STX_OK;
+    const size_t seg = ctx->stage_bytes / STX_STAGE_SEGS;
+    if (bytes > seg) {  // larger than a segment of the ring: plain synchronous copy
+        STX_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+        STX_HIP(hipStreamSynchronize(ctx->stream));
+        return STX_OK;
+    }
+    size_t off = ctx->stage_off;
+    int cur = ctx->stage_seg;  // the segment that holds the previous upload
+    if (off + bytes > (size_t)(cur + 1) * seg) {  // does not fit into the rest of it: on to the next segment
+        const int next = (cur + 1) % STX_STAGE_SEGS;
+        if (!ctx->stage_ev[cur]) STX_HIP(hipEventCreateWithFlags(&ctx->stage_ev[cur], hipEventDisableTiming));
+        STX_HIP(hipEventRecord(ctx->stage_ev[cur], ctx->stream));  // behind the last copy out of segment `cur`
+        ctx->stage_ev_set[cur] = true;
+        if (ctx->stage_ev_set[next]) STX_HIP(hipEventSynchronize(ctx->stage_ev[next]));  // its copies of the previous lap
+        off = (size_t)next * seg;
+        cur = next;
+    }
+    ctx->stage_seg = cur;
+    uint8_t* slot = ctx->stage + off;
+    memcpy(slot, h, bytes);
+    ctx->stage_off = off + ((bytes + 255) & ~(size_t)255);
+    STX_HIP(hipMemcpyAsync(d, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return STX_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -527,22 +556,8 @@ static int upload_small(stx_ctx* ctx, const void* h, size_t bytes, void** d_out)
 {
     void* d = nullptr;
     STX_TRY(stx_dev_alloc(ctx, std::max<size_t>(bytes, 4), &d));
-    if (bytes > ctx->stage_bytes) {
-        hipError_t e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) { stx_dev_free(ctx, d); return stx_fail(STX_ERR_HIP, "upload: %s", hipGetErrorString(e)); }
-    } else if (bytes > 0) {
-        if (ctx->stage_off + bytes > ctx->stage_bytes) {
-            hipError_t e = hipStreamSynchronize(ctx->stream);
-            if (e != hipSuccess) { stx_dev_free(ctx, d); return stx_fail(STX_ERR_HIP, "upload: %s", hipGetErrorString(e)); }
-            ctx->stage_off = 0;
-        }
-        uint8_t* slot = ctx->stage + ctx->stage_off;
-        memcpy(slot, h, bytes);
-        ctx->stage_off += (bytes + 255) & ~(size_t)255;
-        hipError_t e = hipMemcpyAsync(d, slot, bytes, hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) { stx_dev_free(ctx, d); return stx_fail(STX_ERR_HIP, "upload: %s", hipGetErrorString(e)); }
-    }
+    const int rc = stx_stage_upload(ctx, d, h, bytes);
+    if (rc != STX_OK) { stx_dev_free(ctx, d); return rc; }
     *d_out = d;
     return STX_OK;
 }
@@ -1357,22 +1372,7 @@ static int mb_upload(stx_blender* b, const StxMbImage* h, int n, StxMbImage** d_
     void* d = nullptr;
     STX_TRY(stx_dev_alloc(ctx, sizeof(StxMbImage) * std::max(n, 1), &d));
     b->pyr_allocs.push_back(d);
-    if (n > 0) {
-        const size_t bytes = sizeof(StxMbImage) * (size_t)n;
-        if (bytes > ctx->stage_bytes) {  // larger than the ring: plain synchronous copy
-            STX_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
-            STX_HIP(hipStreamSynchronize(ctx->stream));
-        } else {
-            if (ctx->stage_off + bytes > ctx->stage_bytes) {  // wrap: earlier slots may still be in flight
-                STX_HIP(hipStreamSynchronize(ctx->stream));
-                ctx->stage_off = 0;
-            }
-            uint8_t* slot = ctx->stage + ctx->stage_off;
-            memcpy(slot, h, bytes);
-            ctx->stage_off += (bytes + 255) & ~(size_t)255;
-            STX_HIP(hipMemcpyAsync(d, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
-        }
-    }
+    if (n > 0) STX_TRY(stx_stage_upload(ctx, d, h, sizeof(StxMbImage) * (size_t)n));
     *d_out = (StxMbImage*)d;
     return STX_OK;
 }
@@ -1627,11 +1627,20 @@ static bool mb_strip_range(const stx_blender* b, int img_w, int img_h, int tlx, 
     return hi > lo;
 }
 
-static void strip_layout(int w, int h, size_t* img_stride, size_t* mask_stride, size_t* bytes)
+// flags & STX_STRIP_MASK_BITS: the mask rows hold one bit per pixel (0 / 255 masks only)
+static void strip_layout(int w, int h, int flags, size_t* img_stride, size_t* mask_stride, size_t* bytes)
 {
     *img_stride = align_up(align_up((size_t)w, 8) * 3, 64);
-    *mask_stride = align_up(align_up((size_t)w, 8), 64);
+    *mask_stride = (flags & STX_STRIP_MASK_BITS) ? align_up(align_up((size_t)w, 8) / 8, 64) : align_up(align_up((size_t)w, 8), 64);
     *bytes = (*img_stride + *mask_stride) * (size_t)h;
+}
+
+STX_EXPORT int stx_strip_bytes(int w, int h, int flags, size_t* out_bytes)
+{
+    if (!out_bytes || w <= 0 || h <= 0) return stx_fail(STX_ERR_INVALID, "strip of %dx%d", w, h);
+    size_t si, sm;
+    strip_layout(w, h, flags, &si, &sm, out_bytes);
+    return STX_OK;
 }
 
 // The same range along y (rows [y0, y1) of an image that the rows [by0, by1) of the panorama depend on): pyrDown / pyrUp and
@@ -1699,7 +1708,7 @@ STX_EXPORT int stx_strip_rect(const stx_blender* b, int img_w, int img_h, int tl
     out_x0x1[0] = x0; out_x0x1[1] = x1;
     if (out_bytes) {
         size_t si, sm, nb = 0;
-        if (x1 > x0) strip_layout(x1 - x0, img_h, &si, &sm, &nb);
+        if (x1 > x0) strip_layout(x1 - x0, img_h, 0, &si, &sm, &nb);
         *out_bytes = nb;
     }
     return STX_OK;
@@ -1707,8 +1716,8 @@ STX_EXPORT int stx_strip_rect(const stx_blender* b, int img_w, int img_h, int tl
 
 // columns [x0, x1) of u8x3 images and of their u8 masks -> one flat buffer each: the image rows (pitch as an image buffer
 // of that width has it), then the mask rows.  All strips of a call are copied by one kernel launch per 16 strips.
-STX_EXPORT int stx_strip_pack_batch(stx_ctx* ctx, int n, const stx_buf* const* imgs, const stx_buf* const* masks, const int* x0s,
-                                    const int* x1s, stx_buf** out_packed)
+static int strip_pack_batch_impl(stx_ctx* ctx, int n, const stx_buf* const* imgs, const stx_buf* const* masks, const int* x0s,
+                                 const int* x1s, int flags, stx_buf** out_packed)
 {
     if (!ctx || n < 0 || (n > 0 && (!imgs || !masks || !x0s || !x1s || !out_packed))) return stx_fail(STX_ERR_INVALID, "null argument");
     STX_TRY(stx_set_device(ctx));
@@ -1724,15 +1733,17 @@ STX_EXPORT int stx_strip_pack_batch(stx_ctx* ctx, int n, const stx_buf* const* i
             rc = stx_fail(STX_ERR_INVALID, "strip columns [%d,%d) of %d (x0 must be a multiple of 8)", x0s[i], x1s[i], img->w);
         else if (img->parent || mask->parent)
             rc = stx_fail(STX_ERR_INVALID, "strip: whole image buffers only (rows of whole 8-pixel groups)");
+        else if ((flags & STX_STRIP_MASK_BITS) && !mask->mask_binary)
+            rc = stx_fail(STX_ERR_INVALID, "strip: a mask can travel as bits only when it is known to hold 0 / 255");
         if (rc != STX_OK) break;
         ws[i] = x1s[i] - x0s[i];
         size_t nbytes;
-        strip_layout(ws[i], img->h, &si[i], &sm[i], &nbytes);
+        strip_layout(ws[i], img->h, flags, &si[i], &sm[i], &nbytes);
         if (nbytes > ((size_t)1 << 30)) { rc = stx_fail(STX_ERR_UNSUPPORTED, "strip larger than 1 GiB"); break; }
         rc = stx_buf_new(ctx, (int)nbytes, 1, 1, STX_U8, &flats[i]);
         if (rc == STX_OK) flats[i]->mask_binary = mask->mask_binary;
     }
-    if (rc == STX_OK) rc = stx_launch_strip_pack(ctx, n, imgs, masks, x0s, ws.data(), flats.data(), si.data(), sm.data());
+    if (rc == STX_OK) rc = stx_launch_strip_pack(ctx, n, imgs, masks, x0s, ws.data(), flats.data(), si.data(), sm.data(), (flags & STX_STRIP_MASK_BITS) != 0);
     if (rc != STX_OK) {
         for (stx_buf* f : flats) stx_buf_release(f);
         return rc;
@@ -1741,50 +1752,90 @@ STX_EXPORT int stx_strip_pack_batch(stx_ctx* ctx, int n, const stx_buf* const* i
     return STX_OK;
 }
 
+STX_EXPORT int stx_strip_pack_batch(stx_ctx* ctx, int n, const stx_buf* const* imgs, const stx_buf* const* masks, const int* x0s,
+                                    const int* x1s, stx_buf** out_packed)
+{
+    return strip_pack_batch_impl(ctx, n, imgs, masks, x0s, x1s, 0, out_packed);
+}
+
+STX_EXPORT int stx_strip_pack_batch_ex(stx_ctx* ctx, int n, const stx_buf* const* imgs, const stx_buf* const* masks, const int* x0s,
+                                       const int* x1s, int flags, stx_buf** out_packed)
+{
+    return strip_pack_batch_impl(ctx, n, imgs, masks, x0s, x1s, flags, out_packed);
+}
+
 STX_EXPORT int stx_strip_pack(stx_ctx* ctx, const stx_buf* img, const stx_buf* mask, int x0, int x1, stx_buf** out_packed)
 {
     return stx_strip_pack_batch(ctx, 1, &img, &mask, &x0, &x1, out_packed);
 }
 
-// the image and mask of a received strip as views of the flat buffer (which they keep alive)
+// the image and mask of received strips: views of the flat buffers (which they keep alive); with STX_STRIP_MASK_BITS the masks
+// are fresh buffers filled by one expand launch per 16 strips
+static int strip_unpack_impl(int n, const stx_buf* const* packed, const int* ws, const int* hs, int flags, stx_buf** out_imgs,
+                             stx_buf** out_masks)
+{
+    const bool bits = (flags & STX_STRIP_MASK_BITS) != 0;
+    std::vector<const uint8_t*> bit_rows(n, nullptr);
+    std::vector<size_t> sms(n, 0);
+    for (int i = 0; i < n; i++) out_imgs[i] = out_masks[i] = nullptr;
+    int rc = STX_OK;
+    for (int i = 0; i < n && rc == STX_OK; i++) {
+        const stx_buf* p = packed[i];
+        size_t si, sm, nbytes;
+        if (!p || ws[i] <= 0 || hs[i] <= 0) { rc = stx_fail(STX_ERR_INVALID, "strip of %dx%d", ws[i], hs[i]); break; }
+        strip_layout(ws[i], hs[i], flags, &si, &sm, &nbytes);
+        if (p->elem != STX_U8 || p->c != 1 || p->h != 1 || (size_t)p->w < nbytes) {
+            rc = stx_fail(STX_ERR_INVALID, "packed strip of %d bytes, %zu needed for %dx%d", p->w, nbytes, ws[i], hs[i]);
+            break;
+        }
+        stx_buf* root = const_cast<stx_buf*>(p);
+        for (int k = 0; k < (bits ? 1 : 2); k++) {
+            stx_buf* v = new stx_buf();
+            v->ctx = p->ctx; v->base = p->base;
+            v->ptr = p->ptr + (k ? si * (size_t)hs[i] : 0);
+            v->w = ws[i]; v->h = hs[i]; v->c = k ? 1 : 3; v->elem = STX_U8;
+            v->stride = k ? sm : si;
+            v->parent = root;
+            v->mask_binary = k && (flags & STX_CONTRIB_U8_BINARY) ? 1 : 0;
+            stx_buf_retain(root);
+            (k ? out_masks : out_imgs)[i] = v;
+        }
+        if (bits) {
+            rc = stx_buf_new(p->ctx, ws[i], hs[i], 1, STX_U8, &out_masks[i]);
+            if (rc == STX_OK) out_masks[i]->mask_binary = 1;
+            bit_rows[i] = p->ptr + si * (size_t)hs[i];
+            sms[i] = sm;
+        }
+    }
+    if (rc == STX_OK && bits && n > 0) {
+        rc = stx_set_device(packed[0]->ctx);
+        if (rc == STX_OK) rc = stx_launch_strip_bits_expand(packed[0]->ctx, n, bit_rows.data(), sms.data(), out_masks);
+    }
+    if (rc != STX_OK)
+        for (int i = 0; i < n; i++) { stx_buf_release(out_imgs[i]); stx_buf_release(out_masks[i]); out_imgs[i] = out_masks[i] = nullptr; }
+    return rc;
+}
+
 STX_EXPORT int stx_strip_unpack(const stx_buf* packed, int w, int h, int flags, stx_buf** out_img, stx_buf** out_mask)
 {
     if (!packed || !out_img || !out_mask) return stx_fail(STX_ERR_INVALID, "null argument");
-    size_t si, sm, nbytes;
-    if (w <= 0 || h <= 0) return stx_fail(STX_ERR_INVALID, "strip of %dx%d", w, h);
-    strip_layout(w, h, &si, &sm, &nbytes);
-    if (packed->elem != STX_U8 || packed->c != 1 || packed->h != 1 || (size_t)packed->w < nbytes)
-        return stx_fail(STX_ERR_INVALID, "packed strip of %d bytes, %zu needed for %dx%d", packed->w, nbytes, w, h);
-    stx_buf* root = const_cast<stx_buf*>(packed);
-    for (int k = 0; k < 2; k++) {
-        stx_buf* v = new stx_buf();
-        v->ctx = packed->ctx; v->base = packed->base;
-        v->ptr = packed->ptr + (k ? si * (size_t)h : 0);
-        v->w = w; v->h = h; v->c = k ? 1 : 3; v->elem = STX_U8;
-        v->stride = k ? sm : si;
-        v->parent = root;
-        v->mask_binary = k && (flags & STX_CONTRIB_U8_BINARY) ? 1 : 0;
-        stx_buf_retain(root);
-        *(k ? out_mask : out_img) = v;
-    }
-    return STX_OK;
+    return strip_unpack_impl(1, &packed, &w, &h, flags, out_img, out_mask);
 }
 
-// feed n received strips (flat buffers of stx_strip_pack) in one call: strip i holds w[i] x h[i] pixels and belongs at
-// corner (tlx[i], tly[i]) with the global feed index orders[i]
 STX_EXPORT int stx_blend_feed_strips(stx_blender* b, int n, const stx_buf* const* packed, const int* ws, const int* hs, const int* tlxs,
                                      const int* tlys, const int* orders, int flags)
 {
     if (!b || n < 0 || (n > 0 && (!packed || !ws || !hs || !tlxs || !tlys || !orders))) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (n == 0) return STX_OK;
+    std::vector<stx_buf*> imgs(n, nullptr), masks(n, nullptr);
+    STX_TRY(strip_unpack_impl(n, packed, ws, hs, flags, imgs.data(), masks.data()));
+    int rc = STX_OK;
     for (int i = 0; i < n; i++) {
-        stx_buf *img = nullptr, *mask = nullptr;
-        STX_TRY(stx_strip_unpack(packed[i], ws[i], hs[i], flags, &img, &mask));
-        const int rc = stx_blend_feed_ex(b, img, mask, tlxs[i], tlys[i], orders[i]);
-        stx_buf_release(img);  // the blender holds its own references
-        stx_buf_release(mask);
-        if (rc != STX_OK) return rc;
+        if (rc == STX_OK) rc = stx_blend_feed_ex(b, imgs[i], masks[i], tlxs[i], tlys[i], orders[i]);
+        stx_buf_release(imgs[i]);  // the blender holds its own references
+        stx_buf_release(masks[i]);
     }
-    return STX_OK;
+    return rc;
 }
 
 STX_EXPORT int stx_blend_export_contrib(stx_blender* b, int order, int band_x0, int band_x1, stx_buf** out_packed,
@@ -1956,22 +2007,7 @@ static int no_finish(stx_blender* b, stx_buf* pano, stx_buf* pmask, stx_buf* p16
         bytes += (double)im.w * im.h;  // every mask once; the image bytes of the winners are counted with the output
     }
     bytes += 3.0 * pano->w * pano->h;
-    if (n > 0) {
-        const size_t nbytes = sizeof(NoImg) * (size_t)n;
-        if (nbytes > ctx->stage_bytes) {
-            STX_HIP(hipMemcpyAsync(d_tab, b->no_images.data(), nbytes, hipMemcpyHostToDevice, ctx->stream));
-            STX_HIP(hipStreamSynchronize(ctx->stream));
-        } else {
-            if (ctx->stage_off + nbytes > ctx->stage_bytes) {
-                STX_HIP(hipStreamSynchronize(ctx->stream));
-                ctx->stage_off = 0;
-            }
-            uint8_t* slot = ctx->stage + ctx->stage_off;
-            memcpy(slot, b->no_images.data(), nbytes);
-            ctx->stage_off += (nbytes + 255) & ~(size_t)255;
-            STX_HIP(hipMemcpyAsync(d_tab, slot, nbytes, hipMemcpyHostToDevice, ctx->stream));
-        }
-    }
+    if (n > 0) STX_TRY(stx_stage_upload(ctx, d_tab, b->no_images.data(), sizeof(NoImg) * (size_t)n));
     NoGatherK K;
     K.imgs = (const NoImg*)d_tab; K.n = n; K.all_binary = all_binary ? 1 : 0;
     K.w = pano->w; K.h = pano->h;

@@ -878,9 +878,34 @@ int stx_launch_gain_apply(stx_ctx* ctx, stx_buf* img, const float g[3])
 // ---------------------------------------------------------------------------------------------
 namespace {
 constexpr int STRIP_BATCH = 16;
-struct StripK { const uint8_t* img; const uint8_t* mask; uint8_t* dst; long long istride, mstride, si, sm; int h, img_chunks, mask_chunks; };
+struct StripK { const uint8_t* img; const uint8_t* mask; uint8_t* dst; long long istride, mstride, si, sm; int h, img_chunks, mask_chunks, bits; };
 struct StripBatchK { StripK k[STRIP_BATCH]; };
 constexpr int STRIP_ROWS = 4;  // rows per workgroup: four independent 8-byte copies in flight per lane
+// bit j of the result = byte j of m is not 0
+STX_DEV uint32_t strip_nz4(uint32_t m)
+{
+    const uint32_t t = ((((m & 0x7f7f7f7fu) + 0x7f7f7f7fu) | m) & 0x80808080u) >> 7;  // bit 8 j = byte j != 0
+    return (t | (t >> 7) | (t >> 14) | (t >> 21)) & 15u;
+}
+// receiver side of STX_STRIP_MASK_BITS: one byte of bits -> 8 mask bytes 0 / 255 (a lane per 8 pixels, rows on blockIdx.y)
+struct StripBitsK { const uint8_t* bits; long long sm; uint8_t* mask; long long mstride; int groups, h; };
+struct StripBitsBatchK { StripBitsK k[STRIP_BATCH]; };
+__global__ __launch_bounds__(256) void strip_bits_expand_kernel(StripBitsBatchK B)
+{
+    const StripBitsK& P = B.k[blockIdx.z];
+    const int row0 = blockIdx.y * STRIP_ROWS;
+    if (row0 >= P.h) return;
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < P.groups; g += gridDim.x * 256) {
+#pragma unroll
+        for (int r = 0; r < STRIP_ROWS; r++)
+            if (row0 + r < P.h) {
+                const uint32_t b = P.bits[(long long)(row0 + r) * P.sm + g];
+                // bit k of a nibble -> byte k: n * (1 + 2^7 + 2^14 + 2^21) puts bit k at 8 k (and elsewhere: masked off)
+                const uint32_t lo = (((b & 15u) * 0x00204081u) & 0x01010101u) * 255u, hi = (((b >> 4) * 0x00204081u) & 0x01010101u) * 255u;
+                *reinterpret_cast<uint2*>(P.mask + (long long)(row0 + r) * P.mstride + 8ll * g) = make_uint2(lo, hi);
+            }
+    }
+}
 __global__ __launch_bounds__(256) void strip_pack_kernel(StripBatchK B)
 {
     const StripK& P = B.k[blockIdx.z];
@@ -889,6 +914,17 @@ __global__ __launch_bounds__(256) void strip_pack_kernel(StripBatchK B)
     const int per_row = P.img_chunks + P.mask_chunks;
     for (int c = blockIdx.x * 256 + threadIdx.x; c < per_row; c += gridDim.x * 256) {
         const bool im = c < P.img_chunks;
+        if (!im && P.bits) {  // STX_STRIP_MASK_BITS: 8 mask bytes -> one byte, bit j = pixel j is not 0
+            const uint8_t* ms = P.mask + 8ll * (c - P.img_chunks);
+            uint8_t* md = P.dst + P.si * P.h + (c - P.img_chunks);
+#pragma unroll
+            for (int r = 0; r < STRIP_ROWS; r++)
+                if (row0 + r < P.h) {
+                    const uint2 v = *reinterpret_cast<const uint2*>(ms + (long long)(row0 + r) * P.mstride);
+                    md[(long long)(row0 + r) * P.sm] = (uint8_t)(strip_nz4(v.x) | (strip_nz4(v.y) << 4));
+                }
+            continue;
+        }
         const uint8_t* src = im ? P.img + 8ll * c : P.mask + 8ll * (c - P.img_chunks);
         uint8_t* dst = im ? P.dst + 8ll * c : P.dst + P.si * P.h + 8ll * (c - P.img_chunks);
         const long long ss = im ? P.istride : P.mstride, ds = im ? P.si : P.sm;
@@ -904,7 +940,7 @@ __global__ __launch_bounds__(256) void strip_pack_kernel(StripBatchK B)
 }  // namespace
 
 int stx_launch_strip_pack(stx_ctx* ctx, int n, const stx_buf* const* imgs, const stx_buf* const* masks, const int* x0, const int* w,
-                          stx_buf* const* dsts, const size_t* si, const size_t* sm)
+                          stx_buf* const* dsts, const size_t* si, const size_t* sm, bool mask_bits)
 {
     for (int base = 0; base < n; base += STRIP_BATCH) {
         const int m = std::min(STRIP_BATCH, n - base);
@@ -916,15 +952,37 @@ int stx_launch_strip_pack(stx_ctx* ctx, int n, const stx_buf* const* imgs, const
             StripK& K = B.k[i];
             K.img = imgs[g]->ptr + (size_t)x0[g] * 3; K.mask = masks[g]->ptr + x0[g]; K.dst = dsts[g]->ptr;
             K.istride = (long long)imgs[g]->stride; K.mstride = (long long)masks[g]->stride; K.si = (long long)si[g]; K.sm = (long long)sm[g];
-            K.h = imgs[g]->h; K.img_chunks = w8 * 3 / 8; K.mask_chunks = w8 / 8;
+            K.h = imgs[g]->h; K.img_chunks = w8 * 3 / 8; K.mask_chunks = w8 / 8; K.bits = mask_bits ? 1 : 0;
             max_h = std::max(max_h, K.h);
             max_chunks = std::max(max_chunks, K.img_chunks + K.mask_chunks);
-            bytes += 8.0 * (double)w[g] * K.h;
+            bytes += (mask_bits ? 7.125 : 8.0) * (double)w[g] * K.h;
         }
         StxProfScope prof(ctx, "strip_pack", bytes);
         hipLaunchKernelGGL(strip_pack_kernel, dim3((max_chunks + 255) / 256, (max_h + STRIP_ROWS - 1) / STRIP_ROWS, m), dim3(256), 0, ctx->stream, B);
     }
     return check_launch("strip_pack");
+}
+
+// masks[i] (w x h, whole 8-pixel groups per row) <- the bit rows at bits[i] (pitch sm[i])
+int stx_launch_strip_bits_expand(stx_ctx* ctx, int n, const uint8_t* const* bits, const size_t* sm, stx_buf* const* masks)
+{
+    for (int base = 0; base < n; base += STRIP_BATCH) {
+        const int m = std::min(STRIP_BATCH, n - base);
+        StripBitsBatchK B = {};
+        int max_h = 0, max_groups = 0;
+        double bytes = 0.0;
+        for (int i = 0; i < m; i++) {
+            const int g = base + i;
+            StripBitsK& K = B.k[i];
+            K.bits = bits[g]; K.sm = (long long)sm[g]; K.mask = masks[g]->ptr; K.mstride = (long long)masks[g]->stride;
+            K.groups = (masks[g]->w + 7) / 8; K.h = masks[g]->h;
+            max_h = std::max(max_h, K.h); max_groups = std::max(max_groups, K.groups);
+            bytes += 1.125 * (double)masks[g]->w * K.h;
+        }
+        StxProfScope prof(ctx, "strip_unpack", bytes);
+        hipLaunchKernelGGL(strip_bits_expand_kernel, dim3((max_groups + 255) / 256, (max_h + STRIP_ROWS - 1) / STRIP_ROWS, m), dim3(256), 0, ctx->stream, B);
+    }
+    return check_launch("strip_unpack");
 }
 
 // ---------------------------------------------------------------------------------------------

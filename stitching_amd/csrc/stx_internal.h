@@ -67,10 +67,15 @@ struct stx_ctx {
     // pinned scratch for small device->host results (ROI min/max)
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
-    // pinned ring for small host->device uploads (descriptor tables): truly asynchronous copies, the stream is
-    // only synchronised when the ring wraps
+    // pinned ring for small host->device uploads (descriptor tables): truly asynchronous copies.  The ring is cut into
+    // STX_STAGE_SEGS segments; leaving a segment records an event behind its last copy, entering one waits for the event of
+    // its previous lap (recorded three segments of uploads ago: normally long complete) — not for the whole stream, which
+    // with a deep queue of panoramas costs the host tens of milliseconds and the GPU a bubble (stx_stage_upload)
     uint8_t* stage = nullptr;
     size_t stage_bytes = 0, stage_off = 0;
+    hipEvent_t stage_ev[4] = {};
+    bool stage_ev_set[4] = {};
+    int stage_seg = 0;
     // profiler
     bool prof_on = false;
     std::vector<StxProfEntry> prof;
@@ -80,7 +85,10 @@ struct stx_ctx {
     hipEvent_t marks[16] = {};
 };
 
+#define STX_STAGE_SEGS 4
 int stx_dev_alloc(stx_ctx* ctx, size_t bytes, void** out);
+// host -> device copy of a small table through the context's pinned ring: queued on ctx->stream, no host wait in the common case
+int stx_stage_upload(stx_ctx* ctx, void* d, const void* h, size_t bytes);
 void stx_dev_free(stx_ctx* ctx, void* p);
 int stx_set_device(stx_ctx* ctx);
 
@@ -175,7 +183,8 @@ int stx_launch_seam_resize_batch(stx_ctx* ctx, int n, const stx_buf* const* seam
                                  const int* const* d_xt, const int* const* d_yt, uint8_t* const* tmp, const size_t* tstride);
 // image-strip sharding: pack the columns [x0, x0 + w) of n images + masks into n flat buffers (one launch per 16 strips)
 int stx_launch_strip_pack(stx_ctx* ctx, int n, const stx_buf* const* imgs, const stx_buf* const* masks, const int* x0, const int* w,
-                          stx_buf* const* dsts, const size_t* si, const size_t* sm);
+                          stx_buf* const* dsts, const size_t* si, const size_t* sm, bool mask_bits);
+int stx_launch_strip_bits_expand(stx_ctx* ctx, int n, const uint8_t* const* bits, const size_t* sm, stx_buf* const* masks);
 
 constexpr int STX_DT_RC = 64;  // rows per chunk of the distance transform's column pass (stx_blend.hip: DT_RC)
 // feather blender as a deferred gather: device table of the fed images, in feed order

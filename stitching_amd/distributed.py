@@ -104,15 +104,14 @@ class GeometryContext:
         self._lib = _lib.lib()
 
 
-def strip_pack(ctx, img, mask, x0, x1):
+def strip_pack(ctx, img, mask, x0, x1, flags=0):
     """columns [x0, x1) of a warped image + mask -> one flat device buffer (stx_strip_pack)"""
-    out = C.c_void_p()
-    _lib.check(ctx._lib.stx_strip_pack(ctx.handle, img._h, mask._h, int(x0), int(x1), C.byref(out)))
-    return DeviceImage(ctx, out)
+    return strip_pack_batch(ctx, [(img, mask, x0, x1)], flags)[0]
 
 
-def strip_pack_batch(ctx, items):
-    """items: [(image, mask, x0, x1)] -> [flat device buffer]: every strip a rank owes, one copy kernel per 16 strips"""
+def strip_pack_batch(ctx, items, flags=0):
+    """items: [(image, mask, x0, x1)] -> [flat device buffer]: every strip a rank owes, one copy kernel per 16 strips.
+    flags: _lib.STRIP_MASK_BITS -> the masks (0 / 255 only) travel as one bit per pixel"""
     n = len(items)
     if n == 0:
         return []
@@ -121,7 +120,7 @@ def strip_pack_batch(ctx, items):
     x0s = (C.c_int * n)(*[int(i[2]) for i in items])
     x1s = (C.c_int * n)(*[int(i[3]) for i in items])
     outs = (C.c_void_p * n)()
-    _lib.check(ctx._lib.stx_strip_pack_batch(ctx.handle, n, imgs, masks, x0s, x1s, outs))
+    _lib.check(ctx._lib.stx_strip_pack_batch_ex(ctx.handle, n, imgs, masks, x0s, x1s, int(flags), outs))
     return [DeviceImage(ctx, C.c_void_p(outs[i])) for i in range(n)]
 
 
@@ -178,10 +177,14 @@ class ShardPlan:
     """Who owns which columns and which contribution strips travel where.  Pure geometry: built from
     the global corner/size lists, identical on every rank."""
 
-    def __init__(self, corners, warped_sizes, owners, world, blender_probe, exchange="strips"):
+    def __init__(self, corners, warped_sizes, owners, world, blender_probe, exchange="strips", mask_bits=False):
+        """mask_bits (strips): the masks are known to hold 0 / 255 only and travel as one bit per pixel
+        (STX_STRIP_MASK_BITS: 3.125 instead of 4 bytes per pixel on the links)."""
         if exchange not in ("strips", "contribs"):
             raise StitchingError(f"unknown exchange form {exchange!r}")
         self.exchange = exchange
+        self.mask_bits = bool(mask_bits) and exchange == "strips"
+        self.strip_flags = _lib.STRIP_MASK_BITS if self.mask_bits else 0
         self.corners = [tuple(int(v) for v in c) for c in corners]
         self.sizes = [tuple(int(v) for v in s) for s in warped_sizes]
         self.owners = list(owners)
@@ -200,6 +203,10 @@ class ShardPlan:
                 if exchange == "strips":
                     (x0, x1), nbytes = blender_probe.strip_rect(s, c, self.band(g))
                     if x1 > x0:
+                        if self.mask_bits:
+                            nb = C.c_size_t()
+                            _lib.check(_lib.lib().stx_strip_bytes(x1 - x0, int(s[1]), self.strip_flags, C.byref(nb)))
+                            nbytes = int(nb.value)
                         self.messages.append((k, self.owners[k], g, (x0, x1, x1 - x0, s[1]), nbytes))
                     continue
                 rect, nbytes = blender_probe.contrib_rect(s, c, self.band(g))
@@ -367,7 +374,7 @@ class ShardedStitchJob:
 
     def __init__(self, frames, cameras, all_cameras, rank, world, all_sizes=None, warper_type="spherical",
                  blender_type="multiband", num_bands=5, blend_strength=None, ctx=None, dist=None, transport=None,
-                 split_boundary=True, exchange="strips"):
+                 split_boundary=True, exchange="strips", mask_bits=True):
         """split_boundary: warp / feed the images that owe strips to other ranks first and the rest while the strips
         travel (lowest latency of ONE panorama).  A caller that keeps several panoramas in flight on several contexts
         passes False: all local images go through one warp launch and one pyramid build, and the other panorama's
@@ -393,6 +400,7 @@ class ShardedStitchJob:
         self.transport = transport
         self.split_boundary = bool(split_boundary)
         self.exchange = exchange
+        self.mask_bits = bool(mask_bits)  # every mask of this job is a warped mask (0 / 255): they may travel as bits
         self.plan_ = None
 
     @property
@@ -408,7 +416,7 @@ class ShardedStitchJob:
         self.req_bands = int((np.log(blend_width) / np.log(2.0) - 1.0))
         self.roi = roi
         probe = make_shard_blender(self.ctx, roi, self.req_bands)
-        self.plan_ = ShardPlan(corners, wsizes, self.owners, self.world, probe, self.exchange)
+        self.plan_ = ShardPlan(corners, wsizes, self.owners, self.world, probe, self.exchange, self.mask_bits)
         self.last_num_bands = self.plan_.num_bands
         if self.transport is None:
             self.transport = default_transport(self.ctx, self.rank, self.world, self.dist)
@@ -435,7 +443,8 @@ class ShardedStitchJob:
             warped = self._warp_and_feed(blender, [k for k in self.my_orders if k in senders], p)
             sends = []
             if p.exchange == "strips":
-                packed = strip_pack_batch(self.ctx, [(warped[k][0], warped[k][1], rect[0], rect[1]) for (k, _s, _d, rect, _n) in send_msgs])
+                packed = strip_pack_batch(self.ctx, [(warped[k][0], warped[k][1], rect[0], rect[1]) for (k, _s, _d, rect, _n) in send_msgs],
+                                          p.strip_flags)
                 sends = [(dst, buf, nbytes) for (_k, _src, dst, _rect, nbytes), buf in zip(send_msgs, packed)]
             else:
                 exported = blender.export_contribs([(k, p.band(dst)) for (k, _src, dst, _rect, _nbytes) in send_msgs])
@@ -455,7 +464,7 @@ class ShardedStitchJob:
             # every strip of this job comes from a u8 warp with a 0 / 255 mask (warp_images_and_masks on all ranks)
             if p.exchange == "strips":
                 blender.feed_strips([(buf, m[3][2], m[3][3], (p.corners[m[0]][0] + m[3][0], p.corners[m[0]][1]), m[0])
-                                     for m, buf in zip(recv_msgs, rbufs)], _lib.CONTRIB_U8_BINARY)
+                                     for m, buf in zip(recv_msgs, rbufs)], _lib.CONTRIB_U8_BINARY | p.strip_flags)
             else:
                 for m, buf in zip(recv_msgs, rbufs):
                     blender.feed_contrib(m[0], m[3], buf, _lib.CONTRIB_U8_BINARY)
@@ -570,28 +579,29 @@ def _mask_is_binary(ctx, mask):
 
 
 # ------------------------------------------------------------------------------------ test helper
-def virtual_sharded_blend(ctx, warped, masks, corners, sizes, world, num_bands, exchange="strips"):
+def virtual_sharded_blend(ctx, warped, masks, corners, sizes, world, num_bands, exchange="strips", mask_bits=False):
     """All `world` ranks simulated in ONE process on one GPU: same kernels, same geometry, the
     exchange is a pointer hand-over.  Returns (panorama, mask, plan) as numpy arrays."""
     n = len(warped)
     owners = owners_contiguous(n, world)
     roi = Blender.result_roi(corners, sizes)
     probe = make_shard_blender(ctx, roi, num_bands)
-    plan = ShardPlan(corners, sizes, owners, world, probe, exchange)
+    d_imgs = [as_device(w, ctx) for w in warped]
+    d_masks = [as_device(m, ctx) for m in masks]
+    binary = [_mask_is_binary(ctx, m) for m in d_masks]
+    plan = ShardPlan(corners, sizes, owners, world, probe, exchange, mask_bits and all(binary))  # bits need 0 / 255 masks
     blenders = []
     for g in range(world):
         b = make_shard_blender(ctx, roi, num_bands)
         b.set_band(*plan.band(g))
         blenders.append(b)
-    d_imgs = [as_device(w, ctx) for w in warped]
-    d_masks = [as_device(m, ctx) for m in masks]
     for k in range(n):
         feed_own_image(blenders[owners[k]], plan, owners[k], k, d_imgs[k], d_masks[k])
     for (k, src, dst, rect, nbytes) in plan.messages:
         if exchange == "strips":
-            packed = strip_pack(ctx, d_imgs[k], d_masks[k], rect[0], rect[1])
-            assert packed.width * packed.height >= nbytes
-            simg, smask = strip_unpack(packed, rect[2], rect[3], _lib.CONTRIB_U8_BINARY if _mask_is_binary(ctx, d_masks[k]) else 0)
+            packed = strip_pack(ctx, d_imgs[k], d_masks[k], rect[0], rect[1], plan.strip_flags)
+            assert packed.width * packed.height == nbytes
+            simg, smask = strip_unpack(packed, rect[2], rect[3], (_lib.CONTRIB_U8_BINARY if binary[k] else 0) | plan.strip_flags)
             blenders[dst].feed_ex(simg, smask, (plan.corners[k][0] + rect[0], plan.corners[k][1]), k)
             continue
         packed, r = blenders[src].export_contrib(k, plan.band(dst))

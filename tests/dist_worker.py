@@ -30,11 +30,15 @@ def main():
     corners, sizes, req_bands = case["corners"], case["sizes"], case["req_bands"]
     roi = D.Blender.result_roi(corners, sizes)
     probe = D.make_shard_blender(None, roi, req_bands)  # geometry only: no GPU, no context
-    plan = D.ShardPlan(corners, sizes, D.owners_contiguous(len(corners), world), world, probe, case.get("exchange", "strips"))
+    plan = D.ShardPlan(corners, sizes, D.owners_contiguous(len(corners), world), world, probe, case.get("exchange", "strips"),
+                       case.get("mask_bits", False))
     if plan.exchange == "strips":
         for (k, src, dst, (x0, x1, w, h), nbytes) in plan.messages:
             assert 0 <= x0 < x1 <= sizes[k][0] and w == x1 - x0 and h == sizes[k][1] and x0 % 8 == 0, "strip geometry"
-            assert nbytes >= 4 * w * h
+            if plan.mask_bits:  # image rows + one bit per mask pixel (rows padded to 64 bytes)
+                assert 3 * w * h + w * h // 8 <= nbytes <= 3 * w * h + w * h // 8 + 160 * h  # + padding of the two row pitches
+            else:
+                assert nbytes >= 4 * w * h
 
     # 1. every rank derives the same plan
     sig = hashlib.sha256(json.dumps([plan.edges, plan.messages, plan.num_bands]).encode()).hexdigest()

@@ -68,6 +68,11 @@ def test_multi_row_layout_over_gloo(oracle, world):
     assert strips["ok"] and contribs["ok"] and strips["edges"] == contribs["edges"]
     # 4 bytes per strip pixel against 13.3 per contribution pixel
     assert strips["bytes"] < 0.6 * contribs["bytes"]
+    # masks as bits: 3.125 bytes per strip pixel (+ row padding), same messages
+    bits = launch(world, {"corners": [list(c) for c in corners], "sizes": [list(s) for s in sizes], "req_bands": 4, "exchange": "strips",
+                          "mask_bits": True})
+    assert bits["ok"] and bits["messages"] == strips["messages"] and bits["edges"] == strips["edges"]
+    assert 0.76 * strips["bytes"] < bits["bytes"] < 0.85 * strips["bytes"]
 
 
 def test_owners_are_contiguous_runs():

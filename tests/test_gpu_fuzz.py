@@ -125,7 +125,8 @@ def test_random_sharded_blend_bit_exact(oracle, gpu_ctx, seed):
     req = int(np.log(np.sqrt(o["pano"].shape[0] * o["pano"].shape[1]) * strength / 100) / np.log(2.0) - 1.0)
     if req < 0:
         pytest.skip("blend width below one band")
-    pano, mask, plan = virtual_sharded_blend(gpu_ctx, o["w_imgs"], feed_masks, o["corners"], o["sizes"], world, req, exchange)
+    pano, mask, plan = virtual_sharded_blend(gpu_ctx, o["w_imgs"], feed_masks, o["corners"], o["sizes"], world, req, exchange,
+                                             mask_bits=seed % 2 == 0)  # (bits only where every mask is 0 / 255)
     tag = dict(world=world, n=n, w=w, h=h, strength=strength, wtype=wtype, bands=plan.num_bands, edges=plan.edges, exchange=exchange)
     assert pano.shape == o["pano"].shape, tag
     assert np.array_equal(mask, o["pmask"]), tag

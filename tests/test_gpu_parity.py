@@ -185,7 +185,7 @@ def test_error_paths(gpu_ctx):
         w.warp_image(np.zeros((10, 10), np.uint8), S.CameraParams(focal=100.0))
 
 
-@pytest.mark.parametrize("exchange", ["strips", "contribs"])
+@pytest.mark.parametrize("exchange", ["strips", "strips+bits", "contribs"])
 @pytest.mark.parametrize("world,strength,n", [(2, 30, 4), (3, 12, 6), (2, 4, 4)])
 def test_sharded_blend_equals_single_gpu(oracle, gpu_ctx, world, strength, n, exchange):
     """Column bands + strips (the multi-GPU data path, all ranks simulated on one GPU; both exchange forms: warped image
@@ -196,7 +196,9 @@ def test_sharded_blend_equals_single_gpu(oracle, gpu_ctx, world, strength, n, ex
     o = helpers.run_pipeline(oracle.Warper, oracle.Blender, imgs, cams, blend_strength=strength)
     nb = o["blender"].blender.num_bands()
     req = int(np.log(np.sqrt(o["pano"].shape[0] * o["pano"].shape[1]) * strength / 100) / np.log(2.0) - 1.0)
-    pano, mask, plan = virtual_sharded_blend(gpu_ctx, o["w_imgs"], o["w_masks"], o["corners"], o["sizes"], world, req, exchange)
+    pano, mask, plan = virtual_sharded_blend(gpu_ctx, o["w_imgs"], o["w_masks"], o["corners"], o["sizes"], world, req,
+                                             exchange.split("+")[0], mask_bits=exchange.endswith("+bits"))
+    assert plan.mask_bits == exchange.endswith("+bits")
     assert plan.num_bands == nb and len(plan.messages) >= world - 1
     assert pano.shape == o["pano"].shape
     assert np.array_equal(mask, o["pmask"])

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Per-rank device time of the sharded job on ONE GPU: rank R of an N-rank job runs alone with a replay transport
-(received strips = zero-filled buffers of the planned sizes, allocated once), two panoramas in flight — what one GPU
-of an N-GPU node does per step, without the exchange itself.  Workload = bench.py's at N > 1: BASELINE config 3
+(received strips = the REAL strips, made once at start-up by warping the other ranks' frames here and packing the planned
+columns — zero-filled stand-ins would be skipped by the occupancy maps and flatter the gather), two panoramas in flight —
+what one GPU of an N-GPU node does per step, without the exchange itself.  Workload = bench.py's at N > 1: BASELINE config 3
 (N of 8 yaw columns x 4 pitch rows, one column per GPU; `ring`: the tele ring of round 1, 8 frames per GPU).
 usage: python tools/sim_rank.py [N] [R] [steps] [config3|config4|ring]"""
 import json
@@ -17,23 +18,39 @@ from stitching_amd import synthetic  # noqa: E402
 from stitching_amd.distributed import ShardedStitchJob, flat_device_buffer  # noqa: E402
 
 
-class ZeroStrips:
+class ReplayStrips:
+    """transport stand-in: finish() hands out the strips prepared by `prepare` (one set per context), in plan order"""
     name = "replay"
 
     def __init__(self):
         self.cache = {}
 
+    def prepare(self, job, cams, w, h):
+        from stitching_amd.distributed import strip_pack_batch  # noqa: E402
+
+        p, ctx = job.plan_, job.ctx
+        msgs = p.recvs(job.rank)
+        bufs = []
+        S.set_device_resident(True)
+        try:
+            for (k, src, dst, rect, nbytes) in msgs:  # one image at a time: the warped neighbours are not kept
+                img, mask, _ = job.warper.warp_images_and_masks([S.DeviceImage.from_numpy(synthetic.make_frame(k, w, h), ctx)], [cams[k]])
+                if p.exchange == "strips":
+                    b = strip_pack_batch(ctx, [(img[0], mask[0], rect[0], rect[1])], p.strip_flags)[0]
+                    assert b.width * b.height == nbytes
+                else:  # contributions: sizes only (not replayed with content)
+                    b = flat_device_buffer(ctx, np.zeros(nbytes, np.uint8))
+                bufs.append(b)
+        finally:
+            S.set_device_resident(False)
+        ctx.sync()
+        self.cache[id(ctx)] = bufs
+
     def start(self, sends, recvs, ctx=None):
-        self.ctx, self.recvs = ctx, recvs
+        self.ctx = ctx
 
     def finish(self, ctx=None):
-        out = []
-        for i, (src, nb) in enumerate(self.recvs):
-            key = (id(self.ctx), i, nb)
-            if key not in self.cache:
-                self.cache[key] = flat_device_buffer(self.ctx, np.zeros(nb, np.uint8))
-            out.append(self.cache[key])
-        return out
+        return list(self.cache[id(ctx or self.ctx)])
 
 
 def main():
@@ -56,12 +73,15 @@ def main():
     frames = [synthetic.make_frame(i, w, h) for i in my]
     ctxs = [S.get_context(), S.Context(S.get_context().device)]
     jobs = []
+    replay = ReplayStrips()
     for split in (False, True):
         js = []
         for c in ctxs:
             j = ShardedStitchJob(frames if not js else js[0].frames, [cams[i] for i in my], cams, rank, world, ctx=c,
-                                 transport=ZeroStrips(), split_boundary=split, **kw)
+                                 transport=replay, split_boundary=split, **kw)
             j.plan()
+            if id(c) not in replay.cache:
+                replay.prepare(j, cams, w, h)
             js.append(j)
         jobs.append(js)
     res = {"world": world, "rank": rank, "layout": layout, "frames_per_gpu": fpg}
