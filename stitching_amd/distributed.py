@@ -7,8 +7,9 @@ MI355X-first design of SURVEY.md §8(e) / DESIGN.md §6:
   * rank g owns the panorama columns [b_g, b_{g+1}) (edges on multiples of max(8, 2^bands));
   * every rank warps and builds pyramids for ITS images only;
   * an image whose 2^bands-aligned feed rectangle reaches another rank's columns sends that rank a strip.
-    exchange="strips" (default): the COLUMNS of the warped image and mask the other band depends on (4 bytes per
-    pixel, copied out by the DMA engine); the receiver feeds them like an image of its own and builds their pyramids.
+    exchange="strips" (default): the COLUMNS of the warped image and mask the other band depends on (3 bytes per pixel
+    + the mask as a byte or, 0 / 255 masks, as a bit; one pack kernel per 16 strips); the receiver feeds them like an
+    image of its own and builds their pyramids.
     exchange="contribs" (round 1): per level the products (short)(L*W) and the weights W over the band's region
     (13.3 bytes per pixel and an export pass on the sender).  Either way this is the only data-path communication —
     point-to-point over xGMI (RCCL send/recv), never an all-reduce of the panorama pyramid;
