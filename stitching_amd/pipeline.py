@@ -19,6 +19,65 @@ from .synthetic import blend_strength_for_bands
 from .warper import Warper
 
 
+def mask_box(mask):
+    """(first column, one past the last column, width, first row, one past the last row, height) of the non-zero values of a
+    host mask, or None when there are none"""
+    m2 = mask.reshape(mask.shape[0], mask.shape[1], -1).any(axis=2)
+    nx, ny = np.flatnonzero(m2.any(axis=0)), np.flatnonzero(m2.any(axis=1))
+    if not nx.size:
+        return None
+    return (int(nx[0]), int(nx[-1]) + 1, int(mask.shape[1]), int(ny[0]), int(ny[-1]) + 1, int(mask.shape[0]))
+
+
+def view_rects(handle, corners, sizes, boxes, min_gain=0.9):
+    """Per image the rectangle (x0, x1, y0, y1) of its warped image that can influence the panorama, or None (all of it);
+    None altogether when nothing is cut.  `handle`: the multi-band blender prepared on (corners, sizes) — a geometry-only one
+    (distributed.make_shard_blender(None, roi, bands)) will do; `boxes`: mask_box of the mask each image is fed with, at
+    its final or at a lower resolution.
+
+    The fed mask of image k is non-zero inside the columns [m0, m1) and rows [n0, n1) only.  Its weight pyramid W_l is then
+    non-zero within 2^(l+1) - 2 level-0 pixels of that box, at most 2^(B+1) — call that box, snapped outwards to the band
+    grid, the image's band.  Outside its band the image adds (short)(L * 0.f) = 0 and 0.f whatever its pixels are; inside
+    it, L and W are what the whole image gives as long as everything within the pyramids' reach of the band is present:
+    exactly the guarantee of the strips of the sharded blender (`stx_strip_rect`; `stx_view_rect` adds the
+    same range along y), whose cut edges are farther from the band than any pyramid tap.  So the view for its own band is
+    all of image k that has to exist.  Seam masks given at low resolution: the final mask is dilate(3x3) ->
+    INTER_LINEAR_EXACT -> AND, non-zero at x only if a dilated low-resolution column floor(sx) or floor(sx) + 1 is,
+    sx = (x + 0.5) * lw / w - 0.5 (rows alike).  (tests/test_crop_theory.py checks the statement on the CPU oracle.)"""
+    B = handle.num_bands()
+    if B <= 0:
+        return None
+    roi = Blender.result_roi(corners, sizes)
+    align, reach = max(8, 1 << B), 2 << B
+
+    def band(lo, hi, size, msize, origin):
+        if msize != size:  # low-resolution seam mask: the final-mask positions that can be non-zero
+            lo = int(np.floor((lo - 2 + 0.5) * size / msize - 0.5)) - 1
+            hi = int(np.ceil((hi + 2 + 0.5) * size / msize - 0.5)) + 1
+        lo, hi = max(lo, 0), min(hi, size)
+        return max(((origin + lo - reach) // align) * align, 0), -((-(origin + hi + reach)) // align) * align
+
+    out = []
+    for (cx, cy), (w, h), box in zip(corners, sizes, boxes):
+        if box is None:
+            out.append(None)
+            continue
+        bx0, bx1 = band(box[0], box[1], w, box[2], cx - roi[0])
+        by0, by1 = band(box[3], box[4], h, box[5], cy - roi[1])
+        r = (C.c_int * 4)()
+        _lib.check(_lib.lib().stx_view_rect(handle._h, int(w), int(h), int(cx), int(cy), int(bx0), int(bx1), int(by0), int(by1), r))
+        x0, x1, y0, y1 = (int(v) for v in r)
+        if x1 <= x0 or y1 <= y0:
+            out.append(None)
+            continue
+        if x1 - x0 > min_gain * w:
+            x0, x1 = 0, w
+        if y1 - y0 > min_gain * h:
+            y0, y1 = 0, h
+        out.append((x0, x1, y0, y1) if (x1 - x0) * (y1 - y0) < w * h else None)
+    return None if all(o is None for o in out) else out
+
+
 class StitchJob:
     """Pre-staged inputs of one panorama: device-resident source frames + cameras."""
 
@@ -34,7 +93,7 @@ class StitchJob:
         crop_to_masks (multi-band blender, feed_masks / seam_masks given as host arrays): a seam mask keeps one cell of its
         image, and nothing farther than the pyramids reach from that cell can touch the panorama.  The reference warps
         every image whole and cuts afterwards (stitching/stitcher.py:119-127); here only the rectangle the blender can see
-        are warped, masked and fed — the same panorama bit for bit (`_crop_rects`)."""
+        are warped, masked and fed — the same panorama bit for bit (`view_rects`)."""
         if len(frames) != len(cameras) or not frames:
             raise StitchingError("need one camera per frame and at least one frame")
         self.ctx = ctx or get_context()
@@ -52,12 +111,7 @@ class StitchJob:
         self._mask_cols = None
         given = feed_masks if feed_masks is not None else seam_masks
         if crop_to_masks and given is not None and all(isinstance(m, np.ndarray) for m in given):
-            self._mask_cols = []
-            for m in given:
-                m2 = m.reshape(m.shape[0], m.shape[1], -1).any(axis=2)
-                nx, ny = np.flatnonzero(m2.any(axis=0)), np.flatnonzero(m2.any(axis=1))
-                self._mask_cols.append((int(nx[0]), int(nx[-1]) + 1, int(m.shape[1]), int(ny[0]), int(ny[-1]) + 1, int(m.shape[0]))
-                                       if nx.size else None)
+            self._mask_cols = [mask_box(m) for m in given]
         self._crop_cache = None
         self.feed_masks = None if feed_masks is None else [as_device(m, self.ctx) for m in feed_masks]
         self.seam_masks = None if seam_masks is None else [as_device(m, self.ctx) for m in seam_masks]
@@ -78,56 +132,11 @@ class StitchJob:
         return self.corners, self.warped_sizes
 
     def _crop_rects(self, handle):
-        """Per image the rectangle (x0, x1, y0, y1) of its warped image that can influence the panorama, or None (all of it).
-
-        The fed mask of image k is non-zero inside the columns [m0, m1) and rows [n0, n1) only.  Its weight pyramid W_l is then
-        non-zero within 2^(l+1) - 2 level-0 pixels of that box, at most 2^(B+1) — call that box, snapped outwards to the band
-        grid, the image's band.  Outside its band the image adds (short)(L * 0.f) = 0 and 0.f whatever its pixels are; inside
-        it, L and W are what the whole image gives as long as everything within the pyramids' reach of the band is present:
-        exactly the guarantee of the strips of the sharded blender (`stx_strip_rect`; `stx_view_rect` adds the
-        same range along y), whose cut edges are farther from the band than any pyramid tap.  So the view for its own band is
-        all of image k that has to exist.  Seam masks given at low resolution: the final mask is dilate(3x3) ->
-        INTER_LINEAR_EXACT -> AND, non-zero at x only if a dilated low-resolution column floor(sx) or floor(sx) + 1 is,
-        sx = (x + 0.5) * lw / w - 0.5 (rows alike)."""
+        """see view_rects"""
         key = (tuple(self.corners), tuple(self.warped_sizes), self.blend_strength)
-        if self._crop_cache is not None and self._crop_cache[0] == key:
-            return self._crop_cache[1]
-        B = handle.num_bands()
-        roi = Blender.result_roi(self.corners, self.warped_sizes)
-        out = None
-        if B > 0:
-            align, reach = max(8, 1 << B), 2 << B
-
-            def band(lo, hi, size, msize, origin):
-                if msize != size:  # low-resolution seam mask: the final-mask positions that can be non-zero
-                    lo = int(np.floor((lo - 2 + 0.5) * size / msize - 0.5)) - 1
-                    hi = int(np.ceil((hi + 2 + 0.5) * size / msize - 0.5)) + 1
-                lo, hi = max(lo, 0), min(hi, size)
-                return max(((origin + lo - reach) // align) * align, 0), -((-(origin + hi + reach)) // align) * align
-
-            out = []
-            for (cx, cy), (w, h), box in zip(self.corners, self.warped_sizes, self._mask_cols):
-                if box is None:
-                    out.append(None)
-                    continue
-                bx0, bx1 = band(box[0], box[1], w, box[2], cx - roi[0])
-                by0, by1 = band(box[3], box[4], h, box[5], cy - roi[1])
-                r = (C.c_int * 4)()
-                _lib.check(self.ctx._lib.stx_view_rect(handle._h, int(w), int(h), int(cx), int(cy), int(bx0), int(bx1), int(by0),
-                                                       int(by1), r))
-                x0, x1, y0, y1 = (int(v) for v in r)
-                if x1 <= x0 or y1 <= y0:
-                    out.append(None)
-                    continue
-                if x1 - x0 > 0.9 * w:
-                    x0, x1 = 0, w
-                if y1 - y0 > 0.9 * h:
-                    y0, y1 = 0, h
-                out.append((x0, x1, y0, y1) if (x1 - x0) * (y1 - y0) < w * h else None)
-            if all(o is None for o in out):
-                out = None
-        self._crop_cache = (key, out)
-        return out
+        if self._crop_cache is None or self._crop_cache[0] != key:
+            self._crop_cache = (key, view_rects(handle, self.corners, self.warped_sizes, self._mask_cols))
+        return self._crop_cache[1]
 
     def run(self):
         """warp every frame, feed it, blend.  Returns device-resident (panorama u8x3, mask u8)."""

@@ -1,0 +1,64 @@
+"""The statement behind StitchJob(crop_to_masks) / pipeline.view_rects, checked on the CPU oracle (no GPU): feeding the
+multi-band blender only the rectangle of each warped image that view_rects names — cut out of the whole warped image and its
+fed mask, at the shifted corner — gives the panorama of the whole images, bit for bit.  (tests/test_gpu_crop.py and the fuzz
+test check the product path, where the rectangle is all that is ever warped.)"""
+import numpy as np
+import pytest
+
+from stitching_amd import synthetic
+from stitching_amd.distributed import make_shard_blender
+from stitching_amd.pipeline import mask_box, view_rects
+
+
+def _case(oracle, wtype, cams, w, h, strength, low_scale):
+    n = len(cams)
+    imgs = [synthetic.make_frame(10 + i, w, h) for i in range(n)]
+    ow = oracle.Warper(wtype)
+    ow.set_scale(cams)
+    sizes = [(w, h)] * n
+    corners, wsizes = ow.warp_rois(sizes, cams)
+    wimgs = [ow.warp_image(im, c) for im, c in zip(imgs, cams)]
+    wmasks = [ow.create_and_warp_mask(s, c) for s, c in zip(sizes, cams)]
+    seams = synthetic.voronoi_seam_masks(wmasks, corners, wsizes)
+    low = [np.ascontiguousarray(m[::low_scale, ::low_scale]) for m in seams] if low_scale else None
+    fed = [oracle.seam_resize(l, m) for l, m in zip(low, wmasks)] if low_scale else seams
+
+    def blend(parts):
+        b = oracle.Blender("multiband", strength)
+        b.prepare(corners, wsizes)  # the panorama is that of the whole images
+        for im, m, c in parts:
+            b.feed(im, m, c)
+        pano, mask = b.blend()
+        return np.asarray(pano), np.asarray(mask), b.blender.num_bands()
+
+    whole_pano, whole_mask, bands = blend(zip(wimgs, fed, corners))
+    roi = oracle.result_roi(corners, wsizes)
+    handle = make_shard_blender(None, roi, bands)  # geometry only
+    assert handle.num_bands() == bands
+    rects = view_rects(handle, corners, wsizes, [mask_box(m) for m in (low if low_scale else fed)], min_gain=1.0)
+    assert rects is not None, "nothing is cut: the case does not test the statement"
+    parts = []
+    for im, m, (cx, cy), r in zip(wimgs, fed, corners, rects):
+        if r is None:
+            parts.append((im, m, (cx, cy)))
+        else:
+            x0, x1, y0, y1 = r
+            assert not m[:, :x0].any() and not m[:, x1:].any() and not m[:y0].any() and not m[y1:].any(), "the view must hold the mask"
+            parts.append((np.ascontiguousarray(im[y0:y1, x0:x1]), np.ascontiguousarray(m[y0:y1, x0:x1]), (cx + x0, cy + y0)))
+    pano, mask, _ = blend(parts)
+    cut = sum(1.0 - ((r[1] - r[0]) * (r[3] - r[2])) / (s[0] * s[1]) for r, s in zip(rects, wsizes) if r is not None) / n
+    assert np.array_equal(mask, whole_mask)
+    assert np.array_equal(pano, whole_pano), int(np.count_nonzero(pano != whole_pano))
+    return cut
+
+
+@pytest.mark.parametrize("wtype,low_scale,strength", [("spherical", 0, 2), ("cylindrical", 0, 4), ("spherical", 5, 2), ("plane", 7, 3)])
+def test_ring_cut_to_seam_cells(oracle, wtype, low_scale, strength):
+    cams = synthetic.ring_cameras(5, 700, 420, span_deg=70.0 if wtype == "plane" else 115.0)
+    assert _case(oracle, wtype, cams, 700, 420, strength, low_scale) > 0.05
+
+
+@pytest.mark.parametrize("low_scale", [0, 6])
+def test_grid_cut_on_all_four_sides(oracle, low_scale):
+    cams = synthetic.grid_cameras(3, 3, 600, 480, span_deg=95.0, max_edge_lat_deg=42.0)
+    assert _case(oracle, "spherical", cams, 600, 480, 1.5, low_scale) > 0.15
