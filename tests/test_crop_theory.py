@@ -62,3 +62,44 @@ def test_ring_cut_to_seam_cells(oracle, wtype, low_scale, strength):
 def test_grid_cut_on_all_four_sides(oracle, low_scale):
     cams = synthetic.grid_cameras(3, 3, 600, 480, span_deg=95.0, max_edge_lat_deg=42.0)
     assert _case(oracle, "spherical", cams, 600, 480, 1.5, low_scale) > 0.15
+
+
+@pytest.mark.parametrize("world,wtype,strength", [(2, "spherical", 3), (3, "spherical", 6), (2, "cylindrical", 2)])
+def test_strips_reproduce_their_band(oracle, world, wtype, strength):
+    """The sharded blender's guarantee on the CPU oracle: with every image replaced by the strip
+    stx_strip_rect names for a column band, the columns of that band come out as from the whole images."""
+    from stitching_amd.distributed import ShardPlan, owners_contiguous
+
+    n, w, h = 2 * world, 640, 400
+    cams = synthetic.ring_cameras(n, w, h, span_deg=30.0 * n)
+    imgs = [synthetic.make_frame(40 + i, w, h) for i in range(n)]
+    ow = oracle.Warper(wtype)
+    ow.set_scale(cams)
+    sizes = [(w, h)] * n
+    corners, wsizes = ow.warp_rois(sizes, cams)
+    wimgs = [ow.warp_image(im, c) for im, c in zip(imgs, cams)]
+    wmasks = [ow.create_and_warp_mask(s, c) for s, c in zip(sizes, cams)]
+
+    def blend(parts):
+        b = oracle.Blender("multiband", strength)
+        b.prepare(corners, wsizes)
+        for im, m, c in parts:
+            b.feed(im, m, c)
+        pano, mask = b.blend()
+        return np.asarray(pano), np.asarray(mask), b.blender.num_bands()
+
+    whole_pano, whole_mask, bands = blend(zip(wimgs, wmasks, corners))
+    probe = make_shard_blender(None, oracle.result_roi(corners, wsizes), bands)
+    plan = ShardPlan(corners, wsizes, owners_contiguous(n, world), world, probe)
+    assert plan.num_bands == bands and any(m[3][2] < wsizes[m[0]][0] for m in plan.messages), "no strip is narrower than its image"
+    for g in range(world):
+        bx0, bx1 = plan.band(g)
+        parts = []
+        for k in range(n):
+            (x0, x1), _ = probe.strip_rect(wsizes[k], corners[k], (bx0, bx1))
+            if x1 > x0:
+                parts.append((np.ascontiguousarray(wimgs[k][:, x0:x1]), np.ascontiguousarray(wmasks[k][:, x0:x1]),
+                              (corners[k][0] + x0, corners[k][1])))
+        pano, mask, _ = blend(parts)
+        assert np.array_equal(mask[:, bx0:bx1], whole_mask[:, bx0:bx1]), g
+        assert np.array_equal(pano[:, bx0:bx1], whole_pano[:, bx0:bx1]), (g, int(np.count_nonzero(pano[:, bx0:bx1] != whole_pano[:, bx0:bx1])))
