@@ -15,8 +15,9 @@ warped (fused image + mask), fed to the blender and the panorama is produced in 
   --config 3 / 4 at N = 1: one GPU's share of that configuration, unsharded (the same-family single-GPU rate).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP events on the
-stream the kernel runs on), `parity` (N = 1: the panorama of the timed path against the oracle's) and `cpu_baseline`
-(the oracle, timed on the host cores, N = 1 only).  torch is imported only for N > 1 (rendezvous / barrier); the
+stream the kernel runs on), `parity` (N = 1: the panorama of the timed path against the oracle's; N > 1: every rank's band
+against the oracle's columns of that band — rank 0 runs the oracle once on all frames, after the timed region;
+--no-parity skips it) and `cpu_baseline` (the oracle, timed on the host cores, N = 1 only).  torch is imported only for N > 1 (rendezvous / barrier); the
 product path is ctypes -> libstitching_amd.so.
 """
 import argparse
@@ -50,6 +51,8 @@ def parse():
     p.add_argument("--warper", default="")
     p.add_argument("--blender", default="")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-parity", action="store_true", help="N > 1: skip the comparison of every rank's band with the oracle's "
+                   "panorama (rank 0 runs the oracle once on all frames, outside the timed region)")
     p.add_argument("--no-extra", action="store_true", help="skip the extra legs (seam masks, configs 4 / 5, latency)")
     p.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU-baseline sample (0: all frames of the step, which also gives `parity`)")
     p.add_argument("--profile-steps", type=int, default=3)
@@ -212,6 +215,66 @@ def cpu_baseline(wl, frames, cams, all_cams, n_frames):
     return res, np.asarray(pano), np.asarray(pmask)
 
 
+def oracle_panorama(wl, frames, all_cams):
+    """The oracle's panorama of ALL frames of the configuration (the checker of the N > 1 `parity` record; never timed)."""
+    import numpy as np
+
+    from oracle import oracle as O
+    from stitching_amd.synthetic import blend_strength_for_bands
+
+    O.build()
+    O.set_num_threads(max(1, min(O.max_threads(), 64)))
+    w = O.Warper(wl["warper"])
+    w.set_scale(all_cams)
+    sizes = [(f.shape[1], f.shape[0]) for f in frames]
+    corners, wsizes = w.warp_rois(sizes, all_cams)
+    roi = O.result_roi(corners, wsizes)
+    strength = blend_strength_for_bands(wl["bands"], roi[2], roi[3]) if wl["blender"] == "multiband" else 5
+    b = O.Blender(wl["blender"], strength)
+    b.prepare(corners, wsizes)
+    for f, c, corner in zip(frames, all_cams, corners):
+        b.feed(w.warp_image(f, c), w.create_and_warp_mask((f.shape[1], f.shape[0]), c), corner)
+    pano, pmask = b.blend()
+    return np.asarray(pano), np.asarray(pmask), corners, wsizes
+
+
+def sharded_parity(job, dist, rank, world, wl, all_cams):
+    """N > 1: every rank produces one more band with the job object that was timed; rank 0 runs the oracle on all frames of
+    the configuration and compares each rank's band with the oracle's columns of that band, byte for byte."""
+    import numpy as np
+
+    from stitching_amd import synthetic
+
+    band, bmask = (np.asarray(a) for a in job.run())
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object((band, bmask), parts, dst=0)
+    if rank != 0:
+        return None
+    t0 = time.perf_counter()
+    frames = [synthetic.make_frame(i, wl["width"], wl["height"]) for i in range(wl["n_total"])]
+    o_pano, o_mask, o_corners, o_sizes = oracle_panorama(wl, frames, all_cams)
+    p = job.plan_
+    rec = {"vs": "oracle (oracle/stx_oracle.cpp, default model) on all %d frames, compared per rank with the columns of its band" % wl["n_total"],
+           "ranks": world, "oracle_seconds": round(time.perf_counter() - t0, 1)}
+    if [tuple(c) for c in o_corners] != p.corners or [tuple(s) for s in o_sizes] != p.sizes:
+        rec["roi_mismatch"] = True
+        return rec
+    diffs, nbytes, masks_ok = [], 0, True
+    for g, (bp, bm) in enumerate(parts):
+        x0, x1 = p.band(g)
+        op, om = o_pano[:, x0:x1], o_mask[:, x0:x1]
+        if bp.shape != op.shape or bm.shape != om.shape:
+            rec["shape_mismatch"] = [g, list(bp.shape), list(op.shape)]
+            return rec
+        d = np.abs(bp.astype(np.int16) - op.astype(np.int16))
+        diffs.append(int(d.max()) if d.size else 0)
+        nbytes += int(np.count_nonzero(d))
+        masks_ok = masks_ok and bool(np.array_equal(bm, om))
+    rec.update(max_abs_diff=max(diffs), differing_bytes=nbytes, mask_equal=masks_ok, per_rank_max_abs_diff=diffs,
+               panorama_shape=list(o_pano.shape), band_edges=list(p.edges))
+    return rec
+
+
 def timed_rounds(run_step, barrier, steps, warmup, n_inflight, min_seconds, reduce_max):
     """W warm-up steps, then rounds of exactly K timed steps (barrier + stream sync on both sides, max over ranks) until
     the rounds hold >= min_seconds of work.  Returns (seconds per round list)."""
@@ -357,6 +420,10 @@ def main():
         share = fpg * W * H / 1e6 / (sum(sr) / (max(4, args.steps // 2) * len(sr)))
         del sj
 
+    parity_n = None
+    if world > 1 and not args.no_parity and wl["blender"] == "multiband":
+        parity_n = sharded_parity(jobs[0], dist, rank, world, wl, all_cams)
+
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -401,8 +468,9 @@ def main():
                          "note": "rounds of exactly --steps steps, repeated until >= %.2g s are timed; value = all steps / all time" % args.min_seconds},
         "config": {"workload": f"{wl['name']}; {wl['warper']} warp + {bands_txt}{wl['blender']} blend, inputs resident in HBM",
                    "baseline_config": wl["cfg"], "frames_per_gpu": fpg,
-                   "sharding": ("contiguous yaw columns -> panorama column bands, contribution strips "
-                                f"({jobs[0].transport.name})") if world > 1 else "single GPU",
+                   "sharding": ("contiguous yaw columns -> panorama column bands, "
+                                + ("warped-image strips" if getattr(jobs[0], "exchange", "strips") == "strips" else "per-level contribution strips")
+                                + f" over {jobs[0].transport.name} send/recv") if world > 1 else "single GPU",
                    "ranks_share_a_gpu": bool(shared and world > 1),
                    "panoramas_in_flight": len(jobs),
                    "warped_mpix_per_step": round(warped_mpix, 2),
@@ -417,6 +485,8 @@ def main():
                         "frac_of_hbm_peak": round(kbytes / max(ksum, 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
                         "note": "bytes the fused kernels move (algorithmic, per kernel) / summed kernel time: the bandwidth fraction of the path"},
     }
+    if parity_n is not None:
+        result["parity"] = parity_n
     if world > 1:
         p = job.plan_
         result["config"]["exchange"] = {"messages": len(p.messages), "bytes_per_step": p.exchanged_bytes(),

@@ -183,8 +183,8 @@ int stx_blend_destroy(stx_blender* b);
  * stx_gain_apply      <- stitching/exposure_error_compensator.py:43-45 compensator.apply(idx, corner, img, mask) for the
  *                        "gain" / "channel" compensators (GainCompensator::apply, ChannelsCompensator::apply =
  *                        cv::multiply(image, gain): fp32 product, cvRound, saturate to u8), in place on the warped image
- *                        between warp and feed (stitching/stitcher.py:123,219-221).  The block compensators need
- *                        cv::resize of the gain map and stay on the host.
+ *                        between warp and feed (stitching/stitcher.py:123,219-221).  The block compensators
+ *                        ("gain_blocks", "channel_blocks") are stx_block_gain_apply below.
  * stx_timelapse_frame <- stitching/timelapser.py:36-52 timelapser.process(img, mask, corner) + getDst():
  *                        zero frame of the roi given to initialize(), the image pasted at its corner. */
 int stx_gain_apply(stx_ctx* ctx, stx_buf* img_u8x3, const float gains_bgr[3]);

@@ -668,11 +668,34 @@ static int seam_resize_batch_impl(stx_ctx* ctx, int n, const stx_buf* const* sea
         fast = fast && ((uintptr_t)m->ptr & 3) == 0 && (m->stride & 3) == 0 && (size_t)((m->w + 3) & ~3) <= m->stride;
     }
     if (n == 0) return STX_OK;
-    if (!fast) {
-        if (sub) return stx_fail(STX_ERR_UNSUPPORTED, "seam mask rectangles need dword-aligned final masks");
-        for (int i = 0; i < n; i++) STX_TRY(stx_seam_mask_resize(ctx, seam_masks[i], final_masks[i], &outs[i]));
+    // final masks the 4-pixel kernel cannot read in place (a view that starts on an odd byte, a pitch that is not a multiple
+    // of 4): whole masks go through the per-image call; rectangles (sub) are first copied into aligned buffers of their own
+    std::vector<stx_buf*> aligned;  // released on every path below
+    std::vector<const stx_buf*> fm(final_masks, final_masks + n);
+    struct ReleaseAll { std::vector<stx_buf*>& v; ~ReleaseAll() { for (stx_buf* b : v) stx_buf_release(b); } } release_aligned{aligned};
+    if (!fast && !sub) {
+        for (int i = 0; i < n; i++) {
+            const int rc1 = stx_seam_mask_resize(ctx, seam_masks[i], final_masks[i], &outs[i]);
+            if (rc1 != STX_OK) {  // hand nothing out: release what the earlier iterations produced
+                for (int j = 0; j < i; j++) { stx_buf_release(outs[j]); outs[j] = nullptr; }
+                return rc1;
+            }
+        }
         return STX_OK;
     }
+    if (!fast) {
+        for (int i = 0; i < n; i++) {
+            const stx_buf* m = final_masks[i];
+            if (((uintptr_t)m->ptr & 3) == 0 && (m->stride & 3) == 0 && (size_t)((m->w + 3) & ~3) <= m->stride) continue;
+            stx_buf* c = nullptr;
+            STX_TRY(stx_buf_new(ctx, m->w, m->h, 1, STX_U8, &c));
+            aligned.push_back(c);
+            STX_HIP(hipMemcpy2DAsync(c->ptr, c->stride, m->ptr, m->stride, (size_t)m->w, (size_t)m->h, hipMemcpyDeviceToDevice, ctx->stream));
+            c->mask_binary = m->mask_binary;
+            fm[i] = c;
+        }
+    }
+    final_masks = fm.data();
     // tables of all images in one upload: per image xt (dw rounded up to 4 entries) then yt
     std::vector<int> all;
     std::vector<size_t> xoff(n), yoff(n);

@@ -238,7 +238,7 @@ class GlooHostTransport:
 
     def __init__(self, dist, ctx):
         self.dist, self.ctx = dist, ctx
-        self._pending = None
+        self._pending = {}  # id(context) -> (sends, recvs, context): one exchange per context may be pending, as with RcclTransport
 
     def exchange(self, sends, recvs, ctx=None):
         """sends: [(dst, DeviceImage packed, nbytes)], recvs: [(src, nbytes)] -> [DeviceImage]"""
@@ -246,12 +246,20 @@ class GlooHostTransport:
         return [flat_device_buffer(ctx or self.ctx, a) for a in gloo_exchange_host(self.dist, host_sends, recvs)]
 
     # split form (same contract as RcclTransport): the host-staged exchange has nothing to overlap, it runs in finish()
+    # Several contexts (panoramas in flight) may share the transport; the exchanges then run in the order of the finish()
+    # calls, which must be the same on every rank.
     def start(self, sends, recvs, ctx=None):
-        self._pending = (sends, recvs, ctx)
+        ctx = ctx or self.ctx
+        if id(ctx) in self._pending:
+            raise StitchingError("an exchange of this context is already pending on this transport")
+        self._pending[id(ctx)] = (sends, recvs, ctx)
+        self._last = ctx
 
     def finish(self, ctx=None):
-        sends, recvs, ctx = self._pending
-        self._pending = None
+        key = id(ctx or self._last)
+        if key not in self._pending:
+            raise StitchingError("finish() without a pending exchange of this context")
+        sends, recvs, ctx = self._pending.pop(key)
         return self.exchange(sends, recvs, ctx)
 
 
@@ -294,23 +302,17 @@ class RcclTransport:
     name = "rccl"
 
     def __init__(self, ctx, rank, world, unique_id):
-        import os
-
-        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # one node: every rank bootstraps over loopback (see unique_id)
         self.ctx, self.rank, self.world = ctx, rank, world
         h = C.c_void_p()
         uid = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
         _lib.check(ctx._lib.stx_comm_create(ctx.handle, int(world), int(rank), uid, C.byref(h)))
         self._h = h
-        self._inflight, self._last, self._sent = {}, None, None
+        self._inflight, self._last = {}, None
 
     @staticmethod
     def unique_id():
-        import os
-
-        # all ranks live on one node: RCCL's bootstrap (ncclGetUniqueId opens a listening socket) stays on the loopback
-        # interface unless the caller chose another (interface discovery has been seen to stall on boxes without a network)
-        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        """ncclGetUniqueId.  No environment is touched here: a caller whose ranks all share one host may wrap this call and the
+        constructor in `loopback_bootstrap()` (default_transport does, after comparing host names)."""
         uid = (C.c_ubyte * 128)()
         _lib.check(_lib.lib().stx_comm_unique_id(uid))
         return bytes(uid)
@@ -336,6 +338,8 @@ class RcclTransport:
             peers[i], is_send[i], ptrs[i], sizes[i] = src, 0, buf.device_ptr(), nbytes
             i += 1
         for dst, packed, nbytes in sends:
+            if packed.ctx is not ctx:
+                raise StitchingError("strips must be packed on the context that exchanges them (its stream orders their lifetime)")
             peers[i], is_send[i], ptrs[i], sizes[i] = dst, 1, packed.device_ptr(), nbytes
             i += 1
         _lib.check(lib.stx_comm_exchange_begin_on(self._h, ctx.handle, n, peers, is_send, ptrs, sizes))
@@ -346,10 +350,12 @@ class RcclTransport:
         """Order the stream of `ctx` (default: the context of the latest start) after ITS transfer — exchanges of
         other contexts that were started in between are not waited for; returns the received strips."""
         rbufs, sent, ctx = self._inflight.pop(id(ctx or self._last))
+        # stx_comm_exchange_end_on makes the context's stream wait for the event recorded on the communicator's stream
+        # behind the whole send / recv group.  The sent strips were allocated by that context, whose allocator is ordered by
+        # its stream: once the wait is queued, a block released here can only be handed to work that runs after the
+        # transfer — so the references are dropped now (no "keep n generations" guess).
         _lib.check(ctx._lib.stx_comm_exchange_end_on(self._h, ctx.handle))
-        # the sent strips must outlive the transfer: they are released only after a later exchange of the same
-        # context has been ordered behind this one (two generations are kept)
-        self._sent = (self._sent or [])[-2:] + [sent]
+        del sent
         return rbufs
 
     def exchange(self, sends, recvs, ctx=None):
@@ -503,6 +509,39 @@ class ShardedStitchJob:
         return np.concatenate([p[0] for p in parts], axis=1), np.concatenate([p[1] for p in parts], axis=1)
 
 
+class loopback_bootstrap:
+    """`with loopback_bootstrap(enabled):` RCCL's bootstrap sockets (ncclGetUniqueId / ncclCommInitRank) stay on the loopback
+    interface while the block runs — interface discovery has been seen to stall on boxes without a network — unless the
+    caller already chose an interface.  The previous environment is restored on exit, so nothing else in the process (a
+    torch.distributed nccl group created later, a multi-node job) inherits the choice."""
+
+    def __init__(self, enabled):
+        self.enabled, self.prev = bool(enabled), None
+
+    def __enter__(self):
+        import os
+
+        self.touched = self.enabled and "NCCL_SOCKET_IFNAME" not in os.environ
+        if self.touched:
+            os.environ["NCCL_SOCKET_IFNAME"] = "lo"
+        return self
+
+    def __exit__(self, *exc):
+        import os
+
+        if self.touched:
+            os.environ.pop("NCCL_SOCKET_IFNAME", None)
+        return False
+
+
+def all_ranks_on_one_host(dist, world):
+    import socket
+
+    names = [None] * world
+    dist.all_gather_object(names, socket.gethostname())
+    return len(set(names)) == 1
+
+
 def default_transport(ctx, rank, world, dist):
     """RCCL when it initialises on this node, else the host-staged gloo transport."""
     if world == 1:
@@ -519,17 +558,20 @@ def default_transport(ctx, rank, world, dist):
     # Every rank issues the same sequence of collectives whatever fails where: (1) rank 0 ALWAYS broadcasts — the unique
     # id, or None when librccl is missing / refused or RCCL is not wanted; (2) ranks that got an id try to join the
     # communicator; (3) one all-reduce(MIN) decides for everybody.
+    one_host = all_ranks_on_one_host(dist, world)  # a collective: every rank calls it
     uid = [None]
     if rank == 0 and want == "rccl":
         try:
-            uid = [RcclTransport.unique_id()]
+            with loopback_bootstrap(one_host):
+                uid = [RcclTransport.unique_id()]
         except Exception as e:  # noqa: BLE001
             print(f"[stitching_amd] rank 0: no RCCL unique id ({e}); using host-staged gloo", file=sys.stderr)
     dist.broadcast_object_list(uid, src=0)
     ok, tr = 0, None
     if uid[0] is not None:
         try:
-            tr = RcclTransport(ctx, rank, world, uid[0])
+            with loopback_bootstrap(one_host):
+                tr = RcclTransport(ctx, rank, world, uid[0])
             ok = 1
         except Exception as e:  # noqa: BLE001 - any failure -> agree on the fallback below
             print(f"[stitching_amd] rank {rank}: RCCL transport unavailable ({e}); using host-staged gloo", file=sys.stderr)

@@ -62,7 +62,11 @@ class MegapixDownscaler(MegapixScaler):
 
 
 def _decode(name):
-    """u8 BGR HWC, as cv.imread(name) returns it."""
+    """u8 BGR HWC, as cv.imread(name) returns it (IMREAD_COLOR: 3 channels, 8 bits, the EXIF orientation applied).
+    Without cv2 the file goes through Pillow: the EXIF orientation tag is applied (`ImageOps.exif_transpose`, as cv.imread
+    does by default — a portrait phone JPEG keeps its swapped width and height), everything is converted to 8-bit RGB.
+    Known remaining differences from cv.imread: 16-bit PNG / TIFF are scaled by Pillow's own conversion rather than >> 8,
+    CMYK JPEGs use Pillow's profile-less formula, and libjpeg builds may differ in their IDCT by +-1."""
     try:
         import cv2 as cv
     except ImportError:
@@ -74,8 +78,10 @@ def _decode(name):
     except ImportError as e:
         raise StitchingError("reading image files needs cv2 or Pillow") from e
     try:
+        from PIL import ImageOps
+
         with Image.open(name) as im:
-            rgb = np.asarray(im.convert("RGB"))
+            rgb = np.asarray(ImageOps.exif_transpose(im).convert("RGB"))
     except (OSError, ValueError):
         return None
     return np.ascontiguousarray(rgb[:, :, ::-1])
@@ -159,13 +165,16 @@ class Images:
         return (img.shape[1], img.shape[0])
 
     @staticmethod
-    def resize_img_by_scaler(scaler, size, img):
+    def resize_img_by_scaler(scaler, size, img, device_resident=None):
+        """device_resident: None -> the process-wide setting; True / False: this call only (Images.stage passes True instead
+        of flipping the global)"""
+        resident = config.device_resident() if device_resident is None else device_resident
         desired = scaler.get_scaled_img_size(size)
         if desired == Images.get_image_size(img):  # INTER_LINEAR_EXACT to the same size is the identity
-            if isinstance(img, DeviceImage) or not config.device_resident():
+            if isinstance(img, DeviceImage) or not resident:
                 return img
             return DeviceImage.from_numpy(img)
-        return resize_linear_exact(img, desired, ctx=img.ctx if isinstance(img, DeviceImage) else None)
+        return resize_linear_exact(img, desired, ctx=img.ctx if isinstance(img, DeviceImage) else None, device_resident=resident)
 
     @staticmethod
     def check_resolution(resolution):
@@ -183,12 +192,21 @@ class Images:
 
     @staticmethod
     def to_binary(img):
-        """stitching/images.py:153-158: BGR2GRAY (Y = (R 4899 + G 9617 + B 1868 + 8192) >> 14, cv::cvtColor's 8-bit path),
-        then 255 where the value exceeds 0.5."""
+        """stitching/images.py:153-158: cv.cvtColor(BGR2GRAY), then 255 where the value exceeds 0.5.  cv2 does the
+        conversion when it is importable.  Otherwise the 8-bit path of OpenCV 4.x / 5.x is restated (from memory of
+        color_rgb.simd.hpp / color.hpp, unverified like the rest of the oracle): Y = (R 9798 + G 19235 + B 3735 + 2^14) >> 15
+        (`RY15, GY15, BY15, gray_shift = 15`; the 2.x / 3.x line used 4899, 9617, 1868 >> 14).  The two grey images differ
+        at 43 864 of the 2^24 BGR triples, the thresholded result at NONE: with either formula exactly the seven triples
+        (B, G, R) = (0..4, 0, 0), (0, 0, 1), (1, 0, 1) give 0 (tests/test_images.py::test_to_binary_zero_set)."""
         img = np.asarray(img)
         if img.ndim == 3:
-            b, g, r = (img[:, :, k].astype(np.uint32) for k in range(3))
-            img = ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8)
+            try:
+                import cv2 as cv
+
+                img = cv.cvtColor(np.ascontiguousarray(img), cv.COLOR_BGR2GRAY)
+            except ImportError:
+                b, g, r = (img[:, :, k].astype(np.uint32) for k in range(3))
+                img = ((r * 9798 + g * 19235 + b * 3735 + 16384) >> 15).astype(np.uint8)
         return np.where(img > 0.5, 255, 0).astype(np.uint8)
 
     # ---- staging (no counterpart in the reference: it reads and resizes one image at a time on the host)
@@ -201,7 +219,8 @@ class Images:
         n = len(self._staging_sources())
         if n == 0:
             return
-        self._pin_pool, self._pin_lock = {}, threading.Lock()
+        # per call: two stage() generators over one Images object must not share (or clobber) each other's buffers
+        pin_pool, pin_lock = {}, threading.Lock()
         with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
             pending = deque()
             nxt = 0
@@ -209,7 +228,7 @@ class Images:
             def submit():
                 nonlocal nxt
                 if nxt < n:
-                    pending.append(pool.submit(self._load_pinned, nxt))
+                    pending.append(pool.submit(self._load_pinned, nxt, pin_pool, pin_lock))
                     nxt += 1
 
             for _ in range(max(1, depth)):
@@ -224,25 +243,19 @@ class Images:
                 in_flight.append(host)
                 if len(in_flight) > max(1, depth):
                     ctx.sync()  # page-locked buffers go back to the decoders only after their queued copies have landed
-                    with self._pin_lock:
+                    with pin_lock:
                         for b in in_flight:
-                            self._pin_pool.setdefault((b.shape, b.dtype.str), []).append(b)
+                            pin_pool.setdefault((b.shape, b.dtype.str), []).append(b)
                     in_flight.clear()
-                prev = config.device_resident()
-                config.set_device_resident(True)
-                try:
-                    out = Images.resize_img_by_scaler(self._get_scaler(resolution), self._sizes[idx], dev)
-                finally:
-                    config.set_device_resident(prev)
-                yield out
+                yield Images.resize_img_by_scaler(self._get_scaler(resolution), self._sizes[idx], dev, device_resident=True)
                 idx += 1
             ctx.sync()
 
-    def _load_pinned(self, i):
+    def _load_pinned(self, i, pin_pool, pin_lock):
         src = self._staging_sources()[i]
         a = Images.read_image(src) if isinstance(src, str) else np.asarray(src)
-        with self._pin_lock:
-            free = self._pin_pool.get((a.shape, a.dtype.str))
+        with pin_lock:
+            free = pin_pool.get((a.shape, a.dtype.str))
             buf = free.pop() if free else None
         if buf is None:
             buf = pinned_empty(a.shape, a.dtype)

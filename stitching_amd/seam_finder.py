@@ -15,14 +15,16 @@ from .device import DeviceImage, as_device, get_context
 from .stitching_error import StitchingError
 
 
-def resize_linear_exact(img, size, ctx=None):
-    """cv.resize(img, size, interpolation=cv.INTER_LINEAR_EXACT) for u8 images with 1 or 3 channels; size = (w, h)."""
+def resize_linear_exact(img, size, ctx=None, device_resident=None):
+    """cv.resize(img, size, interpolation=cv.INTER_LINEAR_EXACT) for u8 images with 1 or 3 channels; size = (w, h).
+    device_resident: True -> a DeviceImage, False -> numpy, None -> the process-wide setting (config.device_resident())."""
     ctx = ctx or get_context()
     d = as_device(img, ctx)
     out = C.c_void_p()
     _lib.check(ctx._lib.stx_resize_linear_exact(ctx.handle, d._h, int(size[0]), int(size[1]), C.byref(out)))
     r = DeviceImage(ctx, out)
-    return r if config.device_resident() else r.numpy()
+    resident = config.device_resident() if device_resident is None else device_resident
+    return r if resident else r.numpy()
 
 
 class SeamFinder:

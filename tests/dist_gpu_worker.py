@@ -1,0 +1,74 @@
+"""Worker of tests/test_gpu_two_process.py: one rank of a REAL multi-process sharded job whose ranks share GPU 0.
+
+Every rank is its own process with its own device context; the strips travel over the host-staged gloo transport (RCCL
+refuses two ranks on one device).  Each rank warps its frames, exchanges strips, blends its band; rank 0 gathers the bands
+and compares the assembled panorama with the oracle's panorama of all frames, byte for byte."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch.distributed as dist
+
+    import stitching_amd as S
+    from stitching_amd import synthetic
+    from stitching_amd.distributed import ShardedStitchJob
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    case = json.loads(os.environ["STX_TEST_CASE"])
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    S.set_default_device(0)
+    ctx = S.get_context()
+    w, h, per = case["w"], case["h"], case["per_rank"]
+    n = per * world
+    if case["layout"] == "ring":
+        cams = synthetic.ring_cameras(n, w, h, span_deg=case.get("span", 40.0 * n))
+    else:  # yaw columns x pitch rows, one column (or two) per rank
+        cams = synthetic.grid_cameras(n // case["rows"], case["rows"], w, h, max_edge_lat_deg=case.get("max_lat", 83.0),
+                                      layout_yaw=case.get("layout_yaw"))
+    mine = range(rank * per, (rank + 1) * per)
+    frames = [synthetic.make_frame(case.get("seed", 0) + i, w, h) for i in mine]
+    job = ShardedStitchJob(frames, [cams[i] for i in mine], cams, rank, world, warper_type=case["warper"], num_bands=case["bands"],
+                           ctx=ctx, dist=dist, split_boundary=case.get("split", True), exchange=case.get("exchange", "strips"),
+                           mask_bits=case.get("mask_bits", True))
+    plan = job.plan()
+    res = {"transport": job.transport.name, "bands": plan.num_bands, "messages": len(plan.messages), "bytes": plan.exchanged_bytes()}
+    for _ in range(case.get("repeat", 2)):  # the second panorama reuses cached blocks, buffers and the transport
+        pano, mask = job.run()
+    full, fmask = job.gather(pano, mask)
+    if rank == 0:
+        from oracle import oracle as O
+
+        O.build()
+        O.set_num_threads(max(1, min(O.max_threads(), 32)))
+        all_frames = [synthetic.make_frame(case.get("seed", 0) + i, w, h) for i in range(n)]
+        ow = O.Warper(case["warper"])
+        ow.set_scale(cams)
+        sizes = [(w, h)] * n
+        corners, wsizes = ow.warp_rois(sizes, cams)
+        roi = O.result_roi(corners, wsizes)
+        ob = O.Blender("multiband", synthetic.blend_strength_for_bands(case["bands"], roi[2], roi[3]))
+        ob.prepare(corners, wsizes)
+        for f, c, corner in zip(all_frames, cams, corners):
+            ob.feed(ow.warp_image(f, c), ow.create_and_warp_mask((w, h), c), corner)
+        o_pano, o_mask = (np.asarray(a) for a in ob.blend())
+        res["shape"] = list(full.shape)
+        res["shape_equal"] = full.shape == o_pano.shape and fmask.shape == o_mask.shape
+        if res["shape_equal"]:
+            d = np.abs(full.astype(np.int16) - o_pano.astype(np.int16))
+            res.update(max_abs_diff=int(d.max()), differing_bytes=int(np.count_nonzero(d)), mask_equal=bool(np.array_equal(fmask, o_mask)),
+                       rois_equal=[tuple(c) for c in corners] == plan.corners and [tuple(s) for s in wsizes] == plan.sizes)
+        res["ok"] = bool(res.get("shape_equal") and res.get("max_abs_diff") == 0 and res.get("mask_equal") and res.get("rois_equal"))
+        print(json.dumps(res), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,9 +13,11 @@ Part 2: size-independent properties:
     (weights 2, sums doubled: the normalised Laplacians are identical);
   * order independence of the integer sums: permuting the feed order leaves the panorama bit-identical
     when every pixel is covered by at most 2 images with 0/1 weights (fp32 sums of small integers are exact);
-  * sharding: column bands + contribution strips equal the single blender bit for bit;
-  * config 4 / 5 shapes (cylindrical 7 bands on 8000x6000 sources; affine + feather / no) run and are
-    self-consistent (mask == panorama coverage, panorama zero outside the mask).
+
+Config 4 also goes through the SHARDED path at full size (test_config4_sharded_vs_oracle): 16 frames 8000x6000 = 4 of the
+16 yaw columns x 4 pitch rows, cylindrical, 7 bands (gap 384, alignment 128), two ranks with two yaw columns each —
+bench.py's `--config 4 --gpus 2` layout — through ShardedStitchJob in both split orders with the masks travelling as bits,
+and as virtual shards; every panorama equals the oracle's bit for bit.
 """
 import numpy as np
 import pytest
@@ -23,6 +25,7 @@ import pytest
 import stitching_amd as S
 from stitching_amd import synthetic
 from stitching_amd.pipeline import StitchJob
+from tests import helpers
 
 pytestmark = pytest.mark.gpu
 
@@ -92,63 +95,6 @@ def test_config2_feed_twice_and_feed_order(gpu_ctx, frames):
     d3 = np.abs(p1.astype(np.int16) - p3.astype(np.int16))
     # int16 sums are order independent; fp32 weight sums differ at ULP level only where > 2 images overlap
     assert d3.max() <= 1 and np.count_nonzero(d3) < 1e-4 * d3.size
-
-
-def test_config3_sharded_equals_single_full_size(gpu_ctx, frames):
-    from stitching_amd.distributed import virtual_sharded_blend
-
-    cams = synthetic.ring_cameras(8, W, H)[:4]
-    job = StitchJob(frames, cams, num_bands=5)
-    job.plan()
-    S.set_device_resident(True)
-    try:
-        imgs, masks, rois = job.warper.warp_images_and_masks(job.frames, job.cameras)
-        b = S.Blender("multiband", job.blend_strength)
-        b.prepare(job.corners, job.warped_sizes)
-        for i in range(4):
-            b.feed(imgs[i], masks[i], job.corners[i])
-        nb = b.blender.num_bands()
-        pano, pmask = (np.asarray(a) for a in b.blend())
-        roi = S.Blender.result_roi(job.corners, job.warped_sizes)
-        req = int(np.log(np.sqrt(roi[2] * roi[3]) * job.blend_strength / 100) / np.log(2.0) - 1.0)
-        sp, sm, plan = virtual_sharded_blend(gpu_ctx, imgs, masks, job.corners, job.warped_sizes, 2, req)
-    finally:
-        S.set_device_resident(False)
-    assert plan.num_bands == nb == 5 and plan.exchanged_bytes() > 0
-    assert np.array_equal(sm, pmask) and np.array_equal(sp, pano)
-
-
-def test_config4_cylindrical_7_bands_large_sources(gpu_ctx):
-    w, h = 8000, 6000
-    fr = [S.DeviceImage.from_numpy(synthetic.make_frame(i, w, h), gpu_ctx) for i in range(3)]
-    cams = synthetic.ring_cameras(8, w, h)[:3]
-    job = StitchJob(fr, cams, warper_type="cylindrical", num_bands=7)
-    pano, pmask = (np.asarray(a) for a in job.run())
-    assert job.last_num_bands == 7
-    assert pano.shape[:2] == pmask.shape and pmask.any()
-    assert set(np.unique(pmask)) <= {0, 255}
-    assert not pano[pmask == 0].any()
-    # every warped image lies inside the panorama and is covered by the mask
-    cov = np.count_nonzero(pmask) / pmask.size
-    assert 0.5 < cov <= 1.0
-
-
-@pytest.mark.parametrize("btype", ["feather", "no"])
-def test_config5_affine_tiles(gpu_ctx, btype):
-    tiles = [synthetic.make_frame(i, W, H) for i in range(4)]
-    cams = synthetic.affine_scan_cameras(4, W, H)
-    job = StitchJob(tiles, cams, warper_type="affine", blender_type=btype)
-    pano, pmask = (np.asarray(a) for a in job.run())
-    assert pano.shape[:2] == pmask.shape
-    assert not pano[pmask == 0].any()
-    if btype == "no":
-        # masked overwrite: the last fed tile is visible unchanged where it lies
-        x, y = job.corners[3][0] - min(c[0] for c in job.corners), job.corners[3][1] - min(c[1] for c in job.corners)
-        wi, _, _ = job.warper.warp_image_and_mask(tiles[3], cams[3])
-        wi = np.asarray(wi)
-        sub = pano[y:y + wi.shape[0], x:x + wi.shape[1]]
-        m = np.asarray(job.warper.create_and_warp_mask((W, H), cams[3])) > 0
-        assert np.array_equal(sub[m], wi[m])
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -243,6 +189,44 @@ def test_config4_share_vs_oracle(oracle, gpu_ctx):
     o = _oracle_panorama(oracle, frames, cams, "cylindrical", num_bands=7)
     assert job.corners == o["corners"] and job.warped_sizes == o["sizes"]
     _assert_same(pano, pmask, o)
+
+
+def test_config4_sharded_vs_oracle(oracle, gpu_ctx):
+    """BASELINE configs[3] through the sharded path: 4 of the 16 yaw columns x 4 pitch rows (16 frames 8000x6000), cylindrical,
+    7 bands, two ranks x two yaw columns x 4 rows — the layout of `bench.py --config 4 --gpus 2`.  ShardedStitchJob as the
+    bench drives it, in both split orders, masks as bits (STX_STRIP_MASK_BITS); then 2 and 4 virtual shards of the same 16
+    warps (4: one yaw column per rank, strips to second neighbours).  All equal the oracle bit for bit."""
+    from stitching_amd.distributed import virtual_sharded_blend
+
+    w, h = 8000, 6000
+    cams = synthetic.grid_cameras(4, 4, w, h, max_edge_lat_deg=50.0, layout_yaw=16)
+    frames = [synthetic.make_frame(100 + i, w, h) for i in range(16)]
+    o = _oracle_panorama(oracle, frames, cams, "cylindrical", num_bands=7)
+    assert o["blender"].blender.num_bands() == 7
+    d_frames = [S.DeviceImage.from_numpy(f, gpu_ctx) for f in frames]
+    for split in (True, False):
+        sp, sm, jobs = helpers.run_sharded_job_in_one_process(gpu_ctx, d_frames, cams, 2, 8, warper_type="cylindrical", num_bands=7,
+                                                              split_boundary=split, exchange="strips", mask_bits=True)
+        p = jobs[0].plan_
+        assert p.num_bands == 7 and p.mask_bits and p.exchanged_bytes() > 0
+        assert p.corners == [tuple(c) for c in o["corners"]] and p.sizes == [tuple(s) for s in o["sizes"]]
+        assert all(e % 128 == 0 for e in p.edges[:-1])
+        assert p.owners == [0] * 8 + [1] * 8
+        _assert_same(sp, sm, o)
+    del jobs
+    job = StitchJob(d_frames, cams, warper_type="cylindrical", num_bands=7)
+    job.plan()
+    S.set_device_resident(True)
+    try:
+        imgs, masks, rois = job.warper.warp_images_and_masks(job.frames, job.cameras)
+        roi = S.Blender.result_roi(job.corners, job.warped_sizes)
+        req = int(np.log(np.sqrt(roi[2] * roi[3]) * job.blend_strength / 100) / np.log(2.0) - 1.0)
+        for world, bits in ((2, False), (4, True)):
+            sp, sm, plan = virtual_sharded_blend(gpu_ctx, imgs, masks, job.corners, job.warped_sizes, world, req, "strips", bits)
+            assert plan.num_bands == 7 and plan.exchanged_bytes() > 0 and plan.mask_bits == bits
+            _assert_same(sp, sm, o)
+    finally:
+        S.set_device_resident(False)
 
 
 @pytest.mark.parametrize("btype", ["feather", "no"])

@@ -211,10 +211,15 @@ def test_rccl_transport_self_exchange(gpu_ctx):
     """The RCCL strip transport (dlopen'd librccl, ncclSend/ncclRecv grouped on the ctx stream) on a
     1-rank communicator: a strip sent to self arrives intact.  Multi-rank behaviour is the same code
     path with peers != rank (8-GPU node only)."""
-    from stitching_amd.distributed import RcclTransport
+    import os
+
+    from stitching_amd.distributed import RcclTransport, loopback_bootstrap
     from stitching_amd.device import DeviceImage
 
-    tr = RcclTransport(gpu_ctx, 0, 1, RcclTransport.unique_id())
+    env_before = os.environ.get("NCCL_SOCKET_IFNAME")
+    with loopback_bootstrap(True):  # one rank, one host: bootstrap over the loopback interface; the environment is restored
+        tr = RcclTransport(gpu_ctx, 0, 1, RcclTransport.unique_id())
+    assert os.environ.get("NCCL_SOCKET_IFNAME") == env_before
     rng = np.random.default_rng(7)
     host = rng.integers(0, 256, size=(1, 1 << 20), dtype=np.uint8)
     src = DeviceImage.from_numpy(host, gpu_ctx)
@@ -283,50 +288,9 @@ def test_sharded_job_bands_equal_single_job(oracle, gpu_ctx, split, exchange):
     single = StitchJob(frames, cams, num_bands=4)
     pano, pmask = (np.asarray(a) for a in single.run())
 
-    class Recorder:
-        def __init__(self):
-            self.sent = []
-
-        def start(self, sends, recvs, ctx=None):
-            self.sent = [(dst, np.asarray(p).reshape(-1)[:nb].copy()) for dst, p, nb in sends]
-            self.recvs = recvs
-
-        def finish(self, ctx=None):
-            return [flat_device_buffer(gpu_ctx, np.zeros(nb, np.uint8)) for _, nb in self.recvs]
-
-    class Replay:
-        def __init__(self, inbox):
-            self.inbox = inbox
-
-        def start(self, sends, recvs, ctx=None):
-            self.recvs = recvs
-
-        def finish(self, ctx=None):
-            out = []
-            for src, nb in self.recvs:
-                a = self.inbox[src].pop(0)
-                assert a.size == nb
-                out.append(flat_device_buffer(gpu_ctx, a))
-            return out
-
-    per = n // world
-    jobs, recs = [], []
-    for r in range(world):
-        rec = Recorder()
-        job = ShardedStitchJob(frames[r * per:(r + 1) * per], cams[r * per:(r + 1) * per], cams, r, world, num_bands=4,
-                               ctx=gpu_ctx, transport=rec, split_boundary=split, exchange=exchange)
-        job.plan()
-        job.run()
-        jobs.append(job)
-        recs.append(rec)
+    sp, sm, jobs = helpers.run_sharded_job_in_one_process(gpu_ctx, frames, cams, world, n // world, num_bands=4, split_boundary=split,
+                                                          exchange=exchange)
     assert jobs[0].last_num_bands == single.last_num_bands
-    bands = []
-    for r in range(world):
-        inbox = {src: [a for dst, a in recs[src].sent if dst == r] for src in range(world) if src != r}
-        jobs[r].transport = Replay(inbox)
-        bands.append(tuple(np.asarray(a) for a in jobs[r].run()))
-    sp = np.concatenate([b[0] for b in bands], axis=1)
-    sm = np.concatenate([b[1] for b in bands], axis=1)
     assert sp.shape == pano.shape
     assert np.array_equal(sm, pmask) and np.array_equal(sp, pano)
 

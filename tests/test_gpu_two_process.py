@@ -1,0 +1,68 @@
+"""Real multi-process runs of the sharded path on ONE GPU: every rank is its own process (own HIP context, own blender,
+own band), the strips travel through the host-staged gloo transport, rank 0 assembles the bands and compares the panorama
+with the oracle's — the N > 1 code path of bench.py with pixels checked, not only payload bytes
+(tests/test_distributed_cpu.py) or a record / replay inside one process (test_sharded_job_bands_equal_single_job)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def launch(world, case, timeout=420):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   STX_TEST_CASE=json.dumps(case), GLOO_SOCKET_IFNAME="lo", STITCHING_AMD_FORCE_DEVICE="0", STITCHING_AMD_TRANSPORT="gloo",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("sharded worker timed out")
+        outs.append((p.returncode, o, e))
+    for rc, o, e in outs:
+        assert rc == 0, f"worker failed:\n{e[-3000:]}"
+    return json.loads(outs[0][1].strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("split", [True, False])
+def test_two_ranks_ring_panorama_equals_oracle(gpu_ctx, split):
+    """6 frames, spherical, 4 bands, 2 ranks x 3 frames: the gathered panorama is the oracle's."""
+    res = launch(2, dict(layout="ring", w=803, h=601, per_rank=3, warper="spherical", bands=4, split=split))
+    assert res["transport"] == "gloo-host" and res["bands"] == 4 and res["messages"] >= 2 and res["bytes"] > 0
+    assert res["ok"], res
+
+
+def test_three_ranks_multi_row_cylindrical_equals_oracle(gpu_ctx):
+    """config 4 in small: 3 yaw columns x 4 pitch rows of 1000x750 frames, cylindrical, 5 bands, one column per rank, the
+    masks as bits: strips between all pairs of ranks."""
+    res = launch(3, dict(layout="grid", rows=4, w=1000, h=750, per_rank=4, warper="cylindrical", bands=5, max_lat=50.0, layout_yaw=16,
+                         seed=100, mask_bits=True))
+    assert res["bands"] == 5 and res["messages"] >= 4
+    assert res["ok"], res
+
+
+def test_two_ranks_config3_columns_equal_oracle(gpu_ctx):
+    """config 3 in half size: 2 of the 8 yaw columns x 4 pitch rows (the +-56 degree rows warp to twice their source size),
+    spherical, 5 bands, contribution exchange as well as strips."""
+    for exchange in ("strips", "contribs"):
+        res = launch(2, dict(layout="grid", rows=4, w=2000, h=1500, per_rank=4, warper="spherical", bands=5, layout_yaw=8, exchange=exchange,
+                             mask_bits=exchange == "strips"))
+        assert res["bands"] == 5 and res["bytes"] > 0
+        assert res["ok"], (exchange, res)

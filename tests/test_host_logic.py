@@ -100,3 +100,44 @@ def test_make_frame_is_seeded_and_textured():
     assert a.dtype == np.uint8 and a.shape == (48, 64, 3)
     assert np.array_equal(a, b) and not np.array_equal(a, c)
     assert a.std() > 10
+
+
+def test_loopback_bootstrap_restores_the_environment(monkeypatch):
+    """library code must not leave NCCL_SOCKET_IFNAME=lo behind (a later multi-node or torch nccl user in the same
+    process would bootstrap over loopback and hang)."""
+    import os
+
+    from stitching_amd.distributed import loopback_bootstrap
+
+    monkeypatch.delenv("NCCL_SOCKET_IFNAME", raising=False)
+    with loopback_bootstrap(True):
+        assert os.environ["NCCL_SOCKET_IFNAME"] == "lo"
+    assert "NCCL_SOCKET_IFNAME" not in os.environ
+    with loopback_bootstrap(False):  # ranks on several hosts: never touched
+        assert "NCCL_SOCKET_IFNAME" not in os.environ
+    monkeypatch.setenv("NCCL_SOCKET_IFNAME", "eth7")  # the caller's choice wins and survives
+    with loopback_bootstrap(True):
+        assert os.environ["NCCL_SOCKET_IFNAME"] == "eth7"
+    assert os.environ["NCCL_SOCKET_IFNAME"] == "eth7"
+
+
+def test_gloo_host_transport_keeps_one_pending_exchange_per_context():
+    from stitching_amd.distributed import GlooHostTransport
+    from stitching_amd.stitching_error import StitchingError
+
+    class Ctx:
+        pass
+
+    a, b = Ctx(), Ctx()
+    tr = GlooHostTransport(dist=None, ctx=a)
+    tr.exchange = lambda sends, recvs, ctx=None: (sends, recvs, ctx)  # the wire is tested in test_distributed_cpu.py
+    tr.start(["sa"], ["ra"], a)
+    tr.start(["sb"], ["rb"], b)
+    assert tr.finish(a) == (["sa"], ["ra"], a)  # round 2 returned B's strips here
+    assert tr.finish(b) == (["sb"], ["rb"], b)
+    with pytest.raises(StitchingError):
+        tr.finish(a)
+    tr.start(["s1"], ["r1"])  # default: the transport's own context, and finish() the latest start
+    with pytest.raises(StitchingError):
+        tr.start(["s2"], ["r2"], a)
+    assert tr.finish() == (["s1"], ["r1"], a)

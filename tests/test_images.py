@@ -84,6 +84,43 @@ def test_filename_images_decode(tmp_path):
         Images.of([names[0]])
 
 
+def test_to_binary_zero_set():
+    """Images.to_binary = cvtColor(BGR2GRAY) > 0.5: exactly seven BGR triples are black after the threshold — with the 15-bit
+    coefficients of OpenCV 4.x / 5.x and with the 14-bit ones of 2.x / 3.x alike (the grey values themselves differ at 43 864
+    triples, never across the 0 / 1 boundary)."""
+    b, g, r = np.meshgrid(np.arange(8, dtype=np.uint8), np.arange(8, dtype=np.uint8), np.arange(8, dtype=np.uint8), indexing="ij")
+    img = np.stack([b.ravel(), g.ravel(), r.ravel()], axis=1).reshape(1, -1, 3)
+    out = Images.to_binary(img)
+    zero = {tuple(int(v) for v in img[0, i]) for i in np.flatnonzero(out[0] == 0)}
+    assert zero == {(0, 0, 0), (1, 0, 0), (2, 0, 0), (3, 0, 0), (4, 0, 0), (0, 0, 1), (1, 0, 1)}
+    y14 = (r.astype(np.uint32) * 4899 + g.astype(np.uint32) * 9617 + b.astype(np.uint32) * 1868 + 8192) >> 14
+    assert np.array_equal(out.reshape(b.shape) > 0, y14 > 0)
+    assert np.array_equal(Images.to_binary(np.array([[0, 1, 200]], np.uint8)), [[0, 255, 255]])
+
+
+def test_decode_applies_the_exif_orientation(tmp_path):
+    """cv.imread applies the EXIF orientation tag; so does the Pillow fallback (a portrait phone JPEG keeps its swapped
+    width and height: sizes, scales and camera estimates depend on it)."""
+    Image = pytest.importorskip("PIL.Image")
+    from stitching_amd.images import _decode
+
+    a = np.zeros((40, 64, 3), np.uint8)
+    a[:20, :32] = (255, 0, 0)  # a red top-left quadrant (RGB)
+    plain, tagged = str(tmp_path / "plain.png"), str(tmp_path / "rot.jpg")
+    Image.fromarray(a).save(plain)
+    exif = Image.Exif()
+    exif[0x0112] = 6  # the stored pixels must be turned by 90 degrees clockwise for display
+    Image.fromarray(a).save(tagged, quality=100, subsampling=0, exif=exif)
+    p = _decode(plain)
+    assert p.shape == (40, 64, 3) and tuple(p[5, 5]) == (0, 0, 255)  # BGR
+    t = _decode(tagged)
+    assert t.shape == (64, 40, 3), "orientation 6 swaps width and height"
+    # the red quadrant ends up top-right
+    assert t[5, 35, 2] > 200 and t[5, 35, 0] < 60 and t[5, 5, 2] < 60 and t[40, 35, 2] < 60
+    imgs = Images.of([tagged, tagged])
+    assert [Images.get_image_size(i) for i in imgs] == [(40, 64)] * 2
+
+
 @pytest.mark.gpu
 def test_resize_generator_matches_oracle(oracle, gpu_ctx):
     frames = [synthetic.make_frame(i, 803, 601) for i in range(3)]
