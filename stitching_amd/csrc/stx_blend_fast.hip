@@ -72,32 +72,43 @@ STX_DEV pk16 pk_splat(unsigned short v) { pk16 r = {v, v}; return r; }
 // The six coarse samples c0..c5 = plane[cx - 1 .. cx + 4] of one row, as the pairs the 8-wide pyrUp patch needs, from ONE
 // dword-aligned 16-byte load of plane[cx - 2 .. cx + 5] (cx is a multiple of 4, so the window starts 4 bytes before an
 // 8-byte boundary).  pyrUp's border rule — column -1 -> 1, column cw -> cw - 1 — only changes c0 (to c2, when cx == 0)
-// and c5 (to c4, when cx + 4 == cw): two selects instead of two more loads with their own addresses.  The two shorts in
-// front of a plane's first row are read and never used: every plane this is called on has >= 4 readable bytes in front.
+// and c5 (to c4, when cx + 4 == cw).  Both are byte permutations of the window, so the rule lives in the SELECTOR of the
+// v_perm that builds the pair anyway (UpSel: two registers made once per image and lane) — no select, no second candidate:
+// 3 VALU per window (round 2: 7).  The two shorts in front of a plane's first row are read and never used: every plane this
+// is called on has >= 4 readable bytes in front.
 struct UpRow { uint32_t A0, B0, A1, B1, A2; };  // (c0,c1) (c1,c2) (c2,c3) (c3,c4) (c4,c5)
-STX_DEV UpRow up_row_window(const STX_GAS short* __restrict__ plane, uint32_t elem_off, bool left_edge, bool right_edge)
+struct UpSel { uint32_t a0, a2; };
+// window dwords (x,c0) (c1,c2) (c3,c4) (c5,x); v_perm(hi, lo, sel): selector bytes 0-3 pick from `lo`, 4-7 from `hi`
+STX_DEV UpSel up_sel(bool left_edge, bool right_edge)
 {
-    const v4u w = *reinterpret_cast<const STX_GAS v4u_a4*>(plane + elem_off - 2);  // (x,c0) (c1,c2) (c3,c4) (c5,x)
+    UpSel s;
+    s.a0 = left_edge ? 0x05040706u : 0x05040302u;   // perm(w.y, w.x): (c2,c1) at the left edge, else (c0,c1)
+    s.a2 = right_edge ? 0x03020302u : 0x05040302u;  // perm(w.w, w.z): (c4,c4) at the right edge, else (c4,c5)
+    return s;
+}
+// row: first sample of the plane's row (wave-uniform); boff: byte offset of sample cx in the row (2 cx)
+STX_DEV UpRow up_row_window(const STX_GAS short* __restrict__ row, uint32_t boff, UpSel sel)
+{
+    const STX_GAS char* q = reinterpret_cast<const STX_GAS char*>(row) + (size_t)boff;
+    const v4u w = *reinterpret_cast<const STX_GAS v4u_a4*>(q - 4);  // (x,c0) (c1,c2) (c3,c4) (c5,x)
     UpRow r;
     r.B0 = w.y;
     r.B1 = w.z;
     r.A1 = __builtin_amdgcn_alignbit(w.z, w.y, 16);
-    const uint32_t a0 = __builtin_amdgcn_alignbit(w.y, w.x, 16), a0e = __builtin_amdgcn_alignbit(w.y, w.y, 16);  // (c0,c1) / (c2,c1)
-    const uint32_t a2 = __builtin_amdgcn_alignbit(w.w, w.z, 16), a2e = __builtin_amdgcn_perm(w.z, w.z, 0x03020302u);  // (c4,c5) / (c4,c4)
-    r.A0 = left_edge ? a0e : a0;
-    r.A2 = right_edge ? a2e : a2;
+    r.A0 = __builtin_amdgcn_perm(w.y, w.x, sel.a0);
+    r.A2 = __builtin_amdgcn_perm(w.w, w.z, sel.a2);
     return r;
 }
 
-// pyrUp_<FixPtCast<short,6>> of one plane holding values 0..255 for the 8x2 patch with coarse origin (cx, cy)
-STX_DEV void up_patch_pk(const STX_GAS short* __restrict__ plane, uint32_t stride, int cw, int ch, int cx, int cy, pk16 up[2][4])
+// pyrUp_<FixPtCast<short,6>> of one plane holding values 0..255 for the 8x2 patch with coarse origin (cx, cy).
+// cy (and with it the three row pointers) is wave-uniform: a wavefront owns two panorama rows.
+STX_DEV void up_patch_pk(const STX_GAS short* __restrict__ plane, uint32_t stride, int ch, uint32_t boff, int cy, UpSel sel, pk16 up[2][4])
 {
     const int rr[3] = {up_idx(cy - 1, ch), cy, up_idx(cy + 1, ch)};
-    const bool le = cx == 0, re = cx + 4 >= cw;
     pk16 HE[3][2], HO[3][2];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        const UpRow t = up_row_window(plane, (uint32_t)rr[r] * stride + (uint32_t)cx, le, re);
+        const UpRow t = up_row_window(plane + (size_t)((uint32_t)rr[r] * stride), boff, sel);
         HE[r][0] = pk(t.A0) + pk(t.B0) * pk_splat(6) + pk(t.A1);            // c[j] + 6 c[j+1] + c[j+2], j = 0,1
         HE[r][1] = pk(t.A1) + pk(t.B1) * pk_splat(6) + pk(t.A2);            // j = 2,3
         HO[r][0] = pk(t.B0) + pk(t.A1);                                     // c[j+1] + c[j+2] (the factor 4 is folded below)
@@ -650,7 +661,9 @@ STX_DEV void mb_level_fast_body(const MbLevelK& P)
     int tile_tx, tile_ty;
     if (!xcd_tile(P.tiles, blockIdx.x, tile_tx, tile_ty)) return;
     const int tile_x = P.x0 + tile_tx * 512, tile_y = P.y0 + tile_ty * 8;
-    const int X0 = tile_x + (tid & 63) * 8, Y0 = tile_y + (tid >> 6) * 2;
+    // a wavefront owns two rows: its row index is wave-uniform, and saying so (readfirstlane) moves every row test, row
+    // offset and row pointer below to the scalar unit
+    const int X0 = tile_x + (tid & 63) * 8, Y0 = tile_y + __builtin_amdgcn_readfirstlane(tid >> 6) * 2;
     const bool active = X0 < P.x1 && Y0 < P.y1;
 
     int acc[2][8][3];
@@ -701,8 +714,8 @@ STX_DEV void mb_level_fast_body(const MbLevelK& P)
                 for (int c = 0; c < 3; c++) {
                     if (U8SRC && !contrib) {
                         pk16 upk[2][4];
-                        up_patch_pk(gp(im.g[lv + 1]) + c * im.g_plane[lv + 1], (uint32_t)im.g_stride[lv + 1], lw >> 1, lh >> 1,
-                                    lx0 >> 1, ly0 >> 1, upk);
+                        up_patch_pk(gp(im.g[lv + 1]) + c * im.g_plane[lv + 1], (uint32_t)im.g_stride[lv + 1], lh >> 1,
+                                    (uint32_t)(lx0 >> 1) * 2u, ly0 >> 1, up_sel(lx0 == 0, (lx0 >> 1) + 4 >= (lw >> 1)), upk);
 #pragma unroll
                         for (int r = 0; r < 2; r++) {
                             const v4u gv = *reinterpret_cast<const STX_GAS v4u*>(
@@ -807,8 +820,8 @@ STX_DEV void mb_level_fast_body(const MbLevelK& P)
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     pk16 upk[2][4];
-                    up_patch_pk(gp(im.g[1]) + c * im.g_plane[1], (uint32_t)im.g_stride[1], im.fw >> 1, im.fh >> 1, (X0 - im.fx) >> 1,
-                                (Y0 - im.fy) >> 1, upk);
+                    up_patch_pk(gp(im.g[1]) + c * im.g_plane[1], (uint32_t)im.g_stride[1], im.fh >> 1, (uint32_t)((X0 - im.fx) >> 1) * 2u,
+                                (Y0 - im.fy) >> 1, up_sel(X0 == im.fx, ((X0 - im.fx) >> 1) + 4 >= (im.fw >> 1)), upk);
 #pragma unroll
                     for (int r = 0; r < 2; r++) {
                         uint32_t px[4];
@@ -974,15 +987,14 @@ STX_DEV uint32_t unpks(pk16s v) { return __builtin_bit_cast(uint32_t, v); }
 STX_DEV pk16s pks_splat(short v) { pk16s r = {v, v}; return r; }
 
 // returns false (and leaves `up` untouched) when a tap is outside [-500, 500]
-STX_DEV bool up_patch_pks(const STX_GAS short* __restrict__ plane, uint32_t stride, int cw, int ch, int cx, int cy, pk16s up[2][4])
+STX_DEV bool up_patch_pks(const STX_GAS short* __restrict__ plane, uint32_t stride, int ch, uint32_t boff, int cy, UpSel sel, pk16s up[2][4])
 {
     const int rr[3] = {up_idx(cy - 1, ch), cy, up_idx(cy + 1, ch)};
-    const bool le = cx == 0, re = cx + 4 >= cw;
     pk16s HE[3][2], HO[3][2];
     pk16 worst = pk_splat(0);
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        const UpRow t = up_row_window(plane, (uint32_t)rr[r] * stride + (uint32_t)cx, le, re);
+        const UpRow t = up_row_window(plane + (size_t)((uint32_t)rr[r] * stride), boff, sel);
         worst = __builtin_elementwise_max(worst, pk(t.A0) + pk_splat(500));
         worst = __builtin_elementwise_max(worst, pk(t.A1) + pk_splat(500));
         worst = __builtin_elementwise_max(worst, pk(t.A2) + pk_splat(500));
@@ -1059,7 +1071,8 @@ STX_DEV void level0_epilogue_pk(const MbLevelK& P, int X0, int Y0, uint32_t (&ac
         for (int c = 0; c < 3; c++) {
             const short* plane = P.up + c * P.up_plane - ((long long)P.up_y0 * P.up_stride + P.up_x0);
             pk16s up[2][4];
-            if (!up_patch_pks(gp(plane), (uint32_t)P.up_stride, P.pw >> 1, P.ph >> 1, X0 >> 1, Y0 >> 1, up)) {
+            if (!up_patch_pks(gp(plane), (uint32_t)P.up_stride, P.ph >> 1, (uint32_t)(X0 >> 1) * 2u, Y0 >> 1,
+                              up_sel(X0 == 0, (X0 >> 1) + 4 >= (P.pw >> 1)), up)) {
                 int u32[2][8];
                 up_patch(plane, P.up_stride, P.pw >> 1, P.ph >> 1, X0 >> 1, Y0 >> 1, u32);
 #pragma unroll
@@ -1129,7 +1142,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVE
     int tile_tx, tile_ty;
     if (!xcd_tile(P.tiles, blockIdx.x, tile_tx, tile_ty)) return;
     const int tile_x = P.x0 + tile_tx * 512, tile_y = P.y0 + tile_ty * 8;
-    const int X0 = tile_x + (tid & 63) * 8, Y0 = tile_y + (tid >> 6) * 2;
+    const int X0 = tile_x + (tid & 63) * 8, Y0 = tile_y + __builtin_amdgcn_readfirstlane(tid >> 6) * 2;  // Y0: wave-uniform (scalar)
     const bool active = X0 < P.x1 && Y0 < P.y1;
 
     uint32_t acc[2][3][4];  // [row][channel][pair]: int16 sums, wrap-around like OpenCV's short +=
@@ -1233,6 +1246,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVE
                 }
             }
             // (no early-out on an all-zero mask: it would put the G_1 loads behind the mask loads' round trip)
+            const uint32_t g1_boff = (uint32_t)((X0 - im.fx) >> 1) * 2u;  // this lane's samples of G_1: byte offset in a row
+            const UpSel g1_sel = up_sel(X0 == im.fx, ((X0 - im.fx) >> 1) + 4 >= (im.fw >> 1));
             uint32_t M[2][4];
 #pragma unroll
             for (int r = 0; r < 2; r++) {
@@ -1249,8 +1264,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVE
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 pk16 up[2][4];
-                up_patch_pk(gp(im.g[1]) + c * im.g_plane[1], (uint32_t)im.g_stride[1], im.fw >> 1, im.fh >> 1, (X0 - im.fx) >> 1,
-                            (Y0 - im.fy) >> 1, up);
+                up_patch_pk(gp(im.g[1]) + c * im.g_plane[1], (uint32_t)im.g_stride[1], im.fh >> 1, g1_boff, (Y0 - im.fy) >> 1, g1_sel, up);
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
                     uint32_t px[4];
