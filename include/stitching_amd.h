@@ -41,6 +41,20 @@ extern "C" {
 #define STX_ERR_STATE (-4)       /* call order violated (e.g. feed after finish)      */
 #define STX_ERR_UNSUPPORTED (-5) /* valid in the reference, not implemented here      */
 
+/* trig modes.  stitching/warper.py:44-51 builds a cv.PyRotationWarper per call; its projectors evaluate sinf / cosf with the
+ * HOST's libm, so the warp coordinates of the reference depend on the machine it runs on.  The back end offers:
+ *   STX_TRIG_EXACT       correctly rounded sinf / cosf (default; equals any libm wherever that libm is correctly rounded);
+ *   STX_TRIG_GLIBC       sinf / cosf as glibc >= 2.28 computes them on an x86-64-v3 host (__sinf_fma / __cosf_fma): bit-identical to
+ *                        that libm on every float argument (tests/test_glibc_trig.py);
+ *   STX_TRIG_GLIBC_NOFMA the same routines without fused multiply-add (__sinf_sse2 / __cosf_sse2).
+ * The mode is process-wide, like the libm it stands for: STITCHING_AMD_TRIG = exact | glibc | glibc-nofma at first use, or
+ * stx_set_trig_mode.  atan2f / acosf / tanf / ... (forward maps: warp_roi) stay correctly rounded in every mode. */
+#define STX_TRIG_EXACT 0
+#define STX_TRIG_GLIBC 1
+#define STX_TRIG_GLIBC_NOFMA 2
+int stx_set_trig_mode(int mode);
+int stx_get_trig_mode(void);
+
 /* warper types: the names of Warper.WARP_TYPE_CHOICES (stitching/warper.py:10-27);
  * cv.PyRotationWarper(type, scale) string -> id in the Python shim */
 #define STX_WARP_PLANE 0

@@ -23,7 +23,7 @@ WARP_TYPES = {"plane": 0, "affine": 1, "cylindrical": 2, "spherical": 3, "fishey
               "compressedPlanePortraitA1.5B1": 9, "paniniA2B1": 10, "paniniA1.5B1": 11, "paniniPortraitA2B1": 12,
               "paniniPortraitA1.5B1": 13, "mercator": 14, "transverseMercator": 15}
 BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REFLECT, BORDER_REFLECT_101 = 0, 1, 2, 4
-TRIG_LIBM, TRIG_EXACT = 0, 1
+TRIG_LIBM, TRIG_EXACT, TRIG_GLIBC, TRIG_GLIBC_NOFMA = 0, 1, 2, 3  # glibc: sinf / cosf of glibc >= 2.28, restated (FMA / SSE2 build)
 
 
 def build(force=False):
@@ -79,6 +79,10 @@ def lib():
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_set_num_threads.restype = None
         L.orc_set_model.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.orc_trig_eval.argtypes = [C.c_int, C.c_int, fp, fp, C.c_longlong]
+        L.orc_trig_eval.restype = None
+        L.orc_trig_compare_range.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.c_int]
+        L.orc_trig_compare_range.restype = C.c_longlong
         _lib = L
     return _lib
 
@@ -92,6 +96,22 @@ def _f32(a):
     if a.shape != (3, 3):
         raise ValueError("K and R must be 3x3")
     return a
+
+
+def trig_eval(mode, x, want_cos=False):
+    """sinf / cosf of an fp32 array under a trig mode (TRIG_LIBM: the host's libm, TRIG_EXACT, TRIG_GLIBC, TRIG_GLIBC_NOFMA)"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    lib().orc_trig_eval(int(mode), int(bool(want_cos)), _p(x, C.c_float), _p(out, C.c_float), x.size)
+    return out
+
+
+def trig_compare_range(mode_a, mode_b, lo_bits, hi_bits, which=3, max_examples=8):
+    """Number of float bit patterns in [lo_bits, hi_bits) where the two modes disagree for sinf (which & 1) / cosf (which & 2),
+    and the first few of them."""
+    ex = (C.c_uint32 * max_examples)()
+    n = lib().orc_trig_compare_range(int(mode_a), int(mode_b), int(lo_bits), int(hi_bits), int(which), ex, max_examples)
+    return int(n), [int(e) for e in ex[:min(n, max_examples)]]
 
 
 def set_num_threads(n):

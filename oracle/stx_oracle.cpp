@@ -287,10 +287,118 @@ double cosh_d(double x)
     return 0.5 * (e + 1.0 / e);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// trig = 2 / 3 ("glibc" / "glibc-nofma"): glibc >= 2.28 sinf / cosf, restated.  [from memory of glibc's
+// sysdeps/ieee754/flt-32/{s_sinf.c, s_cosf.c, sincosf.h, sincosf_data.c} — Szabolcs Nagy's routines from ARM's optimized-routines;
+// pinned HERE against the host's own libm over >= 10^8 arguments: tests/test_glibc_trig.py, tools/check_glibc_trig.py]
+//   double x = y;  |y| < pi/4: the polynomial directly (|y| < 2^-12: sin = y, cos = 1);
+//   |y| < 120: reduce_fast — r = x * (2/pi * 2^24), n = ((int32)r + 0x800000) >> 24 (the x86-64 build has no TOINT_INTRINSICS),
+//              x -= n * pi/2 (one double: exact enough up to 120), sign table, 2nd coefficient set (negated cosine) for n & 2;
+//   else     : reduce_large — 32 x 96 -> 128-bit fixed-point product with 4/pi to 192 bits.
+// The polynomial is sinf_poly (sine: x + x^3 s1 + x^7 (s2 + x^2 s3); cosine: (c0 + x^2 c1) + x^4 c2 + x^6 (c3 + x^2 c4)), evaluated in
+// double and rounded once to float.  x86-64 glibc ships two builds behind an ifunc: __sinf_sse2 (every operation rounded:
+// mode 3) and __sinf_fma (compiled -mfma with GCC's default -ffp-contract=fast: every a * b whose only uses are additions /
+// subtractions fuses — mode 2, what any x86-64-v3 host runs).  The two differ on about one argument in 10^8.
+// ------------------------------------------------------------------------------------------
+struct SincosTab { double sign[4]; double hpi_inv, hpi, c0, c1, c2, c3, c4, s1, s2, s3; };
+const SincosTab g_sincosf_table[2] = {
+    {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, 0x1p0, -0x1.ffffffd0c621cp-2, 0x1.55553e1068f19p-5,
+     -0x1.6c087e89a359dp-10, 0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13},
+    {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, -0x1p0, 0x1.ffffffd0c621cp-2, -0x1.55553e1068f19p-5,
+     0x1.6c087e89a359dp-10, -0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13}};
+const uint32_t g_inv_pio4[24] = {0xa2,       0xa2f9,     0xa2f983,   0xa2f9836e, 0xf9836e4e, 0x836e4e44, 0x6e4e4415, 0x4e441529,
+                                 0x441529fc, 0x1529fc27, 0x29fc2757, 0xfc2757d1, 0x2757d1f5, 0x57d1f534, 0xd1f534dd, 0xf534ddc0,
+                                 0x34ddc0db, 0xddc0db62, 0xc0db6295, 0xdb629599, 0x6295993c, 0x95993c43, 0x993c4390, 0x3c439041};
+inline uint32_t f2u(float v) { uint32_t u; std::memcpy(&u, &v, 4); return u; }
+inline uint32_t abstop12(float x) { return (f2u(x) >> 20) & 0x7ff; }
+// a * b + c as the build in question evaluates it
+inline double gl_mad(double a, double b, double c, bool fma) { return fma ? __builtin_fma(a, b, c) : a * b + c; }
+
+inline float gl_sinf_poly(double x, double x2, const SincosTab& p, int n, bool fma)
+{
+    if ((n & 1) == 0) {
+        const double x3 = x * x2;
+        const double s1 = gl_mad(x2, p.s3, p.s2, fma);
+        const double x7 = x3 * x2;
+        const double s = gl_mad(x3, p.s1, x, fma);
+        return (float)gl_mad(x7, s1, s, fma);
+    }
+    const double x4 = x2 * x2;
+    const double c2 = gl_mad(x2, p.c4, p.c3, fma);
+    const double c1 = gl_mad(x2, p.c1, p.c0, fma);
+    const double x6 = x4 * x2;
+    const double c = gl_mad(x4, p.c2, c1, fma);
+    return (float)gl_mad(x6, c2, c, fma);
+}
+inline double gl_reduce_fast(double x, const SincosTab& p, int* np, bool fma)
+{
+    const double r = x * p.hpi_inv;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    *np = n;
+    return gl_mad(-(double)n, p.hpi, x, fma);  // x - n * hpi
+}
+inline double gl_reduce_large(uint32_t xi, int* np)
+{
+    const uint32_t* arr = &g_inv_pio4[(xi >> 26) & 15];
+    const int shift = (xi >> 23) & 7;
+    uint64_t n, res0, res1, res2;
+    xi = (xi & 0xffffff) | 0x800000;
+    xi <<= shift;
+    res0 = xi * arr[0];  // 32-bit product, as in the source
+    res1 = (uint64_t)xi * arr[4];
+    res2 = (uint64_t)xi * arr[8];
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    n = (res0 + (1ULL << 61)) >> 62;
+    res0 -= n << 62;
+    const double x = (double)(int64_t)res0;
+    *np = (int)n;
+    return x * 0x1.921FB54442D18p-62;  // pi63
+}
+float glibc_sincosf1(float y, bool want_cos, bool fma)
+{
+    double x = y, s;
+    int n;
+    const SincosTab* p = &g_sincosf_table[0];
+    const int flip = want_cos ? 1 : 0;
+    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+        if (abstop12(y) < abstop12(0x1p-12f)) return want_cos ? 1.0f : y;
+        return gl_sinf_poly(x, x * x, *p, flip, fma);
+    }
+    if (abstop12(y) < abstop12(120.0f)) {
+        x = gl_reduce_fast(x, *p, &n, fma);
+        s = p->sign[n & 3];
+        if (n & 2) p = &g_sincosf_table[1];
+        return gl_sinf_poly(x * s, x * x, *p, n ^ flip, fma);
+    }
+    if (abstop12(y) < abstop12(std::numeric_limits<float>::infinity())) {
+        const uint32_t xi = f2u(y);
+        const int sign = (int)(xi >> 31);
+        x = gl_reduce_large(xi, &n);
+        s = p->sign[(n + sign) & 3];
+        if ((n + sign) & 2) p = &g_sincosf_table[1];
+        return gl_sinf_poly(x * s, x * x, *p, n ^ flip, fma);
+    }
+    return std::numeric_limits<float>::quiet_NaN();  // __math_invalidf
+}
+
+// mode 0: the host's libm for everything; 1: the correctly rounded fp64 routines above; 2 / 3: sinf / cosf as glibc >= 2.28
+// computes them (FMA build / SSE2 build), everything else as mode 1
 struct Trig {
     int mode;
-    float sin_(float x) const { if (!mode) return sinf(x); double s, c; sincos_d((double)x, &s, &c); return (float)s; }
-    float cos_(float x) const { if (!mode) return cosf(x); double s, c; sincos_d((double)x, &s, &c); return (float)c; }
+    float sin_(float x) const
+    {
+        if (!mode) return sinf(x);
+        if (mode >= 2) return glibc_sincosf1(x, false, mode == 2);
+        double s, c; sincos_d((double)x, &s, &c); return (float)s;
+    }
+    float cos_(float x) const
+    {
+        if (!mode) return cosf(x);
+        if (mode >= 2) return glibc_sincosf1(x, true, mode == 2);
+        double s, c; sincos_d((double)x, &s, &c); return (float)c;
+    }
     float atan2_(float y, float x) const { return mode ? (float)atan2_d((double)y, (double)x) : atan2f(y, x); }
     float acos_(float w) const { return mode ? (float)acos_d((double)w) : acosf(w); }
     float tan_(float x) const { return mode ? (float)tan_d((double)x) : tanf(x); }
@@ -1396,6 +1504,46 @@ ORC_API int orc_blender_feed(void* h, const int16_t* img, const uint8_t* mask, i
 }
 ORC_API int orc_blender_blend(void* h, int16_t* out, uint8_t* out_mask) { ((Blender*)h)->blend(out, out_mask); return 0; }
 ORC_API void orc_blender_destroy(void* h) { delete (Blender*)h; }
+
+// sinf / cosf of n arguments under a trig mode (0: host libm, 1: exact, 2: glibc FMA build, 3: glibc SSE2 build) — for the
+// tests that pin the glibc restatement against the host's libm
+ORC_API void orc_trig_eval(int mode, int want_cos, const float* x, float* out, long long n)
+{
+    Trig t{mode};
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (long long i = 0; i < n; i++) out[i] = want_cos ? t.cos_(x[i]) : t.sin_(x[i]);
+}
+// number of arguments in the bit-pattern range [lo, hi) (as float patterns, sign bit included by the caller's choice) where
+// mode_a and mode_b disagree for sinf (bit 0 of `which`) / cosf (bit 1); the first few are written to `examples`
+ORC_API long long orc_trig_compare_range(int mode_a, int mode_b, uint32_t lo, uint32_t hi, int which, uint32_t* examples, int max_examples)
+{
+    Trig a{mode_a}, b{mode_b};
+    long long bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad) num_threads(g_threads)
+    for (long long u = (long long)lo; u < (long long)hi; u++) {
+        float x;
+        const uint32_t bits = (uint32_t)u;
+        std::memcpy(&x, &bits, 4);
+        bool d = false;
+        if (which & 1) { const float p = a.sin_(x), q = b.sin_(x); d = d || (f2u(p) != f2u(q) && !(p != p && q != q)); }
+        if (which & 2) { const float p = a.cos_(x), q = b.cos_(x); d = d || (f2u(p) != f2u(q) && !(p != p && q != q)); }
+        if (d) bad++;
+    }
+    // examples: a serial second pass over the (rare) disagreements keeps the parallel loop simple
+    if (examples && max_examples > 0 && bad > 0) {
+        int k = 0;
+        for (long long u = (long long)lo; u < (long long)hi && k < max_examples; u++) {
+            float x;
+            const uint32_t bits = (uint32_t)u;
+            std::memcpy(&x, &bits, 4);
+            bool d = false;
+            if (which & 1) { const float p = a.sin_(x), q = b.sin_(x); d = d || (f2u(p) != f2u(q) && !(p != p && q != q)); }
+            if (which & 2) { const float p = a.cos_(x), q = b.cos_(x); d = d || (f2u(p) != f2u(q) && !(p != p && q != q)); }
+            if (d) examples[k++] = bits;
+        }
+    }
+    return bad;
+}
 
 // exposed for tests of the "exact" trig routines
 ORC_API void orc_sincos_d(double x, double* s, double* c) { sincos_d(x, s, c); }

@@ -14,3 +14,27 @@ def set_device_resident(on=True):
 
 def device_resident():
     return _device_resident
+
+
+def set_trig_mode(mode):
+    """Which sinf / cosf the projectors follow (include/stitching_amd.h STX_TRIG_*): "exact" (correctly rounded, default),
+    "glibc" (glibc >= 2.28 on an x86-64-v3 host, bit for bit: what cv.PyRotationWarper gets from libm there,
+    stitching/warper.py:44-51) or "glibc-nofma".  Process-wide, like the libm it stands for; STITCHING_AMD_TRIG sets the start-up
+    value.  Returns the previous mode."""
+    from . import _lib
+
+    L = _lib.lib()
+    names = {v: k for k, v in _lib.TRIG_MODES.items()}
+    prev = names[L.stx_get_trig_mode()]
+    if mode not in _lib.TRIG_MODES:
+        from .stitching_error import StitchingError
+
+        raise StitchingError(f"unknown trig mode {mode!r}: one of {sorted(_lib.TRIG_MODES)}")
+    _lib.check(L.stx_set_trig_mode(_lib.TRIG_MODES[mode]))
+    return prev
+
+
+def trig_mode():
+    from . import _lib
+
+    return {v: k for k, v in _lib.TRIG_MODES.items()}[_lib.lib().stx_get_trig_mode()]

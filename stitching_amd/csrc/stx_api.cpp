@@ -791,6 +791,35 @@ static void mul3x3_f32(const float* a, const float* b, float* d)
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// trig mode: which sinf / cosf the projectors follow (stx_device_math.h).  Process-wide like the libm it stands for; initialised
+// from STITCHING_AMD_TRIG = exact | glibc | glibc-nofma on first use.
+// ---------------------------------------------------------------------------------------------
+static std::atomic<int> g_trig_mode{-1};
+
+static int trig_mode_now()
+{
+    int m = g_trig_mode.load();
+    if (m >= 0) return m;
+    const char* e = getenv("STITCHING_AMD_TRIG");
+    m = STX_TRIG_EXACT;
+    if (e && !strcmp(e, "glibc")) m = STX_TRIG_GLIBC;
+    else if (e && !strcmp(e, "glibc-nofma")) m = STX_TRIG_GLIBC_NOFMA;
+    else if (e && *e && strcmp(e, "exact")) fprintf(stderr, "[stitching_amd] STITCHING_AMD_TRIG=%s is not one of exact, glibc, glibc-nofma: using exact\n", e);
+    int expected = -1;
+    g_trig_mode.compare_exchange_strong(expected, m);
+    return g_trig_mode.load();
+}
+
+STX_EXPORT int stx_get_trig_mode(void) { return trig_mode_now(); }
+
+STX_EXPORT int stx_set_trig_mode(int mode)
+{
+    if (mode < STX_TRIG_EXACT || mode > STX_TRIG_GLIBC_NOFMA) return stx_fail(STX_ERR_INVALID, "trig mode %d", mode);
+    g_trig_mode.store(mode);  // (ROI cache entries carry their mode in the key)
+    return STX_OK;
+}
+
 int stx_make_projector(int type, float scale, const float* K, const float* R, StxProjector* p)
 {
     if (type < STX_WARP_PLANE || type >= STX_WARP_TYPE_COUNT)
@@ -800,6 +829,7 @@ int stx_make_projector(int type, float scale, const float* K, const float* R, St
         if (!std::isfinite(K[i]) || !std::isfinite(R[i])) return stx_fail(STX_ERR_INVALID, "K/R contain non-finite values");
     p->type = type;
     p->scale = scale;
+    p->trig = trig_mode_now();
     // PyRotationWarper's constructor: "compressedPlaneA2B1" -> CompressedRectilinearWarper(2.0f, 1.0f), "...A1.5B1" -> (1.5f, 1.0f), ...
     static const struct { int family; float a; } kTypes[STX_WARP_TYPE_COUNT] = {
         {STX_F_PLANE, 1.f}, {STX_F_PLANE, 1.f}, {STX_F_CYLINDRICAL, 1.f}, {STX_F_SPHERICAL, 1.f}, {STX_F_FISHEYE, 1.f},
@@ -946,7 +976,7 @@ static int rois_impl(stx_ctx* ctx, int n, const StxProjector* projs, const int* 
 // ROI cache: the reference recomputes detectResultRoi inside every warp()/warpRoi() call
 // (stitching/warper.py:44,59,80 build three warpers per image); we compute it once per camera.
 struct RoiKey {
-    int type, w, h;
+    int type, w, h, trig;
     float scale, K[9], R[9];
     bool operator<(const RoiKey& o) const { return memcmp(this, &o, sizeof(RoiKey)) < 0; }
 };
@@ -957,6 +987,7 @@ static RoiKey make_key(int type, float scale, const float* K, const float* R, in
     RoiKey k;
     memset(&k, 0, sizeof(k));
     k.type = type; k.w = w; k.h = h; k.scale = scale;
+    k.trig = trig_mode_now();  // the forward maps of the per-pixel projector families call sinf / cosf
     memcpy(k.K, K, 36);
     memcpy(k.R, R, 36);
     return k;

@@ -102,13 +102,29 @@ STX_DEV UpRow up_row_window(const STX_GAS short* __restrict__ row, uint32_t boff
 
 // pyrUp_<FixPtCast<short,6>> of one plane holding values 0..255 for the 8x2 patch with coarse origin (cx, cy).
 // cy (and with it the three row pointers) is wave-uniform: a wavefront owns two panorama rows.
+// pyrUp_'s row rule (up_idx: -1 -> 1, or 0 when there is one row; n -> n - 1) for i >= -1, as scalar-unit arithmetic
+STX_DEV int up_idx_s(int i, int n) { return min(abs(i), n - 1); }
+// first sample of row `r` of a plane, held in SGPRs: the loads below then take the scalar base + 32-bit lane offset form
+// (the empty asm keeps the compiler from folding the lane offset into a 64-bit vector address first)
+STX_DEV const STX_GAS short* row_ptr_s(const STX_GAS short* plane, int r, uint32_t stride)
+{
+    // (readfirstlane of a value the compiler already knows to be uniform folds away; where it does not know — argument blocks
+    // read through a pointer — it is what makes the value scalar)
+    const unsigned long long a = (unsigned long long)(plane + (size_t)((uint32_t)r * stride));
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    const STX_GAS short* row = (const STX_GAS short*)(((unsigned long long)hi << 32) | lo);
+    asm("" : "+s"(row));  // not volatile: a side-effecting asm counts as a memory clobber and turns every scalar descriptor load after it into a vector load
+    return row;
+}
+
 STX_DEV void up_patch_pk(const STX_GAS short* __restrict__ plane, uint32_t stride, int ch, uint32_t boff, int cy, UpSel sel, pk16 up[2][4])
 {
-    const int rr[3] = {up_idx(cy - 1, ch), cy, up_idx(cy + 1, ch)};
+    const int rr[3] = {up_idx_s(cy - 1, ch), cy, up_idx_s(cy + 1, ch)};
     pk16 HE[3][2], HO[3][2];
+    asm("" : "+v"(boff));  // the zero-extension of the lane offset stays in this block: scalar base + 32-bit lane offset loads
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        const UpRow t = up_row_window(plane + (size_t)((uint32_t)rr[r] * stride), boff, sel);
+        const UpRow t = up_row_window(row_ptr_s(plane, rr[r], stride), boff, sel);
         HE[r][0] = pk(t.A0) + pk(t.B0) * pk_splat(6) + pk(t.A1);            // c[j] + 6 c[j+1] + c[j+2], j = 0,1
         HE[r][1] = pk(t.A1) + pk(t.B1) * pk_splat(6) + pk(t.A2);            // j = 2,3
         HO[r][0] = pk(t.B0) + pk(t.A1);                                     // c[j+1] + c[j+2] (the factor 4 is folded below)
@@ -989,12 +1005,13 @@ STX_DEV pk16s pks_splat(short v) { pk16s r = {v, v}; return r; }
 // returns false (and leaves `up` untouched) when a tap is outside [-500, 500]
 STX_DEV bool up_patch_pks(const STX_GAS short* __restrict__ plane, uint32_t stride, int ch, uint32_t boff, int cy, UpSel sel, pk16s up[2][4])
 {
-    const int rr[3] = {up_idx(cy - 1, ch), cy, up_idx(cy + 1, ch)};
+    const int rr[3] = {up_idx_s(cy - 1, ch), cy, up_idx_s(cy + 1, ch)};
     pk16s HE[3][2], HO[3][2];
     pk16 worst = pk_splat(0);
+    asm("" : "+v"(boff));  // as in up_patch_pk
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        const UpRow t = up_row_window(plane + (size_t)((uint32_t)rr[r] * stride), boff, sel);
+        const UpRow t = up_row_window(row_ptr_s(plane, rr[r], stride), boff, sel);
         worst = __builtin_elementwise_max(worst, pk(t.A0) + pk_splat(500));
         worst = __builtin_elementwise_max(worst, pk(t.A1) + pk_splat(500));
         worst = __builtin_elementwise_max(worst, pk(t.A2) + pk_splat(500));
@@ -1032,6 +1049,11 @@ STX_DEV uint32_t bgr_dword(const uint32_t (&U)[3][4])
 
 STX_DEV void level0_epilogue_pk(const MbLevelK& P, int X0, int Y0, uint32_t (&acc)[2][3][4], uint32_t (&cnt)[2][4])
 {
+    // The constants (1, 1) and (-1, -1) as values the compiler cannot see through: against literal constants LLVM rewrites
+    // min(max(a, -1), 1) and min(count, 1) into per-half compares and selects — 8 and 5 VALU per register instead of 3 and 2
+    // (measured in the ISA: 193 -> 72 VALU for the normalisation of a lane).
+    uint32_t k_p1 = 0x00010001u, k_m1 = 0xffffffffu;
+    asm("" : "+s"(k_p1), "+s"(k_m1));
     // ---- normalizeUsingWeightMap
     uint32_t v[2][3][4];
     const uint32_t anyc = (cnt[0][0] | cnt[0][1] | cnt[0][2] | cnt[0][3]) | (cnt[1][0] | cnt[1][1] | cnt[1][2] | cnt[1][3]);
@@ -1043,8 +1065,7 @@ STX_DEV void level0_epilogue_pk(const MbLevelK& P, int X0, int Y0, uint32_t (&ac
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const pk16s a = pks(acc[r][c][q]);
-                    const pk16s sg = __builtin_elementwise_min(__builtin_elementwise_max(a, pks_splat(-1)), pks_splat(1));
-                    v[r][c][q] = unpks(a - sg);
+                    v[r][c][q] = unpks(a - __builtin_elementwise_min(__builtin_elementwise_max(a, pks(k_m1)), pks(k_p1)));  // a - sign(a)
                 }
     } else {
 #pragma unroll
@@ -1097,7 +1118,7 @@ STX_DEV void level0_epilogue_pk(const MbLevelK& P, int X0, int Y0, uint32_t (&ac
         const int oy = y - P.pano_y0, ox = X0 - P.pano_x0;
         uint32_t keep[4], U[3][4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) keep[q] = unpk(pk_splat(0) - __builtin_elementwise_min(pk(cnt[r][q]), pk_splat(1)));
+        for (int q = 0; q < 4; q++) keep[q] = unpk(pk_splat(0) - __builtin_elementwise_min(pk(cnt[r][q]), pk(k_p1)));  // 0xffff where covered
 #pragma unroll
         for (int c = 0; c < 3; c++)
 #pragma unroll
@@ -1300,6 +1321,219 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVE
     level0_epilogue_pk(P, X0, Y0, acc, cnt);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Levels 1 .. B-3 of u8-sourced images (every fed image is u8x3, no received contribution strips): the reference's own
+// operating point (stitching/blender.py:41 widens u8 warps).  G_lv is 0..255, so pyrUp and the Laplacian run in packed 16-bit
+// lanes (as mb_level_fast_body<.., U8SRC>), and on top of that:
+//   * the sums are kept as wrapping int16 pairs (OpenCV's `short +=`; only the low 16 bits of a sum are ever used);
+//   * a weight pyramid is exactly 1.f in the interior of its mask (the taps sum to 256 / 256) and exactly 0.f outside its
+//     reach.  Where all 16 weights of an image under a lane's 8 x 2 patch are 1.f for every lane of the wavefront
+//     (min over the bit patterns: weights are in [0, 1]), (short)(L * 1.f) is L and the products / truncations / conversions
+//     (5 VALU per sample and channel) become one packed add per pixel pair;
+//   * a lane whose weight sums are all 0.f or 1.f — at most one all-ones image, every other image all zeros there —
+//     normalises with a - sign(a) (three packed ops per pair, see level0_epilogue_pk) instead of 48 divisions;
+//   * the collapse runs in signed 16-bit lanes when all taps are within +-500 (up_patch_pks), else the 32-bit patch.
+// Same integers and the same fp32 operations in the same order as mb_level_fast_body; 104 -> ? us for levels 1 + 2 of config 2.
+// ---------------------------------------------------------------------------------------------
+STX_DEV uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) { return min(min(a, b), c); }
+STX_DEV uint32_t max3u(uint32_t a, uint32_t b, uint32_t c) { return max(max(a, b), c); }
+
+__global__ __launch_bounds__(256) void mb_level_pk_kernel(MbLevelK P)
+{
+    const int tid = threadIdx.x;
+    const int lv = P.level;
+    int tile_tx, tile_ty;
+    if (!xcd_tile(P.tiles, blockIdx.x, tile_tx, tile_ty)) return;
+    const int tile_x = P.x0 + tile_tx * 512, tile_y = P.y0 + tile_ty * 8;
+    const int X0 = tile_x + (tid & 63) * 8, Y0 = tile_y + __builtin_amdgcn_readfirstlane(tid >> 6) * 2;  // Y0: wave-uniform
+    const bool active = X0 < P.x1 && Y0 < P.y1;
+
+    uint32_t acc[2][3][4];  // [row][channel][pair]: wrapping int16 sums, pair order (0,2)(4,6)(1,3)(5,7)
+    float ws[2][8];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[r][0][q] = acc[r][1][q] = acc[r][2][q] = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) ws[r][j] = 0.f;
+    }
+    uint32_t ones = 0;     // images whose 16 weights here are all 1.f
+    uint32_t mixed = 0;    // != 0: some image had a weight here that is neither covered by `ones` nor 0.f
+
+    for (int base = 0; base < P.n_images; base += 64) {
+        bool hit = false;
+        {
+            const int kk = base + (tid & 63);
+            if (kk < P.n_images) {
+                const StxMbImage& im = P.images[kk];
+                const int rx = im.fx >> lv, ry = im.fy >> lv, rw = im.fw >> lv, rh = im.fh >> lv;
+                hit = rx < tile_x + 512 && rx + rw > tile_x && ry < Y0 + 2 && ry + rh > Y0;
+                if (hit) hit = occ_hit<false>(im, lv, tile_x, Y0);
+            }
+        }
+        unsigned long long todo = __ballot(hit);
+        while (todo) {
+            const int k = base + (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const StxMbImage& im = P.images[k];
+            if (!active) continue;
+            const int lx0 = X0 - (im.fx >> lv), ly0 = Y0 - (im.fy >> lv);
+            const int lw = im.fw >> lv, lh = im.fh >> lv;
+            if ((unsigned)lx0 >= (unsigned)lw || (unsigned)ly0 >= (unsigned)lh) continue;
+            // the 16 weights (bit patterns; all in [0, 1], so unsigned order = float order)
+            uint32_t wb[2][8];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const STX_GAS float* q = gp(im.wt[lv]) + ((uint32_t)(ly0 + r) * (uint32_t)im.wt_stride[lv] + (uint32_t)lx0);
+                const v4u a = *reinterpret_cast<const STX_GAS v4u*>(q), b = *reinterpret_cast<const STX_GAS v4u*>(q + 4);
+                wb[r][0] = a.x; wb[r][1] = a.y; wb[r][2] = a.z; wb[r][3] = a.w;
+                wb[r][4] = b.x; wb[r][5] = b.y; wb[r][6] = b.z; wb[r][7] = b.w;
+            }
+            uint32_t lo = min3u(wb[0][0], wb[0][1], wb[0][2]);
+            lo = min3u(lo, wb[0][3], wb[0][4]); lo = min3u(lo, wb[0][5], wb[0][6]); lo = min3u(lo, wb[0][7], wb[1][0]);
+            lo = min3u(lo, wb[1][1], wb[1][2]); lo = min3u(lo, wb[1][3], wb[1][4]); lo = min3u(lo, wb[1][5], wb[1][6]);
+            lo = min(lo, wb[1][7]);
+            const bool all1 = lo == 0x3f800000u;
+            const bool wave_all1 = __ballot(!all1) == 0ull;  // over the lanes that reached this point
+            const uint32_t g1_boff = (uint32_t)(lx0 >> 1) * 2u;
+            const UpSel g1_sel = up_sel(lx0 == 0, (lx0 >> 1) + 4 >= (lw >> 1));
+            if (wave_all1) {
+                ones += 1u;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    pk16 upk[2][4];
+                    up_patch_pk(gp(im.g[lv + 1]) + c * im.g_plane[lv + 1], (uint32_t)im.g_stride[lv + 1], lh >> 1, g1_boff, ly0 >> 1, g1_sel, upk);
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        const v4u gv = *reinterpret_cast<const STX_GAS v4u*>(reinterpret_cast<const STX_GAS char*>(
+                            row_ptr_s(gp(im.g[lv]) + c * im.g_plane[lv], ly0 + r, (uint32_t)im.g_stride[lv])) + (size_t)((uint32_t)lx0 * 2u));
+                        // natural pairs (0,1)(2,3)(4,5)(6,7) -> the pyrUp pair order (0,2)(4,6)(1,3)(5,7); L in [-255, 255]
+                        acc[r][c][0] = unpk(pk(acc[r][c][0]) + (pk(__builtin_amdgcn_perm(gv.y, gv.x, 0x05040100u)) - upk[r][0]));
+                        acc[r][c][1] = unpk(pk(acc[r][c][1]) + (pk(__builtin_amdgcn_perm(gv.w, gv.z, 0x05040100u)) - upk[r][1]));
+                        acc[r][c][2] = unpk(pk(acc[r][c][2]) + (pk(__builtin_amdgcn_perm(gv.y, gv.x, 0x07060302u)) - upk[r][2]));
+                        acc[r][c][3] = unpk(pk(acc[r][c][3]) + (pk(__builtin_amdgcn_perm(gv.w, gv.z, 0x07060302u)) - upk[r][3]));
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) ws[r][j] = fadd(ws[r][j], 1.0f);
+                continue;
+            }
+            {   // book-keeping for the epilogue's short cut
+                uint32_t hi = max3u(wb[0][0], wb[0][1], wb[0][2]);
+                hi = max3u(hi, wb[0][3], wb[0][4]); hi = max3u(hi, wb[0][5], wb[0][6]); hi = max3u(hi, wb[0][7], wb[1][0]);
+                hi = max3u(hi, wb[1][1], wb[1][2]); hi = max3u(hi, wb[1][3], wb[1][4]); hi = max3u(hi, wb[1][5], wb[1][6]);
+                hi = max(hi, wb[1][7]);
+                if (all1) ones += 1u;
+                else mixed |= hi;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                pk16 upk[2][4];
+                up_patch_pk(gp(im.g[lv + 1]) + c * im.g_plane[lv + 1], (uint32_t)im.g_stride[lv + 1], lh >> 1, g1_boff, ly0 >> 1, g1_sel, upk);
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const v4u gv = *reinterpret_cast<const STX_GAS v4u*>(reinterpret_cast<const STX_GAS char*>(
+                        row_ptr_s(gp(im.g[lv]) + c * im.g_plane[lv], ly0 + r, (uint32_t)im.g_stride[lv])) + (size_t)((uint32_t)lx0 * 2u));
+                    const uint32_t Lq[4] = {
+                        unpk(pk(__builtin_amdgcn_perm(gv.y, gv.x, 0x05040100u)) - upk[r][0]),
+                        unpk(pk(__builtin_amdgcn_perm(gv.w, gv.z, 0x05040100u)) - upk[r][1]),
+                        unpk(pk(__builtin_amdgcn_perm(gv.y, gv.x, 0x07060302u)) - upk[r][2]),
+                        unpk(pk(__builtin_amdgcn_perm(gv.w, gv.z, 0x07060302u)) - upk[r][3])};
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        // pair q holds the pixels (jl, jh): q = 0: (0, 2), 1: (4, 6), 2: (1, 3), 3: (5, 7)
+                        const int jl = (q & 1) * 4 + (q >> 1), jh = jl + 2;
+                        const int tl = trunc_small(fmul((float)s16lo(Lq[q]), __uint_as_float(wb[r][jl])));
+                        const int th = trunc_small(fmul((float)s16hi(Lq[q]), __uint_as_float(wb[r][jh])));
+                        acc[r][c][q] = unpk(pk(acc[r][c][q]) + pk(pack16(tl, th)));
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) ws[r][j] = fadd(ws[r][j], __uint_as_float(wb[r][j]));
+        }
+    }
+    if (!active) return;
+
+    // ---- normalizeUsingWeightMap
+    uint32_t k_p1 = 0x00010001u, k_m1 = 0xffffffffu;  // opaque constants: see level0_epilogue_pk
+    asm("" : "+s"(k_p1), "+s"(k_m1));
+    uint32_t v[2][3][4];
+    if (mixed == 0u && ones <= 1u) {  // every weight sum of the lane is 0.f or 1.f: (short)(a / (w + 1e-5f)) = a - sign(a) (0 stays 0)
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const pk16s a = pks(acc[r][c][q]);
+                    v[r][c][q] = unpks(a - __builtin_elementwise_min(__builtin_elementwise_max(a, pks(k_m1)), pks(k_p1)));
+                }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int jl = (q & 1) * 4 + (q >> 1), jh = jl + 2;
+                int o[2][3];
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) {
+                    const float den = fadd(ws[r][hf ? jh : jl], WEIGHT_EPS);
+                    float q0, q1, q2;
+                    div3_shared(den, (float)(hf ? s16hi(acc[r][0][q]) : s16lo(acc[r][0][q])),
+                                (float)(hf ? s16hi(acc[r][1][q]) : s16lo(acc[r][1][q])),
+                                (float)(hf ? s16hi(acc[r][2][q]) : s16lo(acc[r][2][q])), q0, q1, q2);
+                    o[hf][0] = trunc_small(q0); o[hf][1] = trunc_small(q1); o[hf][2] = trunc_small(q2);
+                }
+#pragma unroll
+                for (int c = 0; c < 3; c++) v[r][c][q] = pack16(o[0][c], o[1][c]);
+            }
+    }
+    // ---- + pyrUp(finished coarser level), saturating
+    if (P.up) {
+        const UpSel usel = up_sel(X0 == 0, (X0 >> 1) + 4 >= (P.pw >> 1));
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const short* plane = P.up + c * P.up_plane - ((long long)P.up_y0 * P.up_stride + P.up_x0);
+            pk16s up[2][4];
+            if (!up_patch_pks(gp(plane), (uint32_t)P.up_stride, P.ph >> 1, (uint32_t)(X0 >> 1) * 2u, Y0 >> 1, usel, up)) {
+                int u32[2][8];
+                up_patch(plane, P.up_stride, P.pw >> 1, P.ph >> 1, X0 >> 1, Y0 >> 1, u32);
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    up[r][0] = pks(pack16(u32[r][0], u32[r][2]));
+                    up[r][1] = pks(pack16(u32[r][4], u32[r][6]));
+                    up[r][2] = pks(pack16(u32[r][1], u32[r][3]));
+                    up[r][3] = pks(pack16(u32[r][5], u32[r][7]));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[r][c][q] = unpks(__builtin_elementwise_add_sat(up[r][q], pks(v[r][c][q])));
+        }
+    }
+    // ---- store: pair order -> natural order, 16 bytes per row and plane
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (Y0 + r >= P.y1) break;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            v4u o;
+            o.x = __builtin_amdgcn_perm(v[r][c][2], v[r][c][0], 0x05040100u);  // (px0, px1)
+            o.y = __builtin_amdgcn_perm(v[r][c][2], v[r][c][0], 0x07060302u);  // (px2, px3)
+            o.z = __builtin_amdgcn_perm(v[r][c][3], v[r][c][1], 0x05040100u);  // (px4, px5)
+            o.w = __builtin_amdgcn_perm(v[r][c][3], v[r][c][1], 0x07060302u);  // (px6, px7)
+            *reinterpret_cast<STX_GAS v4u*>(gp(P.out) + c * P.out_plane + (long long)(Y0 + r - P.out_y0) * P.out_stride + (X0 - P.out_x0)) = o;
+        }
+    }
+}
+
 bool launched_ok() { return hipGetLastError() == hipSuccess; }
 
 }  // namespace
@@ -1379,8 +1613,10 @@ bool stx_fast_mb_level(stx_ctx* ctx, const MbLevelK& K)
         else if (K.all_u8) hipLaunchKernelGGL((mb_level_fast_kernel<false, true, false, true>), grid, dim3(256), 0, st, KT);
         else hipLaunchKernelGGL((mb_level_fast_kernel<false, true, false, false>), grid, dim3(256), 0, st, KT);
     } else {
+        static const bool no_pk_levels = getenv("STITCHING_AMD_NO_PK_LEVELS") != nullptr;  // diagnostic: A/B against mb_level_fast_kernel
         if (K.level == 0 && K.all_u8 && K.num_bands > 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, false, true>), grid, dim3(256), 0, st, KT);
         else if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, false, false>), grid, dim3(256), 0, st, KT);
+        else if (K.all_u8 && K.level < K.num_bands && !no_pk_levels) hipLaunchKernelGGL(mb_level_pk_kernel, grid, dim3(256), 0, st, KT);
         else if (K.all_u8) hipLaunchKernelGGL((mb_level_fast_kernel<false, false, false, true>), grid, dim3(256), 0, st, KT);
         else hipLaunchKernelGGL((mb_level_fast_kernel<false, false, false, false>), grid, dim3(256), 0, st, KT);
     }

@@ -226,9 +226,94 @@ STX_DEV float atanf_x(float x) { return (float)atan_d((double)x); }
 STX_DEV float logf_x(float x) { return (float)log_d((double)x); }
 STX_DEV float sinhf_x(float x) { return (float)sinh_d((double)x); }
 STX_DEV float coshf_x(float x) { return (float)cosh_d((double)x); }
+// ---- trig = glibc: sinf / cosf exactly as glibc >= 2.28 computes them (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h:
+// double-precision range reduction by one multiply-subtract below 120, a 192-bit 4/pi table above, an 8th-degree sine / cosine
+// polynomial, one rounding to float).  What cv::detail's projectors get from the host's libm on a glibc machine
+// (stitching/warper.py:44-51 -> PyRotationWarper -> sinf / cosf), bit for bit: the oracle's restatement of the same routine
+// equals the host's sinf and cosf on every one of the 2^32 float arguments (tests/test_glibc_trig.py, tools/check_glibc_trig.py).
+// fma: the __sinf_fma build every x86-64-v3 host selects (GCC contracts each product whose only uses are sums); !fma: __sinf_sse2.
+// The two differ at 17 positive arguments of all floats.
+STX_DEV double gl_mad(double a, double b, double c, bool use_fma) { return use_fma ? fma(a, b, c) : __dadd_rn(__dmul_rn(a, b), c); }
+STX_DEV uint32_t gl_abstop12(float x) { return (__float_as_uint(x) >> 20) & 0x7ffu; }
+STX_DEV float gl_sinf_poly(double x, double x2, bool neg_cos, int n, bool use_fma)
+{
+    // __sincosf_table[0] / [1] (the second entry holds the negated cosine polynomial)
+    const double c0 = neg_cos ? -0x1p0 : 0x1p0, c1 = neg_cos ? 0x1.ffffffd0c621cp-2 : -0x1.ffffffd0c621cp-2,
+                 c2 = neg_cos ? -0x1.55553e1068f19p-5 : 0x1.55553e1068f19p-5, c3 = neg_cos ? 0x1.6c087e89a359dp-10 : -0x1.6c087e89a359dp-10,
+                 c4 = neg_cos ? -0x1.99343027bf8c3p-16 : 0x1.99343027bf8c3p-16;
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    if ((n & 1) == 0) {
+        const double x3 = __dmul_rn(x, x2);
+        const double t1 = gl_mad(x2, s3, s2, use_fma);
+        const double x7 = __dmul_rn(x3, x2);
+        const double s = gl_mad(x3, s1, x, use_fma);
+        return (float)gl_mad(x7, t1, s, use_fma);
+    }
+    const double x4 = __dmul_rn(x2, x2);
+    const double t2 = gl_mad(x2, c4, c3, use_fma);
+    const double t1 = gl_mad(x2, c1, c0, use_fma);
+    const double x6 = __dmul_rn(x4, x2);
+    const double c = gl_mad(x4, c2, t1, use_fma);
+    return (float)gl_mad(x6, t2, c, use_fma);
+}
+STX_DEV double gl_reduce_large(uint32_t xi, int* np)
+{
+    const uint32_t inv_pio4[24] = {0xa2,       0xa2f9,     0xa2f983,   0xa2f9836e, 0xf9836e4e, 0x836e4e44, 0x6e4e4415, 0x4e441529,
+                                   0x441529fc, 0x1529fc27, 0x29fc2757, 0xfc2757d1, 0x2757d1f5, 0x57d1f534, 0xd1f534dd, 0xf534ddc0,
+                                   0x34ddc0db, 0xddc0db62, 0xc0db6295, 0xdb629599, 0x6295993c, 0x95993c43, 0x993c4390, 0x3c439041};
+    const int i0 = (int)((xi >> 26) & 15u);
+    const int shift = (int)((xi >> 23) & 7u);
+    xi = (xi & 0xffffffu) | 0x800000u;
+    xi <<= shift;
+    unsigned long long res0 = (unsigned long long)(uint32_t)(xi * inv_pio4[i0]);  // 32-bit product, as in the source
+    const unsigned long long res1 = (unsigned long long)xi * inv_pio4[i0 + 4];
+    const unsigned long long res2 = (unsigned long long)xi * inv_pio4[i0 + 8];
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    const unsigned long long n = (res0 + (1ull << 61)) >> 62;
+    res0 -= n << 62;
+    *np = (int)n;
+    return __dmul_rn((double)(long long)res0, 0x1.921FB54442D18p-62);
+}
+STX_DEV float gl_sincosf1(float y, bool want_cos, bool use_fma)
+{
+    double x = (double)y;
+    int n;
+    const int flip = want_cos ? 1 : 0;
+    if (gl_abstop12(y) < gl_abstop12(0x1.921FB6p-1f)) {
+        if (gl_abstop12(y) < gl_abstop12(0x1p-12f)) return want_cos ? 1.0f : y;
+        return gl_sinf_poly(x, __dmul_rn(x, x), false, flip, use_fma);
+    }
+    if (gl_abstop12(y) < gl_abstop12(120.0f)) {
+        const double r = __dmul_rn(x, 0x1.45F306DC9C883p+23);
+        n = ((int)r + 0x800000) >> 24;
+        x = gl_mad(-(double)n, 0x1.921FB54442D18p0, x, use_fma);
+        const double sg = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;  // sign[n & 3] = {1, -1, -1, 1}
+        return gl_sinf_poly(__dmul_rn(x, sg), __dmul_rn(x, x), (n & 2) != 0, n ^ flip, use_fma);
+    }
+    if (gl_abstop12(y) < 0x7f8u) {
+        const uint32_t xi = __float_as_uint(y);
+        const int sign = (int)(xi >> 31);
+        x = gl_reduce_large(xi, &n);
+        const int m = (n + sign) & 3;
+        const double sg = (m == 1 || m == 2) ? -1.0 : 1.0;
+        return gl_sinf_poly(__dmul_rn(x, sg), __dmul_rn(x, x), (m & 2) != 0, n ^ flip, use_fma);
+    }
+    return __uint_as_float(0x7fc00000u);
+}
+// trig: STX_TRIG_EXACT (0, correctly rounded), STX_TRIG_GLIBC (1), STX_TRIG_GLIBC_NOFMA (2) — include/stitching_amd.h
+STX_DEV void sincosf_m(float x, int trig, float* s, float* c);
 STX_DEV float sinf_x(float x) { double s, c; sincos_d((double)x, &s, &c); return (float)s; }
 STX_DEV float cosf_x(float x) { double s, c; sincos_d((double)x, &s, &c); return (float)c; }
 STX_DEV void sincosf_x(float x, float* s, float* c) { double sd, cd; sincos_d((double)x, &sd, &cd); *s = (float)sd; *c = (float)cd; }
+STX_DEV void sincosf_m(float x, int trig, float* s, float* c)
+{
+    if (trig == 0) { sincosf_x(x, s, c); return; }
+    *s = gl_sincosf1(x, false, trig == 1);
+    *c = gl_sincosf1(x, true, trig == 1);
+}
+STX_DEV float sinf_m(float x, int trig) { return trig == 0 ? sinf_x(x) : gl_sincosf1(x, false, trig == 1); }
+STX_DEV float cosf_m(float x, int trig) { return trig == 0 ? cosf_x(x) : gl_sincosf1(x, true, trig == 1); }
 STX_DEV float atan2f_x(float y, float x) { return (float)atan2_d((double)y, (double)x); }
 STX_DEV float acosf_x(float w) { return (float)acos_d((double)w); }
 

@@ -61,6 +61,7 @@ struct WarpK {
     // nearest-neighbour inside test on 32 v: cvRound(v) in [0, n-1]  <=>  -16 <= 32 v < m32_hi (ties go to even)
     float mx32_hi, my32_hi;
     float c2, c5, c8;  // plane: kr2 (1 - t2), kr5 (1 - t2), kr8 (1 - t2), each rounded once (host fp32 = device fp32)
+    int trig;    // STX_TRIG_*: which sinf / cosf the projector's trigonometry follows (stx_device_math.h: sincosf_m)
     int num_ok;  // host-proved: |numerators| <= 2^60 and finite tables, the per-lane magnitude test is skipped
     int z_one;   // host-proved (plane / affine): z = 1.f for every pixel, the quotients are the numerators
 };
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void warp_tables_kernel(WarpBatchK B)
     if (i < P.dw) {
         const float uu = (float)(P.tlx + i);
         float2 o = make_float2(0.f, 0.f);
-        if (TYPE == STX_WARP_SPHERICAL || TYPE == STX_WARP_CYLINDRICAL) sincosf_x(fdiv(uu, P.scale), &o.x, &o.y);
+        if (TYPE == STX_WARP_SPHERICAL || TYPE == STX_WARP_CYLINDRICAL) sincosf_m(fdiv(uu, P.scale), P.trig, &o.x, &o.y);
         else o.x = fsub(fdiv(uu, P.scale), P.t[0]);
         colT[i] = o;
     } else if (i < P.dw + dh4) {
@@ -131,8 +132,8 @@ __global__ __launch_bounds__(256) void warp_tables_kernel(WarpBatchK B)
         if (TYPE == STX_WARP_SPHERICAL && P.family == STX_F_MERCATOR) {
             // MercatorProjector::mapBackward is the sphere's with another latitude: v_ = atan(sinh(v')), x_ = cos v_ sin u',
             // y_ = sin v_, z_ = cos v_ cos u' — the same per-pixel arithmetic from a different row table
-            sincosf_x(atanf_x(sinhf_x(fdiv(vv, P.scale))), &rb, &ra);
-        } else if (TYPE == STX_WARP_SPHERICAL) sincosf_x(fsub(PI_F, fdiv(vv, P.scale)), &ra, &rb);
+            sincosf_m(atanf_x(sinhf_x(fdiv(vv, P.scale))), P.trig, &rb, &ra);
+        } else if (TYPE == STX_WARP_SPHERICAL) sincosf_m(fsub(PI_F, fdiv(vv, P.scale)), P.trig, &ra, &rb);
         else if (TYPE == STX_WARP_CYLINDRICAL) ra = fdiv(vv, P.scale);
         else ra = fsub(fdiv(vv, P.scale), P.t[1]);
         const float y_ = TYPE == STX_WARP_SPHERICAL ? rb : ra;
@@ -677,7 +678,7 @@ STX_DEV float4 gen_col(const WarpK& P, float upx)
     float4 o = make_float4(u, 0.f, 0.f, 0.f);
     if (G == GEN_CRECT || G == GEN_PANINI) {
         const float u_ = fmul(P.pa, atanf_x(fdiv(u, P.pa)));
-        sincosf_x(u_, &o.x, &o.y);  // sinf_x(u_) / cosf_x(u_) are these very values
+        sincosf_m(u_, P.trig, &o.x, &o.y);  // sinf(u_) / cosf(u_) are these very values
         if (G == GEN_PANINI) {
             o.z = fmul(fmul(P.pb, P.pa), tanf_x(fdiv(u_, P.pa)));
             o.w = u_ == u_ ? 1.f : 0.f;
@@ -694,7 +695,7 @@ STX_DEV float2 gen_row(const WarpK& P, float vpx)
 {
     const float v = fdiv(vpx, P.scale);
     float2 o = make_float2(v, 0.f);
-    if (G == GEN_TMERC) sincosf_x(v, &o.x, &o.y);
+    if (G == GEN_TMERC) sincosf_m(v, P.trig, &o.x, &o.y);
     return o;
 }
 
@@ -707,8 +708,8 @@ STX_DEV void gen_dir(const WarpK& P, const float4 c, const float2 r, float& x_, 
         const float rad = fsqrt(fadd(fmul(u, u), fmul(v, v)));
         const float v_ = P.family == STX_F_FISHEYE ? rad : fmul(2.f, atanf_x(fdiv(1.f, rad)));
         float sinv, cosv, su, cu;
-        sincosf_x(fsub(PI_F, v_), &sinv, &cosv);
-        sincosf_x(u_, &su, &cu);
+        sincosf_m(fsub(PI_F, v_), P.trig, &sinv, &cosv);
+        sincosf_m(u_, P.trig, &su, &cu);
         x_ = fmul(sinv, su);
         y_ = cosv;
         z_ = fmul(sinv, cu);
@@ -723,10 +724,10 @@ STX_DEV void gen_dir(const WarpK& P, const float4 c, const float2 r, float& x_, 
         v_ = c.w != 0.f ? atanf_x(fdiv(fmul(r.x, su), c.z)) : 0.f;
     } else {
         v_ = asinf_x(fdiv(r.x, c.y));
-        sincosf_x(atan2f_x(c.x, r.y), &su, &cu);
+        sincosf_m(atan2f_x(c.x, r.y), P.trig, &su, &cu);
     }
     float sv, cv;
-    sincosf_x(v_, &sv, &cv);
+    sincosf_m(v_, P.trig, &sv, &cv);
     x_ = fmul(cv, su);
     y_ = sv;
     z_ = fmul(cv, cu);
@@ -793,10 +794,11 @@ struct RoiK {
     int family;    // STX_F_*
     float pa, pb;
     int full;      // 1: every source pixel (RotationWarperBase::detectResultRoi), 0: the border (detectResultRoiByBorder)
+    int trig;      // STX_TRIG_* (the forward maps of the per-pixel projector families call sinf / cosf)
 };
 
 // mapForward of the projectors without a detectResultRoi override; direction already multiplied by r_kinv
-__device__ __noinline__ void forward_general(int family, float a, float b, float scale, float x_, float y_, float z_, float* out2)
+__device__ __noinline__ void forward_general(int family, float a, float b, float scale, int trig, float x_, float y_, float z_, float* out2)
 {
     const bool portrait = family == STX_F_CRECT_PORTRAIT || family == STX_F_PANINI_PORTRAIT;
     if (portrait) { const float t = x_; x_ = y_; y_ = t; }
@@ -806,11 +808,11 @@ __device__ __noinline__ void forward_general(int family, float a, float b, float
     if (family == STX_F_FISHEYE || family == STX_F_STEREOGRAPHIC) {
         const float v_ = fsub(PI_F, acosf_x(w));
         float su, cu;
-        sincosf_x(u_, &su, &cu);
+        sincosf_m(u_, trig, &su, &cu);
         float r = v_;
         if (family == STX_F_STEREOGRAPHIC) {
             float sv, cv;
-            sincosf_x(v_, &sv, &cv);
+            sincosf_m(v_, trig, &sv, &cv);
             r = fdiv(sv, fsub(1.f, cv));
         }
         u = fmul(fmul(scale, r), cu);
@@ -820,20 +822,20 @@ __device__ __noinline__ void forward_general(int family, float a, float b, float
         const float s = portrait ? -scale : scale;
         if (family == STX_F_CRECT || family == STX_F_CRECT_PORTRAIT) {
             u = fmul(fmul(s, a), tanf_x(fdiv(u_, a)));
-            v = fdiv(fmul(fmul(scale, b), tanf_x(v_)), cosf_x(u_));
+            v = fdiv(fmul(fmul(scale, b), tanf_x(v_)), cosf_m(u_, trig));
         } else if (family == STX_F_PANINI || family == STX_F_PANINI_PORTRAIT) {
             const float tg = fmul(a, tanf_x(fdiv(u_, a)));
             u = fmul(s, tg);
-            const float sinu = sinf_x(u_);
+            const float sinu = sinf_m(u_, trig);
             if ((double)fabsf(sinu) < 1E-7) v = fmul(fmul(scale, b), tanf_x(v_));
             else v = fdiv(fmul(fmul(fmul(scale, b), tg), tanf_x(v_)), sinu);
         } else if (family == STX_F_MERCATOR) {
             u = fmul(scale, u_);
             v = fmul(scale, logf_x(tanf_x(fadd((float)(3.14159265358979323846 / 4), fdiv(v_, 2.f)))));
         } else {  // transverse mercator
-            const float B = fmul(cosf_x(v_), sinf_x(u_));
+            const float B = fmul(cosf_m(v_, trig), sinf_m(u_, trig));
             u = fmul(fdiv(scale, 2.f), logf_x(fdiv(fadd(1.f, B), fsub(1.f, B))));
-            v = fmul(scale, atan2f_x(tanf_x(v_), cosf_x(u_)));
+            v = fmul(scale, atan2f_x(tanf_x(v_), cosf_m(u_, trig)));
         }
     }
     out2[0] = u; out2[1] = v;
@@ -868,7 +870,7 @@ __global__ __launch_bounds__(256) void roi_kernel(RoiBatchK B, float* __restrict
         float u, v;
         if (GEN) {
             float o[2];
-            forward_general(P.family, P.pa, P.pb, P.scale, x_, y_, z_, o);
+            forward_general(P.family, P.pa, P.pb, P.scale, P.trig, x_, y_, z_, o);
             u = o[0]; v = o[1];
         } else if (P.type == STX_WARP_SPHERICAL) {
             u = fmul(P.scale, atan2f_x(x_, z_));
@@ -1027,6 +1029,7 @@ void fill_warpk(const StxWarpLaunch& L, WarpK* Kp, double* bytes)
     for (int i = 0; i < 3; i++) K.t[i] = L.proj.t[i];
     K.scale = L.proj.scale;
     K.family = L.proj.family; K.pa = L.proj.a; K.pb = L.proj.b;
+    K.trig = L.proj.trig;
     K.tlx = L.tlx; K.tly = L.tly; K.dw = L.dw; K.dh = L.dh;
     K.sw = L.sw; K.sh = L.sh;
     const bool img = L.dimg != nullptr, mask = L.dmask != nullptr;
@@ -1127,6 +1130,7 @@ int stx_launch_roi_minmax(stx_ctx* ctx, int n, const StxProjector* projs, const 
                 k.w = sizes_wh[2 * g];
                 k.h = sizes_wh[2 * g + 1];
                 k.family = projs[g].family; k.pa = projs[g].a; k.pb = projs[g].b;
+                k.trig = projs[g].trig;
                 k.full = full ? 1 : 0;
                 if (full && (long long)k.w * k.h > 0x7fffffffll) return stx_fail(STX_ERR_UNSUPPORTED, "image of %dx%d pixels", k.w, k.h);
             }

@@ -45,6 +45,16 @@ MODELS = [
 ]
 
 
+# --ref libm: the trig modes against the oracle that calls the HOST's libm, as cv::detail's projectors do.  "glibc" is the product's
+# STX_TRIG_GLIBC mode (the same routine on the device: tests/test_gpu_trig.py compares the two bit for bit).
+TRIG_MODELS = [
+    ("libm trig (the host's sinf / cosf: what OpenCV calls)", dict(trig=O.TRIG_LIBM)),
+    ("glibc restatement, FMA build (product: STITCHING_AMD_TRIG=glibc)", dict(trig=O.TRIG_GLIBC)),
+    ("glibc restatement, SSE2 build (product: STITCHING_AMD_TRIG=glibc-nofma)", dict(trig=O.TRIG_GLIBC_NOFMA)),
+    ("exact trig (product default)", dict(trig=O.TRIG_EXACT)),
+]
+
+
 def run(frames, cams, bands, warper_type, trig=O.TRIG_EXACT, pyrdown32f="scalar", lanes=4, remap="q15", masks_fn=None):
     prev = O.set_model(pyrdown32f=pyrdown32f, lanes=lanes, remap=remap)
     try:
@@ -85,6 +95,7 @@ def main():
     ap.add_argument("--seams", action="store_true", help="Voronoi seam masks instead of the full warped masks")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--json", default="")
+    ap.add_argument("--ref", default="default", choices=["default", "libm"], help="libm: the trig modes against the host-libm oracle")
     args = ap.parse_args()
     O.build()
     O.set_num_threads(args.threads or min(O.max_threads(), 64))
@@ -93,7 +104,7 @@ def main():
     masks_fn = synthetic.voronoi_seam_masks if args.seams else None
     rows = []
     base = None
-    for name, kw in MODELS:
+    for name, kw in (TRIG_MODELS if args.ref == "libm" else MODELS):
         t = time.perf_counter()
         r = run(frames, cams, args.bands, args.warper, masks_fn=masks_fn, **kw)
         dt = time.perf_counter() - t
@@ -116,8 +127,9 @@ def main():
                          seconds=round(dt, 2)))
         print(f"# {name}: {dt:.1f} s", file=sys.stderr)
     hdr = (f"Oracle model sensitivity: {args.frames} frames {args.width}x{args.height}, {args.warper} warp, {args.bands} bands, "
-           f"{'Voronoi seam masks' if args.seams else 'full warped masks'}; differences against the default model "
-           f"(the one the HIP path reproduces bit for bit)")
+           f"{'Voronoi seam masks' if args.seams else 'full warped masks'}; differences against "
+           + ("the oracle on the HOST's libm (%s %s): what OpenCV's projectors call" % __import__("platform").libc_ver() if args.ref == "libm" else
+              "the default model (the one the HIP path reproduces bit for bit)"))
     print(hdr + "\n")
     print("| model | same ROIs | warped images: max abs diff / differing bytes | panorama: max abs diff / differing bytes (fraction) / bytes off by > 1 | mask bytes differing |")
     print("|---|---|---|---|---|")
