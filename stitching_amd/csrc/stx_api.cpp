@@ -1586,7 +1586,11 @@ static int mb_finish(stx_blender* b, stx_buf* pano, stx_buf* pmask, stx_buf* pan
     mb_level_regions(b, b->band_x0, b->band_x1, xb, xe);
     std::vector<short*> out(nb + 2, nullptr);
     std::vector<long long> ostride(nb + 2, 0), oplane(nb + 2, 0);
-    for (int lv = nb; lv >= 0; lv--) {
+    // The three coarsest levels go through one launch (mb_coarse_kernel: the finished levels B and B-1 live in LDS only) when
+    // there are at least 3 bands, i.e. when level B-2 is not the panorama itself.  STITCHING_AMD_NO_COARSE_FUSION: diagnostic.
+    static const bool no_fusion = getenv("STITCHING_AMD_NO_COARSE_FUSION") != nullptr;
+    const bool fuse = nb >= 3 && !no_fusion;
+    for (int lv = fuse ? nb - 2 : nb; lv >= 0; lv--) {
         MbLevelK K;
         mb_fill_common(b, &K, d_images, n, lv);
         K.all_u8 = all_u8 ? 1 : 0;
@@ -1611,6 +1615,15 @@ static int mb_finish(stx_blender* b, stx_buf* pano, stx_buf* pmask, stx_buf* pan
             out[lv] = (short*)((uint8_t*)p + MB_FRONT_PAD); ostride[lv] = st; oplane[lv] = st * ph;
             K.out = out[lv]; K.out_stride = st; K.out_plane = st * ph;
             K.out_x0 = xb[lv]; K.out_y0 = 0;
+        }
+        if (fuse && lv == nb - 2) {
+            // algorithmic bytes: the inputs of the three levels over their regions once, the finished level B-2 once
+            double bytes = mb_level_bytes(b, b->images, lv, K.x0, K.x1, false, false) - (double)(K.x1 - K.x0) * (b->rh >> lv) * 6.0 / 4.0;
+            for (int l2 = nb - 1; l2 <= nb; l2++)
+                bytes += mb_level_bytes(b, b->images, l2, xb[l2], xe[l2], false, false) - (double)(xe[l2] - xb[l2]) * (b->rh >> l2) * (l2 < nb ? 7.5 : 6.0);
+            K.up = nullptr;
+            STX_TRY(stx_launch_mb_coarse(ctx, K, bytes));
+            continue;
         }
         STX_TRY(stx_launch_mb_level(ctx, K, mb_level_bytes(b, b->images, lv, K.x0, K.x1, false, pano16 != nullptr)));
     }

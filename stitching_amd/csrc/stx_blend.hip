@@ -252,6 +252,138 @@ STX_DEV void mb_level_body(const MbLevelK& P)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The three coarsest levels B, B-1, B-2 in ONE launch (round 3).  They are tiny (config 2: 52 k, 209 k and 832 k samples) and
+// each is a single wave of workgroups whose time is memory latency, not bandwidth: as three dependent launches they cost
+// 8 + 19 + 33 us of an otherwise idle GPU.  Here a workgroup owns a 32 x 16 tile of level B-2 and recomputes, in LDS, the
+// finished samples of level B-1 (18 x 10) and of level B (at most 12 x 8) that its tile's pyrUp chain reaches — the halo is recomputed
+// instead of being exchanged between workgroups, so the levels B and B-1 never exist in memory and nothing waits for a grid.
+// Per sample this is mb_level_body's arithmetic (same loads, same fp32 operations in the same order); only the finished coarser
+// level comes from LDS instead of HBM.
+// ---------------------------------------------------------------------------------------------
+constexpr int CO_TW = 32, CO_TH = 16;            // tile of level B-2
+constexpr int CO_W1 = CO_TW / 2 + 2, CO_H1 = CO_TH / 2 + 2;   // level B-1 samples a tile can reach: 18 x 10
+constexpr int CO_W0 = CO_W1 / 2 + 3, CO_H0 = CO_H1 / 2 + 3;   // level B: 12 x 8 (a window that starts on an odd sample reaches one more)
+
+// gather + normalise of ONE sample of level lv >= 1 (the loop body of mb_level_body<false> without the store)
+STX_DEV void mb_gather_norm(const StxMbImage* __restrict__ images, int n_images, int num_bands, int lv, int x, int y, int (&v)[3])
+{
+    int acc0 = 0, acc1 = 0, acc2 = 0;
+    float ws = 0.f;
+    for (int k = 0; k < n_images; k++) {
+        const StxMbImage& im = images[k];
+        const int lx = x - (im.fx >> lv), ly = y - (im.fy >> lv);
+        const int lw = im.fw >> lv, lh = im.fh >> lv;
+        if ((unsigned)lx >= (unsigned)lw || (unsigned)ly >= (unsigned)lh) continue;
+        const float w = im.wt[lv][(long long)ly * im.wt_stride[lv] + lx];
+        const short* G = im.g[lv] + (long long)ly * im.g_stride[lv] + lx;
+        int L[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            int gval = G[c * im.g_plane[lv]];
+            if (im.kind == 0 && lv < num_bands) {
+                int u = pyr_up_at(im.g[lv + 1] + c * im.g_plane[lv + 1], im.g_stride[lv + 1], lw >> 1, lh >> 1, lx, ly);
+                gval = sat_s16(gval - u);
+            }
+            L[c] = gval;
+        }
+        if (im.kind == 1) {  // already (short)(L * W)
+            acc0 += L[0]; acc1 += L[1]; acc2 += L[2];
+        } else {
+            acc0 += trunc_s16(fmul((float)L[0], w));
+            acc1 += trunc_s16(fmul((float)L[1], w));
+            acc2 += trunc_s16(fmul((float)L[2], w));
+        }
+        ws = fadd(ws, w);
+    }
+    const float den = fadd(ws, WEIGHT_EPS);
+    v[0] = trunc_s16(fdiv((float)(short)acc0, den));
+    v[1] = trunc_s16(fdiv((float)(short)acc1, den));
+    v[2] = trunc_s16(fdiv((float)(short)acc2, den));
+}
+
+// pyr_up_at on a window of the coarser level held in LDS: plane[(row - oy) * pitch + (col - ox)], level size cw x ch
+STX_DEV int pyr_up_at_lds(const short* __restrict__ plane, int pitch, int ox, int oy, int cw, int ch, int X, int Y)
+{
+    const int px = X >> 1, py = Y >> 1;
+    const int xl = up_idx(px - 1, cw) - ox, xc = px - ox, xr = up_idx(px + 1, cw) - ox;
+    const short* rc = plane + (py - oy) * pitch;
+    const short* rb = plane + (up_idx(py + 1, ch) - oy) * pitch;
+    int hc, hb, v;
+    if (X & 1) {
+        hc = (rc[xc] + rc[xr]) * 4;
+        hb = (rb[xc] + rb[xr]) * 4;
+    } else {
+        hc = rc[xl] + rc[xc] * 6 + rc[xr];
+        hb = rb[xl] + rb[xc] * 6 + rb[xr];
+    }
+    if (Y & 1) {
+        v = (hc + hb) * 4;
+    } else {
+        const short* rt = plane + (up_idx(py - 1, ch) - oy) * pitch;
+        const int ht = (X & 1) ? (rt[xc] + rt[xr]) * 4 : rt[xl] + rt[xc] * 6 + rt[xr];
+        v = ht + hc * 6 + hb;
+    }
+    return (int)(short)((v + 32) >> 6);
+}
+
+struct MbCoarseK {
+    const StxMbImage* images;
+    int n_images, num_bands;
+    int x0, x1, y1;          // region of level B-2 that is produced: [x0, x1) x [0, y1)
+    short* out; long long out_stride, out_plane; int out_x0;  // finished level B-2 (planar int16), origin (out_x0, 0)
+    int pw, ph;              // padded panorama size at level B-2 (a multiple of 4)
+};
+
+__global__ __launch_bounds__(256) void mb_coarse_kernel(MbCoarseK P)
+{
+    __shared__ short s0[3][CO_H0 * CO_W0];  // finished level B
+    __shared__ short s1[3][CO_H1 * CO_W1];  // finished level B-1
+    const int tid = threadIdx.x;
+    const int B = P.num_bands;
+    const int tx0 = P.x0 + blockIdx.x * CO_TW, ty0 = blockIdx.y * CO_TH;       // tile origin, level B-2
+    const int tx1 = min(tx0 + CO_TW, P.x1), ty1 = min(ty0 + CO_TH, P.y1);    // exclusive
+    const int pw1 = P.pw >> 1, ph1 = P.ph >> 1, pw0 = P.pw >> 2, ph0 = P.ph >> 2;
+    // level B-1 samples the tile's pyrUp reaches: columns (x >> 1) - 1 .. (x >> 1) + 1 of every x in the tile, clipped (the border
+    // rule of pyrUp maps -1 -> 1 and n -> n - 1, both inside the clipped window)
+    const int ax0 = max((tx0 >> 1) - 1, 0), ax1 = min(((tx1 - 1) >> 1) + 1, pw1 - 1);
+    const int ay0 = max((ty0 >> 1) - 1, 0), ay1 = min(((ty1 - 1) >> 1) + 1, ph1 - 1);
+    const int aw = ax1 - ax0 + 1, ah = ay1 - ay0 + 1;
+    // ... and the level B samples those reach
+    const int bx0 = max((ax0 >> 1) - 1, 0), bx1 = min((ax1 >> 1) + 1, pw0 - 1);
+    const int by0 = max((ay0 >> 1) - 1, 0), by1 = min((ay1 >> 1) + 1, ph0 - 1);
+    const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+    for (int i = tid; i < bw * bh; i += 256) {  // level B: L_B = G_B, nothing above it
+        const int yy = i / bw, xx = i - yy * bw;
+        int v[3];
+        mb_gather_norm(P.images, P.n_images, B, B, bx0 + xx, by0 + yy, v);
+#pragma unroll
+        for (int c = 0; c < 3; c++) s0[c][yy * CO_W0 + xx] = (short)v[c];
+    }
+    __syncthreads();
+    for (int i = tid; i < aw * ah; i += 256) {  // level B-1
+        const int yy = i / aw, xx = i - yy * aw;
+        int v[3];
+        mb_gather_norm(P.images, P.n_images, B, B - 1, ax0 + xx, ay0 + yy, v);
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            s1[c][yy * CO_W1 + xx] = (short)sat_s16(pyr_up_at_lds(s0[c], CO_W0, bx0, by0, pw0, ph0, ax0 + xx, ay0 + yy) + v[c]);
+    }
+    __syncthreads();
+    for (int i = tid; i < CO_TW * CO_TH; i += 256) {  // level B-2 -> memory
+        const int yy = i / CO_TW, xx = i - yy * CO_TW;
+        const int x = tx0 + xx, y = ty0 + yy;
+        if (x >= tx1 || y >= ty1) continue;
+        int v[3];
+        mb_gather_norm(P.images, P.n_images, B, B - 2, x, y, v);
+        short* O = P.out + (long long)y * P.out_stride + (x - P.out_x0);
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            O[c * P.out_plane] = (short)sat_s16(pyr_up_at_lds(s1[c], CO_W1, ax0, ay0, pw1, ph1, x, y) + v[c]);
+    }
+}
+
 template <bool L0>
 __global__ __launch_bounds__(256) void mb_level_kernel(MbLevelK P)
 {
@@ -342,6 +474,23 @@ int stx_launch_mb_pyramids(stx_ctx* ctx, const StxMbImage* d_images, const StxMb
         STX_TRY(check_launch("mb_down"));
     }
     return STX_OK;
+}
+
+// levels B, B-1, B-2 of a blender with B >= 3 bands in one launch: K = the argument block of level B-2 (its `up` is ignored)
+int stx_launch_mb_coarse(stx_ctx* ctx, const MbLevelK& K, double algo_bytes)
+{
+    if (K.x1 <= K.x0 || K.y1 <= K.y0) return STX_OK;
+    if (K.level != K.num_bands - 2 || K.level < 1 || K.y0 != 0 || K.out_y0 != 0 || K.emit)
+        return stx_fail(STX_ERR_INVALID, "mb_coarse: not the argument block of level B-2");
+    StxProfScope prof(ctx, "mb_coarse", algo_bytes);
+    MbCoarseK C;
+    C.images = K.images; C.n_images = K.n_images; C.num_bands = K.num_bands;
+    C.x0 = K.x0; C.x1 = K.x1; C.y1 = K.y1;
+    C.out = K.out; C.out_stride = K.out_stride; C.out_plane = K.out_plane; C.out_x0 = K.out_x0;
+    C.pw = K.pw; C.ph = K.ph;
+    const dim3 grid((K.x1 - K.x0 + CO_TW - 1) / CO_TW, (K.y1 + CO_TH - 1) / CO_TH);
+    hipLaunchKernelGGL(mb_coarse_kernel, grid, dim3(256), 0, ctx->stream, C);
+    return check_launch("mb_coarse");
 }
 
 int stx_launch_mb_level(stx_ctx* ctx, const MbLevelK& K, double algo_bytes)

@@ -1555,7 +1555,8 @@ bool stx_fast_mb_down_batch(stx_ctx* ctx, const StxMbImage* d_images, const StxM
     bool pk_ok = true;  // packed 16-bit row sums need u8 images with 0 / 255 masks
     for (int i = 0; i < n; i++) pk_ok = pk_ok && !h_images[i].img0_is_s16 && h_images[i].mask_binary;
     dim3 grid(stx_tile_grid(M), 1, n);
-    if (level == 0 && pk_ok) hipLaunchKernelGGL(mb_down0_lds_kernel<true>, grid, dim3(256), 0, ctx->stream, d_images, M);
+    static const unsigned pad_lds = getenv("STITCHING_AMD_D0_LDS") ? (unsigned)atoi(getenv("STITCHING_AMD_D0_LDS")) : 0u;  // diagnostic, see stx_warp.hip
+    if (level == 0 && pk_ok) hipLaunchKernelGGL(mb_down0_lds_kernel<true>, grid, dim3(256), pad_lds, ctx->stream, d_images, M);
     else if (level == 0) hipLaunchKernelGGL(mb_down0_lds_kernel<false>, grid, dim3(256), 0, ctx->stream, d_images, M);
     else hipLaunchKernelGGL(mb_down_lds_kernel, grid, dim3(256), 0, ctx->stream, d_images, level, M);
     return launched_ok();
@@ -1602,8 +1603,10 @@ bool stx_fast_mb_level(stx_ctx* ctx, const MbLevelK& K)
     dim3 grid(stx_tile_grid(KT.tiles), 1);
     hipStream_t st = ctx->stream;
     if (K.level == 0 && K.pk_ok && !K.emit && K.num_bands > 0) {
-        if (K.has_contrib) hipLaunchKernelGGL(mb_level0_pk_kernel<true>, grid, dim3(256), 0, st, KT);
-        else hipLaunchKernelGGL(mb_level0_pk_kernel<false>, grid, dim3(256), 0, st, KT);
+        // STITCHING_AMD_L0_LDS (diagnostic): dynamic LDS as an occupancy limit, see stx_warp.hip
+        static const unsigned pad_lds = getenv("STITCHING_AMD_L0_LDS") ? (unsigned)atoi(getenv("STITCHING_AMD_L0_LDS")) : 0u;
+        if (K.has_contrib) hipLaunchKernelGGL(mb_level0_pk_kernel<true>, grid, dim3(256), pad_lds, st, KT);
+        else hipLaunchKernelGGL(mb_level0_pk_kernel<false>, grid, dim3(256), pad_lds, st, KT);
     } else if (K.emit) {
         if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, true, false>), grid, dim3(256), 0, st, KT);
         else if (K.all_u8) hipLaunchKernelGGL((mb_level_fast_kernel<false, false, true, true>), grid, dim3(256), 0, st, KT);

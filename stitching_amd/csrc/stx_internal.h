@@ -172,6 +172,7 @@ struct StxMbImage {  // device-visible descriptor of one fed image (all levels)
 int stx_launch_mb_pyramids(stx_ctx* ctx, const StxMbImage* d_images, const StxMbImage* h_images, int n, int num_bands);
 struct MbLevelK;
 int stx_launch_mb_level(stx_ctx* ctx, const MbLevelK& K, double algo_bytes);
+int stx_launch_mb_coarse(stx_ctx* ctx, const MbLevelK& K_level_Bm2, double algo_bytes);  // levels B, B-1, B-2 in one launch
 
 // pointwise exposure gain (next row N1) --------------------------------------------------------------
 int stx_launch_gain_apply(stx_ctx* ctx, stx_buf* img, const float g[3]);

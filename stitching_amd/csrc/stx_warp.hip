@@ -970,9 +970,12 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
                 per_xcd = std::max(per_xcd, ((bands + 7) / 8) * wb * tx);
             }
             const dim3 gf(8 * per_xcd, 1, m);  // 1-D tile index per image, see the kernel's XCD-aware order
-            if (img && mask) hipLaunchKernelGGL((warp_fast_kernel<TYPE, true, true>), gf, dim3(256), 0, s, B);
-            else if (img) hipLaunchKernelGGL((warp_fast_kernel<TYPE, true, false>), gf, dim3(256), 0, s, B);
-            else hipLaunchKernelGGL((warp_fast_kernel<TYPE, false, true>), gf, dim3(256), 0, s, B);
+            // STITCHING_AMD_WARP_LDS (diagnostic): bytes of dynamic LDS requested on top of the kernel's own — an occupancy limit
+            // (160 KB per CU / request = workgroups per CU) for co-residency experiments with the other panorama's kernels
+            static const unsigned pad_lds = getenv("STITCHING_AMD_WARP_LDS") ? (unsigned)atoi(getenv("STITCHING_AMD_WARP_LDS")) : 0u;
+            if (img && mask) hipLaunchKernelGGL((warp_fast_kernel<TYPE, true, true>), gf, dim3(256), pad_lds, s, B);
+            else if (img) hipLaunchKernelGGL((warp_fast_kernel<TYPE, true, false>), gf, dim3(256), pad_lds, s, B);
+            else hipLaunchKernelGGL((warp_fast_kernel<TYPE, false, true>), gf, dim3(256), pad_lds, s, B);
         } else {
             for (int i = 0; i < m; i++) {
                 StxProfScope prof(ctx, prof_name, algo_bytes[base + i]);

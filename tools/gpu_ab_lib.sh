@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of library builds / environment switches on ONE GPU box: the short bench for every variant, interleaved, REPS times.
-# usage: bash tools/gpu_ab_lib.sh <tag> <reps> "label|lib-or-empty|ENV=1 ENV2=1" ...     (AB_TESTS=1: the GPU suite on the default library first)
+# usage: bash tools/gpu_ab_lib.sh <tag> <reps> "label|lib-or-empty|ENV=1 ENV2=1|extra bench args" ...     (AB_TESTS=1: the GPU suite on the default library first)
 TAG=${1:-abl}; REPS=${2:-2}; shift 2
 OUT=gpurun_out/$TAG; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -9,9 +9,9 @@ if [ -n "${AB_TESTS:-}" ]; then
 fi
 for i in $(seq $REPS); do
   for spec in "$@"; do
-    IFS='|' read -r label lib envs <<< "$spec"
+    IFS='|' read -r label lib envs xargs <<< "$spec"
     ( [ -n "$lib" ] && export STITCHING_AMD_LIB="$GRAFT_REPO_ROOT/$lib"; for e in $envs; do export "$e"; done
-      timeout 600 python bench.py --no-cpu-baseline --e2e-steps 0 ${AB_ARGS:---no-extra} --steps 20 > "$OUT/bench_${label}_$i.json" 2> "$OUT/bench_${label}_$i.err" )
+      timeout 600 python bench.py --no-cpu-baseline --e2e-steps 0 ${AB_ARGS:---no-extra} --steps 20 $xargs > "$OUT/bench_${label}_$i.json" 2> "$OUT/bench_${label}_$i.err" )
     python - "$OUT/bench_${label}_$i.json" "$label" <<'PY'
 import json,sys
 try:
