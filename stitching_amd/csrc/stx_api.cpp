@@ -1397,12 +1397,16 @@ static int mb_feed(stx_blender* b, const stx_buf* img, const stx_buf* mask, int 
     im.iw = w; im.ih = h;
     im.ix = tlx - b->rx; im.iy = tly - b->ry;
     im.left = im.ix - im.fx; im.top = im.iy - im.fy;
+    // the Gaussian levels of a u8 image are 0..255: stored as bytes (3 instead of 6 bytes per sample on every pyramid pass)
+    im.g_u8 = img->elem == STX_U8 ? 1 : 0;
     for (int i = 1; i <= nb; i++) {
         const int lw = im.fw >> i, lh = im.fh >> i;
-        const long long gs = (long long)align_up((size_t)lw, 32), ws = (long long)align_up((size_t)lw, 16);
+        // rows of 64 bytes either way
+        const long long gs = (long long)align_up((size_t)lw, im.g_u8 ? 64 : 32), ws = (long long)align_up((size_t)lw, 16);
         void *g = nullptr, *wt = nullptr;
-        // MB_FRONT_PAD: the pyrUp tap loads of the gather kernels start two samples in front of a row (up_row_window)
-        STX_TRY(stx_dev_alloc(ctx, MB_FRONT_PAD + (size_t)gs * lh * 3 * sizeof(short), &g));
+        // MB_FRONT_PAD in front, 64 bytes behind: the pyrUp tap windows of the gather kernels start up to 4 bytes in front of a row
+        // and end up to 8 bytes behind its last sample (up_row_window / up_row_window_u8)
+        STX_TRY(stx_dev_alloc(ctx, MB_FRONT_PAD + (size_t)gs * lh * 3 * (im.g_u8 ? 1 : sizeof(short)) + 64, &g));
         b->pyr_allocs.push_back(g);
         STX_TRY(stx_dev_alloc(ctx, (size_t)ws * lh * sizeof(float), &wt));
         b->pyr_allocs.push_back(wt);
@@ -1484,9 +1488,10 @@ static double mb_level_bytes(const stx_blender* b, const std::vector<StxMbImage>
         if (lv == 0 && im.kind == 0) { rx = im.ix; rw = im.iw; ry = im.iy; rh = im.ih; }
         const double cols = std::max(0, std::min(rx + rw, x1) - std::max(rx, x0)), rows = std::min(ry + rh, ph) - ry;
         if (cols <= 0 || rows <= 0) continue;
+        const double g3 = im.g_u8 ? 3.0 : 6.0;  // the three Gaussian planes of a sample: bytes (u8 image) or int16
         if (im.kind == 1) bytes += cols * rows * 10.0;
-        else if (lv == 0) bytes += cols * rows * ((im.img0_is_s16 ? 6 : 3) + 1) + (nb > 0 ? cols * rows * 6.0 / 4.0 : 0.0);
-        else bytes += cols * rows * 10.0 + (lv < nb ? cols * rows * 6.0 / 4.0 : 0.0);
+        else if (lv == 0) bytes += cols * rows * ((im.img0_is_s16 ? 6 : 3) + 1) + (nb > 0 ? cols * rows * g3 / 4.0 : 0.0);
+        else bytes += cols * rows * (g3 + 4.0) + (lv < nb ? cols * rows * g3 / 4.0 : 0.0);
     }
     const double area = (double)(x1 - x0) * ph;
     if (emit) return bytes + area * 10.0;

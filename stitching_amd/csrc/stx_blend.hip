@@ -53,7 +53,19 @@ STX_DEV float h5f(float s0, float s1, float s2, float s3, float s4)
     return fadd(fadd(fadd(fmul(s2, 6.f), fmul(fadd(s1, s3), 4.f)), s0), s4);
 }
 
-// pyrDown of (bordered level 0) -> level 1: G_1 planar int16, W_1 fp32
+// sample `idx` (row * stride + column, + channel * plane) of level lv of an image's Gaussian pyramid: bytes when the image was
+// fed as u8 (StxMbImage::g_u8), else int16
+STX_DEV int ld_g(const StxMbImage& im, int lv, long long idx)
+{
+    return im.g_u8 ? (int)reinterpret_cast<const uint8_t*>(im.g[lv])[idx] : (int)im.g[lv][idx];
+}
+STX_DEV void st_g(const StxMbImage& im, int lv, long long idx, int v)
+{
+    if (im.g_u8) reinterpret_cast<uint8_t*>(im.g[lv])[idx] = (uint8_t)v;
+    else im.g[lv][idx] = (short)v;
+}
+
+// pyrDown of (bordered level 0) -> level 1: G_1 planar (u8 / int16), W_1 fp32
 template <bool S16>
 __global__ __launch_bounds__(256) void mb_down0_kernel(StxMbImage im)
 {
@@ -87,10 +99,10 @@ __global__ __launch_bounds__(256) void mb_down0_kernel(StxMbImage im)
         vr[k] = r[2] * 6 + (r[1] + r[3]) * 4 + r[0] + r[4];
         vw[k] = h5f(w[0], w[1], w[2], w[3], w[4]);
     }
-    short* G = im.g[1] + (long long)y * im.g_stride[1] + x;
-    G[0] = (short)((vb[2] * 6 + (vb[1] + vb[3]) * 4 + vb[0] + vb[4] + 128) >> 8);
-    G[im.g_plane[1]] = (short)((vg[2] * 6 + (vg[1] + vg[3]) * 4 + vg[0] + vg[4] + 128) >> 8);
-    G[2 * im.g_plane[1]] = (short)((vr[2] * 6 + (vr[1] + vr[3]) * 4 + vr[0] + vr[4] + 128) >> 8);
+    const long long o = (long long)y * im.g_stride[1] + x;
+    st_g(im, 1, o, (vb[2] * 6 + (vb[1] + vb[3]) * 4 + vb[0] + vb[4] + 128) >> 8);
+    st_g(im, 1, o + im.g_plane[1], (vg[2] * 6 + (vg[1] + vg[3]) * 4 + vg[0] + vg[4] + 128) >> 8);
+    st_g(im, 1, o + 2 * im.g_plane[1], (vr[2] * 6 + (vr[1] + vr[3]) * 4 + vr[0] + vr[4] + 128) >> 8);
     im.wt[1][(long long)y * im.wt_stride[1] + x] = fmul(h5f(vw[0], vw[1], vw[2], vw[3], vw[4]), INV256);
 }
 
@@ -105,7 +117,6 @@ __global__ __launch_bounds__(256) void mb_down_kernel(StxMbImage im, int lv)
     int cx[5];
 #pragma unroll
     for (int j = 0; j < 5; j++) cx[j] = reflect101(2 * x - 2 + j, iw);
-    const short* G = im.g[lv];
     const long long gs = im.g_stride[lv], gp = im.g_plane[lv];
     const float* W = im.wt[lv];
     const long long ws = im.wt_stride[lv];
@@ -116,27 +127,29 @@ __global__ __launch_bounds__(256) void mb_down_kernel(StxMbImage im, int lv)
         int sy = reflect101(2 * y - 2 + k, ih);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const short* row = G + c * gp + (long long)sy * gs;
-            v[c][k] = row[cx[2]] * 6 + (row[cx[1]] + row[cx[3]]) * 4 + row[cx[0]] + row[cx[4]];
+            const long long row = c * gp + (long long)sy * gs;
+            v[c][k] = ld_g(im, lv, row + cx[2]) * 6 + (ld_g(im, lv, row + cx[1]) + ld_g(im, lv, row + cx[3])) * 4 + ld_g(im, lv, row + cx[0]) +
+                      ld_g(im, lv, row + cx[4]);
         }
         const float* wr = W + (long long)sy * ws;
         vw[k] = h5f(wr[cx[0]], wr[cx[1]], wr[cx[2]], wr[cx[3]], wr[cx[4]]);
     }
-    short* O = im.g[lv + 1] + (long long)y * im.g_stride[lv + 1] + x;
 #pragma unroll
     for (int c = 0; c < 3; c++)
-        O[c * im.g_plane[lv + 1]] = (short)((v[c][2] * 6 + (v[c][1] + v[c][3]) * 4 + v[c][0] + v[c][4] + 128) >> 8);
+        st_g(im, lv + 1, c * im.g_plane[lv + 1] + (long long)y * im.g_stride[lv + 1] + x,
+             (v[c][2] * 6 + (v[c][1] + v[c][3]) * 4 + v[c][0] + v[c][4] + 128) >> 8);
     im.wt[lv + 1][(long long)y * im.wt_stride[lv + 1] + x] = fmul(h5f(vw[0], vw[1], vw[2], vw[3], vw[4]), INV256);
 }
 
-// pyrUp_<FixPtCast<short,6>> sampled at one destination pixel (X, Y) of a planar int16 image
-STX_DEV int pyr_up_at(const short* __restrict__ plane, long long stride, int cw, int ch, int X, int Y)
+// pyrUp_<FixPtCast<short,6>> sampled at one destination pixel (X, Y) of a planar image (int16, or the bytes of a u8 pyramid)
+template <class T>
+STX_DEV int pyr_up_at(const T* __restrict__ plane, long long stride, int cw, int ch, int X, int Y)
 {
     const int px = X >> 1, py = Y >> 1;
     const int xl = up_idx(px - 1, cw), xr = up_idx(px + 1, cw);
     const int yt = up_idx(py - 1, ch), yb = up_idx(py + 1, ch);
-    const short* rc = plane + (long long)py * stride;
-    const short* rb = plane + (long long)yb * stride;
+    const T* rc = plane + (long long)py * stride;
+    const T* rb = plane + (long long)yb * stride;
     int hc, hb, v;
     if (X & 1) {
         hc = (rc[px] + rc[xr]) * 4;
@@ -148,11 +161,17 @@ STX_DEV int pyr_up_at(const short* __restrict__ plane, long long stride, int cw,
     if (Y & 1) {
         v = (hc + hb) * 4;
     } else {
-        const short* rt = plane + (long long)yt * stride;
+        const T* rt = plane + (long long)yt * stride;
         int ht = (X & 1) ? (rt[px] + rt[xr]) * 4 : rt[xl] + rt[px] * 6 + rt[xr];
         v = ht + hc * 6 + hb;
     }
     return (int)(short)((v + 32) >> 6);
+}
+// ... of channel c of level lv of an image's Gaussian pyramid
+STX_DEV int pyr_up_g(const StxMbImage& im, int lv, int c, int cw, int ch, int X, int Y)
+{
+    if (im.g_u8) return pyr_up_at(reinterpret_cast<const uint8_t*>(im.g[lv]) + c * im.g_plane[lv], im.g_stride[lv], cw, ch, X, Y);
+    return pyr_up_at(im.g[lv] + c * im.g_plane[lv], im.g_stride[lv], cw, ch, X, Y);
 }
 
 
@@ -173,15 +192,12 @@ STX_DEV void mb_level_body(const MbLevelK& P)
             const int lw = im.fw >> lv, lh = im.fh >> lv;
             if ((unsigned)lx >= (unsigned)lw || (unsigned)ly >= (unsigned)lh) continue;
             const float w = im.wt[lv][(long long)ly * im.wt_stride[lv] + lx];
-            const short* G = im.g[lv] + (long long)ly * im.g_stride[lv] + lx;
+            const long long gi = (long long)ly * im.g_stride[lv] + lx;
             int L[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                int gval = G[c * im.g_plane[lv]];
-                if (im.kind == 0 && lv < P.num_bands) {
-                    int u = pyr_up_at(im.g[lv + 1] + c * im.g_plane[lv + 1], im.g_stride[lv + 1], lw >> 1, lh >> 1, lx, ly);
-                    gval = sat_s16(gval - u);
-                }
+                int gval = ld_g(im, lv, gi + c * im.g_plane[lv]);
+                if (im.kind == 0 && lv < P.num_bands) gval = sat_s16(gval - pyr_up_g(im, lv + 1, c, lw >> 1, lh >> 1, lx, ly));
                 L[c] = gval;
             }
             if (im.kind == 1) {  // already (short)(L * W)
@@ -204,10 +220,7 @@ STX_DEV void mb_level_body(const MbLevelK& P)
             if (P.num_bands > 0) {
                 const int bx = x - im.fx, by = y - im.fy;
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    int u = pyr_up_at(im.g[1] + c * im.g_plane[1], im.g_stride[1], im.fw >> 1, im.fh >> 1, bx, by);
-                    L[c] = sat_s16(L[c] - u);
-                }
+                for (int c = 0; c < 3; c++) L[c] = sat_s16(L[c] - pyr_up_g(im, 1, c, im.fw >> 1, im.fh >> 1, bx, by));
             }
             acc0 += trunc_s16(fmul((float)L[0], w));
             acc1 += trunc_s16(fmul((float)L[1], w));
@@ -277,15 +290,12 @@ STX_DEV void mb_gather_norm(const StxMbImage* __restrict__ images, int n_images,
         const int lw = im.fw >> lv, lh = im.fh >> lv;
         if ((unsigned)lx >= (unsigned)lw || (unsigned)ly >= (unsigned)lh) continue;
         const float w = im.wt[lv][(long long)ly * im.wt_stride[lv] + lx];
-        const short* G = im.g[lv] + (long long)ly * im.g_stride[lv] + lx;
+        const long long gi = (long long)ly * im.g_stride[lv] + lx;
         int L[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            int gval = G[c * im.g_plane[lv]];
-            if (im.kind == 0 && lv < num_bands) {
-                int u = pyr_up_at(im.g[lv + 1] + c * im.g_plane[lv + 1], im.g_stride[lv + 1], lw >> 1, lh >> 1, lx, ly);
-                gval = sat_s16(gval - u);
-            }
+            int gval = ld_g(im, lv, gi + c * im.g_plane[lv]);
+            if (im.kind == 0 && lv < num_bands) gval = sat_s16(gval - pyr_up_g(im, lv + 1, c, lw >> 1, lh >> 1, lx, ly));
             L[c] = gval;
         }
         if (im.kind == 1) {  // already (short)(L * W)
@@ -454,8 +464,9 @@ int stx_launch_mb_pyramids(stx_ctx* ctx, const StxMbImage* d_images, const StxMb
         for (int i = 0; i < n; i++) {
             const StxMbImage& im = h_images[i];
             const double ip = (double)(im.fw >> lv) * (im.fh >> lv), op = ip / 4.0;
-            if (lv == 0) bytes += ((im.img0_is_s16 ? 6.0 : 3.0) + 1.0) * im.iw * im.ih + 10.0 * op;
-            else bytes += 10.0 * ip + 10.0 * op;
+            const double gw = (im.g_u8 ? 3.0 : 6.0) + 4.0;  // bytes per pyramid sample: 3 Gaussian planes (bytes / int16) + the fp32 weight
+            if (lv == 0) bytes += ((im.img0_is_s16 ? 6.0 : 3.0) + 1.0) * im.iw * im.ih + gw * op;
+            else bytes += gw * ip + gw * op;
             any_s16 = any_s16 || im.img0_is_s16;
         }
         StxProfScope prof(ctx, lv == 0 ? "mb_down0" : "mb_down", bytes);

@@ -100,31 +100,66 @@ STX_DEV UpRow up_row_window(const STX_GAS short* __restrict__ row, uint32_t boff
     return r;
 }
 
-// pyrUp_<FixPtCast<short,6>> of one plane holding values 0..255 for the 8x2 patch with coarse origin (cx, cy).
-// cy (and with it the three row pointers) is wave-uniform: a wavefront owns two panorama rows.
 // pyrUp_'s row rule (up_idx: -1 -> 1, or 0 when there is one row; n -> n - 1) for i >= -1, as scalar-unit arithmetic
 STX_DEV int up_idx_s(int i, int n) { return min(abs(i), n - 1); }
 // first sample of row `r` of a plane, held in SGPRs: the loads below then take the scalar base + 32-bit lane offset form
-// (the empty asm keeps the compiler from folding the lane offset into a 64-bit vector address first)
+// (the empty asm keeps the compiler from folding the lane offset into a 64-bit vector address first; it is not volatile: a
+// side-effecting asm counts as a memory clobber and turns every scalar descriptor load after it into a vector load).
+// readfirstlane of a value the compiler already knows to be uniform folds away; where it does not know — argument blocks read
+// through a pointer — it is what makes the value scalar.
 STX_DEV const STX_GAS short* row_ptr_s(const STX_GAS short* plane, int r, uint32_t stride)
 {
-    // (readfirstlane of a value the compiler already knows to be uniform folds away; where it does not know — argument blocks
-    // read through a pointer — it is what makes the value scalar)
     const unsigned long long a = (unsigned long long)(plane + (size_t)((uint32_t)r * stride));
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
     const STX_GAS short* row = (const STX_GAS short*)(((unsigned long long)hi << 32) | lo);
-    asm("" : "+s"(row));  // not volatile: a side-effecting asm counts as a memory clobber and turns every scalar descriptor load after it into a vector load
+    asm("" : "+s"(row));
     return row;
 }
 
-STX_DEV void up_patch_pk(const STX_GAS short* __restrict__ plane, uint32_t stride, int ch, uint32_t boff, int cy, UpSel sel, pk16 up[2][4])
+// The same six samples from a plane of BYTES (the Gaussian levels of u8 images, StxMbImage::g_u8): one dword-aligned 12-byte load
+// of plane[cx - 4 .. cx + 7] — (., ., ., c0) (c1, c2, c3, c4) (c5, ., ., .) — and five v_perm that widen the bytes to the 16-bit
+// pairs; the border rule again lives in two selectors.  Half the bytes of the int16 window (and two registers less per load),
+// two VALU more.  boff: byte offset of sample cx in the row (= cx).
+typedef uint32_t v3u __attribute__((ext_vector_type(3)));
+typedef v3u __attribute__((aligned(4))) v3u_a4;
+STX_DEV UpSel up_sel_u8(bool left_edge, bool right_edge)
+{
+    UpSel s;
+    s.a0 = left_edge ? 0x0c040c05u : 0x0c040c03u;   // perm(d1, d0): (c2, c1) at the left edge, else (c0, c1)
+    s.a2 = right_edge ? 0x0c030c03u : 0x0c040c03u;  // perm(d2, d1): (c4, c4) at the right edge, else (c4, c5)
+    return s;
+}
+STX_DEV UpRow up_row_window_u8(const STX_GAS uint8_t* __restrict__ row, uint32_t boff, UpSel sel)
+{
+    const STX_GAS uint8_t* q = row + (size_t)boff;
+    const v3u w = *reinterpret_cast<const STX_GAS v3u_a4*>(q - 4);
+    UpRow r;
+    r.A0 = __builtin_amdgcn_perm(w.y, w.x, sel.a0);
+    r.B0 = __builtin_amdgcn_perm(w.y, w.y, 0x0c010c00u);
+    r.A1 = __builtin_amdgcn_perm(w.y, w.y, 0x0c020c01u);
+    r.B1 = __builtin_amdgcn_perm(w.y, w.y, 0x0c030c02u);
+    r.A2 = __builtin_amdgcn_perm(w.z, w.y, sel.a2);
+    return r;
+}
+STX_DEV const STX_GAS uint8_t* row_ptr_s(const STX_GAS uint8_t* plane, int r, uint32_t stride)
+{
+    const unsigned long long a = (unsigned long long)(plane + (size_t)((uint32_t)r * stride));
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    const STX_GAS uint8_t* row = (const STX_GAS uint8_t*)(((unsigned long long)hi << 32) | lo);
+    asm("" : "+s"(row));
+    return row;
+}
+
+// pyrUp_<FixPtCast<short,6>> of one byte plane (values 0..255) for the 8x2 patch with coarse origin (cx, cy).
+// cy (and with it the three row pointers) is wave-uniform: a wavefront owns two panorama rows.  boff = cx, sel = up_sel_u8(...).
+STX_DEV void up_patch_pk(const STX_GAS uint8_t* __restrict__ plane, uint32_t stride, int ch, uint32_t boff, int cy, UpSel sel, pk16 up[2][4])
 {
     const int rr[3] = {up_idx_s(cy - 1, ch), cy, up_idx_s(cy + 1, ch)};
     pk16 HE[3][2], HO[3][2];
     asm("" : "+v"(boff));  // the zero-extension of the lane offset stays in this block: scalar base + 32-bit lane offset loads
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        const UpRow t = up_row_window(row_ptr_s(plane, rr[r], stride), boff, sel);
+        const UpRow t = up_row_window_u8(row_ptr_s(plane, rr[r], stride), boff, sel);
         HE[r][0] = pk(t.A0) + pk(t.B0) * pk_splat(6) + pk(t.A1);            // c[j] + 6 c[j+1] + c[j+2], j = 0,1
         HE[r][1] = pk(t.A1) + pk(t.B1) * pk_splat(6) + pk(t.A2);            // j = 2,3
         HO[r][0] = pk(t.B0) + pk(t.A1);                                     // c[j+1] + c[j+2] (the factor 4 is folded below)
@@ -137,6 +172,20 @@ STX_DEV void up_patch_pk(const STX_GAS short* __restrict__ plane, uint32_t strid
         up[1][k] = (HE[1][k] + HE[2][k] + pk_splat(8)) >> pk_splat(4);
         up[1][2 + k] = (HO[1][k] + HO[2][k] + pk_splat(2)) >> pk_splat(2);
     }
+}
+// byte plane c of level lv of a u8 pyramid
+STX_DEV const STX_GAS uint8_t* g8(const StxMbImage& im, int lv, int c)
+{
+    return gp(reinterpret_cast<const uint8_t*>(im.g[lv])) + c * im.g_plane[lv];
+}
+// the 8 samples at (row r, column x0) of a byte plane as the pyrUp pair order (0,2)(4,6)(1,3)(5,7), zero-extended to 16 bits
+STX_DEV void g8_row_pairs(const STX_GAS uint8_t* plane, int r, uint32_t stride, uint32_t x0, uint32_t (&q)[4])
+{
+    const v2u gv = *reinterpret_cast<const STX_GAS v2u*>(row_ptr_s(plane, r, stride) + (size_t)x0);
+    q[0] = __builtin_amdgcn_perm(gv.x, gv.x, 0x0c020c00u);
+    q[1] = __builtin_amdgcn_perm(gv.y, gv.y, 0x0c020c00u);
+    q[2] = __builtin_amdgcn_perm(gv.x, gv.x, 0x0c030c01u);
+    q[3] = __builtin_amdgcn_perm(gv.y, gv.y, 0x0c030c01u);
 }
 
 
@@ -188,7 +237,7 @@ constexpr int LV_BAND = 4;  // same for the 512 x 8 tiles of the level kernels
 template <bool PK>
 STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, short* hs1, short* hs2, float* hw)
 {
-    const int by = reflect101(row, im.fh) - im.top;  // bordered row -> image row
+    const int by = reflect101_near(row, im.fh) - im.top;  // bordered row -> image row
     const bool yin = (unsigned)by < (unsigned)im.ih;
     const int sy = reflect(by, im.ih);
     const uint8_t* irow = im.img0 + (long long)sy * im.img0_stride;
@@ -276,7 +325,7 @@ STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, s
     } else {
 #pragma unroll
         for (int j = 0; j < 11; j++) {
-            const int bx = reflect101(c0 + j, im.fw) - im.left;
+            const int bx = reflect101_near(c0 + j, im.fw) - im.left;
             const uint8_t* p = irow + reflect(bx, im.iw) * 3;
             px[j][0] = p[0]; px[j][1] = p[1]; px[j][2] = p[2];
             f[j] = (yin && (unsigned)bx < (unsigned)im.iw)
@@ -347,9 +396,11 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
 #pragma unroll
             for (int k = 0; k < 5; k++) a[k] = pk(*reinterpret_cast<const uint32_t*>(&s_h[c][2 * yl + k][2 * p]));
             const pk16 v = (a[0] + a[4] + a[2] * pk_splat(6) + (a[1] + a[3]) * pk_splat(4) + pk_splat(128)) >> pk_splat(8);
-            short* o = im.g[1] + c * im.g_plane[1] + (long long)y * im.g_stride[1] + xo;
-            if (two) *reinterpret_cast<uint32_t*>(o) = unpk(v);
-            else o[0] = (short)(unpk(v) & 0xffffu);
+            // G_1 of a u8 image is <= 255: one byte per sample (StxMbImage::g_u8)
+            uint8_t* o = reinterpret_cast<uint8_t*>(im.g[1]) + c * im.g_plane[1] + (long long)y * im.g_stride[1] + xo;
+            const uint32_t b2 = __builtin_amdgcn_perm(0u, unpk(v), 0x0c0c0200u);
+            if (two) *reinterpret_cast<uint16_t*>(o) = (uint16_t)b2;
+            else o[0] = (uint8_t)b2;
         }
         float fa[5], fb[5];
         {
@@ -375,6 +426,22 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
     dn_note_occ(occ, nz, tid, X0, Y0, ow, oh);
 }
 
+// level >= 1 of a byte pyramid: the 19 samples p[c0 .. c0 + 18], c0 = 16 t - 2: dword, 16 bytes, dword around them
+STX_DEV void dn_load19_u8(const uint8_t* __restrict__ p, int c0, int iw, bool fast, int s[19])
+{
+    if (fast) {
+        const uint32_t a = *reinterpret_cast<const uint32_t*>(p + c0 - 2);
+        const uint4 b = *reinterpret_cast<const uint4*>(p + c0 + 2);
+        const uint32_t c = *reinterpret_cast<const uint32_t*>(p + c0 + 18);
+        const uint32_t w[6] = {a, b.x, b.y, b.z, b.w, c};
+#pragma unroll
+        for (int j = 0; j < 19; j++) s[j] = (int)byte_of(w, j + 2);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 19; j++) s[j] = p[reflect101_near(c0 + j, iw)];
+    }
+}
+
 // level >= 1 (planar int16 x3 + fp32): 8 outputs from 19 input elements per plane
 STX_DEV void dn_load19_s16(const short* __restrict__ p, int c0, int iw, bool fast, int s[19])
 {
@@ -390,7 +457,7 @@ STX_DEV void dn_load19_s16(const short* __restrict__ p, int c0, int iw, bool fas
         s[18] = p[c0 + 18];
     } else {
 #pragma unroll
-        for (int j = 0; j < 19; j++) s[j] = p[reflect101(c0 + j, iw)];
+        for (int j = 0; j < 19; j++) s[j] = p[reflect101_near(c0 + j, iw)];
     }
 }
 
@@ -407,6 +474,7 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
     const int X0 = tile_tx * DN_TOW, Y0 = tile_ty * DN_TOH;
     if (X0 >= ow || Y0 >= oh) return;
     const short* G = im.g[lv];
+    const bool g8b = im.g_u8 != 0;  // byte planes (u8 image) or int16 planes: uniform for the workgroup
     const long long gs = im.g_stride[lv], gp = im.g_plane[lv];
     uint8_t* const occ = im.occ[lv + 1];
     asm volatile("" ::"s"(occ));  // as in the level-0 kernel
@@ -414,13 +482,14 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
     for (int task = tid; task < DN_ROWS * (DN_TOW / 8); task += 256) {
         const int r = task / (DN_TOW / 8), q = task % (DN_TOW / 8);
         if (X0 + 8 * q >= ow || r >= r_end) continue;
-        const int sy = reflect101(2 * Y0 - 2 + r, ih);
+        const int sy = reflect101_near(2 * Y0 - 2 + r, ih);
         const int c0 = 2 * (X0 + 8 * q) - 2;
         const bool fast = c0 >= 0 && c0 + 18 < iw;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             int s[19];
-            dn_load19_s16(G + c * gp + (long long)sy * gs, c0, iw, fast, s);
+            if (g8b) dn_load19_u8(reinterpret_cast<const uint8_t*>(G) + c * gp + (long long)sy * gs, c0, iw, fast, s);
+            else dn_load19_s16(G + c * gp + (long long)sy * gs, c0, iw, fast, s);
             int4 lo, hi;
             lo.x = h5i(s[0], s[1], s[2], s[3], s[4]);
             lo.y = h5i(s[2], s[3], s[4], s[5], s[6]);
@@ -451,7 +520,7 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
             f[18] = wq[c0 + 18];
         } else {
 #pragma unroll
-            for (int j = 0; j < 19; j++) f[j] = wq[reflect101(c0 + j, iw)];
+            for (int j = 0; j < 19; j++) f[j] = wq[reflect101_near(c0 + j, iw)];
         }
         float4 lo, hi;
         lo.x = h5f(f[0], f[1], f[2], f[3], f[4]);
@@ -485,9 +554,15 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
             }
             const int va = (h5i(a[0], a[1], a[2], a[3], a[4]) + 128) >> 8;
             const int vb = (h5i(b[0], b[1], b[2], b[3], b[4]) + 128) >> 8;
-            short* o = im.g[lv + 1] + c * im.g_plane[lv + 1] + (long long)y * im.g_stride[lv + 1] + xo;
-            if (two) *reinterpret_cast<uint32_t*>(o) = pack16(va, vb);
-            else o[0] = (short)va;
+            if (g8b) {
+                uint8_t* o = reinterpret_cast<uint8_t*>(im.g[lv + 1]) + c * im.g_plane[lv + 1] + (long long)y * im.g_stride[lv + 1] + xo;
+                if (two) *reinterpret_cast<uint16_t*>(o) = (uint16_t)((uint32_t)va | ((uint32_t)vb << 8));
+                else o[0] = (uint8_t)va;
+            } else {
+                short* o = im.g[lv + 1] + c * im.g_plane[lv + 1] + (long long)y * im.g_stride[lv + 1] + xo;
+                if (two) *reinterpret_cast<uint32_t*>(o) = pack16(va, vb);
+                else o[0] = (short)va;
+            }
         }
         float fa[5], fb[5];
 #pragma unroll
@@ -517,21 +592,33 @@ STX_DEV int s6(int v) { return (v + 32) >> 6; }
 STX_DEV int trunc_small(float v) { return (int)v; }
 
 // pyrUp_<FixPtCast<short,6>> of one plane for the 8x2 patch whose coarse origin is (cx, cy);
-// cx is a multiple of 4 and cx+3 < cw
-STX_DEV void up_patch(const short* __restrict__ plane, long long stride, int cw, int ch, int cx, int cy, int up[2][8])
+// cx is a multiple of 4 and cx+3 < cw.  T = short: an int16 plane (finished levels, the pyramids of int16 images);
+// T = uint8_t: a byte plane (the pyramids of u8 images)
+template <class T>
+STX_DEV void up_patch(const T* __restrict__ plane, long long stride, int cw, int ch, int cx, int cy, int up[2][8])
 {
     const int rr[3] = {up_idx(cy - 1, ch), cy, up_idx(cy + 1, ch)};
     const bool le = cx == 0, re = cx + 4 >= cw;  // pyrUp's border rule: column -1 -> 1, column cw -> cw - 1
     int he[3][4], ho[3][4];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        const short* p = plane + (long long)rr[r] * stride;
+        const T* p = plane + (long long)rr[r] * stride;
         int c[6];
-        // one dword-aligned 16-byte window plane[cx - 2 .. cx + 5] instead of an 8-byte load and two single samples
-        const v4u w = *reinterpret_cast<const v4u_a4*>(p + cx - 2);
-        c[1] = s16lo(w.y); c[2] = s16hi(w.y); c[3] = s16lo(w.z); c[4] = s16hi(w.z);
-        c[0] = le ? c[2] : s16hi(w.x);
-        c[5] = re ? c[4] : s16lo(w.w);
+        if (sizeof(T) == 2) {
+            // one dword-aligned 16-byte window plane[cx - 2 .. cx + 5] instead of an 8-byte load and two single samples
+            const v4u w = *reinterpret_cast<const v4u_a4*>(p + cx - 2);
+            c[1] = s16lo(w.y); c[2] = s16hi(w.y); c[3] = s16lo(w.z); c[4] = s16hi(w.z);
+            c[0] = s16hi(w.x);
+            c[5] = s16lo(w.w);
+        } else {
+            // bytes: one dword-aligned 12-byte window plane[cx - 4 .. cx + 7]
+            const v3u w = *reinterpret_cast<const v3u_a4*>(p + cx - 4);
+            c[0] = (int)(w.x >> 24);
+            c[1] = (int)(w.y & 255u); c[2] = (int)((w.y >> 8) & 255u); c[3] = (int)((w.y >> 16) & 255u); c[4] = (int)(w.y >> 24);
+            c[5] = (int)(w.z & 255u);
+        }
+        if (le) c[0] = c[2];
+        if (re) c[5] = c[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             he[r][j] = c[j] + 6 * c[j + 1] + c[j + 2];
@@ -730,18 +817,14 @@ STX_DEV void mb_level_fast_body(const MbLevelK& P)
                 for (int c = 0; c < 3; c++) {
                     if (U8SRC && !contrib) {
                         pk16 upk[2][4];
-                        up_patch_pk(gp(im.g[lv + 1]) + c * im.g_plane[lv + 1], (uint32_t)im.g_stride[lv + 1], lh >> 1,
-                                    (uint32_t)(lx0 >> 1) * 2u, ly0 >> 1, up_sel(lx0 == 0, (lx0 >> 1) + 4 >= (lw >> 1)), upk);
+                        up_patch_pk(g8(im, lv + 1, c), (uint32_t)im.g_stride[lv + 1], lh >> 1, (uint32_t)(lx0 >> 1), ly0 >> 1,
+                                    up_sel_u8(lx0 == 0, (lx0 >> 1) + 4 >= (lw >> 1)), upk);
 #pragma unroll
                         for (int r = 0; r < 2; r++) {
-                            const v4u gv = *reinterpret_cast<const STX_GAS v4u*>(
-                                gp(im.g[lv]) + c * im.g_plane[lv] + ((uint32_t)(ly0 + r) * (uint32_t)im.g_stride[lv] + (uint32_t)lx0));
-                            // natural pairs (0,1)(2,3)(4,5)(6,7) -> the pyrUp pair order (0,2)(4,6)(1,3)(5,7)
-                            const uint32_t Lq[4] = {
-                                unpk(pk(__builtin_amdgcn_perm(gv.y, gv.x, 0x05040100u)) - upk[r][0]),
-                                unpk(pk(__builtin_amdgcn_perm(gv.w, gv.z, 0x05040100u)) - upk[r][1]),
-                                unpk(pk(__builtin_amdgcn_perm(gv.y, gv.x, 0x07060302u)) - upk[r][2]),
-                                unpk(pk(__builtin_amdgcn_perm(gv.w, gv.z, 0x07060302u)) - upk[r][3])};
+                            uint32_t gq[4];  // the pyrUp pair order (0,2)(4,6)(1,3)(5,7)
+                            g8_row_pairs(g8(im, lv, c), ly0 + r, (uint32_t)im.g_stride[lv], (uint32_t)lx0, gq);
+                            const uint32_t Lq[4] = {unpk(pk(gq[0]) - upk[r][0]), unpk(pk(gq[1]) - upk[r][1]), unpk(pk(gq[2]) - upk[r][2]),
+                                                    unpk(pk(gq[3]) - upk[r][3])};
 #pragma unroll
                             for (int j = 0; j < 8; j++) {
                                 const int q = (j & 1) ? 2 + (j >> 2) : (j >> 2);
@@ -751,18 +834,34 @@ STX_DEV void mb_level_fast_body(const MbLevelK& P)
                         }
                         continue;
                     }
+                    // images of either kind: the pyramid of a u8 image is bytes, that of an int16 image (and a received contribution
+                    // strip) int16 — a wave-uniform branch per image
+                    const bool g8b = !contrib && im.g_u8 != 0;
                     int up[2][8];
-                    if (!contrib)
-                        up_patch(im.g[lv + 1] + c * im.g_plane[lv + 1], im.g_stride[lv + 1], lw >> 1, lh >> 1, lx0 >> 1,
-                                 ly0 >> 1, up);
+                    if (!contrib) {
+                        if (g8b) up_patch(reinterpret_cast<const uint8_t*>(im.g[lv + 1]) + c * im.g_plane[lv + 1], im.g_stride[lv + 1], lw >> 1,
+                                          lh >> 1, lx0 >> 1, ly0 >> 1, up);
+                        else up_patch(im.g[lv + 1] + c * im.g_plane[lv + 1], im.g_stride[lv + 1], lw >> 1, lh >> 1, lx0 >> 1, ly0 >> 1, up);
+                    }
 #pragma unroll
                     for (int r = 0; r < 2; r++) {
-                        const short* grow = im.g[lv] + c * im.g_plane[lv] + (long long)(ly0 + r) * im.g_stride[lv] + lx0;
-                        uint4 gv = *reinterpret_cast<const uint4*>(grow);
-                        const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w};
+                        int gs8[8];
+                        if (g8b) {
+                            const uint2 gb = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(im.g[lv]) + c * im.g_plane[lv] +
+                                                                             (long long)(ly0 + r) * im.g_stride[lv] + lx0);
+                            const uint32_t gw2[2] = {gb.x, gb.y};
+#pragma unroll
+                            for (int j = 0; j < 8; j++) gs8[j] = (int)byte_of(gw2, j);
+                        } else {
+                            const short* grow = im.g[lv] + c * im.g_plane[lv] + (long long)(ly0 + r) * im.g_stride[lv] + lx0;
+                            uint4 gv = *reinterpret_cast<const uint4*>(grow);
+                            const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+                            for (int j = 0; j < 8; j++) gs8[j] = (j & 1) ? s16hi(gw[j >> 1]) : s16lo(gw[j >> 1]);
+                        }
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
-                            int g = (j & 1) ? s16hi(gw[j >> 1]) : s16lo(gw[j >> 1]);
+                            int g = gs8[j];
                             if (contrib) {
                                 acc[r][j][c] += g;
                             } else {
@@ -836,8 +935,8 @@ STX_DEV void mb_level_fast_body(const MbLevelK& P)
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     pk16 upk[2][4];
-                    up_patch_pk(gp(im.g[1]) + c * im.g_plane[1], (uint32_t)im.g_stride[1], im.fh >> 1, (uint32_t)((X0 - im.fx) >> 1) * 2u,
-                                (Y0 - im.fy) >> 1, up_sel(X0 == im.fx, ((X0 - im.fx) >> 1) + 4 >= (im.fw >> 1)), upk);
+                    up_patch_pk(g8(im, 1, c), (uint32_t)im.g_stride[1], im.fh >> 1, (uint32_t)((X0 - im.fx) >> 1),
+                                (Y0 - im.fy) >> 1, up_sel_u8(X0 == im.fx, ((X0 - im.fx) >> 1) + 4 >= (im.fw >> 1)), upk);
 #pragma unroll
                     for (int r = 0; r < 2; r++) {
                         uint32_t px[4];
@@ -872,9 +971,11 @@ STX_DEV void mb_level_fast_body(const MbLevelK& P)
                 int up[3][2][8];
                 if (P.num_bands > 0) {
 #pragma unroll
-                    for (int c = 0; c < 3; c++)
-                        up_patch(im.g[1] + c * im.g_plane[1], im.g_stride[1], im.fw >> 1, im.fh >> 1, (X0 - im.fx) >> 1,
-                                 (Y0 - im.fy) >> 1, up[c]);
+                    for (int c = 0; c < 3; c++) {
+                        if (im.g_u8) up_patch(reinterpret_cast<const uint8_t*>(im.g[1]) + c * im.g_plane[1], im.g_stride[1], im.fw >> 1, im.fh >> 1,
+                                              (X0 - im.fx) >> 1, (Y0 - im.fy) >> 1, up[c]);
+                        else up_patch(im.g[1] + c * im.g_plane[1], im.g_stride[1], im.fw >> 1, im.fh >> 1, (X0 - im.fx) >> 1, (Y0 - im.fy) >> 1, up[c]);
+                    }
                 }
                 const bool fastx = lx0 >= 0 && lx0 + 8 <= im.iw;
 #pragma unroll
@@ -1267,8 +1368,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVE
                 }
             }
             // (no early-out on an all-zero mask: it would put the G_1 loads behind the mask loads' round trip)
-            const uint32_t g1_boff = (uint32_t)((X0 - im.fx) >> 1) * 2u;  // this lane's samples of G_1: byte offset in a row
-            const UpSel g1_sel = up_sel(X0 == im.fx, ((X0 - im.fx) >> 1) + 4 >= (im.fw >> 1));
+            const uint32_t g1_boff = (uint32_t)((X0 - im.fx) >> 1);  // this lane's samples of G_1 (bytes): offset in a row
+            const UpSel g1_sel = up_sel_u8(X0 == im.fx, ((X0 - im.fx) >> 1) + 4 >= (im.fw >> 1));
             uint32_t M[2][4];
 #pragma unroll
             for (int r = 0; r < 2; r++) {
@@ -1285,7 +1386,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVE
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 pk16 up[2][4];
-                up_patch_pk(gp(im.g[1]) + c * im.g_plane[1], (uint32_t)im.g_stride[1], im.fh >> 1, g1_boff, (Y0 - im.fy) >> 1, g1_sel, up);
+                up_patch_pk(g8(im, 1, c), (uint32_t)im.g_stride[1], im.fh >> 1, g1_boff, (Y0 - im.fy) >> 1, g1_sel, up);
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
                     uint32_t px[4];
@@ -1396,23 +1497,20 @@ __global__ __launch_bounds__(256) void mb_level_pk_kernel(MbLevelK P)
             lo = min(lo, wb[1][7]);
             const bool all1 = lo == 0x3f800000u;
             const bool wave_all1 = __ballot(!all1) == 0ull;  // over the lanes that reached this point
-            const uint32_t g1_boff = (uint32_t)(lx0 >> 1) * 2u;
-            const UpSel g1_sel = up_sel(lx0 == 0, (lx0 >> 1) + 4 >= (lw >> 1));
+            const uint32_t g1_boff = (uint32_t)(lx0 >> 1);
+            const UpSel g1_sel = up_sel_u8(lx0 == 0, (lx0 >> 1) + 4 >= (lw >> 1));
             if (wave_all1) {
                 ones += 1u;
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     pk16 upk[2][4];
-                    up_patch_pk(gp(im.g[lv + 1]) + c * im.g_plane[lv + 1], (uint32_t)im.g_stride[lv + 1], lh >> 1, g1_boff, ly0 >> 1, g1_sel, upk);
+                    up_patch_pk(g8(im, lv + 1, c), (uint32_t)im.g_stride[lv + 1], lh >> 1, g1_boff, ly0 >> 1, g1_sel, upk);
 #pragma unroll
                     for (int r = 0; r < 2; r++) {
-                        const v4u gv = *reinterpret_cast<const STX_GAS v4u*>(reinterpret_cast<const STX_GAS char*>(
-                            row_ptr_s(gp(im.g[lv]) + c * im.g_plane[lv], ly0 + r, (uint32_t)im.g_stride[lv])) + (size_t)((uint32_t)lx0 * 2u));
-                        // natural pairs (0,1)(2,3)(4,5)(6,7) -> the pyrUp pair order (0,2)(4,6)(1,3)(5,7); L in [-255, 255]
-                        acc[r][c][0] = unpk(pk(acc[r][c][0]) + (pk(__builtin_amdgcn_perm(gv.y, gv.x, 0x05040100u)) - upk[r][0]));
-                        acc[r][c][1] = unpk(pk(acc[r][c][1]) + (pk(__builtin_amdgcn_perm(gv.w, gv.z, 0x05040100u)) - upk[r][1]));
-                        acc[r][c][2] = unpk(pk(acc[r][c][2]) + (pk(__builtin_amdgcn_perm(gv.y, gv.x, 0x07060302u)) - upk[r][2]));
-                        acc[r][c][3] = unpk(pk(acc[r][c][3]) + (pk(__builtin_amdgcn_perm(gv.w, gv.z, 0x07060302u)) - upk[r][3]));
+                        uint32_t gq[4];  // the pyrUp pair order (0,2)(4,6)(1,3)(5,7); L in [-255, 255]
+                        g8_row_pairs(g8(im, lv, c), ly0 + r, (uint32_t)im.g_stride[lv], (uint32_t)lx0, gq);
+#pragma unroll
+                        for (int q = 0; q < 4; q++) acc[r][c][q] = unpk(pk(acc[r][c][q]) + (pk(gq[q]) - upk[r][q]));
                     }
                 }
 #pragma unroll
@@ -1432,16 +1530,13 @@ __global__ __launch_bounds__(256) void mb_level_pk_kernel(MbLevelK P)
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 pk16 upk[2][4];
-                up_patch_pk(gp(im.g[lv + 1]) + c * im.g_plane[lv + 1], (uint32_t)im.g_stride[lv + 1], lh >> 1, g1_boff, ly0 >> 1, g1_sel, upk);
+                up_patch_pk(g8(im, lv + 1, c), (uint32_t)im.g_stride[lv + 1], lh >> 1, g1_boff, ly0 >> 1, g1_sel, upk);
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
-                    const v4u gv = *reinterpret_cast<const STX_GAS v4u*>(reinterpret_cast<const STX_GAS char*>(
-                        row_ptr_s(gp(im.g[lv]) + c * im.g_plane[lv], ly0 + r, (uint32_t)im.g_stride[lv])) + (size_t)((uint32_t)lx0 * 2u));
-                    const uint32_t Lq[4] = {
-                        unpk(pk(__builtin_amdgcn_perm(gv.y, gv.x, 0x05040100u)) - upk[r][0]),
-                        unpk(pk(__builtin_amdgcn_perm(gv.w, gv.z, 0x05040100u)) - upk[r][1]),
-                        unpk(pk(__builtin_amdgcn_perm(gv.y, gv.x, 0x07060302u)) - upk[r][2]),
-                        unpk(pk(__builtin_amdgcn_perm(gv.w, gv.z, 0x07060302u)) - upk[r][3])};
+                    uint32_t gq[4];
+                    g8_row_pairs(g8(im, lv, c), ly0 + r, (uint32_t)im.g_stride[lv], (uint32_t)lx0, gq);
+                    const uint32_t Lq[4] = {unpk(pk(gq[0]) - upk[r][0]), unpk(pk(gq[1]) - upk[r][1]), unpk(pk(gq[2]) - upk[r][2]),
+                                            unpk(pk(gq[3]) - upk[r][3])};
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         // pair q holds the pixels (jl, jh): q = 0: (0, 2), 1: (4, 6), 2: (1, 3), 3: (5, 7)

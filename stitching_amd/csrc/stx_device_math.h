@@ -364,11 +364,25 @@ STX_DEV int reflect(int p, int len)
 STX_DEV int reflect101(int p, int len)
 {
     if ((unsigned)p < (unsigned)len) return p;
+    // one mirror image away (every border tap of a 5-tap stencil on a level wider than 2 samples): no division.  The modulo form
+    // below costs ~45 instructions per call; unrolled 19 x 4 times in the border path of the pyrDown kernels it made every
+    // workgroup on an image edge take 15 us (round 3: the coarse pyramid levels are nothing but edge workgroups)
+    const int q = p < 0 ? -p : 2 * len - 2 - p;
+    if ((unsigned)q < (unsigned)len) return q;
     if (len == 1) return 0;
     int period = 2 * len - 2;
     int m = p % period;
     if (m < 0) m += period;
     return m < len ? m : period - m;
+}
+// reflect101 for taps at most one mirror image away (-(len - 1) <= p <= 2 len - 2), branch-free; any other p gives SOME index
+// inside [0, len) (the LDS pyrDown kernels evaluate whole groups of 4 / 8 outputs and read — never use — the taps of the outputs
+// past the image).  Exact for every tap of a 5-tap stencil centred on 2 x, x < len / 2, len >= 2.
+STX_DEV int reflect101_near(int p, int len)
+{
+    const int a = abs(p);
+    const int b = a >= len ? 2 * len - 2 - a : a;
+    return max(b, 0);
 }
 // pyrUp_ index rule on both axes: -1 -> 1 (0 when n == 1), n -> n-1
 STX_DEV int up_idx(int i, int n) { return i < 0 ? (n > 1 ? 1 : 0) : (i >= n ? n - 1 : i); }

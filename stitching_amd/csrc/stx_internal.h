@@ -159,7 +159,10 @@ struct StxMbImage {  // device-visible descriptor of one fed image (all levels)
     int ix, iy;            // image corner relative to the (padded) panorama roi
     int fx, fy, fw, fh;    // feed rect (tl_new .. br_new) relative to the panorama roi, level 0
     int left, top;         // copyMakeBorder offsets: bordered(x,y) = img(reflect(x-left), reflect(y-top))
-    // levels 1..B: planar int16 Gaussian pyramid (3 planes) and fp32 weight pyramid
+    // levels 1..B: planar Gaussian pyramid (3 planes) and fp32 weight pyramid.  g_u8 = 1 (every image fed as u8: all values are
+    // 0..255): the planes hold one BYTE per sample — g[] then points to bytes, g_stride / g_plane count samples either way.  int16
+    // images (and received contribution strips, kind 1) keep int16 planes.  64 readable bytes in front of every allocation.
+    int g_u8;
     short* g[STX_MAX_BANDS + 1]; long long g_stride[STX_MAX_BANDS + 1]; long long g_plane[STX_MAX_BANDS + 1];
     float* wt[STX_MAX_BANDS + 1]; long long wt_stride[STX_MAX_BANDS + 1];
     // occupancy of the weight pyramid (null: not recorded): occ[i][p * nt + t] != 0 iff W_i has a non-zero value in the rows
