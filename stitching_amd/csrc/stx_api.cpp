@@ -332,9 +332,10 @@ int stx_buf_new(stx_ctx* ctx, int w, int h, int c, int elem, stx_buf** out)
     b->w = w; b->h = h; b->c = c; b->elem = elem;
     // rows are 64-byte aligned and hold a whole number of 8-pixel groups (kernels store 4 or 8 px per lane)
     b->stride = align_up(align_up((size_t)w, 8) * c * stx_elem_bytes(elem), 64);
-    // + 64: the gather kernels read whole dwords around the last pixels of the last row
-    STX_TRY(stx_dev_alloc(ctx, b->stride * h + 64, &b->base));
-    b->ptr = (uint8_t*)b->base;
+    // 64 bytes in front and 64 behind: the gather kernels read whole aligned windows around the first / last pixels of a row —
+    // also where an 8-pixel group of a lane lies partly left of the image (up to 21 bytes before row 0), see mb_level0_pk_kernel
+    STX_TRY(stx_dev_alloc(ctx, STX_BUF_FRONT_PAD + b->stride * h + 64, &b->base));
+    b->ptr = (uint8_t*)b->base + STX_BUF_FRONT_PAD;
     *out = b.release();
     return STX_OK;
 }

@@ -206,6 +206,48 @@ STX_DEV uint32_t pair_mask(const uint32_t* m)
 
 
 
+
+// bytes 0xff where pixel j (0..7) of a lane's strip starting at image column lx0 lies inside the image: all ones for the wavefronts
+// that hold no partial lane (one ballot), else bit j -> byte j by multiplication
+STX_DEV void lane_valid_bytes(int lx0, int iw, uint32_t& vm0, uint32_t& vm1)
+{
+    vm0 = vm1 = 0xffffffffu;
+    if (__builtin_amdgcn_ballot_w64(lx0 < 0 || lx0 + 8 > iw) != 0ull) {
+        const int lo = max(-lx0, 0), hi = min(iw - lx0, 8);                 // pixels lo .. hi - 1 are inside
+        const uint32_t bits = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+        vm0 = (((bits & 15u) * 0x00204081u) & 0x01010101u) * 0xffu;
+        vm1 = (((bits >> 4) * 0x00204081u) & 0x01010101u) * 0xffu;
+    }
+}
+// The 8 BGR pixels (24 bytes -> pw[6]) and 8 mask bytes (-> mw[2], ANDed with the validity bytes) at (lx0, ly) of a u8 image:
+// two dword-aligned 16-byte loads and three dword loads whatever lx0 is (-7 .. iw - 1).  A lane whose pixels lie partly left / right
+// of the image reads memory of the allocation there (STX_BUF_FRONT_PAD in front of row 0, the row pitch / the next row elsewhere)
+// and never uses it: those mask bytes are cleared and every use of a pixel is multiplied by its mask.  Offsets are taken from 64
+// bytes in front of the image so that they stay non-negative.  (Round 2 fetched the inside pixels of such a lane byte by byte
+// behind per-pixel branches: 16 dependent round trips for every wavefront that holds one — two lanes per image and row pair, a
+// quarter of all wavefront visits.)
+STX_DEV void load_px8_u8(const StxMbImage& im, int lx0, int ly, uint32_t vm0, uint32_t vm1, uint32_t (&pw)[6], uint32_t (&mw)[2])
+{
+    const uint32_t off = (uint32_t)ly * (uint32_t)im.img0_stride + (uint32_t)(lx0 * 3 + 64);
+    const STX_GAS uint8_t* q = gp(im.img0) - 64 + (off & ~3u);
+    const uint32_t s = off & 3u;
+    const v4u d0 = *reinterpret_cast<const STX_GAS v4u_a4*>(q);
+    const v4u d1 = *reinterpret_cast<const STX_GAS v4u_a4*>(q + 16);
+    pw[0] = __builtin_amdgcn_alignbyte(d0.y, d0.x, s);
+    pw[1] = __builtin_amdgcn_alignbyte(d0.z, d0.y, s);
+    pw[2] = __builtin_amdgcn_alignbyte(d0.w, d0.z, s);
+    pw[3] = __builtin_amdgcn_alignbyte(d1.x, d0.w, s);
+    pw[4] = __builtin_amdgcn_alignbyte(d1.y, d1.x, s);
+    pw[5] = __builtin_amdgcn_alignbyte(d1.z, d1.y, s);
+    const uint32_t moff = (uint32_t)ly * (uint32_t)im.mask0_stride + (uint32_t)(lx0 + 64);
+    const STX_GAS uint8_t* mq = gp(im.mask0) - 64 + (moff & ~3u);
+    const uint32_t ms = moff & 3u;
+    const uint32_t m0 = *reinterpret_cast<const STX_GAS uint32_t*>(mq), m1 = *reinterpret_cast<const STX_GAS uint32_t*>(mq + 4),
+                   m2 = *reinterpret_cast<const STX_GAS uint32_t*>(mq + 8);
+    mw[0] = __builtin_amdgcn_alignbyte(m1, m0, ms) & vm0;
+    mw[1] = __builtin_amdgcn_alignbyte(m2, m1, ms) & vm1;
+}
+
 STX_DEV int s16lo(uint32_t v) { return (int)(short)(v & 0xffffu); }
 STX_DEV int s16hi(uint32_t v) { return (int)(short)(v >> 16); }
 STX_DEV uint32_t pack16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
@@ -234,12 +276,15 @@ constexpr int LV_BAND = 4;  // same for the 512 x 8 tiles of the level kernels
 
 // level 0 (u8 BGR + u8 mask): 4 outputs from 11 input pixels
 // PK: every image of the launch is u8 with a 0 / 255 mask (decided on the host: no per-task branch in the kernel)
-template <bool PK>
+// NEAR: the border of the image inside its feed rectangle is narrower than the image (left, right <= iw, top, bottom <= ih: every
+// position is at most one mirror image away: branch-free index maps, no division); !NEAR (an exchange strip a few columns wide inside
+// a 96-column border): cv::borderInterpolate's general form
+template <bool PK, bool NEAR>
 STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, short* hs1, short* hs2, float* hw)
 {
     const int by = reflect101_near(row, im.fh) - im.top;  // bordered row -> image row
     const bool yin = (unsigned)by < (unsigned)im.ih;
-    const int sy = reflect(by, im.ih);
+    const int sy = NEAR ? reflect_near(by, im.ih) : reflect(by, im.ih);
     const uint8_t* irow = im.img0 + (long long)sy * im.img0_stride;
     const int c0 = 2 * xo - 2;     // first bordered column of the 11 this task reads
     const int a0 = c0 - im.left;   // ... as an image column
@@ -323,13 +368,17 @@ STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, s
             for (int j = 0; j < 11; j++) f[j] = 0.f;
         }
     } else {
+        // an 11-pixel run that meets a border: every load unconditional and from a position inside the image (so that all 44 of them
+        // are in flight together), the CONSTANT-0 border of the weight as a select afterwards
+        const uint8_t* mrow = im.mask0 + (long long)min(max(by, 0), im.ih - 1) * im.mask0_stride;
 #pragma unroll
         for (int j = 0; j < 11; j++) {
             const int bx = reflect101_near(c0 + j, im.fw) - im.left;
-            const uint8_t* p = irow + reflect(bx, im.iw) * 3;
+            const int sx = NEAR ? reflect_near(bx, im.iw) : reflect(bx, im.iw);
+            const uint8_t* p = irow + sx * 3;
             px[j][0] = p[0]; px[j][1] = p[1]; px[j][2] = p[2];
-            f[j] = (yin && (unsigned)bx < (unsigned)im.iw)
-                       ? fmul((float)im.mask0[(long long)by * im.mask0_stride + bx], INV255) : 0.f;
+            const float mv = fmul((float)mrow[sx], INV255);
+            f[j] = (yin && (unsigned)bx < (unsigned)im.iw) ? mv : 0.f;
         }
     }
 #pragma unroll
@@ -373,11 +422,13 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
     // rows / columns of the tile past the image's last output feed nothing (narrow exchange strips and the right / bottom
     // edge tiles would otherwise run the reflecting slow path for them)
     const int r_end = 2 * min(DN_TOH, oh - Y0) + 3;
+    // uniform for the workgroup: which form of the border index maps this image needs (dn_task_level0)
+    const bool near = im.left <= im.iw && im.fw - im.left - im.iw <= im.iw && im.top <= im.ih && im.fh - im.top - im.ih <= im.ih;
     for (int task = tid; task < DN_ROWS * (DN_TOW / 4); task += 256) {
         const int r = task / (DN_TOW / 4), q = task % (DN_TOW / 4);
         if (X0 + 4 * q >= ow || r >= r_end) continue;
-        dn_task_level0<PK>(im, 2 * Y0 - 2 + r, X0 + 4 * q, &s_h[0][r][4 * q], &s_h[1][r][4 * q], &s_h[2][r][4 * q],
-                           &s_w[r][4 * q]);
+        if (near) dn_task_level0<PK, true>(im, 2 * Y0 - 2 + r, X0 + 4 * q, &s_h[0][r][4 * q], &s_h[1][r][4 * q], &s_h[2][r][4 * q], &s_w[r][4 * q]);
+        else dn_task_level0<PK, false>(im, 2 * Y0 - 2 + r, X0 + 4 * q, &s_h[0][r][4 * q], &s_h[1][r][4 * q], &s_h[2][r][4 * q], &s_w[r][4 * q]);
     }
     __syncthreads();
     const int p = tid & 31, rg = tid >> 5;  // output pair, row group (2 rows)
@@ -882,7 +933,10 @@ STX_DEV void mb_level_fast_body(const MbLevelK& P)
                 // weight 0 and add nothing.  (num_bands > 0: the launcher's condition.)
                 const int lx0 = X0 - im.ix, ly0 = Y0 - im.iy;
                 if (lx0 + 8 <= 0 || lx0 >= im.iw || ly0 + 2 <= 0 || ly0 >= im.ih) continue;
-                const bool fastx = lx0 >= 0 && lx0 + 8 <= im.iw;
+                // lanes partly left / right of the image: the same aligned loads, mask bytes outside the image cleared (weight 0:
+                // whatever the pixel bytes are, (short)(L * 0.f) = 0) — see mb_level0_pk_kernel
+                uint32_t vm0, vm1;
+                lane_valid_bytes(lx0, im.iw, vm0, vm1);
                 uint32_t pw_[2][6], mw[2][2];
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
@@ -891,41 +945,7 @@ STX_DEV void mb_level_fast_body(const MbLevelK& P)
                     for (int q = 0; q < 6; q++) pw_[r][q] = 0;
                     mw[r][0] = mw[r][1] = 0;
                     if ((unsigned)ly >= (unsigned)im.ih) continue;
-                    if (fastx) {
-                        const uint32_t off = (uint32_t)ly * (uint32_t)im.img0_stride + (uint32_t)lx0 * 3u;
-                        const STX_GAS uint8_t* q = gp(im.img0) + (off & ~3u);
-                        const uint32_t s = off & 3u;
-                        const v4u d0 = *reinterpret_cast<const STX_GAS v4u_a4*>(q);
-                        const v4u d1 = *reinterpret_cast<const STX_GAS v4u_a4*>(q + 16);
-                        pw_[r][0] = __builtin_amdgcn_alignbyte(d0.y, d0.x, s);
-                        pw_[r][1] = __builtin_amdgcn_alignbyte(d0.z, d0.y, s);
-                        pw_[r][2] = __builtin_amdgcn_alignbyte(d0.w, d0.z, s);
-                        pw_[r][3] = __builtin_amdgcn_alignbyte(d1.x, d0.w, s);
-                        pw_[r][4] = __builtin_amdgcn_alignbyte(d1.y, d1.x, s);
-                        pw_[r][5] = __builtin_amdgcn_alignbyte(d1.z, d1.y, s);
-                        const uint32_t moff = (uint32_t)ly * (uint32_t)im.mask0_stride + (uint32_t)lx0;
-                        const STX_GAS uint8_t* mq = gp(im.mask0) + (moff & ~3u);
-                        const uint32_t ms = moff & 3u;
-                        const uint32_t m0 = *reinterpret_cast<const STX_GAS uint32_t*>(mq), m1 = *reinterpret_cast<const STX_GAS uint32_t*>(mq + 4),
-                                       m2 = *reinterpret_cast<const STX_GAS uint32_t*>(mq + 8);
-                        mw[r][0] = __builtin_amdgcn_alignbyte(m1, m0, ms);
-                        mw[r][1] = __builtin_amdgcn_alignbyte(m2, m1, ms);
-                    } else {
-                        const STX_GAS uint8_t* irow = gp(im.img0) + (uint32_t)ly * (uint32_t)im.img0_stride;
-                        const STX_GAS uint8_t* mrow = gp(im.mask0) + (uint32_t)ly * (uint32_t)im.mask0_stride;
-#pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            const int lx = lx0 + j;
-                            if ((unsigned)lx < (unsigned)im.iw) {
-                                const STX_GAS uint8_t* p = irow + lx * 3;
-                                const uint32_t v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
-                                const int bo = 3 * j;
-                                pw_[r][bo >> 2] |= v << (8 * (bo & 3));
-                                if ((bo & 3) > 1) pw_[r][(bo >> 2) + 1] |= v >> (32 - 8 * (bo & 3));
-                                mw[r][j >> 2] |= (uint32_t)mrow[lx] << (8 * (j & 3));
-                            }
-                        }
-                    }
+                    load_px8_u8(im, lx0, ly, vm0, vm1, pw_[r], mw[r]);
                 }
                 float w[2][8];
 #pragma unroll
@@ -977,55 +997,17 @@ STX_DEV void mb_level_fast_body(const MbLevelK& P)
                         else up_patch(im.g[1] + c * im.g_plane[1], im.g_stride[1], im.fw >> 1, im.fh >> 1, (X0 - im.fx) >> 1, (Y0 - im.fy) >> 1, up[c]);
                     }
                 }
-                const bool fastx = lx0 >= 0 && lx0 + 8 <= im.iw;
+                uint32_t vm0, vm1;
+                lane_valid_bytes(lx0, im.iw, vm0, vm1);
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
                     const int ly = ly0 + r;
                     if ((unsigned)ly >= (unsigned)im.ih) continue;
                     uint32_t pw_[6], mw[2];
-                    if (fastx) {
-                        const long long off = (long long)ly * im.img0_stride + (long long)lx0 * 3;
-                        const uint8_t* q = im.img0 + (off & ~3ll);
-                        const uint32_t s = (uint32_t)off & 3u;
-                        U4a4 d0 = *reinterpret_cast<const U4a4*>(q);
-                        U4a4 d1 = *reinterpret_cast<const U4a4*>(q + 16);
-                        pw_[0] = __builtin_amdgcn_alignbyte(d0.v[1], d0.v[0], s);
-                        pw_[1] = __builtin_amdgcn_alignbyte(d0.v[2], d0.v[1], s);
-                        pw_[2] = __builtin_amdgcn_alignbyte(d0.v[3], d0.v[2], s);
-                        pw_[3] = __builtin_amdgcn_alignbyte(d1.v[0], d0.v[3], s);
-                        pw_[4] = __builtin_amdgcn_alignbyte(d1.v[1], d1.v[0], s);
-                        pw_[5] = __builtin_amdgcn_alignbyte(d1.v[2], d1.v[1], s);
-                        const long long moff = (long long)ly * im.mask0_stride + lx0;
-                        const uint8_t* mq = im.mask0 + (moff & ~3ll);
-                        const uint32_t ms = (uint32_t)moff & 3u;
-                        uint32_t m0 = *reinterpret_cast<const uint32_t*>(mq), m1 = *reinterpret_cast<const uint32_t*>(mq + 4),
-                                 m2 = *reinterpret_cast<const uint32_t*>(mq + 8);
-                        mw[0] = __builtin_amdgcn_alignbyte(m1, m0, ms);
-                        mw[1] = __builtin_amdgcn_alignbyte(m2, m1, ms);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 6; i++) pw_[i] = 0;
-                        mw[0] = mw[1] = 0;
-                        const uint8_t* irow = im.img0 + (long long)ly * im.img0_stride;
-                        const uint8_t* mrow = im.mask0 + (long long)ly * im.mask0_stride;
-#pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            const int lx = lx0 + j;
-                            if ((unsigned)lx < (unsigned)im.iw) {
-                                const uint8_t* p = irow + lx * 3;
-                                const uint32_t v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
-                                // place the 24-bit pixel at byte 3*j of the stream
-                                const int bo = 3 * j;
-                                pw_[bo >> 2] |= v << (8 * (bo & 3));
-                                if ((bo & 3) > 1) pw_[(bo >> 2) + 1] |= v >> (32 - 8 * (bo & 3));
-                                mw[j >> 2] |= (uint32_t)mrow[lx] << (8 * (j & 3));
-                            }
-                        }
-                    }
+                    load_px8_u8(im, lx0, ly, vm0, vm1, pw_, mw);
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
-                        const int lx = lx0 + j;
-                        if (!fastx && (unsigned)lx >= (unsigned)im.iw) continue;
+                        if ((unsigned)(lx0 + j) >= (unsigned)im.iw) continue;  // outside the image: nothing is added (not even 0.f to the weight sum)
                         const float w = fmul((float)byte_of(mw, j), INV255);
 #pragma unroll
                         for (int c = 0; c < 3; c++) {
@@ -1322,7 +1304,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVE
             }
             const int lx0 = X0 - im.ix, ly0 = Y0 - im.iy;
             if (lx0 + 8 <= 0 || lx0 >= im.iw || ly0 + 2 <= 0 || ly0 >= im.ih) continue;
-            const bool fastx = lx0 >= 0 && lx0 + 8 <= im.iw;
+            // lanes partly left / right of the image take the same aligned loads (load_px8_u8): no per-pixel path
             uint32_t pw_[2][6], mw[2][2];
 #pragma unroll
             for (int r = 0; r < 2; r++) {
@@ -1331,41 +1313,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVE
                 for (int q = 0; q < 6; q++) pw_[r][q] = 0;
                 mw[r][0] = mw[r][1] = 0;
                 if ((unsigned)ly >= (unsigned)im.ih) continue;
-                if (fastx) {
-                    const uint32_t off = (uint32_t)ly * (uint32_t)im.img0_stride + (uint32_t)lx0 * 3u;
-                    const STX_GAS uint8_t* q = gp(im.img0) + (off & ~3u);
-                    const uint32_t s = off & 3u;
-                    const v4u d0 = *reinterpret_cast<const STX_GAS v4u_a4*>(q);
-                    const v4u d1 = *reinterpret_cast<const STX_GAS v4u_a4*>(q + 16);
-                    pw_[r][0] = __builtin_amdgcn_alignbyte(d0.y, d0.x, s);
-                    pw_[r][1] = __builtin_amdgcn_alignbyte(d0.z, d0.y, s);
-                    pw_[r][2] = __builtin_amdgcn_alignbyte(d0.w, d0.z, s);
-                    pw_[r][3] = __builtin_amdgcn_alignbyte(d1.x, d0.w, s);
-                    pw_[r][4] = __builtin_amdgcn_alignbyte(d1.y, d1.x, s);
-                    pw_[r][5] = __builtin_amdgcn_alignbyte(d1.z, d1.y, s);
-                    const uint32_t moff = (uint32_t)ly * (uint32_t)im.mask0_stride + (uint32_t)lx0;
-                    const STX_GAS uint8_t* mq = gp(im.mask0) + (moff & ~3u);
-                    const uint32_t ms = moff & 3u;
-                    const uint32_t m0 = *reinterpret_cast<const STX_GAS uint32_t*>(mq), m1 = *reinterpret_cast<const STX_GAS uint32_t*>(mq + 4),
-                                   m2 = *reinterpret_cast<const STX_GAS uint32_t*>(mq + 8);
-                    mw[r][0] = __builtin_amdgcn_alignbyte(m1, m0, ms);
-                    mw[r][1] = __builtin_amdgcn_alignbyte(m2, m1, ms);
-                } else {
-                    const STX_GAS uint8_t* irow = gp(im.img0) + (uint32_t)ly * (uint32_t)im.img0_stride;
-                    const STX_GAS uint8_t* mrow = gp(im.mask0) + (uint32_t)ly * (uint32_t)im.mask0_stride;
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const int lx = lx0 + j;
-                        if ((unsigned)lx < (unsigned)im.iw) {
-                            const STX_GAS uint8_t* p = irow + lx * 3;
-                            const uint32_t v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
-                            const int bo = 3 * j;
-                            pw_[r][bo >> 2] |= v << (8 * (bo & 3));
-                            if ((bo & 3) > 1) pw_[r][(bo >> 2) + 1] |= v >> (32 - 8 * (bo & 3));
-                            mw[r][j >> 2] |= (uint32_t)mrow[lx] << (8 * (j & 3));
-                        }
-                    }
-                }
+                load_px8_u8(im, lx0, ly, 0xffffffffu, 0xffffffffu, pw_[r], mw[r]);
+            }
+            {   // mask bytes of the pixels outside the image: cleared (after the loads: two registers less while they are in flight)
+                uint32_t vm0, vm1;
+                lane_valid_bytes(lx0, im.iw, vm0, vm1);
+                mw[0][0] &= vm0; mw[0][1] &= vm1; mw[1][0] &= vm0; mw[1][1] &= vm1;
             }
             // (no early-out on an all-zero mask: it would put the G_1 loads behind the mask loads' round trip)
             const uint32_t g1_boff = (uint32_t)((X0 - im.fx) >> 1);  // this lane's samples of G_1 (bytes): offset in a row

@@ -375,6 +375,14 @@ STX_DEV int reflect101(int p, int len)
     if (m < 0) m += period;
     return m < len ? m : period - m;
 }
+// cv::borderInterpolate BORDER_REFLECT for positions at most one mirror image away (-len <= p <= 2 len - 1), branch-free; any other
+// p gives some index inside [0, len)
+STX_DEV int reflect_near(int p, int len)
+{
+    const int a = p ^ (p >> 31);  // p < 0 ? -p - 1 : p
+    const int b = a >= len ? 2 * len - 1 - a : a;
+    return max(b, 0);
+}
 // reflect101 for taps at most one mirror image away (-(len - 1) <= p <= 2 len - 2), branch-free; any other p gives SOME index
 // inside [0, len) (the LDS pyrDown kernels evaluate whole groups of 4 / 8 outputs and read — never use — the taps of the outputs
 // past the image).  Exact for every tap of a 5-tap stencil centred on 2 x, x < len / 2, len >= 2.

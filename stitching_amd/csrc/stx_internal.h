@@ -114,6 +114,9 @@ struct stx_buf {
     std::atomic<int> refs{1};
 };
 
+// readable bytes in front of the first row of every image the library allocates (views inherit them from their parent: whatever
+// precedes a view's first pixel is memory of the same allocation)
+constexpr size_t STX_BUF_FRONT_PAD = 64;
 inline int stx_elem_bytes(int elem) { return elem == STX_U8 ? 1 : (elem == STX_S16 ? 2 : 4); }
 int stx_buf_new(stx_ctx* ctx, int w, int h, int c, int elem, stx_buf** out);
 void stx_buf_retain(stx_buf* b);
