@@ -1546,8 +1546,10 @@ STX_EXPORT int stx_blend_feed_ex(stx_blender* b, const stx_buf* img, const stx_b
     im.dstride = ((long long)img->w + 15) & ~15ll;
     im.n_chunks = (img->h + STX_DT_RC - 1) / STX_DT_RC;
     void *wm = nullptr, *summ = nullptr;
-    STX_TRY(stx_dev_alloc(b->ctx, sizeof(uint16_t) * (size_t)im.dstride * img->h, &wm));
+    // 64 bytes in front and behind: a lane's group of 4 distances may start up to 3 samples left of a row / end 3 right of it
+    STX_TRY(stx_dev_alloc(b->ctx, 64 + sizeof(uint16_t) * (size_t)im.dstride * img->h + 64, &wm));
     b->pyr_allocs.push_back(wm);
+    wm = (uint8_t*)wm + 64;
     // per (chunk, column): the zero rows as a 64-bit set, then the first and the last of them
     STX_TRY(stx_dev_alloc(b->ctx, (sizeof(unsigned long long) + 2 * sizeof(int)) * (size_t)im.dstride * im.n_chunks, &summ));
     b->pyr_allocs.push_back(summ);

@@ -55,9 +55,12 @@ STX_DEV float h5f(float s0, float s1, float s2, float s3, float s4)
 
 // sample `idx` (row * stride + column, + channel * plane) of level lv of an image's Gaussian pyramid: bytes when the image was
 // fed as u8 (StxMbImage::g_u8), else int16
+// (pointers read from a descriptor in memory are generic to the compiler; all of ours are device global memory: global_load
+// instead of flat_load)
+#define STX_GAS __attribute__((address_space(1)))
 STX_DEV int ld_g(const StxMbImage& im, int lv, long long idx)
 {
-    return im.g_u8 ? (int)reinterpret_cast<const uint8_t*>(im.g[lv])[idx] : (int)im.g[lv][idx];
+    return im.g_u8 ? (int)((const STX_GAS uint8_t*)reinterpret_cast<const uint8_t*>(im.g[lv]))[idx] : (int)((const STX_GAS short*)im.g[lv])[idx];
 }
 STX_DEV void st_g(const StxMbImage& im, int lv, long long idx, int v)
 {
@@ -170,8 +173,8 @@ STX_DEV int pyr_up_at(const T* __restrict__ plane, long long stride, int cw, int
 // ... of channel c of level lv of an image's Gaussian pyramid
 STX_DEV int pyr_up_g(const StxMbImage& im, int lv, int c, int cw, int ch, int X, int Y)
 {
-    if (im.g_u8) return pyr_up_at(reinterpret_cast<const uint8_t*>(im.g[lv]) + c * im.g_plane[lv], im.g_stride[lv], cw, ch, X, Y);
-    return pyr_up_at(im.g[lv] + c * im.g_plane[lv], im.g_stride[lv], cw, ch, X, Y);
+    if (im.g_u8) return pyr_up_at((const STX_GAS uint8_t*)reinterpret_cast<const uint8_t*>(im.g[lv]) + c * im.g_plane[lv], im.g_stride[lv], cw, ch, X, Y);
+    return pyr_up_at((const STX_GAS short*)im.g[lv] + c * im.g_plane[lv], im.g_stride[lv], cw, ch, X, Y);
 }
 
 
@@ -289,7 +292,7 @@ STX_DEV void mb_gather_norm(const StxMbImage* __restrict__ images, int n_images,
         const int lx = x - (im.fx >> lv), ly = y - (im.fy >> lv);
         const int lw = im.fw >> lv, lh = im.fh >> lv;
         if ((unsigned)lx >= (unsigned)lw || (unsigned)ly >= (unsigned)lh) continue;
-        const float w = im.wt[lv][(long long)ly * im.wt_stride[lv] + lx];
+        const float w = ((const STX_GAS float*)im.wt[lv])[(long long)ly * im.wt_stride[lv] + lx];
         const long long gi = (long long)ly * im.g_stride[lv] + lx;
         int L[3];
 #pragma unroll
@@ -557,6 +560,17 @@ STX_DEV uint32_t ld_u32_unaligned(const uint8_t* p)  // 4 bytes at any address, 
     return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u));
 }
 
+// bytes 0xff where pixel j (0..3) of a lane's group starting at image column lx lies inside an image w columns wide.  A group
+// partly left / right of a u8 image is read with the same unaligned dword loads as a whole one — what lies outside is memory of the
+// allocation (STX_BUF_FRONT_PAD, the row pitch) — and masked with this (round 3; the per-pixel byte path cost a wavefront that held
+// such a lane four dependent round trips).
+STX_DEV uint32_t quad_valid_bytes(int lx, int w)
+{
+    const int lo = max(-lx, 0), hi = min(w - lx, 4);
+    const uint32_t bits = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+    return ((bits * 0x00204081u) & 0x01010101u) * 0xffu;
+}
+
 // Column passes: a lane owns 4 adjacent columns (one mask dword per row, 16-byte stores of the distances), a workgroup
 // of 64 lanes 256 columns of one chunk of DT_RC rows.  Columns >= w inside the last group are computed on whatever the
 // row padding holds and land in the padding of the distance rows (dstride is a multiple of 16), where nothing reads them.
@@ -765,11 +779,17 @@ __global__ __launch_bounds__(256) void feather_gather_kernel(FeatherGatherK P)
         if (lx + 3 < 0 || lx >= im.w) continue;
         const uint16_t* wrow = im.dist + (long long)ly * im.dstride;
         const uint8_t* irow = im.img + (long long)ly * im.istride;
-        if (!im.is_s16 && lx >= 0 && lx + 3 < im.w) {
-            // whole group inside a u8 image: the four weights and the twelve image bytes as wide loads
+        if (!im.is_s16) {
+            // a u8 image: the four weights and the twelve image bytes as wide loads — also for a group partly left / right of the
+            // image, whose outside pixels get the weight 0.f (nothing is added: (short)(px * 0.f) = 0, w + 0.f = w)
             const uint32_t d01 = ld_u32_unaligned(reinterpret_cast<const uint8_t*>(wrow + lx)), d23 = ld_u32_unaligned(reinterpret_cast<const uint8_t*>(wrow + lx + 2));
-            const float w4[4] = {feather_weight(d01 & 0xffffu, P.sharpness), feather_weight(d01 >> 16, P.sharpness),
-                                 feather_weight(d23 & 0xffffu, P.sharpness), feather_weight(d23 >> 16, P.sharpness)};
+            float w4[4] = {feather_weight(d01 & 0xffffu, P.sharpness), feather_weight(d01 >> 16, P.sharpness),
+                           feather_weight(d23 & 0xffffu, P.sharpness), feather_weight(d23 >> 16, P.sharpness)};
+            if (lx < 0 || lx + 3 >= im.w) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if ((unsigned)(lx + j) >= (unsigned)im.w) w4[j] = 0.f;
+            }
             const uint32_t b3[3] = {ld_u32_unaligned(irow + lx * 3), ld_u32_unaligned(irow + lx * 3 + 4), ld_u32_unaligned(irow + lx * 3 + 8)};
             // away from the mask's edge every weight is exactly 1.f (distance * sharpness >= 1) and (short)(px * 1.f) = px:
             // a wavefront in which that holds for all lanes adds the bytes as integers
@@ -915,9 +935,12 @@ __global__ __launch_bounds__(256) void no_gather_kernel(NoGatherK P)
         if (lx + 3 < 0 || lx >= im.w) continue;
         const uint8_t* mrow = im.mask + (long long)ly * im.mstride;
         uint32_t m4;
-        const bool quad = lx >= 0 && lx + 3 < im.w;
-        if (quad) m4 = ld_u32_unaligned(mrow + lx);
-        else {
+        const bool whole = lx >= 0 && lx + 3 < im.w;
+        const bool quad = whole || !im.is_s16;  // u8 images: partial groups take the wide loads too, masked
+        if (quad) {
+            m4 = ld_u32_unaligned(mrow + lx);
+            if (!whole) m4 &= quad_valid_bytes(lx, im.w);
+        } else {
             m4 = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++)

@@ -59,6 +59,7 @@ STX_DEV bool xcd_tile(const StxTileMap& M, uint32_t b, int& tx, int& ty)
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef v4u __attribute__((aligned(4))) v4u_a4;  // 16 bytes, only dword-aligned
+typedef v2u __attribute__((aligned(4))) v2u_a4;
 
 struct __attribute__((aligned(4))) U4a4 { uint32_t v[4]; };  // 16 bytes, only dword-aligned
 struct __attribute__((aligned(4))) U2a4 { uint32_t v[2]; };
@@ -285,28 +286,30 @@ STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, s
     const int by = reflect101_near(row, im.fh) - im.top;  // bordered row -> image row
     const bool yin = (unsigned)by < (unsigned)im.ih;
     const int sy = NEAR ? reflect_near(by, im.ih) : reflect(by, im.ih);
-    const uint8_t* irow = im.img0 + (long long)sy * im.img0_stride;
+    // global address space, 32-bit offsets from the image's (uniform) base: scalar base + lane offset loads
+    const STX_GAS uint8_t* img = gp(im.img0);
+    const uint32_t rowoff = (uint32_t)sy * (uint32_t)im.img0_stride;
     const int c0 = 2 * xo - 2;     // first bordered column of the 11 this task reads
     const int a0 = c0 - im.left;   // ... as an image column
     int px[11][3];
     float f[11];
     if (c0 >= 0 && c0 + 10 < im.fw && a0 >= 0 && a0 + 10 < im.iw) {
-        const long long off = (long long)a0 * 3;  // 33 bytes
-        const uint8_t* q = irow + (off & ~3ll);
-        const uint32_t s = (uint32_t)off & 3u;
-        U4a4 d0 = *reinterpret_cast<const U4a4*>(q);
-        U4a4 d1 = *reinterpret_cast<const U4a4*>(q + 16);
-        U2a4 d2 = *reinterpret_cast<const U2a4*>(q + 32);
+        const uint32_t off = rowoff + (uint32_t)a0 * 3u;  // 33 bytes
+        const STX_GAS uint8_t* q = img + (off & ~3u);
+        const uint32_t s = off & 3u;
+        const v4u d0 = *reinterpret_cast<const STX_GAS v4u_a4*>(q);
+        const v4u d1 = *reinterpret_cast<const STX_GAS v4u_a4*>(q + 16);
+        const v2u d2 = *reinterpret_cast<const STX_GAS v2u_a4*>(q + 32);
         uint32_t w[9];
-        w[0] = __builtin_amdgcn_alignbyte(d0.v[1], d0.v[0], s);
-        w[1] = __builtin_amdgcn_alignbyte(d0.v[2], d0.v[1], s);
-        w[2] = __builtin_amdgcn_alignbyte(d0.v[3], d0.v[2], s);
-        w[3] = __builtin_amdgcn_alignbyte(d1.v[0], d0.v[3], s);
-        w[4] = __builtin_amdgcn_alignbyte(d1.v[1], d1.v[0], s);
-        w[5] = __builtin_amdgcn_alignbyte(d1.v[2], d1.v[1], s);
-        w[6] = __builtin_amdgcn_alignbyte(d1.v[3], d1.v[2], s);
-        w[7] = __builtin_amdgcn_alignbyte(d2.v[0], d1.v[3], s);
-        w[8] = __builtin_amdgcn_alignbyte(d2.v[1], d2.v[0], s);
+        w[0] = __builtin_amdgcn_alignbyte(d0.y, d0.x, s);
+        w[1] = __builtin_amdgcn_alignbyte(d0.z, d0.y, s);
+        w[2] = __builtin_amdgcn_alignbyte(d0.w, d0.z, s);
+        w[3] = __builtin_amdgcn_alignbyte(d1.x, d0.w, s);
+        w[4] = __builtin_amdgcn_alignbyte(d1.y, d1.x, s);
+        w[5] = __builtin_amdgcn_alignbyte(d1.z, d1.y, s);
+        w[6] = __builtin_amdgcn_alignbyte(d1.w, d1.z, s);
+        w[7] = __builtin_amdgcn_alignbyte(d2.x, d1.w, s);
+        w[8] = __builtin_amdgcn_alignbyte(d2.y, d2.x, s);
         if (PK) {
             // packed path (u8 image, 0 / 255 mask): outputs o = 0..3 use pixels 2o .. 2o+4 with weights 1 4 6 4 1;
             // as pairs (out0,out1) = (p0,p2) + 4(p1,p3) + 6(p2,p4) + 4(p3,p5) + (p4,p6), (out2,out3) likewise from p4..p10
@@ -327,14 +330,14 @@ STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, s
                 *reinterpret_cast<uint2*>(hs[c]) = make_uint2(unpk(o01), unpk(o23));
             }
             if (yin) {
-                const long long moff = (long long)by * im.mask0_stride + a0;  // 11 bytes
-                const uint8_t* mq = im.mask0 + (moff & ~3ll);
-                const uint32_t ms = (uint32_t)moff & 3u;
-                U4a4 m = *reinterpret_cast<const U4a4*>(mq);
+                const uint32_t moff = (uint32_t)by * (uint32_t)im.mask0_stride + (uint32_t)a0;  // 11 bytes
+                const STX_GAS uint8_t* mq = gp(im.mask0) + (moff & ~3u);
+                const uint32_t ms = moff & 3u;
+                const v4u m = *reinterpret_cast<const STX_GAS v4u_a4*>(mq);
                 uint32_t mb[3];  // 0 / 255 -> 0 / 1: W_0 is exactly 0.f or 1.f, the fp32 row sums are small integers
-                mb[0] = __builtin_amdgcn_alignbyte(m.v[1], m.v[0], ms) & 0x01010101u;
-                mb[1] = __builtin_amdgcn_alignbyte(m.v[2], m.v[1], ms) & 0x01010101u;
-                mb[2] = __builtin_amdgcn_alignbyte(m.v[3], m.v[2], ms) & 0x01010101u;
+                mb[0] = __builtin_amdgcn_alignbyte(m.y, m.x, ms) & 0x01010101u;
+                mb[1] = __builtin_amdgcn_alignbyte(m.z, m.y, ms) & 0x01010101u;
+                mb[2] = __builtin_amdgcn_alignbyte(m.w, m.z, ms) & 0x01010101u;
                 const pk16 o01 = pk(pair_u8<0, 2>(mb)) + pk(pair_u8<4, 6>(mb)) + pk(pair_u8<2, 4>(mb)) * pk_splat(6) +
                                  (pk(pair_u8<1, 3>(mb)) + pk(pair_u8<3, 5>(mb))) * pk_splat(4);
                 const pk16 o23 = pk(pair_u8<4, 6>(mb)) + pk(pair_u8<8, 10>(mb)) + pk(pair_u8<6, 8>(mb)) * pk_splat(6) +
@@ -353,14 +356,14 @@ STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, s
             px[j][2] = (int)byte_of(w, 3 * j + 2);
         }
         if (yin) {
-            const long long moff = (long long)by * im.mask0_stride + a0;  // 11 bytes
-            const uint8_t* mq = im.mask0 + (moff & ~3ll);
-            const uint32_t ms = (uint32_t)moff & 3u;
-            U4a4 m = *reinterpret_cast<const U4a4*>(mq);
+            const uint32_t moff = (uint32_t)by * (uint32_t)im.mask0_stride + (uint32_t)a0;  // 11 bytes
+            const STX_GAS uint8_t* mq = gp(im.mask0) + (moff & ~3u);
+            const uint32_t ms = moff & 3u;
+            const v4u m = *reinterpret_cast<const STX_GAS v4u_a4*>(mq);
             uint32_t mw[3];
-            mw[0] = __builtin_amdgcn_alignbyte(m.v[1], m.v[0], ms);
-            mw[1] = __builtin_amdgcn_alignbyte(m.v[2], m.v[1], ms);
-            mw[2] = __builtin_amdgcn_alignbyte(m.v[3], m.v[2], ms);
+            mw[0] = __builtin_amdgcn_alignbyte(m.y, m.x, ms);
+            mw[1] = __builtin_amdgcn_alignbyte(m.z, m.y, ms);
+            mw[2] = __builtin_amdgcn_alignbyte(m.w, m.z, ms);
 #pragma unroll
             for (int j = 0; j < 11; j++) f[j] = fmul((float)byte_of(mw, j), INV255);
         } else {
@@ -370,12 +373,12 @@ STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, s
     } else {
         // an 11-pixel run that meets a border: every load unconditional and from a position inside the image (so that all 44 of them
         // are in flight together), the CONSTANT-0 border of the weight as a select afterwards
-        const uint8_t* mrow = im.mask0 + (long long)min(max(by, 0), im.ih - 1) * im.mask0_stride;
+        const STX_GAS uint8_t* mrow = gp(im.mask0) + (uint32_t)min(max(by, 0), im.ih - 1) * (uint32_t)im.mask0_stride;
 #pragma unroll
         for (int j = 0; j < 11; j++) {
             const int bx = reflect101_near(c0 + j, im.fw) - im.left;
             const int sx = NEAR ? reflect_near(bx, im.iw) : reflect(bx, im.iw);
-            const uint8_t* p = irow + sx * 3;
+            const STX_GAS uint8_t* p = img + (rowoff + (uint32_t)sx * 3u);
             px[j][0] = p[0]; px[j][1] = p[1]; px[j][2] = p[2];
             const float mv = fmul((float)mrow[sx], INV255);
             f[j] = (yin && (unsigned)bx < (unsigned)im.iw) ? mv : 0.f;
@@ -448,9 +451,9 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
             for (int k = 0; k < 5; k++) a[k] = pk(*reinterpret_cast<const uint32_t*>(&s_h[c][2 * yl + k][2 * p]));
             const pk16 v = (a[0] + a[4] + a[2] * pk_splat(6) + (a[1] + a[3]) * pk_splat(4) + pk_splat(128)) >> pk_splat(8);
             // G_1 of a u8 image is <= 255: one byte per sample (StxMbImage::g_u8)
-            uint8_t* o = reinterpret_cast<uint8_t*>(im.g[1]) + c * im.g_plane[1] + (long long)y * im.g_stride[1] + xo;
+            STX_GAS uint8_t* o = gp(reinterpret_cast<uint8_t*>(im.g[1])) + ((uint32_t)c * (uint32_t)im.g_plane[1] + (uint32_t)y * (uint32_t)im.g_stride[1] + (uint32_t)xo);
             const uint32_t b2 = __builtin_amdgcn_perm(0u, unpk(v), 0x0c0c0200u);
-            if (two) *reinterpret_cast<uint16_t*>(o) = (uint16_t)b2;
+            if (two) *reinterpret_cast<STX_GAS uint16_t*>(o) = (uint16_t)b2;
             else o[0] = (uint8_t)b2;
         }
         float fa[5], fb[5];
@@ -469,46 +472,50 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
         }
         const float wa = fmul(h5f(fa[0], fa[1], fa[2], fa[3], fa[4]), INV256);
         const float wb = fmul(h5f(fb[0], fb[1], fb[2], fb[3], fb[4]), INV256);
-        float* o = im.wt[1] + (long long)y * im.wt_stride[1] + xo;
-        if (two) *reinterpret_cast<float2*>(o) = make_float2(wa, wb);
+        STX_GAS float* o = gp(im.wt[1]) + ((uint32_t)y * (uint32_t)im.wt_stride[1] + (uint32_t)xo);
+        typedef float v2fl __attribute__((ext_vector_type(2)));
+        if (two) { const v2fl wab = {wa, wb}; *reinterpret_cast<STX_GAS v2fl*>(o) = wab; }
         else o[0] = wa;
         nz |= __float_as_uint(wa) | (two ? __float_as_uint(wb) : 0u);
     }
     dn_note_occ(occ, nz, tid, X0, Y0, ow, oh);
 }
 
-// level >= 1 of a byte pyramid: the 19 samples p[c0 .. c0 + 18], c0 = 16 t - 2: dword, 16 bytes, dword around them
-STX_DEV void dn_load19_u8(const uint8_t* __restrict__ p, int c0, int iw, bool fast, int s[19])
+// level >= 1 of a byte pyramid: the 19 samples p[c0 .. c0 + 18], c0 = 16 t - 2: dword, 16 bytes, dword around them.
+// p = base + off (global address space, 32-bit offset from the uniform plane base: scalar base + lane offset loads)
+STX_DEV void dn_load19_u8(const STX_GAS uint8_t* __restrict__ base, uint32_t off, int c0, int iw, bool fast, int s[19])
 {
     if (fast) {
-        const uint32_t a = *reinterpret_cast<const uint32_t*>(p + c0 - 2);
-        const uint4 b = *reinterpret_cast<const uint4*>(p + c0 + 2);
-        const uint32_t c = *reinterpret_cast<const uint32_t*>(p + c0 + 18);
+        const STX_GAS uint8_t* p = base + (off + (uint32_t)c0);
+        const uint32_t a = *reinterpret_cast<const STX_GAS uint32_t*>(p - 2);
+        const v4u b = *reinterpret_cast<const STX_GAS v4u*>(p + 2);
+        const uint32_t c = *reinterpret_cast<const STX_GAS uint32_t*>(p + 18);
         const uint32_t w[6] = {a, b.x, b.y, b.z, b.w, c};
 #pragma unroll
         for (int j = 0; j < 19; j++) s[j] = (int)byte_of(w, j + 2);
     } else {
 #pragma unroll
-        for (int j = 0; j < 19; j++) s[j] = p[reflect101_near(c0 + j, iw)];
+        for (int j = 0; j < 19; j++) s[j] = base[off + (uint32_t)reflect101_near(c0 + j, iw)];
     }
 }
 
 // level >= 1 (planar int16 x3 + fp32): 8 outputs from 19 input elements per plane
-STX_DEV void dn_load19_s16(const short* __restrict__ p, int c0, int iw, bool fast, int s[19])
+STX_DEV void dn_load19_s16(const STX_GAS short* __restrict__ base, uint32_t off, int c0, int iw, bool fast, int s[19])
 {
     if (fast) {  // c0 = 16t - 2: dword, 2 x 16-byte, short
-        uint32_t a = *reinterpret_cast<const uint32_t*>(p + c0);
-        uint4 b = *reinterpret_cast<const uint4*>(p + c0 + 2);
-        uint4 c = *reinterpret_cast<const uint4*>(p + c0 + 10);
+        const STX_GAS short* p = base + (off + (uint32_t)c0);
+        const uint32_t a = *reinterpret_cast<const STX_GAS uint32_t*>(p);
+        const v4u b = *reinterpret_cast<const STX_GAS v4u*>(p + 2);
+        const v4u c = *reinterpret_cast<const STX_GAS v4u*>(p + 10);
         s[0] = s16lo(a); s[1] = s16hi(a);
         s[2] = s16lo(b.x); s[3] = s16hi(b.x); s[4] = s16lo(b.y); s[5] = s16hi(b.y);
         s[6] = s16lo(b.z); s[7] = s16hi(b.z); s[8] = s16lo(b.w); s[9] = s16hi(b.w);
         s[10] = s16lo(c.x); s[11] = s16hi(c.x); s[12] = s16lo(c.y); s[13] = s16hi(c.y);
         s[14] = s16lo(c.z); s[15] = s16hi(c.z); s[16] = s16lo(c.w); s[17] = s16hi(c.w);
-        s[18] = p[c0 + 18];
+        s[18] = p[18];
     } else {
 #pragma unroll
-        for (int j = 0; j < 19; j++) s[j] = p[reflect101_near(c0 + j, iw)];
+        for (int j = 0; j < 19; j++) s[j] = base[off + (uint32_t)reflect101_near(c0 + j, iw)];
     }
 }
 
@@ -526,7 +533,7 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
     if (X0 >= ow || Y0 >= oh) return;
     const short* G = im.g[lv];
     const bool g8b = im.g_u8 != 0;  // byte planes (u8 image) or int16 planes: uniform for the workgroup
-    const long long gs = im.g_stride[lv], gp = im.g_plane[lv];
+    const uint32_t gs = (uint32_t)im.g_stride[lv], gpl = (uint32_t)im.g_plane[lv];
     uint8_t* const occ = im.occ[lv + 1];
     asm volatile("" ::"s"(occ));  // as in the level-0 kernel
     const int r_end = 2 * min(DN_TOH, oh - Y0) + 3;  // as in the level-0 kernel
@@ -539,8 +546,8 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             int s[19];
-            if (g8b) dn_load19_u8(reinterpret_cast<const uint8_t*>(G) + c * gp + (long long)sy * gs, c0, iw, fast, s);
-            else dn_load19_s16(G + c * gp + (long long)sy * gs, c0, iw, fast, s);
+            if (g8b) dn_load19_u8(gp(reinterpret_cast<const uint8_t*>(G)), (uint32_t)c * gpl + (uint32_t)sy * gs, c0, iw, fast, s);
+            else dn_load19_s16(gp(G), (uint32_t)c * gpl + (uint32_t)sy * gs, c0, iw, fast, s);
             int4 lo, hi;
             lo.x = h5i(s[0], s[1], s[2], s[3], s[4]);
             lo.y = h5i(s[2], s[3], s[4], s[5], s[6]);
@@ -558,15 +565,16 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
             *reinterpret_cast<int4*>(&s_h[c][r][4 * q]) = make_int4(lo.x, lo.z, hi.x, hi.z);
             *reinterpret_cast<int4*>(&s_h[c][r][32 + 4 * q]) = make_int4(lo.y, lo.w, hi.y, hi.w);
         }
-        const float* wq = im.wt[lv] + (long long)sy * im.wt_stride[lv];
+        const STX_GAS float* wq = gp(im.wt[lv]) + (uint32_t)sy * (uint32_t)im.wt_stride[lv];
         float f[19];
         if (fast) {
-            float2 a = *reinterpret_cast<const float2*>(wq + c0);
-            f[0] = a.x; f[1] = a.y;
+            const v2u a = *reinterpret_cast<const STX_GAS v2u*>(wq + c0);
+            f[0] = __uint_as_float(a.x); f[1] = __uint_as_float(a.y);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                float4 b = *reinterpret_cast<const float4*>(wq + c0 + 2 + 4 * k);
-                f[2 + 4 * k] = b.x; f[3 + 4 * k] = b.y; f[4 + 4 * k] = b.z; f[5 + 4 * k] = b.w;
+                const v4u b = *reinterpret_cast<const STX_GAS v4u*>(wq + c0 + 2 + 4 * k);
+                f[2 + 4 * k] = __uint_as_float(b.x); f[3 + 4 * k] = __uint_as_float(b.y); f[4 + 4 * k] = __uint_as_float(b.z);
+                f[5 + 4 * k] = __uint_as_float(b.w);
             }
             f[18] = wq[c0 + 18];
         } else {
@@ -605,13 +613,14 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
             }
             const int va = (h5i(a[0], a[1], a[2], a[3], a[4]) + 128) >> 8;
             const int vb = (h5i(b[0], b[1], b[2], b[3], b[4]) + 128) >> 8;
+            const uint32_t oo = (uint32_t)c * (uint32_t)im.g_plane[lv + 1] + (uint32_t)y * (uint32_t)im.g_stride[lv + 1] + (uint32_t)xo;
             if (g8b) {
-                uint8_t* o = reinterpret_cast<uint8_t*>(im.g[lv + 1]) + c * im.g_plane[lv + 1] + (long long)y * im.g_stride[lv + 1] + xo;
-                if (two) *reinterpret_cast<uint16_t*>(o) = (uint16_t)((uint32_t)va | ((uint32_t)vb << 8));
+                STX_GAS uint8_t* o = gp(reinterpret_cast<uint8_t*>(im.g[lv + 1])) + oo;
+                if (two) *reinterpret_cast<STX_GAS uint16_t*>(o) = (uint16_t)((uint32_t)va | ((uint32_t)vb << 8));
                 else o[0] = (uint8_t)va;
             } else {
-                short* o = im.g[lv + 1] + c * im.g_plane[lv + 1] + (long long)y * im.g_stride[lv + 1] + xo;
-                if (two) *reinterpret_cast<uint32_t*>(o) = pack16(va, vb);
+                STX_GAS short* o = gp(im.g[lv + 1]) + oo;
+                if (two) *reinterpret_cast<STX_GAS uint32_t*>(o) = pack16(va, vb);
                 else o[0] = (short)va;
             }
         }
@@ -623,8 +632,9 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
         }
         const float wa = fmul(h5f(fa[0], fa[1], fa[2], fa[3], fa[4]), INV256);
         const float wb = fmul(h5f(fb[0], fb[1], fb[2], fb[3], fb[4]), INV256);
-        float* o = im.wt[lv + 1] + (long long)y * im.wt_stride[lv + 1] + xo;
-        if (two) *reinterpret_cast<float2*>(o) = make_float2(wa, wb);
+        STX_GAS float* o = gp(im.wt[lv + 1]) + ((uint32_t)y * (uint32_t)im.wt_stride[lv + 1] + (uint32_t)xo);
+        typedef float v2fl __attribute__((ext_vector_type(2)));
+        if (two) { const v2fl wab = {wa, wb}; *reinterpret_cast<STX_GAS v2fl*>(o) = wab; }
         else o[0] = wa;
         nz |= __float_as_uint(wa) | (two ? __float_as_uint(wb) : 0u);
     }
