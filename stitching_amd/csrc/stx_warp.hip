@@ -334,8 +334,10 @@ STX_DEV void blend_pair_to_lds(const STX_GAS uint8_t* src, uint32_t stride, uint
 {
     // row < 2^15 and stride < 2^24 (fast_ok): 24-bit multiply, full rate
     const uint32_t a = __umul24(iy, stride) + ix * 3u;
+    // the lower row through its own scalar base (src + stride: one scalar add per wavefront) and the SAME lane offset — not
+    // src + (offset + stride), a vector add per pixel
     const STX_GAS uint32_t* q0 = reinterpret_cast<const STX_GAS uint32_t*>(src + (a & ~3u));
-    const STX_GAS uint32_t* q1 = reinterpret_cast<const STX_GAS uint32_t*>(src + ((a & ~3u) + stride));
+    const STX_GAS uint32_t* q1 = reinterpret_cast<const STX_GAS uint32_t*>((src + stride) + (a & ~3u));
     const uint32_t d0 = q0[0], d1 = q0[1], d2 = q0[2], e0 = q1[0], e1 = q1[1], e2 = q1[2];
     const uint32_t sh = a & 3u;
     const uint32_t l0 = __builtin_amdgcn_alignbyte(d1, d0, sh), h0 = __builtin_amdgcn_alignbyte(d2, d1, sh);
