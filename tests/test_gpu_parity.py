@@ -126,6 +126,33 @@ def test_blend_int16_input_and_int16_result(oracle, gpu_ctx):
     assert np.array_equal(np.asarray(pano), oracle.convert_scale_abs(o16))
 
 
+@pytest.mark.parametrize("strength,n", [(15, 4), (40, 5)])
+def test_blend_mixed_u8_and_int16_images(oracle, gpu_ctx, strength, n):
+    """One blender fed u8 AND int16 images: the Gaussian pyramid of a u8 image is stored as bytes, that of an int16 image as
+    int16 (StxMbImage::g_u8, round 3) — the gather kernels take a wave-uniform branch per image.  int16 images with values
+    outside 0..255, u8 images as the warper returns them; every level kernel (generic, register-blocked, coarse fusion)."""
+    imgs, cams = helpers.small_ring(n, 517, 389, span=35.0 * n)
+    ow = oracle.Warper("spherical")
+    ow.set_scale(cams)
+    sizes = [(517, 389)] * n
+    wu8 = [ow.warp_image(i, c) for i, c in zip(imgs, cams)]
+    wm = [ow.create_and_warp_mask(s, c) for s, c in zip(sizes, cams)]
+    corners, wsz = ow.warp_rois(sizes, cams)
+    fed = [w if k % 2 == 0 else (w.astype(np.int16) * 2 - 100) for k, w in enumerate(wu8)]  # even: u8, odd: int16 beyond 0..255
+    ob, gb = oracle.Blender("multiband", strength), S.Blender("multiband", strength)
+    ob.prepare(corners, wsz)
+    gb.prepare(corners, wsz)
+    for a, m, c in zip(fed, wm, corners):
+        ob.blender.feed(a.astype(np.int16), m, c)
+        gb.feed(a, m, c)
+    assert gb.blender.num_bands() == ob.blender.num_bands() >= 3
+    o16, omask = ob.blender.blend()
+    pano, mask, p16 = gb.blender.blend(want_s16=True)
+    assert np.array_equal(np.asarray(mask), omask)
+    assert np.array_equal(np.asarray(p16), o16)
+    assert np.array_equal(np.asarray(pano), oracle.convert_scale_abs(o16))
+
+
 @pytest.mark.parametrize("wtype,strength", [("spherical", 30), ("cylindrical", 12)])
 def test_blend_larger_odd_sizes(oracle, gpu_ctx, wtype, strength):
     """Sizes that are not multiples of anything, 5-6 bands: exercises the register-blocked kernels

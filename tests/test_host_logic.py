@@ -141,3 +141,17 @@ def test_gloo_host_transport_keeps_one_pending_exchange_per_context():
     with pytest.raises(StitchingError):
         tr.start(["s2"], ["r2"], a)
     assert tr.finish() == (["s1"], ["r1"], a)
+
+
+def test_trig_mode_switch_needs_no_gpu():
+    """stx_set_trig_mode / stx_get_trig_mode are process-wide switches (include/stitching_amd.h): usable without a device."""
+    prev = S.trig_mode()
+    try:
+        assert prev in ("exact", "glibc", "glibc-nofma")
+        assert S.set_trig_mode("glibc") == prev and S.trig_mode() == "glibc"
+        assert S.set_trig_mode("glibc-nofma") == "glibc" and S.trig_mode() == "glibc-nofma"
+        with pytest.raises(S.StitchingError):
+            S.set_trig_mode("newlib")
+        assert S.trig_mode() == "glibc-nofma"
+    finally:
+        S.set_trig_mode(prev)
