@@ -517,8 +517,11 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
     float xs[4], ys[4];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
+        // fl(32 x + 1.5 * 2^23) as ONE fused multiply-add: 32 x is exact (a power of two), so the fma rounds the same real number
+        // the multiply + add pair rounds; the products themselves (xs, ys) are only needed off the interior path
         const v2f x32 = X[h] * 32.f, y32 = Y[h] * 32.f;
-        const v2f tx = x32 + 12582912.f, ty = y32 + 12582912.f;
+        const v2f k32 = {32.f, 32.f}, kmg = {12582912.f, 12582912.f};
+        const v2f tx = __builtin_elementwise_fma(X[h], k32, kmg), ty = __builtin_elementwise_fma(Y[h], k32, kmg);
         xs[2 * h] = x32.x; xs[2 * h + 1] = x32.y; ys[2 * h] = y32.x; ys[2 * h + 1] = y32.y;
         ux[2 * h] = __float_as_uint(tx.x); ux[2 * h + 1] = __float_as_uint(tx.y);
         uy[2 * h] = __float_as_uint(ty.x); uy[2 * h + 1] = __float_as_uint(ty.y);
