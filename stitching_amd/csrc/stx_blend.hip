@@ -148,26 +148,26 @@ __global__ __launch_bounds__(256) void mb_down_kernel(StxMbImage im, int lv)
 template <class T>
 STX_DEV int pyr_up_at(const T* __restrict__ plane, long long stride, int cw, int ch, int X, int Y)
 {
+    // Branch-free: all nine taps of the 3 x 3 window are loaded whatever the parities of X and Y and the unused ones get weight 0 —
+    // a load behind a divergent parity branch is a memory round trip of its own (the three coarse levels' kernel spent 236 dependent
+    // loads per wavefront that way); the integers summed are the same.
     const int px = X >> 1, py = Y >> 1;
     const int xl = up_idx(px - 1, cw), xr = up_idx(px + 1, cw);
     const int yt = up_idx(py - 1, ch), yb = up_idx(py + 1, ch);
+    const T* rt = plane + (long long)yt * stride;
     const T* rc = plane + (long long)py * stride;
     const T* rb = plane + (long long)yb * stride;
-    int hc, hb, v;
-    if (X & 1) {
-        hc = (rc[px] + rc[xr]) * 4;
-        hb = (rb[px] + rb[xr]) * 4;
-    } else {
-        hc = rc[xl] + rc[px] * 6 + rc[xr];
-        hb = rb[xl] + rb[px] * 6 + rb[xr];
-    }
-    if (Y & 1) {
-        v = (hc + hb) * 4;
-    } else {
-        const T* rt = plane + (long long)yt * stride;
-        int ht = (X & 1) ? (rt[px] + rt[xr]) * 4 : rt[xl] + rt[px] * 6 + rt[xr];
-        v = ht + hc * 6 + hb;
-    }
+    const int t0 = rt[xl], t1 = rt[px], t2 = rt[xr];
+    const int c0 = rc[xl], c1 = rc[px], c2 = rc[xr];
+    const int b0 = rb[xl], b1 = rb[px], b2 = rb[xr];
+    // The tap weights are ARITHMETIC in the parity bits, not selects: a select between 0 and a loaded value is turned back into a
+    // branch around the load by the compiler.
+    const int ox = X & 1, oy = Y & 1;
+    const int wl = 1 - ox, wc = 6 - 2 * ox, wr = 1 + 3 * ox;   // odd column: (centre + right) * 4; even: left + 6 centre + right
+    const int ht = __mul24(t0, wl) + __mul24(t1, wc) + __mul24(t2, wr);
+    const int hc = __mul24(c0, wl) + __mul24(c1, wc) + __mul24(c2, wr);
+    const int hb = __mul24(b0, wl) + __mul24(b1, wc) + __mul24(b2, wr);
+    const int v = __mul24(ht, 1 - oy) + __mul24(hc, 6 - 2 * oy) + __mul24(hb, 1 + 3 * oy);   // odd row: (centre + below) * 4
     return (int)(short)((v + 32) >> 6);
 }
 // ... of channel c of level lv of an image's Gaussian pyramid
@@ -282,6 +282,28 @@ constexpr int CO_TW = 32, CO_TH = 16;            // tile of level B-2
 constexpr int CO_W1 = CO_TW / 2 + 2, CO_H1 = CO_TH / 2 + 2;   // level B-1 samples a tile can reach: 18 x 10
 constexpr int CO_W0 = CO_W1 / 2 + 3, CO_H0 = CO_H1 / 2 + 3;   // level B: 12 x 8 (a window that starts on an odd sample reaches one more)
 
+// the Laplacian (kind 0, below the top level) or the stored value of one sample of one image: every load of the sample — the value
+// itself and the 3 x 9 pyrUp taps of the next level — is issued before the first use (the element type is decided once, not per channel)
+template <class T>
+STX_DEV void mb_sample_of(const StxMbImage& im, bool lap, int lv, int lx, int ly, int lw, int lh, int (&L)[3])
+{
+    const STX_GAS T* g = (const STX_GAS T*)reinterpret_cast<const T*>(im.g[lv]);
+    const long long gi = (long long)ly * im.g_stride[lv] + lx;
+    int gv[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) gv[c] = (int)g[gi + c * im.g_plane[lv]];
+    if (lap) {
+        const STX_GAS T* g1 = (const STX_GAS T*)reinterpret_cast<const T*>(im.g[lv + 1]);
+        int up[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) up[c] = pyr_up_at(g1 + c * im.g_plane[lv + 1], im.g_stride[lv + 1], lw >> 1, lh >> 1, lx, ly);
+#pragma unroll
+        for (int c = 0; c < 3; c++) gv[c] = sat_s16(gv[c] - up[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) L[c] = gv[c];
+}
+
 // gather + normalise of ONE sample of level lv >= 1 (the loop body of mb_level_body<false> without the store)
 STX_DEV void mb_gather_norm(const StxMbImage* __restrict__ images, int n_images, int num_bands, int lv, int x, int y, int (&v)[3])
 {
@@ -293,14 +315,10 @@ STX_DEV void mb_gather_norm(const StxMbImage* __restrict__ images, int n_images,
         const int lw = im.fw >> lv, lh = im.fh >> lv;
         if ((unsigned)lx >= (unsigned)lw || (unsigned)ly >= (unsigned)lh) continue;
         const float w = ((const STX_GAS float*)im.wt[lv])[(long long)ly * im.wt_stride[lv] + lx];
-        const long long gi = (long long)ly * im.g_stride[lv] + lx;
+        const bool lap = im.kind == 0 && lv < num_bands;
         int L[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            int gval = ld_g(im, lv, gi + c * im.g_plane[lv]);
-            if (im.kind == 0 && lv < num_bands) gval = sat_s16(gval - pyr_up_g(im, lv + 1, c, lw >> 1, lh >> 1, lx, ly));
-            L[c] = gval;
-        }
+        if (im.g_u8) mb_sample_of<uint8_t>(im, lap, lv, lx, ly, lw, lh, L);
+        else mb_sample_of<short>(im, lap, lv, lx, ly, lw, lh, L);
         if (im.kind == 1) {  // already (short)(L * W)
             acc0 += L[0]; acc1 += L[1]; acc2 += L[2];
         } else {

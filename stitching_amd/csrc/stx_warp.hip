@@ -381,8 +381,9 @@ template <int TYPE, bool IMG, bool MASK>
 __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
 {
     const WarpK& P = B.k[blockIdx.z];
-    const float2* __restrict__ colT = B.colT[blockIdx.z];
-    const STX_CAS v4f* rowT = (const STX_CAS v4f*)B.rowT[blockIdx.z];  // wave-uniform reads: scalar loads
+    // the two table pointers ride in the same batch of scalar loads as the per-image scalars below (left to the compiler they are
+    // fetched after the early exit: one more dependent scalar-cache round trip in front of the table reads)
+    unsigned long long colT_a = (unsigned long long)B.colT[blockIdx.z], rowT_a = (unsigned long long)B.rowT[blockIdx.z];
     const int lane = threadIdx.x & 63;
     // The per-image scalars of the tile-index math and of the tests below are fetched up front, as a few wide scalar
     // loads with one wait: a wavefront lives for 256 pixels only, and the compiler otherwise sinks every one of these
@@ -397,7 +398,10 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
     uint32_t sstride = (uint32_t)P.sstride;
     asm volatile("" : "+s"(tiles_x), "+s"(tiles_y), "+s"(band_tiles), "+s"(band_rows), "+s"(magic_tx), "+s"(magic_band), "+s"(dw),
                  "+s"(dh), "+s"(ux_int), "+s"(uy_int), "+s"(num_ok));
-    asm volatile("" : "+s"(src_a), "+s"(dimg_a), "+s"(dmask_a), "+s"(dimg_stride), "+s"(dmask_stride), "+s"(sstride));
+    asm volatile("" : "+s"(src_a), "+s"(dimg_a), "+s"(dmask_a), "+s"(dimg_stride), "+s"(dmask_stride), "+s"(sstride), "+s"(colT_a),
+                 "+s"(rowT_a));
+    const STX_GAS v2f* colT = (const STX_GAS v2f*)colT_a;   // scalar base + 32-bit lane offset
+    const STX_CAS v4f* rowT = (const STX_CAS v4f*)rowT_a;  // wave-uniform reads: scalar loads
     // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only), and the
     // per-XCD L2s do not share lines.  Bands of WARP_BAND tile rows go round-robin to the XCDs: vertically adjacent
     // tiles — which read the same source rows — mostly meet in one L2 instead of fetching those rows once per
@@ -426,7 +430,7 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
     const int y0 = tile_y * WARP_TH;
     // columns beyond the image are computed on the clamped table entry, rows beyond it on the repeated last row
     // (harmless) and never stored
-    const float2 ct = colT[min(xw + lane, dw - 1)];
+    const v2f ct = *(const STX_GAS v2f*)((const STX_GAS char*)colT + ((uint32_t)min(xw + lane, dw - 1) << 3));  // dw < 2^29
     // The wavefront's 4 rows as two row pairs: every step below is a packed fp32 operation on (row 2h, row 2h + 1).
     // Row constants: one 64-byte block {ra x4}, {p1 x4}, {p4 x4}, {p7 x4} per tile row, a single scalar load.
     const v4f RA = rowT[4 * tile_y], P1 = rowT[4 * tile_y + 1], P4 = rowT[4 * tile_y + 2], P7 = rowT[4 * tile_y + 3];
