@@ -55,6 +55,23 @@ extern "C" {
 int stx_set_trig_mode(int mode);
 int stx_get_trig_mode(void);
 
+/* remap modes.  stitching/warper.py:46-51 calls cv.remap(INTER_LINEAR, BORDER_REFLECT) on fp32 maps.  OpenCV 4.x quantises the
+ * position to 1/32 pixel and blends the four taps with Q15 table weights (remapBilinear); the reference pins opencv-python 5.0.0.93
+ * (requirements.txt:1), whose build is not available here — if it interpolates in fp32 on the unquantised position, the bytes differ by
+ * 1-2 LSB on about a sixth of the pixels (profiles/r02_oracle_sensitivity.md).  The back end offers both arithmetic models:
+ *   STX_REMAP_Q15        the classic fixed-point scheme (default; the tuned kernels);
+ *   STX_REMAP_FLOAT      fp32 bilinear on the unquantised position: a = x - floor(x), t = a (p01 - p00) + p00, u likewise on the lower
+ *                        row, cvRound(b (u - t) + t), every step rounded to fp32 (multiply and add separate);
+ *   STX_REMAP_FLOAT_FMA  the same with each multiply-add fused.
+ * The float modes are a MODEL of that build (oracle/stx_oracle.cpp: bilinear_px_float), unverified against it like everything here
+ * that restates OpenCV; they run on the plain one-pixel-per-lane kernels.  Masks (INTER_NEAREST) are the same in every mode.
+ * Process-wide: STITCHING_AMD_REMAP = q15 | float | float-fma at first use, or stx_set_remap_mode. */
+#define STX_REMAP_Q15 0
+#define STX_REMAP_FLOAT 1
+#define STX_REMAP_FLOAT_FMA 2
+int stx_set_remap_mode(int mode);
+int stx_get_remap_mode(void);
+
 /* warper types: the names of Warper.WARP_TYPE_CHOICES (stitching/warper.py:10-27);
  * cv.PyRotationWarper(type, scale) string -> id in the Python shim */
 #define STX_WARP_PLANE 0

@@ -38,3 +38,27 @@ def trig_mode():
     from . import _lib
 
     return {v: k for k, v in _lib.TRIG_MODES.items()}[_lib.lib().stx_get_trig_mode()]
+
+
+def set_remap_mode(mode):
+    """Interpolation model of the image samples of a warp (include/stitching_amd.h STX_REMAP_*): "q15" (OpenCV 4.x's fixed-point
+    remap, default), "float" or "float-fma" (fp32 bilinear on the unquantised position: a model of a cv.remap that interpolates in
+    floating point, stitching/warper.py:46-51 with the pinned opencv-python 5.x — unverified).  Process-wide; STITCHING_AMD_REMAP sets
+    the start-up value.  Returns the previous mode."""
+    from . import _lib
+
+    L = _lib.lib()
+    names = {v: k for k, v in _lib.REMAP_MODES.items()}
+    prev = names[L.stx_get_remap_mode()]
+    if mode not in _lib.REMAP_MODES:
+        from .stitching_error import StitchingError
+
+        raise StitchingError(f"unknown remap mode {mode!r}: one of {sorted(_lib.REMAP_MODES)}")
+    _lib.check(L.stx_set_remap_mode(_lib.REMAP_MODES[mode]))
+    return prev
+
+
+def remap_mode():
+    from . import _lib
+
+    return {v: k for k, v in _lib.REMAP_MODES.items()}[_lib.lib().stx_get_remap_mode()]

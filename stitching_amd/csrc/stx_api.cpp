@@ -821,6 +821,33 @@ STX_EXPORT int stx_set_trig_mode(int mode)
     return STX_OK;
 }
 
+// remap mode: the interpolation model of the image samples (include/stitching_amd.h); process-wide, initialised from
+// STITCHING_AMD_REMAP = q15 | float | float-fma on first use
+static std::atomic<int> g_remap_mode{-1};
+
+static int remap_mode_now()
+{
+    int m = g_remap_mode.load();
+    if (m >= 0) return m;
+    const char* e = getenv("STITCHING_AMD_REMAP");
+    m = STX_REMAP_Q15;
+    if (e && !strcmp(e, "float")) m = STX_REMAP_FLOAT;
+    else if (e && !strcmp(e, "float-fma")) m = STX_REMAP_FLOAT_FMA;
+    else if (e && *e && strcmp(e, "q15")) fprintf(stderr, "[stitching_amd] STITCHING_AMD_REMAP=%s is not one of q15, float, float-fma: using q15\n", e);
+    int expected = -1;
+    g_remap_mode.compare_exchange_strong(expected, m);
+    return g_remap_mode.load();
+}
+
+STX_EXPORT int stx_get_remap_mode(void) { return remap_mode_now(); }
+
+STX_EXPORT int stx_set_remap_mode(int mode)
+{
+    if (mode < STX_REMAP_Q15 || mode > STX_REMAP_FLOAT_FMA) return stx_fail(STX_ERR_INVALID, "remap mode %d", mode);
+    g_remap_mode.store(mode);
+    return STX_OK;
+}
+
 int stx_make_projector(int type, float scale, const float* K, const float* R, StxProjector* p)
 {
     if (type < STX_WARP_PLANE || type >= STX_WARP_TYPE_COUNT)
@@ -831,6 +858,7 @@ int stx_make_projector(int type, float scale, const float* K, const float* R, St
     p->type = type;
     p->scale = scale;
     p->trig = trig_mode_now();
+    p->remap = remap_mode_now();
     // PyRotationWarper's constructor: "compressedPlaneA2B1" -> CompressedRectilinearWarper(2.0f, 1.0f), "...A1.5B1" -> (1.5f, 1.0f), ...
     static const struct { int family; float a; } kTypes[STX_WARP_TYPE_COUNT] = {
         {STX_F_PLANE, 1.f}, {STX_F_PLANE, 1.f}, {STX_F_CYLINDRICAL, 1.f}, {STX_F_SPHERICAL, 1.f}, {STX_F_FISHEYE, 1.f},

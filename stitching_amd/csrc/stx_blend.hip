@@ -367,7 +367,12 @@ struct MbCoarseK {
     int pw, ph;              // padded panorama size at level B-2 (a multiple of 4)
 };
 
-__global__ __launch_bounds__(256) void mb_coarse_kernel(MbCoarseK P)
+// 7 wavefronts per SIMD (72 registers; the unconstrained build takes 78 -> 6): config 2's 1 680 workgroups are one resident set on
+// 256 CUs x 7, and a second round of a latency-bound kernel doubles its time
+#ifndef STX_COARSE_WAVES
+#define STX_COARSE_WAVES 7
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_COARSE_WAVES, 8))) void mb_coarse_kernel(MbCoarseK P)
 {
     __shared__ short s0[3][CO_H0 * CO_W0];  // finished level B
     __shared__ short s1[3][CO_H1 * CO_W1];  // finished level B-1

@@ -135,6 +135,7 @@ struct StxProjector {
     float scale;
     float k[9], rinv[9], r_kinv[9], k_rinv[9], t[3];
     int trig;  // STX_TRIG_*: the process-wide trig mode at the time the projector was made (stx_set_trig_mode)
+    int remap; // STX_REMAP_*: likewise the interpolation model of the image samples (stx_set_remap_mode)
 };
 int stx_make_projector(int type, float scale, const float* K, const float* R, StxProjector* out);
 

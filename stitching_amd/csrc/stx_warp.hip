@@ -62,6 +62,7 @@ struct WarpK {
     float mx32_hi, my32_hi;
     float c2, c5, c8;  // plane: kr2 (1 - t2), kr5 (1 - t2), kr8 (1 - t2), each rounded once (host fp32 = device fp32)
     int trig;    // STX_TRIG_*: which sinf / cosf the projector's trigonometry follows (stx_device_math.h: sincosf_m)
+    int remap;   // STX_REMAP_*: the interpolation model of the image samples; anything but Q15 runs the one-pixel-per-lane kernels
     int num_ok;  // host-proved: |numerators| <= 2^60 and finite tables, the per-lane magnitude test is skipped
     int z_one;   // host-proved (plane / affine): z = 1.f for every pixel, the quotients are the numerators
 };
@@ -99,6 +100,49 @@ STX_DEV uint32_t bil(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, uin
     uint32_t h0 = p00 * (32u - fx) + p01 * fx;
     uint32_t h1 = p10 * (32u - fx) + p11 * fx;
     return (h0 * (32u - fy) + h1 * fy + 512u) >> 10;
+}
+
+// 24-bit pixel j of a lane's 4 adjacent pixels into its 3 output dwords
+STX_DEV void put_px(uint32_t (&out)[3], int j, uint32_t px)
+{
+    if (j == 0) out[0] = px;
+    else if (j == 1) { out[0] |= px << 24; out[1] = px >> 8; }
+    else if (j == 2) { out[1] |= px << 16; out[2] = px >> 16; }
+    else out[2] |= px << 8;
+}
+
+// STX_REMAP_FLOAT / STX_REMAP_FLOAT_FMA: fp32 bilinear on the unquantised position with BORDER_REFLECT taps — the model of a remap that
+// interpolates in floating point (include/stitching_amd.h spells out the sequence of fp32 operations; the tests compare it with the
+// CPU checker's).  A position that is not a finite number of moderate size samples (-1, -1).  One pixel at a time, byte loads: this mode
+// exists to be compared with, not to be fast.
+STX_DEV uint32_t sample_float(const uint8_t* __restrict__ src, long long sstride, int sw, int sh, bool fused, float x, float y)
+{
+    if (!(x > -1.0e9f && x < 1.0e9f && y > -1.0e9f && y < 1.0e9f)) { x = -1.f; y = -1.f; }
+    const float fxf = floorf(x), fyf = floorf(y);
+    const int ix = (int)fxf, iy = (int)fyf;
+    const float a = fsub(x, fxf), b = fsub(y, fyf);
+    const int sx0 = reflect(ix, sw), sx1 = reflect(ix + 1, sw);
+    const int sy0 = reflect(iy, sh), sy1 = reflect(iy + 1, sh);
+    const uint8_t* r0 = src + (long long)sy0 * sstride;
+    const uint8_t* r1 = src + (long long)sy1 * sstride;
+    uint32_t px = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float p00 = (float)r0[sx0 * 3 + c], p01 = (float)r0[sx1 * 3 + c];
+        const float p10 = (float)r1[sx0 * 3 + c], p11 = (float)r1[sx1 * 3 + c];
+        float t, u, v;
+        if (fused) {
+            t = __fmaf_rn(a, fsub(p01, p00), p00);
+            u = __fmaf_rn(a, fsub(p11, p10), p10);
+            v = __fmaf_rn(b, fsub(u, t), t);
+        } else {
+            t = fadd(fmul(a, fsub(p01, p00)), p00);
+            u = fadd(fmul(a, fsub(p11, p10)), p10);
+            v = fadd(fmul(b, fsub(u, t)), t);
+        }
+        px |= (uint32_t)min(max(cv_round(v), 0), 255) << (8 * c);
+    }
+    return px;
 }
 
 // Separable part of mapBackward, evaluated once per destination column / row (fp64 "exact" trig):
@@ -198,7 +242,9 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpK P, const float2* __rest
                 x = yy = -1.f;
             }
         }
-        if (IMG) {
+        if (IMG && P.remap != STX_REMAP_Q15) {
+            put_px(out, j, sample_float(P.src, P.sstride, P.sw, P.sh, P.remap == STX_REMAP_FLOAT_FMA, x, yy));
+        } else if (IMG) {
             // remap(): sx = cvRound(x*32); (ix, fx) = (sx >> 5 saturated to short, sx & 31)
             int sx = cv_round(fmul(x, 32.f)), sy = cv_round(fmul(yy, 32.f));
             uint32_t fx = (uint32_t)sx & 31u, fy = (uint32_t)sy & 31u;
@@ -635,6 +681,7 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
 // generic remapBilinear / BORDER_REFLECT sample of one pixel -> 24-bit BGR
 STX_DEV uint32_t sample_generic(const WarpK& P, float x, float yy)
 {
+    if (P.remap != STX_REMAP_Q15) return sample_float(P.src, P.sstride, P.sw, P.sh, P.remap == STX_REMAP_FLOAT_FMA, x, yy);
     int sx = cv_round(fmul(x, 32.f)), sy = cv_round(fmul(yy, 32.f));
     uint32_t fx = (uint32_t)sx & 31u, fy = (uint32_t)sy & 31u;
     int ix = sat_s16(sx >> 5), iy = sat_s16(sy >> 5);
@@ -657,14 +704,6 @@ STX_DEV uint32_t sample_generic(const WarpK& P, float x, float yy)
         rr = bil(r0[sx0 * 3 + 2], r0[sx1 * 3 + 2], r1[sx0 * 3 + 2], r1[sx1 * 3 + 2], fx, fy);
     }
     return b | (g << 8) | (rr << 16);
-}
-
-STX_DEV void put_px(uint32_t (&out)[3], int j, uint32_t px)
-{
-    if (j == 0) out[0] = px;
-    else if (j == 1) { out[0] |= px << 24; out[1] = px >> 8; }
-    else if (j == 2) { out[1] |= px << 16; out[2] = px >> 16; }
-    else out[2] |= px << 8;
 }
 
 // Family groups of the per-pixel kernel.  What depends on the destination column alone (u') or on the row alone (v') is
@@ -924,7 +963,7 @@ __global__ __launch_bounds__(256) void roi_kernel(RoiBatchK B, float* __restrict
 
 bool fast_ok(const WarpK& K)
 {
-    return !K.msrc && K.sw <= 32767 && K.sh <= 32767 && K.sw >= 2 && K.sh >= 2 && (long long)K.sstride * K.sh < (1ll << 31);
+    return !K.msrc && K.remap == STX_REMAP_Q15 && K.sw <= 32767 && K.sh <= 32767 && K.sw >= 2 && K.sh >= 2 && (long long)K.sstride * K.sh < (1ll << 31);
 }
 
 template <int TYPE>
@@ -1042,6 +1081,7 @@ void fill_warpk(const StxWarpLaunch& L, WarpK* Kp, double* bytes)
     K.scale = L.proj.scale;
     K.family = L.proj.family; K.pa = L.proj.a; K.pb = L.proj.b;
     K.trig = L.proj.trig;
+    K.remap = L.proj.remap;
     K.tlx = L.tlx; K.tly = L.tly; K.dw = L.dw; K.dh = L.dh;
     K.sw = L.sw; K.sh = L.sh;
     const bool img = L.dimg != nullptr, mask = L.dmask != nullptr;

@@ -16,6 +16,11 @@ MI355X-first design of SURVEY.md §8(e) / DESIGN.md §6:
   * the receiver adds everything in global feed order, so the assembled panorama is bit-identical to the single-GPU
     result.
 
+The feather and the "no" blender (stitching/blender.py:27-36) shard the same way with simpler strips (round 3): both are per-pixel
+once an image's weight map is known, and a feather weight min(dist * sharpness, 1) depends on the mask only within 1 / sharpness
+columns — so the strip is the band's columns of the image plus that halo (none for "no"), the receiver feeds it like an image into a
+blender prepared for its band (+ halo) and crops the result; everything is fed in global order (`flat_strip_columns`).
+
 `ShardPlan` is pure geometry (every rank computes the same plan from the global camera list);
 `ShardedStitchJob` runs one rank; transports move packed contribution buffers:
 `RcclTransport` (C ABI -> librccl), `GlooHostTransport` (host-staged, for tests / 1-GPU boxes).
@@ -174,15 +179,47 @@ def band_edges(corners, sizes, owners, world, roi, num_bands):
     return edges
 
 
+FEATHER_DIST_CAP = 8192  # the distance transform saturates there (csrc/stx_blend.hip: 16-bit distances; OpenCV's 16.16 fixed point)
+
+
+def feather_halo(sharpness):
+    """Columns of mask a feather weight can depend on: weight = min(dist * sharpness, 1) with dist the L1 distance to the nearest
+    zero of the image's mask (FeatherBlender::feed -> createWeightMap).  A zero farther than 1 / sharpness (or than the saturation
+    distance) away leaves the weight at its cap, so with this many columns on both sides a strip's distance transform yields the
+    weights of the whole image's wherever they are below the cap, and the cap elsewhere; + 2: fl(d * sharpness) >= 1 for every
+    integer d beyond the halo, whatever the rounding of the product."""
+    if not sharpness > 0:
+        return FEATHER_DIST_CAP + 1
+    return int(min(np.ceil(1.0 / float(np.float32(sharpness))) + 2, FEATHER_DIST_CAP + 1))
+
+
+def flat_strip_columns(corner, size, roi, band, halo):
+    """Columns [x0, x1) of an image that the owner of `band` needs under a per-pixel blender: where the image meets the band, widened
+    by `halo` inside the image.  x0 == x1: the image does not reach the band."""
+    tlx, w = int(corner[0]) - int(roi[0]), int(size[0])
+    if min(band[1], tlx + w) <= max(band[0], tlx):
+        return (0, 0)
+    # the first column on a multiple of 8 (stx_strip_pack's rule: the mask bits of a row start on a byte); up to 7 more columns of halo
+    return ((max(band[0] - halo, tlx) - tlx) & ~7, min(band[1] + halo, tlx + w) - tlx)
+
+
 class ShardPlan:
     """Who owns which columns and which contribution strips travel where.  Pure geometry: built from
     the global corner/size lists, identical on every rank."""
 
-    def __init__(self, corners, warped_sizes, owners, world, blender_probe, exchange="strips", mask_bits=False):
+    def __init__(self, corners, warped_sizes, owners, world, blender_probe, exchange="strips", mask_bits=False, kind="multiband",
+                 halo=0):
         """mask_bits (strips): the masks are known to hold 0 / 255 only and travel as one bit per pixel
-        (STX_STRIP_MASK_BITS: 3.125 instead of 4 bytes per pixel on the links)."""
+        (STX_STRIP_MASK_BITS: 3.125 instead of 4 bytes per pixel on the links).
+        kind: "multiband" (blender_probe: a ShardBlender of the panorama, asked for the strip geometry), or "feather" / "no"
+        (blender_probe unused; halo: feather_halo(sharpness) / 0)."""
         if exchange not in ("strips", "contribs"):
             raise StitchingError(f"unknown exchange form {exchange!r}")
+        if kind not in ("multiband", "feather", "no"):
+            raise StitchingError(f"unknown blender type {kind!r}")
+        if kind != "multiband" and exchange != "strips":
+            raise StitchingError("the feather and the plain blender exchange image strips")
+        self.kind, self.halo = kind, int(halo) if kind == "feather" else 0
         self.exchange = exchange
         self.mask_bits = bool(mask_bits) and exchange == "strips"
         self.strip_flags = _lib.STRIP_MASK_BITS if self.mask_bits else 0
@@ -191,7 +228,7 @@ class ShardPlan:
         self.owners = list(owners)
         self.world = int(world)
         self.roi = Blender.result_roi(self.corners, self.sizes)
-        self.num_bands = blender_probe.num_bands()
+        self.num_bands = blender_probe.num_bands() if kind == "multiband" else 0
         self.edges = band_edges(self.corners, self.sizes, self.owners, self.world, self.roi, self.num_bands)
         # messages: (order k, src rank, dst rank, rect, bytes), sorted by (dst, k) so that every
         # rank posts sends / receives in one global order.  rect: contribs -> (x, y, w, h) relative to the roi;
@@ -202,9 +239,12 @@ class ShardPlan:
                 if g == self.owners[k]:
                     continue
                 if exchange == "strips":
-                    (x0, x1), nbytes = blender_probe.strip_rect(s, c, self.band(g))
+                    if kind == "multiband":
+                        (x0, x1), nbytes = blender_probe.strip_rect(s, c, self.band(g))
+                    else:
+                        (x0, x1), nbytes = flat_strip_columns(c, s, self.roi, self.band(g), self.halo), None
                     if x1 > x0:
-                        if self.mask_bits:
+                        if self.mask_bits or nbytes is None:
                             nb = C.c_size_t()
                             _lib.check(_lib.lib().stx_strip_bytes(x1 - x0, int(s[1]), self.strip_flags, C.byref(nb)))
                             nbytes = int(nb.value)
@@ -217,6 +257,17 @@ class ShardPlan:
 
     def band(self, g):
         return (self.edges[g], self.edges[g + 1])
+
+    def band_roi(self, g):
+        """feather / no: (roi the blender of rank g is prepared for — its band + halo, absolute panorama coordinates —, the band's
+        columns inside it)"""
+        b0, b1 = self.band(g)
+        lo, hi = max(b0 - self.halo - 7, 0), min(b1 + self.halo, self.roi[2])  # - 7: flat_strip_columns rounds a strip's start down
+        return (self.roi[0] + lo, self.roi[1], hi - lo, self.roi[3]), (b0 - lo, b1 - lo)
+
+    def own_columns(self, k, g):
+        """feather / no: the columns of image k that rank g's blender is fed (its own image or a received strip)"""
+        return flat_strip_columns(self.corners[k], self.sizes[k], self.roi, self.band(g), self.halo)
 
     def sends(self, rank):
         return [m for m in self.messages if m[1] == rank]
@@ -386,8 +437,11 @@ class ShardedStitchJob:
         travel (lowest latency of ONE panorama).  A caller that keeps several panoramas in flight on several contexts
         passes False: all local images go through one warp launch and one pyramid build, and the other panorama's
         kernels fill the time of the exchange."""
-        if blender_type != "multiband":
-            raise StitchingError("sharded blending is implemented for the multi-band blender")
+        if blender_type not in Blender.BLENDER_CHOICES:
+            raise StitchingError(f"unknown blender type {blender_type!r}")
+        if blender_type != "multiband" and exchange != "strips":
+            raise StitchingError("the feather and the plain blender exchange image strips")
+        self.blender_type = blender_type
         self.ctx = ctx or get_context()
         self.rank, self.world = int(rank), int(world)
         self.frames = [as_device(f, self.ctx) for f in frames]
@@ -417,6 +471,23 @@ class ShardedStitchJob:
     def plan(self):
         corners, wsizes = self.warper.warp_rois(self.all_sizes, self.all_cameras)
         roi = Blender.result_roi(corners, wsizes)
+        if self.blender_type != "multiband":
+            # Blender.prepare's choice (stitching/blender.py:25-36): "no", or a feather width below one pixel -> the plain blender
+            if self.blend_strength is None:
+                self.blend_strength = Blender.DEFAULT_BLEND_STRENGTH
+            blend_width = np.sqrt(roi[2] * roi[3]) * self.blend_strength / 100
+            self.roi = roi
+            if self.blender_type == "no" or blend_width < 1:
+                self.flat_kind, self.sharpness = "no", 0.0
+            else:
+                self.flat_kind, self.sharpness = "feather", 1.0 / blend_width
+            self.req_bands = 0
+            self.plan_ = ShardPlan(corners, wsizes, self.owners, self.world, None, "strips", self.mask_bits, kind=self.flat_kind,
+                                   halo=feather_halo(self.sharpness))
+            self.last_num_bands = 0
+            if self.transport is None:
+                self.transport = default_transport(self.ctx, self.rank, self.world, self.dist)
+            return self.plan_
         if self.blend_strength is None:
             self.blend_strength = blend_strength_for_bands(self.num_bands_req, roi[2], roi[3])
         blend_width = np.sqrt(roi[2] * roi[3]) * self.blend_strength / 100
@@ -440,6 +511,11 @@ class ShardedStitchJob:
             raise StitchingError("warp rois changed between plan() and run()")
         prev = config.device_resident()
         config.set_device_resident(True)
+        if p.kind != "multiband":
+            try:
+                return self._run_flat(p)
+            finally:
+                config.set_device_resident(prev)
         try:
             blender = make_shard_blender(self.ctx, self.roi, self.req_bands)
             blender.set_band(*p.band(self.rank))
@@ -479,6 +555,38 @@ class ShardedStitchJob:
         finally:
             config.set_device_resident(prev)
         return pano, mask
+
+    def _run_flat(self, p):
+        """feather / "no": warp everything, send every other band its columns (+ halo), feed this band's blender its own columns and the
+        received strips in global feed order, blend, crop the halo off."""
+        imgs, masks, rois = self.warper.warp_images_and_masks(self.frames, self.cameras)
+        warped = {}
+        for k, img, mask, roi in zip(self.my_orders, imgs, masks, rois):
+            if roi[0:2] != p.corners[k]:
+                raise StitchingError("warp roi changed between plan() and run()")
+            warped[k] = (img, mask)
+        send_msgs, recv_msgs = p.sends(self.rank), p.recvs(self.rank)
+        packed = strip_pack_batch(self.ctx, [(warped[k][0], warped[k][1], rect[0], rect[1]) for (k, _s, _d, rect, _n) in send_msgs], p.strip_flags)
+        self.transport.start([(dst, buf, nbytes) for (_k, _src, dst, _rect, nbytes), buf in zip(send_msgs, packed)],
+                             [(m[1], m[4]) for m in recv_msgs], self.ctx)
+        band_roi, (c0, c1) = p.band_roi(self.rank)
+        blender = ShardBlender(self.ctx, _lib.BLEND_FEATHER if p.kind == "feather" else _lib.BLEND_NO, 0, self.sharpness, band_roi)
+        items = []  # (global feed index, image, mask, corner)
+        for k in self.my_orders:
+            x0, x1 = p.own_columns(k, self.rank)
+            if x1 > x0:
+                img, mask = warped[k]
+                whole = x0 == 0 and x1 == p.sizes[k][0]
+                items.append((k, img if whole else img[:, x0:x1], mask if whole else mask[:, x0:x1], (p.corners[k][0] + x0, p.corners[k][1])))
+        rbufs = self.transport.finish(self.ctx)
+        for m, buf in zip(recv_msgs, rbufs):
+            simg, smask = strip_unpack(buf, m[3][2], m[3][3], _lib.CONTRIB_U8_BINARY | p.strip_flags)
+            items.append((m[0], simg, smask, (p.corners[m[0]][0] + m[3][0], p.corners[m[0]][1])))
+        # the plain blender overwrites and the feather blender adds fp32 weights: both in the order of the reference's feed loop
+        for k, img, mask, corner in sorted(items, key=lambda it: it[0]):
+            blender.feed_ex(img, mask, corner, k)
+        pano, mask = blender.blend()
+        return pano[:, c0:c1], mask[:, c0:c1]
 
     def _warp_and_feed(self, blender, orders, p):
         """-> {order: (warped image, mask)} of the images fed"""
@@ -622,6 +730,35 @@ def _mask_is_binary(ctx, mask):
 
 
 # ------------------------------------------------------------------------------------ test helper
+def virtual_sharded_flat_blend(ctx, warped, masks, corners, sizes, world, kind, sharpness=0.0, mask_bits=False):
+    """virtual_sharded_blend for the feather (kind="feather", sharpness) and the plain (kind="no") blender"""
+    n = len(warped)
+    owners = owners_contiguous(n, world)
+    d_imgs = [as_device(w, ctx) for w in warped]
+    d_masks = [as_device(m, ctx) for m in masks]
+    binary = [_mask_is_binary(ctx, m) for m in d_masks]
+    plan = ShardPlan(corners, sizes, owners, world, None, "strips", mask_bits and all(binary), kind=kind, halo=feather_halo(sharpness))
+    bands = []
+    for g in range(world):
+        band_roi, (c0, c1) = plan.band_roi(g)
+        b = ShardBlender(ctx, _lib.BLEND_FEATHER if kind == "feather" else _lib.BLEND_NO, 0, sharpness, band_roi)
+        strips = {m[0]: m for m in plan.recvs(g)}
+        for k in range(n):
+            if owners[k] == g:
+                x0, x1 = plan.own_columns(k, g)
+                if x1 > x0:
+                    b.feed_ex(d_imgs[k][:, x0:x1], d_masks[k][:, x0:x1], (plan.corners[k][0] + x0, plan.corners[k][1]), k)
+            elif k in strips:
+                rect, nbytes = strips[k][3], strips[k][4]
+                packed = strip_pack(ctx, d_imgs[k], d_masks[k], rect[0], rect[1], plan.strip_flags)
+                assert packed.width * packed.height == nbytes
+                simg, smask = strip_unpack(packed, rect[2], rect[3], (_lib.CONTRIB_U8_BINARY if binary[k] else 0) | plan.strip_flags)
+                b.feed_ex(simg, smask, (plan.corners[k][0] + rect[0], plan.corners[k][1]), k)
+        pano, mask = b.blend()
+        bands.append((np.asarray(pano)[:, c0:c1], np.asarray(mask)[:, c0:c1]))
+    return np.concatenate([p for p, _ in bands], axis=1), np.concatenate([m for _, m in bands], axis=1), plan
+
+
 def virtual_sharded_blend(ctx, warped, masks, corners, sizes, world, num_bands, exchange="strips", mask_bits=False):
     """All `world` ranks simulated in ONE process on one GPU: same kernels, same geometry, the
     exchange is a pointer hand-over.  Returns (panorama, mask, plan) as numpy arrays."""

@@ -34,7 +34,9 @@ def main():
                                       layout_yaw=case.get("layout_yaw"))
     mine = range(rank * per, (rank + 1) * per)
     frames = [synthetic.make_frame(case.get("seed", 0) + i, w, h) for i in mine]
-    job = ShardedStitchJob(frames, [cams[i] for i in mine], cams, rank, world, warper_type=case["warper"], num_bands=case["bands"],
+    btype = case.get("blender", "multiband")  # "feather" / "no": case["strength"] is the reference's blend_strength
+    job = ShardedStitchJob(frames, [cams[i] for i in mine], cams, rank, world, warper_type=case["warper"], num_bands=case.get("bands", 5),
+                           blender_type=btype, blend_strength=case.get("strength") if btype != "multiband" else None,
                            ctx=ctx, dist=dist, split_boundary=case.get("split", True), exchange=case.get("exchange", "strips"),
                            mask_bits=case.get("mask_bits", True))
     plan = job.plan()
@@ -53,7 +55,7 @@ def main():
         sizes = [(w, h)] * n
         corners, wsizes = ow.warp_rois(sizes, cams)
         roi = O.result_roi(corners, wsizes)
-        ob = O.Blender("multiband", synthetic.blend_strength_for_bands(case["bands"], roi[2], roi[3]))
+        ob = O.Blender(btype, case["strength"] if btype != "multiband" else synthetic.blend_strength_for_bands(case["bands"], roi[2], roi[3]))
         ob.prepare(corners, wsizes)
         for f, c, corner in zip(all_frames, cams, corners):
             ob.feed(ow.warp_image(f, c), ow.create_and_warp_mask((w, h), c), corner)

@@ -1,0 +1,82 @@
+"""The feather and the plain ("no") blender through the sharded path (VERDICT r2 "what's missing" 7;
+stitching/blender.py:27-36): column bands, strips = the band's columns of an image + the feather halo, per-band blenders fed in
+global order, halo cropped off.  All ranks on one GPU: as virtual shards (pointer hand-over) and as ShardedStitchJob ranks
+(record / replay transport), against the single blender and against the oracle; tests/test_gpu_two_process.py runs real
+processes; tests/test_crop_theory.py::test_flat_strips_reproduce_their_band is the same statement on the CPU oracle alone."""
+import numpy as np
+import pytest
+
+import stitching_amd as S
+from stitching_amd import synthetic
+from stitching_amd.distributed import feather_halo, virtual_sharded_flat_blend
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _warped(oracle, n, w, h, span, seams, wtype="spherical"):
+    cams = synthetic.ring_cameras(n, w, h, span_deg=span)
+    imgs = [synthetic.make_frame(300 + i, w, h) for i in range(n)]
+    ow = oracle.Warper(wtype)
+    ow.set_scale(cams)
+    sizes = [(w, h)] * n
+    corners, wsizes = ow.warp_rois(sizes, cams)
+    wimgs = [ow.warp_image(im, c) for im, c in zip(imgs, cams)]
+    wmasks = [ow.create_and_warp_mask(s, c) for s, c in zip(sizes, cams)]
+    if seams:
+        wmasks = synthetic.voronoi_seam_masks(wmasks, corners, wsizes)
+    return cams, imgs, corners, wsizes, wimgs, wmasks
+
+
+@pytest.mark.parametrize("mask_bits", [False, True])
+@pytest.mark.parametrize("seams", [False, True])
+@pytest.mark.parametrize("world,kind,strength", [(2, "feather", 5), (3, "feather", 1.5), (4, "feather", 12), (3, "no", 5)])
+def test_virtual_shards_equal_oracle(oracle, gpu_ctx, world, kind, strength, seams, mask_bits):
+    n, w, h = 2 * world, 640, 400
+    _, _, corners, wsizes, wimgs, wmasks = _warped(oracle, n, w, h, 30.0 * n, seams)
+    ob = oracle.Blender(kind, strength)
+    ob.prepare(corners, wsizes)
+    for im, m, c in zip(wimgs, wmasks, corners):
+        ob.feed(im, m, c)
+    o_pano, o_mask = (np.asarray(a) for a in ob.blend())
+    roi = oracle.result_roi(corners, wsizes)
+    sharp = 1.0 / (np.sqrt(roi[2] * roi[3]) * strength / 100) if kind == "feather" else 0.0
+    pano, mask, plan = virtual_sharded_flat_blend(gpu_ctx, wimgs, wmasks, corners, wsizes, world, kind, sharp, mask_bits=mask_bits)
+    assert plan.halo == (feather_halo(sharp) if kind == "feather" else 0) and len(plan.messages) >= world - 1
+    assert plan.mask_bits == mask_bits  # warped and seam masks are 0 / 255
+    assert pano.shape == o_pano.shape and np.array_equal(mask, o_mask)
+    assert np.array_equal(pano, o_pano), f"{np.count_nonzero(pano != o_pano)} differing bytes"
+    # ... and the single blender of the product
+    b = S.Blender(kind, strength)
+    b.prepare(corners, wsizes)
+    for im, m, c in zip(wimgs, wmasks, corners):
+        b.feed(im, m, c)
+    s_pano, s_mask = (np.asarray(a) for a in b.blend())
+    assert np.array_equal(pano, s_pano) and np.array_equal(mask, s_mask)
+
+
+@pytest.mark.parametrize("blender,strength,world,per_rank", [("feather", 3, 2, 3), ("feather", 8, 3, 2), ("no", 5, 3, 2)])
+def test_sharded_job_feather_and_plain_equal_oracle(oracle, gpu_ctx, blender, strength, world, per_rank):
+    """ShardedStitchJob(blender_type=...) as bench.py / a user drives it — warp, pack, exchange, feed, blend, crop — every rank
+    executed on this GPU (record / replay); the concatenated bands are the oracle's panorama."""
+    n, w, h = world * per_rank, 803, 601
+    cams = synthetic.ring_cameras(n, w, h, span_deg=28.0 * n)
+    frames = [synthetic.make_frame(500 + i, w, h) for i in range(n)]
+    pano, mask, jobs = helpers.run_sharded_job_in_one_process(gpu_ctx, frames, cams, world, per_rank, blender_type=blender,
+                                                              blend_strength=strength)
+    assert all(j.plan_.kind == blender and j.plan_.num_bands == 0 for j in jobs)
+    o = helpers.run_pipeline(oracle.Warper, oracle.Blender, frames, cams, blender_type=blender, blend_strength=strength)
+    assert jobs[0].plan_.corners == [tuple(c) for c in o["corners"]]
+    assert np.array_equal(mask, o["pmask"])
+    assert np.array_equal(pano, o["pano"]), f"{np.count_nonzero(pano != o['pano'])} differing bytes"
+
+
+def test_feather_narrower_than_a_pixel_is_the_plain_blender(oracle, gpu_ctx):
+    """Blender.prepare's rule (stitching/blender.py:27): blend_width < 1 -> the plain blender, sharded too."""
+    n, w, h = 4, 320, 240
+    cams = synthetic.ring_cameras(n, w, h, span_deg=100.0)
+    frames = [synthetic.make_frame(700 + i, w, h) for i in range(n)]
+    pano, mask, jobs = helpers.run_sharded_job_in_one_process(gpu_ctx, frames, cams, 2, 2, blender_type="feather", blend_strength=0.05)
+    assert jobs[0].plan_.kind == "no"
+    o = helpers.run_pipeline(oracle.Warper, oracle.Blender, frames, cams, blender_type="feather", blend_strength=0.05)
+    assert np.array_equal(mask, o["pmask"]) and np.array_equal(pano, o["pano"])

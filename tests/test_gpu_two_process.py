@@ -66,3 +66,12 @@ def test_two_ranks_config3_columns_equal_oracle(gpu_ctx):
                              mask_bits=exchange == "strips"))
         assert res["bands"] == 5 and res["bytes"] > 0
         assert res["ok"], (exchange, res)
+
+
+@pytest.mark.parametrize("blender,strength", [("feather", 4), ("no", 5)])
+def test_three_ranks_feather_and_plain_blender_equal_oracle(gpu_ctx, blender, strength):
+    """The feather and the plain blender (stitching/blender.py:27-36) sharded: 3 ranks x 2 frames of a ring, each rank blends its band
+    (+ the feather halo) from its own columns and the strips it receives, in global feed order; the gathered panorama is the oracle's."""
+    res = launch(3, dict(layout="ring", w=803, h=601, per_rank=2, warper="spherical", blender=blender, strength=strength, span=170.0))
+    assert res["transport"] == "gloo-host" and res["bands"] == 0 and res["messages"] >= 4 and res["bytes"] > 0
+    assert res["ok"], res

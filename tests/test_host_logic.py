@@ -155,3 +155,26 @@ def test_trig_mode_switch_needs_no_gpu():
         assert S.trig_mode() == "glibc-nofma"
     finally:
         S.set_trig_mode(prev)
+
+
+def test_remap_mode_switch_needs_no_gpu():
+    """stx_set_remap_mode / stx_get_remap_mode (include/stitching_amd.h STX_REMAP_*): process-wide, usable without a device; the
+    environment variable only sets the start-up value (checked in a fresh interpreter)."""
+    import os
+    import subprocess
+    import sys
+
+    prev = S.remap_mode()
+    try:
+        assert prev in ("q15", "float", "float-fma")
+        assert S.set_remap_mode("float") == prev and S.remap_mode() == "float"
+        assert S.set_remap_mode("float-fma") == "float" and S.remap_mode() == "float-fma"
+        with pytest.raises(S.StitchingError):
+            S.set_remap_mode("lanczos")
+        assert S.remap_mode() == "float-fma"
+    finally:
+        S.set_remap_mode(prev)
+    code = "import stitching_amd as S; print(S.remap_mode(), S.trig_mode())"
+    env = dict(os.environ, STITCHING_AMD_REMAP="float-fma", STITCHING_AMD_TRIG="glibc")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+    assert out.stdout.split() == ["float-fma", "glibc"]
