@@ -26,6 +26,7 @@ blender prepared for its band (+ halo) and crops the result; everything is fed i
 `RcclTransport` (C ABI -> librccl), `GlooHostTransport` (host-staged, for tests / 1-GPU boxes).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -208,11 +209,13 @@ class ShardPlan:
     the global corner/size lists, identical on every rank."""
 
     def __init__(self, corners, warped_sizes, owners, world, blender_probe, exchange="strips", mask_bits=False, kind="multiband",
-                 halo=0):
+                 halo=0, balance="midway"):
         """mask_bits (strips): the masks are known to hold 0 / 255 only and travel as one bit per pixel
         (STX_STRIP_MASK_BITS: 3.125 instead of 4 bytes per pixel on the links).
         kind: "multiband" (blender_probe: a ShardBlender of the panorama, asked for the strip geometry), or "feather" / "no"
-        (blender_probe unused; halo: feather_halo(sharpness) / 0)."""
+        (blender_probe unused; halo: feather_halo(sharpness) / 0).
+        balance: "midway" (band edges midway between the ranks' images) or "links" (edges moved towards equal widths as far as that
+        lightens the busiest link)."""
         if exchange not in ("strips", "contribs"):
             raise StitchingError(f"unknown exchange form {exchange!r}")
         if kind not in ("multiband", "feather", "no"):
@@ -229,18 +232,47 @@ class ShardPlan:
         self.world = int(world)
         self.roi = Blender.result_roi(self.corners, self.sizes)
         self.num_bands = blender_probe.num_bands() if kind == "multiband" else 0
+        self._probe = blender_probe
+        self.balance = balance
         self.edges = band_edges(self.corners, self.sizes, self.owners, self.world, self.roi, self.num_bands)
-        # messages: (order k, src rank, dst rank, rect, bytes), sorted by (dst, k) so that every
-        # rank posts sends / receives in one global order.  rect: contribs -> (x, y, w, h) relative to the roi;
-        # strips -> (x0, x1, w, h): columns of image k and the strip's size
-        self.messages = []
+        self.messages = self._messages()
+        if balance == "links" and self.world > 2:
+            # Band edges between "midway between the ranks' images" (even pyramid work, but the two end bands of a multi-row panorama
+            # take in the overhang of their wide frames and the end links carry it) and equal widths (the reverse): the mix with the
+            # lightest busiest link.  Config 3: 96.5 MB on the links 1 -> 0 and 6 -> 7 with the midway edges, 77.8 MB a quarter of the
+            # way to equal widths — for 9 % more pyramid samples on the busiest rank.  Pure geometry: every rank
+            # evaluates the same candidates in the same order.
+            align, fw = max(8, 1 << self.num_bands), self.roi[2]
+            midway = list(self.edges)
+            best = (self.busiest_link_bytes(), midway, self.messages)
+            for t in (0.125, 0.25, 0.375, 0.5):
+                cand = [0]
+                for g in range(1, self.world):
+                    e = int((1.0 - t) * midway[g] + t * fw * g / self.world) // align * align
+                    cand.append(min(max(e, cand[-1] + align), fw - align * (self.world - g)))
+                cand.append(fw)
+                self.edges = cand
+                msgs = self._messages()
+                self.messages = msgs
+                load = self.busiest_link_bytes()
+                if load < best[0]:
+                    best = (load, cand, msgs)
+            _, self.edges, self.messages = best
+        elif balance not in ("midway", "links"):
+            raise StitchingError(f"unknown band balance {balance!r}")
+
+    def _messages(self):
+        """(order k, src rank, dst rank, rect, bytes) of every strip under the current edges, sorted by (dst, k) so that every rank posts
+        sends / receives in one global order.  rect: contribs -> (x, y, w, h) relative to the roi; strips -> (x0, x1, w, h): columns
+        of image k and the strip's size"""
+        out = []
         for k, (c, s) in enumerate(zip(self.corners, self.sizes)):
             for g in range(self.world):
                 if g == self.owners[k]:
                     continue
-                if exchange == "strips":
-                    if kind == "multiband":
-                        (x0, x1), nbytes = blender_probe.strip_rect(s, c, self.band(g))
+                if self.exchange == "strips":
+                    if self.kind == "multiband":
+                        (x0, x1), nbytes = self._probe.strip_rect(s, c, self.band(g))
                     else:
                         (x0, x1), nbytes = flat_strip_columns(c, s, self.roi, self.band(g), self.halo), None
                     if x1 > x0:
@@ -248,12 +280,23 @@ class ShardPlan:
                             nb = C.c_size_t()
                             _lib.check(_lib.lib().stx_strip_bytes(x1 - x0, int(s[1]), self.strip_flags, C.byref(nb)))
                             nbytes = int(nb.value)
-                        self.messages.append((k, self.owners[k], g, (x0, x1, x1 - x0, s[1]), nbytes))
+                        out.append((k, self.owners[k], g, (x0, x1, x1 - x0, s[1]), nbytes))
                     continue
-                rect, nbytes = blender_probe.contrib_rect(s, c, self.band(g))
+                rect, nbytes = self._probe.contrib_rect(s, c, self.band(g))
                 if rect[2] > 0:
-                    self.messages.append((k, self.owners[k], g, rect, nbytes))
-        self.messages.sort(key=lambda m: (m[2], m[0]))
+                    out.append((k, self.owners[k], g, rect, nbytes))
+        out.sort(key=lambda m: (m[2], m[0]))
+        return out
+
+    def link_bytes(self):
+        """{(src, dst): bytes per panorama}: xGMI is point to point, so these are per-link loads"""
+        links = {}
+        for (_k, src, dst, _rect, nbytes) in self.messages:
+            links[(src, dst)] = links.get((src, dst), 0) + nbytes
+        return links
+
+    def busiest_link_bytes(self):
+        return max(self.link_bytes().values(), default=0)
 
     def band(self, g):
         return (self.edges[g], self.edges[g + 1])
@@ -432,7 +475,7 @@ class ShardedStitchJob:
 
     def __init__(self, frames, cameras, all_cameras, rank, world, all_sizes=None, warper_type="spherical",
                  blender_type="multiband", num_bands=5, blend_strength=None, ctx=None, dist=None, transport=None,
-                 split_boundary=True, exchange="strips", mask_bits=True):
+                 split_boundary=True, exchange="strips", mask_bits=True, balance=None):
         """split_boundary: warp / feed the images that owe strips to other ranks first and the rest while the strips
         travel (lowest latency of ONE panorama).  A caller that keeps several panoramas in flight on several contexts
         passes False: all local images go through one warp launch and one pyramid build, and the other panorama's
@@ -462,6 +505,10 @@ class ShardedStitchJob:
         self.split_boundary = bool(split_boundary)
         self.exchange = exchange
         self.mask_bits = bool(mask_bits)  # every mask of this job is a warped mask (0 / 255): they may travel as bits
+        # ShardPlan(balance=...): where the band edges go; None -> STITCHING_AMD_BALANCE, else "links".  Measured on one MI355X playing
+        # single ranks of the 8-rank config-3 job (tools/sim_rank.py, gpurun r3o): rank 3 0.834 -> 0.874 ms per step, rank 0 0.776 ->
+        # 0.680, rank 1 0.723 -> 0.730, while the job's busiest link goes from 96.5 to 77.8 MB per panorama
+        self.balance = balance or os.environ.get("STITCHING_AMD_BALANCE") or "links"
         self.plan_ = None
 
     @property
@@ -483,7 +530,7 @@ class ShardedStitchJob:
                 self.flat_kind, self.sharpness = "feather", 1.0 / blend_width
             self.req_bands = 0
             self.plan_ = ShardPlan(corners, wsizes, self.owners, self.world, None, "strips", self.mask_bits, kind=self.flat_kind,
-                                   halo=feather_halo(self.sharpness))
+                                   halo=feather_halo(self.sharpness), balance=self.balance)
             self.last_num_bands = 0
             if self.transport is None:
                 self.transport = default_transport(self.ctx, self.rank, self.world, self.dist)
@@ -494,7 +541,7 @@ class ShardedStitchJob:
         self.req_bands = int((np.log(blend_width) / np.log(2.0) - 1.0))
         self.roi = roi
         probe = make_shard_blender(self.ctx, roi, self.req_bands)
-        self.plan_ = ShardPlan(corners, wsizes, self.owners, self.world, probe, self.exchange, self.mask_bits)
+        self.plan_ = ShardPlan(corners, wsizes, self.owners, self.world, probe, self.exchange, self.mask_bits, balance=self.balance)
         self.last_num_bands = self.plan_.num_bands
         if self.transport is None:
             self.transport = default_transport(self.ctx, self.rank, self.world, self.dist)
@@ -759,7 +806,7 @@ def virtual_sharded_flat_blend(ctx, warped, masks, corners, sizes, world, kind, 
     return np.concatenate([p for p, _ in bands], axis=1), np.concatenate([m for _, m in bands], axis=1), plan
 
 
-def virtual_sharded_blend(ctx, warped, masks, corners, sizes, world, num_bands, exchange="strips", mask_bits=False):
+def virtual_sharded_blend(ctx, warped, masks, corners, sizes, world, num_bands, exchange="strips", mask_bits=False, balance="midway"):
     """All `world` ranks simulated in ONE process on one GPU: same kernels, same geometry, the
     exchange is a pointer hand-over.  Returns (panorama, mask, plan) as numpy arrays."""
     n = len(warped)
@@ -769,7 +816,7 @@ def virtual_sharded_blend(ctx, warped, masks, corners, sizes, world, num_bands, 
     d_imgs = [as_device(w, ctx) for w in warped]
     d_masks = [as_device(m, ctx) for m in masks]
     binary = [_mask_is_binary(ctx, m) for m in d_masks]
-    plan = ShardPlan(corners, sizes, owners, world, probe, exchange, mask_bits and all(binary))  # bits need 0 / 255 masks
+    plan = ShardPlan(corners, sizes, owners, world, probe, exchange, mask_bits and all(binary), balance=balance)  # bits need 0 / 255 masks
     blenders = []
     for g in range(world):
         b = make_shard_blender(ctx, roi, num_bands)

@@ -81,3 +81,36 @@ def test_owners_are_contiguous_runs():
     assert owners_contiguous(8, 2) == [0] * 4 + [1] * 4
     assert owners_contiguous(7, 3) == [0, 0, 0, 1, 1, 2, 2]
     assert owners_contiguous(2, 2) == [0, 1]
+
+
+def test_band_balance_for_the_links(oracle):
+    """ShardPlan(balance="links") on BASELINE config 3's layout in quarter size: band edges moved from "midway between the ranks'
+    images" towards equal widths while that lightens the busiest link.  Pure geometry (no GPU): same strips rule, fewer bytes on
+    the end links, edges still on the 2^bands grid, every rank a band."""
+    from stitching_amd.distributed import ShardPlan, make_shard_blender, owners_contiguous
+
+    W, H, world = 1000, 750, 8
+    cams = synthetic.grid_cameras(world, 4, W, H)
+    ow = oracle.Warper("spherical")
+    ow.set_scale(cams)
+    corners, wsizes = ow.warp_rois([(W, H)] * len(cams), cams)
+    roi = oracle.result_roi(corners, wsizes)
+    probe = make_shard_blender(None, roi, 3)
+    owners = owners_contiguous(len(cams), world)
+    mid = ShardPlan(corners, wsizes, owners, world, probe, "strips", True)
+    bal = ShardPlan(corners, wsizes, owners, world, probe, "strips", True, balance="links")
+    assert mid.balance == "midway" and bal.balance == "links"
+    align = 1 << bal.num_bands
+    assert bal.edges[0] == 0 and bal.edges[-1] == roi[2] and all(b > a and a % align == 0 for a, b in zip(bal.edges, bal.edges[1:]))
+    assert bal.busiest_link_bytes() < 0.9 * mid.busiest_link_bytes()
+    # the end bands gave columns away
+    assert bal.edges[1] < mid.edges[1] and bal.edges[-2] > mid.edges[-2]
+    # a plan is its edges: rebuilding the messages under the chosen edges gives the chosen messages
+    assert bal._messages() == bal.messages and sum(bal.link_bytes().values()) == bal.exchanged_bytes()
+    # a two-rank job has one link each way and nothing to balance
+    two = ShardPlan(corners[:8], wsizes[:8], owners_contiguous(8, 2), 2, make_shard_blender(None, oracle.result_roi(corners[:8], wsizes[:8]), 3),
+                    "strips", True, balance="links")
+    assert two.edges == ShardPlan(corners[:8], wsizes[:8], owners_contiguous(8, 2), 2,
+                                  make_shard_blender(None, oracle.result_roi(corners[:8], wsizes[:8]), 3), "strips", True).edges
+    with pytest.raises(Exception):
+        ShardPlan(corners, wsizes, owners, world, probe, "strips", True, balance="compute")

@@ -126,8 +126,10 @@ def test_random_sharded_blend_bit_exact(oracle, gpu_ctx, seed):
     if req < 0:
         pytest.skip("blend width below one band")
     pano, mask, plan = virtual_sharded_blend(gpu_ctx, o["w_imgs"], feed_masks, o["corners"], o["sizes"], world, req, exchange,
-                                             mask_bits=seed % 2 == 0)  # (bits only where every mask is 0 / 255)
-    tag = dict(world=world, n=n, w=w, h=h, strength=strength, wtype=wtype, bands=plan.num_bands, edges=plan.edges, exchange=exchange)
+                                             mask_bits=seed % 2 == 0,  # (bits only where every mask is 0 / 255)
+                                             balance="links" if seed % 3 == 0 else "midway")  # band edges placed for the links
+    tag = dict(world=world, n=n, w=w, h=h, strength=strength, wtype=wtype, bands=plan.num_bands, edges=plan.edges, exchange=exchange,
+               balance=plan.balance)
     assert pano.shape == o["pano"].shape, tag
     assert np.array_equal(mask, o["pmask"]), tag
     assert np.array_equal(pano, o["pano"]), (tag, int(np.count_nonzero(pano != o["pano"])))

@@ -80,3 +80,28 @@ def test_feather_narrower_than_a_pixel_is_the_plain_blender(oracle, gpu_ctx):
     assert jobs[0].plan_.kind == "no"
     o = helpers.run_pipeline(oracle.Warper, oracle.Blender, frames, cams, blender_type="feather", blend_strength=0.05)
     assert np.array_equal(mask, o["pmask"]) and np.array_equal(pano, o["pano"])
+
+
+def test_bands_balanced_for_the_links_equal_oracle(oracle, gpu_ctx):
+    """ShardPlan(balance="links") — band edges moved towards equal widths to lighten the busiest link — on BASELINE config 3's layout
+    at an eighth of its size (8 yaw columns x 4 pitch rows, 8 ranks): other edges, other strips, the same panorama (multi-band through
+    virtual shards and ShardedStitchJob ranks, feather through ShardedStitchJob ranks)."""
+    from stitching_amd.distributed import virtual_sharded_blend
+
+    w, h, world = 500, 375, 8
+    cams = synthetic.grid_cameras(world, 4, w, h)
+    frames = [synthetic.make_frame(900 + i, w, h) for i in range(len(cams))]
+    o = helpers.run_pipeline(oracle.Warper, oracle.Blender, frames, cams, blend_strength=1.0)
+    req = o["blender"].blender.num_bands()
+    pano, mask, plan = virtual_sharded_blend(gpu_ctx, o["w_imgs"], o["w_masks"], o["corners"], o["sizes"], world, req, "strips", True, balance="links")
+    _, _, mid = virtual_sharded_blend(gpu_ctx, o["w_imgs"], o["w_masks"], o["corners"], o["sizes"], world, req, "strips", True)
+    assert req == 2 and plan.balance == "links" and plan.edges != mid.edges and plan.busiest_link_bytes() < 0.9 * mid.busiest_link_bytes()
+    assert np.array_equal(mask, o["pmask"]) and np.array_equal(pano, o["pano"])
+    pano, mask, jobs = helpers.run_sharded_job_in_one_process(gpu_ctx, frames, cams, world, 4, blend_strength=1.0, balance="links")
+    assert jobs[0].plan_.edges == plan.edges
+    assert np.array_equal(mask, o["pmask"]) and np.array_equal(pano, o["pano"])
+    of = helpers.run_pipeline(oracle.Warper, oracle.Blender, frames, cams, blender_type="feather", blend_strength=2)
+    pano, mask, jobs = helpers.run_sharded_job_in_one_process(gpu_ctx, frames, cams, world, 4, blender_type="feather", blend_strength=2,
+                                                              balance="links")
+    assert jobs[0].plan_.balance == "links"
+    assert np.array_equal(mask, of["pmask"]) and np.array_equal(pano, of["pano"])

@@ -119,7 +119,10 @@ def main():
         p = js[0].plan_
         res["split" if split else "nosplit"] = {"ms_per_step": round(ms, 4), "mpix_per_s": round(fpg * w * h / ms / 1e3, 1),
                                                 "sends": len(p.sends(rank)), "recvs": len(p.recvs(rank)),
-                                                "sent_MB": round(sum(m[4] for m in p.sends(rank)) / 1e6, 1)}
+                                                "sent_MB": round(sum(m[4] for m in p.sends(rank)) / 1e6, 1),
+                                                "busiest_link_of_rank_MB": round(max([v for (s_, _d), v in p.link_bytes().items() if s_ == rank], default=0) / 1e6, 1),
+                                                "busiest_link_of_job_MB": round(p.busiest_link_bytes() / 1e6, 1),
+                                                "balance": p.balance, "band_edges": p.edges}
     # kernel breakdown of one no-split step on one context
     c = ctxs[0]
     c.prof_enable(True)
