@@ -25,6 +25,15 @@ namespace {
 
 constexpr int WARP_TW = 256;  // tile width  (64 lanes x 4 px)
 constexpr int WARP_TH = 4;    // tile height (4 waves x 1 row)
+// fast kernel: a wavefront takes WARP_IT blocks of WARP_TH rows of its 64 columns one after the other (tile 256 x WARP_IT * WARP_TH): the
+// per-image scalars, the tile index and the column table entry are then fetched once for all of them.  Measured (round 3, A/B on one
+// box): 2 blocks per wavefront 212 us against 180 us with 1 — half as many wavefronts, each twice as long, hide the sampling loads
+// worse than the saved prologues are worth.  1 it stays; the loop is kept for the experiment (-DSTX_WARP_IT=2).
+#ifndef STX_WARP_IT
+#define STX_WARP_IT 1
+#endif
+constexpr int WARP_IT = STX_WARP_IT;
+constexpr int WARP_FTH = WARP_TH * WARP_IT;  // tile height of the fast kernel
 constexpr int WARP_BAND = 4;  // tile rows per XCD band (fast kernel); measured 1: 548, 2: 424, 4: 360, 8: 327, 16: 311 MB fetched
 constexpr float PI_F = 3.14159274101257324f;  // static_cast<float>(CV_PI)
 
@@ -424,7 +433,7 @@ STX_DEV int periodic_axis(int s, int n, int period, float inv_period, int bias)
 }
 
 template <int TYPE, bool IMG, bool MASK>
-__global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void warp_fast_kernel(WarpBatchK B)
 {
     const WarpK& P = B.k[blockIdx.z];
     // the two table pointers ride in the same batch of scalar loads as the per-image scalars below (left to the compiler they are
@@ -473,13 +482,27 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
     __shared__ uint32_t s_mk[4][WARP_TH][16];  // [wavefront][row][dword]: 64 px x 1 B
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and known to be
     const int xw = tile_x * WARP_TW + wv * 64;  // first column of this wavefront
-    const int y0 = tile_y * WARP_TH;
     // columns beyond the image are computed on the clamped table entry, rows beyond it on the repeated last row
     // (harmless) and never stored
     const v2f ct = *(const STX_GAS v2f*)((const STX_GAS char*)colT + ((uint32_t)min(xw + lane, dw - 1) << 3));  // dw < 2^29
+    // column-only products (cylinder, plane), once per lane
+    float q0 = 0.f, q3 = 0.f, q6 = 0.f, r2 = 0.f, r5 = 0.f, r8 = 0.f;
+    if (TYPE != STX_WARP_SPHERICAL) {
+        q0 = fmul(P.kr[0], ct.x); q3 = fmul(P.kr[3], ct.x); q6 = fmul(P.kr[6], ct.x);
+        if (TYPE == STX_WARP_CYLINDRICAL) { r2 = fmul(P.kr[2], ct.y); r5 = fmul(P.kr[5], ct.y); r8 = fmul(P.kr[8], ct.y); }
+        else { r2 = P.c2; r5 = P.c5; r8 = P.c8; }
+    }
+    const STX_GAS uint8_t* src = (const STX_GAS uint8_t*)src_a;
+    uint8_t* const lpx = reinterpret_cast<uint8_t*>(&s_px[wv][0][0]) + lane * 3;  // + 192 per row, + channel
+    uint8_t* const lmk = reinterpret_cast<uint8_t*>(&s_mk[wv][0][0]) + lane;      // + 64 per row
+#pragma unroll 1
+  for (int it = 0; it < WARP_IT; it++) {
+    const int row_blk = tile_y * WARP_IT + it;  // block of WARP_TH rows
+    const int y0 = row_blk * WARP_TH;
+    if (it > 0 && y0 >= dh) break;
     // The wavefront's 4 rows as two row pairs: every step below is a packed fp32 operation on (row 2h, row 2h + 1).
-    // Row constants: one 64-byte block {ra x4}, {p1 x4}, {p4 x4}, {p7 x4} per tile row, a single scalar load.
-    const v4f RA = rowT[4 * tile_y], P1 = rowT[4 * tile_y + 1], P4 = rowT[4 * tile_y + 2], P7 = rowT[4 * tile_y + 3];
+    // Row constants: one 64-byte block {ra x4}, {p1 x4}, {p4 x4}, {p7 x4} per block of rows, a single scalar load.
+    const v4f RA = rowT[4 * row_blk], P1 = rowT[4 * row_blk + 1], P4 = rowT[4 * row_blk + 2], P7 = rowT[4 * row_blk + 3];
     v2f X[2], Y[2], Z[2];
     {
         const v2f ra[2] = {{RA.x, RA.y}, {RA.z, RA.w}}, p1[2] = {{P1.x, P1.y}, {P1.z, P1.w}};
@@ -493,11 +516,6 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
                 Z[h] = (x_ * P.kr[6] + p7[h]) + z_ * P.kr[8];
             }
         } else {
-            // column-only products, once per lane
-            const float q0 = fmul(P.kr[0], ct.x), q3 = fmul(P.kr[3], ct.x), q6 = fmul(P.kr[6], ct.x);
-            float r2, r5, r8;
-            if (TYPE == STX_WARP_CYLINDRICAL) { r2 = fmul(P.kr[2], ct.y); r5 = fmul(P.kr[5], ct.y); r8 = fmul(P.kr[8], ct.y); }
-            else { r2 = P.c2; r5 = P.c5; r8 = P.c8; }
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 X[h] = (p1[h] + q0) + r2;
@@ -578,9 +596,6 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
     }
     const uint32_t uxmn = min(min(ux[0], ux[1]), min(ux[2], ux[3])), uxmx = max(max(ux[0], ux[1]), max(ux[2], ux[3]));
     const uint32_t uymn = min(min(uy[0], uy[1]), min(uy[2], uy[3])), uymx = max(max(uy[0], uy[1]), max(uy[2], uy[3]));
-    const STX_GAS uint8_t* src = (const STX_GAS uint8_t*)src_a;
-    uint8_t* const lpx = reinterpret_cast<uint8_t*>(&s_px[wv][0][0]) + lane * 3;  // + 192 per row, + channel
-    uint8_t* const lmk = reinterpret_cast<uint8_t*>(&s_mk[wv][0][0]) + lane;      // + 64 per row
     // interior: valid for the image samples; the nearest-neighbour mask sample of an interior position is inside too
     const bool lane_int = uxmn >= RND_U0 && uxmx <= ux_int && uymn >= RND_U0 && uymx <= uy_int;
     const bool wave_int = __builtin_amdgcn_ballot_w64(!lane_int) == 0;
@@ -671,6 +686,12 @@ __global__ __launch_bounds__(256) void warp_fast_kernel(WarpBatchK B)
                     wave_int ? 0xffffffffu : s_mk[wv][r][c];
         }
     }
+    // the next block of rows overwrites the staging rows: this wavefront's reads above come first (LDS operations of one wavefront
+    // execute in order; the compiler is told)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -989,7 +1010,7 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
             B.k[i] = K;
             B.k[i].band_rows = WARP_BAND;
             B.k[i].tiles_x = (K.dw + WARP_TW - 1) / WARP_TW;
-            B.k[i].tiles_y = (K.dh + WARP_TH - 1) / WARP_TH;
+            B.k[i].tiles_y = (K.dh + WARP_FTH - 1) / WARP_FTH;
             B.k[i].band_tiles = B.k[i].band_rows * B.k[i].tiles_x;
             B.k[i].magic_tx = (uint32_t)((1ull << 32) / (uint32_t)B.k[i].tiles_x) + 1u;
             B.k[i].magic_band = (uint32_t)((1ull << 32) / (uint32_t)B.k[i].band_tiles) + 1u;
@@ -1013,7 +1034,7 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
             StxProfScope prof(ctx, prof_name, bytes);
             int per_xcd = 0;  // workgroups each XCD needs: its share of the bands, whole bands only
             for (int i = 0; i < m; i++) {
-                const int tx = (B.k[i].dw + WARP_TW - 1) / WARP_TW, ty = (B.k[i].dh + WARP_TH - 1) / WARP_TH;
+                const int tx = (B.k[i].dw + WARP_TW - 1) / WARP_TW, ty = (B.k[i].dh + WARP_FTH - 1) / WARP_FTH;
                 const int wb = B.k[i].band_rows, bands = (ty + wb - 1) / wb;
                 per_xcd = std::max(per_xcd, ((bands + 7) / 8) * wb * tx);
             }
