@@ -490,7 +490,9 @@ def main():
     if world > 1:
         p = job.plan_
         result["config"]["exchange"] = {"messages": len(p.messages), "bytes_per_step": p.exchanged_bytes(),
-                                        "rank0_sends_MB": round(sum(m[4] for m in p.sends(0)) / 1e6, 1)}
+                                        "rank0_sends_MB": round(sum(m[4] for m in p.sends(0)) / 1e6, 1),
+                                        "busiest_link_MB": round(p.busiest_link_bytes() / 1e6, 1),  # xGMI is point to point
+                                        "band_balance": p.balance, "band_edges": p.edges}
         result["same_family_single_gpu"] = {
             "value_per_gpu": round(share, 1), "unit": "Mpix/s",
             "efficiency_vs_it": round(value / world / share, 4),
