@@ -27,8 +27,9 @@ constexpr int WARP_TW = 256;  // tile width  (64 lanes x 4 px)
 constexpr int WARP_TH = 4;    // tile height (4 waves x 1 row)
 // fast kernel: a wavefront takes WARP_IT blocks of WARP_TH rows of its 64 columns one after the other (tile 256 x WARP_IT * WARP_TH): the
 // per-image scalars, the tile index and the column table entry are then fetched once for all of them.  Measured (round 3, A/B on one
-// box): 2 blocks per wavefront 212 us against 180 us with 1 — half as many wavefronts, each twice as long, hide the sampling loads
-// worse than the saved prologues are worth.  1 it stays; the loop is kept for the experiment (-DSTX_WARP_IT=2).
+// box): 2 blocks per wavefront 212 us against 180 us with 1 — gfx9 has one vmcnt for loads and stores, so the second block's sample
+// loads cannot be waited for without also waiting for the first block's stores; a one-block wavefront just ends behind its stores.
+// 1 it stays; the loop is kept for the experiment (-DSTX_WARP_IT=2).
 #ifndef STX_WARP_IT
 #define STX_WARP_IT 1
 #endif
