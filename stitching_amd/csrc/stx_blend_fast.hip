@@ -814,6 +814,9 @@ STX_DEV bool occ_hit(const StxMbImage& im, int lv, int tile_x, int Y0)
     return ((w0 & m0) | (w1 & m1) | (n > 8 ? w2 & 0xffu : 0u)) != 0u;
 }
 
+template <bool WF>
+STX_DEV void level0_epilogue_pk(const MbLevelK& P, int X0, int Y0, uint32_t (&acc)[2][3][4], uint32_t (&cnt)[2][4], const float (*ws)[8]);
+
 // CONTRIB: the image table may hold received contribution strips (kind 1); EMIT: write un-normalised sums.
 // Both are compile-time so that the common single-GPU instantiation carries neither path.
 // U8SRC (levels >= 1): every image was fed as u8, so G_i is 0..255 and pyrUp / the Laplacian run in packed 16-bit lanes
@@ -839,6 +842,22 @@ STX_DEV void mb_level_fast_body(const MbLevelK& P)
             acc[r][j][0] = acc[r][j][1] = acc[r][j][2] = 0;
             ws[r][j] = 0.f;
         }
+    // Level 0 of u8 images with fp32 weights, single blender (no strips of products, no export): the sums live as int16 PAIRS
+    // (order (0,2)(4,6)(1,3)(5,7) of the packed pyrUp), 24 registers instead of 48.  OpenCV's accumulator is a short that wraps
+    // (dst += (short)(L * w)); a wrapping 16-bit add is that very operation, and the epilogue's (short) cast of the int sums of
+    // the other instantiations gives the same residue.
+    // The weight sums are COUNTS (16-bit pairs) until the first image with a grey mask byte under this wavefront arrives; then they
+    // become the fp32 sums `ws` (a count converts exactly) and stay so.  A wavefront that never meets a grey byte — most of them: a
+    // resized seam mask is grey only along the seam — runs the arithmetic of mb_level0_pk_kernel, epilogue included.
+    constexpr bool PKACC = L0 && U8SRC && !CONTRIB && !EMIT;
+    uint32_t accp[2][3][4], cntp[2][4];
+    bool ws_live = false;  // wave-uniform
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) accp[r][c][0] = accp[r][c][1] = accp[r][c][2] = accp[r][c][3] = 0u;
+        cntp[r][0] = cntp[r][1] = cntp[r][2] = cntp[r][3] = 0u;
+    }
 
     // every wavefront finds the images under ITS two rows of the tile with one ballot (no LDS list, no barrier:
     // the other three wavefronts of the block no longer wait for the first one's descriptor loads)
@@ -958,10 +977,56 @@ STX_DEV void mb_level_fast_body(const MbLevelK& P)
                     load_px8_u8(im, lx0, ly, vm0, vm1, pw_[r], mw[r]);
                 }
                 float w[2][8];
+                if (!PKACC) {
 #pragma unroll
-                for (int r = 0; r < 2; r++)
+                    for (int r = 0; r < 2; r++)
 #pragma unroll
-                    for (int j = 0; j < 8; j++) w[r][j] = fmul((float)byte_of(mw[r], j), INV255);
+                        for (int j = 0; j < 8; j++) w[r][j] = fmul((float)byte_of(mw[r], j), INV255);
+                }
+                // Resized seam masks are grey only along the seams: where every mask byte under this wavefront is 0 or 255 the product
+                // (short)(L * w) is L or 0 — a mask AND on the packed Laplacian pairs instead of convert / multiply / convert per
+                // pixel and channel (a byte is 0 / 255 iff it equals its sign bit replicated: t = the sign bits, (t << 8) - t = 255 t)
+                bool img_binary = false;
+                uint32_t mk[2][4];
+                if (PKACC) {
+                    uint32_t grey = 0u;
+#pragma unroll
+                    for (int r = 0; r < 2; r++)
+#pragma unroll
+                        for (int hlf = 0; hlf < 2; hlf++) {
+                            const uint32_t t = (mw[r][hlf] >> 7) & 0x01010101u;
+                            grey |= mw[r][hlf] ^ ((t << 8) - t);
+                        }
+                    img_binary = __ballot(grey != 0u) == 0ull;
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {  // 0xffff / 0 per pixel in the pair order (0,2)(4,6)(1,3)(5,7)
+                        mk[r][0] = __builtin_amdgcn_perm(0u, mw[r][0], 0x02020000u);
+                        mk[r][1] = __builtin_amdgcn_perm(0u, mw[r][1], 0x02020000u);
+                        mk[r][2] = __builtin_amdgcn_perm(0u, mw[r][0], 0x03030101u);
+                        mk[r][3] = __builtin_amdgcn_perm(0u, mw[r][1], 0x03030101u);
+                    }
+                    if (!img_binary && !ws_live) {  // the first grey image of this wavefront: counts -> fp32 sums
+                        ws_live = true;
+#pragma unroll
+                        for (int r = 0; r < 2; r++)
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                ws[r][(q & 1) * 4 + (q >> 1)] = (float)(cntp[r][q] & 0xffffu);
+                                ws[r][(q & 1) * 4 + (q >> 1) + 2] = (float)(cntp[r][q] >> 16);
+                            }
+                    }
+                    if (ws_live) {
+#pragma unroll
+                        for (int r = 0; r < 2; r++)
+#pragma unroll
+                            for (int j = 0; j < 8; j++) w[r][j] = fmul((float)byte_of(mw[r], j), INV255);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 2; r++)
+#pragma unroll
+                            for (int q = 0; q < 4; q++) cntp[r][q] = unpk(pk(cntp[r][q]) + pk(mk[r][q] & 0x00010001u));
+                    }
+                }
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     pk16 upk[2][4];
@@ -983,18 +1048,36 @@ STX_DEV void mb_level_fast_body(const MbLevelK& P)
                         uint32_t Lq[4];
 #pragma unroll
                         for (int q = 0; q < 4; q++) Lq[q] = unpk(pk(px[q]) - upk[r][q]);  // in [-255, 255]
+                        if (PKACC) {
+                            if (img_binary) {
 #pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            const int q = (j & 1) ? 2 + (j >> 2) : (j >> 2);
-                            const int L = ((j >> 1) & 1) ? s16hi(Lq[q]) : s16lo(Lq[q]);
-                            acc[r][j][c] += trunc_small(fmul((float)L, w[r][j]));
+                                for (int q = 0; q < 4; q++) accp[r][c][q] = unpk(pk(accp[r][c][q]) + pk(Lq[q] & mk[r][q]));
+                            } else {
+#pragma unroll
+                                for (int q = 0; q < 4; q++) {
+                                    // pair q = pixels (j0, j0 + 2): j0 = 0, 4, 1, 5
+                                    const int j0 = (q & 1) * 4 + (q >> 1);
+                                    const int lo = trunc_small(fmul((float)s16lo(Lq[q]), w[r][j0]));
+                                    const int hi = trunc_small(fmul((float)s16hi(Lq[q]), w[r][j0 + 2]));
+                                    accp[r][c][q] = unpk(pk(accp[r][c][q]) + pk(pack16(lo, hi)));
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; j++) {
+                                const int q = (j & 1) ? 2 + (j >> 2) : (j >> 2);
+                                const int L = ((j >> 1) & 1) ? s16hi(Lq[q]) : s16lo(Lq[q]);
+                                acc[r][j][c] += trunc_small(fmul((float)L, w[r][j]));
+                            }
                         }
                     }
                 }
+                if (!PKACC || ws_live) {
 #pragma unroll
-                for (int r = 0; r < 2; r++)
+                    for (int r = 0; r < 2; r++)
 #pragma unroll
-                    for (int j = 0; j < 8; j++) ws[r][j] = fadd(ws[r][j], w[r][j]);
+                        for (int j = 0; j < 8; j++) ws[r][j] = fadd(ws[r][j], w[r][j]);
+                }
             } else {
                 const int lx0 = X0 - im.ix, ly0 = Y0 - im.iy;
                 if (lx0 + 8 <= 0 || lx0 >= im.iw || ly0 + 2 <= 0 || ly0 >= im.ih) continue;
@@ -1053,6 +1136,20 @@ STX_DEV void mb_level_fast_body(const MbLevelK& P)
         return;
     }
 
+    if (PKACC) {
+        if (!ws_live) {
+            level0_epilogue_pk<false>(P, X0, Y0, accp, cntp, nullptr);
+        } else {
+            // compare(dst_band_weights_0, WEIGHT_EPS, CMP_GT) as 1 / 0 per pixel
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    cntp[r][q] = (ws[r][(q & 1) * 4 + (q >> 1)] > WEIGHT_EPS ? 1u : 0u) | (ws[r][(q & 1) * 4 + (q >> 1) + 2] > WEIGHT_EPS ? 0x10000u : 0u);
+            level0_epilogue_pk<true>(P, X0, Y0, accp, cntp, ws);
+        }
+        return;
+    }
     level_epilogue<L0>(P, X0, Y0, acc, ws);
 }
 
@@ -1061,6 +1158,7 @@ __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
 {
     mb_level_fast_body<L0, CONTRIB, EMIT, U8SRC>(P);
 }
+
 
 // Strip export for sharded blending: ONE launch for all (strip, level) pairs that take the same instantiation; blockIdx.z
 // picks the argument block from a device array, blocks beyond a member's own tile grid leave at once.
@@ -1140,7 +1238,10 @@ STX_DEV uint32_t bgr_dword(const uint32_t (&U)[3][4])
     return lo | hi;
 }
 
-STX_DEV void level0_epilogue_pk(const MbLevelK& P, int X0, int Y0, uint32_t (&acc)[2][3][4], uint32_t (&cnt)[2][4])
+// WF: the weight sums are fp32 values `ws` (grey masks somewhere under the wavefront): every pixel takes the division, and `cnt` holds
+// 1 / 0 per pixel for "weight sum > WEIGHT_EPS" (only the final mask and the zeroing look at it)
+template <bool WF>
+STX_DEV void level0_epilogue_pk(const MbLevelK& P, int X0, int Y0, uint32_t (&acc)[2][3][4], uint32_t (&cnt)[2][4], const float (*ws)[8])
 {
     // The constants (1, 1) and (-1, -1) as values the compiler cannot see through: against literal constants LLVM rewrites
     // min(max(a, -1), 1) and min(count, 1) into per-half compares and selects — 8 and 5 VALU per register instead of 3 and 2
@@ -1150,7 +1251,7 @@ STX_DEV void level0_epilogue_pk(const MbLevelK& P, int X0, int Y0, uint32_t (&ac
     // ---- normalizeUsingWeightMap
     uint32_t v[2][3][4];
     const uint32_t anyc = (cnt[0][0] | cnt[0][1] | cnt[0][2] | cnt[0][3]) | (cnt[1][0] | cnt[1][1] | cnt[1][2] | cnt[1][3]);
-    if ((anyc & 0xfffefffeu) == 0u) {
+    if (!WF && (anyc & 0xfffefffeu) == 0u) {
 #pragma unroll
         for (int r = 0; r < 2; r++)
 #pragma unroll
@@ -1168,7 +1269,9 @@ STX_DEV void level0_epilogue_pk(const MbLevelK& P, int X0, int Y0, uint32_t (&ac
                 int o[2][3];
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++) {
-                    const float den = fadd((float)(hf ? (cnt[r][q] >> 16) : (cnt[r][q] & 0xffffu)), WEIGHT_EPS);
+                    // pair q = pixels (j0, j0 + 2), j0 = 0, 4, 1, 5
+                    const float den = WF ? fadd(ws[r][(q & 1) * 4 + (q >> 1) + 2 * hf], WEIGHT_EPS)
+                                         : fadd((float)(hf ? (cnt[r][q] >> 16) : (cnt[r][q] & 0xffffu)), WEIGHT_EPS);
                     float q0, q1, q2;
                     div3_shared(den, (float)(hf ? s16hi(acc[r][0][q]) : s16lo(acc[r][0][q])),
                                 (float)(hf ? s16hi(acc[r][1][q]) : s16lo(acc[r][1][q])),
@@ -1382,7 +1485,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVE
         cnt[r][2] = pair_u8<1, 3>(cntb[r]);
         cnt[r][3] = pair_u8<5, 7>(cntb[r]);
     }
-    level0_epilogue_pk(P, X0, Y0, acc, cnt);
+    level0_epilogue_pk<false>(P, X0, Y0, acc, cnt, nullptr);
 }
 
 
@@ -1675,6 +1778,7 @@ bool stx_fast_mb_level(stx_ctx* ctx, const MbLevelK& K)
         else hipLaunchKernelGGL((mb_level_fast_kernel<false, true, false, false>), grid, dim3(256), 0, st, KT);
     } else {
         static const bool no_pk_levels = getenv("STITCHING_AMD_NO_PK_LEVELS") != nullptr;  // diagnostic: A/B against mb_level_fast_kernel
+        // (4 waves per SIMD at 121 registers; forced to 5 it spills 19 of them: 309 against 203 us on the resized-seam-mask leg)
         if (K.level == 0 && K.all_u8 && K.num_bands > 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, false, true>), grid, dim3(256), 0, st, KT);
         else if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, false, false>), grid, dim3(256), 0, st, KT);
         else if (K.all_u8 && K.level < K.num_bands && !no_pk_levels) hipLaunchKernelGGL(mb_level_pk_kernel, grid, dim3(256), 0, st, KT);
