@@ -476,10 +476,14 @@ class ShardedStitchJob:
     def __init__(self, frames, cameras, all_cameras, rank, world, all_sizes=None, warper_type="spherical",
                  blender_type="multiband", num_bands=5, blend_strength=None, ctx=None, dist=None, transport=None,
                  split_boundary=True, exchange="strips", mask_bits=True, balance=None):
-        """split_boundary: warp / feed the images that owe strips to other ranks first and the rest while the strips
+        """blender_type / blend_strength: as stitching.blender.Blender (stitching/blender.py:5-38); for "multiband" `num_bands` sets the
+        band count when blend_strength is None (the benchmark's way of naming a configuration).
+        split_boundary (multiband): warp / feed the images that owe strips to other ranks first and the rest while the strips
         travel (lowest latency of ONE panorama).  A caller that keeps several panoramas in flight on several contexts
         passes False: all local images go through one warp launch and one pyramid build, and the other panorama's
-        kernels fill the time of the exchange."""
+        kernels fill the time of the exchange.
+        exchange: "strips" (warped-image columns) or, multiband only, "contribs" (round 1's per-level products).
+        balance: ShardPlan's band-edge rule, "links" (default) or "midway"."""
         if blender_type not in Blender.BLENDER_CHOICES:
             raise StitchingError(f"unknown blender type {blender_type!r}")
         if blender_type != "multiband" and exchange != "strips":
