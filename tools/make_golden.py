@@ -60,6 +60,13 @@ CASES = {
     "mercator_mb": dict(n=3, w=240, h=180, span=80.0, warper="mercator", blender="multiband", strength=8),
     "transverse_mercator_mb": dict(n=3, w=240, h=180, span=80.0, warper="transverseMercator", blender="multiband",
                                    strength=8),
+    # the arithmetic modes of round 3 (include/stitching_amd.h STX_REMAP_*, STX_TRIG_*): the fp32-interpolation model of cv.remap and
+    # glibc's own sinf / cosf — both pure restatements, deterministic on any host
+    "spherical_mb_remap_float": dict(n=3, w=400, h=300, span=110.0, warper="spherical", blender="multiband", strength=6, remap="float"),
+    "cylindrical_no_remap_float_fma": dict(n=3, w=320, h=240, span=90.0, warper="cylindrical", blender="no", strength=5,
+                                           remap="float-fma"),
+    "spherical_mb_trig_glibc": dict(n=4, w=400, h=300, span=150.0, warper="spherical", blender="multiband", strength=6, trig="glibc"),
+    "fisheye_no_trig_glibc_nofma": dict(n=3, w=240, h=180, span=80.0, warper="fisheye", blender="no", strength=5, trig="glibc-nofma"),
 }
 SMALL = "plane_mb3"
 
@@ -80,7 +87,35 @@ def inputs_for(p):
 
 
 def run_case(p, warper_cls, blender_cls):
-    """Same call sequence for the oracle and for the product (tests/helpers.py)."""
+    """Same call sequence for the oracle and for the product (tests/helpers.py).  A case may name a remap / trig mode: set on
+    whichever implementation runs (the oracle's model switches, the product's process-wide modes) and restored afterwards."""
+    if p.get("remap") or p.get("trig"):
+        q = {k: v for k, v in p.items() if k not in ("remap", "trig")}
+        if warper_cls.__module__.startswith("oracle"):
+            from oracle import oracle as O
+
+            prev = O.set_model()
+            O.set_model(**dict(prev, remap={"float": "float", "float-fma": "float_fma"}.get(p.get("remap"), prev["remap"])))
+            tmode = {"glibc": O.TRIG_GLIBC, "glibc-nofma": O.TRIG_GLIBC_NOFMA}.get(p.get("trig"))
+
+            class W(warper_cls):
+                def __init__(self, warper_type="spherical"):
+                    super().__init__(warper_type, **({"trig": tmode} if tmode is not None else {}))
+
+            try:
+                return run_case(q, W, blender_cls)
+            finally:
+                O.set_model(**prev)
+        import stitching_amd as S
+
+        prev_r, prev_t = S.remap_mode(), S.trig_mode()
+        try:
+            S.set_remap_mode(p.get("remap", prev_r))
+            S.set_trig_mode(p.get("trig", prev_t))
+            return run_case(q, warper_cls, blender_cls)
+        finally:
+            S.set_remap_mode(prev_r)
+            S.set_trig_mode(prev_t)
     from stitching_amd import synthetic
     from tests import helpers
 
