@@ -29,9 +29,19 @@ def main():
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     corners, sizes, req_bands = case["corners"], case["sizes"], case["req_bands"]
     roi = D.Blender.result_roi(corners, sizes)
-    probe = D.make_shard_blender(None, roi, req_bands)  # geometry only: no GPU, no context
+    kind = case.get("kind", "multiband")  # "feather" / "no": strips = band columns + halo, no probe blender
+    probe = D.make_shard_blender(None, roi, req_bands) if kind == "multiband" else None  # geometry only: no GPU, no context
     plan = D.ShardPlan(corners, sizes, D.owners_contiguous(len(corners), world), world, probe, case.get("exchange", "strips"),
-                       case.get("mask_bits", False))
+                       case.get("mask_bits", False), kind=kind, halo=D.feather_halo(case.get("sharpness", 0.0)),
+                       balance=case.get("balance", "midway"))
+    if kind != "multiband":
+        for g in range(world):
+            band_roi, (c0, c1) = plan.band_roi(g)
+            assert c1 - c0 == plan.edges[g + 1] - plan.edges[g] and band_roi[2] >= c1 and band_roi[0] >= roi[0]
+            for k in range(len(corners)):
+                x0, x1 = plan.own_columns(k, g)
+                if x1 > x0:  # what the band's blender is fed lies inside the roi it is prepared for
+                    assert band_roi[0] <= corners[k][0] + x0 and corners[k][0] + x1 <= band_roi[0] + band_roi[2]
     if plan.exchange == "strips":
         for (k, src, dst, (x0, x1, w, h), nbytes) in plan.messages:
             assert 0 <= x0 < x1 <= sizes[k][0] and w == x1 - x0 and h == sizes[k][1] and x0 % 8 == 0, "strip geometry"

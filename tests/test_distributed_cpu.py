@@ -114,3 +114,19 @@ def test_band_balance_for_the_links(oracle):
                                   make_shard_blender(None, oracle.result_roi(corners[:8], wsizes[:8]), 3), "strips", True).edges
     with pytest.raises(Exception):
         ShardPlan(corners, wsizes, owners, world, probe, "strips", True, balance="compute")
+
+
+@pytest.mark.parametrize("world,kind,sharpness", [(2, "feather", 0.02), (3, "feather", 0.004), (3, "no", 0.0)])
+def test_flat_blender_plans_and_exchange_over_gloo(oracle, world, kind, sharpness):
+    """The sharded feather / plain blender's plan on every rank of a gloo world: the same strips everywhere, each inside the roi its
+    band's blender is prepared for, the payloads of the planned sizes arrive intact; with the link-balanced edges too."""
+    n = 2 * world
+    cams = synthetic.ring_cameras(n, 800, 600, span_deg=40.0 * n)
+    w = oracle.Warper("spherical")
+    w.set_scale(cams)
+    corners, sizes = w.warp_rois([(800, 600)] * n, cams)
+    base = {"corners": [list(c) for c in corners], "sizes": [list(s) for s in sizes], "req_bands": 0, "kind": kind, "sharpness": sharpness}
+    res = launch(world, base)
+    assert res["ok"] and res["bands"] == 0 and res["messages"] >= world - 1 and res["bytes"] > 0
+    bits = launch(world, dict(base, mask_bits=True, balance="links"))
+    assert bits["ok"] and bits["messages"] == res["messages"] and bits["bytes"] < 0.85 * res["bytes"]
