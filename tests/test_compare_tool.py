@@ -24,6 +24,17 @@ def test_model_sweep_and_golden_roundtrip(oracle, tmp_path, monkeypatch):
     assert best == {"trig": "libm", "remap": "q15", "pyrdown32f": best["pyrdown32f"], "lanes": best["lanes"]}
     assert rep["model_sweep"]["warp"]["libm/q15"] == 0 and rep["model_sweep"]["warp"]["exact/float"] > 0
     assert rep["model_sweep"]["blend"]["simd_hv/4"] == 0
+    # the stand-in calls this host's libm: the product's switch that reproduces it is one of the two glibc builds (on a glibc
+    # host), with the classic remap
+    pm = rep["product_modes"]
+    assert pm["STITCHING_AMD_REMAP"] == "q15" and pm["STITCHING_AMD_TRIG"] in ("glibc", "glibc-nofma", "exact")
+    from tests.test_glibc_trig import _host_is_glibc
+
+    if _host_is_glibc():
+        # (not 0: the subset holds a fisheye case, whose backward map also calls atan2f — correctly rounded in every product mode,
+        # the host's own in the stand-in; the tabled projectors are reproduced exactly, tests/test_gpu_trig.py)
+        assert pm["STITCHING_AMD_TRIG"] in ("glibc", "glibc-nofma")
+        assert pm["warp_differing_bytes"] < rep["model_sweep"]["warp"]["exact/q15"]
     # the tool's main comparison runs the DEFAULT oracle model against the stand-in: within the measured bounds, not exact
     assert rc in (0, 1) and rep["worst_next_rows"] == 0
     z = np.load(golden)

@@ -31,7 +31,9 @@ def model_sweep(cv, O, G, report, golden):
     (pyrDown order, with the warp inputs taken from the oracle so that only the blender differs)."""
     from stitching_amd import synthetic
 
-    warp_models = [(t, r) for t in ("libm", "exact") for r in O.REMAP_MODELS]
+    # trig: this host's libm, correctly rounded, and the two builds of glibc's routine that the PRODUCT can be switched to
+    trig_ids = {"libm": O.TRIG_LIBM, "exact": O.TRIG_EXACT, "glibc": O.TRIG_GLIBC, "glibc-nofma": O.TRIG_GLIBC_NOFMA}
+    warp_models = [(t, r) for t in trig_ids for r in O.REMAP_MODELS]
     pyr_models = [(m, l) for m in O.PYRDOWN32F_MODELS for l in ((4,) if m == "scalar" else (4, 8))]
     warp_score = {m: 0 for m in warp_models}
     pyr_score = {m: 0 for m in pyr_models}
@@ -50,7 +52,7 @@ def model_sweep(cv, O, G, report, golden):
             refs.append((ref, refm, roi))
         for (t, r) in warp_models:
             O.set_model(remap=r)
-            ow = O.Warper(p["warper"], trig=O.TRIG_LIBM if t == "libm" else O.TRIG_EXACT)
+            ow = O.Warper(p["warper"], trig=trig_ids[t])
             ow.set_scale(cams)
             for (ref, refm, roi), img, c in zip(refs, imgs, cams):
                 mine = ow.warp_image(img, c, aspect)
@@ -99,13 +101,24 @@ def model_sweep(cv, O, G, report, golden):
         O.set_model()
     print("\nmodel sweep (differing bytes over all cases; 0 = this build follows that model):")
     for k, v in sorted(warp_score.items(), key=lambda kv: kv[1]):
-        print(f"  warp: trig={k[0]:5s} remap={k[1]:9s} {v}")
+        print(f"  warp: trig={k[0]:11s} remap={k[1]:9s} {v}")
     for k, v in sorted(pyr_score.items(), key=lambda kv: kv[1]):
         print(f"  blend: pyrdown32f={k[0]:12s} lanes={k[1]} {v}")
     bw_, bp_ = min(warp_score, key=warp_score.get), min(pyr_score, key=pyr_score.get)
     report["model_sweep"] = {"warp": {f"{k[0]}/{k[1]}": v for k, v in warp_score.items()},
                              "blend": {f"{k[0]}/{k[1]}": v for k, v in pyr_score.items()},
                              "best": {"trig": bw_[0], "remap": bw_[1], "pyrdown32f": bp_[0], "lanes": bp_[1]}}
+    # Which switches of the PRODUCT (include/stitching_amd.h: STX_TRIG_*, STX_REMAP_*) reproduce this OpenCV build's warp: the best
+    # remap model, and among the trig modes the product has (exact, glibc, glibc-nofma) the one with the fewest differing bytes under
+    # that remap.  The blender has one arithmetic (scalar pyrDown order); a SIMD-order build differs from it by at most 1 LSB.
+    remap_env = {"q15": "q15", "float": "float", "float_fma": "float-fma"}[bw_[1]]
+    prod_trig = min(("exact", "glibc", "glibc-nofma"), key=lambda t: warp_score[(t, bw_[1])])
+    report["product_modes"] = {"STITCHING_AMD_TRIG": prod_trig, "STITCHING_AMD_REMAP": remap_env,
+                               "warp_differing_bytes": warp_score[(prod_trig, bw_[1])],
+                               "blend_matches_scalar_pyrdown": pyr_score[("scalar", 4)] == 0,
+                               "blend_differing_bytes_scalar": pyr_score[("scalar", 4)]}
+    print(f"\nto reproduce this OpenCV build with stitching_amd:  STITCHING_AMD_TRIG={prod_trig}  STITCHING_AMD_REMAP={remap_env}"
+          f"   (warp: {warp_score[(prod_trig, bw_[1])]} differing bytes over all cases; blend, scalar pyrDown order: {pyr_score[('scalar', 4)]})")
     if golden is not None:
         golden["__meta__"] = np.frombuffer(json.dumps({"cv2": cv.__version__, "best": report["model_sweep"]["best"],
                                                       "warp_diff": warp_score[bw_], "blend_diff": pyr_score[bp_]}).encode(), np.uint8)
