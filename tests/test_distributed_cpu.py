@@ -130,3 +130,17 @@ def test_flat_blender_plans_and_exchange_over_gloo(oracle, world, kind, sharpnes
     assert res["ok"] and res["bands"] == 0 and res["messages"] >= world - 1 and res["bytes"] > 0
     bits = launch(world, dict(base, mask_bits=True, balance="links"))
     assert bits["ok"] and bits["messages"] == res["messages"] and bits["bytes"] < 0.85 * res["bytes"]
+
+
+def test_eight_ranks_config3_layout_link_balanced_over_gloo(oracle):
+    """BASELINE config 3's layout at an eighth of its size with all 8 ranks as gloo processes and the band edges placed for the links
+    (the default of ShardedStitchJob): every rank derives the same plan, strips to first, second and third neighbours arrive intact."""
+    cams = synthetic.grid_cameras(8, 4, 500, 375)
+    w = oracle.Warper("spherical")
+    w.set_scale(cams)
+    corners, sizes = w.warp_rois([(500, 375)] * len(cams), cams)
+    case = {"corners": [list(c) for c in corners], "sizes": [list(s) for s in sizes], "req_bands": 2, "exchange": "strips", "mask_bits": True}
+    mid = launch(8, dict(case, balance="midway"))
+    bal = launch(8, dict(case, balance="links"))
+    assert mid["ok"] and bal["ok"] and bal["bands"] == mid["bands"] == 2
+    assert bal["edges"] != mid["edges"] and bal["edges"][1] < mid["edges"][1] and bal["messages"] >= 8 * 4
