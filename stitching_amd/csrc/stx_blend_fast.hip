@@ -851,7 +851,7 @@ STX_DEV void mb_level_fast_body(const MbLevelK& P)
     // resized seam mask is grey only along the seam — runs the arithmetic of mb_level0_pk_kernel, epilogue included.
     constexpr bool PKACC = L0 && U8SRC && !CONTRIB && !EMIT;
     uint32_t accp[2][3][4], cntp[2][4];
-    bool ws_live = false;  // per lane: a lane outside the grey image keeps counting until a grey image reaches it
+    bool ws_live = false;  // wave-uniform
 #pragma unroll
     for (int r = 0; r < 2; r++) {
 #pragma unroll
@@ -1137,19 +1137,9 @@ STX_DEV void mb_level_fast_body(const MbLevelK& P)
     }
 
     if (PKACC) {
-        if (__ballot(ws_live) == 0ull) {  // no lane of the wavefront met a grey byte
+        if (!ws_live) {
             level0_epilogue_pk<false>(P, X0, Y0, accp, cntp, nullptr);
         } else {
-            // one epilogue for the whole wavefront: lanes that are still counting convert now (exact)
-            if (!ws_live) {
-#pragma unroll
-                for (int r = 0; r < 2; r++)
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        ws[r][(q & 1) * 4 + (q >> 1)] = (float)(cntp[r][q] & 0xffffu);
-                        ws[r][(q & 1) * 4 + (q >> 1) + 2] = (float)(cntp[r][q] >> 16);
-                    }
-            }
             // compare(dst_band_weights_0, WEIGHT_EPS, CMP_GT) as 1 / 0 per pixel
 #pragma unroll
             for (int r = 0; r < 2; r++)
