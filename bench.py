@@ -66,12 +66,16 @@ def parse():
 
 
 def kernel_source_hash():
-    """sha256 over the device sources (.hip files and the device headers): a traffic profile is only quoted for the
-    kernels it was measured on (host-side API changes do not move bytes)."""
+    """sha256 over the device CODE (.hip files and the device headers; // comments and white space dropped, so that rewording a
+    comment does not orphan a traffic profile): a profile is only quoted for the kernels it was measured on (host-side API changes
+    do not move bytes)."""
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "stitching_amd", "csrc", "*"))):
         if f.endswith(".hip") or os.path.basename(f) in ("stx_device_math.h", "stx_blend_kernels.h"):  # device code only
-            h.update(open(f, "rb").read())
+            for line in open(f, encoding="utf-8", errors="replace"):
+                code = "".join(line.split("//", 1)[0].split())  # none of these sources holds "//" inside a string literal
+                if code:
+                    h.update(code.encode() + b"\n")
     return h.hexdigest()[:16]
 
 

@@ -851,7 +851,8 @@ STX_DEV void mb_level_fast_body(const MbLevelK& P)
     // resized seam mask is grey only along the seam — runs the arithmetic of mb_level0_pk_kernel, epilogue included.
     constexpr bool PKACC = L0 && U8SRC && !CONTRIB && !EMIT;
     uint32_t accp[2][3][4], cntp[2][4];
-    bool ws_live = false;  // wave-uniform
+    bool ws_live = false;  // per lane: a lane outside the grey image keeps counting until a grey image reaches it; a wavefront whose lanes
+                           // disagree at the end runs both epilogues under their masks (one common fp32 epilogue measured slower)
 #pragma unroll
     for (int r = 0; r < 2; r++) {
 #pragma unroll
