@@ -72,6 +72,27 @@ int stx_get_trig_mode(void);
 int stx_set_remap_mode(int mode);
 int stx_get_remap_mode(void);
 
+/* pyrDown order of the fp32 weight pyramids.  stitching/blender.py:40-41 -> MultiBandBlender::feed -> pyrDown(CV_32F) per level.  The
+ * 5-tap sums are integers for the image planes (any order gives the same bits) but fp32 for the weights, where OpenCV's scalar loop
+ * and its SIMD code associate differently:
+ *   scalar      row:  s2*6 + (s1+s3)*4 + s0 + s4                 column: the same expression
+ *   SIMD        row:  s2*6 + ((s1+s3)*4 + (s0+s4))               column: (r1+r3+r2)*4 + (r0+r4+(r2+r2))
+ * and a build with FMA contracts each multiply-add.  The vector code covers the outputs 1 .. 1 + ((width0-1)/L)*L of a row
+ * (width0 = min((w-3)/2+1, dw), L = lanes per vector) and the first (dw/L)*L outputs of the column pass; the rest is the scalar loop.
+ * With 0 / 255 masks the levels 1..3 are exact in every order; coarser levels, and grey masks from level 1 on, move by an ULP and the
+ * panorama by at most 1 LSB at a few bytes (profiles/r02_oracle_sensitivity.md).
+ *   STX_PYRDOWN_SCALAR (default: the tuned kernels)   STX_PYRDOWN_SIMD_V: column pass vectorised   STX_PYRDOWN_SIMD_HV: both
+ *   | STX_PYRDOWN_FMA: fused multiply-adds in the vector code;   lanes = 4 (SSE / NEON), 8 (AVX2), 16 (AVX-512)
+ * Like the float remap these are MODELS of OpenCV builds (the CPU checker holds the same ones), unverified here; any mode but the default
+ * builds the pyramids with the plain one-sample-per-lane kernels.  Process-wide: STITCHING_AMD_PYRDOWN = scalar | simd-v | simd-hv |
+ * simd-v-fma | simd-hv-fma, optionally ":lanes" (simd-hv:8), at first use, or stx_set_pyrdown_mode; read when a blender builds its pyramids. */
+#define STX_PYRDOWN_SCALAR 0
+#define STX_PYRDOWN_SIMD_V 1
+#define STX_PYRDOWN_SIMD_HV 3
+#define STX_PYRDOWN_FMA 4
+int stx_set_pyrdown_mode(int mode, int lanes);
+int stx_get_pyrdown_mode(int* out_lanes);
+
 /* warper types: the names of Warper.WARP_TYPE_CHOICES (stitching/warper.py:10-27);
  * cv.PyRotationWarper(type, scale) string -> id in the Python shim */
 #define STX_WARP_PLANE 0

@@ -26,11 +26,12 @@ BLEND_NO, BLEND_FEATHER, BLEND_MULTIBAND = 0, 1, 2
 U8, S16, F32 = 0, 1, 2
 TRIG_MODES = {"exact": 0, "glibc": 1, "glibc-nofma": 2}
 REMAP_MODES = {"q15": 0, "float": 1, "float-fma": 2}
+PYRDOWN_MODES = {"scalar": 0, "simd-v": 1, "simd-hv": 3, "simd-v-fma": 5, "simd-hv-fma": 7}
 CONTRIB_U8_BINARY = 1
 STRIP_MASK_BITS = 2
 
 EXPORTS = (
-    "stx_version stx_last_error stx_set_trig_mode stx_get_trig_mode stx_set_remap_mode stx_get_remap_mode stx_device_count stx_ctx_create stx_ctx_destroy stx_ctx_sync "
+    "stx_version stx_last_error stx_set_trig_mode stx_get_trig_mode stx_set_remap_mode stx_get_remap_mode stx_set_pyrdown_mode stx_get_pyrdown_mode stx_device_count stx_ctx_create stx_ctx_destroy stx_ctx_sync "
     "stx_host_alloc stx_host_free stx_buf_from_host stx_buf_from_host_async stx_buf_alloc stx_buf_to_host stx_buf_to_host_async stx_buf_view stx_buf_info stx_buf_device_ptr stx_buf_free "
     "stx_warp_roi stx_warp_rois stx_warp stx_warp_image_and_mask stx_warp_batch stx_warp_batch_rects stx_warp_mask "
     "stx_gain_apply stx_block_gain_apply stx_resize_linear_exact stx_seam_mask_resize stx_seam_mask_resize_batch stx_seam_mask_resize_batch_sub stx_timelapse_frame stx_result_roi stx_blend_create stx_blend_num_bands stx_blend_feed stx_blend_finish stx_blend_finish_ex "
@@ -62,6 +63,9 @@ def lib():
     L.stx_get_trig_mode.restype = C.c_int
     L.stx_set_remap_mode.argtypes = [C.c_int]
     L.stx_get_remap_mode.restype = C.c_int
+    L.stx_set_pyrdown_mode.argtypes = [C.c_int, C.c_int]
+    L.stx_get_pyrdown_mode.argtypes = [C.POINTER(C.c_int)]
+    L.stx_get_pyrdown_mode.restype = C.c_int
     L.stx_device_count.argtypes = [ip]
     L.stx_ctx_create.argtypes = [C.c_int, vpp]
     L.stx_ctx_destroy.argtypes = [vp]

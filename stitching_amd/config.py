@@ -62,3 +62,32 @@ def remap_mode():
     from . import _lib
 
     return {v: k for k, v in _lib.REMAP_MODES.items()}[_lib.lib().stx_get_remap_mode()]
+
+
+def set_pyrdown_mode(mode, lanes=4):
+    """Order of the fp32 sums of the weight pyramids (include/stitching_amd.h STX_PYRDOWN_*): "scalar" (default: the tuned kernels) or
+    the order of OpenCV's vector code — "simd-v", "simd-hv", "simd-v-fma", "simd-hv-fma" with `lanes` (4, 8, 16) floats per vector
+    (cv.detail_MultiBandBlender.feed -> pyrDown(CV_32F), stitching/blender.py:40-41).  Models of OpenCV builds, unverified; any mode but
+    the default builds the pyramids with the plain kernels.  Process-wide, read when a blender builds its pyramids; STITCHING_AMD_PYRDOWN
+    ("simd-hv:8") sets the start-up value.  Returns the previous (mode, lanes)."""
+    from . import _lib
+
+    L = _lib.lib()
+    prev = pyrdown_mode()
+    if mode not in _lib.PYRDOWN_MODES:
+        from .stitching_error import StitchingError
+
+        raise StitchingError(f"unknown pyrDown mode {mode!r}: one of {sorted(_lib.PYRDOWN_MODES)}")
+    _lib.check(L.stx_set_pyrdown_mode(_lib.PYRDOWN_MODES[mode], int(lanes)))
+    return prev
+
+
+def pyrdown_mode():
+    """-> (mode name, lanes)"""
+    import ctypes as C
+
+    from . import _lib
+
+    lanes = C.c_int()
+    m = _lib.lib().stx_get_pyrdown_mode(C.byref(lanes))
+    return {v: k for k, v in _lib.PYRDOWN_MODES.items()}[m], int(lanes.value)

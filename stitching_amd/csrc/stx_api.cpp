@@ -848,6 +848,47 @@ STX_EXPORT int stx_set_remap_mode(int mode)
     return STX_OK;
 }
 
+// pyrDown order of the fp32 weight pyramids (include/stitching_amd.h STX_PYRDOWN_*): process-wide, from STITCHING_AMD_PYRDOWN
+// ("simd-hv", "simd-v-fma:8", ...) on first use; packed as mode | lanes << 8
+static std::atomic<int> g_pyrdown{-1};
+
+static int pyrdown_now()
+{
+    int m = g_pyrdown.load();
+    if (m >= 0) return m;
+    const char* e = getenv("STITCHING_AMD_PYRDOWN");
+    int mode = STX_PYRDOWN_SCALAR, lanes = 4;
+    if (e && *e) {
+        std::string v(e);
+        const size_t colon = v.find(':');
+        if (colon != std::string::npos) { lanes = atoi(v.c_str() + colon + 1); v.resize(colon); }
+        if (v == "simd-v") mode = STX_PYRDOWN_SIMD_V;
+        else if (v == "simd-hv") mode = STX_PYRDOWN_SIMD_HV;
+        else if (v == "simd-v-fma") mode = STX_PYRDOWN_SIMD_V | STX_PYRDOWN_FMA;
+        else if (v == "simd-hv-fma") mode = STX_PYRDOWN_SIMD_HV | STX_PYRDOWN_FMA;
+        else if (v != "scalar") fprintf(stderr, "[stitching_amd] STITCHING_AMD_PYRDOWN=%s is not scalar, simd-v, simd-hv, simd-v-fma or simd-hv-fma: using scalar\n", e);
+        if (lanes != 4 && lanes != 8 && lanes != 16) { fprintf(stderr, "[stitching_amd] STITCHING_AMD_PYRDOWN lanes %d: using 4\n", lanes); lanes = 4; }
+    }
+    int expected = -1;
+    g_pyrdown.compare_exchange_strong(expected, mode | (lanes << 8));
+    return g_pyrdown.load();
+}
+
+STX_EXPORT int stx_get_pyrdown_mode(int* out_lanes)
+{
+    const int m = pyrdown_now();
+    if (out_lanes) *out_lanes = m >> 8;
+    return m & 255;
+}
+
+STX_EXPORT int stx_set_pyrdown_mode(int mode, int lanes)
+{
+    const bool known = mode == STX_PYRDOWN_SCALAR || (mode & ~STX_PYRDOWN_FMA) == STX_PYRDOWN_SIMD_V || (mode & ~STX_PYRDOWN_FMA) == STX_PYRDOWN_SIMD_HV;
+    if (!known || (lanes != 4 && lanes != 8 && lanes != 16)) return stx_fail(STX_ERR_INVALID, "pyrDown mode %d, lanes %d", mode, lanes);
+    g_pyrdown.store(mode | (lanes << 8));
+    return STX_OK;
+}
+
 int stx_make_projector(int type, float scale, const float* K, const float* R, StxProjector* p)
 {
     if (type < STX_WARP_PLANE || type >= STX_WARP_TYPE_COUNT)
@@ -1473,7 +1514,8 @@ static int mb_ensure_pyramids(stx_blender* b)
     // occupancy maps of the weight pyramids (StxMbImage::occ): one arena for this batch.  Only where every level is built by
     // the batched LDS kernels, which write them (int16 sources take the generic level-0 kernel).
     static const bool occ_off = getenv("STITCHING_AMD_NO_OCC") != nullptr;  // diagnostic: A/B of the bookkeeping
-    if (todo.size() <= 65535 && !occ_off) {
+    const int pyr = pyrdown_now();  // != scalar: the generic kernels build every level, and they keep no occupancy maps
+    if (todo.size() <= 65535 && !occ_off && (pyr & 255) == STX_PYRDOWN_SCALAR) {
         const int nl = b->num_bands + 1;
         std::vector<size_t> off(todo.size() * (size_t)nl, 0);
         size_t bytes = 0;
@@ -1500,7 +1542,7 @@ static int mb_ensure_pyramids(stx_blender* b)
     }
     StxMbImage* d = nullptr;
     STX_TRY(mb_upload(b, todo.data(), (int)todo.size(), &d));
-    STX_TRY(stx_launch_mb_pyramids(b->ctx, d, todo.data(), (int)todo.size(), b->num_bands));
+    STX_TRY(stx_launch_mb_pyramids(b->ctx, d, todo.data(), (int)todo.size(), b->num_bands, pyr & 255, pyr >> 8));
     for (size_t i = 0; i < b->images.size(); i++) b->built[i] = 1;
     return STX_OK;
 }

@@ -53,6 +53,30 @@ STX_DEV float h5f(float s0, float s1, float s2, float s3, float s4)
     return fadd(fadd(fadd(fmul(s2, 6.f), fmul(fadd(s1, s3), 4.f)), s0), s4);
 }
 
+// ... and in the order of OpenCV's vector code (include/stitching_amd.h STX_PYRDOWN_*): row sums, column sums, fused or not
+STX_DEV float h5f_simd(float s0, float s1, float s2, float s3, float s4, bool fused)
+{
+    const float outer = fadd(s0, s4), inner = fadd(s1, s3);
+    const float t = fused ? __fmaf_rn(inner, 4.f, outer) : fadd(fmul(inner, 4.f), outer);
+    return fused ? __fmaf_rn(s2, 6.f, t) : fadd(fmul(s2, 6.f), t);
+}
+STX_DEV float v5f_simd(float r0, float r1, float r2, float r3, float r4, bool fused)
+{
+    const float a = fadd(fadd(r1, r3), r2), b = fadd(fadd(r0, r4), fadd(r2, r2));
+    return fused ? __fmaf_rn(a, 4.f, b) : fadd(fmul(a, 4.f), b);
+}
+// which outputs of a level w samples wide (dw outputs) the vector code forms: rows 1 <= x < hx1, columns x < vx1
+struct PyrOrder { int hx1, vx1; bool fused; };
+STX_DEV PyrOrder pyr_order(int mode, int lanes, int w, int dw)
+{
+    PyrOrder o;
+    const int width0 = min((w - 3) / 2 + 1, dw);
+    o.hx1 = (mode & 2) && width0 > 1 ? 1 + ((width0 - 1) / lanes) * lanes : 1;
+    o.vx1 = (mode & 1) ? (dw / lanes) * lanes : 0;
+    o.fused = (mode & 4) != 0;
+    return o;
+}
+
 // sample `idx` (row * stride + column, + channel * plane) of level lv of an image's Gaussian pyramid: bytes when the image was
 // fed as u8 (StxMbImage::g_u8), else int16
 // (pointers read from a descriptor in memory are generic to the compiler; all of ours are device global memory: global_load
@@ -70,9 +94,10 @@ STX_DEV void st_g(const StxMbImage& im, int lv, long long idx, int v)
 
 // pyrDown of (bordered level 0) -> level 1: G_1 planar (u8 / int16), W_1 fp32
 template <bool S16>
-__global__ __launch_bounds__(256) void mb_down0_kernel(StxMbImage im)
+__global__ __launch_bounds__(256) void mb_down0_kernel(StxMbImage im, int pyr_mode, int pyr_lanes)
 {
     const int ow = im.fw >> 1, oh = im.fh >> 1;
+    const PyrOrder po = pyr_order(pyr_mode, pyr_lanes, im.fw, ow);
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= ow || y >= oh) return;
@@ -100,20 +125,22 @@ __global__ __launch_bounds__(256) void mb_down0_kernel(StxMbImage im)
         vb[k] = b[2] * 6 + (b[1] + b[3]) * 4 + b[0] + b[4];
         vg[k] = g[2] * 6 + (g[1] + g[3]) * 4 + g[0] + g[4];
         vr[k] = r[2] * 6 + (r[1] + r[3]) * 4 + r[0] + r[4];
-        vw[k] = h5f(w[0], w[1], w[2], w[3], w[4]);
+        vw[k] = (x >= 1 && x < po.hx1) ? h5f_simd(w[0], w[1], w[2], w[3], w[4], po.fused) : h5f(w[0], w[1], w[2], w[3], w[4]);
     }
     const long long o = (long long)y * im.g_stride[1] + x;
     st_g(im, 1, o, (vb[2] * 6 + (vb[1] + vb[3]) * 4 + vb[0] + vb[4] + 128) >> 8);
     st_g(im, 1, o + im.g_plane[1], (vg[2] * 6 + (vg[1] + vg[3]) * 4 + vg[0] + vg[4] + 128) >> 8);
     st_g(im, 1, o + 2 * im.g_plane[1], (vr[2] * 6 + (vr[1] + vr[3]) * 4 + vr[0] + vr[4] + 128) >> 8);
-    im.wt[1][(long long)y * im.wt_stride[1] + x] = fmul(h5f(vw[0], vw[1], vw[2], vw[3], vw[4]), INV256);
+    const float col = x < po.vx1 ? v5f_simd(vw[0], vw[1], vw[2], vw[3], vw[4], po.fused) : h5f(vw[0], vw[1], vw[2], vw[3], vw[4]);
+    im.wt[1][(long long)y * im.wt_stride[1] + x] = fmul(col, INV256);
 }
 
 // pyrDown level i -> i+1 (i >= 1), planar int16 x3 + fp32
-__global__ __launch_bounds__(256) void mb_down_kernel(StxMbImage im, int lv)
+__global__ __launch_bounds__(256) void mb_down_kernel(StxMbImage im, int lv, int pyr_mode, int pyr_lanes)
 {
     const int iw = im.fw >> lv, ih = im.fh >> lv;
     const int ow = iw >> 1, oh = ih >> 1;
+    const PyrOrder po = pyr_order(pyr_mode, pyr_lanes, iw, ow);
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= ow || y >= oh) return;
@@ -135,13 +162,15 @@ __global__ __launch_bounds__(256) void mb_down_kernel(StxMbImage im, int lv)
                       ld_g(im, lv, row + cx[4]);
         }
         const float* wr = W + (long long)sy * ws;
-        vw[k] = h5f(wr[cx[0]], wr[cx[1]], wr[cx[2]], wr[cx[3]], wr[cx[4]]);
+        vw[k] = (x >= 1 && x < po.hx1) ? h5f_simd(wr[cx[0]], wr[cx[1]], wr[cx[2]], wr[cx[3]], wr[cx[4]], po.fused)
+                                       : h5f(wr[cx[0]], wr[cx[1]], wr[cx[2]], wr[cx[3]], wr[cx[4]]);
     }
 #pragma unroll
     for (int c = 0; c < 3; c++)
         st_g(im, lv + 1, c * im.g_plane[lv + 1] + (long long)y * im.g_stride[lv + 1] + x,
              (v[c][2] * 6 + (v[c][1] + v[c][3]) * 4 + v[c][0] + v[c][4] + 128) >> 8);
-    im.wt[lv + 1][(long long)y * im.wt_stride[lv + 1] + x] = fmul(h5f(vw[0], vw[1], vw[2], vw[3], vw[4]), INV256);
+    const float col = x < po.vx1 ? v5f_simd(vw[0], vw[1], vw[2], vw[3], vw[4], po.fused) : h5f(vw[0], vw[1], vw[2], vw[3], vw[4]);
+    im.wt[lv + 1][(long long)y * im.wt_stride[lv + 1] + x] = fmul(col, INV256);
 }
 
 // pyrUp_<FixPtCast<short,6>> sampled at one destination pixel (X, Y) of a planar image (int16, or the bytes of a u8 pyramid)
@@ -482,7 +511,8 @@ inline dim3 grid64x4(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
 
 // Builds G_1..G_B / W_1..W_B of every fed image: one launch per level for all images
 // (grid.z = image) on the LDS kernels; int16 sources and degenerate sizes use the generic kernels.
-int stx_launch_mb_pyramids(stx_ctx* ctx, const StxMbImage* d_images, const StxMbImage* h_images, int n, int num_bands)
+int stx_launch_mb_pyramids(stx_ctx* ctx, const StxMbImage* d_images, const StxMbImage* h_images, int n, int num_bands, int pyr_mode,
+                           int pyr_lanes)
 {
     for (int lv = 0; lv < num_bands; lv++) {
         double bytes = 0.0;
@@ -496,16 +526,17 @@ int stx_launch_mb_pyramids(stx_ctx* ctx, const StxMbImage* d_images, const StxMb
             any_s16 = any_s16 || im.img0_is_s16;
         }
         StxProfScope prof(ctx, lv == 0 ? "mb_down0" : "mb_down", bytes);
-        const bool batched = stx_fast_mb_down_batch(ctx, d_images, h_images, n, lv);
+        // the LDS kernels sum the weights in the scalar order; every other order goes through the generic kernels
+        const bool batched = pyr_mode == STX_PYRDOWN_SCALAR && stx_fast_mb_down_batch(ctx, d_images, h_images, n, lv);
         for (int i = 0; i < n; i++) {
             const StxMbImage& im = h_images[i];
             if (batched && !(lv == 0 && im.img0_is_s16)) continue;
             const int ow = (im.fw >> lv) >> 1, oh = (im.fh >> lv) >> 1;
             if (lv == 0) {
-                if (im.img0_is_s16) hipLaunchKernelGGL(mb_down0_kernel<true>, grid64x4(ow, oh), dim3(256), 0, ctx->stream, im);
-                else hipLaunchKernelGGL(mb_down0_kernel<false>, grid64x4(ow, oh), dim3(256), 0, ctx->stream, im);
+                if (im.img0_is_s16) hipLaunchKernelGGL(mb_down0_kernel<true>, grid64x4(ow, oh), dim3(256), 0, ctx->stream, im, pyr_mode, pyr_lanes);
+                else hipLaunchKernelGGL(mb_down0_kernel<false>, grid64x4(ow, oh), dim3(256), 0, ctx->stream, im, pyr_mode, pyr_lanes);
             } else {
-                hipLaunchKernelGGL(mb_down_kernel, grid64x4(ow, oh), dim3(256), 0, ctx->stream, im, lv);
+                hipLaunchKernelGGL(mb_down_kernel, grid64x4(ow, oh), dim3(256), 0, ctx->stream, im, lv, pyr_mode, pyr_lanes);
             }
         }
         STX_TRY(check_launch("mb_down"));

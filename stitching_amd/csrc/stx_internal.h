@@ -176,7 +176,9 @@ struct StxMbImage {  // device-visible descriptor of one fed image (all levels)
     // seam masks, exchange strips) a wavefront at a time.
     uint8_t* occ[STX_MAX_BANDS + 1];
 };
-int stx_launch_mb_pyramids(stx_ctx* ctx, const StxMbImage* d_images, const StxMbImage* h_images, int n, int num_bands);
+// pyr_mode / pyr_lanes: STX_PYRDOWN_* (include/stitching_amd.h); anything but SCALAR builds every level with the generic kernels
+int stx_launch_mb_pyramids(stx_ctx* ctx, const StxMbImage* d_images, const StxMbImage* h_images, int n, int num_bands, int pyr_mode,
+                           int pyr_lanes);
 struct MbLevelK;
 int stx_launch_mb_level(stx_ctx* ctx, const MbLevelK& K, double algo_bytes);
 int stx_launch_mb_coarse(stx_ctx* ctx, const MbLevelK& K_level_Bm2, double algo_bytes);  // levels B, B-1, B-2 in one launch

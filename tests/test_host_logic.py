@@ -178,3 +178,30 @@ def test_remap_mode_switch_needs_no_gpu():
     env = dict(os.environ, STITCHING_AMD_REMAP="float-fma", STITCHING_AMD_TRIG="glibc")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     assert out.stdout.split() == ["float-fma", "glibc"]
+
+
+def test_pyrdown_mode_switch_needs_no_gpu():
+    """stx_set_pyrdown_mode / stx_get_pyrdown_mode (include/stitching_amd.h STX_PYRDOWN_*): process-wide, usable without a device; the
+    environment variable ("simd-hv:8") only sets the start-up value (checked in fresh interpreters)."""
+    import os
+    import subprocess
+    import sys
+
+    prev = S.pyrdown_mode()
+    try:
+        assert prev[0] in ("scalar", "simd-v", "simd-hv", "simd-v-fma", "simd-hv-fma") and prev[1] in (4, 8, 16)
+        assert S.set_pyrdown_mode("simd-hv", 8) == prev and S.pyrdown_mode() == ("simd-hv", 8)
+        assert S.set_pyrdown_mode("simd-v-fma") == ("simd-hv", 8) and S.pyrdown_mode() == ("simd-v-fma", 4)
+        for bad in (("avx2", 8), ("simd-hv", 3)):
+            with pytest.raises(S.StitchingError):
+                S.set_pyrdown_mode(*bad)
+        assert S.pyrdown_mode() == ("simd-v-fma", 4)
+    finally:
+        S.set_pyrdown_mode(*prev)
+    code = "import stitching_amd as S; print(*S.pyrdown_mode())"
+    root = os.path.dirname(os.path.dirname(__file__))
+    for env_value, want in (("simd-hv:8", ["simd-hv", "8"]), ("simd-v-fma", ["simd-v-fma", "4"]), ("scalar:16", ["scalar", "16"]),
+                            ("nonsense:5", ["scalar", "4"])):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, STITCHING_AMD_PYRDOWN=env_value), capture_output=True,
+                             text=True, check=True, cwd=root)
+        assert out.stdout.split() == want, (env_value, out.stdout, out.stderr)

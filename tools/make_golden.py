@@ -67,6 +67,12 @@ CASES = {
                                            remap="float-fma"),
     "spherical_mb_trig_glibc": dict(n=4, w=400, h=300, span=150.0, warper="spherical", blender="multiband", strength=6, trig="glibc"),
     "fisheye_no_trig_glibc_nofma": dict(n=3, w=240, h=180, span=80.0, warper="fisheye", blender="no", strength=5, trig="glibc-nofma"),
+    # ... and the order of the fp32 weight sums of OpenCV's vector pyrDown (STX_PYRDOWN_*), 6 bands so that the levels where 0 / 255 masks
+    # stop being exact exist, 8 floats per vector
+    "spherical_mb6_pyrdown_simd_hv8": dict(n=4, w=640, h=480, span=150.0, warper="spherical", blender="multiband", bands=6,
+                                           pyrdown=["simd-hv", 8]),
+    "cylindrical_mb6_pyrdown_simd_v_fma": dict(n=4, w=640, h=480, span=150.0, warper="cylindrical", blender="multiband", bands=6,
+                                               pyrdown=["simd-v-fma", 4]),
 }
 SMALL = "plane_mb3"
 
@@ -89,13 +95,17 @@ def inputs_for(p):
 def run_case(p, warper_cls, blender_cls):
     """Same call sequence for the oracle and for the product (tests/helpers.py).  A case may name a remap / trig mode: set on
     whichever implementation runs (the oracle's model switches, the product's process-wide modes) and restored afterwards."""
-    if p.get("remap") or p.get("trig"):
-        q = {k: v for k, v in p.items() if k not in ("remap", "trig")}
+    if p.get("remap") or p.get("trig") or p.get("pyrdown"):
+        q = {k: v for k, v in p.items() if k not in ("remap", "trig", "pyrdown")}
+        pyr = p.get("pyrdown")
         if warper_cls.__module__.startswith("oracle"):
             from oracle import oracle as O
 
             prev = O.set_model()
-            O.set_model(**dict(prev, remap={"float": "float", "float-fma": "float_fma"}.get(p.get("remap"), prev["remap"])))
+            model = dict(prev, remap={"float": "float", "float-fma": "float_fma"}.get(p.get("remap"), prev["remap"]))
+            if pyr:
+                model.update(pyrdown32f=pyr[0].replace("-", "_"), lanes=pyr[1])
+            O.set_model(**model)
             tmode = {"glibc": O.TRIG_GLIBC, "glibc-nofma": O.TRIG_GLIBC_NOFMA}.get(p.get("trig"))
 
             class W(warper_cls):
@@ -108,14 +118,16 @@ def run_case(p, warper_cls, blender_cls):
                 O.set_model(**prev)
         import stitching_amd as S
 
-        prev_r, prev_t = S.remap_mode(), S.trig_mode()
+        prev_r, prev_t, prev_p = S.remap_mode(), S.trig_mode(), S.pyrdown_mode()
         try:
             S.set_remap_mode(p.get("remap", prev_r))
             S.set_trig_mode(p.get("trig", prev_t))
+            S.set_pyrdown_mode(*(pyr or prev_p))
             return run_case(q, warper_cls, blender_cls)
         finally:
             S.set_remap_mode(prev_r)
             S.set_trig_mode(prev_t)
+            S.set_pyrdown_mode(*prev_p)
     from stitching_amd import synthetic
     from tests import helpers
 
