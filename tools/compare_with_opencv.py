@@ -110,15 +110,17 @@ def model_sweep(cv, O, G, report, golden):
                              "best": {"trig": bw_[0], "remap": bw_[1], "pyrdown32f": bp_[0], "lanes": bp_[1]}}
     # Which switches of the PRODUCT (include/stitching_amd.h: STX_TRIG_*, STX_REMAP_*) reproduce this OpenCV build's warp: the best
     # remap model, and among the trig modes the product has (exact, glibc, glibc-nofma) the one with the fewest differing bytes under
-    # that remap.  The blender has one arithmetic (scalar pyrDown order); a SIMD-order build differs from it by at most 1 LSB.
+    # that remap; the pyrDown order of the weight pyramids that matches best (STX_PYRDOWN_*).
     remap_env = {"q15": "q15", "float": "float", "float_fma": "float-fma"}[bw_[1]]
     prod_trig = min(("exact", "glibc", "glibc-nofma"), key=lambda t: warp_score[(t, bw_[1])])
-    report["product_modes"] = {"STITCHING_AMD_TRIG": prod_trig, "STITCHING_AMD_REMAP": remap_env,
+    pyr_env = bp_[0].replace("_", "-") + (f":{bp_[1]}" if bp_[0] != "scalar" else "")
+    report["product_modes"] = {"STITCHING_AMD_TRIG": prod_trig, "STITCHING_AMD_REMAP": remap_env, "STITCHING_AMD_PYRDOWN": pyr_env,
                                "warp_differing_bytes": warp_score[(prod_trig, bw_[1])],
-                               "blend_matches_scalar_pyrdown": pyr_score[("scalar", 4)] == 0,
+                               "blend_differing_bytes": pyr_score[bp_],
                                "blend_differing_bytes_scalar": pyr_score[("scalar", 4)]}
-    print(f"\nto reproduce this OpenCV build with stitching_amd:  STITCHING_AMD_TRIG={prod_trig}  STITCHING_AMD_REMAP={remap_env}"
-          f"   (warp: {warp_score[(prod_trig, bw_[1])]} differing bytes over all cases; blend, scalar pyrDown order: {pyr_score[('scalar', 4)]})")
+    print(f"\nto reproduce this OpenCV build with stitching_amd:  STITCHING_AMD_TRIG={prod_trig}  STITCHING_AMD_REMAP={remap_env}  "
+          f"STITCHING_AMD_PYRDOWN={pyr_env}   (warp: {warp_score[(prod_trig, bw_[1])]} differing bytes over all cases; blend: {pyr_score[bp_]}, "
+          f"{pyr_score[('scalar', 4)]} in the default scalar order)")
     if golden is not None:
         golden["__meta__"] = np.frombuffer(json.dumps({"cv2": cv.__version__, "best": report["model_sweep"]["best"],
                                                       "warp_diff": warp_score[bw_], "blend_diff": pyr_score[bp_]}).encode(), np.uint8)
