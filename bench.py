@@ -425,7 +425,7 @@ def main():
         del sj
 
     parity_n = None
-    if world > 1 and not args.no_parity and wl["blender"] == "multiband":
+    if world > 1 and not args.no_parity:  # every blender type shards (feather and "no": distributed.py, round 3)
         parity_n = sharded_parity(jobs[0], dist, rank, world, wl, all_cams)
 
     if rank != 0:
