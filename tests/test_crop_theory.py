@@ -160,3 +160,64 @@ def test_flat_strips_reproduce_their_band(oracle, world, kind, strength, seams):
     owners = owners_contiguous(n, world)
     want = {(k, g) for g in range(world) for k in range(n) if owners[k] != g and plan.own_columns(k, g)[1] > plan.own_columns(k, g)[0]}
     assert {(m[0], m[2]) for m in plan.messages} == want
+
+
+def test_feather_halo_bounds_the_reach_of_a_weight():
+    """feather_halo's claim, numerically: beyond the halo every L1 distance d gives fl32(d * sharpness) >= 1 (the weight is at its cap),
+    whatever the rounding of the fp32 product; for sharpness below 1 / 8192 the distance transform's saturation bounds the reach instead."""
+    from stitching_amd.distributed import FEATHER_DIST_CAP, feather_halo
+
+    rng = np.random.default_rng(5)
+    for s in np.concatenate([np.logspace(-6, 0.5, 400), rng.uniform(1e-4, 0.2, 400), [1.0 / 8192, 1.0 / 8191, 1.0 / 8193, 0.02, 1.0]]):
+        s32 = np.float32(s)
+        halo = feather_halo(float(s))
+        assert 1 <= halo <= FEATHER_DIST_CAP + 1
+        if halo <= FEATHER_DIST_CAP:
+            d = np.arange(halo, halo + 64, dtype=np.float32)  # a zero just outside the strip is at least halo away from the band
+            assert np.all(d * s32 >= np.float32(1.0)), (s, halo)
+        else:  # every distance >= 8192 is treated as 8192: zeros farther than the cap cannot be told apart
+            assert halo == FEATHER_DIST_CAP + 1
+    assert feather_halo(0.0) == FEATHER_DIST_CAP + 1 and feather_halo(1.0) == 3
+
+
+def test_flat_strip_columns_invariants():
+    """flat_strip_columns / ShardPlan.band_roi on random geometry: a strip starts on a multiple of 8 inside its image, covers the
+    band's part of the image plus the halo (clipped to the image), and lies inside the roi its band's blender is prepared for."""
+    from stitching_amd.distributed import ShardPlan, flat_strip_columns, owners_contiguous
+
+    rng = np.random.default_rng(17)
+    for _ in range(200):
+        world = int(rng.integers(2, 6))
+        n = world * int(rng.integers(1, 4))
+        sizes = [(int(rng.integers(64, 900)), int(rng.integers(40, 500))) for _ in range(n)]
+        xs = np.sort(rng.integers(0, 3000, n))
+        corners = [(int(x) - 1500, int(rng.integers(-200, 200))) for x in xs]
+        halo = int(rng.choice([0, 1, 7, 33, 250]))
+        kind = "feather" if halo else "no"
+        try:
+            plan = ShardPlan(corners, sizes, owners_contiguous(n, world), world, None, "strips", bool(rng.integers(0, 2)), kind=kind, halo=halo,
+                             balance=str(rng.choice(["midway", "links"])))
+        except Exception as e:  # a panorama too narrow for `world` bands of 8 columns
+            assert "too narrow" in str(e)
+            continue
+        assert plan.edges[0] == 0 and plan.edges[-1] == plan.roi[2] and all(b > a for a, b in zip(plan.edges, plan.edges[1:]))
+        for g in range(world):
+            band_roi, (c0, c1) = plan.band_roi(g)
+            b0, b1 = plan.band(g)
+            assert c1 - c0 == b1 - b0 and band_roi[0] >= plan.roi[0] and band_roi[0] + band_roi[2] <= plan.roi[0] + plan.roi[2]
+            for k in range(n):
+                x0, x1 = plan.own_columns(k, g)
+                assert (x0, x1) == flat_strip_columns(corners[k], sizes[k], plan.roi, (b0, b1), plan.halo)
+                tlx, w = corners[k][0] - plan.roi[0], sizes[k][0]
+                meets = min(b1, tlx + w) > max(b0, tlx)
+                assert (x1 > x0) == meets
+                if not meets:
+                    continue
+                assert x0 % 8 == 0 and 0 <= x0 < x1 <= w
+                # everything of the image within `halo` of the band is inside the strip
+                assert tlx + x0 <= max(b0 - plan.halo, tlx) and tlx + x1 == min(b1 + plan.halo, tlx + w)
+                # ... and the strip inside the blender's roi
+                assert band_roi[0] <= corners[k][0] + x0 and corners[k][0] + x1 <= band_roi[0] + band_roi[2]
+        owners = plan.owners
+        want = {(k, g) for g in range(world) for k in range(n) if owners[k] != g and plan.own_columns(k, g)[1] > plan.own_columns(k, g)[0]}
+        assert {(m[0], m[2]) for m in plan.messages} == want
