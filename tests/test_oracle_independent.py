@@ -1,0 +1,238 @@
+"""Cross-checks of the oracle's sub-routines against INDEPENDENT implementations (scipy.ndimage / float64 closed forms).
+
+Every other known-answer test of the oracle was written by the author of the oracle; parity versus real OpenCV is unpinned
+(no cv2 here).  These tests pin each sub-routine to a formulation that shares no code and no author with it:
+
+  * distanceTransform(DIST_L1, 3)  (stitching/blender.py:34-36 -> FeatherBlender::createWeightMap)
+        == scipy.ndimage.distance_transform_cdt(metric="taxicab"), and the mask without a zero saturates at 8192;
+  * pyrDown 16S / 32F  (blender.py:31-32 -> MultiBandBlender::feed -> createLaplacePyr)
+        == correlate1d([1,4,6,4,1], mode="mirror") on both axes, every second sample, (v + 128) >> 8;
+  * pyrUp 16S  == zero-stuffing + the same 5 taps with OpenCV's border rule stated as padding, (v + 32) >> 6;
+  * mapBackward (warper.py:44-51 -> buildMaps) against the closed form evaluated in float64;
+  * remap INTER_LINEAR / BORDER_REFLECT (warper.py:46-51) == map_coordinates(order=1, mode="reflect") at the 1/32-px
+    quantised position up to round-half-up against round-half-even, and within the local-gradient bound at the exact position;
+  * remap INTER_NEAREST / BORDER_CONSTANT (warper.py:61-67) == map_coordinates(order=0, mode="constant") on rounded positions.
+"""
+import numpy as np
+import pytest
+from scipy import ndimage
+
+from stitching_amd import synthetic
+
+
+# ------------------------------------------------------------------------------------------------ distance transform
+@pytest.mark.parametrize("seed", range(6))
+def test_distance_transform_l1_equals_scipy_taxicab(oracle, seed):
+    rng = np.random.default_rng(100 + seed)
+    h, w = int(rng.integers(3, 200)), int(rng.integers(3, 260))
+    mask = np.full((h, w), 255, np.uint8)
+    kind = seed % 3
+    if kind == 0:  # isolated zeros
+        n = int(rng.integers(1, 12))
+        mask[rng.integers(0, h, n), rng.integers(0, w, n)] = 0
+    elif kind == 1:  # a warped-mask-like shape: zeros outside a rotated rectangle
+        yy, xx = np.mgrid[0:h, 0:w]
+        a = rng.uniform(-0.4, 0.4)
+        u = (xx - w / 2) * np.cos(a) + (yy - h / 2) * np.sin(a)
+        v = -(xx - w / 2) * np.sin(a) + (yy - h / 2) * np.cos(a)
+        mask[(np.abs(u) > 0.38 * w) | (np.abs(v) > 0.36 * h)] = 0
+    else:  # random blobs, grey values count as "set" (the transform looks at != 0 only)
+        mask = np.where(rng.random((h, w)) < 0.03, 0, rng.integers(1, 256, (h, w))).astype(np.uint8)
+    if mask.all():
+        mask[h // 2, w // 2] = 0
+    ours = oracle.distance_transform_l1(mask)
+    ref = ndimage.distance_transform_cdt(mask != 0, metric="taxicab")
+    assert ours.dtype == np.float32 and np.array_equal(ours, ref.astype(np.float32))
+
+
+def test_distance_transform_without_a_zero_saturates(oracle):
+    """No zero anywhere: OpenCV's 16.16 fixed-point transform starts from INT_MAX >> 2 at the (virtual) border and clamps to it,
+    (float)((INT_MAX >> 2) / 65536.f) = 8192 — the cap the feather halo of the sharded blender relies on."""
+    d = oracle.distance_transform_l1(np.full((37, 53), 255, np.uint8))
+    assert np.all(d == 8192.0)
+    # one zero far away: plain city-block distances, nothing saturates below the cap
+    m = np.full((40, 300), 255, np.uint8)
+    m[7, 5] = 0
+    d = oracle.distance_transform_l1(m)
+    yy, xx = np.mgrid[0:40, 0:300]
+    assert np.array_equal(d, (np.abs(yy - 7) + np.abs(xx - 5)).astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------------------ pyramids
+def _down_taps(a):
+    k = np.array([1, 4, 6, 4, 1], np.int64)
+    t = ndimage.correlate1d(a.astype(np.int64), k, axis=0, mode="mirror")
+    t = ndimage.correlate1d(t, k, axis=1, mode="mirror")
+    return t[::2, ::2]
+
+
+@pytest.mark.parametrize("shape", [(64, 96), (33, 47), (2, 2), (1, 9), (9, 1), (5, 4), (128, 3)])
+def test_pyr_down_16s_equals_mirror_correlation(oracle, shape):
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    for lo, hi in ((0, 256), (-32768, 32768)):
+        src = rng.integers(lo, hi, shape + (3,)).astype(np.int16)
+        ref = np.stack([(_down_taps(src[:, :, c]) + 128) >> 8 for c in range(3)], axis=2)
+        # no saturation in OpenCV's FixPtCast: the sum of 256 int16 weights / 256 stays inside int16
+        assert ref.min() >= -32768 and ref.max() <= 32767
+        assert np.array_equal(oracle.pyr_down_16s(src), ref.astype(np.int16))
+    one = rng.integers(-500, 500, shape).astype(np.int16)
+    assert np.array_equal(oracle.pyr_down_16s(one), ((_down_taps(one) + 128) >> 8).astype(np.int16))
+
+
+@pytest.mark.parametrize("shape", [(64, 96), (33, 47), (2, 2), (5, 4)])
+def test_pyr_down_32f_equals_mirror_correlation(oracle, shape):
+    """The weight pyramid (fp32): whatever order OpenCV adds the 25 products in, the result is the float64 value up to a few fp32
+    roundings; on 0 / 1 weights (warped masks scaled by 1 / 255 are 0.f or 1.f) the first levels are EXACT in any order."""
+    rng = np.random.default_rng(7 + shape[0])
+    k = np.array([1, 4, 6, 4, 1], np.float64)
+    for binary in (True, False):
+        src = (rng.random(shape) < 0.6).astype(np.float32) if binary else rng.random(shape).astype(np.float32)
+        t = ndimage.correlate1d(src.astype(np.float64), k, axis=0, mode="mirror")
+        ref = ndimage.correlate1d(t, k, axis=1, mode="mirror")[::2, ::2] / 256.0
+        ours = oracle.pyr_down_32f(src)
+        if binary:
+            assert np.array_equal(ours.astype(np.float64), ref)  # multiples of 1/256 below 1: exact
+        else:
+            assert np.abs(ours - ref).max() <= 4 * np.finfo(np.float32).eps
+
+
+def _up_axis(a, axis):
+    """pyrUp along one axis, as zero-stuffing + [1 4 6 4 1]: out[2x] = s[x-1] + 6 s[x] + s[x+1], out[2x+1] = 4 (s[x] + s[x+1])
+    with OpenCV's border rule stated as padding: s[-1] = s[1] (reflect-101; s[0] when there is one sample), s[n] = s[n-1]."""
+    a = np.moveaxis(a.astype(np.int64), axis, 0)
+    n = a.shape[0]
+    left = a[1:2] if n > 1 else a[0:1]
+    ext = np.concatenate([left, a, a[n - 1:n]], axis=0)
+    z = np.zeros((2 * (n + 2),) + a.shape[1:], np.int64)
+    z[::2] = ext
+    t = ndimage.correlate1d(z, np.array([1, 4, 6, 4, 1], np.int64), axis=0, mode="constant", cval=0)
+    return np.moveaxis(t[2:2 + 2 * n], 0, axis)
+
+
+@pytest.mark.parametrize("shape", [(32, 48), (17, 23), (1, 1), (1, 7), (6, 1), (2, 2)])
+def test_pyr_up_16s_equals_zero_stuffing(oracle, shape):
+    rng = np.random.default_rng(31 * shape[0] + shape[1])
+    src = rng.integers(-3000, 3000, shape + (3,)).astype(np.int16)
+    ref = (_up_axis(_up_axis(src, 0), 1) + 32) >> 6
+    assert np.array_equal(oracle.pyr_up_16s(src), ref.astype(np.int16))
+
+
+def test_laplacian_pyramid_collapses_back(oracle):
+    """createLaplacePyr / restoreImageFromLaplacePyr as the blender uses them, built from the two independent formulations above:
+    L_i = G_i - up(G_{i+1}) and the collapse G_i = L_i + up(G_{i+1}) reproduce G_0 exactly while nothing saturates."""
+    rng = np.random.default_rng(5)
+    g = [rng.integers(0, 256, (64, 96, 3)).astype(np.int16)]
+    for _ in range(3):
+        g.append(oracle.pyr_down_16s(g[-1]))
+    lap = [g[i].astype(np.int32) - oracle.pyr_up_16s(g[i + 1]) for i in range(3)] + [g[3].astype(np.int32)]
+    assert max(np.abs(l).max() for l in lap) < 32768
+    cur = lap[3].astype(np.int16)
+    for i in (2, 1, 0):
+        cur = (oracle.pyr_up_16s(cur).astype(np.int32) + lap[i]).astype(np.int16)
+    assert np.array_equal(cur, g[0])
+
+
+# ------------------------------------------------------------------------------------------------ projector
+def _closed_form_backward(warper_type, scale, K, R, u, v):
+    """ProjectorBase::mapBackward in float64 from the fp32 K, R (warpers_inl.hpp): (u, v) -> (x, y) source pixel."""
+    K, R = K.astype(np.float64), R.astype(np.float64)
+    k_rinv = K @ R.T
+    u, v = u.astype(np.float64) / scale, v.astype(np.float64) / scale
+    if warper_type == "spherical":
+        sinv = np.sin(np.pi - v)
+        d = np.stack([sinv * np.sin(u), np.cos(np.pi - v), sinv * np.cos(u)])
+    elif warper_type == "cylindrical":
+        d = np.stack([np.sin(u), v, np.cos(u)])
+    else:  # plane, t = 0
+        d = np.stack([u, v, np.ones_like(u)])
+    p = np.tensordot(k_rinv, d, axes=1)
+    return p[0] / p[2], p[1] / p[2], p[2]
+
+
+@pytest.mark.parametrize("warper_type", ["spherical", "cylindrical", "plane"])
+@pytest.mark.parametrize("which", ["config2", "pitched56"])
+def test_map_backward_against_float64_closed_form(oracle, warper_type, which):
+    """The fp32 maps the reference hands to cv.remap (stitching/warper.py:44-51) against the closed form in float64.  A chain of ~20
+    fp32 roundings cannot be within 1 ULP of the real value; the bound asserted is what that chain allows: the absolute error of a
+    coordinate stays below 1/32 px (remap's own quantum), measured here at <= 2e-3 px for |x| < 8000, i.e. <= 8 ULP of the largest
+    magnitude involved.  The "1 ULP" contract of the north star is the HIP <-> oracle comparison of the same fp32 chain
+    (tests/test_gpu_maps.py: 0 ULP)."""
+    w, h = 4000, 3000
+    if which == "config2":
+        cam = synthetic.ring_cameras(8, w, h)[4 if warper_type == "plane" else 5]  # a plane roi explodes towards 90 degrees of yaw
+    else:
+        cam = synthetic.grid_cameras(8, 4, w, h)[4 * 3 + 3]  # a +56 degree row of config 3
+        if warper_type != "spherical":
+            cam = synthetic.grid_cameras(16, 4, w, h, max_edge_lat_deg=50.0)[4 * 9 + 3]
+    K = oracle.Warper.get_K(cam)
+    scale = 0.75 * w
+    roi = oracle.warp_roi(warper_type, scale, K, cam.R, (w, h))
+    # a 97 x 89 lattice over the whole roi (every pixel of two rows and two columns included through the strides)
+    ys = np.unique(np.linspace(0, roi[3] - 1, 89).astype(int))
+    xs = np.unique(np.linspace(0, roi[2] - 1, 97).astype(int))
+    rows = [oracle.build_maps(warper_type, scale, K, cam.R, (roi[0], roi[1] + int(y), roi[2], 1)) for y in ys]  # whole rows, one at a time
+    xm, ym = np.concatenate([r[0] for r in rows]), np.concatenate([r[1] for r in rows])
+    uu, vv = np.meshgrid((roi[0] + xs).astype(np.float32), (roi[1] + ys).astype(np.float32))
+    rx, ry, rz = _closed_form_backward(warper_type, scale, K, np.asarray(cam.R, np.float32), uu, vv)
+    gx, gy = xm[:, xs], ym[:, xs]
+    front = rz > 1e-3 if warper_type != "plane" else np.ones_like(rz, bool)
+    near = front & (np.abs(rx) < 8000) & (np.abs(ry) < 8000)
+    assert near.mean() > 0.5
+    ex, ey = np.abs(gx - rx)[near].max(), np.abs(gy - ry)[near].max()
+    ulp = np.spacing(np.float32(8000.0))
+    assert ex <= 8 * ulp and ey <= 8 * ulp, (ex, ey)
+    if warper_type != "plane":  # rays behind the camera map to (-1, -1)
+        back = rz < -1e-3
+        assert np.all(gx[back] == -1) and np.all(gy[back] == -1)
+
+
+# ------------------------------------------------------------------------------------------------ remap
+def _quantise(v):
+    """cvRound(v * 32) as remap does it: fp32 product, round half to even"""
+    return np.rint(v.astype(np.float32) * np.float32(32)).astype(np.int64)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_remap_linear_reflect_against_map_coordinates(oracle, seed):
+    rng = np.random.default_rng(40 + seed)
+    sh, sw = int(rng.integers(9, 80)), int(rng.integers(9, 100))
+    src = synthetic.make_frame(seed, sw, sh)
+    h, w = 61, 83
+    # positions from well outside (several mirror images away) to inside, smooth + jitter
+    xmap = (np.linspace(-2.3 * sw, 3.1 * sw, w)[None, :] + rng.uniform(-3, 3, (h, w))).astype(np.float32)
+    ymap = (np.linspace(-1.7 * sh, 2.9 * sh, h)[:, None] + rng.uniform(-3, 3, (h, w))).astype(np.float32)
+    ours = oracle.remap_linear(src, xmap, ymap).astype(np.int64)
+    qx, qy = _quantise(xmap) / 32.0, _quantise(ymap) / 32.0
+    exact = np.stack([ndimage.map_coordinates(src[:, :, c].astype(np.float64), [qy, qx], order=1, mode="reflect") for c in range(3)], axis=2)
+    # at the quantised position the Q15 table weights are exact: the fixed-point result is floor(exact + 1/2)
+    assert np.array_equal(ours, np.floor(exact + 0.5).astype(np.int64))
+    assert np.abs(ours - np.rint(exact)).max() <= 1
+    # at the unquantised position: within the change of the bilinear surface over 1/64 px per axis, + the rounding
+    true = np.stack([ndimage.map_coordinates(src[:, :, c].astype(np.float64), [ymap.astype(np.float64), xmap.astype(np.float64)],
+                                             order=1, mode="reflect") for c in range(3)], axis=2)
+    assert np.abs(ours - true).max() <= 255 * (2 / 64) + 0.5 + 1e-9
+    assert np.mean(np.abs(ours - true)) < 1.0
+
+
+def test_remap_nearest_constant_against_map_coordinates(oracle):
+    rng = np.random.default_rng(3)
+    sh, sw = 40, 56
+    src = rng.integers(1, 256, (sh, sw)).astype(np.uint8)
+    xmap = rng.uniform(-20, sw + 20, (50, 70)).astype(np.float32)
+    ymap = rng.uniform(-20, sh + 20, (50, 70)).astype(np.float32)
+    ours = oracle.remap_nearest(src, xmap, ymap)
+    ix, iy = np.rint(xmap).astype(np.int64), np.rint(ymap).astype(np.int64)
+    ref = ndimage.map_coordinates(src, [iy, ix], order=0, mode="constant", cval=0)
+    assert np.array_equal(ours, ref)
+
+
+def test_bilinear_tab_is_the_outer_product(oracle):
+    """initInterTab2D(INTER_LINEAR, fixpt): 32 x 32 entries of 4 Q15 weights = round(outer((1 - fy, fy), (1 - fx, fx)) * 32768);
+    every product is a multiple of 32, so no entry needs the table's sum-to-32768 fix-up except the (0, 0) one that saturates."""
+    t = oracle.bilinear_tab().astype(np.int64).reshape(32, 32, 4)
+    f = np.arange(32) / 32.0
+    wy, wx = np.stack([1 - f, f], 1), np.stack([1 - f, f], 1)
+    ref = np.rint(np.einsum("ya,xb->yxab", wy, wx) * 32768).reshape(32, 32, 4).astype(np.int64)
+    assert np.array_equal(t.sum(axis=2), np.full((32, 32), 32768))
+    d = t - ref
+    assert np.count_nonzero(d) <= 2 and np.abs(d).max() <= 1  # (0, 0): 32768 does not fit a short -> 32767 + 1 elsewhere
