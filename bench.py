@@ -117,6 +117,19 @@ def workload(args, world):
         cams = synthetic.grid_cameras(2 * world, 4, W, H, max_edge_lat_deg=50.0, layout_yaw=16)
         name = (f"BASELINE config 4{'' if world == 8 else ' family'}: {n_total} synthetic {W}x{H} frames = {2 * world} of 16 yaw columns x 4 "
                 f"pitch rows (f = 0.75 W), two columns per GPU")
+    if w["warper"] != "affine" and len(cams) > 1:
+        # the geometry in numbers (it is NOT SURVEY 8(d)'s 0.70 hfov = 47 degree step: a ring of 8 such frames, and all the more the
+        # +-56 degree rows of config 3, would cross the +-180 degree seam of the parametrisation — DESIGN.md section 6)
+        import math
+
+        import numpy as np
+
+        yaw = lambda c: math.degrees(math.atan2(float(np.asarray(c.R)[0, 2]), float(np.asarray(c.R)[2, 2])))  # noqa: E731
+        rows = 1 if cfg == 2 else 4
+        step = abs(yaw(cams[rows]) - yaw(cams[0])) if len(cams) > rows else 0.0
+        hfov = 2.0 * math.degrees(math.atan(W / (2.0 * float(cams[0].focal))))
+        if step > 0:
+            name += f"; yaw step {step:.1f} deg = {step / hfov:.2f} hfov ({100 * (1 - step / hfov):.0f} % overlap; SURVEY 8(d) names 0.70 hfov)"
     w.update(cams=cams, n_total=n_total, name=name)
     return w
 
@@ -250,8 +263,7 @@ def sharded_parity(job, dist, rank, world, wl, all_cams):
     from stitching_amd import synthetic
 
     band, bmask = (np.asarray(a) for a in job.run())
-    parts = [None] * world if rank == 0 else None
-    dist.gather_object((band, bmask), parts, dst=0)
+    parts = dist.gather((band, bmask), 0)
     if rank != 0:
         return None
     t0 = time.perf_counter()
@@ -322,10 +334,22 @@ def main():
         sys.exit(2)
     dist = None
     if world > 1:
-        import torch.distributed as dist_mod
+        # Control plane = the product's own TCP rendezvous (stitching_amd/rendezvous.py).  Its port: STITCHING_AMD_RDZV_PORT when the
+        # launcher exports one; under torch.distributed.run (the driver's launcher — MASTER_PORT belongs to its store) rank 0 picks a
+        # free port and the launcher's gloo group carries that one integer, then torch is out of the picture.
+        from stitching_amd.rendezvous import TcpGroup, free_port
 
-        dist = dist_mod
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        port = os.environ.get("STITCHING_AMD_RDZV_PORT")
+        if port is None:
+            import torch.distributed as tdist
+
+            tdist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            box = [free_port() if rank == 0 else None]
+            tdist.broadcast_object_list(box, src=0)
+            tdist.barrier()
+            tdist.destroy_process_group()
+            port = box[0]
+        dist = TcpGroup(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), int(port))
 
     import numpy as np
 
@@ -344,7 +368,7 @@ def main():
         dev = local_rank % max(1, ndev)
         shared = world > ndev
     if shared and world > 1:
-        os.environ.setdefault("STITCHING_AMD_TRANSPORT", "gloo")
+        os.environ.setdefault("STITCHING_AMD_TRANSPORT", "host")
     S.set_default_device(dev)
     ctx = S.get_context()
 
@@ -362,7 +386,7 @@ def main():
             # split: the pyramids of the rank's own images are built while its strips travel (measured on one rank of the
             # 8-rank config-3 job, tools/sim_rank.py: 1.03 ms per step against 1.34 ms with everything built after the exchange)
             return ShardedStitchJob(frames_, cams, all_cams, rank, world, warper_type=wl["warper"], blender_type=wl["blender"],
-                                    num_bands=nb, ctx=c, dist=dist, split_boundary=True,
+                                    num_bands=nb, ctx=c, group=dist, split_boundary=True,
                                     transport=(jobs[0].transport if jobs else None))
         j = StitchJob(frames_, cams, warper_type=wl["warper"], blender_type=wl["blender"], num_bands=nb, ctx=c)
         j.warper.set_scale(all_cams)
@@ -387,13 +411,7 @@ def main():
             dist.barrier()
 
     def reduce_max(dt):
-        if dist is None:
-            return dt
-        import torch
-
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+        return dt if dist is None else dist.all_reduce_max(dt)
 
     def run_step(i):
         out = jobs[i % len(jobs)].run()
@@ -431,7 +449,7 @@ def main():
     if rank != 0:
         if dist is not None:
             dist.barrier()
-            dist.destroy_process_group()
+            dist.close()
         return
 
     src_mpix = n_total * W * H / 1e6
@@ -445,14 +463,14 @@ def main():
     avg_ms = dom["total_ms"] / dom["calls"]
     bytes_per_launch = dom["algo_bytes"] / dom["calls"]
     achieved = bytes_per_launch / (avg_ms / 1e3) / 1e9
-    traffic = None
+    traffic, traffic_of = None, {}
     khash = kernel_source_hash()
     if args.traffic_json and os.path.exists(args.traffic_json):
         tj = json.load(open(args.traffic_json))
-        t = tj.get(dom["kernel"])
-        # per-launch PMC bytes of the same kernel on the same workload AND the same kernel sources; anything else: null
-        if t and tj.get("kernel_source_hash") == khash and tj.get("workload_cfg", 2) == wl["cfg"] and world == 1:
-            traffic = round(t["traffic_bytes"])
+        # per-launch PMC bytes of the same kernels on the same workload AND the same kernel sources; anything else: null
+        if tj.get("kernel_source_hash") == khash and tj.get("workload_cfg", 2) == wl["cfg"] and world == 1:
+            traffic_of = {k: round(v["traffic_bytes"]) for k, v in tj.items() if isinstance(v, dict) and "traffic_bytes" in v}
+            traffic = traffic_of.get(dom["kernel"])
     roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_launch_us": round(avg_ms * 1e3, 2), "algo_bytes_per_launch": round(bytes_per_launch),
@@ -483,11 +501,15 @@ def main():
         "kernels": [{"kernel": k["kernel"], "calls_per_step": k["calls"] / max(1, args.profile_steps),
                      "avg_us": round(k["total_ms"] / k["calls"] * 1e3, 2),
                      "algo_GBps": round(k["algo_bytes"] / max(k["total_ms"], 1e-9) / 1e6, 1),
-                     "frac_of_hbm_peak": round(k["algo_bytes"] / max(k["total_ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4)} for k in kernels],
+                     "frac_of_hbm_peak": round(k["algo_bytes"] / max(k["total_ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
+                     "algo_bytes_per_launch": round(k["algo_bytes"] / k["calls"]),
+                     "traffic": traffic_of.get(k["kernel"])} for k in kernels],
         "all_kernels": {"sum_ms_per_step": round(ksum / max(1, args.profile_steps), 4),
                         "algo_GBps": round(kbytes / max(ksum, 1e-9) / 1e6, 1),
                         "frac_of_hbm_peak": round(kbytes / max(ksum, 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
-                        "note": "bytes the fused kernels move (algorithmic, per kernel) / summed kernel time: the bandwidth fraction of the path"},
+                        "note": "bytes the fused kernels move (algorithmic, per kernel) / summed kernel time: the bandwidth fraction of the path; "
+                                "kernels[].traffic = HBM bytes per launch from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, mean over the launches "
+                                "of that name), null unless the profile was taken on these very kernel sources"},
     }
     if parity_n is not None:
         result["parity"] = parity_n
@@ -529,6 +551,9 @@ def main():
         lats.sort()
         result["latency_ms_single_stream"] = {"median": round(lats[len(lats) // 2] * 1e3, 4), "min": round(lats[0] * 1e3, 4),
                                               "max": round(lats[-1] * 1e3, 4), "panoramas": len(lats)}
+        # SURVEY 8(d) words the metric as "first warp launch -> panorama resident": that is this number; `value` is the throughput of
+        # a stream of panoramas (--streams in flight)
+        result["value_single_stream"] = round(src_mpix / lats[len(lats) // 2], 1)
     if world == 1 and not args.no_extra:
         result["extra"] = extra_legs(args, S, synthetic, StitchJob, ctxs, wl, jobs[0], all_cams)
     if world == 1 and args.e2e_steps > 0:
@@ -550,7 +575,7 @@ def main():
     print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        dist.close()
 
 
 def quick_rate(jobs, ctxs, mpix, steps=6, warmup=2, min_seconds=0.25):

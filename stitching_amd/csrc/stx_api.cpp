@@ -211,7 +211,7 @@ static hipEvent_t take_event(stx_ctx* ctx)
     return e;
 }
 
-StxProfScope::StxProfScope(stx_ctx* c, const char* name, double algo_bytes) : ctx(c)
+StxProfScope::StxProfScope(stx_ctx* c, const char* name, double algo_bytes, hipStream_t on) : ctx(c), stream(on ? on : c->stream)
 {
     if (!ctx->prof_on) return;
     auto it = ctx->prof_index.find(name);
@@ -230,20 +230,21 @@ StxProfScope::StxProfScope(stx_ctx* c, const char* name, double algo_bytes) : ct
     pe.start = take_event(ctx);
     pe.stop = take_event(ctx);
     pe.entry = idx;
-    hipEventRecord(pe.start, ctx->stream);
+    hipEventRecord(pe.start, stream);
     ctx->prof_pending.push_back(pe);
     pending = (int)ctx->prof_pending.size() - 1;
 }
 
 StxProfScope::~StxProfScope()
 {
-    if (pending >= 0) hipEventRecord(ctx->prof_pending[pending].stop, ctx->stream);
+    if (pending >= 0) hipEventRecord(ctx->prof_pending[pending].stop, stream);
 }
 
 static void prof_collect(stx_ctx* ctx)
 {
     if (ctx->prof_pending.empty()) return;
     hipStreamSynchronize(ctx->stream);
+    hipStreamSynchronize(ctx->aux_stream);  // the ROI pass is bracketed on the side stream it runs on
     for (auto& pe : ctx->prof_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) ctx->prof[pe.entry].total_ms += ms;
@@ -1277,6 +1278,43 @@ STX_EXPORT int stx_warp_mask(stx_ctx* ctx, int type, float scale, const float K[
     return warp_impl(ctx, type, scale, K, R, nullptr, w, h, false, true, false, nullptr, out_mask, out_xywh);
 }
 
+STX_EXPORT int stx_debug_feather_dist_cap(void) { return STX_FEATHER_DIST_CAP; }
+
+// Test hook (include/stitching_amd_debug.h): the fp32 backward map of a warp as the device projector computes it.
+STX_EXPORT int stx_debug_warp_maps(stx_ctx* ctx, int type, float scale, const float K[9], const float R[9], int w, int h, int which,
+                                   const int rect_xywh[4], stx_buf** out_xmap, stx_buf** out_ymap, int out_xywh[4])
+{
+    if (!ctx || !K || !R || !out_xmap || !out_ymap) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (w <= 0 || h <= 0) return stx_fail(STX_ERR_INVALID, "image size %dx%d", w, h);
+    if (which != 1 && which != 2) return stx_fail(STX_ERR_INVALID, "which = %d (1: the kernel a warp takes, 2: the generic kernel)", which);
+    STX_TRY(stx_set_device(ctx));
+    StxProjector p;
+    STX_TRY(stx_make_projector(type, scale, K, R, &p));
+    int roi[4];
+    if (rect_xywh) memcpy(roi, rect_xywh, 16);
+    else STX_TRY(roi_cached(ctx, type, scale, K, R, w, h, p, roi));
+    if (roi[2] <= 0 || roi[3] <= 0 || (long long)roi[2] * roi[3] > (1ll << 30))
+        return stx_fail(STX_ERR_INVALID, "degenerate warp roi %dx%d", roi[2], roi[3]);
+    stx_buf *bx = nullptr, *by = nullptr;
+    STX_TRY(stx_buf_new(ctx, roi[2], roi[3], 1, STX_F32, &bx));
+    int rc = stx_buf_new(ctx, roi[2], roi[3], 1, STX_F32, &by);
+    if (rc != STX_OK) { stx_buf_release(bx); return rc; }
+    StxWarpLaunch L;
+    L.proj = p;
+    L.tlx = roi[0]; L.tly = roi[1]; L.dw = roi[2]; L.dh = roi[3];
+    L.src = nullptr; L.sw = w; L.sh = h; L.sstride = 0; L.src_channels = 0;
+    L.nearest_src = 0;
+    L.dimg = bx->ptr; L.dimg_stride = bx->stride;
+    L.dmask = by->ptr; L.dmask_stride = by->stride;
+    L.debug_maps = which;
+    rc = stx_launch_warp(ctx, L);
+    if (rc != STX_OK) { stx_buf_release(bx); stx_buf_release(by); return rc; }
+    *out_xmap = bx;
+    *out_ymap = by;
+    if (out_xywh) memcpy(out_xywh, roi, 16);
+    return STX_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // blenders
 // ---------------------------------------------------------------------------------------------
@@ -1310,6 +1348,8 @@ struct stx_blender {
     std::vector<void*> pyr_allocs;
     int band_x0 = 0, band_x1 = 0;     // columns of the final roi this blender produces (sharded blending)
     int next_order = 0;
+    int pyr_mode = 0;                 // STX_PYRDOWN_* | lanes << 8, captured at stx_blend_create: one summation order per panorama
+                                      // whatever stx_set_pyrdown_mode is called with between feed() and blend()
     // no: deferred gather over the fed images (stx_launch_no_gather)
     std::vector<NoImg> no_images;
     // feather: deferred gather as well (stx_launch_feather_weights / _gather)
@@ -1356,6 +1396,7 @@ STX_EXPORT int stx_blend_create(stx_ctx* ctx, int kind, int num_bands, float sha
     }
     b->rx = roi_xywh[0]; b->ry = roi_xywh[1]; b->rw = w; b->rh = h;
     b->band_x0 = 0; b->band_x1 = b->fw;
+    b->pyr_mode = pyrdown_now();
     *out = b.release();
     return STX_OK;
 }
@@ -1514,7 +1555,7 @@ static int mb_ensure_pyramids(stx_blender* b)
     // occupancy maps of the weight pyramids (StxMbImage::occ): one arena for this batch.  Only where every level is built by
     // the batched LDS kernels, which write them (int16 sources take the generic level-0 kernel).
     static const bool occ_off = getenv("STITCHING_AMD_NO_OCC") != nullptr;  // diagnostic: A/B of the bookkeeping
-    const int pyr = pyrdown_now();  // != scalar: the generic kernels build every level, and they keep no occupancy maps
+    const int pyr = b->pyr_mode;  // (the blender's own, fixed at creation) != scalar: the generic kernels build every level, and they keep no occupancy maps
     if (todo.size() <= 65535 && !occ_off && (pyr & 255) == STX_PYRDOWN_SCALAR) {
         const int nl = b->num_bands + 1;
         std::vector<size_t> off(todo.size() * (size_t)nl, 0);

@@ -736,7 +736,7 @@ __global__ __launch_bounds__(64) void dt_col_fill_batch_kernel(const FeatherImg*
                 const uint32_t t = (hf ? hi[j] : lo[j]) >> rr;  // the zero rows of this half from this one on
                 up[j] = (t & 1u) ? 0 : min(up[j] + 1, DT_INF);
                 const int dn = t ? (int)__builtin_ctz(t) : (hf ? far1[j] : far0[j]) - r;
-                o[j] = x + j < P.w ? (uint32_t)min(min(up[j], dn), 8192) : 8192u;  // the row pass reads whole 8-pixel groups
+                o[j] = x + j < P.w ? (uint32_t)min(min(up[j], dn), STX_FEATHER_DIST_CAP) : (uint32_t)STX_FEATHER_DIST_CAP;  // the row pass reads whole 8-pixel groups
             }
             *reinterpret_cast<uint2*>(P.dist + (long long)y * P.dstride + x) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
         }
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(256) void dt_rows_batch_kernel(const FeatherImg* __
         for (int j = 6; j >= 0; j--) v[j] = min(v[j] + j, v[j + 1]);
         const int after = min(carry, wave_excl_prefix_min(v[0] + x0)) - x0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = min(min(v[j], after) - j, 8192);
+        for (int j = 0; j < 8; j++) v[j] = min(min(v[j], after) - j, STX_FEATHER_DIST_CAP);
         carry = __builtin_amdgcn_readlane(v[0] + x0, 63);  // the leftmost group of the step (before the saturation matters: see below)
         if (x0 < wpad) *reinterpret_cast<uint4*>(row + x0) = dt_pack8(v);
     }

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/stitching_amd.h"
+#include "../../include/stitching_amd_debug.h"
 
 #define STX_EXPORT extern "C" __attribute__((visibility("default")))
 #define STX_MAX_BANDS 16
@@ -96,7 +97,8 @@ int stx_set_device(stx_ctx* ctx);
 struct StxProfScope {
     stx_ctx* ctx;
     int pending = -1;
-    StxProfScope(stx_ctx* c, const char* name, double algo_bytes);
+    hipStream_t stream;  // the stream the bracketed kernel is launched on (default: the context's main stream)
+    StxProfScope(stx_ctx* c, const char* name, double algo_bytes, hipStream_t on = nullptr);
     ~StxProfScope();
 };
 
@@ -147,6 +149,7 @@ struct StxWarpLaunch {
     uint8_t* dimg; size_t dimg_stride;    // u8x3 or null
     uint8_t* dmask; size_t dmask_stride;  // u8x1 or null
     int nearest_src;               // 1: out image = nearest sample of a u8x1 source (generic mask warp)
+    int debug_maps = 0;            // stx_debug_warp_maps (test hook): dimg / dmask are f32 maps of x / y; 1: the kernel a warp would take, 2: the generic one
 };
 int stx_launch_warp(stx_ctx* ctx, const StxWarpLaunch& L);
 int stx_launch_warp_batch(stx_ctx* ctx, const StxWarpLaunch* Ls, int n);
@@ -197,6 +200,9 @@ int stx_launch_strip_pack(stx_ctx* ctx, int n, const stx_buf* const* imgs, const
                           stx_buf* const* dsts, const size_t* si, const size_t* sm, bool mask_bits);
 int stx_launch_strip_bits_expand(stx_ctx* ctx, int n, const uint8_t* const* bits, const size_t* sm, stx_buf* const* masks);
 
+// saturation of the L1 distance transform (OpenCV's 16.16 fixed point clamps at INT_MAX >> 2 = 8192.0f): the kernels clamp to it, the
+// sharded feather blender sizes its halo by it (stx_debug_feather_dist_cap -> distributed.FEATHER_DIST_CAP, checked by a host test)
+constexpr int STX_FEATHER_DIST_CAP = 8192;
 constexpr int STX_DT_RC = 64;  // rows per chunk of the distance transform's column pass (stx_blend.hip: DT_RC)
 // feather blender as a deferred gather: device table of the fed images, in feed order
 struct FeatherImg {

@@ -201,7 +201,9 @@ __global__ __launch_bounds__(256) void warp_tables_kernel(WarpBatchK B)
 }
 
 // One lane = 4 adjacent destination pixels of one row; one wave = 256 px of a row; block = 4 rows.
-template <int TYPE, bool IMG, bool MASK>
+// DBG (stx_debug_warp_maps, a test hook): instead of sampling, the fp32 (x, y) of every destination pixel — what buildMaps would have
+// stored — go to two float images (P.dimg = x map, P.dmask = y map; strides in bytes).
+template <int TYPE, bool IMG, bool MASK, bool DBG = false>
 __global__ __launch_bounds__(256) void warp_kernel(WarpK P, const float2* __restrict__ colT, const float4* __restrict__ rowT)
 {
     const int lane = threadIdx.x & 63;
@@ -251,6 +253,13 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpK P, const float2* __rest
             } else {
                 x = yy = -1.f;
             }
+        }
+        if (DBG) {
+            if (x0 + j < P.dw) {
+                reinterpret_cast<float*>(P.dimg + (long long)y * P.dimg_stride)[x0 + j] = x;
+                reinterpret_cast<float*>(P.dmask + (long long)y * P.dmask_stride)[x0 + j] = yy;
+            }
+            continue;
         }
         if (IMG && P.remap != STX_REMAP_Q15) {
             put_px(out, j, sample_float(P.src, P.sstride, P.sw, P.sh, P.remap == STX_REMAP_FLOAT_FMA, x, yy));
@@ -433,7 +442,7 @@ STX_DEV int periodic_axis(int s, int n, int period, float inv_period, int bias)
     return (int)r - 32 * n;
 }
 
-template <int TYPE, bool IMG, bool MASK>
+template <int TYPE, bool IMG, bool MASK, bool DBG = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void warp_fast_kernel(WarpBatchK B)
 {
     const WarpK& P = B.k[blockIdx.z];
@@ -580,6 +589,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 }
             }
         }
+    }
+    if (DBG) {
+        // test hook: the quotients as they stand — the (x, y) mapBackward returns — instead of the samples they select
+        const int col = xw + lane;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (col < dw && y0 + j < dh) {
+                reinterpret_cast<float*>((uint8_t*)dimg_a + (long long)(y0 + j) * dimg_stride)[col] = (j & 1) ? X[j >> 1].y : X[j >> 1].x;
+                reinterpret_cast<float*>((uint8_t*)dmask_a + (long long)(y0 + j) * dmask_stride)[col] = (j & 1) ? Y[j >> 1].y : Y[j >> 1].x;
+            }
+        }
+        continue;
     }
     // 32 x, 32 y (exact) and their cvRound as bit patterns
     uint32_t ux[4], uy[4];
@@ -804,7 +825,7 @@ STX_DEV void gen_dir(const WarpK& P, const float4 c, const float2 r, float& x_, 
     if (P.family == STX_F_CRECT_PORTRAIT || P.family == STX_F_PANINI_PORTRAIT) { const float t = x_; x_ = y_; y_ = t; }
 }
 
-template <int G, bool IMG, bool MASK>
+template <int G, bool IMG, bool MASK, bool DBG = false>
 __global__ __launch_bounds__(256) void warp_general_kernel(WarpK P)
 {
     __shared__ float4 s_col[WARP_TW];
@@ -834,6 +855,13 @@ __global__ __launch_bounds__(256) void warp_general_kernel(WarpK P)
                 yy = fdiv(yy, z);
             } else {
                 x = yy = -1.f;
+            }
+            if (DBG) {
+                if (x0 + j < P.dw) {
+                    reinterpret_cast<float*>(P.dimg + (long long)y * P.dimg_stride)[x0 + j] = x;
+                    reinterpret_cast<float*>(P.dmask + (long long)y * P.dmask_stride)[x0 + j] = yy;
+                }
+                continue;
             }
             if (IMG) put_px(out, j, sample_generic(P, x, yy));
             if (MASK) {
@@ -989,7 +1017,7 @@ bool fast_ok(const WarpK& K)
 }
 
 template <int TYPE>
-int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, const char* prof_name, const double* algo_bytes)
+int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, const char* prof_name, const double* algo_bytes, int dbg)
 {
     hipStream_t s = ctx->stream;
     // per-column / per-row trig tables (a few KB per image, L2 resident), one allocation for the batch, freed in stream order
@@ -1023,7 +1051,7 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
             max_tab = std::max(max_tab, K.dw + ((K.dh + 3) & ~3));
             gx = std::max(gx, (K.dw + WARP_TW - 1) / WARP_TW);
             gy = std::max(gy, (K.dh + WARP_TH - 1) / WARP_TH);
-            fast = fast && fast_ok(K);
+            fast = fast && fast_ok(K) && dbg != 2;
             tab_bytes += (double)K.dw * sizeof(float2) + (double)K.dh * 5 * sizeof(float);
             bytes += algo_bytes[base + i];
         }
@@ -1043,7 +1071,8 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
             // STITCHING_AMD_WARP_LDS (diagnostic): bytes of dynamic LDS requested on top of the kernel's own — an occupancy limit
             // (160 KB per CU / request = workgroups per CU) for co-residency experiments with the other panorama's kernels
             static const unsigned pad_lds = getenv("STITCHING_AMD_WARP_LDS") ? (unsigned)atoi(getenv("STITCHING_AMD_WARP_LDS")) : 0u;
-            if (img && mask) hipLaunchKernelGGL((warp_fast_kernel<TYPE, true, true>), gf, dim3(256), pad_lds, s, B);
+            if (dbg) hipLaunchKernelGGL((warp_fast_kernel<TYPE, false, false, true>), gf, dim3(256), 0, s, B);
+            else if (img && mask) hipLaunchKernelGGL((warp_fast_kernel<TYPE, true, true>), gf, dim3(256), pad_lds, s, B);
             else if (img) hipLaunchKernelGGL((warp_fast_kernel<TYPE, true, false>), gf, dim3(256), pad_lds, s, B);
             else hipLaunchKernelGGL((warp_fast_kernel<TYPE, false, true>), gf, dim3(256), pad_lds, s, B);
         } else {
@@ -1051,7 +1080,8 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
                 StxProfScope prof(ctx, prof_name, algo_bytes[base + i]);
                 const WarpK& K = B.k[i];
                 const dim3 grid((K.dw + WARP_TW - 1) / WARP_TW, (K.dh + WARP_TH - 1) / WARP_TH);
-                if (img && mask) hipLaunchKernelGGL((warp_kernel<TYPE, true, true>), grid, dim3(256), 0, s, K, B.colT[i], B.rowT[i]);
+                if (dbg) hipLaunchKernelGGL((warp_kernel<TYPE, false, false, true>), grid, dim3(256), 0, s, K, B.colT[i], B.rowT[i]);
+                else if (img && mask) hipLaunchKernelGGL((warp_kernel<TYPE, true, true>), grid, dim3(256), 0, s, K, B.colT[i], B.rowT[i]);
                 else if (img) hipLaunchKernelGGL((warp_kernel<TYPE, true, false>), grid, dim3(256), 0, s, K, B.colT[i], B.rowT[i]);
                 else hipLaunchKernelGGL((warp_kernel<TYPE, false, true>), grid, dim3(256), 0, s, K, B.colT[i], B.rowT[i]);
             }
@@ -1065,27 +1095,28 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
 
 // per-pixel projector warpers: one launch per image
 template <int G>
-void launch_general_group(stx_ctx* ctx, const WarpK& K, bool img, bool mask)
+void launch_general_group(stx_ctx* ctx, const WarpK& K, bool img, bool mask, int dbg)
 {
     const dim3 grid((K.dw + WARP_TW - 1) / WARP_TW, (K.dh + GEN_TH - 1) / GEN_TH);
-    if (img && mask) hipLaunchKernelGGL((warp_general_kernel<G, true, true>), grid, dim3(256), 0, ctx->stream, K);
+    if (dbg) hipLaunchKernelGGL((warp_general_kernel<G, false, false, true>), grid, dim3(256), 0, ctx->stream, K);
+    else if (img && mask) hipLaunchKernelGGL((warp_general_kernel<G, true, true>), grid, dim3(256), 0, ctx->stream, K);
     else if (img) hipLaunchKernelGGL((warp_general_kernel<G, true, false>), grid, dim3(256), 0, ctx->stream, K);
     else hipLaunchKernelGGL((warp_general_kernel<G, false, true>), grid, dim3(256), 0, ctx->stream, K);
 }
 
-int launch_general(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, const char* prof_name, const double* algo_bytes)
+int launch_general(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, const char* prof_name, const double* algo_bytes, int dbg)
 {
     for (int i = 0; i < n; i++) {
         StxProfScope prof(ctx, prof_name, algo_bytes[i]);
         const WarpK& K = Ks[i];
         switch (K.family) {
         case STX_F_FISHEYE:
-        case STX_F_STEREOGRAPHIC: launch_general_group<GEN_FISH>(ctx, K, img, mask); break;
+        case STX_F_STEREOGRAPHIC: launch_general_group<GEN_FISH>(ctx, K, img, mask, dbg); break;
         case STX_F_CRECT:
-        case STX_F_CRECT_PORTRAIT: launch_general_group<GEN_CRECT>(ctx, K, img, mask); break;
+        case STX_F_CRECT_PORTRAIT: launch_general_group<GEN_CRECT>(ctx, K, img, mask, dbg); break;
         case STX_F_PANINI:
-        case STX_F_PANINI_PORTRAIT: launch_general_group<GEN_PANINI>(ctx, K, img, mask); break;
-        case STX_F_TRANSVERSE_MERCATOR: launch_general_group<GEN_TMERC>(ctx, K, img, mask); break;
+        case STX_F_PANINI_PORTRAIT: launch_general_group<GEN_PANINI>(ctx, K, img, mask, dbg); break;
+        case STX_F_TRANSVERSE_MERCATOR: launch_general_group<GEN_TMERC>(ctx, K, img, mask, dbg); break;
         default: return stx_fail(STX_ERR_INVALID, "no per-pixel kernel for projector family %d", K.family);
         }
     }
@@ -1165,14 +1196,15 @@ int stx_launch_warp_batch(stx_ctx* ctx, const StxWarpLaunch* Ls, int n)
     std::vector<double> bytes(n);
     for (int i = 0; i < n; i++) fill_warpk(Ls[i], &Ks[i], &bytes[i]);
     const bool img = Ls[0].dimg != nullptr, mask = Ls[0].dmask != nullptr;
-    const char* name = img ? (mask ? "warp_img_mask" : "warp_img") : "warp_mask";
+    const int dbg = Ls[0].debug_maps;  // stx_debug_warp_maps: dimg / dmask are the two float maps
+    const char* name = dbg ? "warp_debug_maps" : (img ? (mask ? "warp_img_mask" : "warp_img") : "warp_mask");
     switch (Ls[0].proj.family) {
-    case STX_F_PLANE: return launch_typed<STX_WARP_PLANE>(ctx, Ks.data(), n, img, mask, name, bytes.data());
-    case STX_F_CYLINDRICAL: return launch_typed<STX_WARP_CYLINDRICAL>(ctx, Ks.data(), n, img, mask, name, bytes.data());
+    case STX_F_PLANE: return launch_typed<STX_WARP_PLANE>(ctx, Ks.data(), n, img, mask, name, bytes.data(), dbg);
+    case STX_F_CYLINDRICAL: return launch_typed<STX_WARP_CYLINDRICAL>(ctx, Ks.data(), n, img, mask, name, bytes.data(), dbg);
     case STX_F_SPHERICAL:
     case STX_F_MERCATOR:  // separable like the sphere (row table: warp_tables_kernel)
-        return launch_typed<STX_WARP_SPHERICAL>(ctx, Ks.data(), n, img, mask, name, bytes.data());
-    default: return launch_general(ctx, Ks.data(), n, img, mask, name, bytes.data());
+        return launch_typed<STX_WARP_SPHERICAL>(ctx, Ks.data(), n, img, mask, name, bytes.data(), dbg);
+    default: return launch_general(ctx, Ks.data(), n, img, mask, name, bytes.data(), dbg);
     }
 }
 
@@ -1208,6 +1240,8 @@ int stx_launch_roi_minmax(stx_ctx* ctx, int n, const StxProjector* projs, const 
                 k.full = full ? 1 : 0;
                 if (full && (long long)k.w * k.h > 0x7fffffffll) return stx_fail(STX_ERR_UNSUPPORTED, "image of %dx%d pixels", k.w, k.h);
             }
+            // algorithmic bytes: the per-block partial results (nothing is read: the points come from the arguments)
+            StxProfScope prof(ctx, "warp_roi", 16.0 * BX * m, ctx->aux_stream);
             if (full) hipLaunchKernelGGL(roi_kernel<true>, dim3(BX, m), dim3(256), 0, ctx->aux_stream, B, dout + 4 * (size_t)BX * base);
             else hipLaunchKernelGGL(roi_kernel<false>, dim3(BX, m), dim3(256), 0, ctx->aux_stream, B, dout + 4 * (size_t)BX * base);
         }

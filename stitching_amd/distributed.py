@@ -23,7 +23,10 @@ blender prepared for its band (+ halo) and crops the result; everything is fed i
 
 `ShardPlan` is pure geometry (every rank computes the same plan from the global camera list);
 `ShardedStitchJob` runs one rank; transports move packed contribution buffers:
-`RcclTransport` (C ABI -> librccl), `GlooHostTransport` (host-staged, for tests / 1-GPU boxes).
+`RcclTransport` (C ABI -> librccl), `HostStagedTransport` (device -> host -> TCP -> device, for tests / 1-GPU boxes).
+
+Control plane: a `group` object with the interface of `stitching_amd.rendezvous.TcpGroup` (plain sockets: the RCCL id broadcast,
+one MIN vote, a plan-digest check, the gather of the bands).  No PyTorch anywhere in the package.
 """
 import ctypes as C
 import os
@@ -323,21 +326,22 @@ class ShardPlan:
 
 
 # ------------------------------------------------------------------------------------ transports
-class GlooHostTransport:
-    """Host-staged exchange over torch.distributed (gloo): device -> host -> peer -> device.
-    Works with several ranks on ONE GPU and on CPU-only rendezvous; used by the tests and as the
-    fallback when RCCL cannot initialise."""
+class HostStagedTransport:
+    """Host-staged exchange over the control-plane group (rendezvous.TcpGroup or anything with its `exchange_bytes`):
+    device -> host -> peer -> device.  Works with several ranks on ONE GPU and on CPU-only rendezvous; used by the tests and as
+    the fallback when RCCL cannot initialise."""
 
-    name = "gloo-host"
+    name = "host-staged"
 
-    def __init__(self, dist, ctx):
-        self.dist, self.ctx = dist, ctx
+    def __init__(self, group, ctx):
+        self.group, self.ctx = group, ctx
         self._pending = {}  # id(context) -> (sends, recvs, context): one exchange per context may be pending, as with RcclTransport
+        self._last = None
 
     def exchange(self, sends, recvs, ctx=None):
         """sends: [(dst, DeviceImage packed, nbytes)], recvs: [(src, nbytes)] -> [DeviceImage]"""
         host_sends = [(dst, np.asarray(packed).reshape(-1)[:nbytes]) for dst, packed, nbytes in sends]
-        return [flat_device_buffer(ctx or self.ctx, a) for a in gloo_exchange_host(self.dist, host_sends, recvs)]
+        return [flat_device_buffer(ctx or self.ctx, a) for a in self.group.exchange_bytes(host_sends, recvs)]
 
     # split form (same contract as RcclTransport): the host-staged exchange has nothing to overlap, it runs in finish()
     # Several contexts (panoramas in flight) may share the transport; the exchanges then run in the order of the finish()
@@ -350,32 +354,11 @@ class GlooHostTransport:
         self._last = ctx
 
     def finish(self, ctx=None):
-        key = id(ctx or self._last)
-        if key not in self._pending:
+        ctx = ctx or self._last
+        if ctx is None or id(ctx) not in self._pending:
             raise StitchingError("finish() without a pending exchange of this context")
-        sends, recvs, ctx = self._pending.pop(key)
+        sends, recvs, ctx = self._pending.pop(id(ctx))
         return self.exchange(sends, recvs, ctx)
-
-
-def gloo_exchange_host(dist, sends, recvs):
-    """Point-to-point exchange of byte strips over a torch.distributed (gloo) group.
-    sends: [(dst, 1-D uint8 array)], recvs: [(src, nbytes)] -> [1-D uint8 arrays] in `recvs` order.
-    Every rank lists its messages in the plan's global (dst, order) order, so the k-th message
-    between a pair of ranks is the same message on both sides."""
-    import torch
-
-    reqs, keep, rbufs = [], [], []
-    for src, nbytes in recvs:
-        t = torch.empty(nbytes, dtype=torch.uint8)
-        rbufs.append(t)
-        reqs.append(dist.irecv(t, src=src))
-    for dst, host in sends:
-        t = torch.from_numpy(np.ascontiguousarray(host))
-        keep.append(t)
-        reqs.append(dist.isend(t, dst=dst))
-    for r in reqs:
-        r.wait()
-    return [t.numpy() for t in rbufs]
 
 
 def flat_device_buffer(ctx, host_bytes):
@@ -390,8 +373,8 @@ def flat_device_buffer(ctx, host_bytes):
 
 class RcclTransport:
     """RCCL send/recv of the packed contribution buffers on the context's HIP stream
-    (stx_comm_* in include/stitching_amd.h).  The unique id is distributed by the caller's
-    control-plane (torch.distributed gloo broadcast in bench.py)."""
+    (stx_comm_* in include/stitching_amd.h).  The unique id is distributed by the control plane
+    (default_transport: one broadcast over the rendezvous group)."""
 
     name = "rccl"
 
@@ -474,8 +457,8 @@ class ShardedStitchJob:
     """One rank of a sharded panorama: device-resident local frames + the global camera list."""
 
     def __init__(self, frames, cameras, all_cameras, rank, world, all_sizes=None, warper_type="spherical",
-                 blender_type="multiband", num_bands=5, blend_strength=None, ctx=None, dist=None, transport=None,
-                 split_boundary=True, exchange="strips", mask_bits=True, balance=None):
+                 blender_type="multiband", num_bands=5, blend_strength=None, ctx=None, group=None, transport=None,
+                 split_boundary=True, exchange="strips", mask_bits=True, balance=None, dist=None):
         """blender_type / blend_strength: as stitching.blender.Blender (stitching/blender.py:5-38); for "multiband" `num_bands` sets the
         band count when blend_strength is None (the benchmark's way of naming a configuration).
         split_boundary (multiband): warp / feed the images that owe strips to other ranks first and the rest while the strips
@@ -483,7 +466,10 @@ class ShardedStitchJob:
         passes False: all local images go through one warp launch and one pyramid build, and the other panorama's
         kernels fill the time of the exchange.
         exchange: "strips" (warped-image columns) or, multiband only, "contribs" (round 1's per-level products).
-        balance: ShardPlan's band-edge rule, "links" (default) or "midway"."""
+        balance: ShardPlan's band-edge rule, "links" (default) or "midway".
+        group: the control plane (stitching_amd.rendezvous.TcpGroup or an object with its interface; `dist` is the old name of the
+        argument): transport negotiation, the plan check of plan(), gather().  A job that is handed a transport and never gathers
+        needs none."""
         if blender_type not in Blender.BLENDER_CHOICES:
             raise StitchingError(f"unknown blender type {blender_type!r}")
         if blender_type != "multiband" and exchange != "strips":
@@ -504,7 +490,7 @@ class ShardedStitchJob:
         self.warper = Warper(warper_type, ctx=self.ctx)
         self.warper.set_scale(self.all_cameras)
         self.num_bands_req, self.blend_strength = num_bands, blend_strength
-        self.dist = dist
+        self.dist = group if group is not None else dist
         self.transport = transport
         self.split_boundary = bool(split_boundary)
         self.exchange = exchange
@@ -522,34 +508,60 @@ class ShardedStitchJob:
     def plan(self):
         corners, wsizes = self.warper.warp_rois(self.all_sizes, self.all_cameras)
         roi = Blender.result_roi(corners, wsizes)
-        if self.blender_type != "multiband":
-            # Blender.prepare's choice (stitching/blender.py:25-36): "no", or a feather width below one pixel -> the plain blender
-            if self.blend_strength is None:
-                self.blend_strength = Blender.DEFAULT_BLEND_STRENGTH
-            blend_width = np.sqrt(roi[2] * roi[3]) * self.blend_strength / 100
-            self.roi = roi
-            if self.blender_type == "no" or blend_width < 1:
-                self.flat_kind, self.sharpness = "no", 0.0
-            else:
+        self.roi = roi
+        flat = self.blender_type != "multiband"
+        if self.blend_strength is None:
+            self.blend_strength = Blender.DEFAULT_BLEND_STRENGTH if flat else blend_strength_for_bands(self.num_bands_req, roi[2], roi[3])
+        blend_width = np.sqrt(roi[2] * roi[3]) * self.blend_strength / 100
+        if flat or blend_width < 1:
+            # Blender.prepare's choice (stitching/blender.py:25-36): "no", or a blend width below one pixel -> the plain blender,
+            # whatever type was asked for
+            if self.blender_type == "feather" and blend_width >= 1:
                 self.flat_kind, self.sharpness = "feather", 1.0 / blend_width
+            else:
+                self.flat_kind, self.sharpness = "no", 0.0
             self.req_bands = 0
             self.plan_ = ShardPlan(corners, wsizes, self.owners, self.world, None, "strips", self.mask_bits, kind=self.flat_kind,
                                    halo=feather_halo(self.sharpness), balance=self.balance)
-            self.last_num_bands = 0
-            if self.transport is None:
-                self.transport = default_transport(self.ctx, self.rank, self.world, self.dist)
-            return self.plan_
-        if self.blend_strength is None:
-            self.blend_strength = blend_strength_for_bands(self.num_bands_req, roi[2], roi[3])
-        blend_width = np.sqrt(roi[2] * roi[3]) * self.blend_strength / 100
-        self.req_bands = int((np.log(blend_width) / np.log(2.0) - 1.0))
-        self.roi = roi
-        probe = make_shard_blender(self.ctx, roi, self.req_bands)
-        self.plan_ = ShardPlan(corners, wsizes, self.owners, self.world, probe, self.exchange, self.mask_bits, balance=self.balance)
+        else:
+            if config.pyrdown_mode()[0] != "scalar":
+                # pyr_order() (csrc/stx_blend.hip) splits a row into vector body and scalar tail from the width and x of the FEED
+                # RECTANGLE; an exchange strip's rectangle is not its image's, so under a vector-order model the fp32 weights of a
+                # strip and of the whole image may round differently at the same column: "sharded == single GPU, bit for bit" would
+                # not hold.  The models exist to be compared with on one GPU; sharded jobs refuse them.
+                raise StitchingError("sharded multi-band blending needs the scalar pyrDown order (STITCHING_AMD_PYRDOWN / set_pyrdown_mode)")
+            self.req_bands = int((np.log(blend_width) / np.log(2.0) - 1.0))
+            probe = make_shard_blender(self.ctx, roi, self.req_bands)
+            self.plan_ = ShardPlan(corners, wsizes, self.owners, self.world, probe, self.exchange, self.mask_bits, balance=self.balance)
         self.last_num_bands = self.plan_.num_bands
+        self._check_plan_agreement()
         if self.transport is None:
             self.transport = default_transport(self.ctx, self.rank, self.world, self.dist)
         return self.plan_
+
+    def plan_digest(self):
+        """What every rank must agree on before the first strip moves: the geometry (edges, messages) and everything process-wide that
+        changes a rank's ROIs or bytes (band balance, trig / remap / pyrDown modes)."""
+        import hashlib
+
+        p = self.plan_
+        state = (p.kind, p.exchange, p.mask_bits, p.halo, p.num_bands, p.balance, list(p.edges), [tuple(m) for m in p.messages],
+                 list(p.corners), list(p.sizes), config.trig_mode(), config.remap_mode(), tuple(config.pyrdown_mode()),
+                 float(self.blend_strength), float(getattr(self, "sharpness", 0.0)))
+        return hashlib.sha256(repr(state).encode()).hexdigest()
+
+    def _check_plan_agreement(self):
+        """ShardPlan is "pure geometry, identical on every rank" only while every rank sees the same cameras AND the same environment
+        (STITCHING_AMD_BALANCE, the arithmetic modes).  A rank that differs would post other sends / receives than its peers expect and
+        the job would hang in the exchange: compare digests over the control plane first and fail with a message instead."""
+        if self.world == 1 or self.dist is None:
+            return
+        mine = self.plan_digest()
+        all_ = self.dist.all_gather(mine)
+        if len(set(all_)) != 1:
+            odd = [r for r, d in enumerate(all_) if d != all_[0]]
+            raise StitchingError(f"rank {self.rank}: the shard plan differs between ranks (ranks {odd} disagree with rank 0): cameras, "
+                                 "STITCHING_AMD_BALANCE or the trig / remap / pyrDown modes are not the same in every process")
 
     def run(self):
         """warp + feed local images, exchange contribution strips, blend this rank's band.
@@ -661,8 +673,7 @@ class ShardedStitchJob:
         band, bmask = np.asarray(pano), np.asarray(mask)
         if self.world == 1 or self.dist is None:
             return band, bmask
-        parts = [None] * self.world if self.rank == 0 else None
-        self.dist.gather_object((band, bmask), parts, dst=0)
+        parts = self.dist.gather((band, bmask), 0)
         if self.rank != 0:
             return None, None
         return np.concatenate([p[0] for p in parts], axis=1), np.concatenate([p[1] for p in parts], axis=1)
@@ -693,54 +704,48 @@ class loopback_bootstrap:
         return False
 
 
-def all_ranks_on_one_host(dist, world):
+def all_ranks_on_one_host(group):
     import socket
 
-    names = [None] * world
-    dist.all_gather_object(names, socket.gethostname())
-    return len(set(names)) == 1
+    return len(set(group.all_gather(socket.gethostname()))) == 1
 
 
-def default_transport(ctx, rank, world, dist):
-    """RCCL when it initialises on this node, else the host-staged gloo transport."""
+def default_transport(ctx, rank, world, group):
+    """RCCL when it initialises on this node, else the host-staged transport over the control-plane group."""
     if world == 1:
         return _NullTransport()
-    if dist is None:
-        raise StitchingError("a torch.distributed process group (gloo) is needed for the control plane")
-    import os
-
-    want = os.environ.get("STITCHING_AMD_TRANSPORT", "rccl")
+    if group is None:
+        raise StitchingError("a control-plane group (stitching_amd.rendezvous.TcpGroup) is needed for more than one rank")
     import sys
 
-    import torch
-
+    want = os.environ.get("STITCHING_AMD_TRANSPORT", "rccl")
+    if want not in ("rccl", "host", "gloo"):  # "gloo": the name this switch had while the control plane was torch.distributed
+        raise StitchingError(f"STITCHING_AMD_TRANSPORT={want!r} (rccl | host)")
     # Every rank issues the same sequence of collectives whatever fails where: (1) rank 0 ALWAYS broadcasts — the unique
     # id, or None when librccl is missing / refused or RCCL is not wanted; (2) ranks that got an id try to join the
     # communicator; (3) one all-reduce(MIN) decides for everybody.
-    one_host = all_ranks_on_one_host(dist, world)  # a collective: every rank calls it
-    uid = [None]
+    one_host = all_ranks_on_one_host(group)  # a collective: every rank calls it
+    uid = None
     if rank == 0 and want == "rccl":
         try:
             with loopback_bootstrap(one_host):
-                uid = [RcclTransport.unique_id()]
+                uid = RcclTransport.unique_id()
         except Exception as e:  # noqa: BLE001
-            print(f"[stitching_amd] rank 0: no RCCL unique id ({e}); using host-staged gloo", file=sys.stderr)
-    dist.broadcast_object_list(uid, src=0)
+            print(f"[stitching_amd] rank 0: no RCCL unique id ({e}); using the host-staged transport", file=sys.stderr)
+    uid = group.broadcast(uid, 0)
     ok, tr = 0, None
-    if uid[0] is not None:
+    if uid is not None:
         try:
             with loopback_bootstrap(one_host):
-                tr = RcclTransport(ctx, rank, world, uid[0])
+                tr = RcclTransport(ctx, rank, world, uid)
             ok = 1
         except Exception as e:  # noqa: BLE001 - any failure -> agree on the fallback below
-            print(f"[stitching_amd] rank {rank}: RCCL transport unavailable ({e}); using host-staged gloo", file=sys.stderr)
-    flag = torch.tensor([ok], dtype=torch.int32)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag.item()) == 1:
+            print(f"[stitching_amd] rank {rank}: RCCL transport unavailable ({e}); using the host-staged transport", file=sys.stderr)
+    if group.all_reduce_min(ok) == 1:
         return tr
     if tr is not None:
         tr.close()
-    return GlooHostTransport(dist, ctx)
+    return HostStagedTransport(group, ctx)
 
 
 class _NullTransport:

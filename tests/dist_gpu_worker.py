@@ -1,7 +1,8 @@
 """Worker of tests/test_gpu_two_process.py: one rank of a REAL multi-process sharded job whose ranks share GPU 0.
 
-Every rank is its own process with its own device context; the strips travel over the host-staged gloo transport (RCCL
-refuses two ranks on one device).  Each rank warps its frames, exchanges strips, blends its band; rank 0 gathers the bands
+Every rank is its own process with its own device context; the control plane is the product's TCP rendezvous and the strips
+travel over the host-staged transport (RCCL refuses two ranks on one device) — or over RCCL when STX_TEST_DEVICES says that every
+rank has a GPU of its own (tests/test_gpu_multi_device.py).  Each rank warps its frames, exchanges strips, blends its band; rank 0 gathers the bands
 and compares the assembled panorama with the oracle's panorama of all frames, byte for byte."""
 import json
 import os
@@ -14,16 +15,15 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    import torch.distributed as dist
-
     import stitching_amd as S
     from stitching_amd import synthetic
     from stitching_amd.distributed import ShardedStitchJob
+    from stitching_amd.rendezvous import TcpGroup
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     case = json.loads(os.environ["STX_TEST_CASE"])
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    S.set_default_device(0)
+    dist = TcpGroup(rank, world, os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]))
+    S.set_default_device(rank if os.environ.get("STX_TEST_DEVICES") == "own" else 0)
     ctx = S.get_context()
     w, h, per = case["w"], case["h"], case["per_rank"]
     n = per * world
@@ -37,7 +37,7 @@ def main():
     btype = case.get("blender", "multiband")  # "feather" / "no": case["strength"] is the reference's blend_strength
     job = ShardedStitchJob(frames, [cams[i] for i in mine], cams, rank, world, warper_type=case["warper"], num_bands=case.get("bands", 5),
                            blender_type=btype, blend_strength=case.get("strength") if btype != "multiband" else None,
-                           ctx=ctx, dist=dist, split_boundary=case.get("split", True), exchange=case.get("exchange", "strips"),
+                           ctx=ctx, group=dist, split_boundary=case.get("split", True), exchange=case.get("exchange", "strips"),
                            mask_bits=case.get("mask_bits", True))
     plan = job.plan()
     res = {"transport": job.transport.name, "bands": plan.num_bands, "messages": len(plan.messages), "bytes": plan.exchanged_bytes()}
@@ -69,7 +69,7 @@ def main():
         res["ok"] = bool(res.get("shape_equal") and res.get("max_abs_diff") == 0 and res.get("mask_equal") and res.get("rois_equal"))
         print(json.dumps(res), flush=True)
     dist.barrier()
-    dist.destroy_process_group()
+    dist.close()
 
 
 if __name__ == "__main__":

@@ -1,8 +1,9 @@
-"""Worker of tests/test_distributed_cpu.py: one rank of a world_size-N gloo group on CPU.
+"""Worker of tests/test_distributed_cpu.py: one rank of a world_size-N group on CPU — over the product's own TCP rendezvous
+(stitching_amd.rendezvous.TcpGroup) or over torch.distributed's gloo behind the same interface (tests/gloo_group.py).
 
 Exercises everything of the sharded path that does not need a GPU: the plan (pure geometry through
 the C ABI with a NULL context), its agreement across ranks, and the strip exchange protocol
-(message order, sizes, payload integrity) over torch.distributed point-to-point."""
+(message order, sizes, payload integrity) point to point."""
 import hashlib
 import json
 import os
@@ -20,13 +21,12 @@ def payload(k, src, dst, nbytes):
 
 
 def main():
-    import torch.distributed as dist
-
     from stitching_amd import distributed as D
+    from tests.gloo_group import make_group
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     case = json.loads(os.environ["STX_TEST_CASE"])
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    group = make_group(os.environ.get("STX_TEST_GROUP", "tcp"), rank, world, os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]))
     corners, sizes, req_bands = case["corners"], case["sizes"], case["req_bands"]
     roi = D.Blender.result_roi(corners, sizes)
     kind = case.get("kind", "multiband")  # "feather" / "no": strips = band columns + halo, no probe blender
@@ -52,9 +52,8 @@ def main():
 
     # 1. every rank derives the same plan
     sig = hashlib.sha256(json.dumps([plan.edges, plan.messages, plan.num_bands]).encode()).hexdigest()
-    sigs = [None] * world
-    dist.all_gather_object(sigs, sig)
-    assert len(set(sigs)) == 1, "ranks disagree on the shard plan"
+    sigs = group.all_gather(sig)
+    assert len(sigs) == world and len(set(sigs)) == 1, "ranks disagree on the shard plan"
 
     # 2. bands tile the panorama on multiples of max(8, 2^B)
     align = max(8, 1 << plan.num_bands)
@@ -64,21 +63,23 @@ def main():
     # 3. the exchange: the bytes each rank receives are the bytes the owner sent, in plan order
     sends = [(m[2], payload(m[0], m[1], m[2], m[4])) for m in plan.sends(rank)]
     recv_msgs = plan.recvs(rank)
-    got = D.gloo_exchange_host(dist, sends, [(m[1], m[4]) for m in recv_msgs])
+    got = group.exchange_bytes(sends, [(m[1], m[4]) for m in recv_msgs])
     for m, a in zip(recv_msgs, got):
         assert a.size == m[4] and np.array_equal(a, payload(m[0], m[1], m[2], m[4])), f"strip {m[:3]} corrupted"
 
     # 4. whole-job throughput accounting of bench.py: MAX over ranks of the elapsed time
-    import torch
-
-    t = torch.tensor([0.5 + rank], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    assert float(t.item()) == 0.5 + world - 1
-    dist.barrier()
+    assert group.all_reduce_max(0.5 + rank) == 0.5 + world - 1
+    assert group.all_reduce_min(rank + 3) == 3
+    assert group.broadcast({"id": bytes(range(128))} if rank == 0 else None, 0) == {"id": bytes(range(128))}
+    parts = group.gather((rank, np.full(3, rank, np.uint8)), 0)
+    assert (parts is None) == (rank != 0)
+    if rank == 0:
+        assert [p[0] for p in parts] == list(range(world)) and all(np.array_equal(p[1], np.full(3, i, np.uint8)) for i, p in enumerate(parts))
+    group.barrier()
     if rank == 0:
         print(json.dumps({"ok": True, "messages": len(plan.messages), "bytes": plan.exchanged_bytes(),
                           "edges": plan.edges, "bands": plan.num_bands}))
-    dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == "__main__":

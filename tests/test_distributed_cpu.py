@@ -1,5 +1,5 @@
-"""world_size-2 / 3 gloo tests of the sharded path on CPU (no GPU): plan agreement across ranks and
-the contribution-strip exchange protocol.  The kernels themselves are covered on the GPU by
+"""world_size-2 / 3 / 4 / 8 tests of the sharded path on CPU (no GPU): plan agreement across ranks and
+the contribution-strip exchange protocol, over the product's TCP rendezvous (default) and over gloo behind the same interface.  The kernels themselves are covered on the GPU by
 tests/test_gpu_parity.py::test_sharded_blend_equals_single_gpu (all ranks simulated on one device)."""
 import json
 import os
@@ -22,12 +22,14 @@ def free_port():
     return p
 
 
-def launch(world, case):
+def launch(world, case, group="tcp", extra_env=None, expect_fail=False):
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), STX_TEST_CASE=json.dumps(case), GLOO_SOCKET_IFNAME="lo")
+                   MASTER_PORT=str(port), STX_TEST_CASE=json.dumps(case), GLOO_SOCKET_IFNAME="lo", STX_TEST_GROUP=group)
+        if extra_env:
+            env.update(extra_env(r))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
@@ -39,18 +41,22 @@ def launch(world, case):
                 q.kill()
             pytest.fail("distributed worker timed out")
         outs.append((p.returncode, o, e))
+    if expect_fail:
+        return outs
     for rc, o, e in outs:
         assert rc == 0, f"worker failed:\n{e[-3000:]}"
     return json.loads(outs[0][1].strip().splitlines()[-1])
 
 
+@pytest.mark.parametrize("group", ["tcp", "gloo"])
 @pytest.mark.parametrize("world,n,req_bands,exchange", [(2, 4, 5, "strips"), (3, 6, 4, "strips"), (2, 8, 3, "contribs"), (3, 6, 4, "contribs")])
-def test_shard_plan_and_strip_exchange_over_gloo(oracle, world, n, req_bands, exchange):
+def test_shard_plan_and_strip_exchange(oracle, world, n, req_bands, exchange, group):
     cams = synthetic.ring_cameras(n, 800, 600, span_deg=40.0 * n)
     w = oracle.Warper("spherical")
     w.set_scale(cams)
     corners, sizes = w.warp_rois([(800, 600)] * n, cams)
-    res = launch(world, {"corners": [list(c) for c in corners], "sizes": [list(s) for s in sizes], "req_bands": req_bands, "exchange": exchange})
+    res = launch(world, {"corners": [list(c) for c in corners], "sizes": [list(s) for s in sizes], "req_bands": req_bands, "exchange": exchange},
+                 group)
     assert res["ok"] and res["messages"] >= world - 1 and res["bytes"] > 0
     assert len(res["edges"]) == world + 1
 

@@ -18,6 +18,10 @@ Config 4 also goes through the SHARDED path at full size (test_config4_sharded_v
 16 yaw columns x 4 pitch rows, cylindrical, 7 bands (gap 384, alignment 128), two ranks with two yaw columns each —
 bench.py's `--config 4 --gpus 2` layout — through ShardedStitchJob in both split orders with the masks travelling as bits,
 and as virtual shards; every panorama equals the oracle's bit for bit.
+
+Round 4: the two multi-GPU configurations LITERALLY — config 3 with 8 ShardedStitchJob ranks x 4 frames and config 4 with all 64
+frames 8000x6000 on 8 ranks x 8 frames (test_config4_literal_64_frames_8_ranks_vs_oracle) — every rank's real job object, link-balanced
+band edges, masks as bits, the exchange as record / replay on one GPU; the assembled panorama equals the oracle's byte for byte.
 """
 import numpy as np
 import pytest
@@ -173,6 +177,19 @@ def test_config3_vs_oracle_single_and_sharded(oracle, gpu_ctx):
                 assert all(plan.owners[4 * g:4 * g + 4] == [g] * 4 for g in range(8))
                 assert any(abs(m[1] - m[2]) > 1 for m in plan.messages)
             _assert_same(sp, sm, o)
+        del imgs, masks, b
+        # the configuration as bench.py --gpus 8 runs it: 8 ShardedStitchJob ranks x 4 frames (one yaw column each), band edges placed
+        # for the links, masks as bits, both split orders; the exchange is a record / replay of the real strips on this one GPU
+        for split in (True, False):
+            sp, sm, jobs = helpers.run_sharded_job_in_one_process(gpu_ctx, job.frames, cams, 8, 4, num_bands=5, split_boundary=split,
+                                                                  exchange="strips", mask_bits=True, balance="links")
+            p = jobs[0].plan_
+            assert p.num_bands == 5 and p.mask_bits and p.balance == "links" and len(p.edges) == 9
+            assert p.corners == [tuple(c) for c in o["corners"]] and p.sizes == [tuple(s) for s in o["sizes"]]
+            assert any(abs(m[1] - m[2]) >= 3 for m in p.messages)  # strips to third neighbours
+            assert all(j.plan_.edges == p.edges and j.plan_.messages == p.messages for j in jobs)
+            _assert_same(sp, sm, o)
+            del jobs
     finally:
         S.set_device_resident(False)
 
@@ -227,6 +244,33 @@ def test_config4_sharded_vs_oracle(oracle, gpu_ctx):
             _assert_same(sp, sm, o)
     finally:
         S.set_device_resident(False)
+
+
+def test_config4_literal_64_frames_8_ranks_vs_oracle(oracle, gpu_ctx):
+    """BASELINE configs[3] LITERALLY (the N = 64 the north star quotes its scaling target on): 64 synthetic frames 8000x6000 as 16 yaw
+    columns x 4 pitch rows, cylindrical warp, 7 bands (gap 384, alignment 128), 8 ShardedStitchJob ranks x 8 frames (two yaw columns
+    each) — the job objects of `bench.py --config 4 --gpus 8` — with link-balanced band edges and the masks as bits.  The exchange
+    is a record / replay of the real strips on one GPU (pass 1 records what every rank sends, pass 2 feeds every rank what the
+    others sent it).  The assembled 527-Mpx panorama equals the oracle's byte for byte.  Minutes, most of them the oracle's."""
+    w, h = 8000, 6000
+    cams = synthetic.grid_cameras(16, 4, w, h, max_edge_lat_deg=50.0)
+    assert len(cams) == 64
+    frames = synthetic.make_frames(range(100, 164), w, h)
+    o = _oracle_panorama(oracle, frames, cams, "cylindrical", num_bands=7)
+    assert o["blender"].blender.num_bands() == 7
+    o_pano, o_mask, o_corners, o_sizes = o["pano"], o["pmask"], o["corners"], o["sizes"]
+    del o
+    d_frames = [S.DeviceImage.from_numpy(f, gpu_ctx) for f in frames]
+    del frames
+    sp, sm, jobs = helpers.run_sharded_job_in_one_process(gpu_ctx, d_frames, cams, 8, 8, warper_type="cylindrical", num_bands=7,
+                                                          split_boundary=True, exchange="strips", mask_bits=True, balance="links")
+    p = jobs[0].plan_
+    assert p.num_bands == 7 and p.mask_bits and p.world == 8 and len(p.messages) >= 14
+    assert p.owners == [g for g in range(8) for _ in range(8)]
+    assert all(e % 128 == 0 for e in p.edges[:-1]) and p.edges[-1] == o_pano.shape[1]
+    assert p.corners == [tuple(c) for c in o_corners] and p.sizes == [tuple(s) for s in o_sizes]
+    assert all(j.plan_.edges == p.edges and j.plan_.messages == p.messages for j in jobs)
+    _assert_same(sp, sm, dict(pano=o_pano, pmask=o_mask))
 
 
 @pytest.mark.parametrize("btype", ["feather", "no"])

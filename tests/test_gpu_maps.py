@@ -1,0 +1,112 @@
+"""The "1 ULP fp32 (warp coords)" clause of the north star, checked DIRECTLY: the fp32 backward map of a warp as the device projector
+computes it (stx_debug_warp_maps, include/stitching_amd_debug.h: the warp kernels stopped after the division x / z, y / z) against the
+CPU checker's build_maps — RotationWarperBase::buildMaps as the reference runs it (stitching/warper.py:44-51).  The fused product
+kernels never store these coordinates, so every other test sees them only through the 1/32-px samples they select.
+
+Asserted: the ULP histogram is {0: every pixel} — for the tuned kernel (tabled trig, packed row pairs, shared-reciprocal division) and
+for the generic one, in the `exact` and the `glibc` trig modes, for the spherical / cylindrical / plane / affine warpers on a config-2
+camera and on the +-56 degree (spherical) / 50 degree-latitude (cylindrical) cameras of configs 3 / 4, whole ROI, every pixel.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import stitching_amd as S
+from stitching_amd import _lib, synthetic
+
+pytestmark = pytest.mark.gpu
+
+W, H = 4000, 3000
+
+
+def device_maps(ctx, warper_type, scale, K, R, size, which, rect=None):
+    K = np.ascontiguousarray(K, np.float32)
+    R = np.ascontiguousarray(R, np.float32)
+    fp = C.POINTER(C.c_float)
+    ox, oy, roi = C.c_void_p(), C.c_void_p(), (C.c_int * 4)()
+    r = (C.c_int * 4)(*rect) if rect is not None else None
+    _lib.check(ctx._lib.stx_debug_warp_maps(ctx.handle, _lib.WARP_TYPE_IDS[warper_type], float(scale), K.ctypes.data_as(fp),
+                                            R.ctypes.data_as(fp), int(size[0]), int(size[1]), int(which), r, C.byref(ox), C.byref(oy), roi))
+    return np.asarray(S.DeviceImage(ctx, ox)), np.asarray(S.DeviceImage(ctx, oy)), tuple(int(v) for v in roi)
+
+
+def ulp_histogram(a, b):
+    """{ulp distance: count} of two fp32 arrays; two NaNs count as equal, NaN against a number as 'nan'."""
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    na, nb = np.isnan(a), np.isnan(b)
+    hist = {}
+    if np.any(na != nb):
+        hist["nan"] = int(np.count_nonzero(na != nb))
+    ok = ~(na | nb)
+
+    def ordered(x):  # monotone map of the float bit patterns onto integers
+        u = x.view(np.uint32).astype(np.int64)
+        return np.where(u & 0x80000000, 0x80000000 - u, u)
+
+    d = np.abs(ordered(a)[ok] - ordered(b)[ok])
+    vals, counts = np.unique(d, return_counts=True)
+    for v, c in zip(vals.tolist(), counts.tolist()):
+        hist[int(v)] = int(c)
+    return hist
+
+
+def cameras():
+    ring = synthetic.ring_cameras(8, W, H)
+    grid3 = synthetic.grid_cameras(8, 4, W, H)                           # config 3: +-18.6 and +-55.8 degree rows
+    grid4 = synthetic.grid_cameras(16, 4, W, H, max_edge_lat_deg=50.0)   # config 4's layout (at 4000x3000)
+    aff = synthetic.affine_scan_cameras(16, W, H)
+    return {
+        "spherical": [("config2", ring[5]), ("row+56", grid3[4 * 2 + 3]), ("row-56", grid3[4 * 6 + 0])],
+        "cylindrical": [("config2", ring[2]), ("config4-top", grid4[4 * 9 + 3]), ("config4-bottom", grid4[4 * 3 + 0])],
+        "plane": [("config2-centre", ring[4]), ("config2-next", ring[3])],
+        "affine": [("config5-tile5", aff[5]), ("config5-tile14", aff[14])],
+    }
+
+
+@pytest.mark.parametrize("trig", ["exact", "glibc"])
+@pytest.mark.parametrize("warper_type", ["spherical", "cylindrical", "plane", "affine"])
+def test_device_maps_equal_build_maps_to_the_bit(oracle, gpu_ctx, warper_type, trig):
+    o_trig = {"exact": oracle.TRIG_EXACT, "glibc": oracle.TRIG_GLIBC}[trig]
+    oracle.set_num_threads(max(1, min(oracle.max_threads(), 32)))
+    prev = S.set_trig_mode(trig)
+    try:
+        for name, cam in cameras()[warper_type]:
+            K = S.Warper.get_K(cam)
+            scale = 1.0 if warper_type == "affine" else 0.75 * W
+            for which in (1, 2):
+                gx, gy, roi = device_maps(gpu_ctx, warper_type, scale, K, cam.R, (W, H), which)
+                assert roi == oracle.warp_roi(warper_type, scale, K, cam.R, (W, H), o_trig)
+                ox, oy = oracle.build_maps(warper_type, scale, K, cam.R, roi, o_trig)
+                hx, hy = ulp_histogram(gx, ox), ulp_histogram(gy, oy)
+                n = roi[2] * roi[3]
+                assert hx == {0: n} and hy == {0: n}, (warper_type, name, trig, which, hx, hy)
+                if warper_type in ("spherical", "cylindrical"):
+                    # the maps are the real thing: most of the roi lands inside the source, the rest mirrors around it
+                    inside = (ox >= 0) & (ox <= W - 1) & (oy >= 0) & (oy <= H - 1)
+                    assert 0.3 < inside.mean() <= 1.0
+    finally:
+        S.set_trig_mode(prev)
+
+
+def test_device_maps_of_a_rectangle_and_of_the_other_projectors(oracle, gpu_ctx):
+    """Any rectangle of warp coordinates (also outside the roi: rays behind the camera map to (-1, -1)) and the per-pixel projector
+    families through their own kernels."""
+    cam = synthetic.grid_cameras(8, 4, W, H)[4 * 5 + 3]
+    K = S.Warper.get_K(cam)
+    scale = 0.75 * W
+    rect = (-9000, -200, 2100, 700)  # spans the back of the sphere for this camera
+    for which in (1, 2):
+        gx, gy, roi = device_maps(gpu_ctx, "spherical", scale, K, cam.R, (W, H), which, rect)
+        assert roi == rect
+        ox, oy = oracle.build_maps("spherical", scale, K, cam.R, rect)
+        assert ulp_histogram(gx, ox) == {0: rect[2] * rect[3]} and ulp_histogram(gy, oy) == {0: rect[2] * rect[3]}
+        assert np.any((ox == -1) & (oy == -1))
+    cam = synthetic.ring_cameras(8, 640, 480)[3]
+    K = S.Warper.get_K(cam)
+    for wt in ("fisheye", "stereographic", "compressedPlaneA2B1", "paniniA1.5B1", "mercator", "transverseMercator", "paniniPortraitA2B1"):
+        gx, gy, roi = device_maps(gpu_ctx, wt, 480.0, K, cam.R, (640, 480), 1)
+        assert roi == oracle.warp_roi(wt, 480.0, K, cam.R, (640, 480))
+        ox, oy = oracle.build_maps(wt, 480.0, K, cam.R, roi)
+        n = roi[2] * roi[3]
+        assert ulp_histogram(gx, ox) == {0: n} and ulp_histogram(gy, oy) == {0: n}, wt

@@ -1,5 +1,5 @@
 """Real multi-process runs of the sharded path on ONE GPU: every rank is its own process (own HIP context, own blender,
-own band), the strips travel through the host-staged gloo transport, rank 0 assembles the bands and compares the panorama
+own band), the control plane is the product's TCP rendezvous, the strips travel through the host-staged transport, rank 0 assembles the bands and compares the panorama
 with the oracle's — the N > 1 code path of bench.py with pixels checked, not only payload bytes
 (tests/test_distributed_cpu.py) or a record / replay inside one process (test_sharded_job_bands_equal_single_job)."""
 import json
@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def launch(world, case, timeout=420):
+def launch(world, case, timeout=420, rank_env=None, expect_fail=False):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -23,8 +23,10 @@ def launch(world, case, timeout=420):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   STX_TEST_CASE=json.dumps(case), GLOO_SOCKET_IFNAME="lo", STITCHING_AMD_FORCE_DEVICE="0", STITCHING_AMD_TRANSPORT="gloo",
+                   STX_TEST_CASE=json.dumps(case), GLOO_SOCKET_IFNAME="lo", STITCHING_AMD_FORCE_DEVICE="0", STITCHING_AMD_TRANSPORT="host",
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if rank_env:
+            env.update(rank_env(r))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
@@ -36,6 +38,8 @@ def launch(world, case, timeout=420):
                 q.kill()
             pytest.fail("sharded worker timed out")
         outs.append((p.returncode, o, e))
+    if expect_fail:
+        return outs
     for rc, o, e in outs:
         assert rc == 0, f"worker failed:\n{e[-3000:]}"
     return json.loads(outs[0][1].strip().splitlines()[-1])
@@ -45,7 +49,7 @@ def launch(world, case, timeout=420):
 def test_two_ranks_ring_panorama_equals_oracle(gpu_ctx, split):
     """6 frames, spherical, 4 bands, 2 ranks x 3 frames: the gathered panorama is the oracle's."""
     res = launch(2, dict(layout="ring", w=803, h=601, per_rank=3, warper="spherical", bands=4, split=split))
-    assert res["transport"] == "gloo-host" and res["bands"] == 4 and res["messages"] >= 2 and res["bytes"] > 0
+    assert res["transport"] == "host-staged" and res["bands"] == 4 and res["messages"] >= 2 and res["bytes"] > 0
     assert res["ok"], res
 
 
@@ -73,5 +77,15 @@ def test_three_ranks_feather_and_plain_blender_equal_oracle(gpu_ctx, blender, st
     """The feather and the plain blender (stitching/blender.py:27-36) sharded: 3 ranks x 2 frames of a ring, each rank blends its band
     (+ the feather halo) from its own columns and the strips it receives, in global feed order; the gathered panorama is the oracle's."""
     res = launch(3, dict(layout="ring", w=803, h=601, per_rank=2, warper="spherical", blender=blender, strength=strength, span=170.0))
-    assert res["transport"] == "gloo-host" and res["bands"] == 0 and res["messages"] >= 4 and res["bytes"] > 0
+    assert res["transport"] == "host-staged" and res["bands"] == 0 and res["messages"] >= 4 and res["bytes"] > 0
     assert res["ok"], res
+
+
+def test_ranks_with_different_environments_fail_loudly_instead_of_hanging(gpu_ctx):
+    """A rank whose process-wide arithmetic mode differs computes other ROIs / bytes than its peers expect: plan() compares digests
+    over the control plane and every rank raises StitchingError — before the first strip is posted (the alternative was a
+    hang in send / recv)."""
+    outs = launch(2, dict(layout="ring", w=803, h=601, per_rank=3, warper="spherical", bands=4), timeout=120,
+                  rank_env=lambda r: {"STITCHING_AMD_TRIG": "glibc"} if r == 1 else {}, expect_fail=True)
+    for rc, o, e in outs:
+        assert rc != 0 and "shard plan differs between ranks" in e, e[-2000:]

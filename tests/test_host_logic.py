@@ -121,15 +121,17 @@ def test_loopback_bootstrap_restores_the_environment(monkeypatch):
     assert os.environ["NCCL_SOCKET_IFNAME"] == "eth7"
 
 
-def test_gloo_host_transport_keeps_one_pending_exchange_per_context():
-    from stitching_amd.distributed import GlooHostTransport
+def test_host_staged_transport_keeps_one_pending_exchange_per_context():
+    from stitching_amd.distributed import HostStagedTransport
     from stitching_amd.stitching_error import StitchingError
 
     class Ctx:
         pass
 
     a, b = Ctx(), Ctx()
-    tr = GlooHostTransport(dist=None, ctx=a)
+    tr = HostStagedTransport(group=None, ctx=a)
+    with pytest.raises(StitchingError):  # before any start(): the intended error, not an AttributeError
+        tr.finish()
     tr.exchange = lambda sends, recvs, ctx=None: (sends, recvs, ctx)  # the wire is tested in test_distributed_cpu.py
     tr.start(["sa"], ["ra"], a)
     tr.start(["sb"], ["rb"], b)
@@ -205,3 +207,79 @@ def test_pyrdown_mode_switch_needs_no_gpu():
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, STITCHING_AMD_PYRDOWN=env_value), capture_output=True,
                              text=True, check=True, cwd=root)
         assert out.stdout.split() == want, (env_value, out.stdout, out.stderr)
+
+
+def test_feather_cap_of_the_plan_is_the_kernels_cap():
+    """distributed.FEATHER_DIST_CAP sizes the halo of the sharded feather blender; the distance-transform kernels clamp to
+    STX_FEATHER_DIST_CAP (csrc/stx_internal.h).  One number in two languages: tied together here."""
+    from stitching_amd import _lib
+    from stitching_amd.distributed import FEATHER_DIST_CAP
+
+    assert _lib.lib().stx_debug_feather_dist_cap() == FEATHER_DIST_CAP == 8192
+
+
+def test_package_never_imports_torch():
+    """north star: host Python calls the kernels through ctypes — no PyTorch.  The control plane of the sharded job is
+    stitching_amd/rendezvous.py (plain sockets)."""
+    import os
+    import re
+
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "stitching_amd")
+    for fn in sorted(os.listdir(pkg)):
+        if fn.endswith(".py"):
+            text = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(import|from)\s+torch\b", text, flags=re.M), fn
+    import subprocess
+    import sys
+
+    code = "import sys, stitching_amd, stitching_amd.distributed, stitching_amd.rendezvous, stitching_amd.pipeline; print('torch' in sys.modules)"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True, cwd=os.path.dirname(pkg))
+    assert out.stdout.strip() == "False"
+
+
+def test_tcp_group_single_rank_and_errors():
+    import socket
+    import threading
+
+    from stitching_amd.rendezvous import TcpGroup, free_port
+    from stitching_amd.stitching_error import StitchingError
+
+    g = TcpGroup(0, 1)
+    assert g.all_gather("x") == ["x"] and g.broadcast(5) == 5 and g.gather(7) == [7] and g.all_reduce_min(3) == 3
+    g.barrier()
+    assert g.exchange_bytes([], []) == []
+    with pytest.raises(StitchingError):
+        TcpGroup(2, 2, port=1)
+    with pytest.raises(StitchingError):
+        TcpGroup(0, 2)  # no port
+    # a rank that never shows up: the others fail with a StitchingError after the timeout instead of hanging
+    port = free_port()
+    with pytest.raises(StitchingError):
+        TcpGroup(0, 2, "127.0.0.1", port, timeout=0.5)
+    # two ranks in two threads: big messages both ways at once (no deadlock on full socket buffers), sizes checked against the plan
+    port = free_port()
+    res = {}
+
+    def run(rank):
+        try:
+            grp = TcpGroup(rank, 2, "127.0.0.1", port, timeout=30)
+            a = np.full(8 << 20, rank + 1, np.uint8)
+            got = grp.exchange_bytes([(1 - rank, a), (1 - rank, a[:5])], [(1 - rank, 8 << 20), (1 - rank, 5)])
+            res[rank] = (got[0][0], got[0].size, got[1].tolist(), grp.all_reduce_max(rank * 1.5))
+            try:
+                grp.exchange_bytes([(1 - rank, a[:7])], [(1 - rank, 9 if rank == 0 else 7)])
+                res[rank] += ("no error",)
+            except StitchingError as e:
+                res[rank] += (str(e),)
+            grp.close()
+        except Exception as e:  # noqa: BLE001
+            res[rank] = e
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+    assert res[0][:4] == (2, 8 << 20, [2] * 5, 1.5) and res[1][:4] == (1, 8 << 20, [1] * 5, 1.5), res
+    assert "expects 9" in res[0][4] and res[1][4] == "no error"
+    _ = socket
