@@ -394,21 +394,65 @@ STX_DEV uint32_t sample_border(const STX_GAS uint8_t* src, uint32_t stride, int 
 // lower one: three channel bytes to LDS at p[0..2].  Every channel value comes out of its dot product already in byte 2
 // of the register:  64 (h0 (32 - fx) + h1 fx + 512) = ((h0 (32 - fx) + h1 fx + 512) >> 10) << 16 + a remainder below
 // bit 16 (weights scaled by 64: <= 2048, sums < 2^25); the byte is stored as it is (ds_write_b8_d16_hi).
+// Issue costs on gfx950 (tools/ubench/valu_rate2.hip, inline asm, profiles/r04_valu_issue_cycles.txt): a wave64 instruction takes ~4.5 cycles
+// of its SIMD for almost everything this kernel uses (v_perm, v_alignbyte, v_dot2, v_pk_*_u16, v_bfe, v_mad_u32_u24, v_lshl_add, v_min3,
+// v_pk_fma_f32 — 5.0 for its two elements), ~2.8 for v_fma_f32 / v_mul_f32 / v_add_u32 / v_and_b32 and 8.4 for v_rcp_f32.  Measured A/Bs of
+// round 4 (one box, interleaved):
+//   STX_WARP_MUL = 1: 3 ix = (ix << 1) + ix, (fy, fy) = fy << 16 | fy, the horizontal weight pair by shifts instead of 24-bit multiplies
+//                     — 185.4 / 186.8 us against 185.6 / 185.6: the multiplies cost what the shifts cost.  Default 0 (the round-3 code).
+//   STX_WARP_UNALIGNED = 1: the 6-byte groups as byte-exact 8-byte loads (HSA unaligned-access mode) instead of aligned 12-byte windows +
+//                     v_alignbyte: 268 us against 185 — the texture-address path splits every unaligned lane access.  Default 0.
+#ifndef STX_WARP_MUL
+#define STX_WARP_MUL 0
+#endif
+#ifndef STX_WARP_UNALIGNED
+#define STX_WARP_UNALIGNED 0
+#endif
+STX_DEV uint32_t lshl_add_u32(uint32_t a, uint32_t b)  // (a << 1) + b, as ONE v_lshl_add_u32 (LLVM folds (x << 1) + x back into a multiply)
+{
+    uint32_t d;
+    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+STX_DEV uint32_t lshl16_or_u32(uint32_t a, uint32_t b)  // (a << 16) | b
+{
+    uint32_t d;
+    asm("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 STX_DEV void blend_pair_to_lds(const STX_GAS uint8_t* src, uint32_t stride, uint32_t ix, uint32_t iy, uint32_t fx, uint32_t fy,
                                uint8_t* p)
 {
-    // row < 2^15 and stride < 2^24 (fast_ok): 24-bit multiply, full rate
+    // row < 2^15 and stride < 2^24 (fast_ok): 24-bit multiply
+#if STX_WARP_MUL
+    const uint32_t a = __umul24(iy, stride) + lshl_add_u32(ix, ix);
+#else
     const uint32_t a = __umul24(iy, stride) + ix * 3u;
+#endif
     // the lower row through its own scalar base (src + stride: one scalar add per wavefront) and the SAME lane offset — not
     // src + (offset + stride), a vector add per pixel
+#if STX_WARP_UNALIGNED
+    typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(1)));
+    const u32x2_u r0 = *reinterpret_cast<const STX_GAS u32x2_u*>(src + a);
+    const u32x2_u r1 = *reinterpret_cast<const STX_GAS u32x2_u*>((src + stride) + a);
+    const uint32_t l0 = r0.x, h0 = r0.y, l1 = r1.x, h1 = r1.y;
+#else
     const STX_GAS uint32_t* q0 = reinterpret_cast<const STX_GAS uint32_t*>(src + (a & ~3u));
     const STX_GAS uint32_t* q1 = reinterpret_cast<const STX_GAS uint32_t*>((src + stride) + (a & ~3u));
     const uint32_t d0 = q0[0], d1 = q0[1], d2 = q0[2], e0 = q1[0], e1 = q1[1], e2 = q1[2];
     const uint32_t sh = a & 3u;
     const uint32_t l0 = __builtin_amdgcn_alignbyte(d1, d0, sh), h0 = __builtin_amdgcn_alignbyte(d2, d1, sh);
     const uint32_t l1 = __builtin_amdgcn_alignbyte(e1, e0, sh), h1 = __builtin_amdgcn_alignbyte(e2, e1, sh);
+#endif
+#if STX_WARP_MUL
+    const uint32_t wy1 = lshl16_or_u32(fy, fy), wy0 = 0x200020u - wy1;  // (fy, fy), (32 - fy, 32 - fy)
+    const uint32_t g = fx << 6;
+    const uint32_t wx = lshl16_or_u32(g, 2048u - g);              // (64 (32 - fx), 64 fx)
+#else
     const uint32_t wy1 = fy * 0x10001u, wy0 = 0x200020u - wy1;  // (fy, fy), (32 - fy, 32 - fy)
     const uint32_t wx = __umul24(fx, 0x3fffc0u) + 2048u;        // (64 (32 - fx), 64 fx)
+#endif
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         // (left tap, right tap) of channel c as two u16: bytes c and c + 3 of the 6-byte BGRBGR group

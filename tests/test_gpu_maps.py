@@ -95,13 +95,14 @@ def test_device_maps_of_a_rectangle_and_of_the_other_projectors(oracle, gpu_ctx)
     cam = synthetic.grid_cameras(8, 4, W, H)[4 * 5 + 3]
     K = S.Warper.get_K(cam)
     scale = 0.75 * W
-    rect = (-9000, -200, 2100, 700)  # spans the back of the sphere for this camera
+    rect = (-8600, 3000, 2100, 700)  # mostly the back of the sphere for this camera: z <= 0 -> (-1, -1), the rest in front
     for which in (1, 2):
         gx, gy, roi = device_maps(gpu_ctx, "spherical", scale, K, cam.R, (W, H), which, rect)
         assert roi == rect
         ox, oy = oracle.build_maps("spherical", scale, K, cam.R, rect)
         assert ulp_histogram(gx, ox) == {0: rect[2] * rect[3]} and ulp_histogram(gy, oy) == {0: rect[2] * rect[3]}
-        assert np.any((ox == -1) & (oy == -1))
+        behind = (ox == -1) & (oy == -1)
+        assert 0.5 < behind.mean() < 1.0
     cam = synthetic.ring_cameras(8, 640, 480)[3]
     K = S.Warper.get_K(cam)
     for wt in ("fisheye", "stereographic", "compressedPlaneA2B1", "paniniA1.5B1", "mercator", "transverseMercator", "paniniPortraitA2B1"):
