@@ -35,6 +35,11 @@ constexpr int WARP_TH = 4;    // tile height (4 waves x 1 row)
 #endif
 constexpr int WARP_IT = STX_WARP_IT;
 constexpr int WARP_FTH = WARP_TH * WARP_IT;  // tile height of the fast kernel
+// wavefronts per workgroup of the fast kernel (they share nothing: no workgroup barrier, LDS per wavefront): its tile is 64 x this wide
+#ifndef STX_WARP_WAVES
+#define STX_WARP_WAVES 4
+#endif
+constexpr int WARP_FW = 64 * STX_WARP_WAVES;
 constexpr int WARP_BAND = 4;  // tile rows per XCD band (fast kernel); measured 1: 548, 2: 424, 4: 360, 8: 327, 16: 311 MB fetched
 constexpr float PI_F = 3.14159274101257324f;  // static_cast<float>(CV_PI)
 
@@ -487,7 +492,7 @@ STX_DEV int periodic_axis(int s, int n, int period, float inv_period, int bias)
 }
 
 template <int TYPE, bool IMG, bool MASK, bool DBG = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void warp_fast_kernel(WarpBatchK B)
+__global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8))) void warp_fast_kernel(WarpBatchK B)
 {
     const WarpK& P = B.k[blockIdx.z];
     // the two table pointers ride in the same batch of scalar loads as the per-image scalars below (left to the compiler they are
@@ -532,10 +537,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // row constants are wave-uniform.  The 3-byte results go through LDS to leave as whole dwords: 768 + 256 bytes per
     // wavefront, written bytewise, read back as the 192 + 64 dwords of the wavefront's 4 rows.  Only the wavefront
     // itself reads what it wrote (LDS operations of one wavefront execute in order): no workgroup barrier.
-    __shared__ uint32_t s_px[4][WARP_TH][48];  // [wavefront][row][dword]: 64 px x 3 B
-    __shared__ uint32_t s_mk[4][WARP_TH][16];  // [wavefront][row][dword]: 64 px x 1 B
+    __shared__ uint32_t s_px[STX_WARP_WAVES][WARP_TH][48];  // [wavefront][row][dword]: 64 px x 3 B
+    __shared__ uint32_t s_mk[STX_WARP_WAVES][WARP_TH][16];  // [wavefront][row][dword]: 64 px x 1 B
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and known to be
-    const int xw = tile_x * WARP_TW + wv * 64;  // first column of this wavefront
+    const int xw = tile_x * WARP_FW + wv * 64;  // first column of this wavefront
     // columns beyond the image are computed on the clamped table entry, rows beyond it on the repeated last row
     // (harmless) and never stored
     const v2f ct = *(const STX_GAS v2f*)((const STX_GAS char*)colT + ((uint32_t)min(xw + lane, dw - 1) << 3));  // dw < 2^29
@@ -1082,7 +1087,7 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
             const WarpK& K = Ks[base + i];
             B.k[i] = K;
             B.k[i].band_rows = WARP_BAND;
-            B.k[i].tiles_x = (K.dw + WARP_TW - 1) / WARP_TW;
+            B.k[i].tiles_x = (K.dw + WARP_FW - 1) / WARP_FW;
             B.k[i].tiles_y = (K.dh + WARP_FTH - 1) / WARP_FTH;
             B.k[i].band_tiles = B.k[i].band_rows * B.k[i].tiles_x;
             B.k[i].magic_tx = (uint32_t)((1ull << 32) / (uint32_t)B.k[i].tiles_x) + 1u;
@@ -1107,7 +1112,7 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
             StxProfScope prof(ctx, prof_name, bytes);
             int per_xcd = 0;  // workgroups each XCD needs: its share of the bands, whole bands only
             for (int i = 0; i < m; i++) {
-                const int tx = (B.k[i].dw + WARP_TW - 1) / WARP_TW, ty = (B.k[i].dh + WARP_FTH - 1) / WARP_FTH;
+                const int tx = (B.k[i].dw + WARP_FW - 1) / WARP_FW, ty = (B.k[i].dh + WARP_FTH - 1) / WARP_FTH;
                 const int wb = B.k[i].band_rows, bands = (ty + wb - 1) / wb;
                 per_xcd = std::max(per_xcd, ((bands + 7) / 8) * wb * tx);
             }
@@ -1115,10 +1120,10 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
             // STITCHING_AMD_WARP_LDS (diagnostic): bytes of dynamic LDS requested on top of the kernel's own — an occupancy limit
             // (160 KB per CU / request = workgroups per CU) for co-residency experiments with the other panorama's kernels
             static const unsigned pad_lds = getenv("STITCHING_AMD_WARP_LDS") ? (unsigned)atoi(getenv("STITCHING_AMD_WARP_LDS")) : 0u;
-            if (dbg) hipLaunchKernelGGL((warp_fast_kernel<TYPE, false, false, true>), gf, dim3(256), 0, s, B);
-            else if (img && mask) hipLaunchKernelGGL((warp_fast_kernel<TYPE, true, true>), gf, dim3(256), pad_lds, s, B);
-            else if (img) hipLaunchKernelGGL((warp_fast_kernel<TYPE, true, false>), gf, dim3(256), pad_lds, s, B);
-            else hipLaunchKernelGGL((warp_fast_kernel<TYPE, false, true>), gf, dim3(256), pad_lds, s, B);
+            if (dbg) hipLaunchKernelGGL((warp_fast_kernel<TYPE, false, false, true>), gf, dim3(WARP_FW), 0, s, B);
+            else if (img && mask) hipLaunchKernelGGL((warp_fast_kernel<TYPE, true, true>), gf, dim3(WARP_FW), pad_lds, s, B);
+            else if (img) hipLaunchKernelGGL((warp_fast_kernel<TYPE, true, false>), gf, dim3(WARP_FW), pad_lds, s, B);
+            else hipLaunchKernelGGL((warp_fast_kernel<TYPE, false, true>), gf, dim3(WARP_FW), pad_lds, s, B);
         } else {
             for (int i = 0; i < m; i++) {
                 StxProfScope prof(ctx, prof_name, algo_bytes[base + i]);
