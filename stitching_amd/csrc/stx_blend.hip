@@ -209,11 +209,21 @@ STX_DEV int pyr_up_g(const StxMbImage& im, int lv, int c, int cw, int ch, int X,
 
 // gather + normalise + collapse of one level (generic, one pixel per lane; all levels, all kinds)
 template <bool L0>
+STX_DEV void mb_level_pixel(const MbLevelK& P, const int x, const int y);
+
+template <bool L0>
 STX_DEV void mb_level_body(const MbLevelK& P)
 {
     const int x = P.x0 + blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = P.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= P.x1 || y >= P.y1) return;
+    mb_level_pixel<L0>(P, x, y);
+}
+
+// one sample (x, y) of a level: every image in feed order, normalise, collapse, store
+template <bool L0>
+STX_DEV void mb_level_pixel(const MbLevelK& P, const int x, const int y)
+{
     const int lv = P.level;
     int acc0 = 0, acc1 = 0, acc2 = 0;
     float ws = 0.f;

@@ -1353,7 +1353,12 @@ STX_DEV void level0_epilogue_pk(const MbLevelK& P, int X0, int Y0, uint32_t (&ac
     }
 }
 
-template <bool CONTRIB>
+// DEFER (masks that may be grey, MbLevelK::defer_list): the packed arithmetic is exact for a lane as long as every mask byte under its
+// 8 x 2 patch is 0 or 255, whatever the other lanes of the wavefront see — so the kernel runs as it is, a lane notes "grey byte seen" (a
+// byte is 0 / 255 iff it equals its sign bit replicated), and at the end such a lane queues its patch for the fp32-weight pass instead of
+// storing.  A resized seam mask is grey along the seams only: 1 - 2 % of the lanes (round 3 switched the WHOLE wavefront to fp32 sums at
+// its first grey byte: 40 % of the wavefronts of the default pipeline).
+template <bool CONTRIB, bool DEFER = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVES, 8))) void mb_level0_pk_kernel(MbLevelK P)
 {
     const int tid = threadIdx.x;
@@ -1371,6 +1376,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVE
         for (int k = 0; k < 4; k++) acc[r][0][k] = acc[r][1][k] = acc[r][2][k] = 0;
         cntb[r][0] = cntb[r][1] = 0;
     }
+    uint32_t grey_seen = 0u;  // DEFER: non-zero once a mask byte under this lane was neither 0 nor 255
 
     // every wavefront finds the images under ITS two rows with one ballot (no LDS list, no barrier)
     for (int base = 0; base < P.n_images; base += 64) {
@@ -1434,6 +1440,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVE
                 lane_valid_bytes(lx0, im.iw, vm0, vm1);
                 mw[0][0] &= vm0; mw[0][1] &= vm1; mw[1][0] &= vm0; mw[1][1] &= vm1;
             }
+            if (DEFER) {
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int hlf = 0; hlf < 2; hlf++) {
+                        const uint32_t t = (mw[r][hlf] >> 7) & 0x01010101u;
+                        grey_seen |= mw[r][hlf] ^ ((t << 8) - t);
+                    }
+            }
             // (no early-out on an all-zero mask: it would put the G_1 loads behind the mask loads' round trip)
             const uint32_t g1_boff = (uint32_t)((X0 - im.fx) >> 1);  // this lane's samples of G_1 (bytes): offset in a row
             const UpSel g1_sel = up_sel_u8(X0 == im.fx, ((X0 - im.fx) >> 1) + 4 >= (im.fw >> 1));
@@ -1477,6 +1492,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVE
         }
     }
     if (!active) return;
+    if (DEFER) {
+        // one atomic per wavefront that holds deferred lanes, on the counter of this workgroup's segment of the queue
+        const bool mine = grey_seen != 0u;
+        const unsigned long long dm = __ballot(mine);
+        if (dm != 0ull) {
+            const unsigned seg = (unsigned)tile_tx % (unsigned)STX_DEFER_SEGS;
+            unsigned base_i = 0u;
+            if ((unsigned)(tid & 63) == (unsigned)__builtin_ctzll(dm)) base_i = atomicAdd(P.defer_count + 32u * seg, (unsigned)__builtin_popcountll(dm));
+            base_i = (unsigned)__builtin_amdgcn_readlane((int)base_i, (int)__builtin_ctzll(dm));
+            if (mine) {
+                const unsigned slot = base_i + (unsigned)__builtin_popcountll(dm & ((1ull << (tid & 63)) - 1ull));
+                if (slot < P.defer_cap)
+                    P.defer_list[(size_t)seg * P.defer_cap + slot] = (unsigned long long)(unsigned)X0 | ((unsigned long long)(unsigned)Y0 << 32);
+                return;
+            }
+        }
+    }
 
     uint32_t cnt[2][4];  // the epilogue wants the counts in the pair layout of acc
 #pragma unroll
@@ -1489,6 +1521,95 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVE
     level0_epilogue_pk<false>(P, X0, Y0, acc, cnt, nullptr);
 }
 
+
+// Second pass of a level-0 gather with deferral: one lane per queued 8 x 2 patch, at any position — nothing here is wave-uniform but the
+// image loop.  Per pixel, channel and image: L = sat(img - pyrUp(G_1)), acc += (short)(L * w) with w = mask / 255 in fp32, weight sums
+// in fp32, in feed order; then the common epilogue (division, collapse, convertScaleAbs): the arithmetic of mb_level_fast_body's general
+// level-0 branch, for 1 - 2 % of the patches of a panorama.  A wavefront takes 64 consecutive entries of one segment (one 512-pixel
+// column of the panorama: two or three images) and blocks of 64 entries are dealt round-robin over ALL wavefronts of the launch,
+// whichever segment they come from: the seams of a panorama sit in a few columns, and with a fixed number of wavefronts per segment
+// those columns' queues were worked off in 4 - 7 serial steps (80 us); a wavefront's own step is a dozen microseconds of dependent loads.
+__global__ __launch_bounds__(256) void mb_level0_deferred_kernel(MbLevelK P)
+{
+    const unsigned wave = blockIdx.x * 4u + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), waves = gridDim.x * 4u;
+    const unsigned lane = threadIdx.x & 63u;
+    unsigned g0 = 0u;  // global index of the current segment's first block of 64 entries
+    // every counter in one batch of loads (lane l holds those of the segments l, l + 64, ...): read one by one inside the loop they were
+    // a chain of defer_segs dependent memory round trips in front of every wavefront's work — 40 of the 45 us this kernel took
+    unsigned cnt_l[STX_DEFER_SEGS / 64];
+#pragma unroll
+    for (int j = 0; j < STX_DEFER_SEGS / 64; j++) {
+        const unsigned sg = lane + 64u * (unsigned)j;
+        cnt_l[j] = sg < (unsigned)P.defer_segs ? min(P.defer_count[32u * sg], P.defer_cap) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < STX_DEFER_SEGS / 64; j++)
+    for (unsigned sl = 0; sl < 64u && 64u * (unsigned)j + sl < (unsigned)P.defer_segs; sl++) {
+        const unsigned seg = 64u * (unsigned)j + sl;
+        const unsigned n = (unsigned)__builtin_amdgcn_readlane((int)cnt_l[j], (int)sl), nb = (n + 63u) >> 6;
+        // the blocks g of [g0, g0 + nb) with g = wave (mod waves)
+        for (unsigned g = g0 + (wave + waves - g0 % waves) % waves; g < g0 + nb; g += waves) {
+            const unsigned i = (g - g0) * 64u + lane;
+            const bool live = i < n;
+            const unsigned long long e = live ? P.defer_list[(size_t)seg * P.defer_cap + i] : 0ull;
+            const int X0 = (int)(unsigned)(e & 0xffffffffull), Y0 = (int)(unsigned)(e >> 32);
+            int acc[2][8][3];
+            float ws[2][8];
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    acc[r][j][0] = acc[r][j][1] = acc[r][j][2] = 0;
+                    ws[r][j] = 0.f;
+                }
+            for (int k = 0; k < P.n_images; k++) {
+                const StxMbImage& im = P.images[k];
+                const int lx0 = X0 - im.ix, ly0 = Y0 - im.iy;
+                const bool inside = live && !(lx0 + 8 <= 0 || lx0 >= im.iw || ly0 + 2 <= 0 || ly0 >= im.ih);
+                if (__ballot(inside) == 0ull) continue;
+                if (!inside) continue;
+                // Straight-line code from here on (no branch per channel, row or pixel), so that every load of this image — nine pyrUp
+                // windows, two rows of pixels and mask bytes — is in flight before the first use: the 64 patches of this wavefront lie in
+                // 64 different rows, every load instruction touches 64 cache lines, and with the loads issued behind one another's uses a
+                // wavefront spent six dependent round trips per image (42 us for the pass).  A pixel outside the image gets weight 0
+                // through its mask byte: (short)(L * 0.f) = 0 and w + 0.f = w, exactly what skipping it does.
+                uint32_t vm0, vm1;
+                {   // lane_valid_bytes without its wave-wide shortcut (the lanes of this kernel sit in different images' columns)
+                    const int lo = max(-lx0, 0), hi = min(im.iw - lx0, 8);
+                    const uint32_t bits = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+                    vm0 = (((bits & 15u) * 0x00204081u) & 0x01010101u) * 0xffu;
+                    vm1 = (((bits >> 4) * 0x00204081u) & 0x01010101u) * 0xffu;
+                }
+                uint32_t pw_[2][6], mw[2][2];
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const int ly = ly0 + r;
+                    const bool rin = (unsigned)ly < (unsigned)im.ih;
+                    load_px8_u8(im, lx0, min(max(ly, 0), im.ih - 1), rin ? vm0 : 0u, rin ? vm1 : 0u, pw_[r], mw[r]);
+                }
+                int up[3][2][8];
+#pragma unroll
+                for (int c = 0; c < 3; c++)  // every image of this launch was fed as u8 (the launcher's condition): byte planes
+                    up_patch(reinterpret_cast<const uint8_t*>(im.g[1]) + c * im.g_plane[1], im.g_stride[1], im.fw >> 1, im.fh >> 1,
+                             (X0 - im.fx) >> 1, (Y0 - im.fy) >> 1, up[c]);
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const float w = fmul((float)byte_of(mw[r], j), INV255);
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            const int L = sat_s16((int)byte_of(pw_[r], 3 * j + c) - up[c][r][j]);
+                            acc[r][j][c] += trunc_small(fmul((float)L, w));
+                        }
+                        ws[r][j] = fadd(ws[r][j], w);
+                    }
+            }
+            if (live) level_epilogue<true>(P, X0, Y0, acc, ws);
+        }
+        g0 += nb;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Levels 1 .. B-3 of u8-sourced images (every fed image is u8x3, no received contribution strips): the reference's own
@@ -1758,6 +1879,13 @@ bool stx_fast_mb_emit_launch(stx_ctx* ctx, int cls, const MbLevelK* d_Ks, const 
     return launched_ok();
 }
 
+// STITCHING_AMD_NO_DEFER (diagnostic): grey masks through round 3's wave-level switch (mb_level_fast_kernel<true, false, false, true>)
+static bool no_defer()
+{
+    static const bool off = getenv("STITCHING_AMD_NO_DEFER") != nullptr;
+    return off;
+}
+
 bool stx_fast_mb_level(stx_ctx* ctx, const MbLevelK& K)
 {
     MbLevelK KT;
@@ -1769,6 +1897,37 @@ bool stx_fast_mb_level(stx_ctx* ctx, const MbLevelK& K)
         static const unsigned pad_lds = getenv("STITCHING_AMD_L0_LDS") ? (unsigned)atoi(getenv("STITCHING_AMD_L0_LDS")) : 0u;
         if (K.has_contrib) hipLaunchKernelGGL(mb_level0_pk_kernel<true>, grid, dim3(256), pad_lds, st, KT);
         else hipLaunchKernelGGL(mb_level0_pk_kernel<false>, grid, dim3(256), pad_lds, st, KT);
+    } else if (K.level == 0 && K.all_u8 && !K.has_contrib && !K.emit && K.num_bands > 0 && !no_defer()) {
+        // u8 images whose masks are not known to be binary (resized seam masks: the reference's default pipeline): the packed kernel
+        // with per-lane deferral + the fp32-weight pass over the queued patches.  The queue has room for every patch of the region; it
+        // and its counter come from the stream-ordered allocator and go back to it right behind the second launch.
+        // a tile holds 256 patches; segment s takes the tile columns tx = s (mod SEGS)
+        const int segs = std::min(KT.tiles.tiles_x, STX_DEFER_SEGS);
+        const size_t seg_cap = (size_t)((KT.tiles.tiles_x + STX_DEFER_SEGS - 1) / STX_DEFER_SEGS) * (size_t)KT.tiles.tiles_y * 256u;
+        const size_t counters = (size_t)STX_DEFER_SEGS * 128;
+        KT.defer_segs = segs;
+        void* q = nullptr;
+        if (stx_dev_alloc(ctx, counters + seg_cap * STX_DEFER_SEGS * sizeof(unsigned long long), &q) != STX_OK) return false;
+        KT.defer_count = reinterpret_cast<unsigned*>(q);
+        KT.defer_list = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint8_t*>(q) + counters);
+        KT.defer_cap = (unsigned)seg_cap;
+        hipMemsetAsync(q, 0, counters, st);
+        hipLaunchKernelGGL((mb_level0_pk_kernel<false, true>), grid, dim3(256), 0, st, KT);
+        {
+            StxProfScope prof2(ctx, "mb_level0_deferred", 0.0);  // inside the caller's "mb_level0" bracket: that one times both launches
+            hipLaunchKernelGGL(mb_level0_deferred_kernel, dim3(1024), dim3(256), 0, st, KT);
+        }
+        static const bool stats = getenv("STITCHING_AMD_DEFER_STATS") != nullptr;  // diagnostic: how many patches took the second pass
+        if (stats) {
+            std::vector<unsigned> hc(counters / 4);
+            hipStreamSynchronize(st);
+            hipMemcpy(hc.data(), q, counters, hipMemcpyDeviceToHost);
+            unsigned long long tot = 0; unsigned mx = 0;
+            for (int sgi = 0; sgi < segs; sgi++) { tot += hc[32 * sgi]; mx = std::max(mx, hc[32 * sgi]); }
+            fprintf(stderr, "[stitching_amd] level-0 deferral: %llu of %llu patches queued (%d segments, fullest %u of %zu)\n", tot,
+                    (unsigned long long)KT.tiles.tiles_x * KT.tiles.tiles_y * 256ull, segs, mx, seg_cap);
+        }
+        stx_dev_free(ctx, q);
     } else if (K.emit) {
         if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, true, false>), grid, dim3(256), 0, st, KT);
         else if (K.all_u8) hipLaunchKernelGGL((mb_level_fast_kernel<false, false, true, true>), grid, dim3(256), 0, st, KT);

@@ -28,6 +28,7 @@ inline unsigned stx_tile_grid(const StxTileMap& m)
     return 8u * (unsigned)(((bands + 7) / 8) * m.band_tiles);
 }
 
+constexpr int STX_DEFER_SEGS = 256;
 struct MbLevelK {
     const StxMbImage* images;
     int n_images, level, num_bands, pw, ph;  // pw, ph: padded panorama size at this level (pyrUp border rule)
@@ -47,12 +48,24 @@ struct MbLevelK {
     int all_u8;  // every level-0 source is u8x3 (the fast level-0 kernel has no int16 loader)
     StxTileMap tiles;  // fast kernels: XCD-aware order of the 512 x 8 tiles
     int pk_ok;   // every image is kind 0, u8x3, with a mask known to hold only 0 / 255 (packed 16-bit kernels)
+    // level 0 with masks that MAY hold grey bytes (resized seam masks: grey along the seams only): the packed kernel runs on every lane
+    // and a lane that meets a grey byte under its 8 x 2 patch appends the patch origin (x | y << 32) here instead of storing; a second,
+    // small launch computes those patches with fp32 weights (mb_level0_deferred_kernel).  null: no deferral.
+    // The queue is cut into segments, one per COLUMN of 512-pixel tiles (tile column tx -> segment tx % STX_DEFER_SEGS; counter s at
+    // defer_count[32 s], its own 128-byte line).  Two measured reasons: (i) one word takes ~88 returning atomics per microsecond on this
+    // chip and a fifth of the wavefronts of the default pipeline queue something — 21 000 atomics on ONE counter cost 60 us; (ii) the 64
+    // patches of a wavefront of the second pass then lie in one 512-pixel column, under the same two or three images — scattered over
+    // the panorama every wavefront walked all images, one dependent memory round trip after the other, alone on its SIMD: another 60 us.
+    // defer_cap: entries per segment (room for every patch of the tile columns that map to it); defer_segs: segments in use.
+    int defer_segs;
+    unsigned long long* defer_list; unsigned* defer_count; unsigned defer_cap;
 };
 
 // fast-path launchers (stx_blend_fast.hip); each returns false when its alignment / size
 // preconditions do not hold and the generic kernel must be used instead.
 bool stx_fast_mb_down_batch(stx_ctx* ctx, const StxMbImage* d_images, const StxMbImage* h_images, int n, int level);
 bool stx_fast_mb_level(stx_ctx* ctx, const MbLevelK& K);
+
 // batched strip export: see stx_blend_fast.hip
 int stx_fast_mb_emit_class(const MbLevelK& K, MbLevelK* KT);
 bool stx_fast_mb_emit_launch(stx_ctx* ctx, int cls, const MbLevelK* d_Ks, const MbLevelK* h_Ks, int count);
