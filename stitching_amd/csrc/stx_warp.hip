@@ -35,9 +35,11 @@ constexpr int WARP_TH = 4;    // tile height (4 waves x 1 row)
 #endif
 constexpr int WARP_IT = STX_WARP_IT;
 constexpr int WARP_FTH = WARP_TH * WARP_IT;  // tile height of the fast kernel
-// wavefronts per workgroup of the fast kernel (they share nothing: no workgroup barrier, LDS per wavefront): its tile is 64 x this wide
+// wavefronts per workgroup of the fast kernel (they share nothing: no workgroup barrier, LDS per wavefront): its tile is 64 x this wide.
+// Measured (round 4, one box, interleaved, config 2): 1: 175.8 / 174.2 us, 2: 177.0 / 177.0, 4: 178.4 / 178.8, 8: 193.9 / 191.2 — a
+// wavefront that finishes frees its slot for the next workgroup at once instead of waiting for its three siblings.
 #ifndef STX_WARP_WAVES
-#define STX_WARP_WAVES 4
+#define STX_WARP_WAVES 1
 #endif
 constexpr int WARP_FW = 64 * STX_WARP_WAVES;
 constexpr int WARP_BAND = 4;  // tile rows per XCD band (fast kernel); measured 1: 548, 2: 424, 4: 360, 8: 327, 16: 311 MB fetched
