@@ -273,7 +273,15 @@ STX_DEV int h5i(int s0, int s1, int s2, int s3, int s4) { return s2 * 6 + (s1 + 
 // two full passes of the 256 threads (16 rows would leave a third, 9 %-full pass)
 constexpr int DN_TOW = 64, DN_TOH = 14, DN_ROWS = 2 * DN_TOH + 3;
 constexpr int DN_BAND = 2;  // tile rows per XCD band
-constexpr int LV_BAND = 4;  // same for the 512 x 8 tiles of the level kernels
+// The gather kernels of the levels: a wavefront owns 512 x 2 samples and shares nothing with its siblings (no LDS, no barrier), so a
+// workgroup is LV_WAVES independent wavefronts and the tile 512 x LV_TH.  One wavefront per workgroup: a wavefront that finishes frees
+// its slot at once instead of waiting for three siblings (level 0 of config 2: 176.5 / 176.4 us against 180.7 / 181.0 with four, 178.9 /
+// 178.3 with two; interleaved A/B on one box, round 4).
+#ifndef STX_LV_WG_WAVES
+#define STX_LV_WG_WAVES 1
+#endif
+constexpr int LV_WAVES = STX_LV_WG_WAVES, LV_TH = 2 * LV_WAVES, LV_THREADS = 64 * LV_WAVES;
+constexpr int LV_BAND = 32 / LV_TH;  // tile rows per XCD band: 32 sample rows
 
 // level 0 (u8 BGR + u8 mask): 4 outputs from 11 input pixels
 // PK: every image of the launch is u8 with a 0 / 255 mask (decided on the host: no per-task branch in the kernel)
@@ -827,7 +835,7 @@ STX_DEV void mb_level_fast_body(const MbLevelK& P)
     const int lv = P.level;
     int tile_tx, tile_ty;
     if (!xcd_tile(P.tiles, blockIdx.x, tile_tx, tile_ty)) return;
-    const int tile_x = P.x0 + tile_tx * 512, tile_y = P.y0 + tile_ty * 8;
+    const int tile_x = P.x0 + tile_tx * 512, tile_y = P.y0 + tile_ty * LV_TH;
     // a wavefront owns two rows: its row index is wave-uniform, and saying so (readfirstlane) moves every row test, row
     // offset and row pointer below to the scalar unit
     const int X0 = tile_x + (tid & 63) * 8, Y0 = tile_y + __builtin_amdgcn_readfirstlane(tid >> 6) * 2;
@@ -1155,7 +1163,7 @@ STX_DEV void mb_level_fast_body(const MbLevelK& P)
 }
 
 template <bool L0, bool CONTRIB, bool EMIT, bool U8SRC>
-__global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
+__global__ __launch_bounds__(LV_THREADS) void mb_level_fast_kernel(MbLevelK P)
 {
     mb_level_fast_body<L0, CONTRIB, EMIT, U8SRC>(P);
 }
@@ -1164,7 +1172,7 @@ __global__ __launch_bounds__(256) void mb_level_fast_kernel(MbLevelK P)
 // Strip export for sharded blending: ONE launch for all (strip, level) pairs that take the same instantiation; blockIdx.z
 // picks the argument block from a device array, blocks beyond a member's own tile grid leave at once.
 template <bool L0, bool U8SRC>
-__global__ __launch_bounds__(256) void mb_emit_multi_kernel(const MbLevelK* __restrict__ Ps)
+__global__ __launch_bounds__(LV_THREADS) void mb_emit_multi_kernel(const MbLevelK* __restrict__ Ps)
 {
     mb_level_fast_body<L0, false, true, U8SRC>(Ps[blockIdx.z]);
 }
@@ -1359,12 +1367,12 @@ STX_DEV void level0_epilogue_pk(const MbLevelK& P, int X0, int Y0, uint32_t (&ac
 // storing.  A resized seam mask is grey along the seams only: 1 - 2 % of the lanes (round 3 switched the WHOLE wavefront to fp32 sums at
 // its first grey byte: 40 % of the wavefronts of the default pipeline).
 template <bool CONTRIB, bool DEFER = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVES, 8))) void mb_level0_pk_kernel(MbLevelK P)
+__global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(STX_L0_WAVES, 8))) void mb_level0_pk_kernel(MbLevelK P)
 {
     const int tid = threadIdx.x;
     int tile_tx, tile_ty;
     if (!xcd_tile(P.tiles, blockIdx.x, tile_tx, tile_ty)) return;
-    const int tile_x = P.x0 + tile_tx * 512, tile_y = P.y0 + tile_ty * 8;
+    const int tile_x = P.x0 + tile_tx * 512, tile_y = P.y0 + tile_ty * LV_TH;
     const int X0 = tile_x + (tid & 63) * 8, Y0 = tile_y + __builtin_amdgcn_readfirstlane(tid >> 6) * 2;  // Y0: wave-uniform (scalar)
     const bool active = X0 < P.x1 && Y0 < P.y1;
 
@@ -1628,13 +1636,13 @@ __global__ __launch_bounds__(256) void mb_level0_deferred_kernel(MbLevelK P)
 STX_DEV uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) { return min(min(a, b), c); }
 STX_DEV uint32_t max3u(uint32_t a, uint32_t b, uint32_t c) { return max(max(a, b), c); }
 
-__global__ __launch_bounds__(256) void mb_level_pk_kernel(MbLevelK P)
+__global__ __launch_bounds__(LV_THREADS) void mb_level_pk_kernel(MbLevelK P)
 {
     const int tid = threadIdx.x;
     const int lv = P.level;
     int tile_tx, tile_ty;
     if (!xcd_tile(P.tiles, blockIdx.x, tile_tx, tile_ty)) return;
-    const int tile_x = P.x0 + tile_tx * 512, tile_y = P.y0 + tile_ty * 8;
+    const int tile_x = P.x0 + tile_tx * 512, tile_y = P.y0 + tile_ty * LV_TH;
     const int X0 = tile_x + (tid & 63) * 8, Y0 = tile_y + __builtin_amdgcn_readfirstlane(tid >> 6) * 2;  // Y0: wave-uniform
     const bool active = X0 < P.x1 && Y0 < P.y1;
 
@@ -1855,7 +1863,7 @@ static bool fast_level_ok(const MbLevelK& K, MbLevelK* KT)
     if (K.n_images > 255) return false;
     // vertically adjacent 512 x 8 tiles share the G_{i+1} / finished-level rows of their pyrUp halos: keep them on one XCD
     *KT = K;
-    KT->tiles = stx_tile_map((K.x1 - K.x0 + 511) / 512, (K.y1 - K.y0 + 7) / 8, LV_BAND);
+    KT->tiles = stx_tile_map((K.x1 - K.x0 + 511) / 512, (K.y1 - K.y0 + LV_TH - 1) / LV_TH, LV_BAND);
     return true;
 }
 
@@ -1873,9 +1881,9 @@ bool stx_fast_mb_emit_launch(stx_ctx* ctx, int cls, const MbLevelK* d_Ks, const 
     unsigned gx = 1;
     for (int i = 0; i < count; i++) gx = std::max(gx, stx_tile_grid(h_Ks[i].tiles));
     const dim3 grid(gx, 1, (unsigned)count);
-    if (cls == 0) hipLaunchKernelGGL((mb_emit_multi_kernel<true, false>), grid, dim3(256), 0, ctx->stream, d_Ks);
-    else if (cls == 1) hipLaunchKernelGGL((mb_emit_multi_kernel<false, true>), grid, dim3(256), 0, ctx->stream, d_Ks);
-    else hipLaunchKernelGGL((mb_emit_multi_kernel<false, false>), grid, dim3(256), 0, ctx->stream, d_Ks);
+    if (cls == 0) hipLaunchKernelGGL((mb_emit_multi_kernel<true, false>), grid, dim3(LV_THREADS), 0, ctx->stream, d_Ks);
+    else if (cls == 1) hipLaunchKernelGGL((mb_emit_multi_kernel<false, true>), grid, dim3(LV_THREADS), 0, ctx->stream, d_Ks);
+    else hipLaunchKernelGGL((mb_emit_multi_kernel<false, false>), grid, dim3(LV_THREADS), 0, ctx->stream, d_Ks);
     return launched_ok();
 }
 
@@ -1895,15 +1903,15 @@ bool stx_fast_mb_level(stx_ctx* ctx, const MbLevelK& K)
     if (K.level == 0 && K.pk_ok && !K.emit && K.num_bands > 0) {
         // STITCHING_AMD_L0_LDS (diagnostic): dynamic LDS as an occupancy limit, see stx_warp.hip
         static const unsigned pad_lds = getenv("STITCHING_AMD_L0_LDS") ? (unsigned)atoi(getenv("STITCHING_AMD_L0_LDS")) : 0u;
-        if (K.has_contrib) hipLaunchKernelGGL(mb_level0_pk_kernel<true>, grid, dim3(256), pad_lds, st, KT);
-        else hipLaunchKernelGGL(mb_level0_pk_kernel<false>, grid, dim3(256), pad_lds, st, KT);
+        if (K.has_contrib) hipLaunchKernelGGL(mb_level0_pk_kernel<true>, grid, dim3(LV_THREADS), pad_lds, st, KT);
+        else hipLaunchKernelGGL(mb_level0_pk_kernel<false>, grid, dim3(LV_THREADS), pad_lds, st, KT);
     } else if (K.level == 0 && K.all_u8 && !K.has_contrib && !K.emit && K.num_bands > 0 && !no_defer()) {
         // u8 images whose masks are not known to be binary (resized seam masks: the reference's default pipeline): the packed kernel
         // with per-lane deferral + the fp32-weight pass over the queued patches.  The queue has room for every patch of the region; it
         // and its counter come from the stream-ordered allocator and go back to it right behind the second launch.
-        // a tile holds 256 patches; segment s takes the tile columns tx = s (mod SEGS)
+        // a tile holds at most 256 patches; segment s takes the tile columns tx = s (mod SEGS)
         const int segs = std::min(KT.tiles.tiles_x, STX_DEFER_SEGS);
-        const size_t seg_cap = (size_t)((KT.tiles.tiles_x + STX_DEFER_SEGS - 1) / STX_DEFER_SEGS) * (size_t)KT.tiles.tiles_y * 256u;
+        const size_t seg_cap = (size_t)((KT.tiles.tiles_x + STX_DEFER_SEGS - 1) / STX_DEFER_SEGS) * (size_t)KT.tiles.tiles_y * (unsigned)LV_THREADS;
         const size_t counters = (size_t)STX_DEFER_SEGS * 128;
         KT.defer_segs = segs;
         void* q = nullptr;
@@ -1912,7 +1920,7 @@ bool stx_fast_mb_level(stx_ctx* ctx, const MbLevelK& K)
         KT.defer_list = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint8_t*>(q) + counters);
         KT.defer_cap = (unsigned)seg_cap;
         hipMemsetAsync(q, 0, counters, st);
-        hipLaunchKernelGGL((mb_level0_pk_kernel<false, true>), grid, dim3(256), 0, st, KT);
+        hipLaunchKernelGGL((mb_level0_pk_kernel<false, true>), grid, dim3(LV_THREADS), 0, st, KT);
         {
             StxProfScope prof2(ctx, "mb_level0_deferred", 0.0);  // inside the caller's "mb_level0" bracket: that one times both launches
             hipLaunchKernelGGL(mb_level0_deferred_kernel, dim3(1024), dim3(256), 0, st, KT);
@@ -1925,25 +1933,25 @@ bool stx_fast_mb_level(stx_ctx* ctx, const MbLevelK& K)
             unsigned long long tot = 0; unsigned mx = 0;
             for (int sgi = 0; sgi < segs; sgi++) { tot += hc[32 * sgi]; mx = std::max(mx, hc[32 * sgi]); }
             fprintf(stderr, "[stitching_amd] level-0 deferral: %llu of %llu patches queued (%d segments, fullest %u of %zu)\n", tot,
-                    (unsigned long long)KT.tiles.tiles_x * KT.tiles.tiles_y * 256ull, segs, mx, seg_cap);
+                    (unsigned long long)KT.tiles.tiles_x * KT.tiles.tiles_y * (unsigned long long)LV_THREADS, segs, mx, seg_cap);
         }
         stx_dev_free(ctx, q);
     } else if (K.emit) {
-        if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, true, false>), grid, dim3(256), 0, st, KT);
-        else if (K.all_u8) hipLaunchKernelGGL((mb_level_fast_kernel<false, false, true, true>), grid, dim3(256), 0, st, KT);
-        else hipLaunchKernelGGL((mb_level_fast_kernel<false, false, true, false>), grid, dim3(256), 0, st, KT);
+        if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, true, false>), grid, dim3(LV_THREADS), 0, st, KT);
+        else if (K.all_u8) hipLaunchKernelGGL((mb_level_fast_kernel<false, false, true, true>), grid, dim3(LV_THREADS), 0, st, KT);
+        else hipLaunchKernelGGL((mb_level_fast_kernel<false, false, true, false>), grid, dim3(LV_THREADS), 0, st, KT);
     } else if (K.has_contrib) {
-        if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, true, false, false>), grid, dim3(256), 0, st, KT);
-        else if (K.all_u8) hipLaunchKernelGGL((mb_level_fast_kernel<false, true, false, true>), grid, dim3(256), 0, st, KT);
-        else hipLaunchKernelGGL((mb_level_fast_kernel<false, true, false, false>), grid, dim3(256), 0, st, KT);
+        if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, true, false, false>), grid, dim3(LV_THREADS), 0, st, KT);
+        else if (K.all_u8) hipLaunchKernelGGL((mb_level_fast_kernel<false, true, false, true>), grid, dim3(LV_THREADS), 0, st, KT);
+        else hipLaunchKernelGGL((mb_level_fast_kernel<false, true, false, false>), grid, dim3(LV_THREADS), 0, st, KT);
     } else {
         static const bool no_pk_levels = getenv("STITCHING_AMD_NO_PK_LEVELS") != nullptr;  // diagnostic: A/B against mb_level_fast_kernel
         // (4 waves per SIMD at 121 registers; forced to 5 it spills 19 of them: 309 against 203 us on the resized-seam-mask leg)
-        if (K.level == 0 && K.all_u8 && K.num_bands > 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, false, true>), grid, dim3(256), 0, st, KT);
-        else if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, false, false>), grid, dim3(256), 0, st, KT);
-        else if (K.all_u8 && K.level < K.num_bands && !no_pk_levels) hipLaunchKernelGGL(mb_level_pk_kernel, grid, dim3(256), 0, st, KT);
-        else if (K.all_u8) hipLaunchKernelGGL((mb_level_fast_kernel<false, false, false, true>), grid, dim3(256), 0, st, KT);
-        else hipLaunchKernelGGL((mb_level_fast_kernel<false, false, false, false>), grid, dim3(256), 0, st, KT);
+        if (K.level == 0 && K.all_u8 && K.num_bands > 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, false, true>), grid, dim3(LV_THREADS), 0, st, KT);
+        else if (K.level == 0) hipLaunchKernelGGL((mb_level_fast_kernel<true, false, false, false>), grid, dim3(LV_THREADS), 0, st, KT);
+        else if (K.all_u8 && K.level < K.num_bands && !no_pk_levels) hipLaunchKernelGGL(mb_level_pk_kernel, grid, dim3(LV_THREADS), 0, st, KT);
+        else if (K.all_u8) hipLaunchKernelGGL((mb_level_fast_kernel<false, false, false, true>), grid, dim3(LV_THREADS), 0, st, KT);
+        else hipLaunchKernelGGL((mb_level_fast_kernel<false, false, false, false>), grid, dim3(LV_THREADS), 0, st, KT);
     }
     return launched_ok();
 }
