@@ -19,7 +19,7 @@ done
 python tools/make_traffic_json.py "$OUT" "$OUT/traffic.json"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o kt -- python bench.py --no-cpu-baseline --no-extra --min-seconds 0 --e2e-steps 0 --steps 20 --warmup 3 --streams 1 > "$OUT/bench_kt.log" 2>&1; echo "rocprof rc=$?"
 cat "$OUT/kt_kernel_stats.csv"
-cp "$OUT/traffic.json" profiles/r03_traffic.json
+cp "$OUT/traffic.json" profiles/r04_traffic.json
 bash tools/prof_pmc_lite.sh ${TAG}_sq --streams 1 > /dev/null 2>&1; cp gpurun_out/${TAG}_sq/summary.txt "$OUT/sq_summary.txt"
 timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
 cat "$OUT/bench.json"

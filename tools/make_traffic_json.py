@@ -28,8 +28,8 @@ def kernel_source_hash():
                     h.update(code.encode() + b"\n")
     return h.hexdigest()[:16]
 
-NAMES = [("warp_fast_kernel<3, true, true>", "warp_img_mask"), ("warp_fast_kernel<2, true, true>", "warp_img_mask"),
-         ("warp_fast_kernel<0, true, true>", "warp_img_mask"), ("mb_level0_pk_kernel", "mb_level0"),
+NAMES = [("warp_fast_kernel<3, true, true", "warp_img_mask"), ("warp_fast_kernel<2, true, true", "warp_img_mask"),
+         ("warp_fast_kernel<0, true, true", "warp_img_mask"), ("mb_level0_pk_kernel", "mb_level0"),
          ("mb_down0_lds_kernel", "mb_down0"), ("mb_down_lds_kernel", "mb_down"), ("warp_tables_kernel", "warp_tables"),
          ("mb_level_pk_kernel", "mb_level"), ("mb_coarse_kernel", "mb_coarse"), ("roi_kernel", "warp_roi"), ("mb_down_tail_kernel", "mb_down_tail")]
 
