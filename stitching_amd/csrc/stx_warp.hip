@@ -25,11 +25,12 @@ namespace {
 
 constexpr int WARP_TW = 256;  // tile width  (64 lanes x 4 px)
 constexpr int WARP_TH = 4;    // tile height (4 waves x 1 row)
-// fast kernel: a wavefront takes WARP_IT blocks of WARP_TH rows of its 64 columns one after the other (tile 256 x WARP_IT * WARP_TH): the
-// per-image scalars, the tile index and the column table entry are then fetched once for all of them.  Measured (round 3, A/B on one
-// box): 2 blocks per wavefront 212 us against 180 us with 1 — gfx9 has one vmcnt for loads and stores, so the second block's sample
-// loads cannot be waited for without also waiting for the first block's stores; a one-block wavefront just ends behind its stores.
-// 1 it stays; the loop is kept for the experiment (-DSTX_WARP_IT=2).
+// fast kernel: a wavefront takes WARP_IT blocks of WARP_TH rows of its 64 columns one after the other (tile 64 x WARP_IT * WARP_TH): the
+// per-image scalars, the tile index and the column table entry are then fetched once for all of them.  Measured: round 3, stores after
+// every block: 2 blocks per wavefront 212 us against 180 us with 1 — gfx9 has one vmcnt for loads and stores, so the second block's
+// sample loads could not be waited for without also waiting for the first block's stores.  Round 4 samples every block before the first
+// result leaves (the stores follow the loop): 179.4 / 182.8 us with 2 blocks against 177.5 / 178.1 with 1 — the diagnosis was right and
+// the prologue it saves is worth nothing measurable.  1 it stays (-DSTX_WARP_IT=2 builds the other).
 #ifndef STX_WARP_IT
 #define STX_WARP_IT 1
 #endif
@@ -415,6 +416,7 @@ STX_DEV uint32_t sample_border(const STX_GAS uint8_t* src, uint32_t stride, int 
 #ifndef STX_WARP_UNALIGNED
 #define STX_WARP_UNALIGNED 0
 #endif
+
 STX_DEV uint32_t lshl_add_u32(uint32_t a, uint32_t b)  // (a << 1) + b, as ONE v_lshl_add_u32 (LLVM folds (x << 1) + x back into a multiply)
 {
     uint32_t d;
@@ -539,8 +541,8 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     // row constants are wave-uniform.  The 3-byte results go through LDS to leave as whole dwords: 768 + 256 bytes per
     // wavefront, written bytewise, read back as the 192 + 64 dwords of the wavefront's 4 rows.  Only the wavefront
     // itself reads what it wrote (LDS operations of one wavefront execute in order): no workgroup barrier.
-    __shared__ uint32_t s_px[STX_WARP_WAVES][WARP_TH][48];  // [wavefront][row][dword]: 64 px x 3 B
-    __shared__ uint32_t s_mk[STX_WARP_WAVES][WARP_TH][16];  // [wavefront][row][dword]: 64 px x 1 B
+    __shared__ uint32_t s_px[STX_WARP_WAVES][WARP_FTH][48];  // [wavefront][row][dword]: 64 px x 3 B
+    __shared__ uint32_t s_mk[STX_WARP_WAVES][WARP_FTH][16];  // [wavefront][row][dword]: 64 px x 1 B
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, and known to be
     const int xw = tile_x * WARP_FW + wv * 64;  // first column of this wavefront
     // columns beyond the image are computed on the clamped table entry, rows beyond it on the repeated last row
@@ -554,13 +556,18 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
         else { r2 = P.c2; r5 = P.c5; r8 = P.c8; }
     }
     const STX_GAS uint8_t* src = (const STX_GAS uint8_t*)src_a;
-    uint8_t* const lpx = reinterpret_cast<uint8_t*>(&s_px[wv][0][0]) + lane * 3;  // + 192 per row, + channel
-    uint8_t* const lmk = reinterpret_cast<uint8_t*>(&s_mk[wv][0][0]) + lane;      // + 64 per row
-#pragma unroll 1
+    uint8_t* const lpx0 = reinterpret_cast<uint8_t*>(&s_px[wv][0][0]) + lane * 3;  // + 192 per row, + channel
+    uint8_t* const lmk0 = reinterpret_cast<uint8_t*>(&s_mk[wv][0][0]) + lane;      // + 64 per row
+    uint32_t int_blocks = 0u;  // bit `it`: block `it` of this wavefront took the interior path (its mask is all 255)
+    int n_blocks = 0;
+#pragma unroll
   for (int it = 0; it < WARP_IT; it++) {
     const int row_blk = tile_y * WARP_IT + it;  // block of WARP_TH rows
     const int y0 = row_blk * WARP_TH;
     if (it > 0 && y0 >= dh) break;
+    n_blocks = it + 1;
+    uint8_t* const lpx = lpx0 + 768 * it;  // this block's 4 staging rows
+    uint8_t* const lmk = lmk0 + 256 * it;
     // The wavefront's 4 rows as two row pairs: every step below is a packed fp32 operation on (row 2h, row 2h + 1).
     // Row constants: one 64-byte block {ra x4}, {p1 x4}, {p4 x4}, {p7 x4} per block of rows, a single scalar load.
     const v4f RA = rowT[4 * row_blk], P1 = rowT[4 * row_blk + 1], P4 = rowT[4 * row_blk + 2], P7 = rowT[4 * row_blk + 3];
@@ -651,8 +658,7 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 reinterpret_cast<float*>((uint8_t*)dmask_a + (long long)(y0 + j) * dmask_stride)[col] = (j & 1) ? Y[j >> 1].y : Y[j >> 1].x;
             }
         }
-        continue;
-    }
+    } else {
     // 32 x, 32 y (exact) and their cvRound as bit patterns
     uint32_t ux[4], uy[4];
     float xs[4], ys[4];
@@ -721,17 +727,28 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
             }
         }
     }
+    int_blocks |= (wave_int ? 1u : 0u) << it;
+    }  // !DBG
+  }
+    if (DBG) return;
+    // Every block of rows is sampled before the first result leaves: gfx9 counts loads and stores in ONE vmcnt, so a store issued
+    // between two blocks would sit in front of the second block's sample loads and the wavefront would wait out a store round trip.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // The wavefront's 4 x 192 bytes (4 x 64 of the mask) sit in LDS in the order lane * 12 (lane * 4): lane = 16 r + c
-    // stores the 12 (4) bytes at column offset 12 c (4 c) of row r — one 12-byte and one 4-byte store per lane.
+    // A block's 4 x 192 bytes (4 x 64 of the mask) sit in LDS in the order lane * 12 (lane * 4): lane = 16 r + c
+    // stores the 12 (4) bytes at column offset 12 c (4 c) of row r — one 12-byte and one 4-byte store per lane and block.
     const int r = lane >> 4, c = lane & 15;
+#pragma unroll
+  for (int it = 0; it < WARP_IT; it++) {
+    if (it >= n_blocks) break;
+    const int y0 = (tile_y * WARP_IT + it) * WARP_TH;
+    const bool wave_int = (int_blocks >> it) & 1u;
     const bool full = y0 + WARP_TH <= dh && (long long)xw * 3 + 192 <= dimg_stride && dimg_stride < (1ll << 24) &&
                       (long long)xw + 64 <= dmask_stride && dmask_stride < (1ll << 24);
     if (full) {
         if (IMG) {
-            const uint32_t* sp = &s_px[wv][0][0] + lane * 3;
+            const uint32_t* sp = &s_px[wv][4 * it][0] + lane * 3;
             STX_GAS uint8_t* base = (STX_GAS uint8_t*)(dimg_a + (unsigned long long)y0 * (unsigned long long)dimg_stride + (unsigned long long)xw * 3ull);
             STX_GAS uint32_t* d = reinterpret_cast<STX_GAS uint32_t*>(base + (__umul24((uint32_t)r, (uint32_t)dimg_stride) + (uint32_t)c * 12u));
             const uint32_t a0 = sp[0], a1 = sp[1], a2 = sp[2];
@@ -740,7 +757,7 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
         if (MASK) {
             STX_GAS uint8_t* base = (STX_GAS uint8_t*)(dmask_a + (unsigned long long)y0 * (unsigned long long)dmask_stride + (unsigned long long)xw);
             *reinterpret_cast<STX_GAS uint32_t*>(base + (__umul24((uint32_t)r, (uint32_t)dmask_stride) + (uint32_t)c * 4u)) =
-                wave_int ? 0xffffffffu : s_mk[wv][r][c];
+                wave_int ? 0xffffffffu : s_mk[wv][4 * it + r][c];
         }
     } else {
         if (IMG) {
@@ -750,20 +767,15 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
             for (int k = 0; k < 3; k++) {
                 const int idx = lane + 64 * k, rr = idx / 48, cdw = idx - rr * 48;
                 if (y0 + rr < dh && (long long)xw * 3 + cdw * 4 + 4 <= dimg_stride)
-                    *reinterpret_cast<uint32_t*>(drow + (long long)(y0 + rr) * dimg_stride + cdw * 4) = s_px[wv][rr][cdw];
+                    *reinterpret_cast<uint32_t*>(drow + (long long)(y0 + rr) * dimg_stride + cdw * 4) = s_px[wv][4 * it + rr][cdw];
             }
         }
         if (MASK) {
             if (y0 + r < dh && (long long)xw + c * 4 + 4 <= dmask_stride)
                 *reinterpret_cast<uint32_t*>((uint8_t*)dmask_a + (long long)(y0 + r) * dmask_stride + xw + c * 4) =
-                    wave_int ? 0xffffffffu : s_mk[wv][r][c];
+                    wave_int ? 0xffffffffu : s_mk[wv][4 * it + r][c];
         }
     }
-    // the next block of rows overwrites the staging rows: this wavefront's reads above come first (LDS operations of one wavefront
-    // execute in order; the compiler is told)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
