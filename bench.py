@@ -60,7 +60,7 @@ def parse():
     p.add_argument("--streams", type=int, default=2, help="panoramas in flight per GPU (contexts = HIP streams); N = 1 "
                    "measured: 1 -> 93.0, 2 -> 105.9, 3 -> 99.6 Gpix/s")
     p.add_argument("--e2e-steps", type=int, default=2, help="PCIe-inclusive passes (host frames in, host panorama out)")
-    p.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r03_traffic.json"),
+    p.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r04_traffic.json"),
                    help="JSON with PMC-derived HBM bytes per launch (tools/make_traffic_json.py)")
     return p.parse_args()
 
