@@ -17,7 +17,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT" -o pmc_$C -- $BENCHQ > "$OUT/pmc_$C.log" 2>&1 || echo "pmc $C failed"
 done
 python tools/make_traffic_json.py "$OUT" "$OUT/traffic.json"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o kt -- python bench.py --no-cpu-baseline --no-extra --min-seconds 0 --e2e-steps 0 --steps 20 --warmup 3 --streams 1 > "$OUT/bench_kt.log" 2>&1; echo "rocprof rc=$?"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o kt -- python bench.py --no-cpu-baseline --no-extra --min-seconds 0 --e2e-steps 0 --steps 80 --warmup 20 --streams 1 --profile-steps 10 > "$OUT/bench_kt.log" 2>&1; echo "rocprof rc=$?"
 cat "$OUT/kt_kernel_stats.csv"
 cp "$OUT/traffic.json" profiles/r04_traffic.json
 bash tools/prof_pmc_lite.sh ${TAG}_sq --streams 1 > /dev/null 2>&1; cp gpurun_out/${TAG}_sq/summary.txt "$OUT/sq_summary.txt"
