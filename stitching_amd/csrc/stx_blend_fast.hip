@@ -272,7 +272,12 @@ STX_DEV int h5i(int s0, int s1, int s2, int s3, int s4) { return s2 * 6 + (s1 + 
 // 64 x 14 outputs: the 31 input rows give 31*8 = 248 (levels >= 1) / 31*16 = 496 (level 0) load tasks, i.e. one /
 // two full passes of the 256 threads (16 rows would leave a third, 9 %-full pass)
 constexpr int DN_TOW = 64, DN_TOH = 14, DN_ROWS = 2 * DN_TOH + 3;
-constexpr int DN_BAND = 2;  // tile rows per XCD band
+// tile rows (of 14 output rows) per XCD band of the level-0 pyrDown.  Round 4, interleaved: 1: 127.8 / 127.0 us, 2: 131.9 / 132.1, 4: 144.2 / 142.2;
+// the plain row-major order 129.2 / 126.8 at 1.6 x the fetched bytes
+#ifndef STX_DN_BAND
+#define STX_DN_BAND 1
+#endif
+constexpr int DN_BAND = STX_DN_BAND;
 // The gather kernels of the levels: a wavefront owns 512 x 2 samples and shares nothing with its siblings (no LDS, no barrier), so a
 // workgroup is LV_WAVES independent wavefronts and the tile 512 x LV_TH.  One wavefront per workgroup: a wavefront that finishes frees
 // its slot at once instead of waiting for three siblings (level 0 of config 2: 176.5 / 176.4 us against 180.7 / 181.0 with four, 178.9 /
@@ -281,7 +286,12 @@ constexpr int DN_BAND = 2;  // tile rows per XCD band
 #define STX_LV_WG_WAVES 1
 #endif
 constexpr int LV_WAVES = STX_LV_WG_WAVES, LV_TH = 2 * LV_WAVES, LV_THREADS = 64 * LV_WAVES;
-constexpr int LV_BAND = 32 / LV_TH;  // tile rows per XCD band: 32 sample rows
+// sample rows per XCD band of the gather kernels.  Measured with one-wavefront workgroups (round 4, interleaved, level 0 of config 2):
+// 64: 181.1 / 180.7 us, 32: 175.9 / 175.9, 16: 172.4 / 174.5, 8: 170.4 / 173.1, 4: 171.0 / 173.1
+#ifndef STX_LV_BAND_ROWS
+#define STX_LV_BAND_ROWS 8
+#endif
+constexpr int LV_BAND = STX_LV_BAND_ROWS / LV_TH;  // tile rows per XCD band
 
 // level 0 (u8 BGR + u8 mask): 4 outputs from 11 input pixels
 // PK: every image of the launch is u8 with a 0 / 255 mask (decided on the host: no per-task branch in the kernel)

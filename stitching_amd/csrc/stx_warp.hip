@@ -43,7 +43,10 @@ constexpr int WARP_FTH = WARP_TH * WARP_IT;  // tile height of the fast kernel
 #define STX_WARP_WAVES 1
 #endif
 constexpr int WARP_FW = 64 * STX_WARP_WAVES;
-constexpr int WARP_BAND = 4;  // tile rows per XCD band (fast kernel); measured 1: 548, 2: 424, 4: 360, 8: 327, 16: 311 MB fetched
+#ifndef STX_WARP_BAND
+#define STX_WARP_BAND 4
+#endif
+constexpr int WARP_BAND = STX_WARP_BAND;  // tile rows per XCD band (fast kernel); measured 1: 548, 2: 424, 4: 360, 8: 327, 16: 311 MB fetched
 constexpr float PI_F = 3.14159274101257324f;  // static_cast<float>(CV_PI)
 
 struct WarpK {
