@@ -52,10 +52,12 @@ struct MbLevelK {
     // and a lane that meets a grey byte under its 8 x 2 patch appends the patch origin (x | y << 32) here instead of storing; a second,
     // small launch computes those patches with fp32 weights (mb_level0_deferred_kernel).  null: no deferral.
     // The queue is cut into segments, one per COLUMN of 512-pixel tiles (tile column tx -> segment tx % STX_DEFER_SEGS; counter s at
-    // defer_count[32 s], its own 128-byte line).  Two measured reasons: (i) one word takes ~88 returning atomics per microsecond on this
-    // chip and a fifth of the wavefronts of the default pipeline queue something — 21 000 atomics on ONE counter cost 60 us; (ii) the 64
+    // defer_count[32 s], its own 128-byte line).  Why: (i) one word takes ~88 returning atomics per microsecond on this chip (the
+    // guide's price) and a fifth of the wavefronts of the default pipeline queue something: 21 000 wavefront-aggregated atomics
+    // would be a fifth of a millisecond if they all met on one counter — a precaution; measured, the single counter was NOT what
+    // made the first version slow (232 us with one counter, 241 us with 256 of them: what hurt was the second pass); (ii) the 64
     // patches of a wavefront of the second pass then lie in one 512-pixel column, under the same two or three images — scattered over
-    // the panorama every wavefront walked all images, one dependent memory round trip after the other, alone on its SIMD: another 60 us.
+    // the panorama every wavefront walked all images, one dependent memory round trip after the other, alone on its SIMD (80 us).
     // defer_cap: entries per segment (room for every patch of the tile columns that map to it); defer_segs: segments in use.
     int defer_segs;
     unsigned long long* defer_list; unsigned* defer_count; unsigned defer_cap;
