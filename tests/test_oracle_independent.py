@@ -236,3 +236,179 @@ def test_bilinear_tab_is_the_outer_product(oracle):
     assert np.array_equal(t.sum(axis=2), np.full((32, 32), 32768))
     d = t - ref
     assert np.count_nonzero(d) <= 2 and np.abs(d).max() <= 1  # (0, 0): 32768 does not fit a short -> 32767 + 1 elsewhere
+
+
+# ------------------------------------------------------------------------------------------------ whole blenders, second implementation
+# tests/numpy_blenders.py restates MultiBandBlender / FeatherBlender / Blender from SURVEY.md Appendix A.6 on top of the scipy
+# formulations above; here whole panoramas of the oracle's C++ blenders are compared with it, bit for bit.
+from tests import numpy_blenders as NB  # noqa: E402
+
+
+def _random_scene(rng, n, wmax, hmax, spread, grey=False, int16_range=False):
+    imgs, masks, corners = [], [], []
+    for _ in range(n):
+        w, h = int(rng.integers(5, wmax)), int(rng.integers(5, hmax))
+        if int16_range:
+            img = rng.integers(-3000, 3000, (h, w, 3)).astype(np.int16)
+        else:
+            img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        if grey:
+            m = rng.integers(0, 256, (h, w)).astype(np.uint8)
+            m[rng.random((h, w)) < 0.3] = 0
+            m[rng.random((h, w)) < 0.3] = 255
+        else:
+            m = np.zeros((h, w), np.uint8)
+            x0, y0 = int(rng.integers(0, w // 2)), int(rng.integers(0, h // 2))
+            m[y0:int(rng.integers(y0 + 1, h + 1)), x0:int(rng.integers(x0 + 1, w + 1))] = 255
+            m[rng.random((h, w)) < 0.05] = 0
+        imgs.append(img)
+        masks.append(m)
+        corners.append((int(rng.integers(-spread, spread)), int(rng.integers(-spread, spread))))
+    return imgs, masks, corners
+
+
+@pytest.mark.parametrize("bands", [0, 1, 2, 3, 4, 6])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_multiband_handle_vs_numpy_second_implementation(oracle, bands, seed):
+    O = oracle
+    rng = np.random.default_rng(1000 * bands + seed)
+    imgs, masks, corners = _random_scene(rng, 4, 70, 60, 40, grey=(seed == 1), int16_range=(seed == 2))
+    roi = NB.result_roi(corners, [(m.shape[1], m.shape[0]) for m in masks])
+    a = O._OracleBlenderHandle(O._OracleBlenderHandle.MULTI_BAND, num_bands=bands)
+    b = NB.NumpyMultiBand(bands)
+    a.prepare(roi)
+    b.prepare(roi)
+    assert a.num_bands() == b.B
+    for img, m, c in zip(imgs, masks, corners):
+        a.feed(img.astype(np.int16), m, c)
+        b.feed(img.astype(np.int16), m, c)
+    ra, ma = a.blend()
+    rb, mb = b.blend()
+    assert np.array_equal(ma, mb)
+    assert np.array_equal(ra, rb)
+
+
+def test_multiband_band_clamp_and_one_pixel_images_vs_numpy(oracle):
+    O = oracle
+    # roi 9 x 3: ceil(log2(9)) = 4 bands at most; 1 x 1 and 1 x n images; an image that touches every border of the roi
+    rng = np.random.default_rng(5)
+    imgs = [rng.integers(0, 256, s + (3,)).astype(np.int16) for s in [(3, 9), (1, 1), (1, 4), (3, 1)]]
+    masks = [np.full(i.shape[:2], 255, np.uint8) for i in imgs]
+    corners = [(0, 0), (4, 1), (2, 2), (8, 0)]
+    roi = NB.result_roi(corners, [(m.shape[1], m.shape[0]) for m in masks])
+    assert roi == (0, 0, 9, 3)
+    a = O._OracleBlenderHandle(O._OracleBlenderHandle.MULTI_BAND, num_bands=9)
+    b = NB.NumpyMultiBand(9)
+    a.prepare(roi)
+    b.prepare(roi)
+    assert a.num_bands() == b.B == 4
+    for img, m, c in zip(imgs, masks, corners):
+        a.feed(img, m, c)
+        b.feed(img, m, c)
+    ra, ma = a.blend()
+    rb, mb = b.blend()
+    assert np.array_equal(ma, mb) and np.array_equal(ra, rb)
+
+
+def test_multiband_accumulator_wrap_vs_numpy(oracle):
+    O = oracle
+    # five images of value 32000 under full masks at the same place: the int16 accumulators wrap (OpenCV adds without saturation)
+    img = np.full((16, 16, 3), 32000, np.int16)
+    m = np.full((16, 16), 255, np.uint8)
+    a = O._OracleBlenderHandle(O._OracleBlenderHandle.MULTI_BAND, num_bands=2)
+    b = NB.NumpyMultiBand(2)
+    a.prepare((0, 0, 16, 16))
+    b.prepare((0, 0, 16, 16))
+    for _ in range(5):
+        a.feed(img, m, (0, 0))
+        b.feed(img, m, (0, 0))
+    ra, ma = a.blend()
+    rb, mb = b.blend()
+    assert np.array_equal(ra, rb) and np.array_equal(ma, mb)
+    assert (ra != 32000).any()  # the wrap really happened
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_feather_handle_vs_numpy_second_implementation(oracle, seed):
+    O = oracle
+    rng = np.random.default_rng(50 + seed)
+    imgs, masks, corners = _random_scene(rng, 5, 60, 50, 30, grey=(seed == 1), int16_range=(seed == 2))
+    if seed == 3:
+        masks[0][...] = 255  # an image without any zero: the transform's cap
+    roi = NB.result_roi(corners, [(m.shape[1], m.shape[0]) for m in masks])
+    sharp = [0.02, 0.5, 0.137, 1.0 / 3][seed]
+    a = O._OracleBlenderHandle(O._OracleBlenderHandle.FEATHER, sharpness=sharp)
+    b = NB.NumpyFeather(sharp)
+    a.prepare(roi)
+    b.prepare(roi)
+    for img, m, c in zip(imgs, masks, corners):
+        a.feed(img.astype(np.int16), m, c)
+        b.feed(img.astype(np.int16), m, c)
+    ra, ma = a.blend()
+    rb, mb = b.blend()
+    assert np.array_equal(ma, mb)
+    assert np.array_equal(ra, rb)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_plain_handle_vs_numpy_second_implementation(oracle, seed):
+    O = oracle
+    rng = np.random.default_rng(70 + seed)
+    imgs, masks, corners = _random_scene(rng, 5, 60, 50, 30, grey=(seed == 1))
+    roi = NB.result_roi(corners, [(m.shape[1], m.shape[0]) for m in masks])
+    a = O._OracleBlenderHandle(O._OracleBlenderHandle.NO)
+    b = NB.NumpyNo()
+    a.prepare(roi)
+    b.prepare(roi)
+    for img, m, c in zip(imgs, masks, corners):
+        a.feed(img.astype(np.int16), m, c)
+        b.feed(img.astype(np.int16), m, c)
+    ra, ma = a.blend()
+    rb, mb = b.blend()
+    assert np.array_equal(ma, mb) and np.array_equal(ra, rb)
+
+
+@pytest.mark.parametrize("blender_type,strength", [("multiband", 5), ("multiband", 20), ("multiband", 0.5), ("feather", 5), ("feather", 1), ("no", 5)])
+def test_blender_class_on_a_warped_ring_vs_numpy(oracle, blender_type, strength):
+    O = oracle
+    """the path as the reference drives it (stitching/blender.py:23-48): spherical warps of a 2 x 2 camera grid (inputs from the oracle's
+    warper), blend strength -> band count / sharpness, feed, blend, convertScaleAbs"""
+    from stitching_amd import synthetic
+    W, H = 96, 72
+    cams = synthetic.grid_cameras(2, 2, W, H)
+    w = O.Warper("spherical")
+    w.set_scale(cams)
+    rng = np.random.default_rng(9)
+    frames = [rng.integers(0, 256, (H, W, 3)).astype(np.uint8) for _ in cams]
+    imgs = list(w.warp_images(frames, cams))
+    masks = list(w.create_and_warp_masks([(W, H)] * len(cams), cams))
+    corners, sizes = w.warp_rois([(W, H)] * len(cams), cams)
+    bl = O.Blender(blender_type, strength)
+    bl.prepare(corners, sizes)
+    for img, m, c in zip(imgs, masks, corners):
+        bl.feed(img, m, c)
+    pa, ma = bl.blend()
+    pb, mb, bands = NB.reference_blend(blender_type, strength, imgs, masks, corners)
+    if bands is not None:
+        assert bl.blender.num_bands() == bands
+    assert np.array_equal(ma, mb)
+    assert np.array_equal(pa, pb)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_multiband_full_int16_range_saturating_laplacian_and_collapse_vs_numpy(oracle, seed):
+    # +-32768 noise: the Laplacian subtraction and the collapse addition both saturate (cv::subtract / cv::add on CV_16S), the accumulators wrap
+    O = oracle
+    rng = np.random.default_rng(300 + seed)
+    a = O._OracleBlenderHandle(O._OracleBlenderHandle.MULTI_BAND, num_bands=3)
+    b = NB.NumpyMultiBand(3)
+    a.prepare((0, 0, 40, 24))
+    b.prepare((0, 0, 40, 24))
+    for c, (w, h) in [((0, 0), (24, 24)), ((16, 0), (24, 24))][:1 + seed]:
+        img = rng.choice(np.array([-32768, 32767, 0, 12345], np.int16), (h, w, 3))
+        m = np.full((h, w), 255, np.uint8)
+        a.feed(img, m, c)
+        b.feed(img, m, c)
+    ra, ma = a.blend()
+    rb, mb = b.blend()
+    assert np.array_equal(ra, rb) and np.array_equal(ma, mb)
