@@ -412,3 +412,50 @@ def test_multiband_full_int16_range_saturating_laplacian_and_collapse_vs_numpy(o
     ra, ma = a.blend()
     rb, mb = b.blend()
     assert np.array_equal(ra, rb) and np.array_equal(ma, mb)
+
+
+# ------------------------------------------------------------------------------------------------ whole warper, second implementation
+# tests/numpy_warper.py restates setCameraParams / mapForward / mapBackward / detectResultRoi / remap from SURVEY.md Appendix A.1-A.4 in
+# numpy float32 (one rounding per operation, libm through float64).  ROIs, fp32 maps, warped images and masks of the oracle, bit for bit.
+from tests import numpy_warper as NW  # noqa: E402
+
+
+def _cameras_for_second_warper(W, H):
+    cams = list(synthetic.grid_cameras(3, 2, W, H))
+    # a camera that looks at the pole (the spherical ROI's pole inclusion) and one rolled and pitched steeply
+    def rot(yaw, pitch, roll):
+        cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+        Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+        Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+        Rz = np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])
+        return (Ry @ Rx @ Rz).astype(np.float32)
+    f = cams[0].focal
+    for (yaw, pitch, roll) in [(0.3, np.pi / 2 - 0.05, 0.0), (0.3, -np.pi / 2 + 0.1, 0.2), (-0.8, 0.6, 0.5), (2.9, -0.3, -1.1)]:
+        cams.append(type(cams[0])(focal=f * 1.07, aspect=1.0, ppx=W / 2 + 1.5, ppy=H / 2 - 2.25, R=rot(yaw, pitch, roll)))
+    return cams
+
+
+@pytest.mark.parametrize("kind", ["spherical", "cylindrical", "plane"])
+def test_warper_vs_numpy_second_implementation(oracle, kind):
+    O = oracle
+    W, H = 160, 120
+    cams = _cameras_for_second_warper(W, H)
+    scale = float(np.median([c.focal for c in cams])) * 0.83
+    rng = np.random.default_rng(17)
+    src = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+    poles = 0
+    for c in cams:
+        K = O.Warper.get_K(c)
+        roi = O.warp_roi(kind, scale, K, c.R, (W, H))
+        if roi[2] * roi[3] > 4_000_000:
+            continue  # a plane warp of a camera that looks sideways: the maps would not fit the test's time
+        assert NW.warp_roi(kind, scale, K, c.R, (W, H)) == roi
+        poles += int(kind == "spherical" and roi[2] > 3.0 * scale)
+        xa, ya = O.build_maps(kind, scale, K, c.R, roi)
+        xb, yb = NW.map_backward(kind, scale, K, c.R, roi)
+        assert np.array_equal(xa.view(np.int32), xb.view(np.int32)) and np.array_equal(ya.view(np.int32), yb.view(np.int32))
+        _, img, mask = O.warp_fused(kind, scale, K, c.R, src)
+        assert np.array_equal(img, NW.remap_linear_reflect(src, xb, yb))
+        assert np.array_equal(mask, NW.remap_nearest_constant(np.full((H, W), 255, np.uint8), xb, yb))
+    if kind == "spherical":
+        assert poles >= 1  # the pole inclusion branch of SphericalWarper::detectResultRoi ran
