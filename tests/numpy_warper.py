@@ -105,8 +105,9 @@ def warp_roi(kind, scale, K, R, size):
         for sign, pole_v in ((1, PI_F * F(scale)), (-1, F(0))):
             x, y, z = rinv[0, 1], F(sign) * rinv[1, 1], rinv[2, 1]
             if y > 0:
-                px = (K32[0, 0] * x + K32[0, 1] * y) / z + K32[0, 2]
-                py = K32[1, 1] * y / z + K32[1, 2]
+                with np.errstate(divide="ignore", invalid="ignore"):  # z = 0 (no pitch, no roll): inf, "not inside"
+                    px = (K32[0, 0] * x + K32[0, 1] * y) / z + K32[0, 2]
+                    py = K32[1, 1] * y / z + K32[1, 2]
                 if 0 < px < W and 0 < py < H:
                     tl_u, tl_v = min(tl_u, F(0)), min(tl_v, pole_v)
                     br_u, br_v = max(br_u, F(0)), max(br_v, pole_v)
