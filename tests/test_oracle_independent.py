@@ -459,3 +459,48 @@ def test_warper_vs_numpy_second_implementation(oracle, kind):
         assert np.array_equal(mask, NW.remap_nearest_constant(np.full((H, W), 255, np.uint8), xb, yb))
     if kind == "spherical":
         assert poles >= 1  # the pole inclusion branch of SphericalWarper::detectResultRoi ran
+
+
+# ------------------------------------------------------------------------------------------------ the "next" rows
+def test_dilate3x3_equals_scipy_maximum_filter(oracle):
+    rng = np.random.default_rng(41)
+    for shape in [(1, 1), (1, 7), (9, 1), (37, 53)]:
+        m = np.where(rng.random(shape) < 0.1, rng.integers(1, 256, shape), 0).astype(np.uint8)
+        assert np.array_equal(oracle.dilate3x3(m), ndimage.maximum_filter(m, size=3, mode="constant", cval=0))
+
+
+@pytest.mark.parametrize("src,dst", [((40, 30), (97, 71)), ((97, 71), (40, 30)), ((64, 48), (64, 48)), ((5, 3), (50, 41)), ((200, 150), (33, 20))])
+def test_resize_linear_exact_close_to_scipy_zoom(oracle, src, dst):
+    # INTER_LINEAR_EXACT samples at (v + 0.5) * scale - 0.5 with clamped ends = scipy's zoom(order=1, grid_mode=True, mode="nearest");
+    # 8.8 horizontal coefficients and the round-half-up of the vertical pass keep it within one level of the float64 value
+    rng = np.random.default_rng(src[0] * 1000 + dst[0])
+    yy, xx = np.mgrid[0:src[1], 0:src[0]]
+    a = np.clip(127 + 90 * np.sin(xx / 5.0) * np.cos(yy / 7.0) + rng.integers(-20, 21, xx.shape), 0, 255).astype(np.uint8)
+    got = oracle.resize_linear_exact(a, dst).astype(np.float64)
+    want = ndimage.zoom(a.astype(np.float64), (dst[1] / src[1], dst[0] / src[0]), order=1, mode="nearest", grid_mode=True)
+    assert got.shape == want.shape == (dst[1], dst[0])
+    assert np.abs(got - want).max() <= 1.0
+    assert np.abs(got - want).mean() < 0.3
+
+
+@pytest.mark.parametrize("src,dst", [((12, 9), (380, 290)), ((13, 10), (400, 300)), ((1, 1), (8, 8)), ((7, 1), (100, 4))])
+def test_resize_linear_f32_close_to_scipy_zoom(oracle, src, dst):
+    rng = np.random.default_rng(src[0] + dst[0])
+    g = rng.uniform(0.5, 2.0, (src[1], src[0])).astype(np.float32)
+    got = oracle.resize_linear_f32(g, dst).astype(np.float64)
+    want = ndimage.zoom(g.astype(np.float64), (dst[1] / src[1], dst[0] / src[0]), order=1, mode="nearest", grid_mode=True)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 4e-6 * 2.0 * 4  # fp32 coefficients and two fp32 lerps on values <= 2
+
+
+def test_gain_apply_equals_float_product_rounded_half_even(oracle):
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (20, 30, 3)).astype(np.uint8)
+    for gains in (1.0, 0.5, 1.5, 2.5, [0.9, 1.1, 1.7]):
+        g = np.broadcast_to(np.asarray(gains, np.float64).astype(np.float32), (3,))
+        want = np.empty_like(img)
+        for c in range(3):
+            prod = [float(np.float32(np.float32(v) * g[c])) for v in range(256)]
+            lut = np.array([min(255, max(0, int(round(p)))) for p in prod], np.uint8)   # Python's round: half to even
+            want[..., c] = lut[img[..., c]]
+        assert np.array_equal(oracle.gain_apply(img, gains), want)
