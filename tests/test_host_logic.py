@@ -283,3 +283,100 @@ def test_tcp_group_single_rank_and_errors():
     assert res[0][:4] == (2, 8 << 20, [2] * 5, 1.5) and res[1][:4] == (1, 8 << 20, [1] * 5, 1.5), res
     assert "expects 9" in res[0][4] and res[1][4] == "no error"
     _ = socket
+
+
+def _run_ranks(world, fn, timeout=60):
+    """`fn(group, rank)` on `world` TcpGroup ranks, one thread each -> {rank: result or exception}"""
+    import threading
+
+    from stitching_amd.rendezvous import TcpGroup, free_port
+
+    port, res = free_port(), {}
+
+    def run(rank):
+        try:
+            grp = TcpGroup(rank, world, "127.0.0.1", port, timeout=20)
+            try:
+                res[rank] = fn(grp, rank)
+            finally:
+                grp.close()
+        except Exception as e:  # noqa: BLE001
+            res[rank] = e
+
+    ts = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout)
+    assert all(not t.is_alive() for t in ts), "a rank hangs"
+    return res
+
+
+def test_tcp_group_five_ranks_collectives_and_mesh():
+    # every collective of the interface, and a strip exchange in which every rank owes every other rank a different number of bytes
+    def body(g, r):
+        w = g.world
+        out = {"gather": g.gather(("r", r), dst=2), "bcast": g.broadcast({"id": bytes(range(8))} if r == 3 else None, src=3),
+               "all": g.all_gather(r * r), "min": g.all_reduce_min(10 - r), "max": g.all_reduce_max(r / 2)}
+        sends = [(d, np.full(1000 * r + d + 1, 16 * r + d, np.uint8)) for d in range(w) if d != r]
+        recvs = [(s, 1000 * s + r + 1) for s in range(w) if s != r]
+        got = g.exchange_bytes(sends, recvs)
+        out["p2p"] = all(a.size == n and (a == 16 * s + r).all() for a, (s, n) in zip(got, recvs))
+        g.barrier()
+        return out
+
+    res = _run_ranks(5, body)
+    for r in range(5):
+        assert not isinstance(res[r], Exception), res[r]
+        assert res[r]["gather"] == ([("r", k) for k in range(5)] if r == 2 else None)
+        assert res[r]["bcast"] == {"id": bytes(range(8))} and res[r]["all"] == [0, 1, 4, 9, 16]
+        assert res[r]["min"] == 6 and res[r]["max"] == 2.0 and res[r]["p2p"]
+
+
+def test_tcp_group_peer_death_is_an_error_not_a_hang():
+    from stitching_amd.stitching_error import StitchingError
+
+    def body(g, r):
+        g.barrier()
+        if r == 1:
+            g.close()  # rank 1 dies between two collectives
+            return "left"
+        return g.all_gather(r)
+
+    res = _run_ranks(3, body)
+    assert res[1] == "left"
+    assert isinstance(res[0], StitchingError), res[0]       # rank 0 reads from the dead peer
+    assert isinstance(res[2], StitchingError), res[2]       # rank 2 waits for rank 0's broadcast, which never comes: rank 0 closed
+
+
+def test_tcp_group_rejects_a_stranger_on_the_rendezvous_port():
+    import socket
+    import threading
+    import time
+
+    from stitching_amd.rendezvous import TcpGroup, free_port
+    from stitching_amd.stitching_error import StitchingError
+
+    port, res = free_port(), {}
+
+    def rank0():
+        try:
+            TcpGroup(0, 2, "127.0.0.1", port, timeout=10)
+            res[0] = "joined"
+        except StitchingError as e:
+            res[0] = e
+
+    t = threading.Thread(target=rank0, daemon=True)
+    t.start()
+    deadline = time.monotonic() + 10
+    while True:
+        try:
+            s = socket.create_connection(("127.0.0.1", port), timeout=1)
+            break
+        except OSError:
+            assert time.monotonic() < deadline
+            time.sleep(0.02)
+    s.sendall(b"GET / HTTP/1.1\r\n\r\n")
+    t.join(20)
+    s.close()
+    assert isinstance(res.get(0), StitchingError) and "stranger" in str(res[0])
