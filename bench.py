@@ -66,14 +66,15 @@ def parse():
 
 
 def kernel_source_hash():
-    """sha256 over the device CODE (.hip files and the device headers; // comments and white space dropped, so that rewording a
+    """sha256 over the device CODE (.hip files, the device headers, the Makefile's flags; comments and white space dropped, so that rewording a
     comment does not orphan a traffic profile): a profile is only quoted for the kernels it was measured on (host-side API changes
     do not move bytes)."""
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "stitching_amd", "csrc", "*"))):
-        if f.endswith(".hip") or os.path.basename(f) in ("stx_device_math.h", "stx_blend_kernels.h"):  # device code only
+        # device code and the Makefile (per-file code-generation flags; its comments start with "#")
+        if f.endswith(".hip") or os.path.basename(f) in ("stx_device_math.h", "stx_blend_kernels.h", "Makefile"):
             for line in open(f, encoding="utf-8", errors="replace"):
-                code = "".join(line.split("//", 1)[0].split())  # none of these sources holds "//" inside a string literal
+                code = "".join(line.split("#" if f.endswith("Makefile") else "//", 1)[0].split())  # no "//" inside a string literal in these sources
                 if code:
                     h.update(code.encode() + b"\n")
     return h.hexdigest()[:16]

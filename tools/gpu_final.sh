@@ -23,10 +23,12 @@ cp "$OUT/traffic.json" profiles/r04_traffic.json
 bash tools/prof_pmc_lite.sh ${TAG}_sq --streams 1 > /dev/null 2>&1; cp gpurun_out/${TAG}_sq/summary.txt "$OUT/sq_summary.txt"
 timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
 cat "$OUT/bench.json"
+for leg in config3 config4 seams; do timeout 300 python tools/prof_legs.py $leg 5 > "$OUT/legs_$leg.txt" 2>&1; cat "$OUT/legs_$leg.txt"; done
+# FINAL_CORE=1: stop here (a short GPU budget): the N = 2 / 4 lines on one shared GPU and the simulated ranks are the optional tail
+if [ -n "${FINAL_CORE:-}" ]; then exit 0; fi
 for N in 2 4; do
   timeout 600 python bench.py --gpus $N --steps 3 --warmup 1 > "$OUT/bench_n${N}_shared_gpu.json" 2> "$OUT/bench_n$N.err"; echo "N=$N rc=$?"
 done
-for leg in config3 config4 seams; do timeout 300 python tools/prof_legs.py $leg 5 > "$OUT/legs_$leg.txt" 2>&1; cat "$OUT/legs_$leg.txt"; done
 if [ "$SIM" = "sim" ]; then
   : > "$OUT/sim_all_ranks_config3.jsonl"
   for R in 0 1 2 3 4 5 6 7; do timeout 300 python tools/sim_rank.py 8 $R 24 config3 2>> "$OUT/sim.err" | tail -1 >> "$OUT/sim_all_ranks_config3.jsonl"; done

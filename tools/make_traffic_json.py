@@ -16,17 +16,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def kernel_source_hash():
-    """sha256 over the device CODE (.hip files and the device headers; // comments and white space dropped, so that rewording a
-    comment does not orphan a traffic profile): a profile is only quoted for the kernels it was measured on (host-side API changes
-    do not move bytes)."""
-    h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "stitching_amd", "csrc", "*"))):
-        if f.endswith(".hip") or os.path.basename(f) in ("stx_device_math.h", "stx_blend_kernels.h"):  # device code only
-            for line in open(f, encoding="utf-8", errors="replace"):
-                code = "".join(line.split("//", 1)[0].split())  # none of these sources holds "//" inside a string literal
-                if code:
-                    h.update(code.encode() + b"\n")
-    return h.hexdigest()[:16]
+    """the hash bench.py keys a traffic profile on (device code + the Makefile's code-generation flags)"""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    return bench.kernel_source_hash()
+
 
 NAMES = [("warp_fast_kernel<3, true, true", "warp_img_mask"), ("warp_fast_kernel<2, true, true", "warp_img_mask"),
          ("warp_fast_kernel<0, true, true", "warp_img_mask"), ("mb_level0_pk_kernel", "mb_level0"),
