@@ -73,8 +73,11 @@ def kernel_source_hash():
     for f in sorted(glob.glob(os.path.join(ROOT, "stitching_amd", "csrc", "*"))):
         # device code and the Makefile (per-file code-generation flags; its comments start with "#")
         if f.endswith(".hip") or os.path.basename(f) in ("stx_device_math.h", "stx_blend_kernels.h", "Makefile"):
+            mk = f.endswith("Makefile")
             for line in open(f, encoding="utf-8", errors="replace"):
-                code = "".join(line.split("#" if f.endswith("Makefile") else "//", 1)[0].split())  # no "//" inside a string literal in these sources
+                if mk and not line.startswith(("FLAGS", "EXTRA", "WARP_EXTRA", "BLEND_EXTRA", "FAST_EXTRA")):
+                    continue  # of the Makefile only the flag assignments
+                code = "".join(line.split("#" if mk else "//", 1)[0].split())  # no "//" inside a string literal in these sources
                 if code:
                     h.update(code.encode() + b"\n")
     return h.hexdigest()[:16]
