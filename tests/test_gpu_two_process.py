@@ -89,3 +89,32 @@ def test_ranks_with_different_environments_fail_loudly_instead_of_hanging(gpu_ct
                   rank_env=lambda r: {"STITCHING_AMD_TRIG": "glibc"} if r == 1 else {}, expect_fail=True)
     for rc, o, e in outs:
         assert rc != 0 and "shard plan differs between ranks" in e, e[-2000:]
+
+
+def _rccl_double_env():
+    """The environment that makes stx_comm.cpp's dlopen("librccl.so.1") find the test double (tests/fake_rccl) and the job ask for RCCL."""
+    from tests import fake_rccl
+
+    d = os.path.dirname(fake_rccl.build())
+    return {"LD_LIBRARY_PATH": d + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""), "STITCHING_AMD_TRANSPORT": "rccl"}
+
+
+@pytest.mark.parametrize("split", [True, False])
+def test_two_ranks_over_the_rccl_code_path_with_a_test_double(gpu_ctx, split):
+    """RcclTransport + stx_comm_* end to end on ONE GPU: the unique id travels over the control plane, both ranks join the communicator,
+    every exchange is one send / recv group on the communicator's stream between the ready / done events — against a librccl stand-in
+    (UNIX sockets + host staging), because the real library refuses two ranks on one device.  The panorama is the oracle's."""
+    env = _rccl_double_env()
+    res = launch(2, dict(layout="ring", w=803, h=601, per_rank=3, warper="spherical", bands=4, split=split, repeat=3), rank_env=lambda r: env)
+    assert res["transport"] == "rccl", res
+    assert res["bands"] == 4 and res["messages"] >= 2 and res["ok"], res
+
+
+def test_three_ranks_all_pairs_over_the_rccl_code_path_with_a_test_double(gpu_ctx):
+    """config 4 in small (strips between all pairs of ranks, masks as bits) through the same path, and the feather blender's sharded form."""
+    env = _rccl_double_env()
+    res = launch(3, dict(layout="grid", rows=4, w=1000, h=750, per_rank=4, warper="cylindrical", bands=5, max_lat=50.0, layout_yaw=16,
+                         seed=100, mask_bits=True), rank_env=lambda r: env)
+    assert res["transport"] == "rccl" and res["bands"] == 5 and res["messages"] >= 4 and res["ok"], res
+    res = launch(3, dict(layout="ring", w=803, h=601, per_rank=2, warper="spherical", blender="feather", strength=4, span=170.0), rank_env=lambda r: env)
+    assert res["transport"] == "rccl" and res["ok"], res

@@ -380,3 +380,31 @@ def test_tcp_group_rejects_a_stranger_on_the_rendezvous_port():
     t.join(20)
     s.close()
     assert isinstance(res.get(0), StitchingError) and "stranger" in str(res[0])
+
+
+def test_rccl_test_double_protocol():
+    """tests/fake_rccl (the librccl stand-in behind tests/test_gpu_two_process.py::test_*_rccl_code_path_*) on host memory: three
+    processes, groups in which every rank sends to and receives from every other rank, a size mismatch reported as an error."""
+    import ctypes as C
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from tests import fake_rccl
+
+    lib = fake_rccl.build(no_hip=True)
+    L = C.CDLL(lib)
+    uid = C.create_string_buffer(128)
+    assert L.ncclGetUniqueId(uid) == 0
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, lib, str(r), "3", uid.raw.hex()], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(3)]
+    res = []
+    for p in procs:
+        o, e = p.communicate(timeout=120)
+        assert p.returncode == 0, e[-2000:]
+        res.append(json.loads(o.strip().splitlines()[-1]))
+    assert all(r["ok"] for r in res), res
+    assert res[0]["rc"] != 0 and "receives 5 bytes from rank 1 which sends 6" in res[0]["err"]
+    assert res[1]["rc"] == 0 and res[2]["rc"] == 0
