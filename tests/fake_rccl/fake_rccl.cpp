@@ -38,6 +38,7 @@ const int TIMEOUT_MS = 120000;
 struct Comm {
     int nranks = 0, rank = 0;
     std::vector<int> fd;  // one stream socket per peer
+    std::string dir;      // rendezvous directory (rank 0 removes it)
 };
 struct Op { bool send; void* ptr; size_t bytes; int peer; Comm* comm; hipStream_t stream; };
 thread_local std::vector<Op> g_ops;
@@ -200,6 +201,8 @@ FAKE_API int ncclCommInitRank(void** out, int nranks, FakeId id, int rank)
         c->fd[r32] = fd;
     }
     close(ls);
+    unlink(me.sun_path);  // every higher rank is connected: the name is not needed any more
+    c->dir = dir;
     *out = c;
     return OK;
 }
@@ -210,6 +213,7 @@ FAKE_API int ncclCommDestroy(void* comm)
     if (!c) return OK;
     for (int fd : c->fd)
         if (fd >= 0) close(fd);
+    if (c->rank == 0) rmdir(c->dir.c_str());  // empty once every rank has unlinked its socket; otherwise it stays, harmlessly
     delete c;
     return OK;
 }
