@@ -504,3 +504,63 @@ def test_gain_apply_equals_float_product_rounded_half_even(oracle):
             lut = np.array([min(255, max(0, int(round(p)))) for p in prod], np.uint8)   # Python's round: half to even
             want[..., c] = lut[img[..., c]]
         assert np.array_equal(oracle.gain_apply(img, gains), want)
+
+
+# ------------------------------------------------------------------------------------------------ seeded sweeps against the second implementations
+@pytest.mark.parametrize("seed", range(40))
+def test_blenders_random_scenes_vs_numpy(oracle, seed):
+    O = oracle
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(1, 7))
+    imgs, masks, corners = _random_scene(rng, n, int(rng.integers(8, 100)), int(rng.integers(8, 90)), int(rng.integers(1, 80)),
+                                         grey=bool(rng.integers(0, 2)), int16_range=bool(rng.integers(0, 2)))
+    roi = NB.result_roi(corners, [(m.shape[1], m.shape[0]) for m in masks])
+    kind = seed % 3
+    if kind == 0:
+        bands = int(rng.integers(0, 8))
+        a, b = O._OracleBlenderHandle(O._OracleBlenderHandle.MULTI_BAND, num_bands=bands), NB.NumpyMultiBand(bands)
+    elif kind == 1:
+        sharp = float(rng.choice([0.02, 0.1, 0.33, 1.0, 1.0 / rng.uniform(1, 40)]))
+        a, b = O._OracleBlenderHandle(O._OracleBlenderHandle.FEATHER, sharpness=sharp), NB.NumpyFeather(sharp)
+    else:
+        a, b = O._OracleBlenderHandle(O._OracleBlenderHandle.NO), NB.NumpyNo()
+    a.prepare(roi)
+    b.prepare(roi)
+    for img, m, c in zip(imgs, masks, corners):
+        a.feed(img.astype(np.int16), m, c)
+        b.feed(img.astype(np.int16), m, c)
+    ra, ma = a.blend()
+    rb, mb = b.blend()
+    assert np.array_equal(ma, mb)
+    assert np.array_equal(ra, rb)
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_warper_random_cameras_vs_numpy(oracle, seed):
+    O = oracle
+    rng = np.random.default_rng(9000 + seed)
+    kind = ["spherical", "cylindrical", "plane"][seed % 3]
+    W, H = int(rng.integers(16, 120)), int(rng.integers(16, 100))
+    lim = 0.45 if kind == "plane" else np.pi  # a plane warper looking sideways has no finite ROI
+    yaw, pitch, roll = rng.uniform(-lim, lim), rng.uniform(-min(lim, 1.45), min(lim, 1.45)), rng.uniform(-lim, lim)
+    cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+    R = (np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+         @ np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])).astype(np.float32)
+    f = float(rng.uniform(0.5, 1.6) * W)
+    K = np.array([[f, 0, W / 2 + rng.uniform(-3, 3)], [0, f * rng.uniform(0.9, 1.1), H / 2 + rng.uniform(-3, 3)], [0, 0, 1]], np.float32)
+    scale = float(f * rng.uniform(0.5, 1.5))
+    roi = O.warp_roi(kind, scale, K, R, (W, H))
+    assert NW.warp_roi(kind, scale, K, R, (W, H)) == roi
+    if roi[2] * roi[3] > 1_500_000:
+        return
+    xa, ya = O.build_maps(kind, scale, K, R, roi)
+    xb, yb = NW.map_backward(kind, scale, K, R, roi)
+    # bit patterns; a NaN (0 / 0 behind a plane camera) only has to be a NaN on both sides
+    assert np.array_equal(np.isnan(xa), np.isnan(xb)) and np.array_equal(np.isnan(ya), np.isnan(yb))
+    ok = ~(np.isnan(xa) | np.isnan(ya))
+    assert np.array_equal(xa.view(np.int32)[ok], xb.view(np.int32)[ok]) and np.array_equal(ya.view(np.int32)[ok], yb.view(np.int32)[ok])
+    src = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+    _, img, mask = O.warp_fused(kind, scale, K, R, src)
+    if ok.all():
+        assert np.array_equal(img, NW.remap_linear_reflect(src, xb, yb))
+        assert np.array_equal(mask, NW.remap_nearest_constant(np.full((H, W), 255, np.uint8), xb, yb))
