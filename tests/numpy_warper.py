@@ -40,7 +40,22 @@ def _dot3(m, row, a, b, c):
     return (m[row, 0] * a + m[row, 1] * b) + m[row, 2] * c
 
 
-def map_backward(kind, scale, K, R, roi):
+def affine_params(H):
+    """AffineWarper::getRTfromHomogeneous: the 3 x 3 affine H that arrives as `R` -> (R', T') of the plane warper it drives (K passes
+    through): T = (h02, h12, 0), R = H with that column cleared, transposed; T' = (R' T) * -1 (the same small-matrix float product)"""
+    H = np.asarray(H, np.float32)
+    T = np.array([H[0, 2], H[1, 2], 0], np.float32)
+    Rp = H.copy()
+    Rp[0, 2] = Rp[1, 2] = 0
+    Rp = Rp.T.copy()
+    Tp = np.array([(Rp[i, 0] * T[0] + Rp[i, 1] * T[1]) + Rp[i, 2] * T[2] for i in range(3)], np.float32) * F(-1)
+    return Rp, Tp
+
+
+def map_backward(kind, scale, K, R, roi, T=None):
+    if kind == "affine":
+        R, T = affine_params(R)
+        kind = "plane"
     k_rinv, _, _ = projector_setup(K, R)
     s = F(scale)
     x0, y0, w, h = roi
@@ -54,7 +69,8 @@ def map_backward(kind, scale, K, R, roi):
     elif kind == "cylindrical":
         x_, y_, z_ = _m(np.sin, u), v, _m(np.cos, u)
     elif kind == "plane":
-        x_, y_, z_ = u, v, np.ones_like(u)   # t = 0: u / s - 0, v / s - 0, 1 - 0
+        t = np.zeros(3, np.float32) if T is None else np.asarray(T, np.float32)
+        x_, y_, z_ = u - t[0], v - t[1], np.full_like(u, F(1) - t[2])
     else:
         raise ValueError(kind)
     x = _dot3(k_rinv, 0, x_, y_, z_)
@@ -68,7 +84,7 @@ def map_backward(kind, scale, K, R, roi):
     return np.where(ok, qx, F(-1)).astype(np.float32), np.where(ok, qy, F(-1)).astype(np.float32)
 
 
-def map_forward(kind, scale, r_kinv, x, y):
+def map_forward(kind, scale, r_kinv, x, y, T=None):
     x, y = np.asarray(x, np.float32), np.asarray(y, np.float32)
     s = F(scale)
     one = np.ones_like(x)
@@ -84,12 +100,17 @@ def map_forward(kind, scale, r_kinv, x, y):
         u = s * np.arctan2(x_.astype(np.float64), z_.astype(np.float64)).astype(np.float32)
         v = (s * y_) / np.sqrt(x_ * x_ + z_ * z_)
     else:
-        u, v = s * (x_ / z_), s * (y_ / z_)
+        t = np.zeros(3, np.float32) if T is None else np.asarray(T, np.float32)
+        u = s * (t[0] + (x_ / z_) * (F(1) - t[2]))
+        v = s * (t[1] + (y_ / z_) * (F(1) - t[2]))
     return u.astype(np.float32), v.astype(np.float32)
 
 
-def warp_roi(kind, scale, K, R, size):
-    """-> (x, y, w, h): detectResultRoiByBorder (+ the poles) for spherical, ByBorder for cylindrical, the four corners for plane"""
+def warp_roi(kind, scale, K, R, size, T=None):
+    """-> (x, y, w, h): detectResultRoiByBorder (+ the poles) for spherical, ByBorder for cylindrical, the four corners for plane / affine"""
+    if kind == "affine":
+        R, T = affine_params(R)
+        kind = "plane"
     _, r_kinv, rinv = projector_setup(K, R)
     W, H = size
     if kind == "plane":
@@ -98,7 +119,7 @@ def warp_roi(kind, scale, K, R, size):
         ax, ay = np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32)
         xs = np.concatenate([ax, ax, np.zeros(H, np.float32), np.full(H, W - 1, np.float32)])
         ys = np.concatenate([np.zeros(W, np.float32), np.full(W, H - 1, np.float32), ay, ay])
-    u, v = map_forward(kind, scale, r_kinv, xs, ys)
+    u, v = map_forward(kind, scale, r_kinv, xs, ys, T)
     tl_u, tl_v, br_u, br_v = u.min(), v.min(), u.max(), v.max()
     if kind == "spherical":
         K32 = np.asarray(K, np.float32)

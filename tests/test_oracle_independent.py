@@ -564,3 +564,27 @@ def test_warper_random_cameras_vs_numpy(oracle, seed):
     if ok.all():
         assert np.array_equal(img, NW.remap_linear_reflect(src, xb, yb))
         assert np.array_equal(mask, NW.remap_nearest_constant(np.full((H, W), 255, np.uint8), xb, yb))
+
+
+@pytest.mark.parametrize("aspect", [1, 0.5, 2.5])
+def test_affine_warper_vs_numpy_second_implementation(oracle, aspect):
+    """AffineStitcher's warper (stitching/stitcher.py:267-287): camera.R carries the 3 x 3 affine H; K and the warper scale are multiplied by
+    `aspect` (warper.py:44,86-93).  getRTfromHomogeneous + the plane projector WITH its translation, ROIs, maps, images, masks."""
+    O = oracle
+    W, H = 120, 90
+    cams = synthetic.affine_scan_cameras(4, W, H)
+    w = O.Warper("affine")
+    w.set_scale(cams)
+    w2, h2 = int(round(W * aspect)), int(round(H * aspect))
+    src = np.random.default_rng(4).integers(0, 256, (h2, w2, 3)).astype(np.uint8)
+    for c in cams:
+        K, sc = O.Warper.get_K(c, aspect), w.scale * aspect
+        roi = O.warp_roi("affine", sc, K, c.R, (w2, h2))
+        assert NW.warp_roi("affine", sc, K, c.R, (w2, h2)) == roi
+        assert abs(roi[2] - w2) <= 4 * max(1, aspect) and abs(roi[3] - h2) <= 4 * max(1, aspect)  # a tile rotated by <= 2 degrees keeps its size
+        xa, ya = O.build_maps("affine", sc, K, c.R, roi)
+        xb, yb = NW.map_backward("affine", sc, K, c.R, roi)
+        assert np.array_equal(xa.view(np.int32), xb.view(np.int32)) and np.array_equal(ya.view(np.int32), yb.view(np.int32))
+        _, img, mask = O.warp_fused("affine", sc, K, c.R, src)
+        assert np.array_equal(img, NW.remap_linear_reflect(src, xb, yb))
+        assert np.array_equal(mask, NW.remap_nearest_constant(np.full((h2, w2), 255, np.uint8), xb, yb))
