@@ -10,6 +10,12 @@ import numpy as np
 F = np.float32
 PI_F = F(np.pi)
 
+# The three places where two recollections of OpenCV differed, as switches: the defaults are what the oracle does;
+# tools/compare_with_opencv.py flips them one at a time against a real cv2 and reports which side OpenCV is on.
+SMALL_MATRIX_PRODUCT = "float"   # "float": cv::gemm's 3 x 3 CV_32F branch, float products summed left to right; "double": double accumulation
+PLANE_ROI_CORNERS = "size-1"     # PlaneWarper::detectResultRoi projects (0, 0) .. (W - 1, H - 1); "size": (W, H)
+AFFINE_USES_K = True             # AffineWarper passes K through to the plane warper; False: the identity
+
 
 def _m(f, x):
     return f(np.asarray(x, np.float64)).astype(np.float32)
@@ -18,6 +24,8 @@ def _m(f, x):
 def _mul3x3_f32(a, b):
     """cv::gemm's small-matrix path for CV_32F (len 3, no flags): float products summed left to right"""
     a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    if SMALL_MATRIX_PRODUCT == "double":
+        return (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
     return np.array([[(a[i, 0] * b[0, j] + a[i, 1] * b[1, j]) + a[i, 2] * b[2, j] for j in range(3)] for i in range(3)], np.float32)
 
 
@@ -56,6 +64,8 @@ def map_backward(kind, scale, K, R, roi, T=None):
     if kind == "affine":
         R, T = affine_params(R)
         kind = "plane"
+        if not AFFINE_USES_K:
+            K = np.eye(3, dtype=np.float32)
     k_rinv, _, _ = projector_setup(K, R)
     s = F(scale)
     x0, y0, w, h = roi
@@ -111,10 +121,13 @@ def warp_roi(kind, scale, K, R, size, T=None):
     if kind == "affine":
         R, T = affine_params(R)
         kind = "plane"
+        if not AFFINE_USES_K:
+            K = np.eye(3, dtype=np.float32)
     _, r_kinv, rinv = projector_setup(K, R)
     W, H = size
     if kind == "plane":
-        xs, ys = np.array([0, 0, W - 1, W - 1], np.float32), np.array([0, H - 1, 0, H - 1], np.float32)
+        cw, ch = (W - 1, H - 1) if PLANE_ROI_CORNERS == "size-1" else (W, H)
+        xs, ys = np.array([0, 0, cw, cw], np.float32), np.array([0, ch, 0, ch], np.float32)
     else:
         ax, ay = np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32)
         xs = np.concatenate([ax, ax, np.zeros(H, np.float32), np.full(H, W - 1, np.float32)])

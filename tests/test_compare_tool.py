@@ -38,6 +38,12 @@ def test_model_sweep_and_golden_roundtrip(oracle, tmp_path, monkeypatch):
         # the host's own in the stand-in; the tabled projectors are reproduced exactly, tests/test_gpu_trig.py)
         assert pm["STITCHING_AMD_TRIG"] in ("glibc", "glibc-nofma")
         assert pm["warp_differing_bytes"] < rep["model_sweep"]["warp"]["exact/q15"]
+    # the three recollection probes: the stand-in IS the oracle, so each must come out on the oracle's side — and decided, not a tie
+    rp = rep["recollection_probes"]
+    assert rp["small_matrix_product"]["opencv_is"] == "float" and rp["small_matrix_product"]["differing_bytes"]["float"] == 0
+    assert rp["small_matrix_product"]["differing_bytes"]["double"] > 0
+    assert rp["plane_roi_corners"]["opencv_is"] == "size-1" and rp["plane_roi_corners"]["rois_equal_of_3"]["size-1"] == 3
+    assert rp["affine_uses_K"]["opencv_is"] is True and rp["affine_uses_K"]["rois_equal_of_4"] == {"True": 4, "False": 0}
     # the tool's main comparison runs the DEFAULT oracle model against the stand-in: within the measured bounds, not exact
     assert rc in (0, 1) and rep["worst_next_rows"] == 0
     z = np.load(golden)

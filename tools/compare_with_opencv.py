@@ -126,6 +126,64 @@ def model_sweep(cv, O, G, report, golden):
                                                       "warp_diff": warp_score[bw_], "blend_diff": pyr_score[bp_]}).encode(), np.uint8)
 
 
+def recollection_probes(cv, report):
+    """The three places where two restatements of OpenCV from memory differed — asked of the real library, through
+    the API alone (PyRotationWarper.warp / warpRoi on plane and affine warpers: no trig involved, so every byte counts):
+      small_matrix_product: K R^T and R K^-1 as float products summed left to right (cv::gemm's 3 x 3 branch) or double-accumulated,
+      plane_roi_corners: PlaneWarper::detectResultRoi projects (W - 1, H - 1) or (W, H),
+      affine_uses_K: AffineWarper passes K through, or drives the plane warper with the identity.
+    The second implementation (tests/numpy_warper.py) is evaluated under both answers; the one cv2 agrees with is reported."""
+    from stitching_amd import synthetic
+    from tests import numpy_warper as NW
+
+    out = {}
+    W, H = 160, 120
+    rng = np.random.default_rng(77)
+    src = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)   # noise: every 1/32-px step of a coordinate shows
+    f = 0.9 * W
+    K = np.array([[f, 0, W / 2 + 0.75], [0, f * 1.03, H / 2 - 1.25], [0, 0, 1]], np.float32)
+    diffs = {"float": 0, "double": 0}
+    corners = {"size-1": 0, "size": 0}
+    for (yaw, pitch, roll) in [(0.31, -0.22, 0.4), (-0.37, 0.18, -1.1), (0.05, 0.41, 2.6)]:
+        cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+        R = (np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+             @ np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])).astype(np.float32)
+        w = cv.PyRotationWarper("plane", float(f))
+        roi = tuple(int(v) for v in w.warpRoi((W, H), K, R))
+        _, ref = w.warp(src, K, R, cv.INTER_LINEAR, cv.BORDER_REFLECT)
+        for c in corners:
+            NW.PLANE_ROI_CORNERS = c
+            corners[c] += int(NW.warp_roi("plane", float(f), K, R, (W, H)) == roi)
+        NW.PLANE_ROI_CORNERS = "size-1"
+        for m in diffs:
+            NW.SMALL_MATRIX_PRODUCT = m
+            xm, ym = NW.map_backward("plane", float(f), K, R, roi)
+            mine = NW.remap_linear_reflect(src, xm, ym)
+            diffs[m] += int(np.count_nonzero(mine != np.asarray(ref))) if mine.shape == np.asarray(ref).shape else mine.size
+        NW.SMALL_MATRIX_PRODUCT = "float"
+    out["small_matrix_product"] = {"differing_bytes": diffs, "opencv_is": min(diffs, key=diffs.get) if diffs["float"] != diffs["double"] else "undecided"}
+    out["plane_roi_corners"] = {"rois_equal_of_3": corners, "opencv_is": max(corners, key=corners.get) if corners["size-1"] != corners["size"] else "undecided"}
+    cams = synthetic.affine_scan_cameras(4, W, H)
+    aspect = 0.5
+    hits = {True: 0, False: 0}
+    for c in cams:
+        Kc = np.eye(3, dtype=np.float32)
+        Kc[0, 0] = Kc[1, 1] = aspect   # Warper.get_K of a unit-focal camera at `aspect`
+        w = cv.PyRotationWarper("affine", 1.0 * aspect)
+        roi = tuple(int(v) for v in w.warpRoi((int(W * aspect), int(H * aspect)), Kc, np.asarray(c.R, np.float32)))
+        for use_k in hits:
+            NW.AFFINE_USES_K = use_k
+            hits[use_k] += int(NW.warp_roi("affine", 1.0 * aspect, Kc, c.R, (int(W * aspect), int(H * aspect))) == roi)
+        NW.AFFINE_USES_K = True
+    out["affine_uses_K"] = {"rois_equal_of_4": {str(k): v for k, v in hits.items()},
+                            "opencv_is": (hits[True] > hits[False]) if hits[True] != hits[False] else "undecided"}
+    oracle_side = {"small_matrix_product": "float", "plane_roi_corners": "size-1", "affine_uses_K": True}
+    for k, v in out.items():
+        v["oracle_is"] = oracle_side[k]
+        print(f"recollection probe {k:22s}: OpenCV is {v['opencv_is']!s:10s} oracle is {v['oracle_is']!s:8s} {'OK' if v['opencv_is'] == v['oracle_is'] else '<-- LOOK HERE'}")
+    report["recollection_probes"] = out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--json", default="")
@@ -143,6 +201,7 @@ def main():
     report = {"cv2": cv.__version__}
     golden = {} if args.write_golden else None
     print("OpenCV", cv.__version__)
+    recollection_probes(cv, report)
     model_sweep(cv, O, G, report, golden)
     if args.write_golden:
         np.savez_compressed(args.write_golden, **golden)
