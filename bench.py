@@ -347,6 +347,8 @@ def main():
         if port is None:
             import torch.distributed as tdist
 
+            if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: do not make gloo resolve the container's host name
             tdist.init_process_group(backend="gloo", rank=rank, world_size=world)
             box = [free_port() if rank == 0 else None]
             tdist.broadcast_object_list(box, src=0)
