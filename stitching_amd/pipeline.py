@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib, config
 from .blender import Blender
-from .device import DeviceImage, as_device, get_context
+from .device import as_device, get_context
 from .stitching_error import StitchingError
 from .synthetic import blend_strength_for_bands
 from .warper import Warper

@@ -5,7 +5,6 @@ gfx950's FETCH_SIZE counts 128-byte read requests at 64 B, so reads are doubled 
 as reported (uncalibrated).  usage: make_traffic_json.py <dir with pmc*_counter_collection.csv> <out.json>"""
 import csv
 import glob
-import hashlib
 import json
 import os
 import re

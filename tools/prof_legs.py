@@ -1,7 +1,6 @@
 #!/usr/bin/env python
 """Per-kernel HIP-event table of an operating point other than the bench default (one panorama at a time).
 usage: python tools/prof_legs.py [seams|voronoi|config4|feather|no|config3] [steps]"""
-import json
 import os
 import sys
 
