@@ -199,3 +199,69 @@ def warp_mask(kind, scale, K, R, size):
     roi = warp_roi(kind, scale, K, R, size)
     xm, ym = map_backward(kind, scale, K, R, roi)
     return roi, remap_nearest_constant(np.full((size[1], size[0]), 255, np.uint8), xm, ym)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The per-pixel projector families (cv.PyRotationWarper's other names, stitching/warper.py:15-26): FORWARD maps only, for the ROIs
+# (RotationWarperBase::detectResultRoi projects every source pixel).  Written from memory of warpers_inl.hpp before looking at the
+# oracle's map_forward.  libm calls through float64 (correctly rounded to fp32 but for rare double-rounding cases).
+FAMILY = {"fisheye": ("fisheye", 0, 0), "stereographic": ("stereographic", 0, 0),
+          "compressedPlaneA2B1": ("crect", 2.0, 1.0), "compressedPlaneA1.5B1": ("crect", 1.5, 1.0),
+          "compressedPlanePortraitA2B1": ("crect_portrait", 2.0, 1.0), "compressedPlanePortraitA1.5B1": ("crect_portrait", 1.5, 1.0),
+          "paniniA2B1": ("panini", 2.0, 1.0), "paniniA1.5B1": ("panini", 1.5, 1.0),
+          "paniniPortraitA2B1": ("panini_portrait", 2.0, 1.0), "paniniPortraitA1.5B1": ("panini_portrait", 1.5, 1.0),
+          "mercator": ("mercator", 0, 0), "transverseMercator": ("tmercator", 0, 0)}
+
+
+def map_forward_family(name, scale, K, R, x, y):
+    fam, a, b = FAMILY[name]
+    a, b, s = F(a), F(b), F(scale)
+    _, rk, _ = projector_setup(K, R)
+    x, y = np.asarray(x, np.float32), np.asarray(y, np.float32)
+
+    def row(i):  # r_kinv[3 i] * x + r_kinv[3 i + 1] * y + r_kinv[3 i + 2]
+        return (rk[i, 0] * x + rk[i, 1] * y) + rk[i, 2]
+
+    if fam.endswith("_portrait"):
+        y_, x_, z_ = row(0), row(1), row(2)
+    else:
+        x_, y_, z_ = row(0), row(1), row(2)
+    norm = np.sqrt((x_ * x_ + y_ * y_) + z_ * z_)
+    with np.errstate(all="ignore"):
+        u_ = np.arctan2(x_.astype(np.float64), z_.astype(np.float64)).astype(np.float32)
+        if fam in ("fisheye", "stereographic"):
+            v_ = PI_F - _m(np.arccos, y_ / norm)
+            if fam == "fisheye":
+                return ((s * v_) * _m(np.cos, u_)).astype(np.float32), ((s * v_) * _m(np.sin, u_)).astype(np.float32)
+            r = _m(np.sin, v_) / (F(1) - _m(np.cos, v_))
+            return ((s * r) * _m(np.cos, u_)).astype(np.float32), ((s * r) * _m(np.sin, u_)).astype(np.float32)
+        v_ = _m(np.arcsin, y_ / norm)
+        if fam in ("crect", "crect_portrait"):
+            sg = -s if fam == "crect_portrait" else s
+            u = (sg * a) * _m(np.tan, u_ / a)
+            v = ((s * b) * _m(np.tan, v_)) / _m(np.cos, u_)
+            return u.astype(np.float32), v.astype(np.float32)
+        if fam in ("panini", "panini_portrait"):
+            sg = -s if fam == "panini_portrait" else s
+            tg = a * _m(np.tan, u_ / a)
+            u = sg * tg
+            sinu = _m(np.sin, u_)
+            v = np.where(np.abs(sinu) < F(1e-7), (s * b) * _m(np.tan, v_), (((s * b) * tg) * _m(np.tan, v_)) / sinu)
+            return u.astype(np.float32), v.astype(np.float32)
+        if fam == "mercator":
+            return (s * u_).astype(np.float32), (s * _m(np.log, _m(np.tan, F(np.pi / 4) + v_ / F(2)))).astype(np.float32)
+        B = _m(np.cos, v_) * _m(np.sin, u_)
+        u = (s / F(2)) * _m(np.log, (F(1) + B) / (F(1) - B))
+        v = s * np.arctan2(_m(np.tan, v_).astype(np.float64), _m(np.cos, u_).astype(np.float64)).astype(np.float32)
+        return u.astype(np.float32), v.astype(np.float32)
+
+
+def warp_roi_family(name, scale, K, R, size):
+    """RotationWarperBase::detectResultRoi: every source pixel forward, float min / max (NaNs never win a comparison), (int) truncation"""
+    W, H = size
+    yy, xx = np.mgrid[0:H, 0:W]
+    u, v = map_forward_family(name, scale, K, R, xx.astype(np.float32), yy.astype(np.float32))
+    with np.errstate(all="ignore"):
+        tl_u, tl_v, br_u, br_v = np.nanmin(u), np.nanmin(v), np.nanmax(u), np.nanmax(v)
+    tl, br = (int(tl_u), int(tl_v)), (int(br_u), int(br_v))
+    return (tl[0], tl[1], br[0] - tl[0] + 1, br[1] - tl[1] + 1)

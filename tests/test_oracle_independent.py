@@ -588,3 +588,24 @@ def test_affine_warper_vs_numpy_second_implementation(oracle, aspect):
         _, img, mask = O.warp_fused("affine", sc, K, c.R, src)
         assert np.array_equal(img, NW.remap_linear_reflect(src, xb, yb))
         assert np.array_equal(mask, NW.remap_nearest_constant(np.full((h2, w2), 255, np.uint8), xb, yb))
+
+
+@pytest.mark.parametrize("name", sorted(NW.FAMILY))
+def test_per_pixel_projector_rois_vs_numpy_forward_maps(oracle, name):
+    """The twelve warper names without a separable map (stitching/warper.py:15-26; the reference's boat tests use fisheye and
+    compressedPlaneA2B1): RotationWarperBase::detectResultRoi = every source pixel through mapForward.  The forward maps were
+    written a second time from memory (tests/numpy_warper.py); the ROIs — integers — have to agree."""
+    O = oracle
+    W, H = 96, 72
+    cams = synthetic.ring_cameras(3, W, H, span_deg=80.0)
+
+    def rot(yaw, pitch, roll):
+        cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+        return (np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+                @ np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])).astype(np.float32)
+
+    f = cams[0].focal
+    K = np.array([[f, 0, W / 2 + 0.5], [0, f, H / 2 - 0.5], [0, 0, 1]], np.float32)
+    for R in [c.R for c in cams] + [rot(0.2, 0.3, 0.1), rot(-0.4, -0.25, 0.6)]:
+        for scale in (f, 0.7 * f):
+            assert NW.warp_roi_family(name, scale, K, R, (W, H)) == O.warp_roi(name, scale, K, R, (W, H))
