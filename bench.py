@@ -34,7 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MIN_TIMED_S = 0.5      # the timed region is repeated in rounds of --steps until it holds at least this much work
+MIN_TIMED_S = 3.0      # the timed region is repeated in rounds of --steps until it holds at least this much work
 
 
 def parse():
@@ -257,6 +257,52 @@ def oracle_panorama(wl, frames, all_cams):
         b.feed(w.warp_image(f, c), w.create_and_warp_mask((f.shape[1], f.shape[0]), c), corner)
     pano, pmask = b.blend()
     return np.asarray(pano), np.asarray(pmask), corners, wsizes
+
+
+def oracle_chain(wl, frames, cams, all_cams, trig=None, model=None, gain_maps=None, low_seams=None, blend_strength=None):
+    """The checker's panorama for an extra leg (never timed): the oracle's warp -> [block gain] -> [seam-mask resize] -> blend chain on
+    host frames under the arithmetic model the leg runs the product in.  -> (panorama, mask, bands)"""
+    import numpy as np
+
+    from oracle import oracle as O
+    from stitching_amd.synthetic import blend_strength_for_bands
+
+    O.build()
+    O.set_num_threads(max(1, min(O.max_threads(), 64)))
+    prev = O.set_model(**model) if model else None
+    try:
+        w = O.Warper(wl["warper"], **({"trig": trig} if trig is not None else {}))
+        w.set_scale(all_cams)
+        sizes = [(f.shape[1], f.shape[0]) for f in frames]
+        corners, wsizes = w.warp_rois(sizes, cams)
+        roi = O.result_roi(corners, wsizes)
+        strength = blend_strength if blend_strength is not None else blend_strength_for_bands(wl["bands"], roi[2], roi[3])
+        b = O.Blender("multiband", strength)
+        b.prepare(corners, wsizes)
+        for k, (f, c, corner) in enumerate(zip(frames, cams, corners)):
+            img = w.warp_image(f, c)
+            mask = w.create_and_warp_mask((f.shape[1], f.shape[0]), c)
+            if gain_maps is not None:
+                img = O.block_gain_apply(img, gain_maps[k])
+            if low_seams is not None:
+                mask = O.seam_resize(low_seams[k], mask)
+            b.feed(img, mask, corner)
+        pano, pmask = b.blend()
+        return np.asarray(pano), np.asarray(pmask), b.blender.num_bands()
+    finally:
+        if prev:
+            O.set_model(**prev)
+
+
+def parity_record(job, o_pano, o_mask, vs):
+    import numpy as np
+
+    g_pano, g_mask = (np.asarray(a) for a in job.run())
+    if g_pano.shape != o_pano.shape:
+        return {"vs": vs, "shape_mismatch": [list(g_pano.shape), list(o_pano.shape)]}
+    d = np.abs(g_pano.astype(np.int16) - o_pano.astype(np.int16))
+    return {"vs": vs, "max_abs_diff": int(d.max()), "differing_bytes": int(np.count_nonzero(d)),
+            "mask_equal": bool(np.array_equal(g_mask, o_mask)), "panorama_shape": list(g_pano.shape)}
 
 
 def sharded_parity(job, dist, rank, world, wl, all_cams):
@@ -561,7 +607,7 @@ def main():
         # a stream of panoramas (--streams in flight)
         result["value_single_stream"] = round(src_mpix / lats[len(lats) // 2], 1)
     if world == 1 and not args.no_extra:
-        result["extra"] = extra_legs(args, S, synthetic, StitchJob, ctxs, wl, jobs[0], all_cams)
+        result["extra"] = extra_legs(args, S, synthetic, StitchJob, ctxs, wl, jobs[0], all_cams, frames)
     if world == 1 and args.e2e_steps > 0:
         result["pcie_inclusive"] = pcie_legs(args, S, StitchJob, ctxs, wl, frames, cams, src_mpix, nb)
     if world == 1 and not args.no_cpu_baseline:
@@ -594,7 +640,7 @@ def quick_rate(jobs, ctxs, mpix, steps=6, warmup=2, min_seconds=0.25):
     return {"value": round(mpix / (ms / 1e3), 1), "unit": "Mpix/s", "ms_per_step": round(ms, 4), "steps_executed": steps * len(r)}
 
 
-def extra_legs(args, S, synthetic, StitchJob, ctxs, wl, job, all_cams):
+def extra_legs(args, S, synthetic, StitchJob, ctxs, wl, job, all_cams, host_frames):
     """Other operating points on the same GPU, same timing method (two panoramas in flight), fewer steps.  Not `value`."""
     import numpy as np
 
@@ -628,6 +674,57 @@ def extra_legs(args, S, synthetic, StitchJob, ctxs, wl, job, all_cams):
                                          note="0.09-scale seam masks -> SeamFinder.resize on the device every step (dilate, "
                                               "INTER_LINEAR_EXACT, AND): non-binary masks, fp32-weight level-0 gather; cropped to the seam cells' reach")
         del js
+        # The reference's DEFAULT composition (stitching/stitcher.py:22-48, run as :117-128): gain_blocks compensator (block gain maps
+        # from the low-resolution pass: here smooth synthetic ones of the size BlocksCompensator makes for 0.1-Mpx images, 32-px blocks),
+        # dp_color seam masks resized per panorama (here the Voronoi cells at 0.09 scale) and multiband at blend_strength 5 — the band
+        # count comes out of the panorama size (stitching/blender.py:25-32), 7 for this one
+        rng = np.random.default_rng(4242)
+        lscale = (0.1e6 / (wl["width"] * wl["height"])) ** 0.5
+        gmaps = []
+        for k, (w_, h_) in enumerate(job.warped_sizes):
+            gh, gw = (int(h_ * lscale) + 31) // 32 + 1, (int(w_ * lscale) + 31) // 32 + 1
+            yy, xx = np.mgrid[0:gh, 0:gw]
+            gmaps.append((1.0 + 0.12 * np.sin(0.7 * xx + k) * np.cos(0.5 * yy - k) + 0.02 * rng.standard_normal((gh, gw))).astype(np.float32))
+        comp = S.ExposureErrorCompensator("gain_blocks")
+        comp.set_gains(gmaps)
+        js = []
+        for c in ctxs:
+            j = StitchJob(job.frames, job.cameras, blend_strength=5, ctx=c, seam_masks=low, compensator=comp)
+            j.warper.set_scale(all_cams)
+            js.append(j)
+        leg = dict(quick_rate(js, ctxs, src_mpix), compensator="gain_blocks (batched, gain maps resident)", seam_masks="0.09 scale, resized on the device",
+                   blend_strength=5, note="the reference's DEFAULT_SETTINGS composition on config 2's frames: warp -> gain_blocks apply -> "
+                                          "SeamFinder.resize -> multiband; cropped to the seam cells' reach")
+        leg["bands"] = js[0].last_num_bands
+        if not args.no_cpu_baseline:
+            o_pano, o_mask, o_bands = oracle_chain(wl, host_frames, job.cameras, all_cams, gain_maps=gmaps, low_seams=low, blend_strength=5)
+            leg["parity"] = parity_record(js[0], o_pano, o_mask, "oracle chain: warp -> block_gain_apply -> seam_resize -> %d-band blend" % o_bands)
+        out["reference_defaults"] = leg
+        del js
+        # The other arithmetic models the library offers (include/stitching_amd.h: STX_REMAP_*, STX_PYRDOWN_*, STX_TRIG_*), priced on the
+        # same frames, each checked against the oracle under the same model
+        modes = {}
+        for name, setup, teardown, okw in (
+            ("remap_float", lambda: S.set_remap_mode("float"), S.set_remap_mode, dict(model=dict(remap="float"))),
+            ("pyrdown_simd_hv8", lambda: S.set_pyrdown_mode("simd-hv", 8), lambda p: S.set_pyrdown_mode(*p), dict(model=dict(pyrdown32f="simd_hv", lanes=8))),
+            ("trig_glibc", lambda: S.set_trig_mode("glibc"), S.set_trig_mode, dict(trig=2)),  # oracle.TRIG_GLIBC,
+        ):
+            prev = setup()
+            try:
+                js = []
+                for c in ctxs:
+                    j = StitchJob(job.frames, job.cameras, num_bands=wl["bands"], ctx=c)
+                    j.warper.set_scale(all_cams)
+                    js.append(j)
+                m = dict(quick_rate(js, ctxs, src_mpix))
+                if not args.no_cpu_baseline:
+                    o_pano, o_mask, _ = oracle_chain(wl, host_frames, job.cameras, all_cams, **okw)
+                    m["parity"] = parity_record(js[0], o_pano, o_mask, "oracle under the same model")
+                modes[name] = m
+                del js
+            finally:
+                teardown(prev)
+        out["modes"] = modes
     if wl["cfg"] == 2:
         # BASELINE configs[3] (config 4), one GPU's share: 8 x 8000x6000, cylindrical, 7 bands
         cams4 = synthetic.grid_cameras(2, 4, 8000, 6000, max_edge_lat_deg=50.0, layout_yaw=16)

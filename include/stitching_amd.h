@@ -162,6 +162,11 @@ int stx_buf_from_host_async(stx_ctx* ctx, const void* host, size_t host_stride_b
 int stx_buf_to_host_async(const stx_buf* buf, void* host, size_t host_stride_bytes);
 /* rectangular sub-view sharing the parent's memory (numpy slicing in stitching/cropper.py:150-151) */
 int stx_buf_view(const stx_buf* buf, int x, int y, int w, int h, stx_buf** out);
+/* Source staging.  stitching/warper.py:43-52 hands cv2 a numpy BGR frame (3 bytes per pixel); the device samples a frame fastest
+ * when a pixel is one aligned dword — the bilinear tap pair is then a single 8-byte load instead of a 12-byte window that has to be
+ * re-aligned per pixel.  stx_buf_stage_bgrx makes that copy of a u8x3 image (u8x4: B, G, R, 0; one HBM-bound pass, 7 bytes per pixel)
+ * as part of a frame's upload; every warp entry point below takes either form and returns the same bytes for both. */
+int stx_buf_stage_bgrx(stx_ctx* ctx, const stx_buf* src_u8x3, stx_buf** out_u8x4);
 /* info = {w, h, channels, elem, stride_bytes, device} */
 int stx_buf_info(const stx_buf* buf, int64_t info[6]);
 /* device address of the first pixel (for zero-copy consumers, e.g. RCCL strip exchange) */
@@ -182,7 +187,8 @@ int stx_warp_rois(stx_ctx* ctx, int type, float scale, int n, const float* K9s, 
  *             stitching/warper.py:58-68 (interp=NEAREST, border=CONSTANT, src u8x1):
  *             cv.PyRotationWarper(type, scale).warp(src, K, R, interp, border)
  *             = RotationWarperBase::buildMaps + cv::remap, fused: maps are never stored.
- * out_tl receives the corner the reference discards (stitching/warper.py:45 `_`). */
+ * out_tl receives the corner the reference discards (stitching/warper.py:45 `_`).
+ * An INTER_LINEAR source may be u8x3 or its staged u8x4 form (stx_buf_stage_bgrx) — here and in every warp entry point below. */
 int stx_warp(stx_ctx* ctx, int type, float scale, const float K[9], const float R[9], const stx_buf* src, int interp,
              int border, stx_buf** out, int out_tl[2]);
 /* fused form of warper.py:43-52 + 58-68 for one camera: one pass computes the backward map
@@ -244,6 +250,14 @@ int stx_gain_apply(stx_ctx* ctx, stx_buf* img_u8x3, const float gains_bgr[3]);
  * INTER_LINEAR) [fp32] + cv::multiply, fused (the full-size gain map is never stored); gain_map is f32x1, or f32x3 (BGR
  * maps, interleaved) for "channel_blocks" (BlocksChannelsCompensator) */
 int stx_block_gain_apply(stx_ctx* ctx, stx_buf* img_u8x3, const stx_buf* gain_map_f32);
+/* the same for all n images of a panorama (the generator loop stitching/stitcher.py:219-221): two launches per 16 images, gain maps
+ * resident on the device.  full_wh_xy0 (or NULL) = {full_w, full_h, x0, y0} per image: imgs[i] is the rectangle at (x0, y0) of a warped
+ * image of size full_w x full_h (a seam-cell crop, stx_warp_batch_rects) and the gain map is laid over the FULL image, as
+ * BlocksCompensator::apply does — the rectangle's bytes equal those of the whole image compensated and then cut.
+ * flags (or NULL): STX_GAIN_MAP_BOUNDED per image — the caller has checked that every gain of the map is finite and below 2^31 / 255. */
+#define STX_GAIN_MAP_BOUNDED 1
+int stx_block_gain_apply_batch(stx_ctx* ctx, int n, stx_buf* const* imgs_u8x3, const stx_buf* const* gain_maps_f32,
+                               const int* full_wh_xy0, const int* flags);
 /* stx_resize_linear_exact <- stitching/images.py:122-124 cv.resize(img, size, interpolation=cv.INTER_LINEAR_EXACT) (u8x1 / u8x3:
  *                            the final-resolution resize of Images.resize, next row N3)
  * stx_seam_mask_resize    <- stitching/seam_finder.py:37-43 SeamFinder.resize: cv.dilate(seam_mask, None), cv.resize(...,

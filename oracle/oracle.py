@@ -541,4 +541,9 @@ def block_gain_apply(img, gain_map):
     if g.shape[:2] != img.shape[:2]:  # cv::resize works per channel (BlocksChannelsCompensator: CV_32FC3 maps)
         g = np.stack([resize_linear_f32(g[:, :, c], (img.shape[1], img.shape[0])) for c in range(g.shape[2])], axis=2)
     v = (img.astype(np.float32) * g).astype(np.float32)
-    return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+    # saturate_cast<uchar>(float) = saturate_cast<uchar>(cvRound(v)); cvRound is cvtss2si on x86-64: INT_MIN for NaN and for products
+    # outside the int range, which then saturates to 0 (not 255) — the device kernels restate exactly this
+    with np.errstate(invalid="ignore"):
+        ok = np.isfinite(v) & (v >= -2147483648.0) & (v < 2147483648.0)
+        r = np.where(ok, np.rint(np.where(ok, v, 0.0)), -2147483648.0)
+    return np.clip(r, 0, 255).astype(np.uint8)

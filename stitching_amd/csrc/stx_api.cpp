@@ -470,6 +470,22 @@ STX_EXPORT int stx_buf_view(const stx_buf* buf, int x, int y, int w, int h, stx_
     return STX_OK;
 }
 
+// Source staging (include/stitching_amd.h): the 4-byte-pixel copy of a u8x3 frame that the warp kernels sample fastest.
+STX_EXPORT int stx_buf_stage_bgrx(stx_ctx* ctx, const stx_buf* src, stx_buf** out)
+{
+    if (!ctx || !src || !out) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (src->elem != STX_U8 || src->c != 3) return stx_fail(STX_ERR_INVALID, "staging needs a u8x3 image");
+    if (src->ctx->device != ctx->device) return stx_fail(STX_ERR_INVALID, "image lives on another device");
+    if (src->h > 65535) return stx_fail(STX_ERR_UNSUPPORTED, "image of %d rows", src->h);
+    STX_TRY(stx_set_device(ctx));
+    stx_buf* b = nullptr;
+    STX_TRY(stx_buf_new(ctx, src->w, src->h, 4, STX_U8, &b));
+    int rc = stx_launch_stage_bgrx(ctx, src, b);
+    if (rc != STX_OK) { stx_buf_release(b); return rc; }
+    *out = b;
+    return STX_OK;
+}
+
 STX_EXPORT int stx_buf_info(const stx_buf* buf, int64_t info[6])
 {
     if (!buf || !info) return stx_fail(STX_ERR_INVALID, "null argument");
@@ -608,14 +624,9 @@ static void linear_f32_table(int src_n, int dst_n, bool clamp_offsets, std::vect
     }
 }
 
-STX_EXPORT int stx_block_gain_apply(stx_ctx* ctx, stx_buf* img, const stx_buf* gain_map)
+// one image through the one-pixel-per-lane kernel: any alignment (views), any gain-map size
+static int block_gain_plain(stx_ctx* ctx, stx_buf* img, const stx_buf* gain_map)
 {
-    if (!ctx || !img || !gain_map) return stx_fail(STX_ERR_INVALID, "null argument");
-    if (img->elem != STX_U8 || img->c != 3) return stx_fail(STX_ERR_INVALID, "block gain apply needs a u8x3 image");
-    if (gain_map->elem != STX_F32 || (gain_map->c != 1 && gain_map->c != 3))
-        return stx_fail(STX_ERR_INVALID, "the gain map must be f32x1 (gain_blocks) or f32x3 (channel_blocks)");
-    if (img->ctx != ctx || gain_map->ctx->device != ctx->device) return stx_fail(STX_ERR_INVALID, "buffers belong to another context");
-    STX_TRY(stx_set_device(ctx));
     std::vector<int> xt, yt;
     linear_f32_table(gain_map->w, img->w, true, xt);
     linear_f32_table(gain_map->h, img->h, false, yt);
@@ -628,6 +639,73 @@ STX_EXPORT int stx_block_gain_apply(stx_ctx* ctx, stx_buf* img, const stx_buf* g
     const int rc = stx_launch_block_gain(ctx, img, gain_map, (const int*)d_tab, (const int*)d_tab + xt.size());
     stx_dev_free(ctx, d_tab);
     return rc;
+}
+
+static int block_gain_check(stx_ctx* ctx, const stx_buf* img, const stx_buf* gain_map)
+{
+    if (!img || !gain_map) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (img->elem != STX_U8 || img->c != 3) return stx_fail(STX_ERR_INVALID, "block gain apply needs a u8x3 image");
+    if (gain_map->elem != STX_F32 || (gain_map->c != 1 && gain_map->c != 3))
+        return stx_fail(STX_ERR_INVALID, "the gain map must be f32x1 (gain_blocks) or f32x3 (channel_blocks)");
+    if (img->ctx != ctx || gain_map->ctx->device != ctx->device) return stx_fail(STX_ERR_INVALID, "buffers belong to another context");
+    return STX_OK;
+}
+
+// flags_or_null[i] & STX_GAIN_MAP_BOUNDED: the caller has checked that every gain of map i is finite and |g| < 2^31 / 255 (then no
+// product p * g can leave the int range, and the kernel drops the cvRound overflow test)
+STX_EXPORT int stx_block_gain_apply_batch(stx_ctx* ctx, int n, stx_buf* const* imgs, const stx_buf* const* gain_maps,
+                                          const int* full_wh_xy0, const int* flags_or_null)
+{
+    if (!ctx || n < 0 || (n > 0 && (!imgs || !gain_maps))) return stx_fail(STX_ERR_INVALID, "bad argument");
+    if (n == 0) return STX_OK;
+    STX_TRY(stx_set_device(ctx));
+    for (int i = 0; i < n; i++) {
+        STX_TRY(block_gain_check(ctx, imgs[i], gain_maps[i]));
+        if (full_wh_xy0) {
+            const int* q = full_wh_xy0 + 4 * i;
+            if (q[2] < 0 || q[3] < 0 || q[2] + imgs[i]->w > q[0] || q[3] + imgs[i]->h > q[1])
+                return stx_fail(STX_ERR_INVALID, "image %d: rectangle (%d,%d,%dx%d) outside the full image %dx%d", i, q[2], q[3], imgs[i]->w, imgs[i]->h, q[0], q[1]);
+        }
+    }
+    // the batched kernels want whole buffers of the library's own (dword rows, 4-pixel groups) and gain maps of block size (their
+    // horizontally interpolated rows are kept: gh x w floats); anything else takes the plain kernel, one image at a time
+    std::vector<stx_buf*> bi;
+    std::vector<const stx_buf*> bg;
+    std::vector<int> sub, fast;
+    size_t scratch = 0;
+    std::vector<size_t> offH, offY;
+    for (int i = 0; i < n; i++) {
+        const stx_buf* im = imgs[i];
+        const bool whole = !im->parent && ((uintptr_t)im->ptr & 3) == 0 && (im->stride & 3) == 0 && (size_t)((im->w + 3) & ~3) * 3 <= im->stride;
+        const size_t hbytes = (size_t)gain_maps[i]->h * ((im->w + 3) & ~3) * gain_maps[i]->c * sizeof(float);
+        const bool same_c = bi.empty() || gain_maps[i]->c == bg[0]->c;
+        if (!whole || hbytes > ((size_t)64 << 20) || !same_c) {
+            if (full_wh_xy0 && (full_wh_xy0[4 * i] != im->w || full_wh_xy0[4 * i + 1] != im->h))
+                return stx_fail(STX_ERR_UNSUPPORTED, "image %d: a rectangle of a larger image must be a whole buffer with a block-sized gain map", i);
+            STX_TRY(block_gain_plain(ctx, imgs[i], gain_maps[i]));
+            continue;
+        }
+        bi.push_back(imgs[i]); bg.push_back(gain_maps[i]);
+        for (int k = 0; k < 4; k++) sub.push_back(full_wh_xy0 ? full_wh_xy0[4 * i + k] : (k == 0 ? im->w : (k == 1 ? im->h : 0)));
+        fast.push_back(flags_or_null && (flags_or_null[i] & STX_GAIN_MAP_BOUNDED) ? 1 : 0);
+        offH.push_back(scratch); scratch += align_up(hbytes, 256);
+        offY.push_back(scratch); scratch += align_up((size_t)im->h * 8, 256);
+    }
+    if (bi.empty()) return STX_OK;
+    void* d = nullptr;
+    STX_TRY(stx_dev_alloc(ctx, scratch, &d));
+    std::vector<float*> Hs(bi.size());
+    std::vector<void*> yts(bi.size());
+    for (size_t i = 0; i < bi.size(); i++) { Hs[i] = (float*)((uint8_t*)d + offH[i]); yts[i] = (uint8_t*)d + offY[i]; }
+    const int rc = stx_launch_block_gain_batch(ctx, (int)bi.size(), bi.data(), bg.data(), sub.data(), Hs.data(), yts.data(), fast.data());
+    stx_dev_free(ctx, d);  // stream-ordered reuse
+    return rc;
+}
+
+STX_EXPORT int stx_block_gain_apply(stx_ctx* ctx, stx_buf* img, const stx_buf* gain_map)
+{
+    if (!ctx) return stx_fail(STX_ERR_INVALID, "null argument");
+    return stx_block_gain_apply_batch(ctx, 1, &img, &gain_map, nullptr, nullptr);
 }
 
 STX_EXPORT int stx_resize_linear_exact(stx_ctx* ctx, const stx_buf* src, int dst_w, int dst_h, stx_buf** out)
@@ -1157,7 +1235,7 @@ STX_EXPORT int stx_warp(stx_ctx* ctx, int type, float scale, const float K[9], c
     if (src->elem != STX_U8) return stx_fail(STX_ERR_INVALID, "warp source must be 8-bit");
     int roi[4];
     if (interp == STX_INTER_LINEAR && border == STX_BORDER_REFLECT) {
-        if (src->c != 3) return stx_fail(STX_ERR_UNSUPPORTED, "INTER_LINEAR warp needs a 3-channel u8 image");
+        if (src->c != 3 && src->c != 4) return stx_fail(STX_ERR_UNSUPPORTED, "INTER_LINEAR warp needs a 3-channel u8 image (or its staged BGRX form)");
         STX_TRY(warp_impl(ctx, type, scale, K, R, src, src->w, src->h, true, false, false, out, nullptr, roi));
     } else if (interp == STX_INTER_NEAREST && border == STX_BORDER_CONSTANT) {
         if (src->c != 1) return stx_fail(STX_ERR_UNSUPPORTED, "INTER_NEAREST warp needs a 1-channel u8 mask");
@@ -1183,7 +1261,8 @@ static int warp_batch_impl(stx_ctx* ctx, int type, float scale, int n, const flo
     std::vector<StxProjector> ps(n);
     std::vector<int> rois(4 * (size_t)n), sizes(2 * (size_t)n);
     for (int i = 0; i < n; i++) {
-        if (!srcs[i] || srcs[i]->elem != STX_U8 || srcs[i]->c != 3) return stx_fail(STX_ERR_INVALID, "warp source %d must be u8x3", i);
+        if (!srcs[i] || srcs[i]->elem != STX_U8 || (srcs[i]->c != 3 && srcs[i]->c != 4))
+            return stx_fail(STX_ERR_INVALID, "warp source %d must be u8x3 (or its staged u8x4 BGRX form)", i);
         // sources may live in another context of the same device (long-lived read-only inputs shared by several streams)
         if (srcs[i]->ctx->device != ctx->device) return stx_fail(STX_ERR_INVALID, "warp source %d lives on another device", i);
         STX_TRY(stx_make_projector(type, scale, K9s + 9 * i, R9s + 9 * i, &ps[i]));
@@ -1226,7 +1305,7 @@ static int warp_batch_impl(stx_ctx* ctx, int type, float scale, int n, const flo
         StxWarpLaunch& L = Ls[i];
         L.proj = ps[i];
         L.tlx = roi[0]; L.tly = roi[1]; L.dw = roi[2]; L.dh = roi[3];
-        L.src = srcs[i]->ptr; L.sw = srcs[i]->w; L.sh = srcs[i]->h; L.sstride = srcs[i]->stride; L.src_channels = 3;
+        L.src = srcs[i]->ptr; L.sw = srcs[i]->w; L.sh = srcs[i]->h; L.sstride = srcs[i]->stride; L.src_channels = srcs[i]->c;
         L.nearest_src = 0;
         L.dimg = bi[i] ? bi[i]->ptr : nullptr; L.dimg_stride = bi[i] ? bi[i]->stride : 0;
         L.dmask = bm[i] ? bm[i]->ptr : nullptr; L.dmask_stride = bm[i] ? bm[i]->stride : 0;
@@ -1264,7 +1343,7 @@ STX_EXPORT int stx_warp_image_and_mask(stx_ctx* ctx, int type, float scale, cons
     if (!ctx || !src) return stx_fail(STX_ERR_INVALID, "null argument");
     if (!out_img && !out_mask) return stx_fail(STX_ERR_INVALID, "nothing requested");
     STX_TRY(stx_set_device(ctx));
-    if (src->elem != STX_U8 || src->c != 3) return stx_fail(STX_ERR_INVALID, "warp source must be u8x3");
+    if (src->elem != STX_U8 || (src->c != 3 && src->c != 4)) return stx_fail(STX_ERR_INVALID, "warp source must be u8x3 (or its staged u8x4 BGRX form)");
     return warp_impl(ctx, type, scale, K, R, src, src->w, src->h, out_img != nullptr, out_mask != nullptr, false,
                      out_img, out_mask, out_xywh);
 }

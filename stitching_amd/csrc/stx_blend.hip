@@ -1490,3 +1490,157 @@ int stx_launch_block_gain(stx_ctx* ctx, stx_buf* img, const stx_buf* gmap, const
     hipLaunchKernelGGL(block_gain_kernel, dim3((img->w + 63) / 64, (img->h + 3) / 4), dim3(256), 0, ctx->stream, K);
     return check_launch("block_gain_apply");
 }
+
+// ---------------------------------------------------------------------------------------------
+// The same product for all images of a panorama in two launches, at HBM rate (stx_block_gain_apply_batch).  cv::resize(INTER_LINEAR)
+// is separable and rounds each pass to fp32, so the horizontal pass is made ONCE per gain-map row: H[r][x] = S[r][s] a0 + S[r][s+1] a1
+// for every column x of the image (gain_rows_kernel: gh x w floats per image, a few hundred KB, L2 resident; the coefficient set-up
+// f = (float)((x + 0.5) scale - 0.5) runs on the device in IEEE double, operation for operation the host loop of linear_f32_table).
+// The product pass then needs two 16-byte reads of H per 4 pixels and row: g = H[r0][x] b0 + H[r1][x] b1, cvRound(p g) saturated.
+// One lane = 4 pixels (three dwords in, three out), one wavefront = 256 pixels of a row, 4 rows one after the other.
+// An image may be the rectangle at (x0, y0) of a larger warped image (full_w x full_h: StitchJob's seam-cell crops): the gain map is
+// laid over the FULL image, as BlocksCompensator::apply lays it over the whole warped image.
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int GAIN_BATCH = 16;
+struct BlockGain4K {
+    uint8_t* img; long long stride; int w, h;          // the (sub-)image, whole rows of the library's own buffers (4-pixel groups)
+    int x0, y0, full_w, full_h;                        // its place in the full warped image
+    const float* gmap; long long gstride; int gw, gh;  // gstride in floats
+    double xscale, yscale;                             // 1 / (full / gain-map size), host double
+    float* H; long long hstride;                       // [gh][hstride] floats x GC; hstride = w rounded up to 4 (x GC)
+    int2* yt;                                          // [h]: (source row, bits of the fraction)
+    int fast;                                          // host-proved: every gain finite and below 2^31 / 255 (no product leaves int range)
+};
+struct BlockGainBatchK { BlockGain4K k[GAIN_BATCH]; };
+
+STX_DEV void gain_coeff(int d, double scale, int src_n, bool clamp, int& sidx, float& f)
+{
+    f = (float)(((double)d + 0.5) * scale - 0.5);
+    sidx = (int)floorf(f);
+    f = stxd::fsub(f, (float)sidx);
+    if (clamp) {
+        if (sidx < 0) { sidx = 0; f = 0.f; }
+        else if (sidx >= src_n - 1) { sidx = src_n - 1; f = 0.f; }
+    }
+}
+
+template <int GC>
+__global__ __launch_bounds__(256) void gain_rows_kernel(BlockGainBatchK B)
+{
+    const BlockGain4K& P = B.k[blockIdx.z];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.y == 0) {  // row table
+        if (i < P.h) {
+            int sy; float f;
+            gain_coeff(P.y0 + i, P.yscale, P.gh, false, sy, f);
+            P.yt[i] = make_int2(sy, __float_as_int(f));
+        }
+        return;
+    }
+    const int r = blockIdx.y - 1;  // gain-map row
+    if (r >= P.gh || i >= P.w) return;
+    int sx; float a1;
+    gain_coeff(P.x0 + i, P.xscale, P.gw, true, sx, a1);
+    const float a0 = stxd::fsub(1.f, a1);
+    const float* row = P.gmap + (long long)r * P.gstride;
+#pragma unroll
+    for (int c = 0; c < GC; c++) {
+        float v;
+        if (sx >= P.gw - 1) v = row[sx * GC + c];
+        else v = stxd::fadd(stxd::fmul(row[sx * GC + c], a0), stxd::fmul(row[(sx + 1) * GC + c], a1));
+        P.H[(long long)r * P.hstride + (long long)i * GC + c] = v;
+    }
+}
+
+// cvRound(p g) saturated to u8 into byte `sel` of `old`; v_cvt_pk_u8_f32 saturates, v_rndne_f32 is the round-half-even of cvRound
+template <bool FAST>
+STX_DEV uint32_t gain_px(uint32_t old, int sel, float p, float g)
+{
+    float v = stxd::fmul(p, g);
+    if (!FAST) v = v < 2147483648.f ? v : 0.f;  // cvRound's INT_MIN for NaN / out-of-range products saturates to 0
+    return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(v), (uint32_t)sel, old);
+}
+
+template <int GC, bool FAST>
+__global__ __launch_bounds__(256) void block_gain4_kernel(BlockGainBatchK B)
+{
+    const BlockGain4K& P = B.k[blockIdx.z];
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (x4 >= P.w) return;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int y = blockIdx.y * 16 + wv * 4 + j;
+        if (y >= P.h) break;
+        const int2 ty = P.yt[y];
+        const float b1 = __int_as_float(ty.y), b0 = stxd::fsub(1.f, b1);
+        const int r0 = min(max(ty.x, 0), P.gh - 1), r1 = min(max(ty.x + 1, 0), P.gh - 1);
+        const float* h0 = P.H + (long long)r0 * P.hstride + (long long)x4 * GC;
+        const float* h1 = P.H + (long long)r1 * P.hstride + (long long)x4 * GC;
+        float g[4 * GC];
+#pragma unroll
+        for (int q = 0; q < GC; q++) {
+            const float4 u = reinterpret_cast<const float4*>(h0)[q], v = reinterpret_cast<const float4*>(h1)[q];
+            g[4 * q + 0] = stxd::fadd(stxd::fmul(u.x, b0), stxd::fmul(v.x, b1));
+            g[4 * q + 1] = stxd::fadd(stxd::fmul(u.y, b0), stxd::fmul(v.y, b1));
+            g[4 * q + 2] = stxd::fadd(stxd::fmul(u.z, b0), stxd::fmul(v.z, b1));
+            g[4 * q + 3] = stxd::fadd(stxd::fmul(u.w, b0), stxd::fmul(v.w, b1));
+        }
+        uint32_t* p = reinterpret_cast<uint32_t*>(P.img + (long long)y * P.stride + (long long)x4 * 3);
+        uint32_t d[3] = {p[0], p[1], p[2]}, o[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 12; k++) {  // byte k of the 12: pixel k / 3, channel k % 3
+            const float pv = (float)((d[k >> 2] >> (8 * (k & 3))) & 255u);
+            o[k >> 2] = gain_px<FAST>(o[k >> 2], k & 3, pv, GC == 1 ? g[k / 3] : g[k]);
+        }
+        p[0] = o[0]; p[1] = o[1]; p[2] = o[2];
+    }
+}
+}  // namespace
+
+// Hs / yts: per image device scratch (gh x hstride x gc floats, h int2), carved by the caller from one allocation
+int stx_launch_block_gain_batch(stx_ctx* ctx, int n, stx_buf* const* imgs, const stx_buf* const* gmaps, const int* full_wh_xy0,
+                                float* const* Hs, void* const* yts, const int* fast)
+{
+    for (int base = 0; base < n; base += GAIN_BATCH) {
+        const int m = std::min(GAIN_BATCH, n - base);
+        const int gc = gmaps[base]->c;
+        BlockGainBatchK B;
+        memset(&B, 0, sizeof(B));
+        int mw = 0, mh = 0, mgh = 0, mt = 0;
+        bool all_fast = true;
+        double bytes = 0.0, rows_bytes = 0.0;
+        for (int i = 0; i < m; i++) {
+            const int g = base + i;
+            BlockGain4K& K = B.k[i];
+            K.img = imgs[g]->ptr; K.stride = (long long)imgs[g]->stride; K.w = imgs[g]->w; K.h = imgs[g]->h;
+            K.full_w = full_wh_xy0 ? full_wh_xy0[4 * g] : K.w; K.full_h = full_wh_xy0 ? full_wh_xy0[4 * g + 1] : K.h;
+            K.x0 = full_wh_xy0 ? full_wh_xy0[4 * g + 2] : 0; K.y0 = full_wh_xy0 ? full_wh_xy0[4 * g + 3] : 0;
+            K.gmap = (const float*)gmaps[g]->ptr; K.gstride = (long long)(gmaps[g]->stride / sizeof(float));
+            K.gw = gmaps[g]->w; K.gh = gmaps[g]->h;
+            K.xscale = 1.0 / ((double)K.full_w / (double)K.gw);
+            K.yscale = 1.0 / ((double)K.full_h / (double)K.gh);
+            K.H = Hs[g]; K.hstride = (long long)((K.w + 3) & ~3) * gc;
+            K.yt = (int2*)yts[g];
+            K.fast = fast[g];
+            all_fast = all_fast && fast[g];
+            mw = std::max(mw, K.w); mh = std::max(mh, K.h); mgh = std::max(mgh, K.gh); mt = std::max(mt, std::max(K.w, K.h));
+            bytes += 6.0 * K.w * K.h;
+            rows_bytes += 4.0 * gc * K.gh * K.w + 8.0 * K.h;
+        }
+        {
+            StxProfScope prof(ctx, "block_gain_rows", rows_bytes);
+            const dim3 grid((mt + 255) / 256, mgh + 1, m);
+            if (gc == 1) hipLaunchKernelGGL(gain_rows_kernel<1>, grid, dim3(256), 0, ctx->stream, B);
+            else hipLaunchKernelGGL(gain_rows_kernel<3>, grid, dim3(256), 0, ctx->stream, B);
+        }
+        StxProfScope prof(ctx, "block_gain_apply", bytes);
+        const dim3 grid((mw + 255) / 256, (mh + 15) / 16, m);
+        if (gc == 1 && all_fast) hipLaunchKernelGGL((block_gain4_kernel<1, true>), grid, dim3(256), 0, ctx->stream, B);
+        else if (gc == 1) hipLaunchKernelGGL((block_gain4_kernel<1, false>), grid, dim3(256), 0, ctx->stream, B);
+        else if (all_fast) hipLaunchKernelGGL((block_gain4_kernel<3, true>), grid, dim3(256), 0, ctx->stream, B);
+        else hipLaunchKernelGGL((block_gain4_kernel<3, false>), grid, dim3(256), 0, ctx->stream, B);
+    }
+    return check_launch("block_gain_apply");
+}

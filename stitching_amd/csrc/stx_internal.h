@@ -153,6 +153,8 @@ struct StxWarpLaunch {
 };
 int stx_launch_warp(stx_ctx* ctx, const StxWarpLaunch& L);
 int stx_launch_warp_batch(stx_ctx* ctx, const StxWarpLaunch* Ls, int n);
+// u8x3 -> u8x4 (BGRX) copy of a source frame (stx_buf_stage_bgrx)
+int stx_launch_stage_bgrx(stx_ctx* ctx, const stx_buf* src, stx_buf* dst);
 int stx_launch_roi_minmax(stx_ctx* ctx, int n, const StxProjector* projs, const int* sizes_wh, float* out_minmax4);
 
 // multi-band -------------------------------------------------------------------------------------
@@ -189,6 +191,8 @@ int stx_launch_mb_coarse(stx_ctx* ctx, const MbLevelK& K_level_Bm2, double algo_
 // pointwise exposure gain (next row N1) --------------------------------------------------------------
 int stx_launch_gain_apply(stx_ctx* ctx, stx_buf* img, const float g[3]);
 int stx_launch_block_gain(stx_ctx* ctx, stx_buf* img, const stx_buf* gmap, const int* d_xt, const int* d_yt);
+int stx_launch_block_gain_batch(stx_ctx* ctx, int n, stx_buf* const* imgs, const stx_buf* const* gmaps, const int* full_wh_xy0,
+                                float* const* Hs, void* const* yts, const int* fast);
 // cv::resize(INTER_LINEAR_EXACT) u8 (next rows N2 / N3); d_xt / d_yt: device tables of (offset, coeff1 | interior << 16)
 int stx_launch_resize_exact(stx_ctx* ctx, const stx_buf* src, stx_buf* dst, const int* d_xt, const int* d_yt, bool dilate,
                             const stx_buf* andmask);

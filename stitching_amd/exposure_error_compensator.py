@@ -43,6 +43,7 @@ class ExposureErrorCompensator:
         self.compensator_type = compensator
         self.nr_feeds, self.block_size = nr_feeds, block_size
         self.gains = None
+        self._dev_gains = {}  # (context, image index) -> (DeviceImage of the gain map, STX_GAIN_MAP_BOUNDED flag): uploaded once
         self.compensator = estimator if estimator is not None else self._cv_estimator(compensator, nr_feeds, block_size)
 
     @staticmethod
@@ -61,6 +62,7 @@ class ExposureErrorCompensator:
     def set_gains(self, gains):
         """gains[i]: scalar ("gain"), 3 per-channel BGR values ("channel") or the fp32 gain map ("gain_blocks":
         cv2's compensator.getMatGains()[i]) for image i."""
+        self._dev_gains = {}
         if self.compensator_type == "gain_blocks":
             self.gains = [np.ascontiguousarray(np.asarray(g, np.float32).reshape(np.asarray(g).shape[:2])) for g in gains]
         elif self.compensator_type == "channel_blocks":  # CV_32FC3 gain maps (one BGR triple per block)
@@ -80,6 +82,43 @@ class ExposureErrorCompensator:
         self.compensator.feed(list(corners), [host(i) for i in imgs], [host(m) for m in masks])
         self.set_gains([host(g) for g in self.compensator.getMatGains()])
 
+    def _gain_map(self, idx, ctx):
+        """The fp32 gain map of image idx in HBM (uploaded at its first use on `ctx`, kept until set_gains) and whether every
+        gain is finite and below 2^31 / 255 (no product with a byte can leave the int range)."""
+        key = (id(ctx), idx)
+        hit = self._dev_gains.get(key)
+        if hit is None:
+            g = self.gains[idx]
+            bounded = bool(np.isfinite(g).all() and np.abs(g).max(initial=0.0) < 8.0e6)
+            hit = self._dev_gains[key] = (as_device(g, ctx), _lib.GAIN_MAP_BOUNDED if bounded else 0)
+        return hit
+
+    def apply_all(self, corners, imgs, masks=None, sub=None, ctx=None):
+        """`apply` for all images of a panorama (the generator loop of stitching/stitcher.py:219-221) — the block compensators in two
+        launches per 16 images with the gain maps resident (stx_block_gain_apply_batch), the others one launch per image.
+        sub: optional (full_w, full_h, x0, y0) per image — imgs[i] is that rectangle of the whole warped image (a seam-cell crop:
+        StitchJob); the gain map is laid over the whole image as BlocksCompensator::apply lays it."""
+        imgs = list(imgs)
+        if self.compensator_type == "no" or not imgs:
+            return imgs
+        if self.compensator_type not in ("gain_blocks", "channel_blocks"):
+            return [self.apply(i, None, img, None) for i, img in enumerate(imgs)]
+        if self.gains is None:
+            raise StitchingError("ExposureErrorCompensator.set_gains(gains) must be called before apply")
+        from .device import DeviceImage
+
+        ctx = ctx or next((i.ctx for i in imgs if isinstance(i, DeviceImage)), None) or get_context()
+        d = [as_device(img, ctx) for img in imgs]
+        n = len(d)
+        gm = [self._gain_map(i, ctx) for i in range(n)]
+        ia, ga = (C.c_void_p * n)(*[a._h for a in d]), (C.c_void_p * n)(*[g[0]._h for g in gm])
+        fl = (C.c_int * n)(*[g[1] for g in gm])
+        q = None
+        if sub is not None:
+            q = np.ascontiguousarray(np.asarray(sub, np.int32).reshape(n, 4)).ctypes.data_as(C.POINTER(C.c_int))
+        _lib.check(ctx._lib.stx_block_gain_apply_batch(ctx.handle, n, ia, ga, q, fl))
+        return d if config.device_resident() else [a.numpy() for a in d]
+
     def apply(self, idx, corner, img, mask):
         """-> the compensated image (same object for device images: the product is written in place, as OpenCV does)."""
         if self.compensator_type == "no":
@@ -91,14 +130,19 @@ class ExposureErrorCompensator:
             raise StitchingError("ExposureErrorCompensator.set_gains(gains) must be called before apply")
         g = self.gains[idx]
         if self.compensator_type in ("gain_blocks", "channel_blocks"):
-            ctx = get_context()
+            from .device import DeviceImage
+
+            ctx = img.ctx if isinstance(img, DeviceImage) else get_context()
             d = as_device(img, ctx)
-            gm = as_device(g, ctx)
-            _lib.check(ctx._lib.stx_block_gain_apply(ctx.handle, d._h, gm._h))
+            gm, flag = self._gain_map(idx, ctx)
+            _lib.check(ctx._lib.stx_block_gain_apply_batch(ctx.handle, 1, (C.c_void_p * 1)(d._h), (C.c_void_p * 1)(gm._h), None,
+                                                           (C.c_int * 1)(flag)))
             return d if config.device_resident() else d.numpy()
         g3 = np.full(3, g[0], np.float64) if g.size == 1 else g[:3]
         g3 = np.ascontiguousarray(g3, np.float32)  # arithm_op demotes the double scalar to float for 8-bit images
-        ctx = get_context()
+        from .device import DeviceImage
+
+        ctx = img.ctx if isinstance(img, DeviceImage) else get_context()
         d = as_device(img, ctx)
         _lib.check(ctx._lib.stx_gain_apply(ctx.handle, d._h, g3.ctypes.data_as(C.POINTER(C.c_float))))
         return d if config.device_resident() else d.numpy()

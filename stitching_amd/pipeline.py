@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib, config
 from .blender import Blender
-from .device import as_device, get_context
+from .device import as_device, as_source, get_context
 from .stitching_error import StitchingError
 from .synthetic import blend_strength_for_bands
 from .warper import Warper
@@ -83,7 +83,7 @@ class StitchJob:
 
     def __init__(self, frames, cameras, warper_type="spherical", blender_type="multiband", num_bands=None,
                  blend_strength=Blender.DEFAULT_BLEND_STRENGTH, ctx=None, async_upload=False, feed_masks=None, seam_masks=None,
-                 crop_to_masks=True):
+                 crop_to_masks=True, compensator=None):
         """async_upload: numpy frames in page-locked memory (pinned_empty) are only queued for upload; they must stay
         untouched until ctx.sync() (a streaming caller alternates two contexts).
         feed_masks: final-resolution u8 masks fed to the blender instead of the warped masks (seam masks already at the
@@ -93,16 +93,20 @@ class StitchJob:
         crop_to_masks (multi-band blender, feed_masks / seam_masks given as host arrays): a seam mask keeps one cell of its
         image, and nothing farther than the pyramids reach from that cell can touch the panorama.  The reference warps
         every image whole and cuts afterwards (stitching/stitcher.py:119-127); here only the rectangle the blender can see
-        are warped, masked and fed — the same panorama bit for bit (`view_rects`)."""
+        are warped, masked and fed — the same panorama bit for bit (`view_rects`).
+        compensator: an ExposureErrorCompensator with its gains set (the low-resolution pass made them): applied to the warped
+        images between warp and feed (stitching/stitcher.py:123,219-221) — all images in one batched launch; on cropped images the
+        gain maps are laid over the whole warped image (the rectangle's offset travels with it)."""
         if len(frames) != len(cameras) or not frames:
             raise StitchingError("need one camera per frame and at least one frame")
         self.ctx = ctx or get_context()
-        self.frames = [as_device(f, self.ctx, wait=not async_upload) for f in frames]
+        self.frames = [as_source(f, self.ctx, wait=not async_upload) for f in frames]
         self.cameras = list(cameras)
         self.sizes = [(f.width, f.height) for f in self.frames]
         self.warper = Warper(warper_type, ctx=self.ctx)
         self.warper.set_scale(self.cameras)
         self.blender_type = blender_type
+        self.compensator = compensator
         self.num_bands = num_bands
         self.blend_strength = blend_strength
         self.corners = self.warped_sizes = None
@@ -163,8 +167,13 @@ class StitchJob:
                     masks = SeamFinder.resize_all(self.seam_masks, masks,
                                                   sub=[(w, h, x0, y0) for (x0, x1, y0, y1), (w, h) in zip(box, self.warped_sizes)])
                 corners = [(r[0], r[1]) for r in rects]
+                if self.compensator is not None:
+                    imgs = self.compensator.apply_all(corners, imgs, masks, ctx=self.ctx,
+                                                      sub=[(w, h, x0, y0) for (x0, x1, y0, y1), (w, h) in zip(box, self.warped_sizes)])
             else:
                 imgs, masks, rois = self.warper.warp_images_and_masks(self.frames, self.cameras)
+                if self.compensator is not None:
+                    imgs = self.compensator.apply_all(self.corners, imgs, masks, ctx=self.ctx)
                 if self.feed_masks is not None:
                     masks = self.feed_masks
                 elif self.seam_masks is not None:
@@ -198,19 +207,20 @@ def compose(frames, cameras, warper_type="spherical", blender_type="multiband", 
     masks (one per image, e.g. from cv2's seam finder), or None for the full warped masks.
     Returns device-resident (panorama u8x3, mask u8)."""
     ctx = ctx or get_context()
-    if compensator is None and seam_masks is not None and blender_type == "multiband":
-        # nothing between the warp and the blender needs whole images: warp and feed only what the seam cells can reach
+    if seam_masks is not None and blender_type == "multiband":
+        # nothing between the warp and the blender needs whole images (the gain of a pixel depends on its position alone): warp,
+        # compensate and feed only what the seam cells can reach
         return StitchJob(frames, cameras, warper_type=warper_type, blender_type=blender_type, blend_strength=blend_strength, ctx=ctx,
-                         seam_masks=[np.asarray(m.get() if hasattr(m, "get") else m) for m in seam_masks]).run()
+                         seam_masks=[np.asarray(m.get() if hasattr(m, "get") else m) for m in seam_masks], compensator=compensator).run()
     prev = config.device_resident()
     config.set_device_resident(True)
     try:
         warper = Warper(warper_type, ctx=ctx)
         warper.set_scale(cameras)
-        imgs, masks, rois = warper.warp_images_and_masks([as_device(f, ctx) for f in frames], cameras)
+        imgs, masks, rois = warper.warp_images_and_masks([as_source(f, ctx) for f in frames], cameras)
         corners, sizes = [r[0:2] for r in rois], [r[2:4] for r in rois]
         if compensator is not None:
-            imgs = [compensator.apply(i, corners[i], img, masks[i]) for i, img in enumerate(imgs)]
+            imgs = compensator.apply_all(corners, imgs, masks, ctx=ctx)
         if seam_masks is not None:
             from .seam_finder import SeamFinder
 

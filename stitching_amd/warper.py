@@ -12,7 +12,7 @@ from statistics import median
 import numpy as np
 
 from . import _lib, config
-from .device import DeviceImage, as_device, get_context
+from .device import DeviceImage, as_source, get_context
 from .stitching_error import StitchingError
 
 _TYPE_IDS = _lib.WARP_TYPE_IDS
@@ -76,9 +76,7 @@ class Warper:
 
     def warp_image(self, img, camera, aspect=1):
         ctx = self._ctx()
-        src = as_device(img, ctx)
-        if src.channels != 3 or src.dtype != np.uint8:
-            raise StitchingError(f"warp_image expects a HxWx3 uint8 image, got {src.shape} {src.dtype}")
+        src = self._source(img, ctx)
         K, R = self._K_R(camera, aspect)
         out, tl = C.c_void_p(), (C.c_int * 2)()
         _lib.check(ctx._lib.stx_warp(ctx.handle, self._type_id(), self._scale(aspect), _fp(K), _fp(R), src._h,
@@ -141,7 +139,7 @@ class Warper:
         """Fused form of warp_image + create_and_warp_mask for one camera: the backward map is
         evaluated once.  Returns (warped_image, warped_mask, (x, y, w, h))."""
         ctx = self._ctx()
-        src = as_device(img, ctx)
+        src = self._source(img, ctx)
         K, R = self._K_R(camera, aspect)
         oi, om, roi = C.c_void_p(), C.c_void_p(), (C.c_int * 4)()
         _lib.check(ctx._lib.stx_warp_image_and_mask(ctx.handle, self._type_id(), self._scale(aspect), _fp(K), _fp(R),
@@ -155,7 +153,7 @@ class Warper:
         rects: optional (x, y, w, h) per image in warp coordinates — only that rectangle of each warped image / mask is
         produced (pixel for pixel what the full warp holds there); the returned rois are then these rectangles."""
         ctx = self._ctx()
-        srcs = [as_device(img, ctx) for img in imgs]
+        srcs = [self._source(img, ctx) for img in imgs]
         cameras = list(cameras)
         n = min(len(srcs), len(cameras))
         if n == 0:
@@ -163,8 +161,6 @@ class Warper:
         Ks = np.empty((n, 3, 3), np.float32)
         Rs = np.empty((n, 3, 3), np.float32)
         for i in range(n):
-            if srcs[i].channels != 3 or srcs[i].dtype != np.uint8:
-                raise StitchingError(f"warp_image expects a HxWx3 uint8 image, got {srcs[i].shape} {srcs[i].dtype}")
             Ks[i], Rs[i] = self._K_R(cameras[i], aspect)
         h_src = (C.c_void_p * n)(*[s._h for s in srcs[:n]])
         h_img, h_mask = (C.c_void_p * n)(), (C.c_void_p * n)()
@@ -181,6 +177,19 @@ class Warper:
         return imgs_out, masks_out, [tuple(int(v) for v in r) for r in rois]
 
     # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _source(img, ctx):
+        """The device form of a warp source.  Host frames (HxWx3 uint8, as cv2 takes them) are uploaded and staged per
+        config.source_layout(); device images may be u8x3 or their staged u8x4 (BGRX) form."""
+        if isinstance(img, DeviceImage):
+            if img.channels not in (3, 4) or img.dtype != np.uint8:
+                raise StitchingError(f"warp_image expects a HxWx3 uint8 image (or a staged BGRX device image), got {img.shape} {img.dtype}")
+            return img  # as it lies in HBM: staging is the owner's call (DeviceImage.staged(), as_source), once per frame
+        a = np.asarray(img)
+        if a.ndim != 3 or a.shape[2] != 3 or a.dtype != np.uint8:
+            raise StitchingError(f"warp_image expects a HxWx3 uint8 image, got {a.shape} {a.dtype}")
+        return as_source(a, ctx)
+
     def _type_id(self):
         if self.warper_type not in Warper.WARP_TYPE_CHOICES:
             raise StitchingError(f"unknown warper type {self.warper_type!r}")

@@ -7,12 +7,17 @@ import numpy as np
 from oracle import oracle as O
 
 __version__ = "0.0-fake-oracle"
+
 INTER_NEAREST, INTER_LINEAR, INTER_LINEAR_EXACT = 0, 1, 5
 BORDER_CONSTANT, BORDER_REFLECT = 0, 2
 CV_8UC3 = 16
 
 # the build this module pretends to be
 MODEL = dict(trig=O.TRIG_LIBM, pyrdown32f="simd_hv", lanes=4, remap="q15")
+
+
+def getBuildInformation():
+    return "stand-in: the oracle under " + repr(MODEL)
 
 
 class _Model:

@@ -12,7 +12,9 @@ PI_F = F(np.pi)
 
 # The three places where two recollections of OpenCV differed, as switches: the defaults are what the oracle does;
 # tools/compare_with_opencv.py flips them one at a time against a real cv2 and reports which side OpenCV is on.
-SMALL_MATRIX_PRODUCT = "float"   # "float": cv::gemm's 3 x 3 CV_32F branch, float products summed left to right; "double": double accumulation
+SMALL_MATRIX_PRODUCT = "float"   # "float": cv::gemm's 3 x 3 CV_32F branch, float products summed left to right; "double": double accumulation;
+                                 # "float_fma": the same branch compiled with multiply-add contraction (an AVX2 / FMA dispatch build):
+                                 # fma(a2, b2, fma(a1, b1, a0 * b0))
 PLANE_ROI_CORNERS = "size-1"     # PlaneWarper::detectResultRoi projects (0, 0) .. (W - 1, H - 1); "size": (W, H)
 AFFINE_USES_K = True             # AffineWarper passes K through to the plane warper; False: the identity
 
@@ -26,6 +28,11 @@ def _mul3x3_f32(a, b):
     a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
     if SMALL_MATRIX_PRODUCT == "double":
         return (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
+    if SMALL_MATRIX_PRODUCT == "float_fma":
+        # fma through float64: the product of two floats is exact there, the sum is rounded to 53 bits and then to 24 (a double rounding
+        # can only differ from the fused result on an exact 29-bit tie: not in these probes)
+        f = lambda x, y, z: np.float32(np.float64(x) * np.float64(y) + np.float64(z))  # noqa: E731
+        return np.array([[f(a[i, 2], b[2, j], f(a[i, 1], b[1, j], a[i, 0] * b[0, j])) for j in range(3)] for i in range(3)], np.float32)
     return np.array([[(a[i, 0] * b[0, j] + a[i, 1] * b[1, j]) + a[i, 2] * b[2, j] for j in range(3)] for i in range(3)], np.float32)
 
 

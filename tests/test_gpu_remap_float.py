@@ -83,3 +83,34 @@ def test_panorama_in_float_mode_equals_the_oracles(oracle, gpu_ctx, remap_guard)
     for a, b in zip(g["w_imgs"], o["w_imgs"]):
         assert np.array_equal(a, b), f"{np.count_nonzero(a != b)} warped bytes differ"
     assert np.array_equal(g["pmask"], o["pmask"]) and np.array_equal(g["pano"], o["pano"])
+
+
+@pytest.mark.parametrize("mode", ["float", "float-fma"])
+@pytest.mark.parametrize("wtype", ["spherical", "cylindrical"])
+def test_float_remap_on_steeply_pitched_frames(oracle, gpu_ctx, remap_guard, wtype, mode):
+    """round 5: the float models run on the tuned kernel — interior wavefronts through its own fp32 blend, wavefronts that touch the
+    border (mirror images, rays behind the camera) pixel by pixel.  Pitched and rolled frames have plenty of both; both source layouts."""
+    import math
+
+    from stitching_amd.camera import CameraParams
+
+    S.set_remap_mode(mode)
+    oracle.set_model(remap=ORACLE_NAME[mode])
+    w, h = 421, 313
+    rng = np.random.default_rng(31)
+    lim = 65.0 if wtype == "spherical" else 36.0
+    g, o = S.Warper(wtype), oracle.Warper(wtype)
+    cams = []
+    for i in range(3):
+        R = (synthetic.rot_y(math.radians(25.0 * i)) @ synthetic.rot_x(math.radians(float(rng.uniform(-lim, lim))))
+             @ synthetic.rot_z(math.radians(float(rng.uniform(-25, 25)))))
+        cams.append(CameraParams(focal=0.8 * w, aspect=1.0, ppx=w / 2.0, ppy=h / 2.0, R=R.astype(np.float32)))
+    g.set_scale(cams)
+    o.set_scale(cams)
+    for k, cam in enumerate(cams):
+        img = synthetic.make_frame(40 + k, w, h)
+        oi = o.warp_image(img, cam)
+        d = S.DeviceImage.from_numpy(img, gpu_ctx)
+        for src in (d, d.staged()):
+            gi = np.asarray(g.warp_image(src, cam))
+            assert np.array_equal(gi, oi), (k, src.channels, int(np.count_nonzero(gi != oi)))

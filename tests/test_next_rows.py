@@ -251,3 +251,102 @@ def test_compose_final_resolution_pipeline(oracle, gpu_ctx):
     comp.set_gains(gmaps)
     pano, mask = compose(imgs, cams, blend_strength=15, compensator=comp, seam_masks=low)
     assert np.array_equal(np.asarray(mask), omask) and np.array_equal(np.asarray(pano), op)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["gain_blocks", "channel_blocks"])
+def test_block_gain_apply_all_batched(oracle, gpu_ctx, kind):
+    """ExposureErrorCompensator.apply_all = the loop of stitching/stitcher.py:219-221 in two launches: images of mixed sizes (more
+    than one kernel batch), gain maps resident; equal to the oracle's per-image apply"""
+    rng = np.random.default_rng(5)
+    sizes = [(517, 389), (640, 480), (33, 17), (1203, 907)] * 5
+    imgs = [synthetic.make_frame(i, max(w, 16), max(h, 12))[:h, :w].copy() for i, (w, h) in enumerate(sizes)]
+    shape = lambda w, h: ((h + 31) // 32, (w + 31) // 32) + ((3,) if kind == "channel_blocks" else ())  # noqa: E731
+    gmaps = [(0.6 + 0.9 * rng.random(shape(w, h))).astype(np.float32) for w, h in sizes]
+    e = S.ExposureErrorCompensator(kind)
+    e.set_gains(gmaps)
+    out = e.apply_all([(0, 0)] * len(imgs), [im.copy() for im in imgs])
+    for k, (o, im, g) in enumerate(zip(out, imgs, gmaps)):
+        assert np.array_equal(np.asarray(o), oracle.block_gain_apply(im, g)), k
+    # a second call reuses the resident maps
+    out2 = e.apply_all([(0, 0)] * 2, [im.copy() for im in imgs[:2]])
+    assert np.array_equal(np.asarray(out2[1]), oracle.block_gain_apply(imgs[1], gmaps[1]))
+
+
+@pytest.mark.gpu
+def test_block_gain_on_a_rectangle_of_the_warped_image(oracle, gpu_ctx):
+    """sub = (full_w, full_h, x0, y0): the gain map lies over the WHOLE warped image (BlocksCompensator::apply), the rectangle's
+    bytes are those of the whole image compensated and then cut — what StitchJob's seam-cell crops rely on"""
+    rng = np.random.default_rng(8)
+    full = synthetic.make_frame(2, 1203, 907)
+    gmap = (0.6 + 0.9 * rng.random((29, 38))).astype(np.float32)
+    want = oracle.block_gain_apply(full, gmap)
+    e = S.ExposureErrorCompensator("gain_blocks")
+    e.set_gains([gmap, gmap, gmap])
+    rects = [(0, 0, 1203, 907), (256, 128, 512, 301), (1000, 900, 203, 7)]
+    subs = [full[y:y + h, x:x + w].copy() for x, y, w, h in rects]
+    out = e.apply_all([(0, 0)] * 3, subs, sub=[(1203, 907, x, y) for x, y, w, h in rects])
+    for o, (x, y, w, h) in zip(out, rects):
+        assert np.array_equal(np.asarray(o), want[y:y + h, x:x + w]), (x, y, w, h)
+
+
+@pytest.mark.gpu
+def test_block_gain_unbounded_maps_and_views(oracle, gpu_ctx):
+    """gains whose products leave the int range (cvRound gives INT_MIN -> saturates to 0), NaN gains, and device views (no dword rows:
+    the one-pixel-per-lane kernel) equal the oracle's bytes"""
+    img = synthetic.make_frame(6, 300, 200)
+    g = np.ones((7, 10), np.float32)
+    g[0, 0], g[3, 4], g[6, 9], g[2, 2] = np.float32(3e7), np.float32(np.nan), np.float32(-4.0), np.float32(np.inf)
+    e = S.ExposureErrorCompensator("gain_blocks")
+    e.set_gains([g])
+    assert np.array_equal(np.asarray(e.apply(0, (0, 0), img.copy(), None)), oracle.block_gain_apply(img, g))
+    S.set_device_resident(True)
+    try:
+        d = S.DeviceImage.from_numpy(synthetic.make_frame(7, 320, 220), gpu_ctx)
+        v = d[10:210, 11:311]
+        host = np.asarray(v).copy()
+        g2 = (0.7 + 0.6 * np.random.default_rng(3).random((7, 10))).astype(np.float32)
+        e2 = S.ExposureErrorCompensator("gain_blocks")
+        e2.set_gains([g2])
+        out = e2.apply(0, (0, 0), v, None)
+        assert np.array_equal(np.asarray(out), oracle.block_gain_apply(host, g2))
+        # the bytes around the view are untouched
+        a = np.asarray(d)
+        assert np.array_equal(a[:10], synthetic.make_frame(7, 320, 220)[:10]) and np.array_equal(a[:, :11], synthetic.make_frame(7, 320, 220)[:, :11])
+    finally:
+        S.set_device_resident(False)
+
+
+@pytest.mark.gpu
+def test_job_with_compensator_and_seam_cells(oracle, gpu_ctx):
+    """StitchJob(compensator=, seam_masks=): warp only what the seam cells reach, compensate those rectangles with the offset gain
+    maps, resize the seam masks, blend — against the oracle chain on whole images (the reference's DEFAULT composition:
+    stitching/stitcher.py:22-48 gain_blocks + dp_color seam masks + multiband)"""
+    from stitching_amd.pipeline import StitchJob
+
+    imgs, cams = helpers_ring(6, 900, 700, 200.0)
+    ow = oracle.Warper("spherical")
+    ow.set_scale(cams)
+    wi = [ow.warp_image(i, c) for i, c in zip(imgs, cams)]
+    wm = [ow.create_and_warp_mask((900, 700), c) for c in cams]
+    corners, sizes = ow.warp_rois([(900, 700)] * 6, cams)
+    rng = np.random.default_rng(21)
+    gmaps = [(0.8 + 0.4 * rng.random(((s[1] // 8 + 31) // 32, (s[0] // 8 + 31) // 32))).astype(np.float32) for s in sizes]
+    low = [np.ascontiguousarray(m[::8, ::8]) for m in synthetic.voronoi_seam_masks(wm, corners, sizes)]
+    ob = oracle.Blender("multiband", 5)
+    ob.prepare(corners, sizes)
+    for a, g, l, m, c in zip(wi, gmaps, low, wm, corners):
+        ob.feed(oracle.block_gain_apply(a, g), oracle.seam_resize(l, m), c)
+    op, omask = ob.blend()
+    comp = S.ExposureErrorCompensator("gain_blocks")
+    comp.set_gains(gmaps)
+    job = StitchJob(imgs, cams, blend_strength=5, ctx=gpu_ctx, seam_masks=low, compensator=comp)
+    pano, mask = job.run()
+    assert job.last_crop is not None  # the crop path really ran
+    assert np.array_equal(np.asarray(mask), omask) and np.array_equal(np.asarray(pano), op)
+
+
+def helpers_ring(n, w, h, span):
+    from tests import helpers
+
+    return helpers.small_ring(n, w, h, span=span)

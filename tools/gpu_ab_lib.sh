@@ -11,7 +11,7 @@ for i in $(seq $REPS); do
   for spec in "$@"; do
     IFS='|' read -r label lib envs xargs <<< "$spec"
     ( [ -n "$lib" ] && export STITCHING_AMD_LIB="$GRAFT_REPO_ROOT/$lib"; for e in $envs; do export "$e"; done
-      timeout 600 python bench.py --no-cpu-baseline --e2e-steps 0 ${AB_ARGS:---no-extra} --steps 20 $xargs > "$OUT/bench_${label}_$i.json" 2> "$OUT/bench_${label}_$i.err" )
+      timeout 600 python bench.py --no-cpu-baseline --e2e-steps 0 ${AB_ARGS:---no-extra} --steps 20 --min-seconds ${AB_MIN_S:-0.5} $xargs > "$OUT/bench_${label}_$i.json" 2> "$OUT/bench_${label}_$i.err" )
     python - "$OUT/bench_${label}_$i.json" "$label" <<'PY'
 import json,sys
 try:
