@@ -387,21 +387,23 @@ def main():
         # Control plane = the product's own TCP rendezvous (stitching_amd/rendezvous.py).  Its port: STITCHING_AMD_RDZV_PORT when the
         # launcher exports one; under torch.distributed.run (the driver's launcher — MASTER_PORT belongs to its store) rank 0 picks a
         # free port and the launcher's gloo group carries that one integer, then torch is out of the picture.
-        from stitching_amd.rendezvous import TcpGroup, free_port
+        from stitching_amd.rendezvous import TcpGroup, bound_listener
 
-        port = os.environ.get("STITCHING_AMD_RDZV_PORT")
+        port, listener = os.environ.get("STITCHING_AMD_RDZV_PORT"), None
         if port is None:
             import torch.distributed as tdist
 
             if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
                 os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: do not make gloo resolve the container's host name
             tdist.init_process_group(backend="gloo", rank=rank, world_size=world)
-            box = [free_port() if rank == 0 else None]
+            if rank == 0:  # rank 0 binds its listening socket NOW and keeps it: nobody can take the port in between
+                listener, lport = bound_listener(os.environ.get("MASTER_ADDR", "127.0.0.1"))
+            box = [lport if rank == 0 else None]
             tdist.broadcast_object_list(box, src=0)
             tdist.barrier()
             tdist.destroy_process_group()
             port = box[0]
-        dist = TcpGroup(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), int(port))
+        dist = TcpGroup(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), int(port), listener=listener)
 
     import numpy as np
 
@@ -567,6 +569,8 @@ def main():
         result["parity"] = parity_n
     if world > 1:
         p = job.plan_
+        tr = jobs[0].transport
+        result["config"]["transport"] = dict(name=tr.name, **(tr.info() if hasattr(tr, "info") else {}))  # rccl: ncclCommCount, ncclGetVersion
         result["config"]["exchange"] = {"messages": len(p.messages), "bytes_per_step": p.exchanged_bytes(),
                                         "rank0_sends_MB": round(sum(m[4] for m in p.sends(0)) / 1e6, 1),
                                         "busiest_link_MB": round(p.busiest_link_bytes() / 1e6, 1),  # xGMI is point to point

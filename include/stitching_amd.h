@@ -360,6 +360,8 @@ int stx_comm_exchange_end(stx_comm* comm);
 int stx_comm_exchange_begin_on(stx_comm* comm, stx_ctx* on, int n_ops, const int* peers, const int* is_send,
                                void* const* dev_ptrs, const size_t* bytes);
 int stx_comm_exchange_end_on(stx_comm* comm, stx_ctx* on);
+/* what librccl itself reports: {ncclCommCount, ncclCommUserRank, ncclGetVersion, device}; -1 where the loaded library lacks the call */
+int stx_comm_info(const stx_comm* comm, int out_info[4]);
 int stx_comm_destroy(stx_comm* comm);
 
 /* ---- measurement hooks (bench.py) -----------------------------------------------------

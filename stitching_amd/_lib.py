@@ -37,7 +37,7 @@ EXPORTS = (
     "stx_warp_roi stx_warp_rois stx_warp stx_warp_image_and_mask stx_warp_batch stx_warp_batch_rects stx_warp_mask "
     "stx_gain_apply stx_block_gain_apply stx_block_gain_apply_batch stx_resize_linear_exact stx_seam_mask_resize stx_seam_mask_resize_batch stx_seam_mask_resize_batch_sub stx_timelapse_frame stx_result_roi stx_blend_create stx_blend_num_bands stx_blend_feed stx_blend_finish stx_blend_finish_ex "
     "stx_blend_destroy stx_blend_set_band stx_blend_feed_ex stx_blend_contrib_rect stx_blend_export_contrib stx_blend_export_contribs "
-    "stx_blend_build stx_blend_feed_contrib stx_blend_feed_contrib_ex stx_buf_flags stx_strip_rect stx_view_rect stx_strip_pack stx_strip_pack_batch stx_strip_pack_batch_ex stx_strip_bytes stx_strip_unpack stx_blend_feed_strips stx_comm_unique_id stx_comm_create stx_comm_exchange stx_comm_exchange_begin stx_comm_exchange_end stx_comm_exchange_begin_on stx_comm_exchange_end_on stx_comm_destroy stx_prof_enable stx_prof_reset stx_prof_count stx_prof_get stx_mark stx_mark_elapsed_ms "
+    "stx_blend_build stx_blend_feed_contrib stx_blend_feed_contrib_ex stx_buf_flags stx_strip_rect stx_view_rect stx_strip_pack stx_strip_pack_batch stx_strip_pack_batch_ex stx_strip_bytes stx_strip_unpack stx_blend_feed_strips stx_comm_unique_id stx_comm_create stx_comm_exchange stx_comm_exchange_begin stx_comm_exchange_end stx_comm_exchange_begin_on stx_comm_exchange_end_on stx_comm_info stx_comm_destroy stx_prof_enable stx_prof_reset stx_prof_count stx_prof_get stx_mark stx_mark_elapsed_ms "
     "stx_debug_warp_maps stx_debug_feather_dist_cap"  # include/stitching_amd_debug.h: test hooks, never called by the package's classes
 ).split()
 
@@ -131,6 +131,7 @@ def lib():
     L.stx_comm_exchange_end.argtypes = [vp]
     L.stx_comm_exchange_begin_on.argtypes = [vp, vp, C.c_int, ip, ip, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.stx_comm_exchange_end_on.argtypes = [vp, vp]
+    L.stx_comm_info.argtypes = [vp, ip]
     L.stx_comm_destroy.argtypes = [vp]
     L.stx_prof_enable.argtypes = [vp, C.c_int]
     L.stx_prof_reset.argtypes = [vp]

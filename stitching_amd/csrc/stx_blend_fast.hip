@@ -1919,13 +1919,14 @@ bool stx_fast_mb_level(stx_ctx* ctx, const MbLevelK& K)
         // u8 images whose masks are not known to be binary (resized seam masks: the reference's default pipeline): the packed kernel
         // with per-lane deferral + the fp32-weight pass over the queued patches.  The queue has room for every patch of the region; it
         // and its counter come from the stream-ordered allocator and go back to it right behind the second launch.
-        // a tile holds at most 256 patches; segment s takes the tile columns tx = s (mod SEGS)
+        // a tile (one wavefront: LV_THREADS lanes) holds at most LV_THREADS patches; segment s takes the tile columns tx = s (mod SEGS), so
+        // only the first min(tiles_x, SEGS) segments exist and only they get room (a 1024-column panorama used to pay for all 256)
         const int segs = std::min(KT.tiles.tiles_x, STX_DEFER_SEGS);
         const size_t seg_cap = (size_t)((KT.tiles.tiles_x + STX_DEFER_SEGS - 1) / STX_DEFER_SEGS) * (size_t)KT.tiles.tiles_y * (unsigned)LV_THREADS;
         const size_t counters = (size_t)STX_DEFER_SEGS * 128;
         KT.defer_segs = segs;
         void* q = nullptr;
-        if (stx_dev_alloc(ctx, counters + seg_cap * STX_DEFER_SEGS * sizeof(unsigned long long), &q) != STX_OK) return false;
+        if (stx_dev_alloc(ctx, counters + seg_cap * (size_t)segs * sizeof(unsigned long long), &q) != STX_OK) return false;
         KT.defer_count = reinterpret_cast<unsigned*>(q);
         KT.defer_list = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint8_t*>(q) + counters);
         KT.defer_cap = (unsigned)seg_cap;

@@ -28,6 +28,10 @@ struct RcclApi {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    // optional (stx_comm_info): what the library itself says about the communicator
+    int (*CommCount)(RcclComm, int*) = nullptr;
+    int (*CommUserRank)(RcclComm, int*) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
 };
 RcclApi g_rccl;
 
@@ -55,6 +59,9 @@ int load_rccl()
     SYM(GroupEnd, "ncclGroupEnd")
     SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+    *(void**)(&a.CommCount) = dlsym(h, "ncclCommCount");
+    *(void**)(&a.CommUserRank) = dlsym(h, "ncclCommUserRank");
+    *(void**)(&a.GetVersion) = dlsym(h, "ncclGetVersion");
     g_rccl = a;
     return STX_OK;
 }
@@ -103,6 +110,19 @@ STX_EXPORT int stx_comm_create(stx_ctx* ctx, int nranks, int rank, const unsigne
     stx_comm* k = new stx_comm();
     k->ctx = ctx; k->comm = c; k->nranks = nranks; k->rank = rank;
     *out = k;
+    return STX_OK;
+}
+
+// {ranks the library counts in the communicator (ncclCommCount), this rank by the library (ncclCommUserRank), library version
+// (ncclGetVersion), device}; -1 where the loaded library lacks the call
+STX_EXPORT int stx_comm_info(const stx_comm* comm, int out[4])
+{
+    if (!comm || !out) return stx_fail(STX_ERR_INVALID, "null argument");
+    out[0] = out[1] = out[2] = -1;
+    out[3] = comm->ctx->device;
+    if (g_rccl.CommCount) STX_RCCL(g_rccl.CommCount(comm->comm, &out[0]));
+    if (g_rccl.CommUserRank) STX_RCCL(g_rccl.CommUserRank(comm->comm, &out[1]));
+    if (g_rccl.GetVersion) STX_RCCL(g_rccl.GetVersion(&out[2]));
     return STX_OK;
 }
 

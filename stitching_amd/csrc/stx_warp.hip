@@ -458,11 +458,6 @@ STX_DEV uint32_t lshl16_or_u32(uint32_t a, uint32_t b)  // (a << 16) | b
 #ifndef STX_WARP_NOAND
 #define STX_WARP_NOAND 1
 #endif
-// STX_WARP_NT = 1: the warped image and mask leave with non-temporal stores (they are read next by another kernel, 317 MB later: keeping
-// them out of the way of the source rows in L2 is the idea)
-#ifndef STX_WARP_NT
-#define STX_WARP_NT 0
-#endif
 // PX4: the source holds 4 bytes per pixel (BGRX, stx_buf_stage_bgrx): the pixel pair of a row is ONE aligned 8-byte load — no 12-byte
 // window, no v_alignbyte, a third of the load instructions (2 instead of 6 per pixel): 96 VALU per 4 pixels instead of 117.
 // The adjacent pixel pair (ix, ix + 1) of rows iy and iy + 1, all four taps inside the source: l = first 4 bytes, h = next 4 of either row
@@ -872,23 +867,12 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
             STX_GAS uint8_t* base = (STX_GAS uint8_t*)(dimg_a + (unsigned long long)y0 * (unsigned long long)dimg_stride + (unsigned long long)xw * 3ull);
             STX_GAS uint32_t* d = reinterpret_cast<STX_GAS uint32_t*>(base + (__umul24((uint32_t)r, (uint32_t)dimg_stride) + (uint32_t)c * 12u));
             const uint32_t a0 = sp[0], a1 = sp[1], a2 = sp[2];
-#if STX_WARP_NT
-            typedef uint32_t u32x3 __attribute__((ext_vector_type(3), aligned(4)));
-            const u32x3 v3 = {a0, a1, a2};
-            __builtin_nontemporal_store(v3, reinterpret_cast<STX_GAS u32x3*>(d));
-#else
-            d[0] = a0; d[1] = a1; d[2] = a2;
-#endif
+            d[0] = a0; d[1] = a1; d[2] = a2;  // (non-temporal stores, round 5: 183.7 / 184.5 us against 177.1 / 177.9 — dropped)
         }
         if (MASK) {
             STX_GAS uint8_t* base = (STX_GAS uint8_t*)(dmask_a + (unsigned long long)y0 * (unsigned long long)dmask_stride + (unsigned long long)xw);
-#if STX_WARP_NT
-            __builtin_nontemporal_store(wave_int ? 0xffffffffu : s_mk[wv][4 * it + r][c],
-                                        reinterpret_cast<STX_GAS uint32_t*>(base + (__umul24((uint32_t)r, (uint32_t)dmask_stride) + (uint32_t)c * 4u)));
-#else
             *reinterpret_cast<STX_GAS uint32_t*>(base + (__umul24((uint32_t)r, (uint32_t)dmask_stride) + (uint32_t)c * 4u)) =
                 wave_int ? 0xffffffffu : s_mk[wv][4 * it + r][c];
-#endif
         }
     } else {
         if (IMG) {

@@ -386,6 +386,12 @@ class RcclTransport:
         self._h = h
         self._inflight, self._last = {}, None
 
+    def info(self):
+        """What librccl itself says about this communicator: ranks it counts, this rank, its version (e.g. 22203), the device"""
+        out = (C.c_int * 4)()
+        _lib.check(self.ctx._lib.stx_comm_info(self._h, out))
+        return {"rccl_ranks": int(out[0]), "rccl_user_rank": int(out[1]), "rccl_version": int(out[2]), "device": int(out[3])}
+
     @staticmethod
     def unique_id():
         """ncclGetUniqueId.  No environment is touched here: a caller whose ranks all share one host may wrap this call and the
@@ -490,7 +496,12 @@ class ShardedStitchJob:
         self.warper = Warper(warper_type, ctx=self.ctx)
         self.warper.set_scale(self.all_cameras)
         self.num_bands_req, self.blend_strength = num_bands, blend_strength
-        self.dist = group if group is not None else dist
+        self.dist = group if group is not None else dist  # `dist`: the older name of the same argument
+        if self.dist is not None:
+            missing = [m for m in ("all_gather", "gather", "broadcast", "barrier", "all_reduce_min", "exchange_bytes") if not hasattr(self.dist, m)]
+            if missing:
+                raise StitchingError(f"group= needs the TcpGroup interface (stitching_amd/rendezvous.py); {type(self.dist).__name__} lacks "
+                                     f"{', '.join(missing)} — wrap it like tests/gloo_group.py wraps torch.distributed")
         self.transport = transport
         self.split_boundary = bool(split_boundary)
         self.exchange = exchange
@@ -506,6 +517,7 @@ class ShardedStitchJob:
         return sum(f.width * f.height for f in self.frames)
 
     def plan(self):
+        refusal = None  # a reason this rank cannot run the job, raised on every rank together after the agreement round
         corners, wsizes = self.warper.warp_rois(self.all_sizes, self.all_cameras)
         roi = Blender.result_roi(corners, wsizes)
         self.roi = roi
@@ -524,17 +536,19 @@ class ShardedStitchJob:
             self.plan_ = ShardPlan(corners, wsizes, self.owners, self.world, None, "strips", self.mask_bits, kind=self.flat_kind,
                                    halo=feather_halo(self.sharpness), balance=self.balance)
         else:
+            # pyr_order() (csrc/stx_blend.hip) splits a row into vector body and scalar tail from the width and x of the FEED
+            # RECTANGLE; an exchange strip's rectangle is not its image's, so under a vector-order model the fp32 weights of a
+            # strip and of the whole image may round differently at the same column: "sharded == single GPU, bit for bit" would
+            # not hold.  The models exist to be compared with on one GPU; sharded jobs refuse them — AFTER the
+            # ranks have compared notes (_check_plan_agreement), so that a rank whose environment alone names such a mode does not
+            # leave its peers waiting in the agreement's all_gather until the rendezvous times out.
             if config.pyrdown_mode()[0] != "scalar":
-                # pyr_order() (csrc/stx_blend.hip) splits a row into vector body and scalar tail from the width and x of the FEED
-                # RECTANGLE; an exchange strip's rectangle is not its image's, so under a vector-order model the fp32 weights of a
-                # strip and of the whole image may round differently at the same column: "sharded == single GPU, bit for bit" would
-                # not hold.  The models exist to be compared with on one GPU; sharded jobs refuse them.
-                raise StitchingError("sharded multi-band blending needs the scalar pyrDown order (STITCHING_AMD_PYRDOWN / set_pyrdown_mode)")
+                refusal = "sharded multi-band blending needs the scalar pyrDown order (STITCHING_AMD_PYRDOWN / set_pyrdown_mode)"
             self.req_bands = int((np.log(blend_width) / np.log(2.0) - 1.0))
             probe = make_shard_blender(self.ctx, roi, self.req_bands)
             self.plan_ = ShardPlan(corners, wsizes, self.owners, self.world, probe, self.exchange, self.mask_bits, balance=self.balance)
         self.last_num_bands = self.plan_.num_bands
-        self._check_plan_agreement()
+        self._check_plan_agreement(refusal)
         if self.transport is None:
             self.transport = default_transport(self.ctx, self.rank, self.world, self.dist)
         return self.plan_
@@ -550,14 +564,19 @@ class ShardedStitchJob:
                  float(self.blend_strength), float(getattr(self, "sharpness", 0.0)))
         return hashlib.sha256(repr(state).encode()).hexdigest()
 
-    def _check_plan_agreement(self):
+    def _check_plan_agreement(self, refusal=None):
         """ShardPlan is "pure geometry, identical on every rank" only while every rank sees the same cameras AND the same environment
         (STITCHING_AMD_BALANCE, the arithmetic modes).  A rank that differs would post other sends / receives than its peers expect and
         the job would hang in the exchange: compare digests over the control plane first and fail with a message instead."""
         if self.world == 1 or self.dist is None:
+            if refusal:
+                raise StitchingError(refusal)
             return
         mine = self.plan_digest()
-        all_ = self.dist.all_gather(mine)
+        both = self.dist.all_gather((mine, refusal))
+        all_, refused = [b[0] for b in both], [(r, b[1]) for r, b in enumerate(both) if b[1]]
+        if refused:  # every rank raises, together
+            raise StitchingError(f"rank {self.rank}: " + "; ".join(f"rank {r}: {msg}" for r, msg in refused))
         if len(set(all_)) != 1:
             odd = [r for r, d in enumerate(all_) if d != all_[0]]
             raise StitchingError(f"rank {self.rank}: the shard plan differs between ranks (ranks {odd} disagree with rank 0): cameras, "
@@ -580,6 +599,8 @@ class ShardedStitchJob:
             finally:
                 config.set_device_resident(prev)
         try:
+            if config.pyrdown_mode()[0] != "scalar":  # the mode is read again when a blender builds its pyramids: it must still be the planned one
+                raise StitchingError("the pyrDown mode changed between plan() and run(): sharded multi-band blending needs the scalar order")
             blender = make_shard_blender(self.ctx, self.roi, self.req_bands)
             blender.set_band(*p.band(self.rank))
             send_msgs = p.sends(self.rank)
@@ -710,6 +731,34 @@ def all_ranks_on_one_host(group):
     return len(set(group.all_gather(socket.gethostname()))) == 1
 
 
+def call_with_timeout(fn, seconds, what):
+    """fn() on a helper thread; StitchingError when it has not returned after `seconds`.  For calls into librccl's bootstrap
+    (ncclGetUniqueId, ncclCommInitRank), which on a node without a usable interface do not fail but wait forever: the job then
+    falls back to the host-staged transport instead of hanging (the helper thread is a daemon and is left behind)."""
+    import threading
+
+    box = {}
+
+    def run():
+        try:
+            box["v"] = fn()
+        except BaseException as e:  # noqa: BLE001 - re-raised on the calling thread
+            box["e"] = e
+
+    t = threading.Thread(target=run, daemon=True, name="stx-rccl-bootstrap")
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        raise StitchingError(f"{what} has not returned after {seconds:.0f} s (STITCHING_AMD_RCCL_TIMEOUT)")
+    if "e" in box:
+        raise box["e"]
+    return box.get("v")
+
+
+def rccl_timeout():
+    return float(os.environ.get("STITCHING_AMD_RCCL_TIMEOUT", "120"))
+
+
 def default_transport(ctx, rank, world, group):
     """RCCL when it initialises on this node, else the host-staged transport over the control-plane group."""
     if world == 1:
@@ -729,7 +778,7 @@ def default_transport(ctx, rank, world, group):
     if rank == 0 and want == "rccl":
         try:
             with loopback_bootstrap(one_host):
-                uid = RcclTransport.unique_id()
+                uid = call_with_timeout(RcclTransport.unique_id, rccl_timeout(), "ncclGetUniqueId")
         except Exception as e:  # noqa: BLE001
             print(f"[stitching_amd] rank 0: no RCCL unique id ({e}); using the host-staged transport", file=sys.stderr)
     uid = group.broadcast(uid, 0)
@@ -737,7 +786,7 @@ def default_transport(ctx, rank, world, group):
     if uid is not None:
         try:
             with loopback_bootstrap(one_host):
-                tr = RcclTransport(ctx, rank, world, uid)
+                tr = call_with_timeout(lambda: RcclTransport(ctx, rank, world, uid), rccl_timeout(), "ncclCommInitRank")
             ok = 1
         except Exception as e:  # noqa: BLE001 - any failure -> agree on the fallback below
             print(f"[stitching_amd] rank {rank}: RCCL transport unavailable ({e}); using the host-staged transport", file=sys.stderr)

@@ -40,7 +40,11 @@ def main():
                            ctx=ctx, group=dist, split_boundary=case.get("split", True), exchange=case.get("exchange", "strips"),
                            mask_bits=case.get("mask_bits", True))
     plan = job.plan()
-    res = {"transport": job.transport.name, "bands": plan.num_bands, "messages": len(plan.messages), "bytes": plan.exchanged_bytes()}
+    res = {"transport": job.transport.name, "bands": plan.num_bands, "messages": len(plan.messages), "bytes": plan.exchanged_bytes(),
+           "max_hops": max([abs(m[2] - m[1]) for m in plan.messages] or [0]),  # how many ranks away the farthest strip travels
+           "peers_of_rank": [len({m[2] for m in plan.sends(r)} | {m[1] for m in plan.recvs(r)}) for r in range(world)]}
+    if hasattr(job.transport, "info"):
+        res.update(job.transport.info())
     for _ in range(case.get("repeat", 2)):  # the second panorama reuses cached blocks, buffers and the transport
         pano, mask = job.run()
     full, fmask = job.gather(pano, mask)

@@ -218,6 +218,10 @@ FAKE_API int ncclCommDestroy(void* comm)
     return OK;
 }
 
+FAKE_API int ncclCommCount(void* comm, int* count) { if (!comm || !count) return fail(ERR_ARGUMENT, "ncclCommCount: bad argument"); *count = static_cast<Comm*>(comm)->nranks; return OK; }
+FAKE_API int ncclCommUserRank(void* comm, int* rank) { if (!comm || !rank) return fail(ERR_ARGUMENT, "ncclCommUserRank: bad argument"); *rank = static_cast<Comm*>(comm)->rank; return OK; }
+FAKE_API int ncclGetVersion(int* v) { if (!v) return fail(ERR_ARGUMENT, "ncclGetVersion: bad argument"); *v = 0; return OK; }  // 0: the test double
+
 FAKE_API int ncclGroupStart() { g_depth++; return OK; }
 
 FAKE_API int ncclGroupEnd()

@@ -118,3 +118,16 @@ def test_three_ranks_all_pairs_over_the_rccl_code_path_with_a_test_double(gpu_ct
     assert res["transport"] == "rccl" and res["bands"] == 5 and res["messages"] >= 4 and res["ok"], res
     res = launch(3, dict(layout="ring", w=803, h=601, per_rank=2, warper="spherical", blender="feather", strength=4, span=170.0), rank_env=lambda r: env)
     assert res["transport"] == "rccl" and res["ok"], res
+
+
+def test_eight_ranks_config3_layout_over_the_rccl_code_path_with_a_test_double(gpu_ctx):
+    """all 8 ranks of BASELINE config 3's layout (8 yaw columns x 4 pitch rows, one column per rank; frames at a fifth
+    of the size, same angles) as 8 processes through RcclTransport / stx_comm_*: the +-56 degree rows warp to twice their source width, so
+    a rank owes strips to its second (and third) neighbours too — all of a rank's sends and receives of a step in ONE ncclGroupStart /
+    ncclGroupEnd (csrc/stx_comm.cpp), the part most likely to misbehave on first contact with a real librccl.  Panorama == oracle."""
+    env = _rccl_double_env()
+    res = launch(8, dict(layout="grid", rows=4, w=800, h=600, per_rank=4, warper="spherical", bands=5, layout_yaw=8, mask_bits=True, repeat=2),
+                 rank_env=lambda r: env, timeout=900)
+    assert res["transport"] == "rccl" and res["rccl_ranks"] == 8 and res["rccl_user_rank"] == 0, res
+    assert res["bands"] == 5 and res["max_hops"] >= 2 and max(res["peers_of_rank"]) >= 4, res  # strips beyond the nearest neighbour
+    assert res["ok"], res

@@ -349,37 +349,112 @@ def test_tcp_group_peer_death_is_an_error_not_a_hang():
     assert isinstance(res[2], StitchingError), res[2]       # rank 2 waits for rank 0's broadcast, which never comes: rank 0 closed
 
 
-def test_tcp_group_rejects_a_stranger_on_the_rendezvous_port():
+def test_tcp_group_drops_strangers_and_goes_on():
+    """a stray connection (a port scanner, a wrong key) to the rendezvous port is closed and the wait goes on — the job does
+    not abort; the real rank, arriving later, is admitted.  Rank 0 hands over its bound listener (no port race)."""
     import socket
     import threading
-    import time
 
-    from stitching_amd.rendezvous import TcpGroup, free_port
+    from stitching_amd.rendezvous import TcpGroup, bound_listener
+
+    lst, port = bound_listener()
+    res = {}
+
+    def run(rank):
+        try:
+            g = TcpGroup(rank, 2, "127.0.0.1", port, timeout=20, listener=lst if rank == 0 else None)
+            res[rank] = g.all_gather(rank)
+            g.close()
+        except Exception as e:  # noqa: BLE001
+            res[rank] = e
+
+    t0 = threading.Thread(target=run, args=(0,), daemon=True)
+    t0.start()
+    for junk in (b"GET / HTTP/1.1\r\n\r\n", b"STXRDZV2" + b"\0" * 60, b""):
+        s = socket.create_connection(("127.0.0.1", port), timeout=2)
+        s.sendall(junk)
+        s.close()
+    t1 = threading.Thread(target=run, args=(1,), daemon=True)
+    t1.start()
+    t0.join(30)
+    t1.join(30)
+    assert res == {0: [0, 1], 1: [0, 1]}, res
+
+
+def test_tcp_group_shared_secret(monkeypatch):
+    """STITCHING_AMD_RDZV_SECRET keys the hello towards rank 0: a rank with the wrong secret is dropped like any stranger (rank 0 times
+    out waiting for the real one), ranks with the right one join"""
+    import threading
+
+    from stitching_amd import rendezvous as R
     from stitching_amd.stitching_error import StitchingError
 
-    port, res = free_port(), {}
+    secrets = {0: b"right", 1: b"wrong"}
+    res = {}
 
-    def rank0():
+    def run(rank, port, lst=None):
         try:
-            TcpGroup(0, 2, "127.0.0.1", port, timeout=10)
-            res[0] = "joined"
+            g = R.TcpGroup(rank, 2, "127.0.0.1", port, timeout=1.5, listener=lst)
+            res[rank] = g.all_gather(rank)
+            g.close()
         except StitchingError as e:
-            res[0] = e
+            res[rank] = e
 
-    t = threading.Thread(target=rank0, daemon=True)
-    t.start()
-    deadline = time.monotonic() + 10
-    while True:
-        try:
-            s = socket.create_connection(("127.0.0.1", port), timeout=1)
-            break
-        except OSError:
-            assert time.monotonic() < deadline
-            time.sleep(0.02)
-    s.sendall(b"GET / HTTP/1.1\r\n\r\n")
-    t.join(20)
-    s.close()
-    assert isinstance(res.get(0), StitchingError) and "stranger" in str(res[0])
+    monkeypatch.setattr(R, "_secret", lambda: secrets[int(threading.current_thread().name)])
+    lst, port = R.bound_listener()
+    ts = [threading.Thread(target=run, args=(r, port, lst if r == 0 else None), name=str(r), daemon=True) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(20)
+    assert isinstance(res[0], StitchingError) and "timed out" in str(res[0]), res
+    assert isinstance(res[1], StitchingError), res
+    secrets[1] = b"right"
+    res.clear()
+    lst, port = R.bound_listener()
+    ts = [threading.Thread(target=run, args=(r, port, lst if r == 0 else None), name=str(r), daemon=True) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(20)
+    assert res == {0: [0, 1], 1: [0, 1]}, res
+
+
+def test_tcp_group_reads_data_not_code():
+    """collective payloads are plain data; a peer that sends a pickle naming a callable (os.system ...) gets a
+    StitchingError on the reading side, nothing is executed; oversized announcements are refused before any allocation"""
+    import io
+    import pickle
+    import socket
+    import struct
+
+    from stitching_amd import rendezvous as R
+    from stitching_amd.stitching_error import StitchingError
+
+    a, b = socket.socketpair()
+    try:
+        payload = {"band": np.arange(12, dtype=np.uint8).reshape(3, 4), "edges": [0, 5, 9], "t": (1.5, "x", None, True), "f": np.float32(2.5)}
+        R._send_obj(a, payload)
+        got = R._recv_obj(b)
+        assert np.array_equal(got["band"], payload["band"]) and got["edges"] == [0, 5, 9] and got["t"] == (1.5, "x", None, True) and got["f"] == 2.5
+
+        class Evil:
+            def __reduce__(self):
+                import os
+
+                return (os.system, ("echo pwned > /tmp/stx_rdzv_pwned",))
+
+        data = pickle.dumps(Evil())
+        a.sendall(struct.pack("<Q", len(data)) + data)
+        with pytest.raises(StitchingError, match="only plain data"):
+            R._recv_obj(b)
+        a.sendall(struct.pack("<Q", 1 << 60))
+        with pytest.raises(StitchingError, match="limit"):
+            R._recv_obj(b)
+    finally:
+        a.close()
+        b.close()
+    _ = io
 
 
 def test_rccl_test_double_protocol():

@@ -9,7 +9,7 @@ curved wedge of the source frame, and what can be sent cheaply is a rectangle (r
 for every message of the plan it maps the strip's destination rectangle back into the source (the oracle's build_maps on a 1 : 8 lattice,
 + 2 px of bilinear support + the lattice step as slack), takes the bounding rectangle of the samples that land inside the frame, and
 compares bytes.  It also prices the extra warp the RECEIVER would run: the strip's destination pixels at the measured per-pixel rate of
-the warp kernel (profiles/r03_e5_legs_config3.txt: 227.7 us for one rank's 4 frames = 89.3 Mpx of ROI -> 2.55 ns per destination px).
+the warp kernel (profiles/r03_e5_legs_config3.txt: 227.7 us for one rank's 4 frames = 89.3 Mpx of ROI -> 2.55 ps per destination px).
 
 usage: python tools/cost_source_strips.py [--out profiles/r04_source_strip_costing.md]
 """

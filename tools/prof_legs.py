@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-kernel HIP-event table of an operating point other than the bench default (one panorama at a time).
-usage: python tools/prof_legs.py [seams|voronoi|config4|feather|no|config3] [steps]"""
+usage: python tools/prof_legs.py [seams|voronoi|defaults|config4|feather|no|config3] [steps]"""
 import os
 import sys
 
@@ -17,7 +17,7 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     ctx = S.get_context()
     W, H = 4000, 3000
-    if leg in ("seams", "voronoi"):
+    if leg in ("seams", "voronoi", "defaults"):
         cams = synthetic.ring_cameras(8, W, H)
         frames = [synthetic.make_frame(i, W, H) for i in range(8)]
         base = StitchJob(frames, cams, num_bands=5)
@@ -26,7 +26,18 @@ def main():
         _, masks, _ = base.warper.warp_images_and_masks(base.frames, base.cameras)
         S.set_device_resident(False)
         seams = synthetic.voronoi_seam_masks([np.asarray(m) for m in masks], base.corners, base.warped_sizes)
-        if leg == "voronoi":
+        if leg == "defaults":  # bench.py extra.reference_defaults: gain_blocks + resized seam masks + blend_strength 5 (7 bands)
+            rng = np.random.default_rng(4242)
+            lscale = (0.1e6 / (W * H)) ** 0.5
+            gmaps = []
+            for k, (w_, h_) in enumerate(base.warped_sizes):
+                gh, gw = (int(h_ * lscale) + 31) // 32 + 1, (int(w_ * lscale) + 31) // 32 + 1
+                yy, xx = np.mgrid[0:gh, 0:gw]
+                gmaps.append((1.0 + 0.12 * np.sin(0.7 * xx + k) * np.cos(0.5 * yy - k) + 0.02 * rng.standard_normal((gh, gw))).astype(np.float32))
+            comp = S.ExposureErrorCompensator("gain_blocks")
+            comp.set_gains(gmaps)
+            job = StitchJob(base.frames, cams, blend_strength=5, seam_masks=[np.ascontiguousarray(m[::11, ::11]) for m in seams], compensator=comp)
+        elif leg == "voronoi":
             job = StitchJob(base.frames, cams, num_bands=5, feed_masks=seams)
         else:
             job = StitchJob(base.frames, cams, num_bands=5, seam_masks=[np.ascontiguousarray(m[::11, ::11]) for m in seams])
