@@ -162,11 +162,6 @@ int stx_buf_from_host_async(stx_ctx* ctx, const void* host, size_t host_stride_b
 int stx_buf_to_host_async(const stx_buf* buf, void* host, size_t host_stride_bytes);
 /* rectangular sub-view sharing the parent's memory (numpy slicing in stitching/cropper.py:150-151) */
 int stx_buf_view(const stx_buf* buf, int x, int y, int w, int h, stx_buf** out);
-/* Source staging.  stitching/warper.py:43-52 hands cv2 a numpy BGR frame (3 bytes per pixel); the device samples a frame fastest
- * when a pixel is one aligned dword — the bilinear tap pair is then a single 8-byte load instead of a 12-byte window that has to be
- * re-aligned per pixel.  stx_buf_stage_bgrx makes that copy of a u8x3 image (u8x4: B, G, R, 0; one HBM-bound pass, 7 bytes per pixel)
- * as part of a frame's upload; every warp entry point below takes either form and returns the same bytes for both. */
-int stx_buf_stage_bgrx(stx_ctx* ctx, const stx_buf* src_u8x3, stx_buf** out_u8x4);
 /* info = {w, h, channels, elem, stride_bytes, device} */
 int stx_buf_info(const stx_buf* buf, int64_t info[6]);
 /* device address of the first pixel (for zero-copy consumers, e.g. RCCL strip exchange) */
@@ -187,8 +182,7 @@ int stx_warp_rois(stx_ctx* ctx, int type, float scale, int n, const float* K9s, 
  *             stitching/warper.py:58-68 (interp=NEAREST, border=CONSTANT, src u8x1):
  *             cv.PyRotationWarper(type, scale).warp(src, K, R, interp, border)
  *             = RotationWarperBase::buildMaps + cv::remap, fused: maps are never stored.
- * out_tl receives the corner the reference discards (stitching/warper.py:45 `_`).
- * An INTER_LINEAR source may be u8x3 or its staged u8x4 form (stx_buf_stage_bgrx) — here and in every warp entry point below. */
+ * out_tl receives the corner the reference discards (stitching/warper.py:45 `_`). */
 int stx_warp(stx_ctx* ctx, int type, float scale, const float K[9], const float R[9], const stx_buf* src, int interp,
              int border, stx_buf** out, int out_tl[2]);
 /* fused form of warper.py:43-52 + 58-68 for one camera: one pass computes the backward map

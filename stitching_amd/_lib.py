@@ -33,7 +33,7 @@ STRIP_MASK_BITS = 2
 
 EXPORTS = (
     "stx_version stx_last_error stx_set_trig_mode stx_get_trig_mode stx_set_remap_mode stx_get_remap_mode stx_set_pyrdown_mode stx_get_pyrdown_mode stx_device_count stx_ctx_create stx_ctx_destroy stx_ctx_sync "
-    "stx_host_alloc stx_host_free stx_buf_from_host stx_buf_from_host_async stx_buf_alloc stx_buf_to_host stx_buf_to_host_async stx_buf_view stx_buf_stage_bgrx stx_buf_info stx_buf_device_ptr stx_buf_free "
+    "stx_host_alloc stx_host_free stx_buf_from_host stx_buf_from_host_async stx_buf_alloc stx_buf_to_host stx_buf_to_host_async stx_buf_view stx_buf_info stx_buf_device_ptr stx_buf_free "
     "stx_warp_roi stx_warp_rois stx_warp stx_warp_image_and_mask stx_warp_batch stx_warp_batch_rects stx_warp_mask "
     "stx_gain_apply stx_block_gain_apply stx_block_gain_apply_batch stx_resize_linear_exact stx_seam_mask_resize stx_seam_mask_resize_batch stx_seam_mask_resize_batch_sub stx_timelapse_frame stx_result_roi stx_blend_create stx_blend_num_bands stx_blend_feed stx_blend_finish stx_blend_finish_ex "
     "stx_blend_destroy stx_blend_set_band stx_blend_feed_ex stx_blend_contrib_rect stx_blend_export_contrib stx_blend_export_contribs "
@@ -80,7 +80,6 @@ def lib():
     L.stx_buf_to_host.argtypes = [vp, vp, C.c_size_t]
     L.stx_buf_to_host_async.argtypes = [vp, vp, C.c_size_t]
     L.stx_buf_view.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vpp]
-    L.stx_buf_stage_bgrx.argtypes = [vp, vp, vpp]
     L.stx_buf_info.argtypes = [vp, C.POINTER(C.c_int64)]
     L.stx_buf_device_ptr.argtypes = [vp, vpp]
     L.stx_buf_free.argtypes = [vp]

@@ -16,27 +16,6 @@ def device_resident():
     return _device_resident
 
 
-_source_layout = os.environ.get("STITCHING_AMD_SOURCE", "bgrx").lower()
-
-
-def set_source_layout(layout):
-    """How the long-lived source frames of a job are kept in HBM (`device.as_source`: StitchJob, ShardedStitchJob, compose,
-    Images.stage): "bgrx" (default) — 4 bytes per pixel, made once per frame by stx_buf_stage_bgrx as part of its upload; the warp
-    samples a bilinear tap pair with one aligned 8-byte load — or "bgr", the 3 bytes per pixel numpy / cv2 hand over (stitching/
-    warper.py:43-52).  Same warped bytes either way.  STITCHING_AMD_SOURCE sets the start-up value.  Returns the previous layout."""
-    global _source_layout
-    if layout not in ("bgr", "bgrx"):
-        from .stitching_error import StitchingError
-
-        raise StitchingError(f"unknown source layout {layout!r}: 'bgr' or 'bgrx'")
-    prev, _source_layout = _source_layout, layout
-    return prev
-
-
-def source_layout():
-    return _source_layout if _source_layout in ("bgr", "bgrx") else "bgrx"
-
-
 def set_trig_mode(mode):
     """Which sinf / cosf the projectors follow (include/stitching_amd.h STX_TRIG_*): "exact" (correctly rounded, default),
     "glibc" (glibc >= 2.28 on an x86-64-v3 host, bit for bit: what cv.PyRotationWarper gets from libm there,

@@ -470,22 +470,6 @@ STX_EXPORT int stx_buf_view(const stx_buf* buf, int x, int y, int w, int h, stx_
     return STX_OK;
 }
 
-// Source staging (include/stitching_amd.h): the 4-byte-pixel copy of a u8x3 frame that the warp kernels sample fastest.
-STX_EXPORT int stx_buf_stage_bgrx(stx_ctx* ctx, const stx_buf* src, stx_buf** out)
-{
-    if (!ctx || !src || !out) return stx_fail(STX_ERR_INVALID, "null argument");
-    if (src->elem != STX_U8 || src->c != 3) return stx_fail(STX_ERR_INVALID, "staging needs a u8x3 image");
-    if (src->ctx->device != ctx->device) return stx_fail(STX_ERR_INVALID, "image lives on another device");
-    if (src->h > 65535) return stx_fail(STX_ERR_UNSUPPORTED, "image of %d rows", src->h);
-    STX_TRY(stx_set_device(ctx));
-    stx_buf* b = nullptr;
-    STX_TRY(stx_buf_new(ctx, src->w, src->h, 4, STX_U8, &b));
-    int rc = stx_launch_stage_bgrx(ctx, src, b);
-    if (rc != STX_OK) { stx_buf_release(b); return rc; }
-    *out = b;
-    return STX_OK;
-}
-
 STX_EXPORT int stx_buf_info(const stx_buf* buf, int64_t info[6])
 {
     if (!buf || !info) return stx_fail(STX_ERR_INVALID, "null argument");
@@ -1235,7 +1219,7 @@ STX_EXPORT int stx_warp(stx_ctx* ctx, int type, float scale, const float K[9], c
     if (src->elem != STX_U8) return stx_fail(STX_ERR_INVALID, "warp source must be 8-bit");
     int roi[4];
     if (interp == STX_INTER_LINEAR && border == STX_BORDER_REFLECT) {
-        if (src->c != 3 && src->c != 4) return stx_fail(STX_ERR_UNSUPPORTED, "INTER_LINEAR warp needs a 3-channel u8 image (or its staged BGRX form)");
+        if (src->c != 3) return stx_fail(STX_ERR_UNSUPPORTED, "INTER_LINEAR warp needs a 3-channel u8 image");
         STX_TRY(warp_impl(ctx, type, scale, K, R, src, src->w, src->h, true, false, false, out, nullptr, roi));
     } else if (interp == STX_INTER_NEAREST && border == STX_BORDER_CONSTANT) {
         if (src->c != 1) return stx_fail(STX_ERR_UNSUPPORTED, "INTER_NEAREST warp needs a 1-channel u8 mask");
@@ -1261,8 +1245,7 @@ static int warp_batch_impl(stx_ctx* ctx, int type, float scale, int n, const flo
     std::vector<StxProjector> ps(n);
     std::vector<int> rois(4 * (size_t)n), sizes(2 * (size_t)n);
     for (int i = 0; i < n; i++) {
-        if (!srcs[i] || srcs[i]->elem != STX_U8 || (srcs[i]->c != 3 && srcs[i]->c != 4))
-            return stx_fail(STX_ERR_INVALID, "warp source %d must be u8x3 (or its staged u8x4 BGRX form)", i);
+        if (!srcs[i] || srcs[i]->elem != STX_U8 || srcs[i]->c != 3) return stx_fail(STX_ERR_INVALID, "warp source %d must be u8x3", i);
         // sources may live in another context of the same device (long-lived read-only inputs shared by several streams)
         if (srcs[i]->ctx->device != ctx->device) return stx_fail(STX_ERR_INVALID, "warp source %d lives on another device", i);
         STX_TRY(stx_make_projector(type, scale, K9s + 9 * i, R9s + 9 * i, &ps[i]));
@@ -1343,7 +1326,7 @@ STX_EXPORT int stx_warp_image_and_mask(stx_ctx* ctx, int type, float scale, cons
     if (!ctx || !src) return stx_fail(STX_ERR_INVALID, "null argument");
     if (!out_img && !out_mask) return stx_fail(STX_ERR_INVALID, "nothing requested");
     STX_TRY(stx_set_device(ctx));
-    if (src->elem != STX_U8 || (src->c != 3 && src->c != 4)) return stx_fail(STX_ERR_INVALID, "warp source must be u8x3 (or its staged u8x4 BGRX form)");
+    if (src->elem != STX_U8 || src->c != 3) return stx_fail(STX_ERR_INVALID, "warp source must be u8x3");
     return warp_impl(ctx, type, scale, K, R, src, src->w, src->h, out_img != nullptr, out_mask != nullptr, false,
                      out_img, out_mask, out_xywh);
 }

@@ -153,8 +153,6 @@ struct StxWarpLaunch {
 };
 int stx_launch_warp(stx_ctx* ctx, const StxWarpLaunch& L);
 int stx_launch_warp_batch(stx_ctx* ctx, const StxWarpLaunch* Ls, int n);
-// u8x3 -> u8x4 (BGRX) copy of a source frame (stx_buf_stage_bgrx)
-int stx_launch_stage_bgrx(stx_ctx* ctx, const stx_buf* src, stx_buf* dst);
 int stx_launch_roi_minmax(stx_ctx* ctx, int n, const StxProjector* projs, const int* sizes_wh, float* out_minmax4);
 
 // multi-band -------------------------------------------------------------------------------------

@@ -86,7 +86,6 @@ struct WarpK {
     int remap;   // STX_REMAP_*: the interpolation model of the image samples; anything but Q15 runs the one-pixel-per-lane kernels
     int num_ok;  // host-proved: |numerators| <= 2^60 and finite tables, the per-lane magnitude test is skipped
     int z_one;   // host-proved (plane / affine): z = 1.f for every pixel, the quotients are the numerators
-    int pxb;     // bytes per source pixel: 3 (BGR as numpy / cv2 hand it over) or 4 (BGRX: a staged source, stx_buf_stage_bgrx)
 };
 
 // Up to WARP_BATCH images per launch: the per-image argument blocks travel in the kernel-argument segment
@@ -137,7 +136,7 @@ STX_DEV void put_px(uint32_t (&out)[3], int j, uint32_t px)
 // interpolates in floating point (include/stitching_amd.h spells out the sequence of fp32 operations; the tests compare it with the
 // CPU checker's).  A position that is not a finite number of moderate size samples (-1, -1).  One pixel at a time, byte loads: this mode
 // exists to be compared with, not to be fast.
-STX_DEV uint32_t sample_float(const uint8_t* __restrict__ src, long long sstride, int sw, int sh, int pxb, bool fused, float x, float y)
+STX_DEV uint32_t sample_float(const uint8_t* __restrict__ src, long long sstride, int sw, int sh, bool fused, float x, float y)
 {
     if (!(x > -1.0e9f && x < 1.0e9f && y > -1.0e9f && y < 1.0e9f)) { x = -1.f; y = -1.f; }
     const float fxf = floorf(x), fyf = floorf(y);
@@ -150,8 +149,8 @@ STX_DEV uint32_t sample_float(const uint8_t* __restrict__ src, long long sstride
     uint32_t px = 0;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        const float p00 = (float)r0[sx0 * pxb + c], p01 = (float)r0[sx1 * pxb + c];
-        const float p10 = (float)r1[sx0 * pxb + c], p11 = (float)r1[sx1 * pxb + c];
+        const float p00 = (float)r0[sx0 * 3 + c], p01 = (float)r0[sx1 * 3 + c];
+        const float p10 = (float)r1[sx0 * 3 + c], p11 = (float)r1[sx1 * 3 + c];
         float t, u, v;
         if (fused) {
             t = __fmaf_rn(a, fsub(p01, p00), p00);
@@ -167,22 +166,6 @@ STX_DEV uint32_t sample_float(const uint8_t* __restrict__ src, long long sstride
     return px;
 }
 
-// The adjacent source pixels (ix, iy), (ix + 1, iy) at byte address a, each as B | G << 8 | R << 16 (the top byte is not used):
-// BGR sources through the aligned 12-byte window, BGRX sources (4-byte aligned) as they lie.
-STX_DEV void load_pair(const uint8_t* base, long long a, int pxb, uint32_t& pl, uint32_t& pr)
-{
-    if (pxb == 4) {
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(base + a);
-        pl = q[0];
-        pr = q[1];
-        return;
-    }
-    uint32_t lo, hi;
-    load6(base, a, lo, hi);
-    pl = lo;
-    pr = (lo >> 24) | (hi << 8);
-}
-
 // remap(): sx = cvRound(x*32); (ix, fx) = (sx >> 5 saturated to short, sx & 31); remapBilinear with BORDER_REFLECT taps
 // (borderInterpolate on each of the 4 taps) -> 24-bit BGR.  The one-pixel-at-a-time form of the fast kernel's sampling.
 STX_DEV uint32_t sample_q15(const WarpK& P, float x, float yy)
@@ -192,15 +175,15 @@ STX_DEV uint32_t sample_q15(const WarpK& P, float x, float yy)
     const int ix = sat_s16(sx >> 5), iy = sat_s16(sy >> 5);
     uint32_t b, g, rr;
     if ((unsigned)ix < (unsigned)(P.sw - 1) && (unsigned)iy < (unsigned)(P.sh - 1)) {
-        const long long a = (long long)iy * P.sstride + (long long)ix * P.pxb;
-        uint32_t l0, r0, l1, r1;
-        load_pair(P.src, a, P.pxb, l0, r0);
-        load_pair(P.src, a + P.sstride, P.pxb, l1, r1);
-        b = bil(l0 & 255u, r0 & 255u, l1 & 255u, r1 & 255u, fx, fy);
-        g = bil((l0 >> 8) & 255u, (r0 >> 8) & 255u, (l1 >> 8) & 255u, (r1 >> 8) & 255u, fx, fy);
-        rr = bil((l0 >> 16) & 255u, (r0 >> 16) & 255u, (l1 >> 16) & 255u, (r1 >> 16) & 255u, fx, fy);
+        const long long a = (long long)iy * P.sstride + (long long)ix * 3;
+        uint32_t l0, h0, l1, h1;
+        load6(P.src, a, l0, h0);
+        load6(P.src, a + P.sstride, l1, h1);
+        b = bil(l0 & 255u, l0 >> 24, l1 & 255u, l1 >> 24, fx, fy);
+        g = bil((l0 >> 8) & 255u, h0 & 255u, (l1 >> 8) & 255u, h1 & 255u, fx, fy);
+        rr = bil((l0 >> 16) & 255u, (h0 >> 8) & 255u, (l1 >> 16) & 255u, (h1 >> 8) & 255u, fx, fy);
     } else {
-        const int sx0 = reflect(ix, P.sw) * P.pxb, sx1 = reflect(ix + 1, P.sw) * P.pxb;
+        const int sx0 = reflect(ix, P.sw) * 3, sx1 = reflect(ix + 1, P.sw) * 3;
         const int sy0 = reflect(iy, P.sh), sy1 = reflect(iy + 1, P.sh);
         const uint8_t* r0 = P.src + (long long)sy0 * P.sstride;
         const uint8_t* r1 = P.src + (long long)sy1 * P.sstride;
@@ -318,7 +301,7 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpK P, const float2* __rest
             continue;
         }
         if (IMG && P.remap != STX_REMAP_Q15) {
-            put_px(out, j, sample_float(P.src, P.sstride, P.sw, P.sh, P.pxb, P.remap == STX_REMAP_FLOAT_FMA, x, yy));
+            put_px(out, j, sample_float(P.src, P.sstride, P.sw, P.sh, P.remap == STX_REMAP_FLOAT_FMA, x, yy));
         } else if (IMG) {
             put_px(out, j, sample_q15(P, x, yy));
         }
@@ -387,10 +370,8 @@ STX_DEV void div2_fast(float d, float n0, float n1, float& q0, float& q1)
 }
 
 // One BORDER_REFLECT tap: the 3 bytes of source pixel (sx, sy) in the low 24 bits (32-bit offsets, global loads)
-template <bool PX4>
 STX_DEV uint32_t tap24(const STX_GAS uint8_t* src, uint32_t stride, int sx, int sy)
 {
-    if (PX4) return *reinterpret_cast<const STX_GAS uint32_t*>(src + ((uint32_t)sy * stride + ((uint32_t)sx << 2)));
     const uint32_t off = (uint32_t)sy * stride + (uint32_t)sx * 3u;
     const STX_GAS uint32_t* q = reinterpret_cast<const STX_GAS uint32_t*>(src + (off & ~3u));
     return __builtin_amdgcn_alignbyte(q[1], q[0], off & 3u);
@@ -398,7 +379,6 @@ STX_DEV uint32_t tap24(const STX_GAS uint8_t* src, uint32_t stride, int sx, int 
 
 // remapBilinear with BORDER_REFLECT on every tap (borderInterpolate per tap, cvRound / short saturation emulated
 // exactly); x32, y32 = 32 x, 32 y.  Same packed blend as the interior path.  Fast-kernel preconditions apply.
-template <bool PX4>
 STX_DEV uint32_t sample_border(const STX_GAS uint8_t* src, uint32_t stride, int sw, int sh, float x32, float y32)
 {
     const int sx = cv_round(x32), sy = cv_round(y32);
@@ -406,8 +386,8 @@ STX_DEV uint32_t sample_border(const STX_GAS uint8_t* src, uint32_t stride, int 
     const int ix = sat_s16(sx >> 5), iy = sat_s16(sy >> 5);
     const int sx0 = reflect(ix, sw), sx1 = reflect(ix + 1, sw);
     const int sy0 = reflect(iy, sh), sy1 = reflect(iy + 1, sh);
-    const uint32_t t00 = tap24<PX4>(src, stride, sx0, sy0), t01 = tap24<PX4>(src, stride, sx1, sy0);
-    const uint32_t t10 = tap24<PX4>(src, stride, sx0, sy1), t11 = tap24<PX4>(src, stride, sx1, sy1);
+    const uint32_t t00 = tap24(src, stride, sx0, sy0), t01 = tap24(src, stride, sx1, sy0);
+    const uint32_t t10 = tap24(src, stride, sx0, sy1), t11 = tap24(src, stride, sx1, sy1);
     const uint32_t wy1 = fy * 0x10001u, wy0 = 0x200020u - wy1;
     const uint32_t wx = fx * 0xffffu + 32u;
     uint32_t o[3];
@@ -458,24 +438,11 @@ STX_DEV uint32_t lshl16_or_u32(uint32_t a, uint32_t b)  // (a << 16) | b
 #ifndef STX_WARP_NOAND
 #define STX_WARP_NOAND 1
 #endif
-// PX4: the source holds 4 bytes per pixel (BGRX, stx_buf_stage_bgrx): the pixel pair of a row is ONE aligned 8-byte load — no 12-byte
-// window, no v_alignbyte, a third of the load instructions (2 instead of 6 per pixel): 96 VALU per 4 pixels instead of 117.
-// The adjacent pixel pair (ix, ix + 1) of rows iy and iy + 1, all four taps inside the source: l = first 4 bytes, h = next 4 of either row
-// (BGRBGR.. for a 3-byte source: 6 useful bytes; BGRX BGRX for a staged one)
-template <bool PX4>
+// The adjacent pixel pair (ix, ix + 1) of rows iy and iy + 1, all four taps inside the source: l = first 4 bytes, h = next 4 of the 6-byte
+// BGRBGR group of either row
 STX_DEV void load_taps(const STX_GAS uint8_t* src, uint32_t stride, uint32_t ix, uint32_t iy, uint32_t& l0, uint32_t& h0, uint32_t& l1,
                        uint32_t& h1)
 {
-    if (PX4) {
-        uint32_t a;  // row < 2^15 and stride < 2^24 (fast_ok): 24-bit multiply; (ix << 2) + that in one v_lshl_add_u32
-        const uint32_t rowoff = __umul24(iy, stride);
-        asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a) : "v"(ix), "v"(rowoff));
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
-        const u32x2 r0 = *reinterpret_cast<const STX_GAS u32x2*>(src + a);
-        const u32x2 r1 = *reinterpret_cast<const STX_GAS u32x2*>((src + stride) + a);
-        l0 = r0.x; h0 = r0.y; l1 = r1.x; h1 = r1.y;
-        return;
-    }
     // row < 2^15 and stride < 2^24 (fast_ok): 24-bit multiply
 #if STX_WARP_MUL
     const uint32_t a = __umul24(iy, stride) + lshl_add_u32(ix, ix);
@@ -503,12 +470,11 @@ STX_DEV void load_taps(const STX_GAS uint8_t* src, uint32_t stride, uint32_t ix,
 #endif
 }
 
-template <bool PX4>
 STX_DEV void blend_pair_to_lds(const STX_GAS uint8_t* src, uint32_t stride, uint32_t ix, uint32_t iy, uint32_t fx, uint32_t fy,
                                uint8_t* p)
 {
     uint32_t l0, h0, l1, h1;
-    load_taps<PX4>(src, stride, ix, iy, l0, h0, l1, h1);
+    load_taps(src, stride, ix, iy, l0, h0, l1, h1);
 #if STX_WARP_MUL
     const uint32_t wy1 = lshl16_or_u32(fy, fy), wy0 = 0x200020u - wy1;  // (fy, fy), (32 - fy, 32 - fy)
     const uint32_t g = fx << 6;
@@ -519,9 +485,8 @@ STX_DEV void blend_pair_to_lds(const STX_GAS uint8_t* src, uint32_t stride, uint
 #endif
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        // (left tap, right tap) of channel c as two u16: bytes c and c + 3 of the 6-byte BGRBGR group (BGRX: byte c of either dword)
-        const uint32_t sel = PX4 ? (c == 0 ? 0x0c040c00u : (c == 1 ? 0x0c050c01u : 0x0c060c02u))
-                                 : (c == 0 ? 0x0c030c00u : (c == 1 ? 0x0c040c01u : 0x0c050c02u));
+        // (left tap, right tap) of channel c as two u16: bytes c and c + 3 of the 6-byte BGRBGR group
+        const uint32_t sel = c == 0 ? 0x0c030c00u : (c == 1 ? 0x0c040c01u : 0x0c050c02u);
         const v2h t0 = as_v2h(__builtin_amdgcn_perm(h0, l0, sel)), t1 = as_v2h(__builtin_amdgcn_perm(h1, l1, sel));
         const v2h v = t0 * as_v2h(wy0) + t1 * as_v2h(wy1);  // vertical lerp of both taps, <= 255 * 32
         p[c] = (uint8_t)(__builtin_amdgcn_udot2(v, as_v2h(wx), 32768u, false) >> 16);
@@ -531,19 +496,19 @@ STX_DEV void blend_pair_to_lds(const STX_GAS uint8_t* src, uint32_t stride, uint
 // STX_REMAP_FLOAT / STX_REMAP_FLOAT_FMA on the fast kernel (round 5): the fp32 bilinear model of sample_float for a position whose four
 // taps are inside the source (x, y >= 0, so x - floor(x) is exact): the same two loads per row as the Q15 blend, the taps converted
 // straight out of their bytes (v_cvt_f32_ubyteN: no v_perm), every step rounded to fp32 as include/stitching_amd.h spells it out.
-template <bool PX4, bool FUSED>
+template <bool FUSED>
 STX_DEV void blend_float_to_lds(const STX_GAS uint8_t* src, uint32_t stride, float x, float y, uint8_t* p)
 {
     const float fxf = floorf(x), fyf = floorf(y);
     const float a = fsub(x, fxf), b = fsub(y, fyf);
     uint32_t l0, h0, l1, h1;
-    load_taps<PX4>(src, stride, (uint32_t)(int)fxf, (uint32_t)(int)fyf, l0, h0, l1, h1);
+    load_taps(src, stride, (uint32_t)(int)fxf, (uint32_t)(int)fyf, l0, h0, l1, h1);
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        // left tap: byte c of l; right tap: byte c + 3 of the 6-byte group (c = 0: byte 3 of l, else byte c - 1 of h); BGRX: byte c of h
-        const int rs = PX4 ? 8 * c : (c == 0 ? 24 : 8 * (c - 1));
+        // left tap: byte c of l; right tap: byte c + 3 of the 6-byte group (c = 0: byte 3 of l, else byte c - 1 of h)
+        const int rs = c == 0 ? 24 : 8 * (c - 1);
         const float p00 = (float)((l0 >> (8 * c)) & 255u), p10 = (float)((l1 >> (8 * c)) & 255u);
-        const float p01 = (float)((((PX4 || c > 0) ? h0 : l0) >> rs) & 255u), p11 = (float)((((PX4 || c > 0) ? h1 : l1) >> rs) & 255u);
+        const float p01 = (float)(((c > 0 ? h0 : l0) >> rs) & 255u), p11 = (float)(((c > 0 ? h1 : l1) >> rs) & 255u);
         float t, u, v;
         if (FUSED) {
             t = __fmaf_rn(a, fsub(p01, p00), p00);
@@ -583,7 +548,7 @@ STX_DEV int periodic_axis(int s, int n, int period, float inv_period, int bias)
 
 // RM: STX_REMAP_* of the image samples (Q15: the fixed-point blend; FLOAT / FLOAT_FMA: the fp32 model — interior wavefronts through
 // blend_float_to_lds, every other wavefront one pixel at a time through sample_float: borders are a minority)
-template <int TYPE, bool IMG, bool MASK, bool DBG = false, bool PX4 = false, int RM = STX_REMAP_Q15>
+template <int TYPE, bool IMG, bool MASK, bool DBG = false, int RM = STX_REMAP_Q15>
 __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8))) void warp_fast_kernel(WarpBatchK B)
 {
     const WarpK& P = B.k[blockIdx.z];
@@ -773,10 +738,10 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (RM == STX_REMAP_Q15)
-                    blend_pair_to_lds<PX4>(src, sstride, __builtin_amdgcn_ubfe(ux[j], 5, 17), __builtin_amdgcn_ubfe(uy[j], 5, 17), ux[j] & 31u,
+                    blend_pair_to_lds(src, sstride, __builtin_amdgcn_ubfe(ux[j], 5, 17), __builtin_amdgcn_ubfe(uy[j], 5, 17), ux[j] & 31u,
                                            uy[j] & 31u, lpx + 192 * j);
                 else
-                    blend_float_to_lds<PX4, RM == STX_REMAP_FLOAT_FMA>(src, sstride, (j & 1) ? X[j >> 1].y : X[j >> 1].x,
+                    blend_float_to_lds<RM == STX_REMAP_FLOAT_FMA>(src, sstride, (j & 1) ? X[j >> 1].y : X[j >> 1].x,
                                                                       (j & 1) ? Y[j >> 1].y : Y[j >> 1].x, lpx + 192 * j);
             }
         }
@@ -793,7 +758,7 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
         if (IMG) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const uint32_t px = sample_float((const uint8_t*)src_a, (long long)sstride, sw, sh, PX4 ? 4 : 3, RM == STX_REMAP_FLOAT_FMA,
+                const uint32_t px = sample_float((const uint8_t*)src_a, (long long)sstride, sw, sh, RM == STX_REMAP_FLOAT_FMA,
                                                  (j & 1) ? X[j >> 1].y : X[j >> 1].x, (j & 1) ? Y[j >> 1].y : Y[j >> 1].x);
                 lpx[192 * j] = (uint8_t)px;
                 lpx[192 * j + 1] = (uint8_t)(px >> 8);
@@ -818,7 +783,7 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
                     uint32_t ix, iy, fx, fy;
                     mirror_axis((int)(ux[j] - RND_U0), sw, ix, fx);
                     mirror_axis((int)(uy[j] - RND_U0), sh, iy, fy);
-                    blend_pair_to_lds<PX4>(src, sstride, ix, iy, fx, fy, lpx + 192 * j);
+                    blend_pair_to_lds(src, sstride, ix, iy, fx, fy, lpx + 192 * j);
                 }
             } else if (__builtin_amdgcn_ballot_w64(min(uxmn, uymn) < RND_U0 - (1u << 21) || max(uxmx, uymx) >= RND_U0 + (1u << 21)) == 0) {
                 // several mirror images away somewhere in the wavefront: reduce by the period, then mirror as above
@@ -829,12 +794,12 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
                     uint32_t ix, iy, fx, fy;
                     mirror_axis(periodic_axis((int)(ux[j] - RND_U0), sw, per_x, inv_x, bias_x), sw, ix, fx);
                     mirror_axis(periodic_axis((int)(uy[j] - RND_U0), sh, per_y, inv_y, bias_y), sh, iy, fy);
-                    blend_pair_to_lds<PX4>(src, sstride, ix, iy, fx, fy, lpx + 192 * j);
+                    blend_pair_to_lds(src, sstride, ix, iy, fx, fy, lpx + 192 * j);
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const uint32_t px = sample_border<PX4>(src, sstride, sw, sh, xs[j], ys[j]);
+                    const uint32_t px = sample_border(src, sstride, sw, sh, xs[j], ys[j]);
                     lpx[192 * j] = (uint8_t)px;
                     lpx[192 * j + 1] = (uint8_t)(px >> 8);
                     lpx[192 * j + 2] = (uint8_t)(px >> 16);
@@ -902,7 +867,7 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
 // generic remapBilinear / BORDER_REFLECT sample of one pixel -> 24-bit BGR
 STX_DEV uint32_t sample_generic(const WarpK& P, float x, float yy)
 {
-    if (P.remap != STX_REMAP_Q15) return sample_float(P.src, P.sstride, P.sw, P.sh, P.pxb, P.remap == STX_REMAP_FLOAT_FMA, x, yy);
+    if (P.remap != STX_REMAP_Q15) return sample_float(P.src, P.sstride, P.sw, P.sh, P.remap == STX_REMAP_FLOAT_FMA, x, yy);
     return sample_q15(P, x, yy);
 }
 
@@ -1168,41 +1133,6 @@ __global__ __launch_bounds__(256) void roi_kernel(RoiBatchK B, float* __restrict
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Source staging: BGR (3 bytes per pixel, as numpy / cv2 hand frames over) -> BGRX (4 bytes per pixel, X = 0).  Part of the upload of a
-// frame, not of a warp: a frame is staged once and warped many times (low / final resolution, every panorama of a stream).  HBM-bound:
-// 3 bytes read + 4 written per pixel.  One lane = 4 pixels: three dwords in, one 16-byte store out; rows are independent.
-// ---------------------------------------------------------------------------------------------
-template <bool ALIGNED>
-__global__ __launch_bounds__(256) void stage_bgrx_kernel(const uint8_t* __restrict__ src, long long sstride, uint8_t* __restrict__ dst,
-                                                         long long dstride, int w, int h)
-{
-    const int g = blockIdx.x * 256 + threadIdx.x;  // group of 4 pixels
-    const int y = blockIdx.y;
-    if (4 * g >= w) return;
-    const uint8_t* sp = src + (long long)y * sstride + 12ll * g;
-    uint32_t d0, d1, d2;
-    if (ALIGNED) {  // whole buffers: rows are 64-byte aligned and padded to 8 pixels, so the last group may read past w inside the row
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(sp);
-        d0 = q[0]; d1 = q[1]; d2 = q[2];
-    } else {        // views (any byte alignment, no right to read past w): bytes
-        const int n = min(4, w - 4 * g) * 3;
-        uint32_t b[12];
-#pragma unroll
-        for (int i = 0; i < 12; i++) b[i] = i < n ? sp[i] : 0u;
-        d0 = b[0] | b[1] << 8 | b[2] << 16 | b[3] << 24;
-        d1 = b[4] | b[5] << 8 | b[6] << 16 | b[7] << 24;
-        d2 = b[8] | b[9] << 8 | b[10] << 16 | b[11] << 24;
-    }
-    uint4 o;
-    o.x = d0 & 0xffffffu;
-    o.y = __builtin_amdgcn_alignbyte(d1, d0, 3) & 0xffffffu;
-    o.z = __builtin_amdgcn_alignbyte(d2, d1, 2) & 0xffffffu;
-    o.w = d2 >> 8;
-    // the destination is a whole buffer of the library's own (16-byte aligned groups, rows padded to 8 pixels)
-    *reinterpret_cast<uint4*>(dst + (long long)y * dstride + 16ll * g) = o;
-}
-
 bool fast_ok(const WarpK& K)
 {
     return !K.msrc && K.sw <= 32767 && K.sh <= 32767 && K.sw >= 2 && K.sh >= 2 && (long long)K.sstride * K.sh < (1ll << 31);
@@ -1220,11 +1150,9 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
     STX_TRY(stx_dev_alloc(ctx, total * sizeof(float2), &tab));
     float2* cursor = (float2*)tab;
     for (int base = 0, m = 0; base < n; base += m) {
-        // a launch takes up to WARP_BATCH images of one source layout (the sampling block is compiled per pixel stride)
-        const bool px4 = Ks[base].pxb == 4 && Ks[base].src;
+        // a launch takes up to WARP_BATCH images of one remap model (the sampling block is compiled per model)
         const int rm = Ks[base].src ? Ks[base].remap : STX_REMAP_Q15;
-        for (m = 1; m < WARP_BATCH && base + m < n && (Ks[base + m].pxb == 4 && Ks[base + m].src) == px4 &&
-                    (Ks[base + m].src ? Ks[base + m].remap : STX_REMAP_Q15) == rm; m++) {}
+        for (m = 1; m < WARP_BATCH && base + m < n && (Ks[base + m].src ? Ks[base + m].remap : STX_REMAP_Q15) == rm; m++) {}
         WarpBatchK B;
         memset(&B, 0, sizeof(B));
         int max_tab = 0, gx = 0, gy = 0;
@@ -1268,17 +1196,15 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
             // (160 KB per CU / request = workgroups per CU) for co-residency experiments with the other panorama's kernels
             static const unsigned pad_lds = getenv("STITCHING_AMD_WARP_LDS") ? (unsigned)atoi(getenv("STITCHING_AMD_WARP_LDS")) : 0u;
             if (dbg) hipLaunchKernelGGL((warp_fast_kernel<TYPE, false, false, true>), gf, dim3(WARP_FW), 0, s, B);
-#define STX_FAST_LAUNCH(I, M, P4, R) hipLaunchKernelGGL((warp_fast_kernel<TYPE, I, M, false, P4, R>), gf, dim3(WARP_FW), pad_lds, s, B)
-#define STX_FAST_LAUNCH_RM(I, M, P4)                                             \
-    do {                                                                        \
-        if (rm == STX_REMAP_FLOAT) STX_FAST_LAUNCH(I, M, P4, STX_REMAP_FLOAT);   \
-        else if (rm == STX_REMAP_FLOAT_FMA) STX_FAST_LAUNCH(I, M, P4, STX_REMAP_FLOAT_FMA); \
-        else STX_FAST_LAUNCH(I, M, P4, STX_REMAP_Q15);                           \
+#define STX_FAST_LAUNCH(I, M, R) hipLaunchKernelGGL((warp_fast_kernel<TYPE, I, M, false, R>), gf, dim3(WARP_FW), pad_lds, s, B)
+#define STX_FAST_LAUNCH_RM(I, M)                                             \
+    do {                                                                     \
+        if (rm == STX_REMAP_FLOAT) STX_FAST_LAUNCH(I, M, STX_REMAP_FLOAT);   \
+        else if (rm == STX_REMAP_FLOAT_FMA) STX_FAST_LAUNCH(I, M, STX_REMAP_FLOAT_FMA); \
+        else STX_FAST_LAUNCH(I, M, STX_REMAP_Q15);                           \
     } while (0)
-            else if (img && mask && px4) STX_FAST_LAUNCH_RM(true, true, true);
-            else if (img && px4) STX_FAST_LAUNCH_RM(true, false, true);
-            else if (img && mask) STX_FAST_LAUNCH_RM(true, true, false);
-            else if (img) STX_FAST_LAUNCH_RM(true, false, false);
+            else if (img && mask) STX_FAST_LAUNCH_RM(true, true);
+            else if (img) STX_FAST_LAUNCH_RM(true, false);
 #undef STX_FAST_LAUNCH_RM
 #undef STX_FAST_LAUNCH
             else hipLaunchKernelGGL((warp_fast_kernel<TYPE, false, true>), gf, dim3(WARP_FW), pad_lds, s, B);
@@ -1346,7 +1272,6 @@ void fill_warpk(const StxWarpLaunch& L, WarpK* Kp, double* bytes)
     K.sw = L.sw; K.sh = L.sh;
     const bool img = L.dimg != nullptr, mask = L.dmask != nullptr;
     K.src = img ? L.src : nullptr;
-    K.pxb = L.src_channels == 4 ? 4 : 3;
     K.sstride = (long long)L.sstride;
     K.msrc = L.nearest_src ? L.src : nullptr;
     K.msstride = (long long)L.sstride;
@@ -1417,19 +1342,6 @@ int stx_launch_warp_batch(stx_ctx* ctx, const StxWarpLaunch* Ls, int n)
 }
 
 int stx_launch_warp(stx_ctx* ctx, const StxWarpLaunch& L) { return stx_launch_warp_batch(ctx, &L, 1); }
-
-int stx_launch_stage_bgrx(stx_ctx* ctx, const stx_buf* src, stx_buf* dst)
-{
-    // algorithmic bytes: every source pixel read once (3 bytes), written once (4 bytes)
-    StxProfScope prof(ctx, "stage_bgrx", 7.0 * src->w * src->h);
-    const dim3 grid(((src->w + 3) / 4 + 255) / 256, src->h);
-    const bool aligned = !src->parent && ((uintptr_t)src->ptr & 3) == 0 && (src->stride & 3) == 0;
-    if (aligned) hipLaunchKernelGGL(stage_bgrx_kernel<true>, grid, dim3(256), 0, ctx->stream, src->ptr, (long long)src->stride, dst->ptr, (long long)dst->stride, src->w, src->h);
-    else hipLaunchKernelGGL(stage_bgrx_kernel<false>, grid, dim3(256), 0, ctx->stream, src->ptr, (long long)src->stride, dst->ptr, (long long)dst->stride, src->w, src->h);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return stx_fail(STX_ERR_HIP, "stage kernel launch failed: %s", hipGetErrorString(e));
-    return STX_OK;
-}
 
 // out_minmax4[i] = {min u, min v, max u, max v} over the border of image i (cyl / spherical)
 int stx_launch_roi_minmax(stx_ctx* ctx, int n, const StxProjector* projs, const int* sizes_wh, float* out_minmax4)

@@ -216,16 +216,6 @@ class DeviceImage:
         _lib.check(self.ctx._lib.stx_buf_view(self._h, x0, y0, x1 - x0, y1 - y0, C.byref(out)))
         return DeviceImage(self.ctx, out)
 
-    def staged(self, ctx=None):
-        """The 4-byte-pixel (BGRX) copy of a u8x3 frame — the form the warp kernels sample fastest (stx_buf_stage_bgrx: one HBM-bound
-        pass, queued on the context's stream).  A u8x4 image is returned as it is."""
-        if self.channels == 4 and self.dtype == np.uint8:
-            return self
-        ctx = ctx or self.ctx
-        out = C.c_void_p()
-        _lib.check(ctx._lib.stx_buf_stage_bgrx(ctx.handle, self._h, C.byref(out)))
-        return DeviceImage(ctx, out)
-
     def device_ptr(self):
         p = C.c_void_p()
         _lib.check(self.ctx._lib.stx_buf_device_ptr(self._h, C.byref(p)))
@@ -253,13 +243,3 @@ def as_device(img, ctx=None, wait=True):
         return img
     return DeviceImage.from_numpy(img, ctx, wait)
 
-
-def as_source(img, ctx=None, wait=True, layout=None):
-    """A long-lived source frame of a job: as_device, then — under the "bgrx" source layout (config.set_source_layout, the default) —
-    staged to 4 bytes per pixel right behind its upload (the 3-byte upload buffer goes back to the pool in stream order)."""
-    from . import config
-
-    d = as_device(img, ctx, wait)
-    if (layout or config.source_layout()) == "bgrx" and d.channels == 3 and d.dtype == np.uint8:
-        return d.staged(ctx)
-    return d

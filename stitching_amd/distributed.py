@@ -35,7 +35,7 @@ import numpy as np
 
 from . import _lib, config
 from .blender import Blender, _BlenderHandle
-from .device import DeviceImage, as_device, as_source, get_context
+from .device import DeviceImage, as_device, get_context
 from .stitching_error import StitchingError
 from .synthetic import blend_strength_for_bands
 from .warper import Warper
@@ -483,7 +483,7 @@ class ShardedStitchJob:
         self.blender_type = blender_type
         self.ctx = ctx or get_context()
         self.rank, self.world = int(rank), int(world)
-        self.frames = [as_source(f, self.ctx) for f in frames]
+        self.frames = [as_device(f, self.ctx) for f in frames]
         self.cameras = list(cameras)
         self.all_cameras = list(all_cameras)
         n = len(self.all_cameras)

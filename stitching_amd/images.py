@@ -210,12 +210,10 @@ class Images:
         return np.where(img > 0.5, 255, 0).astype(np.uint8)
 
     # ---- staging (no counterpart in the reference: it reads and resizes one image at a time on the host)
-    def stage(self, resolution=None, ctx=None, depth=2, workers=2, for_warp=False):
+    def stage(self, resolution=None, ctx=None, depth=2, workers=2):
         """Generator of device-resident images at `resolution` (default FINAL), decoded `depth` images ahead on `workers`
         threads into page-locked buffers and uploaded with queued copies.  Order and contents equal
-        `resize(resolution)`; sizes / scales are set on the way exactly as iterating does.
-        for_warp: yield every frame in the layout the warp samples fastest (config.source_layout(): BGRX by default — a u8x4
-        DeviceImage made by one more pass behind the resize; Warper takes it like the u8x3 frame and returns the same bytes)."""
+        `resize(resolution)`; sizes / scales are set on the way exactly as iterating does."""
         resolution = resolution or Images.Resolution.FINAL
         ctx = ctx or get_context()
         n = len(self._staging_sources())
@@ -249,8 +247,7 @@ class Images:
                         for b in in_flight:
                             pin_pool.setdefault((b.shape, b.dtype.str), []).append(b)
                     in_flight.clear()
-                out = Images.resize_img_by_scaler(self._get_scaler(resolution), self._sizes[idx], dev, device_resident=True)
-                yield as_source(out, ctx) if for_warp else out
+                yield Images.resize_img_by_scaler(self._get_scaler(resolution), self._sizes[idx], dev, device_resident=True)
                 idx += 1
             ctx.sync()
 

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib, config
 from .blender import Blender
-from .device import as_device, as_source, get_context
+from .device import as_device, get_context
 from .stitching_error import StitchingError
 from .synthetic import blend_strength_for_bands
 from .warper import Warper
@@ -100,7 +100,7 @@ class StitchJob:
         if len(frames) != len(cameras) or not frames:
             raise StitchingError("need one camera per frame and at least one frame")
         self.ctx = ctx or get_context()
-        self.frames = [as_source(f, self.ctx, wait=not async_upload) for f in frames]
+        self.frames = [as_device(f, self.ctx, wait=not async_upload) for f in frames]
         self.cameras = list(cameras)
         self.sizes = [(f.width, f.height) for f in self.frames]
         self.warper = Warper(warper_type, ctx=self.ctx)
@@ -217,7 +217,7 @@ def compose(frames, cameras, warper_type="spherical", blender_type="multiband", 
     try:
         warper = Warper(warper_type, ctx=ctx)
         warper.set_scale(cameras)
-        imgs, masks, rois = warper.warp_images_and_masks([as_source(f, ctx) for f in frames], cameras)
+        imgs, masks, rois = warper.warp_images_and_masks([as_device(f, ctx) for f in frames], cameras)
         corners, sizes = [r[0:2] for r in rois], [r[2:4] for r in rois]
         if compensator is not None:
             imgs = compensator.apply_all(corners, imgs, masks, ctx=ctx)

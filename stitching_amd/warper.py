@@ -12,7 +12,7 @@ from statistics import median
 import numpy as np
 
 from . import _lib, config
-from .device import DeviceImage, as_source, get_context
+from .device import DeviceImage, as_device, get_context
 from .stitching_error import StitchingError
 
 _TYPE_IDS = _lib.WARP_TYPE_IDS
@@ -179,16 +179,11 @@ class Warper:
     # ------------------------------------------------------------------ helpers
     @staticmethod
     def _source(img, ctx):
-        """The device form of a warp source.  Host frames (HxWx3 uint8, as cv2 takes them) are uploaded and staged per
-        config.source_layout(); device images may be u8x3 or their staged u8x4 (BGRX) form."""
-        if isinstance(img, DeviceImage):
-            if img.channels not in (3, 4) or img.dtype != np.uint8:
-                raise StitchingError(f"warp_image expects a HxWx3 uint8 image (or a staged BGRX device image), got {img.shape} {img.dtype}")
-            return img  # as it lies in HBM: staging is the owner's call (DeviceImage.staged(), as_source), once per frame
-        a = np.asarray(img)
-        if a.ndim != 3 or a.shape[2] != 3 or a.dtype != np.uint8:
-            raise StitchingError(f"warp_image expects a HxWx3 uint8 image, got {a.shape} {a.dtype}")
-        return as_source(a, ctx)
+        """The device form of a warp source: a HxWx3 uint8 image, as cv2 takes it (uploaded when it is a host array)."""
+        src = as_device(img, ctx)
+        if src.channels != 3 or src.dtype != np.uint8:
+            raise StitchingError(f"warp_image expects a HxWx3 uint8 image, got {src.shape} {src.dtype}")
+        return src
 
     def _type_id(self):
         if self.warper_type not in Warper.WARP_TYPE_CHOICES:
