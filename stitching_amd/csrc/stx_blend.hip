@@ -521,6 +521,11 @@ inline dim3 grid64x4(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
 
 // Builds G_1..G_B / W_1..W_B of every fed image: one launch per level for all images
 // (grid.z = image) on the LDS kernels; int16 sources and degenerate sizes use the generic kernels.
+// (Round 5 built and measured the fused tail asked for since round 3 — one workgroup per 8 x 8 tile of the last level, the 85 x 85
+// samples of level B - 3 under it staged in LDS, three pyrDowns from LDS to LDS, the cores of the passed levels written: 134 us against
+// the 36 us of the three launches it replaces on config 2 (84 against ~60 on config 4's share; commit history: "fused pyramid tail").
+// 1.7 x redundant halo work, 62 KB of LDS = 2 workgroups per CU = three rounds of a workgroup whose own dependent chain is longer than
+// a whole small launch.  One launch per level stays.)
 int stx_launch_mb_pyramids(stx_ctx* ctx, const StxMbImage* d_images, const StxMbImage* h_images, int n, int num_bands, int pyr_mode,
                            int pyr_lanes)
 {
@@ -1599,6 +1604,52 @@ __global__ __launch_bounds__(256) void block_gain4_kernel(BlockGainBatchK B)
 }
 }  // namespace
 
+// H rows + row tables of n rectangles (see stx_launch_block_gain_batch); imgs may be null (a consumer that multiplies the gain in itself)
+static void fill_gain_k(BlockGain4K& K, stx_buf* img, int w, int h, const stx_buf* gmap, const int* q, float* H, void* yt, int fast)
+{
+    K.img = img ? img->ptr : nullptr; K.stride = img ? (long long)img->stride : 0; K.w = w; K.h = h;
+    K.full_w = q ? q[0] : w; K.full_h = q ? q[1] : h;
+    K.x0 = q ? q[2] : 0; K.y0 = q ? q[3] : 0;
+    K.gmap = (const float*)gmap->ptr; K.gstride = (long long)(gmap->stride / sizeof(float));
+    K.gw = gmap->w; K.gh = gmap->h;
+    K.xscale = 1.0 / ((double)K.full_w / (double)K.gw);
+    K.yscale = 1.0 / ((double)K.full_h / (double)K.gh);
+    K.H = H; K.hstride = (long long)((w + 3) & ~3) * gmap->c;
+    K.yt = (int2*)yt;
+    K.fast = fast;
+}
+
+static void launch_gain_rows(stx_ctx* ctx, const BlockGainBatchK& B, int m, int gc)
+{
+    int mt = 0, mgh = 0;
+    double rows_bytes = 0.0;
+    for (int i = 0; i < m; i++) {
+        mt = std::max(mt, std::max(B.k[i].w, B.k[i].h));
+        mgh = std::max(mgh, B.k[i].gh);
+        rows_bytes += 4.0 * gc * B.k[i].gh * B.k[i].w + 8.0 * B.k[i].h;
+    }
+    StxProfScope prof(ctx, "block_gain_rows", rows_bytes);
+    const dim3 grid((mt + 255) / 256, mgh + 1, m);
+    if (gc == 1) hipLaunchKernelGGL(gain_rows_kernel<1>, grid, dim3(256), 0, ctx->stream, B);
+    else hipLaunchKernelGGL(gain_rows_kernel<3>, grid, dim3(256), 0, ctx->stream, B);
+}
+
+int stx_launch_gain_rows(stx_ctx* ctx, int n, const int* wh, const stx_buf* const* gmaps, const int* full_wh_xy0, float* const* Hs,
+                         void* const* yts)
+{
+    for (int base = 0; base < n; base += GAIN_BATCH) {
+        const int m = std::min(GAIN_BATCH, n - base);
+        BlockGainBatchK B;
+        memset(&B, 0, sizeof(B));
+        for (int i = 0; i < m; i++) {
+            const int g = base + i;
+            fill_gain_k(B.k[i], nullptr, wh[2 * g], wh[2 * g + 1], gmaps[g], full_wh_xy0 ? full_wh_xy0 + 4 * g : nullptr, Hs[g], yts[g], 1);
+        }
+        launch_gain_rows(ctx, B, m, gmaps[base]->c);
+    }
+    return check_launch("block_gain_rows");
+}
+
 // Hs / yts: per image device scratch (gh x hstride x gc floats, h int2), carved by the caller from one allocation
 int stx_launch_block_gain_batch(stx_ctx* ctx, int n, stx_buf* const* imgs, const stx_buf* const* gmaps, const int* full_wh_xy0,
                                 float* const* Hs, void* const* yts, const int* fast)
@@ -1608,33 +1659,17 @@ int stx_launch_block_gain_batch(stx_ctx* ctx, int n, stx_buf* const* imgs, const
         const int gc = gmaps[base]->c;
         BlockGainBatchK B;
         memset(&B, 0, sizeof(B));
-        int mw = 0, mh = 0, mgh = 0, mt = 0;
+        int mw = 0, mh = 0;
         bool all_fast = true;
-        double bytes = 0.0, rows_bytes = 0.0;
+        double bytes = 0.0;
         for (int i = 0; i < m; i++) {
             const int g = base + i;
-            BlockGain4K& K = B.k[i];
-            K.img = imgs[g]->ptr; K.stride = (long long)imgs[g]->stride; K.w = imgs[g]->w; K.h = imgs[g]->h;
-            K.full_w = full_wh_xy0 ? full_wh_xy0[4 * g] : K.w; K.full_h = full_wh_xy0 ? full_wh_xy0[4 * g + 1] : K.h;
-            K.x0 = full_wh_xy0 ? full_wh_xy0[4 * g + 2] : 0; K.y0 = full_wh_xy0 ? full_wh_xy0[4 * g + 3] : 0;
-            K.gmap = (const float*)gmaps[g]->ptr; K.gstride = (long long)(gmaps[g]->stride / sizeof(float));
-            K.gw = gmaps[g]->w; K.gh = gmaps[g]->h;
-            K.xscale = 1.0 / ((double)K.full_w / (double)K.gw);
-            K.yscale = 1.0 / ((double)K.full_h / (double)K.gh);
-            K.H = Hs[g]; K.hstride = (long long)((K.w + 3) & ~3) * gc;
-            K.yt = (int2*)yts[g];
-            K.fast = fast[g];
+            fill_gain_k(B.k[i], imgs[g], imgs[g]->w, imgs[g]->h, gmaps[g], full_wh_xy0 ? full_wh_xy0 + 4 * g : nullptr, Hs[g], yts[g], fast[g]);
             all_fast = all_fast && fast[g];
-            mw = std::max(mw, K.w); mh = std::max(mh, K.h); mgh = std::max(mgh, K.gh); mt = std::max(mt, std::max(K.w, K.h));
-            bytes += 6.0 * K.w * K.h;
-            rows_bytes += 4.0 * gc * K.gh * K.w + 8.0 * K.h;
+            mw = std::max(mw, B.k[i].w); mh = std::max(mh, B.k[i].h);
+            bytes += 6.0 * B.k[i].w * B.k[i].h;
         }
-        {
-            StxProfScope prof(ctx, "block_gain_rows", rows_bytes);
-            const dim3 grid((mt + 255) / 256, mgh + 1, m);
-            if (gc == 1) hipLaunchKernelGGL(gain_rows_kernel<1>, grid, dim3(256), 0, ctx->stream, B);
-            else hipLaunchKernelGGL(gain_rows_kernel<3>, grid, dim3(256), 0, ctx->stream, B);
-        }
+        launch_gain_rows(ctx, B, m, gc);
         StxProfScope prof(ctx, "block_gain_apply", bytes);
         const dim3 grid((mw + 255) / 256, (mh + 15) / 16, m);
         if (gc == 1 && all_fast) hipLaunchKernelGGL((block_gain4_kernel<1, true>), grid, dim3(256), 0, ctx->stream, B);

@@ -150,7 +150,11 @@ struct StxWarpLaunch {
     uint8_t* dmask; size_t dmask_stride;  // u8x1 or null
     int nearest_src;               // 1: out image = nearest sample of a u8x1 source (generic mask warp)
     int debug_maps = 0;            // stx_debug_warp_maps (test hook): dimg / dmask are f32 maps of x / y; 1: the kernel a warp would take, 2: the generic one
+    // fused exposure gain (stx_warp_batch_gain): device tables made by stx_launch_gain_rows for this destination rectangle; null: none
+    const float* gain_H = nullptr; long long gain_hstride = 0; const void* gain_yt = nullptr; int gain_gh = 0;
 };
+// typed projectors only (plane / affine / cylindrical / spherical / mercator), Q15 or float remap: what a fused gain needs
+bool stx_warp_fast_eligible(const StxWarpLaunch& L);
 int stx_launch_warp(stx_ctx* ctx, const StxWarpLaunch& L);
 int stx_launch_warp_batch(stx_ctx* ctx, const StxWarpLaunch* Ls, int n);
 int stx_launch_roi_minmax(stx_ctx* ctx, int n, const StxProjector* projs, const int* sizes_wh, float* out_minmax4);
@@ -191,6 +195,10 @@ int stx_launch_gain_apply(stx_ctx* ctx, stx_buf* img, const float g[3]);
 int stx_launch_block_gain(stx_ctx* ctx, stx_buf* img, const stx_buf* gmap, const int* d_xt, const int* d_yt);
 int stx_launch_block_gain_batch(stx_ctx* ctx, int n, stx_buf* const* imgs, const stx_buf* const* gmaps, const int* full_wh_xy0,
                                 float* const* Hs, void* const* yts, const int* fast);
+// only the first half of it — H rows and row tables of n rectangles (w, h at (x0, y0) of a full_w x full_h image each) — for a consumer
+// that multiplies the gain in itself (the warp kernel's epilogue); wh = {w, h} per rectangle
+int stx_launch_gain_rows(stx_ctx* ctx, int n, const int* wh, const stx_buf* const* gmaps, const int* full_wh_xy0, float* const* Hs,
+                         void* const* yts);
 // cv::resize(INTER_LINEAR_EXACT) u8 (next rows N2 / N3); d_xt / d_yt: device tables of (offset, coeff1 | interior << 16)
 int stx_launch_resize_exact(stx_ctx* ctx, const stx_buf* src, stx_buf* dst, const int* d_xt, const int* d_yt, bool dilate,
                             const stx_buf* andmask);

@@ -86,6 +86,10 @@ struct WarpK {
     int remap;   // STX_REMAP_*: the interpolation model of the image samples; anything but Q15 runs the one-pixel-per-lane kernels
     int num_ok;  // host-proved: |numerators| <= 2^60 and finite tables, the per-lane magnitude test is skipped
     int z_one;   // host-proved (plane / affine): z = 1.f for every pixel, the quotients are the numerators
+    // Exposure gain in the epilogue (stx_warp_batch_gain: BlocksCompensator::apply fused, stitching/stitcher.py:123,219-221): the
+    // horizontally interpolated rows of the gain map over this destination rectangle's columns (gain_rows_kernel: [g_gh][g_hstride] floats,
+    // g_hstride = dw rounded up to 4) and the row table (source row, bits of the fraction) of its rows; null: no gain
+    const float* g_H; long long g_hstride; const int2* g_yt; int g_gh;
 };
 
 // Up to WARP_BATCH images per launch: the per-image argument blocks travel in the kernel-argument segment
@@ -548,7 +552,9 @@ STX_DEV int periodic_axis(int s, int n, int period, float inv_period, int bias)
 
 // RM: STX_REMAP_* of the image samples (Q15: the fixed-point blend; FLOAT / FLOAT_FMA: the fp32 model — interior wavefronts through
 // blend_float_to_lds, every other wavefront one pixel at a time through sample_float: borders are a minority)
-template <int TYPE, bool IMG, bool MASK, bool DBG = false, int RM = STX_REMAP_Q15>
+// GAIN: the warped image leaves multiplied by the block gain of its position (cvRound(p g) saturated, cv::multiply's arithmetic) — applied
+// to the finished bytes on their way from LDS to memory, whatever sampling path made them
+template <int TYPE, bool IMG, bool MASK, bool DBG = false, int RM = STX_REMAP_Q15, bool GAIN = false>
 __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8))) void warp_fast_kernel(WarpBatchK B)
 {
     const WarpK& P = B.k[blockIdx.z];
@@ -831,7 +837,24 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
             const uint32_t* sp = &s_px[wv][4 * it][0] + lane * 3;
             STX_GAS uint8_t* base = (STX_GAS uint8_t*)(dimg_a + (unsigned long long)y0 * (unsigned long long)dimg_stride + (unsigned long long)xw * 3ull);
             STX_GAS uint32_t* d = reinterpret_cast<STX_GAS uint32_t*>(base + (__umul24((uint32_t)r, (uint32_t)dimg_stride) + (uint32_t)c * 12u));
-            const uint32_t a0 = sp[0], a1 = sp[1], a2 = sp[2];
+            uint32_t a0 = sp[0], a1 = sp[1], a2 = sp[2];
+            if (GAIN) {
+                // this lane's 4 pixels: columns xw + 4 c .. + 3 of row y0 + r.  g = H[r0][x] b0 + H[r1][x] b1 as cv::resize(INTER_LINEAR) rounds it
+                const int2 ty = P.g_yt[y0 + r];
+                const float b1 = __int_as_float(ty.y), b0 = fsub(1.f, b1);
+                const int r0 = min(max(ty.x, 0), P.g_gh - 1), r1 = min(max(ty.x + 1, 0), P.g_gh - 1);
+                const int colq = min(xw + 4 * c, (int)P.g_hstride - 4);  // (columns in the row pitch beyond the image: any gain will do)
+                const float4 u = *reinterpret_cast<const float4*>(P.g_H + (long long)r0 * P.g_hstride + colq);
+                const float4 v = *reinterpret_cast<const float4*>(P.g_H + (long long)r1 * P.g_hstride + colq);
+                const float g[4] = {fadd(fmul(u.x, b0), fmul(v.x, b1)), fadd(fmul(u.y, b0), fmul(v.y, b1)), fadd(fmul(u.z, b0), fmul(v.z, b1)),
+                                    fadd(fmul(u.w, b0), fmul(v.w, b1))};
+                const uint32_t in[3] = {a0, a1, a2};
+                uint32_t o[3] = {0u, 0u, 0u};
+#pragma unroll
+                for (int k = 0; k < 12; k++)  // byte k of the 12: pixel k / 3
+                    o[k >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmul((float)((in[k >> 2] >> (8 * (k & 3))) & 255u), g[k / 3])), (uint32_t)(k & 3), o[k >> 2]);
+                a0 = o[0]; a1 = o[1]; a2 = o[2];
+            }
             d[0] = a0; d[1] = a1; d[2] = a2;  // (non-temporal stores, round 5: 183.7 / 184.5 us against 177.1 / 177.9 — dropped)
         }
         if (MASK) {
@@ -846,8 +869,24 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const int idx = lane + 64 * k, rr = idx / 48, cdw = idx - rr * 48;
-                if (y0 + rr < dh && (long long)xw * 3 + cdw * 4 + 4 <= dimg_stride)
-                    *reinterpret_cast<uint32_t*>(drow + (long long)(y0 + rr) * dimg_stride + cdw * 4) = s_px[wv][4 * it + rr][cdw];
+                if (y0 + rr < dh && (long long)xw * 3 + cdw * 4 + 4 <= dimg_stride) {
+                    uint32_t w = s_px[wv][4 * it + rr][cdw];
+                    if (GAIN) {  // edge tiles: the dword's 4 bytes belong to two pixels
+                        const int2 ty = P.g_yt[y0 + rr];
+                        const float b1 = __int_as_float(ty.y), b0 = fsub(1.f, b1);
+                        const float* h0 = P.g_H + (long long)min(max(ty.x, 0), P.g_gh - 1) * P.g_hstride;
+                        const float* h1 = P.g_H + (long long)min(max(ty.x + 1, 0), P.g_gh - 1) * P.g_hstride;
+                        const int pa = (4 * cdw) / 3, pb = (4 * cdw + 3) / 3;
+                        const int xa = min(xw + pa, (int)P.g_hstride - 1), xb = min(xw + pb, (int)P.g_hstride - 1);
+                        const float ga = fadd(fmul(h0[xa], b0), fmul(h1[xa], b1)), gb = fadd(fmul(h0[xb], b0), fmul(h1[xb], b1));
+                        uint32_t o = 0u;
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            o = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmul((float)((w >> (8 * q)) & 255u), (4 * cdw + q) / 3 == pa ? ga : gb)), (uint32_t)q, o);
+                        w = o;
+                    }
+                    *reinterpret_cast<uint32_t*>(drow + (long long)(y0 + rr) * dimg_stride + cdw * 4) = w;
+                }
             }
         }
         if (MASK) {
@@ -1150,9 +1189,10 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
     STX_TRY(stx_dev_alloc(ctx, total * sizeof(float2), &tab));
     float2* cursor = (float2*)tab;
     for (int base = 0, m = 0; base < n; base += m) {
-        // a launch takes up to WARP_BATCH images of one remap model (the sampling block is compiled per model)
+        // a launch takes up to WARP_BATCH images of one remap model (the sampling block is compiled per model), all with or all without a gain
         const int rm = Ks[base].src ? Ks[base].remap : STX_REMAP_Q15;
-        for (m = 1; m < WARP_BATCH && base + m < n && (Ks[base + m].src ? Ks[base + m].remap : STX_REMAP_Q15) == rm; m++) {}
+        const bool gain = Ks[base].g_H != nullptr;
+        for (m = 1; m < WARP_BATCH && base + m < n && (Ks[base + m].src ? Ks[base + m].remap : STX_REMAP_Q15) == rm && (Ks[base + m].g_H != nullptr) == gain; m++) {}
         WarpBatchK B;
         memset(&B, 0, sizeof(B));
         int max_tab = 0, gx = 0, gy = 0;
@@ -1176,6 +1216,10 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
             gx = std::max(gx, (K.dw + WARP_TW - 1) / WARP_TW);
             gy = std::max(gy, (K.dh + WARP_TH - 1) / WARP_TH);
             fast = fast && fast_ok(K) && dbg != 2;
+            if (gain && (!fast_ok(K) || dbg)) {
+                stx_dev_free(ctx, tab);
+                return stx_fail(STX_ERR_UNSUPPORTED, "a fused gain needs the tuned warp kernel (image %d does not qualify)", base + i);
+            }
             tab_bytes += (double)K.dw * sizeof(float2) + (double)K.dh * 5 * sizeof(float);
             bytes += algo_bytes[base + i];
         }
@@ -1196,7 +1240,11 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
             // (160 KB per CU / request = workgroups per CU) for co-residency experiments with the other panorama's kernels
             static const unsigned pad_lds = getenv("STITCHING_AMD_WARP_LDS") ? (unsigned)atoi(getenv("STITCHING_AMD_WARP_LDS")) : 0u;
             if (dbg) hipLaunchKernelGGL((warp_fast_kernel<TYPE, false, false, true>), gf, dim3(WARP_FW), 0, s, B);
-#define STX_FAST_LAUNCH(I, M, R) hipLaunchKernelGGL((warp_fast_kernel<TYPE, I, M, false, R>), gf, dim3(WARP_FW), pad_lds, s, B)
+#define STX_FAST_LAUNCH(I, M, R)                                                                                        \
+    do {                                                                                                               \
+        if (gain) hipLaunchKernelGGL((warp_fast_kernel<TYPE, I, M, false, R, true>), gf, dim3(WARP_FW), pad_lds, s, B);  \
+        else hipLaunchKernelGGL((warp_fast_kernel<TYPE, I, M, false, R, false>), gf, dim3(WARP_FW), pad_lds, s, B);      \
+    } while (0)
 #define STX_FAST_LAUNCH_RM(I, M)                                             \
     do {                                                                     \
         if (rm == STX_REMAP_FLOAT) STX_FAST_LAUNCH(I, M, STX_REMAP_FLOAT);   \
@@ -1239,6 +1287,8 @@ void launch_general_group(stx_ctx* ctx, const WarpK& K, bool img, bool mask, int
 
 int launch_general(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, const char* prof_name, const double* algo_bytes, int dbg)
 {
+    for (int i = 0; i < n; i++)
+        if (Ks[i].g_H) return stx_fail(STX_ERR_UNSUPPORTED, "a fused gain needs the tuned warp kernel (per-pixel projector families have none)");
     for (int i = 0; i < n; i++) {
         StxProfScope prof(ctx, prof_name, algo_bytes[i]);
         const WarpK& K = Ks[i];
@@ -1276,6 +1326,7 @@ void fill_warpk(const StxWarpLaunch& L, WarpK* Kp, double* bytes)
     K.msrc = L.nearest_src ? L.src : nullptr;
     K.msstride = (long long)L.sstride;
     K.dimg = L.dimg; K.dimg_stride = (long long)L.dimg_stride;
+    K.g_H = img ? L.gain_H : nullptr; K.g_hstride = L.gain_hstride; K.g_yt = reinterpret_cast<const int2*>(L.gain_yt); K.g_gh = L.gain_gh;
     K.dmask = L.dmask; K.dmask_stride = (long long)L.dmask_stride;
     // fast kernel: ranges of s = cvRound(32 v) as bit patterns of fl(32 v + 1.5 * 2^23), see WarpK
     const int zx_lo = std::max(-32 * L.sw, -32768 * 32), zx_hi = std::min(64 * L.sw - 33, 32767 * 32 + 31);
@@ -1342,6 +1393,15 @@ int stx_launch_warp_batch(stx_ctx* ctx, const StxWarpLaunch* Ls, int n)
 }
 
 int stx_launch_warp(stx_ctx* ctx, const StxWarpLaunch& L) { return stx_launch_warp_batch(ctx, &L, 1); }
+
+bool stx_warp_fast_eligible(const StxWarpLaunch& L)
+{
+    if (L.proj.family != STX_F_PLANE && L.proj.family != STX_F_CYLINDRICAL && L.proj.family != STX_F_SPHERICAL && L.proj.family != STX_F_MERCATOR) return false;
+    WarpK K;
+    double bytes;
+    fill_warpk(L, &K, &bytes);
+    return fast_ok(K) && !L.debug_maps && L.dimg != nullptr;
+}
 
 // out_minmax4[i] = {min u, min v, max u, max v} over the border of image i (cyl / spherical)
 int stx_launch_roi_minmax(stx_ctx* ctx, int n, const StxProjector* projs, const int* sizes_wh, float* out_minmax4)
