@@ -202,6 +202,15 @@ int stx_warp_batch(stx_ctx* ctx, int type, float scale, int n, const float* K9s,
  * seam cell AFTER warping all of it, :119-121). */
 int stx_warp_batch_rects(stx_ctx* ctx, int type, float scale, int n, const float* K9s, const float* R9s,
                          const stx_buf* const* srcs, const int* rects_xywh, stx_buf** out_imgs, stx_buf** out_masks);
+/* stx_warp_batch[_rects] + the block gains of the exposure compensator in one call: the loops stitching/stitcher.py:119-123 (warp final
+ * images, then compensator.apply on each) for the "gain_blocks" compensator.  gain_maps[i]: f32x1 (f32x3: channel_blocks) map of image i,
+ * laid over its WHOLE warped image (BlocksCompensator::apply) also when rects_xywh names a rectangle of it; gain_flags as in
+ * stx_block_gain_apply_batch.  The product happens in the warp kernel's epilogue when it can (tuned kernel, bounded f32x1 maps), else as
+ * a second pass: out_imgs equal stx_block_gain_apply_batch(stx_warp_batch[_rects](...)) byte for byte either way.  rects_xywh may be NULL
+ * (whole ROIs, returned in out_xywh). */
+int stx_warp_batch_gain(stx_ctx* ctx, int type, float scale, int n, const float* K9s, const float* R9s, const stx_buf* const* srcs,
+                        const int* rects_xywh, const stx_buf* const* gain_maps_f32, const int* gain_flags, stx_buf** out_imgs,
+                        stx_buf** out_masks, int* out_xywh);
 /* stitching/warper.py:58-68 without allocating the 255-filled source (size only) */
 int stx_warp_mask(stx_ctx* ctx, int type, float scale, const float K[9], const float R[9], int w, int h,
                   stx_buf** out_mask, int out_xywh[4]);

@@ -627,11 +627,11 @@ static int block_gain_plain(stx_ctx* ctx, stx_buf* img, const stx_buf* gain_map)
 
 static int block_gain_check(stx_ctx* ctx, const stx_buf* img, const stx_buf* gain_map)
 {
-    if (!img || !gain_map) return stx_fail(STX_ERR_INVALID, "null argument");
-    if (img->elem != STX_U8 || img->c != 3) return stx_fail(STX_ERR_INVALID, "block gain apply needs a u8x3 image");
+    if (!gain_map) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (img && (img->elem != STX_U8 || img->c != 3)) return stx_fail(STX_ERR_INVALID, "block gain apply needs a u8x3 image");
     if (gain_map->elem != STX_F32 || (gain_map->c != 1 && gain_map->c != 3))
         return stx_fail(STX_ERR_INVALID, "the gain map must be f32x1 (gain_blocks) or f32x3 (channel_blocks)");
-    if (img->ctx != ctx || gain_map->ctx->device != ctx->device) return stx_fail(STX_ERR_INVALID, "buffers belong to another context");
+    if ((img && img->ctx != ctx) || gain_map->ctx->device != ctx->device) return stx_fail(STX_ERR_INVALID, "buffers belong to another context");
     return STX_OK;
 }
 
@@ -644,6 +644,7 @@ STX_EXPORT int stx_block_gain_apply_batch(stx_ctx* ctx, int n, stx_buf* const* i
     if (n == 0) return STX_OK;
     STX_TRY(stx_set_device(ctx));
     for (int i = 0; i < n; i++) {
+        if (!imgs[i]) return stx_fail(STX_ERR_INVALID, "null argument");
         STX_TRY(block_gain_check(ctx, imgs[i], gain_maps[i]));
         if (full_wh_xy0) {
             const int* q = full_wh_xy0 + 4 * i;
@@ -1236,7 +1237,8 @@ STX_EXPORT int stx_warp(stx_ctx* ctx, int type, float scale, const float K[9], c
 // rects: null -> the destination rectangle of image i is its ROI (found here, cached); else the caller's rectangle in warp
 // coordinates (any sub-rectangle of the ROI gives exactly the ROI warp's pixels there: every pixel is mapped on its own)
 static int warp_batch_impl(stx_ctx* ctx, int type, float scale, int n, const float* K9s, const float* R9s,
-                           const stx_buf* const* srcs, const int* rects, stx_buf** out_imgs, stx_buf** out_masks, int* out_xywh)
+                           const stx_buf* const* srcs, const int* rects, stx_buf** out_imgs, stx_buf** out_masks, int* out_xywh,
+                           const stx_buf* const* gains = nullptr, const int* gflags = nullptr)
 {
     if (!ctx || !K9s || !R9s || !srcs || n < 0) return stx_fail(STX_ERR_INVALID, "bad argument");
     if (!out_imgs && !out_masks) return stx_fail(STX_ERR_INVALID, "nothing requested");
@@ -1255,8 +1257,9 @@ static int warp_batch_impl(stx_ctx* ctx, int type, float scale, int n, const flo
     // ROIs: cached ones as they are, all missing ones in ONE device pass (one synchronisation)
     if (!g_roi_cache) g_roi_cache = new std::map<RoiKey, std::array<int, 4>>();
     std::vector<int> miss;
-    if (rects) memcpy(rois.data(), rects, sizeof(int) * 4 * (size_t)n);
-    for (int i = 0; i < n && !rects; i++) {
+    // with gains the ROI of every image is needed even under caller-given rectangles: the gain map lies over the WHOLE warped image
+    const bool need_rois = !rects || gains;
+    for (int i = 0; i < n && need_rois; i++) {
         auto it = g_roi_cache->find(make_key(type, scale, K9s + 9 * i, R9s + 9 * i, sizes[2 * i], sizes[2 * i + 1]));
         if (it != g_roi_cache->end()) memcpy(&rois[4 * i], it->second.data(), 16);
         else miss.push_back(i);
@@ -1273,6 +1276,20 @@ static int warp_batch_impl(stx_ctx* ctx, int type, float scale, int n, const flo
             memcpy(&rois[4 * i], &mroi[4 * j], 16);
             (*g_roi_cache)[make_key(type, scale, K9s + 9 * i, R9s + 9 * i, sizes[2 * i], sizes[2 * i + 1])] = {
                 mroi[4 * j], mroi[4 * j + 1], mroi[4 * j + 2], mroi[4 * j + 3]};
+        }
+    }
+    std::vector<int> full_rois;
+    if (gains) {
+        if (!out_imgs) return stx_fail(STX_ERR_INVALID, "gains without images");
+        full_rois = rois;
+        for (int i = 0; i < n; i++) STX_TRY(block_gain_check(ctx, nullptr, gains[i]));
+    }
+    if (rects) {
+        memcpy(rois.data(), rects, sizeof(int) * 4 * (size_t)n);
+        for (int i = 0; i < n && gains; i++) {
+            const int *r = &rois[4 * i], *f = &full_rois[4 * i];
+            if (r[0] < f[0] || r[1] < f[1] || r[0] + r[2] > f[0] + f[2] || r[1] + r[3] > f[1] + f[3])
+                return stx_fail(STX_ERR_INVALID, "image %d: with gains the rectangle must lie inside the warp roi", i);
         }
     }
     std::vector<stx_buf*> bi(n, nullptr), bm(n, nullptr);
@@ -1293,7 +1310,46 @@ static int warp_batch_impl(stx_ctx* ctx, int type, float scale, int n, const flo
         L.dimg = bi[i] ? bi[i]->ptr : nullptr; L.dimg_stride = bi[i] ? bi[i]->stride : 0;
         L.dmask = bm[i] ? bm[i]->ptr : nullptr; L.dmask_stride = bm[i] ? bm[i]->stride : 0;
     }
+    // Exposure gains (BlocksCompensator::apply, stitching/stitcher.py:123,219-221).  Fused into the warp's epilogue when every image runs
+    // the tuned kernel and every map is a bounded single-channel one: the warped bytes leave LDS already multiplied, the 6 bytes per
+    // pixel of a separate pass never move.  Anything else: warp, then stx_block_gain_apply_batch — the same bytes either way.
+    std::vector<int> sub;
+    void* gscratch = nullptr;
+    bool fused = false;
+    if (rc == STX_OK && gains) {
+        for (int i = 0; i < n; i++) {
+            sub.push_back(full_rois[4 * i + 2]); sub.push_back(full_rois[4 * i + 3]);
+            sub.push_back(rois[4 * i] - full_rois[4 * i]); sub.push_back(rois[4 * i + 1] - full_rois[4 * i + 1]);
+        }
+        static const bool no_fuse = getenv("STITCHING_AMD_NO_GAIN_FUSION") != nullptr;  // diagnostic: A/B against the separate pass
+        fused = !no_fuse;
+        for (int i = 0; i < n && fused; i++)
+            fused = gains[i]->c == 1 && gflags && (gflags[i] & STX_GAIN_MAP_BOUNDED) && stx_warp_fast_eligible(Ls[i]) &&
+                    (size_t)gains[i]->h * (size_t)Ls[i].dw < ((size_t)16 << 20);
+        if (fused) {
+            std::vector<size_t> offH(n), offY(n);
+            size_t bytes = 0;
+            for (int i = 0; i < n; i++) {
+                offH[i] = bytes; bytes += align_up((size_t)gains[i]->h * ((Ls[i].dw + 3) & ~3) * sizeof(float), 256);
+                offY[i] = bytes; bytes += align_up((size_t)Ls[i].dh * 8, 256);
+            }
+            rc = stx_dev_alloc(ctx, bytes, &gscratch);
+            if (rc == STX_OK) {
+                std::vector<float*> Hs(n);
+                std::vector<void*> yts(n);
+                std::vector<int> wh(2 * (size_t)n);
+                for (int i = 0; i < n; i++) {
+                    Hs[i] = (float*)((uint8_t*)gscratch + offH[i]); yts[i] = (uint8_t*)gscratch + offY[i];
+                    wh[2 * i] = Ls[i].dw; wh[2 * i + 1] = Ls[i].dh;
+                    Ls[i].gain_H = Hs[i]; Ls[i].gain_hstride = (Ls[i].dw + 3) & ~3; Ls[i].gain_yt = yts[i]; Ls[i].gain_gh = gains[i]->h;
+                }
+                rc = stx_launch_gain_rows(ctx, n, wh.data(), gains, sub.data(), Hs.data(), yts.data());
+            }
+        }
+    }
     if (rc == STX_OK) rc = stx_launch_warp_batch(ctx, Ls.data(), n);
+    if (gscratch) stx_dev_free(ctx, gscratch);  // stream-ordered reuse
+    if (rc == STX_OK && gains && !fused) rc = stx_block_gain_apply_batch(ctx, n, bi.data(), gains, sub.data(), gflags);
     if (rc != STX_OK) {
         for (int i = 0; i < n; i++) { stx_buf_release(bi[i]); stx_buf_release(bm[i]); }
         return rc;
@@ -1318,6 +1374,15 @@ STX_EXPORT int stx_warp_batch_rects(stx_ctx* ctx, int type, float scale, int n, 
 {
     if (!rects_xywh) return stx_fail(STX_ERR_INVALID, "null argument");
     return warp_batch_impl(ctx, type, scale, n, K9s, R9s, srcs, rects_xywh, out_imgs, out_masks, nullptr);
+}
+
+STX_EXPORT int stx_warp_batch_gain(stx_ctx* ctx, int type, float scale, int n, const float* K9s, const float* R9s, const stx_buf* const* srcs,
+                                   const int* rects_xywh_or_null, const stx_buf* const* gain_maps, const int* gain_flags, stx_buf** out_imgs,
+                                   stx_buf** out_masks, int* out_xywh_or_null)
+{
+    if (!gain_maps || !out_imgs) return stx_fail(STX_ERR_INVALID, "null argument");
+    return warp_batch_impl(ctx, type, scale, n, K9s, R9s, srcs, rects_xywh_or_null, out_imgs, out_masks, rects_xywh_or_null ? nullptr : out_xywh_or_null,
+                           gain_maps, gain_flags);
 }
 
 STX_EXPORT int stx_warp_image_and_mask(stx_ctx* ctx, int type, float scale, const float K[9], const float R[9],

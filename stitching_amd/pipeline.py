@@ -158,7 +158,7 @@ class StitchJob:
             if crop is not None:
                 box = [c if c is not None else (0, w, 0, h) for c, (w, h) in zip(crop, self.warped_sizes)]
                 rects = [(cx + x0, cy + y0, x1 - x0, y1 - y0) for (x0, x1, y0, y1), (cx, cy) in zip(box, self.corners)]
-                imgs, masks, rois = self.warper.warp_images_and_masks(self.frames, self.cameras, rects=rects)
+                imgs, masks, rois = self.warper.warp_images_and_masks(self.frames, self.cameras, rects=rects, compensator=self.compensator)
                 if self.feed_masks is not None:
                     masks = [m[y0:y1, x0:x1] for m, (x0, x1, y0, y1) in zip(self.feed_masks, box)]
                 else:
@@ -167,13 +167,8 @@ class StitchJob:
                     masks = SeamFinder.resize_all(self.seam_masks, masks,
                                                   sub=[(w, h, x0, y0) for (x0, x1, y0, y1), (w, h) in zip(box, self.warped_sizes)])
                 corners = [(r[0], r[1]) for r in rects]
-                if self.compensator is not None:
-                    imgs = self.compensator.apply_all(corners, imgs, masks, ctx=self.ctx,
-                                                      sub=[(w, h, x0, y0) for (x0, x1, y0, y1), (w, h) in zip(box, self.warped_sizes)])
             else:
-                imgs, masks, rois = self.warper.warp_images_and_masks(self.frames, self.cameras)
-                if self.compensator is not None:
-                    imgs = self.compensator.apply_all(self.corners, imgs, masks, ctx=self.ctx)
+                imgs, masks, rois = self.warper.warp_images_and_masks(self.frames, self.cameras, compensator=self.compensator)
                 if self.feed_masks is not None:
                     masks = self.feed_masks
                 elif self.seam_masks is not None:
@@ -217,10 +212,8 @@ def compose(frames, cameras, warper_type="spherical", blender_type="multiband", 
     try:
         warper = Warper(warper_type, ctx=ctx)
         warper.set_scale(cameras)
-        imgs, masks, rois = warper.warp_images_and_masks([as_device(f, ctx) for f in frames], cameras)
+        imgs, masks, rois = warper.warp_images_and_masks([as_device(f, ctx) for f in frames], cameras, compensator=compensator)
         corners, sizes = [r[0:2] for r in rois], [r[2:4] for r in rois]
-        if compensator is not None:
-            imgs = compensator.apply_all(corners, imgs, masks, ctx=ctx)
         if seam_masks is not None:
             from .seam_finder import SeamFinder
 

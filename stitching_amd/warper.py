@@ -146,12 +146,15 @@ class Warper:
                                                     src._h, C.byref(oi), C.byref(om), roi))
         return (self._result(DeviceImage(ctx, oi)), self._result(DeviceImage(ctx, om)), tuple(int(v) for v in roi))
 
-    def warp_images_and_masks(self, imgs, cameras, aspect=1, rects=None):
+    def warp_images_and_masks(self, imgs, cameras, aspect=1, rects=None, compensator=None):
         """Batched form of warp_images + create_and_warp_masks (stitching/warper.py:39-41, 54-56) for a list of
         images: one ROI pass, one table launch and one remap launch for all of them (stx_warp_batch).
         Returns (warped_images, warped_masks, rois).
         rects: optional (x, y, w, h) per image in warp coordinates — only that rectangle of each warped image / mask is
-        produced (pixel for pixel what the full warp holds there); the returned rois are then these rectangles."""
+        produced (pixel for pixel what the full warp holds there); the returned rois are then these rectangles.
+        compensator: an ExposureErrorCompensator with block gains set ("gain_blocks" / "channel_blocks"): the warped images come back
+        compensated — stitching/stitcher.py:119-123 in one call (stx_warp_batch_gain: the product rides in the warp kernel's epilogue
+        when it can).  Equal to compensator.apply_all on the plain result, byte for byte."""
         ctx = self._ctx()
         srcs = [self._source(img, ctx) for img in imgs]
         cameras = list(cameras)
@@ -165,14 +168,34 @@ class Warper:
         h_src = (C.c_void_p * n)(*[s._h for s in srcs[:n]])
         h_img, h_mask = (C.c_void_p * n)(), (C.c_void_p * n)()
         rois = np.zeros((n, 4), np.int32)
-        if rects is not None:
+        if compensator is not None and compensator.compensator_type in ("gain_blocks", "channel_blocks"):
+            if compensator.gains is None:
+                raise StitchingError("ExposureErrorCompensator.set_gains(gains) must be called before apply")
+            gm = [compensator._gain_map(i, ctx) for i in range(n)]
+            ga, fl = (C.c_void_p * n)(*[g[0]._h for g in gm]), (C.c_int * n)(*[g[1] for g in gm])
+            rp = None
+            if rects is not None:
+                rois = np.ascontiguousarray(np.asarray(rects, np.int32).reshape(n, 4))
+                rp = rois.ctypes.data_as(C.POINTER(C.c_int))
+            _lib.check(ctx._lib.stx_warp_batch_gain(ctx.handle, self._type_id(), self._scale(aspect), n, _fp(Ks), _fp(Rs), h_src, rp, ga, fl,
+                                                    h_img, h_mask, None if rects is not None else rois.ctypes.data_as(C.POINTER(C.c_int))))
+            compensator = None
+        elif rects is not None:
             rois = np.ascontiguousarray(np.asarray(rects, np.int32).reshape(n, 4))
             _lib.check(ctx._lib.stx_warp_batch_rects(ctx.handle, self._type_id(), self._scale(aspect), n, _fp(Ks), _fp(Rs), h_src,
                                                      rois.ctypes.data_as(C.POINTER(C.c_int)), h_img, h_mask))
         else:
             _lib.check(ctx._lib.stx_warp_batch(ctx.handle, self._type_id(), self._scale(aspect), n, _fp(Ks), _fp(Rs), h_src,
                                                h_img, h_mask, rois.ctypes.data_as(C.POINTER(C.c_int))))
-        imgs_out = [self._result(DeviceImage(ctx, C.c_void_p(h_img[i]))) for i in range(n)]
+        d_imgs = [DeviceImage(ctx, C.c_void_p(h_img[i])) for i in range(n)]
+        if compensator is not None:  # "gain" / "channel" (one launch per image) or "no": after the warp
+            prev = config.device_resident()
+            config.set_device_resident(True)
+            try:
+                d_imgs = compensator.apply_all([tuple(int(v) for v in r[:2]) for r in rois], d_imgs, None, ctx=ctx)
+            finally:
+                config.set_device_resident(prev)
+        imgs_out = [self._result(d) for d in d_imgs]
         masks_out = [self._result(DeviceImage(ctx, C.c_void_p(h_mask[i]))) for i in range(n)]
         return imgs_out, masks_out, [tuple(int(v) for v in r) for r in rois]
 

@@ -350,3 +350,58 @@ def helpers_ring(n, w, h, span):
     from tests import helpers
 
     return helpers.small_ring(n, w, h, span=span)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wtype", ["spherical", "cylindrical", "plane", "fisheye"])
+def test_gains_fused_into_the_warp_equal_the_separate_pass(oracle, gpu_ctx, wtype):
+    """Warper.warp_images_and_masks(compensator=): stitching/stitcher.py:119-123 in one call.  The tuned kernels multiply the block gain
+    in their epilogue (level, pitched and edge tiles; whole ROIs and rectangles of them), a per-pixel projector (fisheye) and an
+    unbounded map take the second pass: always the oracle's warp followed by the oracle's block_gain_apply, byte for byte."""
+    import math
+
+    from stitching_amd.camera import CameraParams
+
+    w, h = 517, 389
+    cams = synthetic.ring_cameras(3, w, h, span_deg=60.0 if wtype == "plane" else 120.0)
+    if wtype != "plane":
+        R = synthetic.rot_y(0.3) @ synthetic.rot_x(math.radians(35.0)) @ synthetic.rot_z(0.4)
+        cams.append(CameraParams(focal=0.8 * w, aspect=1.0, ppx=w / 2.0, ppy=h / 2.0, R=R.astype(np.float32)))
+    imgs = [synthetic.make_frame(30 + i, w, h) for i in range(len(cams))]
+    g, o = S.Warper(wtype), oracle.Warper(wtype)
+    g.set_scale(cams)
+    o.set_scale(cams)
+    corners, sizes = o.warp_rois([(w, h)] * len(cams), cams)
+    rng = np.random.default_rng(12)
+    gmaps = [(0.7 + 0.6 * rng.random(((s[1] + 63) // 64 + 1, (s[0] + 63) // 64 + 1))).astype(np.float32) for s in sizes]
+    want = [oracle.block_gain_apply(o.warp_image(im, c), gm) for im, c, gm in zip(imgs, cams, gmaps)]
+    wmask = [o.create_and_warp_mask((w, h), c) for c in cams]
+    comp = S.ExposureErrorCompensator("gain_blocks")
+    comp.set_gains(gmaps)
+    gi, gmk, rois = g.warp_images_and_masks(imgs, cams, compensator=comp)
+    for k in range(len(cams)):
+        assert tuple(rois[k][:2]) == tuple(corners[k]) and tuple(rois[k][2:]) == tuple(sizes[k])
+        assert np.array_equal(np.asarray(gi[k]), want[k]), (wtype, k, int(np.count_nonzero(np.asarray(gi[k]) != want[k])))
+        assert np.array_equal(np.asarray(gmk[k]), wmask[k])
+    # rectangles of the ROIs (StitchJob's seam-cell crops): the gain map stays laid over the whole warped image
+    rects = [(c[0] + 8 * (k + 1), c[1] + 5, max(s[0] // 2, 9), max(s[1] - 11, 7)) for k, (c, s) in enumerate(zip(corners, sizes))]
+    ri, _, _ = g.warp_images_and_masks(imgs, cams, rects=rects, compensator=comp)
+    for k, (x, y, rw, rh) in enumerate(rects):
+        x0, y0 = x - corners[k][0], y - corners[k][1]
+        assert np.array_equal(np.asarray(ri[k]), want[k][y0:y0 + rh, x0:x0 + rw]), (wtype, "rect", k)
+    # a map whose products can leave the int range: no fusion, the second pass with cvRound's overflow rule
+    bad = [m.copy() for m in gmaps]
+    bad[0][0, 0] = np.float32(3e7)
+    comp.set_gains(bad)
+    bi, _, _ = g.warp_images_and_masks(imgs, cams, compensator=comp)
+    assert np.array_equal(np.asarray(bi[0]), oracle.block_gain_apply(o.warp_image(imgs[0], cams[0]), bad[0]))
+    # per-channel maps (channel_blocks) and scalar gains ride behind the warp
+    c3 = S.ExposureErrorCompensator("channel_blocks")
+    g3 = [(0.7 + 0.6 * rng.random(m.shape + (3,))).astype(np.float32) for m in gmaps]
+    c3.set_gains(g3)
+    ci, _, _ = g.warp_images_and_masks(imgs, cams, compensator=c3)
+    assert np.array_equal(np.asarray(ci[1]), oracle.block_gain_apply(o.warp_image(imgs[1], cams[1]), g3[1]))
+    cs = S.ExposureErrorCompensator("gain")
+    cs.set_gains([1.1, 0.9, 1.05, 1.2][:len(cams)])
+    si, _, _ = g.warp_images_and_masks(imgs, cams, compensator=cs)
+    assert np.array_equal(np.asarray(si[2]), oracle.gain_apply(o.warp_image(imgs[2], cams[2]), 1.05))
