@@ -60,8 +60,8 @@ def parse():
     p.add_argument("--streams", type=int, default=2, help="panoramas in flight per GPU (contexts = HIP streams); N = 1 "
                    "measured: 1 -> 93.0, 2 -> 105.9, 3 -> 99.6 Gpix/s")
     p.add_argument("--e2e-steps", type=int, default=2, help="PCIe-inclusive passes (host frames in, host panorama out)")
-    p.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r04_traffic.json"),
-                   help="JSON with PMC-derived HBM bytes per launch (tools/make_traffic_json.py)")
+    p.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r05_traffic.json"),
+                   help="JSON with PMC-derived HBM bytes per launch and rocprofv3's average launch durations (tools/make_traffic_json.py)")
     return p.parse_args()
 
 
@@ -517,7 +517,7 @@ def main():
     avg_ms = dom["total_ms"] / dom["calls"]
     bytes_per_launch = dom["algo_bytes"] / dom["calls"]
     achieved = bytes_per_launch / (avg_ms / 1e3) / 1e9
-    traffic, traffic_of = None, {}
+    traffic, traffic_of, rocprof_us = None, {}, {}
     khash = kernel_source_hash()
     if args.traffic_json and os.path.exists(args.traffic_json):
         tj = json.load(open(args.traffic_json))
@@ -525,10 +525,16 @@ def main():
         if tj.get("kernel_source_hash") == khash and tj.get("workload_cfg", 2) == wl["cfg"] and world == 1:
             traffic_of = {k: round(v["traffic_bytes"]) for k, v in tj.items() if isinstance(v, dict) and "traffic_bytes" in v}
             traffic = traffic_of.get(dom["kernel"])
+            rocprof_us = tj.get("rocprofv3_avg_us", {})  # rocprofv3 --kernel-trace --stats of the same command on the same sources
     roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_launch_us": round(avg_ms * 1e3, 2), "algo_bytes_per_launch": round(bytes_per_launch),
                 "launches_per_step": dom["calls"] / max(1, args.profile_steps), "kernel_source_hash": khash}
+    if dom["kernel"] in rocprof_us:
+        # the same fraction from rocprofv3's average duration of this kernel (profiles/, another run on another box of the pool: the two
+        # clocks agree within a few per cent)
+        roofline["avg_launch_us_rocprofv3"] = rocprof_us[dom["kernel"]]
+        roofline["frac_rocprofv3"] = round(bytes_per_launch / (rocprof_us[dom["kernel"]] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
     ksum = sum(k["total_ms"] for k in kernels)
     kbytes = sum(k["algo_bytes"] for k in kernels)
     bands_txt = f"{getattr(job, 'last_num_bands', wl['bands'])}-band " if wl["blender"] == "multiband" else ""

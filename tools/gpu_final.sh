@@ -16,14 +16,15 @@ BENCHQ="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --min-
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT" -o pmc_$C -- $BENCHQ > "$OUT/pmc_$C.log" 2>&1 || echo "pmc $C failed"
 done
-python tools/make_traffic_json.py "$OUT" "$OUT/traffic.json"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o kt -- python bench.py --no-cpu-baseline --no-extra --min-seconds 0 --e2e-steps 0 --steps 80 --warmup 20 --streams 1 --profile-steps 10 > "$OUT/bench_kt.log" 2>&1; echo "rocprof rc=$?"
 cat "$OUT/kt_kernel_stats.csv"
-cp "$OUT/traffic.json" profiles/r04_traffic.json
+# PMC bytes per launch + rocprofv3's average durations, keyed by the kernel source hash: what bench.py quotes as `traffic` / `frac_rocprofv3`
+python tools/make_traffic_json.py "$OUT" "$OUT/traffic.json" "$OUT/kt_kernel_stats.csv"
+cp "$OUT/traffic.json" profiles/r05_traffic.json
 bash tools/prof_pmc_lite.sh ${TAG}_sq --streams 1 > /dev/null 2>&1; cp gpurun_out/${TAG}_sq/summary.txt "$OUT/sq_summary.txt"
 timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
 cat "$OUT/bench.json"
-for leg in config3 config4 seams; do timeout 300 python tools/prof_legs.py $leg 5 > "$OUT/legs_$leg.txt" 2>&1; cat "$OUT/legs_$leg.txt"; done
+for leg in config3 config4 seams defaults; do timeout 300 python tools/prof_legs.py $leg 5 > "$OUT/legs_$leg.txt" 2>&1; cat "$OUT/legs_$leg.txt"; done
 # FINAL_CORE=1: stop here (a short GPU budget): the N = 2 / 4 lines on one shared GPU and the simulated ranks are the optional tail
 if [ -n "${FINAL_CORE:-}" ]; then exit 0; fi
 for N in 2 4; do

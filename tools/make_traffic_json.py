@@ -2,7 +2,9 @@
 """rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes -> profiles/<tag>_traffic.json: HBM bytes per launch for the kernels
 bench.py names.  FETCH_SIZE / WRITE_SIZE are reported in KB; per MI355X_MICROARCH.md (HBM section)
 gfx950's FETCH_SIZE counts 128-byte read requests at 64 B, so reads are doubled ("corrected"); WRITE_SIZE is taken
-as reported (uncalibrated).  usage: make_traffic_json.py <dir with pmc*_counter_collection.csv> <out.json>"""
+as reported (uncalibrated).  usage: make_traffic_json.py <dir with pmc*_counter_collection.csv> <out.json> [kernel_stats.csv]
+With a `rocprofv3 --kernel-trace --stats` summary as third argument its average launch durations go into the file too (`rocprofv3_avg_us`):
+bench.py prints `roofline.frac_rocprofv3` from them next to its own HIP-event figure when the kernel source hash matches."""
 import csv
 import glob
 import json
@@ -25,10 +27,10 @@ def kernel_source_hash():
 NAMES = [("warp_fast_kernel<3, true, true", "warp_img_mask"), ("warp_fast_kernel<2, true, true", "warp_img_mask"),
          ("warp_fast_kernel<0, true, true", "warp_img_mask"), ("mb_level0_pk_kernel", "mb_level0"),
          ("mb_down0_lds_kernel", "mb_down0"), ("mb_down_lds_kernel", "mb_down"), ("warp_tables_kernel", "warp_tables"),
-         ("mb_level_pk_kernel", "mb_level"), ("mb_coarse_kernel", "mb_coarse"), ("roi_kernel", "warp_roi"), ("mb_down_tail_kernel", "mb_down_tail")]
+         ("mb_level_pk_kernel", "mb_level"), ("mb_coarse_kernel", "mb_coarse"), ("roi_kernel", "warp_roi")]
 
 
-def main(d, out):
+def main(d, out, stats=None):
     acc = defaultdict(lambda: defaultdict(list))
     for f in sorted(glob.glob(f"{d}/*counter_collection.csv")):
         for row in csv.DictReader(open(f)):
@@ -46,6 +48,16 @@ def main(d, out):
                              "traffic_bytes": 2 * fetch_kb * 1024 + write_kb * 1024,
                              "note": "2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, mean per launch"}
     items = dict(res)
+    if stats and os.path.exists(stats):
+        avg = {}
+        for row in csv.DictReader(open(stats)):
+            k = re.sub(r"\(anonymous namespace\)::", "", row["Name"]).replace("void ", "")
+            for pat, name in NAMES:
+                if k.startswith(pat):
+                    tot, calls = avg.get(name, (0.0, 0))
+                    avg[name] = (tot + float(row["TotalDurationNs"]), calls + int(row["Calls"]))
+        res["rocprofv3_avg_us"] = {name: round(tot / calls / 1e3, 3) for name, (tot, calls) in avg.items() if calls}
+        res["rocprofv3_stats_file"] = os.path.basename(stats)
     res["kernel_source_hash"] = kernel_source_hash()
     res["workload_cfg"] = 2
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
@@ -54,4 +66,4 @@ def main(d, out):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
