@@ -357,7 +357,7 @@ def timed_rounds(run_step, barrier, steps, warmup, n_inflight, min_seconds, redu
         dt = reduce_max(time.perf_counter() - t0)
         rounds.append(dt)
         total += dt
-        if total >= min_seconds or len(rounds) >= 200:
+        if total >= min_seconds or len(rounds) >= 2000:
             return rounds
 
 
@@ -395,13 +395,23 @@ def main():
 
             if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
                 os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: do not make gloo resolve the container's host name
-            tdist.init_process_group(backend="gloo", rank=rank, world_size=world)
-            if rank == 0:  # rank 0 binds its listening socket NOW and keeps it: nobody can take the port in between
-                listener, lport = bound_listener(os.environ.get("MASTER_ADDR", "127.0.0.1"))
-            box = [lport if rank == 0 else None]
-            tdist.broadcast_object_list(box, src=0)
-            tdist.barrier()
-            tdist.destroy_process_group()
+            # gloo prints "[Gloo] Rank 0 is connected to ..." on STDOUT: this process's stdout carries ONE JSON line and nothing else, so
+            # file descriptor 1 points at stderr while the launcher's group is up
+            sys.stdout.flush()
+            saved_fd = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                tdist.init_process_group(backend="gloo", rank=rank, world_size=world)
+                if rank == 0:  # rank 0 binds its listening socket NOW and keeps it: nobody can take the port in between
+                    listener, lport = bound_listener(os.environ.get("MASTER_ADDR", "127.0.0.1"))
+                box = [lport if rank == 0 else None]
+                tdist.broadcast_object_list(box, src=0)
+                tdist.barrier()
+                tdist.destroy_process_group()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved_fd, 1)
+                os.close(saved_fd)
             port = box[0]
         dist = TcpGroup(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), int(port), listener=listener)
 
