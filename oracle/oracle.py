@@ -540,7 +540,8 @@ def block_gain_apply(img, gain_map):
         g = g[:, :, None]
     if g.shape[:2] != img.shape[:2]:  # cv::resize works per channel (BlocksChannelsCompensator: CV_32FC3 maps)
         g = np.stack([resize_linear_f32(g[:, :, c], (img.shape[1], img.shape[0])) for c in range(g.shape[2])], axis=2)
-    v = (img.astype(np.float32) * g).astype(np.float32)
+    with np.errstate(invalid="ignore", over="ignore"):  # NaN / infinite gains are legal inputs here (they saturate to 0 below)
+        v = (img.astype(np.float32) * g).astype(np.float32)
     # saturate_cast<uchar>(float) = saturate_cast<uchar>(cvRound(v)); cvRound is cvtss2si on x86-64: INT_MIN for NaN and for products
     # outside the int range, which then saturates to 0 (not 255) — the device kernels restate exactly this
     with np.errstate(invalid="ignore"):

@@ -179,3 +179,43 @@ def test_random_crop_to_masks_bit_exact(oracle, gpu_ctx, seed):
     tag = dict(wtype=wtype, n=n, w=w, h=h, strength=strength, scale=scale, crop=job.last_crop)
     assert np.array_equal(np.asarray(mask), omask), tag
     assert np.array_equal(np.asarray(pano), opano), (tag, int(np.count_nonzero(np.asarray(pano) != opano)))
+
+
+@pytest.mark.parametrize("seed", list(range(12 + EXTRA)))
+def test_random_gains_in_the_warp_epilogue_bit_exact(oracle, gpu_ctx, seed):
+    """stx_warp_batch_gain on geometries nobody hand-picked: random sizes (odd ones included: edge tiles of the epilogue), cameras from
+    level to steeply pitched, random block-gain maps of random block sizes, whole ROIs and random rectangles of them, both remap models —
+    always the oracle's warp followed by the oracle's block_gain_apply."""
+    rng = np.random.default_rng(7000 + seed)
+    c = _random_case(3000 + seed, pitched=seed % 3 == 2)
+    wtype = c["wtype"] if c["wtype"] in ("spherical", "cylindrical", "plane", "mercator") else "spherical"
+    imgs, cams = c["imgs"], c["cams"]
+    mode = "float" if seed % 4 == 3 else "q15"
+    prev_p, prev_o = S.set_remap_mode(mode), oracle.set_model(remap=mode)
+    try:
+        g, o = S.Warper(wtype), oracle.Warper(wtype)
+        g.set_scale(cams)
+        o.set_scale(cams)
+        sizes0 = [(im.shape[1], im.shape[0]) for im in imgs]
+        corners, sizes = o.warp_rois(sizes0, cams)
+        bs = int(rng.choice([16, 32, 64, 200]))
+        gmaps = [(0.5 + rng.random(((s[1] + bs - 1) // bs + 1, (s[0] + bs - 1) // bs + 1))).astype(np.float32) for s in sizes]
+        want = [oracle.block_gain_apply(o.warp_image(im, cam), gm) for im, cam, gm in zip(imgs, cams, gmaps)]
+        comp = S.ExposureErrorCompensator("gain_blocks")
+        comp.set_gains(gmaps)
+        gi, gm_, rois = g.warp_images_and_masks(imgs, cams, compensator=comp)
+        tag = dict(seed=seed, wtype=wtype, mode=mode, w=c["w"], h=c["h"], bs=bs)
+        for k in range(len(cams)):
+            assert tuple(rois[k]) == tuple(corners[k]) + tuple(sizes[k]), tag
+            assert np.array_equal(np.asarray(gi[k]), want[k]), (tag, k, int(np.count_nonzero(np.asarray(gi[k]) != want[k])))
+        rects = []
+        for (cx, cy), (w, h) in zip(corners, sizes):
+            x0, y0 = int(rng.integers(0, max(1, w // 2))), int(rng.integers(0, max(1, h // 2)))
+            rects.append((cx + x0, cy + y0, int(rng.integers(1, w - x0 + 1)), int(rng.integers(1, h - y0 + 1))))
+        ri, _, _ = g.warp_images_and_masks(imgs, cams, rects=rects, compensator=comp)
+        for k, (x, y, rw, rh) in enumerate(rects):
+            x0, y0 = x - corners[k][0], y - corners[k][1]
+            assert np.array_equal(np.asarray(ri[k]), want[k][y0:y0 + rh, x0:x0 + rw]), (tag, "rect", k, rects[k])
+    finally:
+        S.set_remap_mode(prev_p)
+        oracle.set_model(**prev_o)
