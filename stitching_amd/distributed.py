@@ -464,7 +464,7 @@ class ShardedStitchJob:
 
     def __init__(self, frames, cameras, all_cameras, rank, world, all_sizes=None, warper_type="spherical",
                  blender_type="multiband", num_bands=5, blend_strength=None, ctx=None, group=None, transport=None,
-                 split_boundary=True, exchange="strips", mask_bits=True, balance=None, dist=None):
+                 split_boundary=True, exchange="strips", mask_bits=True, balance=None, dist=None, compensator=None):
         """blender_type / blend_strength: as stitching.blender.Blender (stitching/blender.py:5-38); for "multiband" `num_bands` sets the
         band count when blend_strength is None (the benchmark's way of naming a configuration).
         split_boundary (multiband): warp / feed the images that owe strips to other ranks first and the rest while the strips
@@ -475,7 +475,10 @@ class ShardedStitchJob:
         balance: ShardPlan's band-edge rule, "links" (default) or "midway".
         group: the control plane (stitching_amd.rendezvous.TcpGroup or an object with its interface; `dist` is the old name of the
         argument): transport negotiation, the plan check of plan(), gather().  A job that is handed a transport and never gathers
-        needs none."""
+        needs none.
+        compensator: an ExposureErrorCompensator whose gains are indexed by the GLOBAL image order (every rank holds the same one, as
+        every rank holds all cameras): applied to this rank's warped images between warp and feed (stitching/stitcher.py:123) — the strips
+        a rank sends are strips of compensated images, so the assembled panorama equals the single-GPU one."""
         if blender_type not in Blender.BLENDER_CHOICES:
             raise StitchingError(f"unknown blender type {blender_type!r}")
         if blender_type != "multiband" and exchange != "strips":
@@ -496,6 +499,8 @@ class ShardedStitchJob:
         self.warper = Warper(warper_type, ctx=self.ctx)
         self.warper.set_scale(self.all_cameras)
         self.num_bands_req, self.blend_strength = num_bands, blend_strength
+        self.compensator = compensator
+        self._local_comp = {}
         self.dist = group if group is not None else dist  # `dist`: the older name of the same argument
         if self.dist is not None:
             missing = [m for m in ("all_gather", "gather", "broadcast", "barrier", "all_reduce_min", "exchange_bytes") if not hasattr(self.dist, m)]
@@ -559,9 +564,16 @@ class ShardedStitchJob:
         import hashlib
 
         p = self.plan_
+        comp = None
+        if self.compensator is not None and self.compensator.compensator_type != "no" and self.compensator.gains is not None:
+            # a rank with other gains would not hang anybody, it would quietly blend other bytes: the gains belong to the agreement
+            h = hashlib.sha256()
+            for g in self.compensator.gains:
+                h.update(np.ascontiguousarray(g).tobytes())
+            comp = (self.compensator.compensator_type, h.hexdigest())
         state = (p.kind, p.exchange, p.mask_bits, p.halo, p.num_bands, p.balance, list(p.edges), [tuple(m) for m in p.messages],
                  list(p.corners), list(p.sizes), config.trig_mode(), config.remap_mode(), tuple(config.pyrdown_mode()),
-                 float(self.blend_strength), float(getattr(self, "sharpness", 0.0)))
+                 float(self.blend_strength), float(getattr(self, "sharpness", 0.0)), comp)
         return hashlib.sha256(repr(state).encode()).hexdigest()
 
     def _check_plan_agreement(self, refusal=None):
@@ -643,7 +655,7 @@ class ShardedStitchJob:
     def _run_flat(self, p):
         """feather / "no": warp everything, send every other band its columns (+ halo), feed this band's blender its own columns and the
         received strips in global feed order, blend, crop the halo off."""
-        imgs, masks, rois = self.warper.warp_images_and_masks(self.frames, self.cameras)
+        imgs, masks, rois = self.warper.warp_images_and_masks(self.frames, self.cameras, compensator=self._compensator_for(self.my_orders))
         warped = {}
         for k, img, mask, roi in zip(self.my_orders, imgs, masks, rois):
             if roi[0:2] != p.corners[k]:
@@ -672,6 +684,22 @@ class ShardedStitchJob:
         pano, mask = blender.blend()
         return pano[:, c0:c1], mask[:, c0:c1]
 
+    def _compensator_for(self, orders):
+        """the job's compensator restricted to the images `orders` (global indices), in that order; None without one"""
+        if self.compensator is None or self.compensator.compensator_type == "no":
+            return None
+        key = tuple(orders)
+        c = self._local_comp.get(key)
+        if c is None:
+            from .exposure_error_compensator import ExposureErrorCompensator
+
+            if self.compensator.gains is None:
+                raise StitchingError("ExposureErrorCompensator.set_gains(gains) must be called before a sharded job runs")
+            c = ExposureErrorCompensator(self.compensator.compensator_type, estimator=object())
+            c.set_gains([self.compensator.gains[k] for k in orders])
+            self._local_comp[key] = c
+        return c
+
     def _warp_and_feed(self, blender, orders, p):
         """-> {order: (warped image, mask)} of the images fed"""
         if not orders:
@@ -679,7 +707,7 @@ class ShardedStitchJob:
         local = {k: i for i, k in enumerate(self.my_orders)}
         frames = [self.frames[local[k]] for k in orders]
         cams = [self.cameras[local[k]] for k in orders]
-        imgs, masks, rois = self.warper.warp_images_and_masks(frames, cams)
+        imgs, masks, rois = self.warper.warp_images_and_masks(frames, cams, compensator=self._compensator_for(orders))
         for k, img, mask, roi in zip(orders, imgs, masks, rois):
             if roi[0:2] != p.corners[k]:
                 raise StitchingError("warp roi changed between plan() and run()")

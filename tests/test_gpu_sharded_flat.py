@@ -105,3 +105,45 @@ def test_bands_balanced_for_the_links_equal_oracle(oracle, gpu_ctx):
                                                               balance="links")
     assert jobs[0].plan_.balance == "links"
     assert np.array_equal(mask, of["pmask"]) and np.array_equal(pano, of["pano"])
+
+
+@pytest.mark.parametrize("btype,kind", [("multiband", "gain_blocks"), ("multiband", "gain"), ("feather", "gain_blocks")])
+def test_sharded_job_with_a_compensator_equals_oracle(oracle, gpu_ctx, btype, kind):
+    """The reference's default composition across ranks: every rank applies the exposure gains of ITS images (global indices) between
+    warp and feed — in the warp's epilogue for the block gains — and ships strips of the compensated images; the assembled bands equal the
+    oracle's warp -> gain -> blend chain on all frames (3 ranks x 2 frames, every rank executed on this GPU, strips recorded / replayed)."""
+    import stitching_amd as S
+    from stitching_amd import synthetic
+    from tests import helpers
+
+    w, h, world, per = 803, 601, 3, 2
+    cams = synthetic.ring_cameras(world * per, w, h, span_deg=200.0)
+    frames = [synthetic.make_frame(50 + i, w, h) for i in range(world * per)]
+    ow = oracle.Warper("spherical")
+    ow.set_scale(cams)
+    corners, sizes = ow.warp_rois([(w, h)] * len(cams), cams)
+    rng = np.random.default_rng(9)
+    if kind == "gain_blocks":
+        gains = [(0.8 + 0.4 * rng.random(((s[1] + 31) // 32, (s[0] + 31) // 32))).astype(np.float32) for s in sizes]
+        apply = oracle.block_gain_apply
+    else:
+        gains = [float(g) for g in 0.85 + 0.3 * rng.random(len(cams))]
+        apply = oracle.gain_apply
+    strength = 6 if btype == "multiband" else 4
+    ob = oracle.Blender(btype, strength)
+    ob.prepare(corners, sizes)
+    for f, c, g, corner in zip(frames, cams, gains, corners):
+        ob.feed(apply(ow.warp_image(f, c), g), ow.create_and_warp_mask((w, h), c), corner)
+    o_pano, o_mask = (np.asarray(a) for a in ob.blend())
+    comp = S.ExposureErrorCompensator(kind)
+    comp.set_gains(gains)
+    pano, mask, jobs = helpers.run_sharded_job_in_one_process(gpu_ctx, frames, cams, world, per, blender_type=btype, blend_strength=strength,
+                                                              num_bands=None, compensator=comp)
+    assert pano.shape == o_pano.shape
+    assert np.array_equal(mask, o_mask) and np.array_equal(pano, o_pano), int(np.count_nonzero(pano != o_pano))
+    # the gains are part of what the ranks agree on
+    other = S.ExposureErrorCompensator(kind)
+    other.set_gains([g * 1.01 if kind == "gain" else g + np.float32(0.01) for g in gains])
+    d0 = jobs[0].plan_digest()
+    jobs[0].compensator = other
+    assert jobs[0].plan_digest() != d0
