@@ -464,7 +464,7 @@ class ShardedStitchJob:
 
     def __init__(self, frames, cameras, all_cameras, rank, world, all_sizes=None, warper_type="spherical",
                  blender_type="multiband", num_bands=5, blend_strength=None, ctx=None, group=None, transport=None,
-                 split_boundary=True, exchange="strips", mask_bits=True, balance=None, dist=None, compensator=None):
+                 split_boundary=True, exchange="strips", mask_bits=True, balance=None, dist=None, compensator=None, seam_masks=None):
         """blender_type / blend_strength: as stitching.blender.Blender (stitching/blender.py:5-38); for "multiband" `num_bands` sets the
         band count when blend_strength is None (the benchmark's way of naming a configuration).
         split_boundary (multiband): warp / feed the images that owe strips to other ranks first and the rest while the strips
@@ -478,7 +478,10 @@ class ShardedStitchJob:
         needs none.
         compensator: an ExposureErrorCompensator whose gains are indexed by the GLOBAL image order (every rank holds the same one, as
         every rank holds all cameras): applied to this rank's warped images between warp and feed (stitching/stitcher.py:123) — the strips
-        a rank sends are strips of compensated images, so the assembled panorama equals the single-GPU one."""
+        a rank sends are strips of compensated images, so the assembled panorama equals the single-GPU one.
+        seam_masks: LOW-resolution seam masks by global image order (every rank holds all of them: a few KB each), resized on the device to
+        each warped mask and ANDed with it (SeamFinder.resize, stitching/stitcher.py:124) before the image is fed or its strips are cut —
+        the masks are then grey along the seams and travel as bytes."""
         if blender_type not in Blender.BLENDER_CHOICES:
             raise StitchingError(f"unknown blender type {blender_type!r}")
         if blender_type != "multiband" and exchange != "strips":
@@ -501,6 +504,8 @@ class ShardedStitchJob:
         self.num_bands_req, self.blend_strength = num_bands, blend_strength
         self.compensator = compensator
         self._local_comp = {}
+        self.seam_masks = None if seam_masks is None else list(seam_masks)
+        self._seam_dev = {}
         self.dist = group if group is not None else dist  # `dist`: the older name of the same argument
         if self.dist is not None:
             missing = [m for m in ("all_gather", "gather", "broadcast", "barrier", "all_reduce_min", "exchange_bytes") if not hasattr(self.dist, m)]
@@ -510,7 +515,9 @@ class ShardedStitchJob:
         self.transport = transport
         self.split_boundary = bool(split_boundary)
         self.exchange = exchange
-        self.mask_bits = bool(mask_bits)  # every mask of this job is a warped mask (0 / 255): they may travel as bits
+        # the masks of a job without seam masks are warped masks (0 / 255): they may travel as bits; resized seam masks are grey
+        self.mask_bits = bool(mask_bits) and seam_masks is None
+        self._bin_flag = _lib.CONTRIB_U8_BINARY if seam_masks is None else 0
         # ShardPlan(balance=...): where the band edges go; None -> STITCHING_AMD_BALANCE, else "links".  Measured on one MI355X playing
         # single ranks of the 8-rank config-3 job (tools/sim_rank.py, gpurun r3o): rank 3 0.834 -> 0.874 ms per step, rank 0 0.776 ->
         # 0.680, rank 1 0.723 -> 0.730, while the job's busiest link goes from 96.5 to 77.8 MB per panorama
@@ -571,6 +578,12 @@ class ShardedStitchJob:
             for g in self.compensator.gains:
                 h.update(np.ascontiguousarray(g).tobytes())
             comp = (self.compensator.compensator_type, h.hexdigest())
+        if self.seam_masks is not None:
+            h = hashlib.sha256()
+            for m in self.seam_masks:
+                a = np.ascontiguousarray(np.asarray(m.get() if hasattr(m, "get") else m))
+                h.update(repr(a.shape).encode() + a.tobytes())
+            comp = (comp, "seams", h.hexdigest())
         state = (p.kind, p.exchange, p.mask_bits, p.halo, p.num_bands, p.balance, list(p.edges), [tuple(m) for m in p.messages],
                  list(p.corners), list(p.sizes), config.trig_mode(), config.remap_mode(), tuple(config.pyrdown_mode()),
                  float(self.blend_strength), float(getattr(self, "sharpness", 0.0)), comp)
@@ -643,10 +656,10 @@ class ShardedStitchJob:
             # every strip of this job comes from a u8 warp with a 0 / 255 mask (warp_images_and_masks on all ranks)
             if p.exchange == "strips":
                 blender.feed_strips([(buf, m[3][2], m[3][3], (p.corners[m[0]][0] + m[3][0], p.corners[m[0]][1]), m[0])
-                                     for m, buf in zip(recv_msgs, rbufs)], _lib.CONTRIB_U8_BINARY | p.strip_flags)
+                                     for m, buf in zip(recv_msgs, rbufs)], self._bin_flag | p.strip_flags)
             else:
                 for m, buf in zip(recv_msgs, rbufs):
-                    blender.feed_contrib(m[0], m[3], buf, _lib.CONTRIB_U8_BINARY)
+                    blender.feed_contrib(m[0], m[3], buf, self._bin_flag)
             pano, mask = blender.blend()
         finally:
             config.set_device_resident(prev)
@@ -656,6 +669,7 @@ class ShardedStitchJob:
         """feather / "no": warp everything, send every other band its columns (+ halo), feed this band's blender its own columns and the
         received strips in global feed order, blend, crop the halo off."""
         imgs, masks, rois = self.warper.warp_images_and_masks(self.frames, self.cameras, compensator=self._compensator_for(self.my_orders))
+        masks = self._seam_resized(self.my_orders, masks)
         warped = {}
         for k, img, mask, roi in zip(self.my_orders, imgs, masks, rois):
             if roi[0:2] != p.corners[k]:
@@ -676,7 +690,7 @@ class ShardedStitchJob:
                 items.append((k, img if whole else img[:, x0:x1], mask if whole else mask[:, x0:x1], (p.corners[k][0] + x0, p.corners[k][1])))
         rbufs = self.transport.finish(self.ctx)
         for m, buf in zip(recv_msgs, rbufs):
-            simg, smask = strip_unpack(buf, m[3][2], m[3][3], _lib.CONTRIB_U8_BINARY | p.strip_flags)
+            simg, smask = strip_unpack(buf, m[3][2], m[3][3], self._bin_flag | p.strip_flags)
             items.append((m[0], simg, smask, (p.corners[m[0]][0] + m[3][0], p.corners[m[0]][1])))
         # the plain blender overwrites and the feather blender adds fp32 weights: both in the order of the reference's feed loop
         for k, img, mask, corner in sorted(items, key=lambda it: it[0]):
@@ -700,6 +714,19 @@ class ShardedStitchJob:
             self._local_comp[key] = c
         return c
 
+    def _seam_resized(self, orders, masks):
+        """SeamFinder.resize of the low-resolution seam masks of the images `orders` onto their warped masks (one batched launch); the
+        warped masks themselves without seam masks"""
+        if self.seam_masks is None:
+            return masks
+        from .seam_finder import SeamFinder
+
+        for k in orders:
+            if k not in self._seam_dev:
+                m = self.seam_masks[k]
+                self._seam_dev[k] = as_device(m if isinstance(m, DeviceImage) else np.asarray(m.get() if hasattr(m, "get") else m), self.ctx)
+        return SeamFinder.resize_all([self._seam_dev[k] for k in orders], masks)
+
     def _warp_and_feed(self, blender, orders, p):
         """-> {order: (warped image, mask)} of the images fed"""
         if not orders:
@@ -708,6 +735,7 @@ class ShardedStitchJob:
         frames = [self.frames[local[k]] for k in orders]
         cams = [self.cameras[local[k]] for k in orders]
         imgs, masks, rois = self.warper.warp_images_and_masks(frames, cams, compensator=self._compensator_for(orders))
+        masks = self._seam_resized(orders, masks)
         for k, img, mask, roi in zip(orders, imgs, masks, rois):
             if roi[0:2] != p.corners[k]:
                 raise StitchingError("warp roi changed between plan() and run()")

@@ -147,3 +147,33 @@ def test_sharded_job_with_a_compensator_equals_oracle(oracle, gpu_ctx, btype, ki
     d0 = jobs[0].plan_digest()
     jobs[0].compensator = other
     assert jobs[0].plan_digest() != d0
+
+
+@pytest.mark.parametrize("btype", ["multiband", "feather", "no"])
+def test_sharded_default_composition_equals_oracle(oracle, gpu_ctx, btype):
+    """stitching/stitcher.py:117-128 across ranks: gain_blocks compensator + low-resolution seam masks resized per panorama + blend, 3
+    ranks x 2 frames.  The masks are grey along the seams (INTER_LINEAR_EXACT), so strips carry them as bytes; each rank resizes the seam
+    masks of its own images only.  Assembled bands == the oracle's warp -> block_gain_apply -> seam_resize -> blend on all frames."""
+    w, h, world, per = 803, 601, 3, 2
+    cams = synthetic.ring_cameras(world * per, w, h, span_deg=200.0)
+    frames = [synthetic.make_frame(70 + i, w, h) for i in range(world * per)]
+    ow = oracle.Warper("spherical")
+    ow.set_scale(cams)
+    corners, sizes = ow.warp_rois([(w, h)] * len(cams), cams)
+    wm = [ow.create_and_warp_mask((w, h), c) for c in cams]
+    low = [np.ascontiguousarray(m[::7, ::7]) for m in synthetic.voronoi_seam_masks(wm, corners, sizes)]
+    rng = np.random.default_rng(19)
+    gains = [(0.8 + 0.4 * rng.random(((s[1] + 31) // 32, (s[0] + 31) // 32))).astype(np.float32) for s in sizes]
+    strength = 6 if btype == "multiband" else 4
+    ob = oracle.Blender(btype, strength)
+    ob.prepare(corners, sizes)
+    for f, c, g, l, m, corner in zip(frames, cams, gains, low, wm, corners):
+        ob.feed(oracle.block_gain_apply(ow.warp_image(f, c), g), oracle.seam_resize(l, m), corner)
+    o_pano, o_mask = (np.asarray(a) for a in ob.blend())
+    comp = S.ExposureErrorCompensator("gain_blocks")
+    comp.set_gains(gains)
+    pano, mask, jobs = helpers.run_sharded_job_in_one_process(gpu_ctx, frames, cams, world, per, blender_type=btype, blend_strength=strength,
+                                                              num_bands=None, compensator=comp, seam_masks=low)
+    assert not jobs[0].plan_.mask_bits  # grey masks travel as bytes
+    assert pano.shape == o_pano.shape
+    assert np.array_equal(mask, o_mask) and np.array_equal(pano, o_pano), int(np.count_nonzero(pano != o_pano))
