@@ -211,6 +211,14 @@ int stx_warp_batch_rects(stx_ctx* ctx, int type, float scale, int n, const float
 int stx_warp_batch_gain(stx_ctx* ctx, int type, float scale, int n, const float* K9s, const float* R9s, const stx_buf* const* srcs,
                         const int* rects_xywh, const stx_buf* const* gain_maps_f32, const int* gain_flags, stx_buf** out_imgs,
                         stx_buf** out_masks, int* out_xywh);
+/* One panorama's warps, its ROI pass included: stitching/stitcher.py:188 (warp_rois) + :119-123 in ONE call.  The ROIs are computed by this
+ * call (never taken from the cache of earlier calls: a panorama pays for its own ROI pass) and returned in out_xywh; the host waits for them
+ * once, inside the call, by polling stamps the ROI kernel writes into pinned memory, and launches the warps right behind — the device idles
+ * for ~25 us at the head of a panorama instead of the ~145 us of stx_warp_rois + Python + stx_warp_batch (profiles/r05_latency.md).
+ * gain_maps / gain_flags: as in stx_warp_batch_gain, or NULL.  Results equal stx_warp_rois + stx_warp_batch[_gain] byte for byte. */
+int stx_warp_batch_with_rois(stx_ctx* ctx, int type, float scale, int n, const float* K9s, const float* R9s, const stx_buf* const* srcs,
+                             const stx_buf* const* gain_maps_f32_or_null, const int* gain_flags_or_null, stx_buf** out_imgs,
+                             stx_buf** out_masks, int* out_xywh);
 /* stitching/warper.py:58-68 without allocating the 255-filled source (size only) */
 int stx_warp_mask(stx_ctx* ctx, int type, float scale, const float K[9], const float R[9], int w, int h,
                   stx_buf** out_mask, int out_xywh[4]);

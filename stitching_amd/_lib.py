@@ -34,7 +34,7 @@ STRIP_MASK_BITS = 2
 EXPORTS = (
     "stx_version stx_last_error stx_set_trig_mode stx_get_trig_mode stx_set_remap_mode stx_get_remap_mode stx_set_pyrdown_mode stx_get_pyrdown_mode stx_device_count stx_ctx_create stx_ctx_destroy stx_ctx_sync "
     "stx_host_alloc stx_host_free stx_buf_from_host stx_buf_from_host_async stx_buf_alloc stx_buf_to_host stx_buf_to_host_async stx_buf_view stx_buf_info stx_buf_device_ptr stx_buf_free "
-    "stx_warp_roi stx_warp_rois stx_warp stx_warp_image_and_mask stx_warp_batch stx_warp_batch_rects stx_warp_batch_gain stx_warp_mask "
+    "stx_warp_roi stx_warp_rois stx_warp stx_warp_image_and_mask stx_warp_batch stx_warp_batch_rects stx_warp_batch_gain stx_warp_batch_with_rois stx_warp_mask "
     "stx_gain_apply stx_block_gain_apply stx_block_gain_apply_batch stx_resize_linear_exact stx_seam_mask_resize stx_seam_mask_resize_batch stx_seam_mask_resize_batch_sub stx_timelapse_frame stx_result_roi stx_blend_create stx_blend_num_bands stx_blend_feed stx_blend_finish stx_blend_finish_ex "
     "stx_blend_destroy stx_blend_set_band stx_blend_feed_ex stx_blend_contrib_rect stx_blend_export_contrib stx_blend_export_contribs "
     "stx_blend_build stx_blend_feed_contrib stx_blend_feed_contrib_ex stx_buf_flags stx_strip_rect stx_view_rect stx_strip_pack stx_strip_pack_batch stx_strip_pack_batch_ex stx_strip_bytes stx_strip_unpack stx_blend_feed_strips stx_comm_unique_id stx_comm_create stx_comm_exchange stx_comm_exchange_begin stx_comm_exchange_end stx_comm_exchange_begin_on stx_comm_exchange_end_on stx_comm_info stx_comm_destroy stx_prof_enable stx_prof_reset stx_prof_count stx_prof_get stx_mark stx_mark_elapsed_ms "
@@ -90,6 +90,7 @@ def lib():
     L.stx_warp_batch.argtypes = [vp, C.c_int, C.c_float, C.c_int, fp, fp, vpp, vpp, vpp, ip]
     L.stx_warp_batch_rects.argtypes = [vp, C.c_int, C.c_float, C.c_int, fp, fp, vpp, ip, vpp, vpp]
     L.stx_warp_batch_gain.argtypes = [vp, C.c_int, C.c_float, C.c_int, fp, fp, vpp, ip, vpp, ip, vpp, vpp, ip]
+    L.stx_warp_batch_with_rois.argtypes = [vp, C.c_int, C.c_float, C.c_int, fp, fp, vpp, vpp, ip, vpp, vpp, ip]
     L.stx_warp_mask.argtypes = [vp, C.c_int, C.c_float, fp, fp, C.c_int, C.c_int, vpp, ip]
     L.stx_gain_apply.argtypes = [vp, vp, fp]
     L.stx_block_gain_apply.argtypes = [vp, vp, vp]

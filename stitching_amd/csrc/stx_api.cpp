@@ -80,7 +80,8 @@ STX_EXPORT int stx_ctx_create(int device, stx_ctx** out)
     ctx->pinned_bytes = 1 << 16;
     ctx->stage_bytes = 1 << 20;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocCoherent | hipHostMallocMapped);  // kernels write ROI results into it
+    if (e == hipSuccess) memset(ctx->pinned, 0, ctx->pinned_bytes);
     if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->stage, ctx->stage_bytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(&ctx->aux_scratch, ctx->pinned_bytes);
@@ -1238,7 +1239,7 @@ STX_EXPORT int stx_warp(stx_ctx* ctx, int type, float scale, const float K[9], c
 // coordinates (any sub-rectangle of the ROI gives exactly the ROI warp's pixels there: every pixel is mapped on its own)
 static int warp_batch_impl(stx_ctx* ctx, int type, float scale, int n, const float* K9s, const float* R9s,
                            const stx_buf* const* srcs, const int* rects, stx_buf** out_imgs, stx_buf** out_masks, int* out_xywh,
-                           const stx_buf* const* gains = nullptr, const int* gflags = nullptr)
+                           const stx_buf* const* gains = nullptr, const int* gflags = nullptr, bool fresh_rois = false)
 {
     if (!ctx || !K9s || !R9s || !srcs || n < 0) return stx_fail(STX_ERR_INVALID, "bad argument");
     if (!out_imgs && !out_masks) return stx_fail(STX_ERR_INVALID, "nothing requested");
@@ -1260,6 +1261,7 @@ static int warp_batch_impl(stx_ctx* ctx, int type, float scale, int n, const flo
     // with gains the ROI of every image is needed even under caller-given rectangles: the gain map lies over the WHOLE warped image
     const bool need_rois = !rects || gains;
     for (int i = 0; i < n && need_rois; i++) {
+        if (fresh_rois) { miss.push_back(i); continue; }  // the ROI pass belongs to this call (stx_warp_batch_with_rois)
         auto it = g_roi_cache->find(make_key(type, scale, K9s + 9 * i, R9s + 9 * i, sizes[2 * i], sizes[2 * i + 1]));
         if (it != g_roi_cache->end()) memcpy(&rois[4 * i], it->second.data(), 16);
         else miss.push_back(i);
@@ -1385,6 +1387,15 @@ STX_EXPORT int stx_warp_batch_gain(stx_ctx* ctx, int type, float scale, int n, c
                            gain_maps, gain_flags);
 }
 
+STX_EXPORT int stx_warp_batch_with_rois(stx_ctx* ctx, int type, float scale, int n, const float* K9s, const float* R9s,
+                                        const stx_buf* const* srcs, const stx_buf* const* gain_maps_or_null, const int* gain_flags_or_null,
+                                        stx_buf** out_imgs, stx_buf** out_masks, int* out_xywh)
+{
+    if (!out_xywh) return stx_fail(STX_ERR_INVALID, "null argument");
+    if (gain_maps_or_null && !out_imgs) return stx_fail(STX_ERR_INVALID, "gains without images");
+    return warp_batch_impl(ctx, type, scale, n, K9s, R9s, srcs, nullptr, out_imgs, out_masks, out_xywh, gain_maps_or_null, gain_flags_or_null, true);
+}
+
 STX_EXPORT int stx_warp_image_and_mask(stx_ctx* ctx, int type, float scale, const float K[9], const float R[9],
                                        const stx_buf* src, stx_buf** out_img, stx_buf** out_mask, int out_xywh[4])
 {
@@ -1473,6 +1484,7 @@ struct stx_blender {
     std::vector<char> built;          // pyramid of images[i] exists (kind 0)
     std::vector<stx_buf*> held;
     std::vector<void*> pyr_allocs;
+    StxMbImage* d_all = nullptr;      // device copy of `images` as the pyramid pass uploaded it, while it still equals `images` (else null)
     int band_x0 = 0, band_x1 = 0;     // columns of the final roi this blender produces (sharded blending)
     int next_order = 0;
     int pyr_mode = 0;                 // STX_PYRDOWN_* | lanes << 8, captured at stx_blend_create: one summation order per panorama
@@ -1489,6 +1501,7 @@ static void blender_release(stx_blender* b)
     b->held.clear();
     for (void* p : b->pyr_allocs) stx_dev_free(b->ctx, p);
     b->pyr_allocs.clear();
+    b->d_all = nullptr;
     b->images.clear();
     b->built.clear();
     b->no_images.clear();
@@ -1619,6 +1632,7 @@ static void mb_insert_sorted(stx_blender* b, const StxMbImage& im, bool is_built
     while (pos > 0 && b->images[pos - 1].order > im.order) pos--;
     b->images.insert(b->images.begin() + pos, im);
     b->built.insert(b->built.begin() + pos, is_built ? 1 : 0);
+    b->d_all = nullptr;
 }
 
 static int mb_feed(stx_blender* b, const stx_buf* img, const stx_buf* mask, int tlx, int tly, int order)
@@ -1710,6 +1724,9 @@ static int mb_ensure_pyramids(stx_blender* b)
     }
     StxMbImage* d = nullptr;
     STX_TRY(mb_upload(b, todo.data(), (int)todo.size(), &d));
+    // every image of the blender in this pass (the usual case): blend() reads the very same table — one upload, one copy dispatch fewer
+    // between the pyramids and the collapse
+    b->d_all = todo.size() == b->images.size() && memcmp(todo.data(), b->images.data(), sizeof(StxMbImage) * todo.size()) == 0 ? d : nullptr;
     STX_TRY(stx_launch_mb_pyramids(b->ctx, d, todo.data(), (int)todo.size(), b->num_bands, pyr & 255, pyr >> 8));
     for (size_t i = 0; i < b->images.size(); i++) b->built[i] = 1;
     return STX_OK;
@@ -1820,8 +1837,8 @@ static int mb_finish(stx_blender* b, stx_buf* pano, stx_buf* pmask, stx_buf* pan
     stx_ctx* ctx = b->ctx;
     const int nb = b->num_bands, n = (int)b->images.size();
     STX_TRY(mb_ensure_pyramids(b));
-    StxMbImage* d_images = nullptr;
-    STX_TRY(mb_upload(b, b->images.data(), n, &d_images));
+    StxMbImage* d_images = b->d_all;
+    if (!d_images) STX_TRY(mb_upload(b, b->images.data(), n, &d_images));
     bool all_u8 = true, has_contrib = false, pk_ok = true;
     for (const StxMbImage& im : b->images) {
         if (im.kind == 0 && im.img0_is_s16) all_u8 = false;

@@ -68,6 +68,7 @@ struct stx_ctx {
     // pinned scratch for small device->host results (ROI min/max)
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
+    uint32_t roi_seq = 0;  // sequence number of the last ROI pass (the stamp its blocks write behind their results)
     // pinned ring for small host->device uploads (descriptor tables): truly asynchronous copies.  The ring is cut into
     // STX_STAGE_SEGS segments; leaving a segment records an event behind its last copy, entering one waits for the event of
     // its previous lap (recorded three segments of uploads ago: normally long complete) — not for the whole stream, which

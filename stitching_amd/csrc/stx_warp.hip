@@ -12,6 +12,7 @@
 // only and sin/cos(pi - v) on the row only, so a 256x16 tile needs 4 sincos per thread (kept in
 // registers) + 16 per block (LDS) instead of 4 per pixel.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -1107,10 +1108,11 @@ STX_DEV uint32_t f2ord(float f)
 }
 
 constexpr int ROI_BATCH = 16;
+constexpr int ROI_SPIN_US = 1000;  // host polling of the ROI stamps before it blocks
 struct RoiBatchK { RoiK k[ROI_BATCH]; };
 
 template <bool GEN>  // GEN: the per-pixel projector families (every source pixel), else cylindrical / spherical borders
-__global__ __launch_bounds__(256) void roi_kernel(RoiBatchK B, float* __restrict__ out)
+__global__ __launch_bounds__(256) void roi_kernel(RoiBatchK B, float* __restrict__ out, uint32_t* __restrict__ stamps, uint32_t seq)
 {
     const RoiK& P = B.k[blockIdx.y];
     const int npts = GEN ? P.w * P.h : 2 * P.w + 2 * P.h;
@@ -1167,8 +1169,11 @@ __global__ __launch_bounds__(256) void roi_kernel(RoiBatchK B, float* __restrict
             if (s_part[wv][2] > mxu) mxu = s_part[wv][2];
             if (s_part[wv][3] > mxv) mxv = s_part[wv][3];
         }
-        float* o = out + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        float* o = out + 4 * blk;
         o[0] = mnu; o[1] = mnv; o[2] = mxu; o[3] = mxv;
+        // `out` is pinned host memory: the block's stamp follows its result at system scope, the host reads stamps, then results
+        __hip_atomic_store(stamps + blk, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1406,16 +1411,26 @@ bool stx_warp_fast_eligible(const StxWarpLaunch& L)
 // out_minmax4[i] = {min u, min v, max u, max v} over the border of image i (cyl / spherical)
 int stx_launch_roi_minmax(stx_ctx* ctx, int n, const StxProjector* projs, const int* sizes_wh, float* out_minmax4)
 {
-    // Argument blocks travel as kernel arguments, per-block partial results come back through the context's
-    // pinned scratch: no pageable copies, no atomics.  The pass runs on the context's side stream with its own
-    // device scratch and only that stream is waited for, so work already queued on the main stream keeps going.
+    // Argument blocks travel as kernel arguments; the per-block partial results are written by the kernel STRAIGHT into the context's
+    // pinned host scratch, each followed by a stamp (this pass's sequence number, system-scope release).  The host polls the stamps:
+    // no copy dispatch, no interrupt-driven wait — the ROI pass is the one place where a panorama's latency waits for the host
+    // (82 us of idle device per panorama with copy + hipStreamSynchronize, profiles/r05_latency.md).  After ROI_SPIN_US without
+    // all stamps (device busy with queued work) the wait becomes hipStreamSynchronize, which also covers any failure.
+    // The pass runs on the context's side stream, so work already queued on the main stream keeps going.
     // blocks per image: 32 for the border walk, 256 when every source pixel is projected (one family per call)
     const bool full = n > 0 && projs[0].family > STX_F_SPHERICAL;
     const int BX = full ? 256 : 32;
-    const int cap = (int)(ctx->pinned_bytes / (16 * BX));
+    // results in the first three quarters of the scratch, stamps in the last one — the same split for both block counts, so a result
+    // of one pass can never be read as a stamp of another
+    const size_t stamp_off = ctx->pinned_bytes / 4 * 3;
+    const int cap = (int)(stamp_off / (16 * BX));
+    static const bool no_spin = getenv("STITCHING_AMD_ROI_NO_SPIN") != nullptr;  // diagnostic: A/B against the blocking wait
     for (int start = 0; start < n; start += cap) {
         const int cnt = std::min(cap, n - start);
-        float* dout = (float*)ctx->aux_scratch;
+        float* dout = (float*)ctx->pinned;
+        uint32_t* stamps = (uint32_t*)((uint8_t*)ctx->pinned + stamp_off);
+        uint32_t seq = ++ctx->roi_seq;
+        if (seq == 0) seq = ++ctx->roi_seq;  // 0 = "never written"
         for (int base = 0; base < cnt; base += ROI_BATCH) {
             const int m = std::min(ROI_BATCH, cnt - base);
             RoiBatchK B;
@@ -1435,12 +1450,24 @@ int stx_launch_roi_minmax(stx_ctx* ctx, int n, const StxProjector* projs, const 
             }
             // algorithmic bytes: the per-block partial results (nothing is read: the points come from the arguments)
             StxProfScope prof(ctx, "warp_roi", 16.0 * BX * m, ctx->aux_stream);
-            if (full) hipLaunchKernelGGL(roi_kernel<true>, dim3(BX, m), dim3(256), 0, ctx->aux_stream, B, dout + 4 * (size_t)BX * base);
-            else hipLaunchKernelGGL(roi_kernel<false>, dim3(BX, m), dim3(256), 0, ctx->aux_stream, B, dout + 4 * (size_t)BX * base);
+            if (full) hipLaunchKernelGGL(roi_kernel<true>, dim3(BX, m), dim3(256), 0, ctx->aux_stream, B, dout + 4 * (size_t)BX * base, stamps + (size_t)BX * base, seq);
+            else hipLaunchKernelGGL(roi_kernel<false>, dim3(BX, m), dim3(256), 0, ctx->aux_stream, B, dout + 4 * (size_t)BX * base, stamps + (size_t)BX * base, seq);
         }
+        STX_HIP(hipGetLastError());
         const float* res = (const float*)ctx->pinned;
-        STX_HIP(hipMemcpyAsync(ctx->pinned, dout, 16 * (size_t)BX * cnt, hipMemcpyDeviceToHost, ctx->aux_stream));
-        STX_HIP(hipStreamSynchronize(ctx->aux_stream));
+        bool seen = false;
+        if (!no_spin) {
+            const auto t0 = std::chrono::steady_clock::now();
+            const size_t nst = (size_t)BX * cnt;
+            size_t done = 0;  // stamps [0, done) have been seen
+            for (unsigned spins = 0;; spins++) {
+                while (done < nst && __atomic_load_n(stamps + done, __ATOMIC_ACQUIRE) == seq) done++;
+                if (done == nst) { seen = true; break; }
+                if ((spins & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(ROI_SPIN_US)) break;
+                __builtin_ia32_pause();
+            }
+        }
+        if (!seen) STX_HIP(hipStreamSynchronize(ctx->aux_stream));
         for (int i = 0; i < cnt; i++) {
             // NaN-ignoring fold in the comparison form of the device loop
             float mnu = 3.402823466e+38f, mnv = mnu, mxu = -mnu, mxv = -mnu;

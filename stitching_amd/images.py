@@ -88,7 +88,11 @@ def _decode(name):
 
 
 class Images:
-    """stitching/images.py:13-161 — construct with Images.of(list of numpy images or of file names, ...)."""
+    """stitching/images.py:13-161 — construct with Images.of(list of numpy images or of file names, ...).
+
+    One class for both kinds of input (the reference splits them into two private subclasses): `_items` holds the arrays or
+    the file names, `_dims[i]` the (width, height) of item i once it is known — at once for arrays, after the first decode
+    for files, which is also when the three megapixel scalers get their scale (from the FIRST image, as in the reference)."""
 
     class Resolution(Enum):
         MEDIUM = 0.6
@@ -99,58 +103,77 @@ class Images:
     def of(images, medium_megapix=Resolution.MEDIUM.value, low_megapix=Resolution.LOW.value, final_megapix=Resolution.FINAL.value):
         if not isinstance(images, list):
             raise StitchingError("images must be a list of images or filenames")
-        if len(images) == 0:
+        if not images:
             raise StitchingError("images must not be an empty list")
-        if Images.check_list_element_types(images, (np.ndarray, DeviceImage)):
-            return _ArrayImages(images, medium_megapix, low_megapix, final_megapix)
-        if Images.check_list_element_types(images, str):
-            return _FilenameImages(images, medium_megapix, low_megapix, final_megapix)
-        raise StitchingError("invalid images list: must be numpy arrays (loaded images) or filename strings")
+        loaded = Images.check_list_element_types(images, (np.ndarray, DeviceImage))
+        if not loaded and not Images.check_list_element_types(images, str):
+            raise StitchingError("invalid images list: must be numpy arrays (loaded images) or filename strings")
+        return (_NumpyImages if loaded else _FilenameImages)(images, medium_megapix, low_megapix, final_megapix, _from_files=not loaded)
 
-    def __init__(self, images, medium_megapix, low_megapix, final_megapix):
+    def __init__(self, images, medium_megapix, low_megapix, final_megapix, _from_files=False):
         if medium_megapix < low_megapix:
             raise StitchingError("Medium resolution megapix need to be greater or equal than low resolution megapix")
-        self._scalers = {"MEDIUM": MegapixDownscaler(medium_megapix), "LOW": MegapixDownscaler(low_megapix),
-                         "FINAL": MegapixDownscaler(final_megapix)}
-        self._scales_set = self._sizes_set = self._names_set = False
+        # keyed by the resolution's NAME: the reference's tests look at images._scalers["MEDIUM"]
+        self._scalers = {r.name: MegapixDownscaler(mp) for r, mp in zip(Images.Resolution, (medium_megapix, low_megapix, final_megapix))}
+        self._from_files = _from_files
+        self._items = Images.resolve_wildcards(images) if _from_files else list(images)
+        if len(self._items) < 2:
+            raise StitchingError("2 or more Images needed")
+        self._labels = list(self._items) if _from_files else [str(k) for k in range(1, len(self._items) + 1)]
+        self._dims = [None] * len(self._items)
+        if not _from_files:
+            for k, img in enumerate(self._items):
+                self._note_size(k, Images.get_image_size(img))
 
     # ---- the reference's properties / helpers
     @property
     def sizes(self):
-        assert self._sizes_set
-        return self._sizes
+        assert None not in self._dims, "file names: the sizes are known after the first pass over the images"
+        return list(self._dims)
 
     @property
     def names(self):
-        assert self._names_set
-        return self._names
+        return self._labels
 
     def subset(self, indices):
-        self._sizes = [self._sizes[i] for i in indices]
-        self._names = [self._names[i] for i in indices]
+        for attr in ("_items", "_labels", "_dims"):
+            old = getattr(self, attr)
+            setattr(self, attr, [old[i] for i in indices])
+
+    def __iter__(self):
+        for k, item in enumerate(self._items):
+            if self._from_files:
+                item = Images.read_image(item)
+                self._note_size(k, Images.get_image_size(item))
+            yield item
 
     def resize(self, resolution, imgs=None):
         """generator, stitching/images.py:72-77: every image at `resolution` (cv.resize INTER_LINEAR_EXACT, on the device)"""
-        for idx, img in enumerate(iter(self) if imgs is None else imgs):
-            yield Images.resize_img_by_scaler(self._get_scaler(resolution), self._sizes[idx], img)
+        scaler = self._get_scaler(resolution)
+        for k, img in enumerate(self if imgs is None else imgs):
+            yield Images.resize_img_by_scaler(scaler, self._dims[k], img)
 
-    def _set_scales(self, size):
-        if not self._scales_set:
+    def _note_size(self, k, size):
+        """item k is `size` pixels: the first size ever seen fixes the three scales (stitching/images.py:79-83, 190-201)"""
+        if not self._scalers["FINAL"].is_scale_set:
             for s in self._scalers.values():
                 s.set_scale_by_img_size(size)
-            self._scales_set = True
+        if self._dims[k] is None:
+            self._dims[k] = tuple(size)
 
     def _get_scaler(self, resolution):
         Images.check_resolution(resolution)
         return self._scalers[resolution.name]
 
     def get_ratio(self, from_resolution, to_resolution):
-        assert self._scales_set
-        return self._get_scaler(to_resolution).scale / self._get_scaler(from_resolution).scale
+        num, den = self._get_scaler(to_resolution).scale, self._get_scaler(from_resolution).scale
+        assert num is not None and den is not None, "the scales are set by the first image"
+        return num / den
 
     def get_scaled_img_sizes(self, resolution):
-        assert self._scales_set and self._sizes_set
-        return [self._get_scaler(resolution).get_scaled_img_size(sz) for sz in self._sizes]
+        scaler = self._get_scaler(resolution)
+        assert scaler.scale is not None
+        return [scaler.get_scaled_img_size(sz) for sz in self.sizes]
 
     @staticmethod
     def read_image(img_name):
@@ -216,7 +239,7 @@ class Images:
         `resize(resolution)`; sizes / scales are set on the way exactly as iterating does."""
         resolution = resolution or Images.Resolution.FINAL
         ctx = ctx or get_context()
-        n = len(self._staging_sources())
+        n = len(self._items)
         if n == 0:
             return
         # per call: two stage() generators over one Images object must not share (or clobber) each other's buffers
@@ -247,12 +270,12 @@ class Images:
                         for b in in_flight:
                             pin_pool.setdefault((b.shape, b.dtype.str), []).append(b)
                     in_flight.clear()
-                yield Images.resize_img_by_scaler(self._get_scaler(resolution), self._sizes[idx], dev, device_resident=True)
+                yield Images.resize_img_by_scaler(self._get_scaler(resolution), self._dims[idx], dev, device_resident=True)
                 idx += 1
             ctx.sync()
 
     def _load_pinned(self, i, pin_pool, pin_lock):
-        src = self._staging_sources()[i]
+        src = self._items[i]
         a = Images.read_image(src) if isinstance(src, str) else np.asarray(src)
         with pin_lock:
             free = pin_pool.get((a.shape, a.dtype.str))
@@ -263,55 +286,9 @@ class Images:
         return buf
 
 
-class _ArrayImages(Images):
-    def __init__(self, images, medium_megapix, low_megapix, final_megapix):
-        super().__init__(images, medium_megapix, low_megapix, final_megapix)
-        if len(images) < 2:
-            raise StitchingError("2 or more Images needed")
-        self._images = images
-        self._sizes = [Images.get_image_size(img) for img in images]
-        self._sizes_set = True
-        self._names = [str(i + 1) for i in range(len(images))]
-        self._names_set = True
-        self._set_scales(self._sizes[0])
-
-    def subset(self, indices):
-        super().subset(indices)
-        self._images = [self._images[i] for i in indices]
-
-    def __iter__(self):
-        yield from self._images
-
-    def _staging_sources(self):
-        return self._images
-
-    def _note_size(self, idx, size):
-        pass
+class _NumpyImages(Images):
+    """Images.of(list of arrays): the class the reference's tests expect back (stitching/images.py:161); all behaviour is in Images"""
 
 
 class _FilenameImages(Images):
-    def __init__(self, images, medium_megapix, low_megapix, final_megapix):
-        super().__init__(images, medium_megapix, low_megapix, final_megapix)
-        self._names = Images.resolve_wildcards(images)
-        self._names_set = True
-        if len(self.names) < 2:
-            raise StitchingError("2 or more Images needed")
-        self._sizes = []
-
-    def __iter__(self):
-        for idx, name in enumerate(self.names):
-            img = Images.read_image(name)
-            self._note_size(idx, Images.get_image_size(img))
-            yield img
-
-    def _staging_sources(self):
-        return self._names
-
-    def _note_size(self, idx, size):
-        # the reference's side effects of the first iteration (images.py:190-201): scales from the first image, sizes recorded once
-        self._set_scales(size)
-        if not self._sizes_set:
-            if idx == len(self._sizes):
-                self._sizes.append(size)
-            if len(self._sizes) == len(self.names):
-                self._sizes_set = True
+    """Images.of(list of file names) (stitching/images.py:181)"""

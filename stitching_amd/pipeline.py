@@ -110,6 +110,7 @@ class StitchJob:
         self.num_bands = num_bands
         self.blend_strength = blend_strength
         self.corners = self.warped_sizes = None
+        self._cam_arrays = self.warper.camera_arrays(self.cameras)  # K, R as the batched entry points take them: built once
         # per mask the columns [a, b) and rows [c, d) that hold a non-zero value, and the mask's size (host arrays only: no
         # read-back here)
         self._mask_cols = None
@@ -126,14 +127,18 @@ class StitchJob:
 
     def plan(self):
         """Eager ROI pass (stitching/stitcher.py:188 warp_rois is eager too); one device sync."""
-        self.corners, self.warped_sizes = self.warper.warp_rois(self.sizes, self.cameras)
+        self._adopt(*self.warper.warp_rois(self.sizes, self.cameras, camera_arrays=self._cam_arrays))
+        return self.corners, self.warped_sizes
+
+    def _adopt(self, corners, warped_sizes):
+        """this panorama's ROIs -> the job's plan"""
+        self.corners, self.warped_sizes = corners, warped_sizes
         if any(w <= 0 or h <= 0 for w, h in self.warped_sizes):
             raise StitchingError(f"degenerate warp roi {self.warped_sizes}: the {self.warper.warper_type!r} projection cannot "
                                  "represent these cameras")
         if self.num_bands is not None:
             roi = Blender.result_roi(self.corners, self.warped_sizes)
             self.blend_strength = blend_strength_for_bands(self.num_bands, roi[2], roi[3])
-        return self.corners, self.warped_sizes
 
     def _crop_rects(self, handle):
         """see view_rects"""
@@ -144,12 +149,20 @@ class StitchJob:
 
     def run(self):
         """warp every frame, feed it, blend.  Returns device-resident (panorama u8x3, mask u8)."""
-        # one panorama = one ROI pass (the reference's eager Warper.warp_rois, stitching/stitcher.py:188):
-        # it belongs to the pass and is re-run every time (batched: one device pass, one synchronisation)
-        self.plan()
+        # one panorama = one ROI pass (the reference's eager Warper.warp_rois, stitching/stitcher.py:188): it belongs to the pass and
+        # is re-run every time (batched: one device pass, one wait).  It is the ONE point where the host waits for the device and
+        # the device then waits for the host: without seam-cell crops (which need the ROIs before the warps) pass and warps are one
+        # native call, and everything Python does with the ROIs happens behind the warp launch (profiles/r05_latency.md)
         prev = config.device_resident()
         config.set_device_resident(True)
         try:
+            warped = None
+            if self._mask_cols is None:
+                warped = self.warper.warp_images_and_masks(self.frames, self.cameras, compensator=self.compensator, with_rois=True,
+                                                           camera_arrays=self._cam_arrays)
+                self._adopt([r[0:2] for r in warped[2]], [r[2:4] for r in warped[2]])
+            else:
+                self.plan()
             blender = Blender(self.blender_type, self.blend_strength, ctx=self.ctx)
             blender.prepare(self.corners, self.warped_sizes)
             crop = None
@@ -158,7 +171,8 @@ class StitchJob:
             if crop is not None:
                 box = [c if c is not None else (0, w, 0, h) for c, (w, h) in zip(crop, self.warped_sizes)]
                 rects = [(cx + x0, cy + y0, x1 - x0, y1 - y0) for (x0, x1, y0, y1), (cx, cy) in zip(box, self.corners)]
-                imgs, masks, rois = self.warper.warp_images_and_masks(self.frames, self.cameras, rects=rects, compensator=self.compensator)
+                imgs, masks, rois = self.warper.warp_images_and_masks(self.frames, self.cameras, rects=rects, compensator=self.compensator,
+                                                                      camera_arrays=self._cam_arrays)
                 if self.feed_masks is not None:
                     masks = [m[y0:y1, x0:x1] for m, (x0, x1, y0, y1) in zip(self.feed_masks, box)]
                 else:
@@ -168,7 +182,8 @@ class StitchJob:
                                                   sub=[(w, h, x0, y0) for (x0, x1, y0, y1), (w, h) in zip(box, self.warped_sizes)])
                 corners = [(r[0], r[1]) for r in rects]
             else:
-                imgs, masks, rois = self.warper.warp_images_and_masks(self.frames, self.cameras, compensator=self.compensator)
+                imgs, masks, rois = warped or self.warper.warp_images_and_masks(self.frames, self.cameras, compensator=self.compensator,
+                                                                                camera_arrays=self._cam_arrays)
                 if self.feed_masks is not None:
                     masks = self.feed_masks
                 elif self.seam_masks is not None:

@@ -95,17 +95,25 @@ class Warper:
                                           int(size[0]), int(size[1]), C.byref(out), roi))
         return self._result(DeviceImage(ctx, out))
 
-    def warp_rois(self, sizes, cameras, aspect=1):
+    def camera_arrays(self, cameras, aspect=1):
+        """(K, R) of every camera as the two n x 3 x 3 float32 arrays the batched entry points take: what warp_rois /
+        warp_images_and_masks build on every call, for callers that hold their cameras (StitchJob) to build once and pass as
+        `camera_arrays=` — 16 small numpy conversions per panorama otherwise, on the one stretch where the device waits for the host."""
+        cameras = list(cameras)
+        Ks = np.empty((len(cameras), 3, 3), np.float32)
+        Rs = np.empty((len(cameras), 3, 3), np.float32)
+        for i, cam in enumerate(cameras):
+            Ks[i], Rs[i] = self._K_R(cam, aspect)
+        return Ks, Rs
+
+    def warp_rois(self, sizes, cameras, aspect=1, camera_arrays=None):
         sizes, cameras = list(sizes), list(cameras)
         n = min(len(sizes), len(cameras))
         roi_corners, roi_sizes = [], []
         if n == 0:
             return roi_corners, roi_sizes
         ctx = self._ctx()
-        Ks = np.empty((n, 3, 3), np.float32)
-        Rs = np.empty((n, 3, 3), np.float32)
-        for i in range(n):
-            Ks[i], Rs[i] = self._K_R(cameras[i], aspect)
+        Ks, Rs = camera_arrays if camera_arrays is not None else self.camera_arrays(cameras[:n], aspect)
         wh = np.ascontiguousarray([[int(s[0]), int(s[1])] for s in sizes[:n]], np.int32)
         out = np.zeros((n, 4), np.int32)
         _lib.check(ctx._lib.stx_warp_rois(ctx.handle, self._type_id(), self._scale(aspect), n, _fp(Ks), _fp(Rs),
@@ -146,7 +154,7 @@ class Warper:
                                                     src._h, C.byref(oi), C.byref(om), roi))
         return (self._result(DeviceImage(ctx, oi)), self._result(DeviceImage(ctx, om)), tuple(int(v) for v in roi))
 
-    def warp_images_and_masks(self, imgs, cameras, aspect=1, rects=None, compensator=None):
+    def warp_images_and_masks(self, imgs, cameras, aspect=1, rects=None, compensator=None, with_rois=False, camera_arrays=None):
         """Batched form of warp_images + create_and_warp_masks (stitching/warper.py:39-41, 54-56) for a list of
         images: one ROI pass, one table launch and one remap launch for all of them (stx_warp_batch).
         Returns (warped_images, warped_masks, rois).
@@ -154,23 +162,32 @@ class Warper:
         produced (pixel for pixel what the full warp holds there); the returned rois are then these rectangles.
         compensator: an ExposureErrorCompensator with block gains set ("gain_blocks" / "channel_blocks"): the warped images come back
         compensated — stitching/stitcher.py:119-123 in one call (stx_warp_batch_gain: the product rides in the warp kernel's epilogue
-        when it can).  Equal to compensator.apply_all on the plain result, byte for byte."""
+        when it can).  Equal to compensator.apply_all on the plain result, byte for byte.
+        with_rois (no rects): the ROI pass is made by this call, on the device, whatever earlier calls have cached, and the warps are
+        launched right behind it from native code (stx_warp_batch_with_rois: a panorama's latency, see StitchJob.run).
+        camera_arrays: Warper.camera_arrays(cameras, aspect), for callers that keep it."""
         ctx = self._ctx()
         srcs = [self._source(img, ctx) for img in imgs]
         cameras = list(cameras)
         n = min(len(srcs), len(cameras))
         if n == 0:
             return [], [], []
-        Ks = np.empty((n, 3, 3), np.float32)
-        Rs = np.empty((n, 3, 3), np.float32)
-        for i in range(n):
-            Ks[i], Rs[i] = self._K_R(cameras[i], aspect)
+        Ks, Rs = camera_arrays if camera_arrays is not None else self.camera_arrays(cameras[:n], aspect)
         h_src = (C.c_void_p * n)(*[s._h for s in srcs[:n]])
         h_img, h_mask = (C.c_void_p * n)(), (C.c_void_p * n)()
         rois = np.zeros((n, 4), np.int32)
-        if compensator is not None and compensator.compensator_type in ("gain_blocks", "channel_blocks"):
-            if compensator.gains is None:
-                raise StitchingError("ExposureErrorCompensator.set_gains(gains) must be called before apply")
+        blocks = compensator is not None and compensator.compensator_type in ("gain_blocks", "channel_blocks")
+        if blocks and compensator.gains is None:
+            raise StitchingError("ExposureErrorCompensator.set_gains(gains) must be called before apply")
+        if with_rois and rects is None:
+            ga = fl = None
+            if blocks:
+                gm = [compensator._gain_map(i, ctx) for i in range(n)]
+                ga, fl = (C.c_void_p * n)(*[g[0]._h for g in gm]), (C.c_int * n)(*[g[1] for g in gm])
+                compensator = None
+            _lib.check(ctx._lib.stx_warp_batch_with_rois(ctx.handle, self._type_id(), self._scale(aspect), n, _fp(Ks), _fp(Rs), h_src, ga, fl,
+                                                         h_img, h_mask, rois.ctypes.data_as(C.POINTER(C.c_int))))
+        elif blocks:
             gm = [compensator._gain_map(i, ctx) for i in range(n)]
             ga, fl = (C.c_void_p * n)(*[g[0]._h for g in gm]), (C.c_int * n)(*[g[1] for g in gm])
             rp = None

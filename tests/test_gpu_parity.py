@@ -43,6 +43,23 @@ def test_warp_image_and_mask_bit_exact(oracle, gpu_ctx, wtype):
         assert roi == o.warp_roi((517, 389), cam)
 
 
+@pytest.mark.parametrize("wtype", ["spherical", "cylindrical", "plane", "fisheye"])
+def test_roi_pass_and_warps_in_one_call(oracle, gpu_ctx, wtype):
+    """stx_warp_batch_with_rois (the ROI pass polled from pinned memory, the warps launched behind it) == the oracle's rois, images,
+    masks — twice, the second time with every ROI already in the cache of earlier calls (the pass must run again and agree)."""
+    imgs, cams = helpers.small_ring(5, 431, 297, span=130.0 if wtype not in ("plane", "fisheye") else 50.0)
+    g, o = S.Warper(wtype), oracle.Warper(wtype)
+    g.set_scale(cams)
+    o.set_scale(cams)
+    want = [(o.warp_image(im, c), o.create_and_warp_mask((431, 297), c), o.warp_roi((431, 297), c)) for im, c in zip(imgs, cams)]
+    ka = g.camera_arrays(cams)
+    for _ in range(2):
+        gi, gm, rois = g.warp_images_and_masks(imgs, cams, with_rois=True, camera_arrays=ka)
+        assert rois == [w[2] for w in want]
+        for a, b, w in zip(gi, gm, want):
+            assert np.array_equal(a, w[0]) and np.array_equal(b, w[1])
+
+
 def test_affine_warp_bit_exact(oracle, gpu_ctx):
     cams = synthetic.affine_scan_cameras(4, 300, 200)
     imgs = [synthetic.make_frame(i, 300, 200) for i in range(4)]
