@@ -55,7 +55,7 @@ def parse():
                    "panorama (rank 0 runs the oracle once on all frames, outside the timed region)")
     p.add_argument("--no-extra", action="store_true", help="skip the extra legs (seam masks, configs 4 / 5, latency)")
     p.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU-baseline sample (0: all frames of the step, which also gives `parity`)")
-    p.add_argument("--profile-steps", type=int, default=3)
+    p.add_argument("--profile-steps", type=int, default=10)
     p.add_argument("--min-seconds", type=float, default=MIN_TIMED_S)
     p.add_argument("--streams", type=int, default=2, help="panoramas in flight per GPU (contexts = HIP streams); N = 1 "
                    "measured: 1 -> 93.0, 2 -> 105.9, 3 -> 99.6 Gpix/s")
