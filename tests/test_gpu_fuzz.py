@@ -93,6 +93,14 @@ def test_random_geometry_bit_exact(oracle, gpu_ctx, seed):
     assert g["pano"].shape == o["pano"].shape, tag
     assert np.array_equal(g["pmask"], o["pmask"]), tag
     assert np.array_equal(g["pano"], o["pano"]), (tag, int(np.count_nonzero(g["pano"] != o["pano"])))
+    # the one-call form (ROI pass polled from pinned memory, warps launched behind it: stx_warp_batch_with_rois) on the same geometry
+    w = S.Warper(c["wtype"])
+    w.set_scale(c["cams"])
+    bi, bm, rois = w.warp_images_and_masks(c["imgs"], c["cams"], c["aspect"], with_rois=True)
+    assert [tuple(r[0:2]) for r in rois] == [tuple(int(v) for v in x) for x in o["corners"]], tag
+    assert [tuple(r[2:4]) for r in rois] == [tuple(int(v) for v in x) for x in o["sizes"]], tag
+    for k in range(c["n"]):
+        assert np.array_equal(bi[k], o["w_imgs"][k]) and np.array_equal(bm[k], o["w_masks"][k]), (tag, "one call", k)
 
 
 @pytest.mark.parametrize("seed", list(range(14 + EXTRA)))
