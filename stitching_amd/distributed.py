@@ -501,6 +501,7 @@ class ShardedStitchJob:
         self.all_sizes = list(all_sizes) if all_sizes is not None else [size0] * n
         self.warper = Warper(warper_type, ctx=self.ctx)
         self.warper.set_scale(self.all_cameras)
+        self._cam_arrays = self.warper.camera_arrays(self.cameras)  # K, R of this rank's cameras as the batched entry points take them
         self.num_bands_req, self.blend_strength = num_bands, blend_strength
         self.compensator = compensator
         self._local_comp = {}
@@ -613,7 +614,7 @@ class ShardedStitchJob:
         p = self.plan_ or self.plan()
         # this rank's share of the ROI pass belongs to every panorama (as in StitchJob.run)
         local = {k: i for i, k in enumerate(self.my_orders)}
-        corners, _ = self.warper.warp_rois([self.all_sizes[k] for k in self.my_orders], self.cameras)
+        corners, _ = self.warper.warp_rois([self.all_sizes[k] for k in self.my_orders], self.cameras, camera_arrays=self._cam_arrays)
         if [tuple(c) for c in corners] != [p.corners[k] for k in self.my_orders]:
             raise StitchingError("warp rois changed between plan() and run()")
         prev = config.device_resident()
@@ -668,7 +669,8 @@ class ShardedStitchJob:
     def _run_flat(self, p):
         """feather / "no": warp everything, send every other band its columns (+ halo), feed this band's blender its own columns and the
         received strips in global feed order, blend, crop the halo off."""
-        imgs, masks, rois = self.warper.warp_images_and_masks(self.frames, self.cameras, compensator=self._compensator_for(self.my_orders))
+        imgs, masks, rois = self.warper.warp_images_and_masks(self.frames, self.cameras, compensator=self._compensator_for(self.my_orders),
+                                                              camera_arrays=self._cam_arrays)
         masks = self._seam_resized(self.my_orders, masks)
         warped = {}
         for k, img, mask, roi in zip(self.my_orders, imgs, masks, rois):
@@ -734,7 +736,9 @@ class ShardedStitchJob:
         local = {k: i for i, k in enumerate(self.my_orders)}
         frames = [self.frames[local[k]] for k in orders]
         cams = [self.cameras[local[k]] for k in orders]
-        imgs, masks, rois = self.warper.warp_images_and_masks(frames, cams, compensator=self._compensator_for(orders))
+        idx = [local[k] for k in orders]
+        ka = (np.ascontiguousarray(self._cam_arrays[0][idx]), np.ascontiguousarray(self._cam_arrays[1][idx]))
+        imgs, masks, rois = self.warper.warp_images_and_masks(frames, cams, compensator=self._compensator_for(orders), camera_arrays=ka)
         masks = self._seam_resized(orders, masks)
         for k, img, mask, roi in zip(orders, imgs, masks, rois):
             if roi[0:2] != p.corners[k]:
