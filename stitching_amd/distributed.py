@@ -851,10 +851,41 @@ def default_transport(ctx, rank, world, group):
         except Exception as e:  # noqa: BLE001 - any failure -> agree on the fallback below
             print(f"[stitching_amd] rank {rank}: RCCL transport unavailable ({e}); using the host-staged transport", file=sys.stderr)
     if group.all_reduce_min(ok) == 1:
-        return tr
+        # every rank holds a communicator: before a panorama depends on it, one small exchange around the ring through the very calls
+        # the job will make (start / finish on a context), checked byte for byte and bounded by the same watchdog — a transport that
+        # initialises but does not deliver (first contact with a node's RCCL / xGMI set-up) must cost a message, not the job
+        try:
+            call_with_timeout(lambda: ring_probe(tr, rank, world), rccl_timeout(), "the RCCL ring probe")
+            ok = 1
+        except Exception as e:  # noqa: BLE001
+            ok = 0
+            print(f"[stitching_amd] rank {rank}: RCCL initialised but the ring probe failed ({e}); using the host-staged transport", file=sys.stderr)
+        if group.all_reduce_min(ok) == 1:
+            return tr
     if tr is not None:
         tr.close()
     return HostStagedTransport(group, ctx)
+
+
+def ring_probe(transport, rank, world, nbytes=4096):
+    """`nbytes` of a rank-specific pattern to rank + 1, the pattern of rank - 1 back, through transport.start / finish on a context of
+    its own (a probe that hangs must not leave the job's stream waiting for it).  Raises StitchingError when the bytes differ."""
+    from .device import Context
+
+    def pattern(r):
+        return ((np.arange(nbytes, dtype=np.uint32) * 2654435761 + 40503 * (r + 1)) >> 13).astype(np.uint8).reshape(1, nbytes)
+
+    pctx = Context(transport.ctx.device)
+    try:
+        out = DeviceImage.from_numpy(pattern(rank), pctx)
+        transport.start([((rank + 1) % world, out, nbytes)], [((rank - 1) % world, nbytes)], pctx)
+        got = transport.finish(pctx)
+        pctx.sync()
+        if not np.array_equal(np.asarray(got[0]).reshape(-1)[:nbytes], pattern((rank - 1) % world).reshape(-1)):
+            raise StitchingError(f"rank {rank}: the strip received from rank {(rank - 1) % world} is not the one it sent")
+        del got, out
+    finally:
+        pctx.close()
 
 
 class _NullTransport:

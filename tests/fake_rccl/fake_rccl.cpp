@@ -131,6 +131,8 @@ int run_group(std::vector<Op>& ops)
         if (n != o.bytes) { rc = fail(ERR_ARGUMENT, "rank " + std::to_string(comm->rank) + " receives " + std::to_string(o.bytes) + " bytes from rank " + std::to_string(o.peer) + " which sends " + std::to_string(n)); break; }
         std::vector<char> h(o.bytes);
         if (!read_all(comm->fd[o.peer], h.data(), o.bytes)) { rc = fail(ERR_SYSTEM, "short message"); break; }
+        // FAKE_RCCL_CORRUPT (fault injection): a transport that initialises and then delivers wrong bytes — what the ring probe exists for
+        if (o.bytes && getenv("FAKE_RCCL_CORRUPT")) h[o.bytes / 2] ^= 0x5a;
         if (o.bytes && hipMemcpy(o.ptr, h.data(), o.bytes, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(ERR_INTERNAL, "H2D copy into a receive buffer failed"); break; }
     }
     for (auto& t : writers) t.join();

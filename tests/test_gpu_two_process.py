@@ -110,6 +110,14 @@ def test_two_ranks_over_the_rccl_code_path_with_a_test_double(gpu_ctx, split):
     assert res["bands"] == 4 and res["messages"] >= 2 and res["ok"], res
 
 
+def test_a_transport_that_delivers_wrong_bytes_is_caught_by_the_ring_probe(gpu_ctx):
+    """The librccl stand-in initialises and then flips a byte of every message (FAKE_RCCL_CORRUPT): default_transport's ring probe sees
+    it on every rank, all ranks agree on the host-staged transport, and the panorama is still the oracle's."""
+    env = dict(_rccl_double_env(), FAKE_RCCL_CORRUPT="1")
+    res = launch(2, dict(layout="ring", w=803, h=601, per_rank=3, warper="spherical", bands=4, repeat=2), rank_env=lambda r: env)
+    assert res["transport"] == "host-staged" and res["ok"], res
+
+
 def test_three_ranks_all_pairs_over_the_rccl_code_path_with_a_test_double(gpu_ctx):
     """config 4 in small (strips between all pairs of ranks, masks as bits) through the same path, and the feather blender's sharded form."""
     env = _rccl_double_env()
