@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 5: the side stream joined by stream write / wait values (3: high priority, 4: plain) instead of events (1, 2)
+# NEEDS tools/specs/r05_side_stream_experiment.patch applied (STITCHING_AMD_HI_SMALL); reverted in the tree
 OUT=gpurun_out/r5v; mkdir -p $OUT; cd /root/repo
 python - <<'PY' > $OUT/attr.txt 2>&1
 import ctypes
