@@ -212,7 +212,8 @@ static hipEvent_t take_event(stx_ctx* ctx)
     return e;
 }
 
-StxProfScope::StxProfScope(stx_ctx* c, const char* name, double algo_bytes, hipStream_t on) : ctx(c), stream(on ? on : c->stream)
+StxProfScope::StxProfScope(stx_ctx* c, const char* name, double algo_bytes, hipStream_t on, bool attach)
+    : ctx(c), stream(on ? on : c->stream), attached(attach)
 {
     if (!ctx->prof_on) return;
     auto it = ctx->prof_index.find(name);
@@ -231,15 +232,18 @@ StxProfScope::StxProfScope(stx_ctx* c, const char* name, double algo_bytes, hipS
     pe.start = take_event(ctx);
     pe.stop = take_event(ctx);
     pe.entry = idx;
-    hipEventRecord(pe.start, stream);
+    if (!attached) hipEventRecord(pe.start, stream);
     ctx->prof_pending.push_back(pe);
     pending = (int)ctx->prof_pending.size() - 1;
 }
 
 StxProfScope::~StxProfScope()
 {
-    if (pending >= 0) hipEventRecord(ctx->prof_pending[pending].stop, stream);
+    if (pending >= 0 && !attached) hipEventRecord(ctx->prof_pending[pending].stop, stream);
 }
+
+hipEvent_t StxProfScope::start() const { return pending >= 0 ? ctx->prof_pending[pending].start : nullptr; }
+hipEvent_t StxProfScope::stop() const { return pending >= 0 ? ctx->prof_pending[pending].stop : nullptr; }
 
 static void prof_collect(stx_ctx* ctx)
 {

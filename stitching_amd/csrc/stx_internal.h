@@ -99,8 +99,13 @@ struct StxProfScope {
     stx_ctx* ctx;
     int pending = -1;
     hipStream_t stream;  // the stream the bracketed kernel is launched on (default: the context's main stream)
-    StxProfScope(stx_ctx* c, const char* name, double algo_bytes, hipStream_t on = nullptr);
+    bool attached;       // true: the scope holds ONE launch and the caller attaches start() / stop() to it (hipExtLaunchKernelGGL): the
+                         // events then carry the dispatch's own begin / end stamps, as rocprofv3 reports them.  false: an event recorded
+                         // before and one after whatever the scope launches — 3-5 us more than the kernel (tools/ubench/event_bracket.hip)
+    StxProfScope(stx_ctx* c, const char* name, double algo_bytes, hipStream_t on = nullptr, bool attach = false);
     ~StxProfScope();
+    hipEvent_t start() const;  // null while the profiler is off: launch plainly
+    hipEvent_t stop() const;
 };
 
 // ---------------------------------------------------------------------------------------------

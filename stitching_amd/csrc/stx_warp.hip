@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <hip/hip_ext.h>
+
 #include "stx_device_math.h"
 #include "stx_internal.h"
 
@@ -1233,7 +1235,9 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
             hipLaunchKernelGGL((warp_tables_kernel<TYPE>), dim3((max_tab + 255) / 256, m), dim3(256), 0, s, B);
         }
         if (fast) {
-            StxProfScope prof(ctx, prof_name, bytes);
+            // one launch in this bracket: with the profiler on its events are attached to the launch itself (the kernel's own begin / end
+            // stamps, what rocprofv3 reports), not recorded around it
+            StxProfScope prof(ctx, prof_name, bytes, nullptr, true);
             int per_xcd = 0;  // workgroups each XCD needs: its share of the bands, whole bands only
             for (int i = 0; i < m; i++) {
                 const int tx = (B.k[i].dw + WARP_FW - 1) / WARP_FW, ty = (B.k[i].dh + WARP_FTH - 1) / WARP_FTH;
@@ -1244,11 +1248,15 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
             // STITCHING_AMD_WARP_LDS (diagnostic): bytes of dynamic LDS requested on top of the kernel's own — an occupancy limit
             // (160 KB per CU / request = workgroups per CU) for co-residency experiments with the other panorama's kernels
             static const unsigned pad_lds = getenv("STITCHING_AMD_WARP_LDS") ? (unsigned)atoi(getenv("STITCHING_AMD_WARP_LDS")) : 0u;
-            if (dbg) hipLaunchKernelGGL((warp_fast_kernel<TYPE, false, false, true>), gf, dim3(WARP_FW), 0, s, B);
-#define STX_FAST_LAUNCH(I, M, R)                                                                                        \
-    do {                                                                                                               \
-        if (gain) hipLaunchKernelGGL((warp_fast_kernel<TYPE, I, M, false, R, true>), gf, dim3(WARP_FW), pad_lds, s, B);  \
-        else hipLaunchKernelGGL((warp_fast_kernel<TYPE, I, M, false, R, false>), gf, dim3(WARP_FW), pad_lds, s, B);      \
+#define STX_FAST_LAUNCH_K(...)                                                                                                    \
+    do {                                                                                                                          \
+        if (prof.start()) hipExtLaunchKernelGGL((__VA_ARGS__), gf, dim3(WARP_FW), pad_lds, s, prof.start(), prof.stop(), 0, B);     \
+        else hipLaunchKernelGGL((__VA_ARGS__), gf, dim3(WARP_FW), pad_lds, s, B);                                                   \
+    } while (0)
+#define STX_FAST_LAUNCH(I, M, R)                                                   \
+    do {                                                                           \
+        if (gain) STX_FAST_LAUNCH_K(warp_fast_kernel<TYPE, I, M, false, R, true>);  \
+        else STX_FAST_LAUNCH_K(warp_fast_kernel<TYPE, I, M, false, R, false>);      \
     } while (0)
 #define STX_FAST_LAUNCH_RM(I, M)                                             \
     do {                                                                     \
@@ -1256,11 +1264,13 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
         else if (rm == STX_REMAP_FLOAT_FMA) STX_FAST_LAUNCH(I, M, STX_REMAP_FLOAT_FMA); \
         else STX_FAST_LAUNCH(I, M, STX_REMAP_Q15);                           \
     } while (0)
+            if (dbg) STX_FAST_LAUNCH_K(warp_fast_kernel<TYPE, false, false, true>);
             else if (img && mask) STX_FAST_LAUNCH_RM(true, true);
             else if (img) STX_FAST_LAUNCH_RM(true, false);
+            else STX_FAST_LAUNCH_K(warp_fast_kernel<TYPE, false, true>);
 #undef STX_FAST_LAUNCH_RM
 #undef STX_FAST_LAUNCH
-            else hipLaunchKernelGGL((warp_fast_kernel<TYPE, false, true>), gf, dim3(WARP_FW), pad_lds, s, B);
+#undef STX_FAST_LAUNCH_K
         } else {
             for (int i = 0; i < m; i++) {
                 StxProfScope prof(ctx, prof_name, algo_bytes[base + i]);
