@@ -22,7 +22,7 @@ def free_port():
     return p
 
 
-def launch(world, case, group="tcp", extra_env=None, expect_fail=False):
+def launch(world, case, group="tcp", extra_env=None, expect_fail=False, worker="dist_worker.py"):
     port = free_port()
     procs = []
     for r in range(world):
@@ -30,7 +30,7 @@ def launch(world, case, group="tcp", extra_env=None, expect_fail=False):
                    MASTER_PORT=str(port), STX_TEST_CASE=json.dumps(case), GLOO_SOCKET_IFNAME="lo", STX_TEST_GROUP=group)
         if extra_env:
             env.update(extra_env(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py")], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", worker)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
@@ -150,3 +150,19 @@ def test_eight_ranks_config3_layout_link_balanced_over_gloo(oracle):
     bal = launch(8, dict(case, balance="links"))
     assert mid["ok"] and bal["ok"] and bal["bands"] == mid["bands"] == 2
     assert bal["edges"] != mid["edges"] and bal["edges"][1] < mid["edges"][1] and bal["messages"] >= 8 * 4
+
+
+@pytest.mark.parametrize("fail,want,probed", [("", "rccl", 1), ("id", "host-staged", 0), ("init:0", "host-staged", 0), ("init:2", "host-staged", 0),
+                                              ("probe:1", "host-staged", 1)])
+def test_transport_agreement(fail, want, probed):
+    """default_transport with librccl and the device replaced by stand-ins (tests/transport_agreement_worker.py), 3 ranks over the TCP
+    rendezvous: no unique id, a rank that cannot join, a rank whose ring probe sees wrong bytes — every rank ends on the SAME transport,
+    the probe runs only when every rank holds a communicator, and a communicator that is given up is closed."""
+    outs = launch(3, {}, extra_env=lambda r: {"STX_FAIL": fail}, expect_fail=True, worker="transport_agreement_worker.py")
+    for rc, o, e in outs:
+        assert rc == 0, e[-2000:]
+        res = json.loads(o.strip().splitlines()[-1])
+        assert res["transport"] == want and res["all"] == [want] * 3, (res, e[-500:])
+        assert res["probed"] == probed, res
+        if want == "host-staged" and fail.startswith("probe"):
+            assert res["closed"] == 1, res
