@@ -1558,13 +1558,13 @@ __global__ __launch_bounds__(256) void gain_rows_kernel(BlockGainBatchK B)
     }
 }
 
-// cvRound(p g) saturated to u8 into byte `sel` of `old`; v_cvt_pk_u8_f32 saturates, v_rndne_f32 is the round-half-even of cvRound
+// cvRound(p g) saturated to u8 into byte `sel` of `old`: v_cvt_pk_u8_f32 is the round-half-even of cvRound AND the saturation
 template <bool FAST>
 STX_DEV uint32_t gain_px(uint32_t old, int sel, float p, float g)
 {
     float v = stxd::fmul(p, g);
     if (!FAST) v = v < 2147483648.f ? v : 0.f;  // cvRound's INT_MIN for NaN / out-of-range products saturates to 0
-    return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(v), (uint32_t)sel, old);
+    return __builtin_amdgcn_cvt_pk_u8_f32(v, (uint32_t)sel, old);  // rounds to nearest even and saturates itself: tools/ubench/cvt_pk_u8.hip
 }
 
 template <int GC, bool FAST>

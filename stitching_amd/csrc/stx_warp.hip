@@ -526,7 +526,9 @@ STX_DEV void blend_float_to_lds(const STX_GAS uint8_t* src, uint32_t stride, flo
             u = fadd(fmul(a, fsub(p11, p10)), p10);
             v = fadd(fmul(b, fsub(u, t)), t);
         }
-        p[c] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(v), 0u, 0u);  // cvRound + clamp (v is within [0, 255] up to rounding)
+        // cvRound + clamp in ONE instruction: v_cvt_pk_u8_f32 rounds to nearest even and saturates by itself (equal to the v_rndne_f32 +
+        // conversion pair on every one of the 2^32 floats, NaN -> 0: tools/ubench/cvt_pk_u8.hip)
+        p[c] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(v, 0u, 0u);
     }
 }
 
@@ -855,7 +857,7 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 uint32_t o[3] = {0u, 0u, 0u};
 #pragma unroll
                 for (int k = 0; k < 12; k++)  // byte k of the 12: pixel k / 3
-                    o[k >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmul((float)((in[k >> 2] >> (8 * (k & 3))) & 255u), g[k / 3])), (uint32_t)(k & 3), o[k >> 2]);
+                    o[k >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(fmul((float)((in[k >> 2] >> (8 * (k & 3))) & 255u), g[k / 3]), (uint32_t)(k & 3), o[k >> 2]);  // rounds + saturates itself (see blend_float_to_lds)
                 a0 = o[0]; a1 = o[1]; a2 = o[2];
             }
             d[0] = a0; d[1] = a1; d[2] = a2;  // (non-temporal stores, round 5: 183.7 / 184.5 us against 177.1 / 177.9 — dropped)
@@ -885,7 +887,7 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
                         uint32_t o = 0u;
 #pragma unroll
                         for (int q = 0; q < 4; q++)
-                            o = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmul((float)((w >> (8 * q)) & 255u), (4 * cdw + q) / 3 == pa ? ga : gb)), (uint32_t)q, o);
+                            o = __builtin_amdgcn_cvt_pk_u8_f32(fmul((float)((w >> (8 * q)) & 255u), (4 * cdw + q) / 3 == pa ? ga : gb), (uint32_t)q, o);
                         w = o;
                     }
                     *reinterpret_cast<uint32_t*>(drow + (long long)(y0 + rr) * dimg_stride + cdw * 4) = w;
