@@ -25,7 +25,10 @@ def kernel_source_hash():
 
 
 NAMES = [("warp_fast_kernel<3, true, true", "warp_img_mask"), ("warp_fast_kernel<2, true, true", "warp_img_mask"),
-         ("warp_fast_kernel<0, true, true", "warp_img_mask"), ("mb_level0_pk_kernel", "mb_level0"),
+         ("warp_fast_kernel<0, true, true", "warp_img_mask"),
+         ("warp_fast_kernel<3, true, true, false, 0, true", "warp_img_mask_gain"),
+         ("seam_resize4", "seam_mask_resize"), ("dilate3x3", "seam_mask_dilate"), ("mb_level0_deferred", "mb_level0_deferred"),
+         ("gain_rows_kernel", "block_gain_rows"), ("mb_level0_pk_kernel", "mb_level0"),
          ("mb_down0_lds_kernel", "mb_down0"), ("mb_down_lds_kernel", "mb_down"), ("warp_tables_kernel", "warp_tables"),
          ("mb_level_pk_kernel", "mb_level"), ("mb_coarse_kernel", "mb_coarse"), ("roi_kernel", "warp_roi")]
 
@@ -59,7 +62,9 @@ def main(d, out, stats=None):
         res["rocprofv3_avg_us"] = {name: round(tot / calls / 1e3, 3) for name, (tot, calls) in avg.items() if calls}
         res["rocprofv3_stats_file"] = os.path.basename(stats)
     res["kernel_source_hash"] = kernel_source_hash()
-    res["workload_cfg"] = 2
+    # which workload the passes ran: 2 (the bench default) unless the caller names another leg (tools/prof_cmd.sh)
+    wl = os.environ.get("STX_TRAFFIC_WORKLOAD", "")
+    res["workload_cfg"] = 2 if not wl else wl
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     for k, v in items.items():
         print(f"{k:16s} fetch {v['fetch_bytes_raw']/1e6:9.1f} MB (x2 = {2*v['fetch_bytes_raw']/1e6:9.1f})  write {v['write_bytes_raw']/1e6:9.1f} MB")
