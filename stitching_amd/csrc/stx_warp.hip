@@ -49,6 +49,10 @@ constexpr int WARP_FW = 64 * STX_WARP_WAVES;
 #ifndef STX_WARP_BAND
 #define STX_WARP_BAND 4
 #endif
+// STX_WARP_ZGRID = 1 (A/B only): the grid of rounds 1-5, (workgroups of the LARGEST image, 1, images) — see WarpBatchK::first_wg
+#ifndef STX_WARP_ZGRID
+#define STX_WARP_ZGRID 0
+#endif
 constexpr int WARP_BAND = STX_WARP_BAND;  // tile rows per XCD band (fast kernel); measured 1: 548, 2: 424, 4: 360, 8: 327, 16: 311 MB fetched
 constexpr float PI_F = 3.14159274101257324f;  // static_cast<float>(CV_PI)
 
@@ -104,6 +108,11 @@ struct WarpBatchK {
     // row table, in blocks of 4 destination rows (one tile row): rowT[4 b + 0..3] = {ra x4}, {p1 x4}, {p4 x4}, {p7 x4} of rows
     // 4 b .. 4 b + 3 (rows beyond the image repeat the last one); rowT[dh4 + r / 4][r % 4] = rb of row r (dh4 = dh rounded up to 4)
     float4* rowT[WARP_BATCH];
+    // fast kernel: ONE 1-D grid for the whole batch — image i owns the workgroups [first_wg[i], first_wg[i + 1]), every bound a multiple of
+    // 8 (the XCD of a workgroup is its index modulo 8); entries beyond the batch hold 0xffffffff.  Round 6: a grid of (largest image, 1,
+    // images) launched 28 % empty workgroups for a column of config 3 (ROIs of 7965 x 3024 next to 4122 x 2783) and the launch took 234 us
+    // against 190 us for its four images one after the other (profiles/r06_warp_split.md).
+    uint32_t first_wg[WARP_BATCH];
 };
 constexpr uint32_t RND_U0 = 0x4B400000u;  // bit pattern of 1.5 * 2^23
 
@@ -559,13 +568,30 @@ STX_DEV int periodic_axis(int s, int n, int period, float inv_period, int bias)
 // blend_float_to_lds, every other wavefront one pixel at a time through sample_float: borders are a minority)
 // GAIN: the warped image leaves multiplied by the block gain of its position (cvRound(p g) saturated, cv::multiply's arithmetic) — applied
 // to the finished bytes on their way from LDS to memory, whatever sampling path made them
-template <int TYPE, bool IMG, bool MASK, bool DBG = false, int RM = STX_REMAP_Q15, bool GAIN = false>
+// FLAT: the batch's images share ONE 1-D grid (WarpBatchK::first_wg) instead of a grid of (largest image, 1, images): chosen by the host
+// when the images' tile counts differ (see launch_typed)
+template <int TYPE, bool IMG, bool MASK, bool DBG = false, int RM = STX_REMAP_Q15, bool GAIN = false, bool FLAT = false>
 __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8))) void warp_fast_kernel(WarpBatchK B)
 {
-    const WarpK& P = B.k[blockIdx.z];
+    // which image of the batch this workgroup belongs to: seven scalar compares against the images' first workgroups
+    uint32_t wg = blockIdx.x;
+    int zi = blockIdx.z;
+    if (FLAT) {
+        zi = 0;
+        uint32_t first = 0u;
+#pragma unroll
+        for (int i = 1; i < WARP_BATCH; i++) {
+            const uint32_t f = B.first_wg[i];
+            const bool past = wg >= f;
+            zi = past ? i : zi;
+            first = past ? f : first;
+        }
+        wg -= first;
+    }
+    const WarpK& P = B.k[zi];
     // the two table pointers ride in the same batch of scalar loads as the per-image scalars below (left to the compiler they are
     // fetched after the early exit: one more dependent scalar-cache round trip in front of the table reads)
-    unsigned long long colT_a = (unsigned long long)B.colT[blockIdx.z], rowT_a = (unsigned long long)B.rowT[blockIdx.z];
+    unsigned long long colT_a = (unsigned long long)B.colT[zi], rowT_a = (unsigned long long)B.rowT[zi];
     const int lane = threadIdx.x & 63;
     // The per-image scalars of the tile-index math and of the tests below are fetched up front, as a few wide scalar
     // loads with one wait: a wavefront lives for 256 pixels only, and the compiler otherwise sinks every one of these
@@ -591,12 +617,12 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     // eighths — but then the curved-border bands unbalance the XCDs — and 360 MB with bands of 4 tile rows; the
     // kernel time is the same for all three).
     // divisions by the per-image constants use host-made reciprocals (n * m >> 32, exact for n * d < 2^32)
-    const uint32_t local = blockIdx.x >> 3;
+    const uint32_t local = wg >> 3;
     const uint32_t band_i = band_tiles == 1 ? local : __umulhi(local, magic_band);  // local / (band_rows * tiles_x)
     const uint32_t within = local - band_i * (uint32_t)band_tiles;
     const uint32_t wy = tiles_x == 1 ? within : __umulhi(within, magic_tx);  // within / tiles_x (2^32 / 1 has no 32-bit magic)
     const int tile_x = (int)(within - wy * (uint32_t)tiles_x);
-    const int tile_y = (int)((band_i * 8u + (blockIdx.x & 7u)) * (uint32_t)band_rows + wy);
+    const int tile_y = (int)((band_i * 8u + (wg & 7u)) * (uint32_t)band_rows + wy);
     if (tile_y >= tiles_y) return;
     // Lane layout: a wavefront covers 64 columns x WARP_TH rows, one lane = one column, its WARP_TH pixels one below
     // the other (the workgroup's four wavefronts sit side by side: a 256 x 4 tile).  For every row the 64 lanes then
@@ -1240,13 +1266,31 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
             // one launch in this bracket: with the profiler on its events are attached to the launch itself (the kernel's own begin / end
             // stamps, what rocprofv3 reports), not recorded around it
             StxProfScope prof(ctx, prof_name, bytes, nullptr, true);
-            int per_xcd = 0;  // workgroups each XCD needs: its share of the bands, whole bands only
+            // workgroups an image needs: 8 x (its share of the bands per XCD, whole bands only) x tiles per row.  Two grids:
+            //   z grid   : (the LARGEST image's workgroups, 1, images) — the image is blockIdx.z, nothing to look up; workgroups beyond an
+            //              image's own count exit at once, which costs their dispatch: a column of config 3 (ROIs of 7965 x 3024 next to
+            //              4122 x 2783) launches 28 % empty workgroups;
+            //   flat grid: one 1-D grid, image i owns [first_wg[i], first_wg[i + 1]) — no empty workgroups, but every workgroup makes one
+            //              more dependent scalar load before its per-image block.
+            // Measured (round 6, one box, profiles/r06_warp_split.md): config 2 (equal ROIs) 180-181 us z against 183-188 flat; a column
+            // of config 3 235 z against 223 flat; config 4's 8 frames 1190 z against 1129 flat.  The flat grid is taken when the z grid
+            // would launch more than 5 % empty workgroups (STX_WARP_ZGRID=1 builds a library that never does: the A/B).
+            unsigned long long wgs = 0, wg_max = 0;
+            for (int i = 0; i < WARP_BATCH; i++) B.first_wg[i] = 0xffffffffu;
             for (int i = 0; i < m; i++) {
                 const int tx = (B.k[i].dw + WARP_FW - 1) / WARP_FW, ty = (B.k[i].dh + WARP_FTH - 1) / WARP_FTH;
                 const int wb = B.k[i].band_rows, bands = (ty + wb - 1) / wb;
-                per_xcd = std::max(per_xcd, ((bands + 7) / 8) * wb * tx);
+                const unsigned long long own = 8ull * (unsigned long long)(((bands + 7) / 8) * wb) * (unsigned long long)tx;
+                B.first_wg[i] = (uint32_t)wgs;
+                wgs += own;
+                wg_max = std::max(wg_max, own);
             }
-            const dim3 gf(8 * per_xcd, 1, m);  // 1-D tile index per image, see the kernel's XCD-aware order
+            if (wgs >= (1ull << 31)) {
+                stx_dev_free(ctx, tab);
+                return stx_fail(STX_ERR_UNSUPPORTED, "warp batch of %llu tiles exceeds the grid", wgs);
+            }
+            const bool flat = !STX_WARP_ZGRID && !dbg && (double)wgs < 0.95 * (double)(wg_max * (unsigned long long)m);
+            const dim3 gf(flat ? (unsigned)wgs : (unsigned)wg_max, 1, flat ? 1 : m);
             // STITCHING_AMD_WARP_LDS (diagnostic): bytes of dynamic LDS requested on top of the kernel's own — an occupancy limit
             // (160 KB per CU / request = workgroups per CU) for co-residency experiments with the other panorama's kernels
             static const unsigned pad_lds = getenv("STITCHING_AMD_WARP_LDS") ? (unsigned)atoi(getenv("STITCHING_AMD_WARP_LDS")) : 0u;
@@ -1255,10 +1299,15 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
         if (prof.start()) hipExtLaunchKernelGGL((__VA_ARGS__), gf, dim3(WARP_FW), pad_lds, s, prof.start(), prof.stop(), 0, B);     \
         else hipLaunchKernelGGL((__VA_ARGS__), gf, dim3(WARP_FW), pad_lds, s, B);                                                   \
     } while (0)
-#define STX_FAST_LAUNCH(I, M, R)                                                   \
-    do {                                                                           \
-        if (gain) STX_FAST_LAUNCH_K(warp_fast_kernel<TYPE, I, M, false, R, true>);  \
-        else STX_FAST_LAUNCH_K(warp_fast_kernel<TYPE, I, M, false, R, false>);      \
+#define STX_FAST_LAUNCH_G(I, M, R, G)                                                    \
+    do {                                                                                 \
+        if (flat) STX_FAST_LAUNCH_K(warp_fast_kernel<TYPE, I, M, false, R, G, true>);     \
+        else STX_FAST_LAUNCH_K(warp_fast_kernel<TYPE, I, M, false, R, G, false>);         \
+    } while (0)
+#define STX_FAST_LAUNCH(I, M, R)                              \
+    do {                                                      \
+        if (gain) STX_FAST_LAUNCH_G(I, M, R, true);           \
+        else STX_FAST_LAUNCH_G(I, M, R, false);               \
     } while (0)
 #define STX_FAST_LAUNCH_RM(I, M)                                             \
     do {                                                                     \
@@ -1269,9 +1318,10 @@ int launch_typed(stx_ctx* ctx, const WarpK* Ks, int n, bool img, bool mask, cons
             if (dbg) STX_FAST_LAUNCH_K(warp_fast_kernel<TYPE, false, false, true>);
             else if (img && mask) STX_FAST_LAUNCH_RM(true, true);
             else if (img) STX_FAST_LAUNCH_RM(true, false);
-            else STX_FAST_LAUNCH_K(warp_fast_kernel<TYPE, false, true>);
+            else STX_FAST_LAUNCH_G(false, true, STX_REMAP_Q15, false);
 #undef STX_FAST_LAUNCH_RM
 #undef STX_FAST_LAUNCH
+#undef STX_FAST_LAUNCH_G
 #undef STX_FAST_LAUNCH_K
         } else {
             for (int i = 0; i < m; i++) {
