@@ -238,8 +238,13 @@ class DeviceImage:
 
 
 def as_device(img, ctx=None, wait=True):
-    """numpy array or DeviceImage -> DeviceImage on `ctx` (uploads when needed; wait: see DeviceImage.from_numpy)."""
+    """numpy array, cv.UMat or DeviceImage -> DeviceImage on `ctx` (uploads when needed; wait: see DeviceImage.from_numpy).
+    A cv.UMat is what the reference's own classes hand on where cv2 produced one — the seam masks of `SeamFinder.resize`
+    (stitching/seam_finder.py:37-43) reach `Blender.feed` that way when only Warper and Blender are switched — its array comes out of
+    `.get()`."""
     if isinstance(img, DeviceImage):
         return img
+    if not isinstance(img, np.ndarray) and hasattr(img, "get"):
+        img = img.get()
     return DeviceImage.from_numpy(img, ctx, wait)
 

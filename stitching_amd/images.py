@@ -38,7 +38,10 @@ class MegapixScaler:
         self.scale = None
 
     def get_scale_by_resolution(self, resolution):
-        return float(np.sqrt(self.megapix * 1e6 / resolution)) if self.megapix > 0 else 1.0
+        # numpy.float64 when it is computed, the Python float 1.0 otherwise — exactly the reference's types: Images.get_ratio hands the
+        # quotient to Warper.get_K, whose `K[0, 0] *= aspect` multiplies in float64 for a numpy.float64 and (NumPy >= 2) in float32 for a
+        # Python float, a difference of one unit in the last place of K (tests/test_gpu_reference_glue.py found it)
+        return np.sqrt(self.megapix * 1e6 / resolution) if self.megapix > 0 else 1.0
 
     def set_scale(self, scale):
         self.scale, self.is_scale_set = scale, True

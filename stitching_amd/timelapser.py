@@ -4,6 +4,8 @@
 Writing the JPEG (cv.imwrite, timelapser.py:38) stays with the caller: no image codec lives in this package."""
 import os
 
+import numpy as np
+
 from . import _lib, config
 from .blender import Blender
 from .device import DeviceImage, as_device, get_context
@@ -61,11 +63,17 @@ class Timelapser:
         return self._frame if config.device_resident() else self._frame.numpy()
 
     def process_and_save_frame(self, img_name, img, corner, writer=None):
-        """`writer(filename, frame)` stands where the reference calls cv.imwrite (timelapser.py:38)."""
+        """`writer(filename, frame)` stands where the reference calls cv.imwrite (timelapser.py:38): cv2's when it is importable — the
+        unmodified `Stitcher.blend_images` (stitching/stitcher.py:247-252) passes none — else it has to be given."""
         self.process_frame(img, corner)
         if writer is None:
-            raise StitchingError("no image codec in stitching_amd: pass writer=cv.imwrite (or any callable)")
-        writer(self.get_fixed_filename(img_name), self.get_frame())
+            try:
+                import cv2 as cv
+            except ImportError as e:
+                raise StitchingError("no image codec in stitching_amd and cv2 is not importable: pass writer= (any callable(filename, frame))") from e
+            writer = cv.imwrite
+        frame = self.get_frame()
+        writer(self.get_fixed_filename(img_name), frame if isinstance(frame, np.ndarray) else np.asarray(frame))
 
     def get_fixed_filename(self, img_name):
         dirname, filename = os.path.split(img_name)
