@@ -64,7 +64,11 @@ int stx_get_trig_mode(void);
  *                        row, cvRound(b (u - t) + t), every step rounded to fp32 (multiply and add separate);
  *   STX_REMAP_FLOAT_FMA  the same with each multiply-add fused.
  * The float modes are a MODEL of that build (oracle/stx_oracle.cpp: bilinear_px_float), unverified against it like everything here
- * that restates OpenCV; they run on the plain one-pixel-per-lane kernels.  Masks (INTER_NEAREST) are the same in every mode.
+ * that restates OpenCV.  Since round 5 they run on the tuned batched kernel like the default: wavefronts whose samples all lie inside the
+ * source blend in fp32 straight from the same two 12-byte windows per row (warp_fast_kernel<.., RM>, blend_float_to_lds), wavefronts that
+ * touch a border go one pixel at a time (sample_float); 0.90 x the default's rate on config 2.  Only what the tuned kernel does not
+ * take at all (sources beyond 32767 px or 2 GB, a nearest-neighbour source image) runs on the plain one-pixel-per-lane kernels, in any
+ * mode.  Masks (INTER_NEAREST) are the same in every mode.
  * Process-wide: STITCHING_AMD_REMAP = q15 | float | float-fma at first use, or stx_set_remap_mode. */
 #define STX_REMAP_Q15 0
 #define STX_REMAP_FLOAT 1

@@ -661,20 +661,30 @@ STX_EXPORT int stx_block_gain_apply_batch(stx_ctx* ctx, int n, stx_buf* const* i
     // horizontally interpolated rows are kept: gh x w floats); anything else takes the plain kernel, one image at a time
     std::vector<stx_buf*> bi;
     std::vector<const stx_buf*> bg;
-    std::vector<int> sub, fast;
+    std::vector<int> sub, fast, plain;
     size_t scratch = 0;
     std::vector<size_t> offH, offY;
+    // classify and validate EVERY image before anything is launched: the product is written in place, so a call that fails must not
+    // have multiplied some of its images already (a caller could not retry it)
     for (int i = 0; i < n; i++) {
         const stx_buf* im = imgs[i];
         const bool whole = !im->parent && ((uintptr_t)im->ptr & 3) == 0 && (im->stride & 3) == 0 && (size_t)((im->w + 3) & ~3) * 3 <= im->stride;
         const size_t hbytes = (size_t)gain_maps[i]->h * ((im->w + 3) & ~3) * gain_maps[i]->c * sizeof(float);
-        const bool same_c = bi.empty() || gain_maps[i]->c == bg[0]->c;
+        int first_c = -1;
+        for (int j = 0; j < i && first_c < 0; j++)
+            if (std::find(plain.begin(), plain.end(), j) == plain.end()) first_c = gain_maps[j]->c;
+        const bool same_c = first_c < 0 || gain_maps[i]->c == first_c;
         if (!whole || hbytes > ((size_t)64 << 20) || !same_c) {
             if (full_wh_xy0 && (full_wh_xy0[4 * i] != im->w || full_wh_xy0[4 * i + 1] != im->h))
                 return stx_fail(STX_ERR_UNSUPPORTED, "image %d: a rectangle of a larger image must be a whole buffer with a block-sized gain map", i);
-            STX_TRY(block_gain_plain(ctx, imgs[i], gain_maps[i]));
-            continue;
+            plain.push_back(i);
         }
+    }
+    for (int i : plain) STX_TRY(block_gain_plain(ctx, imgs[i], gain_maps[i]));
+    for (int i = 0; i < n; i++) {
+        if (std::find(plain.begin(), plain.end(), i) != plain.end()) continue;
+        const stx_buf* im = imgs[i];
+        const size_t hbytes = (size_t)gain_maps[i]->h * ((im->w + 3) & ~3) * gain_maps[i]->c * sizeof(float);
         bi.push_back(imgs[i]); bg.push_back(gain_maps[i]);
         for (int k = 0; k < 4; k++) sub.push_back(full_wh_xy0 ? full_wh_xy0[4 * i + k] : (k == 0 ? im->w : (k == 1 ? im->h : 0)));
         fast.push_back(flags_or_null && (flags_or_null[i] & STX_GAIN_MAP_BOUNDED) ? 1 : 0);
@@ -711,6 +721,15 @@ STX_EXPORT int stx_seam_mask_resize(stx_ctx* ctx, const stx_buf* seam_mask, cons
     if (seam_mask->c != 1 || seam_mask->elem != STX_U8 || final_mask->c != 1 || final_mask->elem != STX_U8)
         return stx_fail(STX_ERR_INVALID, "seam masks are u8x1");
     STX_TRY(stx_set_device(ctx));
+    if (seam_mask->ctx->device == ctx->device && final_mask->ctx->device == ctx->device) {  // the one-launch form first
+        stx_buf* d = nullptr;
+        STX_TRY(stx_buf_new(ctx, final_mask->w, final_mask->h, 1, STX_U8, &d));
+        bool done = false;
+        const int rc = stx_launch_seam_resize_lds(ctx, 1, &seam_mask, &final_mask, &d, nullptr, &done);
+        if (rc == STX_OK && done) { *out = d; return STX_OK; }
+        stx_buf_release(d);
+        if (rc != STX_OK) return rc;
+    }
     return resize_impl(ctx, seam_mask, final_mask->w, final_mask->h, true, final_mask, out);
 }
 
@@ -766,6 +785,21 @@ static int seam_resize_batch_impl(stx_ctx* ctx, int n, const stx_buf* const* sea
         }
     }
     final_masks = fm.data();
+    {
+        // the one-launch form: nothing to upload, no scratch (whole buffers of the library's own qualify; anything else: the tables below)
+        std::vector<stx_buf*> d1(n, nullptr);
+        int rc1 = STX_OK;
+        for (int i = 0; i < n && rc1 == STX_OK; i++) rc1 = stx_buf_new(ctx, final_masks[i]->w, final_masks[i]->h, 1, STX_U8, &d1[i]);
+        bool done = false;
+        if (rc1 == STX_OK) rc1 = stx_launch_seam_resize_lds(ctx, n, seam_masks, final_masks, d1.data(), sub, &done);
+        if (rc1 != STX_OK || !done) {
+            for (stx_buf* d : d1) stx_buf_release(d);
+            if (rc1 != STX_OK) return rc1;
+        } else {
+            for (int i = 0; i < n; i++) outs[i] = d1[i];
+            return STX_OK;
+        }
+    }
     // tables of all images in one upload: per image xt (dw rounded up to 4 entries) then yt
     std::vector<int> all;
     std::vector<size_t> xoff(n), yoff(n);

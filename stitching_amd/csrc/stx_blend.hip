@@ -1416,6 +1416,185 @@ int stx_launch_seam_resize_batch(stx_ctx* ctx, int n, const stx_buf* const* seam
     return check_launch("seam_mask_resize");
 }
 
+// ---------------------------------------------------------------------------------------------
+// SeamFinder.resize as ONE launch (round 6; stitching/seam_finder.py:37-43, stitching/stitcher.py:124,223-225).
+// Until round 5 a panorama's seam masks took a table upload (448 KB of coefficients made by the host in double precision), a dilate
+// launch into a global scratch and the resize launch with byte gathers from that scratch (81.6 us for config 2's eight masks, 0.24 of
+// the HBM peak).  Here a workgroup owns a 512 x 64 tile of the destination:
+//   * the coefficients of its 512 columns and 64 rows are made IN the kernel with the same IEEE double operations the host table used
+//     (scale * (v + 0.5) - 0.5, floor, rint of the fraction * 256 — interpolationLinear<ufixedpoint16>::getCoeffs; this file is built
+//     with -ffp-contract=off) and kept in LDS: nothing is uploaded;
+//   * the low-resolution source window under the tile (+ 1 px) goes to LDS, is dilated 3 x 3 there, and every tap is an LDS byte;
+//   * a lane makes 8 adjacent pixels of 16 rows: the final-mask dwords of all its rows are requested before the window is prepared,
+//     the horizontal 8.8 sums live in registers and are redone only when the source row changes, a pixel costs two 24-bit
+//     multiply-adds and 3/4 of a byte permute, a row leaves as one 8-byte store.
+// Same integers as resize_exact_kernel<1, true> (the tests compare both with the CPU checker).
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int SEAM1_COLS = 8, SEAM1_ROWS = 16;
+constexpr int SEAM1_TW = 64 * SEAM1_COLS, SEAM1_TH = 4 * SEAM1_ROWS;
+struct Seam1K {
+    const uint8_t* src; long long sstride; int sw, sh;  // the low-resolution seam mask as the seam finder made it
+    uint8_t* dst; long long dstride; int dw, dh;         // the destination rectangle ...
+    const uint8_t* am; long long amstride;               // ... and the same rectangle of the final warped mask
+    int x0, y0;                                          // where the rectangle lies in the full final mask
+    double xscale, yscale;                               // 1 / (full width / sw), 1 / (full height / sh): the host's doubles
+};
+struct Seam1BatchK { Seam1K k[SEAM_BATCH]; int pitch, raw_bytes; };
+
+// interpolationLinear<ufixedpoint16>::getCoeffs for destination index v: (offset, coeff1 | interior << 16) — stx_api.cpp linear_exact_table
+STX_DEV int2 seam1_coeff(int v, double scale, int src_n)
+{
+    const double fval = scale * ((double)v + 0.5) - 0.5;
+    const int ival = (int)floor(fval);
+    int ofs = 0, c1 = 0, interior = 0;
+    if (ival >= 0 && src_n > 1) {
+        if (ival < src_n - 1) { ofs = ival; c1 = (int)rint((fval - (double)ival) * 256.0); interior = 1; }
+        else ofs = src_n - 1;
+    }
+    return make_int2(ofs, c1 | (interior << 16));
+}
+
+__global__ __launch_bounds__(256) void seam_resize_lds_kernel(Seam1BatchK B)
+{
+    extern __shared__ uint8_t s_win[];
+    __shared__ int2 s_xt[SEAM1_TW];
+    __shared__ int2 s_yt[SEAM1_TH];
+    const Seam1K& P = B.k[blockIdx.z];
+    const int X0 = blockIdx.x * SEAM1_TW, Y0 = blockIdx.y * SEAM1_TH;
+    if (X0 >= P.dw || Y0 >= P.dh) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x8 = X0 + lane * SEAM1_COLS, yb = Y0 + wv * SEAM1_ROWS;
+    const bool mine = x8 < P.dw && yb < P.dh;  // (the row pitch holds whole 8-pixel groups: host-checked)
+    // the final-mask bytes of this lane's rows: in flight while the window is prepared
+    uint2 am[SEAM1_ROWS];
+#pragma unroll
+    for (int r = 0; r < SEAM1_ROWS; r++)
+        am[r] = mine && yb + r < P.dh ? *reinterpret_cast<const uint2*>(P.am + (long long)(yb + r) * P.amstride + x8) : make_uint2(0u, 0u);
+    for (int i = tid; i < SEAM1_TW; i += 256) s_xt[i] = seam1_coeff(P.x0 + min(X0 + i, P.dw - 1), P.xscale, P.sw);
+    if (tid < SEAM1_TH) s_yt[tid] = seam1_coeff(P.y0 + min(Y0 + tid, P.dh - 1), P.yscale, P.sh);
+    __syncthreads();
+    // the source window under this tile
+    const int nx = min(SEAM1_TW, P.dw - X0), ny = min(SEAM1_TH, P.dh - Y0);
+    const int wx0 = s_xt[0].x, wx1 = min(s_xt[nx - 1].x + 1, P.sw - 1);
+    const int wy0 = s_yt[0].x, wy1 = min(s_yt[ny - 1].x + 1, P.sh - 1);
+    const int cw = wx1 - wx0 + 1, rh = wy1 - wy0 + 1, cw2 = cw + 2, pitch = B.pitch;
+    uint8_t* const s_raw = s_win;                 // (rh + 2) x (cw + 2): the window and one pixel around it, 0 outside the image
+    uint8_t* const s_dil = s_win + B.raw_bytes;   // rh x cw: cv::dilate(3 x 3) of it (pixels outside the image do not take part: 0 = no-op for max)
+    const float inv2 = 1.0f / (float)cw2, inv1 = 1.0f / (float)cw;
+    for (int i = tid; i < (rh + 2) * cw2; i += 256) {
+        int r = (int)((float)i * inv2);  // i / cw2: the estimate is one off at most (i < 2^24)
+        int c = i - r * cw2;
+        if (c < 0) { r--; c += cw2; } else if (c >= cw2) { r++; c -= cw2; }
+        const int sy = wy0 - 1 + r, sx = wx0 - 1 + c;
+        s_raw[r * pitch + c] = ((unsigned)sx < (unsigned)P.sw && (unsigned)sy < (unsigned)P.sh) ? P.src[(long long)sy * P.sstride + sx] : (uint8_t)0;
+    }
+    __syncthreads();
+    for (int i = tid; i < rh * cw; i += 256) {
+        int r = (int)((float)i * inv1);
+        int c = i - r * cw;
+        if (c < 0) { r--; c += cw; } else if (c >= cw) { r++; c -= cw; }
+        uint32_t m = 0;
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) m = max(m, (uint32_t)s_raw[(r + dy) * pitch + c + dx]);
+        s_dil[r * pitch + c] = (uint8_t)m;
+    }
+    __syncthreads();
+    if (!mine) return;
+    int o0[SEAM1_COLS], o1[SEAM1_COLS];
+    uint32_t c1[SEAM1_COLS];
+#pragma unroll
+    for (int j = 0; j < SEAM1_COLS; j++) {
+        const int2 t = s_xt[lane * SEAM1_COLS + j];
+        o0[j] = t.x - wx0;
+        o1[j] = min(t.x + 1, P.sw - 1) - wx0;
+        c1[j] = (uint32_t)t.y & 0xffffu;
+    }
+    uint32_t h0[SEAM1_COLS], h1[SEAM1_COLS];
+    int cur = -(1 << 30);
+    const uint32_t keep_lo = x8 + 4 <= P.dw ? 0xffffffffu : (x8 + 0 < P.dw ? 0xffffffffu >> (8 * (4 - (P.dw - x8))) : 0u);
+    const uint32_t keep_hi = x8 + 8 <= P.dw ? 0xffffffffu : (x8 + 4 < P.dw ? 0xffffffffu >> (8 * (8 - (P.dw - x8))) : 0u);
+#pragma unroll
+    for (int r = 0; r < SEAM1_ROWS; r++) {
+        const int y = yb + r;
+        if (y >= P.dh) break;
+        const int2 ty = s_yt[wv * SEAM1_ROWS + r];
+        const int row = __builtin_amdgcn_readfirstlane(ty.x);
+        if (row != cur) {
+            cur = row;
+            const uint8_t* d0 = s_dil + (cur - wy0) * pitch;
+            const uint8_t* d1 = s_dil + (min(cur + 1, P.sh - 1) - wy0) * pitch;
+#pragma unroll
+            for (int j = 0; j < SEAM1_COLS; j++) {
+                const uint32_t a0 = 256u - c1[j];
+                h0[j] = (uint32_t)d0[o0[j]] * a0 + (uint32_t)d0[o1[j]] * c1[j];
+                h1[j] = (uint32_t)d1[o0[j]] * a0 + (uint32_t)d1[o1[j]] * c1[j];
+            }
+        }
+        const uint32_t cy1 = (uint32_t)__builtin_amdgcn_readfirstlane(ty.y) & 0xffffu, cy0 = 256u - cy1;
+        const bool iy = (__builtin_amdgcn_readfirstlane(ty.y) >> 16) != 0;
+        uint32_t sum[SEAM1_COLS];  // the result is byte 2 of every sum: (h0 cy0 + h1 cy1 + 2^15) >> 16 <= 255, ((h0 + 128) >> 8) << 16 likewise
+#pragma unroll
+        for (int j = 0; j < SEAM1_COLS; j++)
+            sum[j] = iy ? __umul24(h1[j], cy1) + (__umul24(h0[j], cy0) + 32768u) : (h0[j] + 128u) << 8;
+        uint2 out;
+        out.x = __builtin_amdgcn_perm(sum[1], sum[0], 0x0c0c0602u) | __builtin_amdgcn_perm(sum[3], sum[2], 0x06020c0cu);
+        out.y = __builtin_amdgcn_perm(sum[5], sum[4], 0x0c0c0602u) | __builtin_amdgcn_perm(sum[7], sum[6], 0x06020c0cu);
+        out.x &= am[r].x & keep_lo;  // bytes beyond the image inside the row pitch: 0, whatever stands in the final mask's padding
+        out.y &= am[r].y & keep_hi;
+        *reinterpret_cast<uint2*>(P.dst + (long long)y * P.dstride + x8) = out;
+    }
+}
+}  // namespace
+
+// -> STX_OK and *done = true when the images qualified and the launch was made; *done = false: the caller takes the table path
+int stx_launch_seam_resize_lds(stx_ctx* ctx, int n, const stx_buf* const* seams, const stx_buf* const* masks, stx_buf* const* dsts,
+                               const int* full_wh_xy0, bool* done)
+{
+    *done = false;
+    static const bool off = getenv("STITCHING_AMD_SEAM_LDS") && atoi(getenv("STITCHING_AMD_SEAM_LDS")) == 0;
+    if (off) return STX_OK;
+    int pitch = 0, rows = 0;
+    for (int i = 0; i < n; i++) {
+        const stx_buf *m = masks[i], *d = dsts[i];
+        const size_t w8 = ((size_t)d->w + 7) & ~(size_t)7;
+        if (((uintptr_t)m->ptr & 7) || (m->stride & 7) || w8 > m->stride || ((uintptr_t)d->ptr & 7) || (d->stride & 7) || w8 > d->stride) return STX_OK;
+        const int fw = full_wh_xy0 ? full_wh_xy0[4 * i] : d->w, fh = full_wh_xy0 ? full_wh_xy0[4 * i + 1] : d->h;
+        const double xs = 1.0 / ((double)fw / (double)seams[i]->w), ys = 1.0 / ((double)fh / (double)seams[i]->h);
+        // source columns / rows under a tile: floor((n - 1) scale) + 2, and one more for the fraction the first one starts at
+        pitch = std::max(pitch, std::min(seams[i]->w, (int)std::ceil(SEAM1_TW * xs) + 3) + 2);
+        rows = std::max(rows, std::min(seams[i]->h, (int)std::ceil(SEAM1_TH * ys) + 3));
+    }
+    pitch = (pitch + 3) & ~3;
+    const size_t raw_bytes = (size_t)pitch * (rows + 2), lds = raw_bytes + (size_t)pitch * rows;
+    if (lds > (40u << 10)) return STX_OK;  // an enlargement factor near 1: the window would not leave room for a second workgroup per CU
+    for (int base = 0; base < n; base += SEAM_BATCH) {
+        const int m = std::min(SEAM_BATCH, n - base);
+        Seam1BatchK B = {};
+        B.pitch = pitch; B.raw_bytes = (int)raw_bytes;
+        int mdw = 0, mdh = 0;
+        double bytes = 0.0;
+        for (int i = 0; i < m; i++) {
+            const int g = base + i;
+            Seam1K& K = B.k[i];
+            K.src = seams[g]->ptr; K.sstride = (long long)seams[g]->stride; K.sw = seams[g]->w; K.sh = seams[g]->h;
+            K.dst = dsts[g]->ptr; K.dstride = (long long)dsts[g]->stride; K.dw = dsts[g]->w; K.dh = dsts[g]->h;
+            K.am = masks[g]->ptr; K.amstride = (long long)masks[g]->stride;
+            const int fw = full_wh_xy0 ? full_wh_xy0[4 * g] : K.dw, fh = full_wh_xy0 ? full_wh_xy0[4 * g + 1] : K.dh;
+            K.x0 = full_wh_xy0 ? full_wh_xy0[4 * g + 2] : 0; K.y0 = full_wh_xy0 ? full_wh_xy0[4 * g + 3] : 0;
+            K.xscale = 1.0 / ((double)fw / (double)K.sw); K.yscale = 1.0 / ((double)fh / (double)K.sh);
+            mdw = std::max(mdw, K.dw); mdh = std::max(mdh, K.dh);
+            bytes += (double)K.sw * K.sh + 2.0 * K.dw * K.dh;
+        }
+        StxProfScope prof(ctx, "seam_mask_resize", bytes);
+        hipLaunchKernelGGL(seam_resize_lds_kernel, dim3((mdw + SEAM1_TW - 1) / SEAM1_TW, (mdh + SEAM1_TH - 1) / SEAM1_TH, m), dim3(256), lds, ctx->stream, B);
+    }
+    *done = true;
+    return check_launch("seam_mask_resize");
+}
+
 int stx_launch_resize_exact(stx_ctx* ctx, const stx_buf* src, stx_buf* dst, const int* d_xt, const int* d_yt, bool dilate,
                             const stx_buf* andmask)
 {
@@ -1544,9 +1723,13 @@ __global__ __launch_bounds__(256) void gain_rows_kernel(BlockGainBatchK B)
         return;
     }
     const int r = blockIdx.y - 1;  // gain-map row
-    if (r >= P.gh || i >= P.w) return;
+    // the columns w .. round_up4(w) - 1 of the row pitch are written too (the gain of the last column): the consumers read a row in
+    // groups of 4 and multiply the image's ROW PADDING with what stands there — scratch left as it was made those padding bytes differ
+    // from run to run
+    const int wpad = (P.w + 3) & ~3;
+    if (r >= P.gh || i >= wpad) return;
     int sx; float a1;
-    gain_coeff(P.x0 + i, P.xscale, P.gw, true, sx, a1);
+    gain_coeff(P.x0 + min(i, P.w - 1), P.xscale, P.gw, true, sx, a1);
     const float a0 = stxd::fsub(1.f, a1);
     const float* row = P.gmap + (long long)r * P.gstride;
 #pragma unroll

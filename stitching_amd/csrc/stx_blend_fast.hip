@@ -328,9 +328,9 @@ STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, s
         w[6] = __builtin_amdgcn_alignbyte(d1.w, d1.z, s);
         w[7] = __builtin_amdgcn_alignbyte(d2.x, d1.w, s);
         w[8] = __builtin_amdgcn_alignbyte(d2.y, d2.x, s);
-        if (PK) {
-            // packed path (u8 image, 0 / 255 mask): outputs o = 0..3 use pixels 2o .. 2o+4 with weights 1 4 6 4 1;
-            // as pairs (out0,out1) = (p0,p2) + 4(p1,p3) + 6(p2,p4) + 4(p3,p5) + (p4,p6), (out2,out3) likewise from p4..p10
+        {
+            // packed image sums (the image is u8 in this kernel whatever its mask is): outputs o = 0..3 use pixels 2o .. 2o+4 with weights
+            // 1 4 6 4 1; as pairs (out0,out1) = (p0,p2) + 4(p1,p3) + 6(p2,p4) + 4(p3,p5) + (p4,p6), (out2,out3) likewise from p4..p10
             short* hs[3] = {hs0, hs1, hs2};
 #pragma unroll
             for (int c = 0; c < 3; c++) {
@@ -347,47 +347,46 @@ STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, s
                 const pk16 o23 = E + I + G * pk_splat(6) + (F + H) * pk_splat(4);
                 *reinterpret_cast<uint2*>(hs[c]) = make_uint2(unpk(o01), unpk(o23));
             }
-            if (yin) {
-                const uint32_t moff = (uint32_t)by * (uint32_t)im.mask0_stride + (uint32_t)a0;  // 11 bytes
-                const STX_GAS uint8_t* mq = gp(im.mask0) + (moff & ~3u);
-                const uint32_t ms = moff & 3u;
-                const v4u m = *reinterpret_cast<const STX_GAS v4u_a4*>(mq);
-                uint32_t mb[3];  // 0 / 255 -> 0 / 1: W_0 is exactly 0.f or 1.f, the fp32 row sums are small integers
-                mb[0] = __builtin_amdgcn_alignbyte(m.y, m.x, ms) & 0x01010101u;
-                mb[1] = __builtin_amdgcn_alignbyte(m.z, m.y, ms) & 0x01010101u;
-                mb[2] = __builtin_amdgcn_alignbyte(m.w, m.z, ms) & 0x01010101u;
-                const pk16 o01 = pk(pair_u8<0, 2>(mb)) + pk(pair_u8<4, 6>(mb)) + pk(pair_u8<2, 4>(mb)) * pk_splat(6) +
-                                 (pk(pair_u8<1, 3>(mb)) + pk(pair_u8<3, 5>(mb))) * pk_splat(4);
-                const pk16 o23 = pk(pair_u8<4, 6>(mb)) + pk(pair_u8<8, 10>(mb)) + pk(pair_u8<6, 8>(mb)) * pk_splat(6) +
-                                 (pk(pair_u8<5, 7>(mb)) + pk(pair_u8<7, 9>(mb))) * pk_splat(4);
-                *reinterpret_cast<float4*>(hw) = make_float4((float)(unpk(o01) & 0xffffu), (float)(unpk(o01) >> 16),
-                                                             (float)(unpk(o23) & 0xffffu), (float)(unpk(o23) >> 16));
-            } else {
-                *reinterpret_cast<float4*>(hw) = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            return;
         }
-#pragma unroll
-        for (int j = 0; j < 11; j++) {
-            px[j][0] = (int)byte_of(w, 3 * j);
-            px[j][1] = (int)byte_of(w, 3 * j + 1);
-            px[j][2] = (int)byte_of(w, 3 * j + 2);
-        }
+        // the mask's 11 bytes.  PK (host: every mask of the launch is 0 / 255): packed counts.  Otherwise (round 6) the SAME packed counts
+        // whenever every lane of the wavefront reads nothing but 0 and 255 — a resized seam mask (SeamFinder.resize) is grey only along
+        // its seams, a strip a dozen pixels wide — and the fp32 form (m / 255, row sums in pyrDown's order) for the wavefronts on a seam:
+        // for 0 / 255 bytes the two agree exactly (W_0 is 0.f or 1.f, the sums are small integers whatever the order).
+        uint32_t mw[3] = {0u, 0u, 0u};
         if (yin) {
             const uint32_t moff = (uint32_t)by * (uint32_t)im.mask0_stride + (uint32_t)a0;  // 11 bytes
             const STX_GAS uint8_t* mq = gp(im.mask0) + (moff & ~3u);
             const uint32_t ms = moff & 3u;
             const v4u m = *reinterpret_cast<const STX_GAS v4u_a4*>(mq);
-            uint32_t mw[3];
             mw[0] = __builtin_amdgcn_alignbyte(m.y, m.x, ms);
             mw[1] = __builtin_amdgcn_alignbyte(m.z, m.y, ms);
-            mw[2] = __builtin_amdgcn_alignbyte(m.w, m.z, ms);
-#pragma unroll
-            for (int j = 0; j < 11; j++) f[j] = fmul((float)byte_of(mw, j), INV255);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 11; j++) f[j] = 0.f;
+            mw[2] = __builtin_amdgcn_alignbyte(m.w, m.z, ms) & 0x00ffffffu;
         }
+        bool packed = PK;
+        if (!PK) {
+            // byte b is 0 or 255  <=>  b == 255 * (b >> 7)
+            const uint32_t odd = (mw[0] ^ (((mw[0] >> 7) & 0x01010101u) * 255u)) | (mw[1] ^ (((mw[1] >> 7) & 0x01010101u) * 255u)) |
+                                 (mw[2] ^ (((mw[2] >> 7) & 0x01010101u) * 255u));
+            packed = __builtin_amdgcn_ballot_w64(odd != 0u) == 0ull;
+        }
+        if (packed) {
+            uint32_t mb[3];  // 0 / 255 -> 0 / 1: W_0 is exactly 0.f or 1.f, the fp32 row sums are small integers
+            mb[0] = mw[0] & 0x01010101u;
+            mb[1] = mw[1] & 0x01010101u;
+            mb[2] = mw[2] & 0x01010101u;
+            const pk16 o01 = pk(pair_u8<0, 2>(mb)) + pk(pair_u8<4, 6>(mb)) + pk(pair_u8<2, 4>(mb)) * pk_splat(6) +
+                             (pk(pair_u8<1, 3>(mb)) + pk(pair_u8<3, 5>(mb))) * pk_splat(4);
+            const pk16 o23 = pk(pair_u8<4, 6>(mb)) + pk(pair_u8<8, 10>(mb)) + pk(pair_u8<6, 8>(mb)) * pk_splat(6) +
+                             (pk(pair_u8<5, 7>(mb)) + pk(pair_u8<7, 9>(mb))) * pk_splat(4);
+            *reinterpret_cast<float4*>(hw) = make_float4((float)(unpk(o01) & 0xffffu), (float)(unpk(o01) >> 16),
+                                                         (float)(unpk(o23) & 0xffffu), (float)(unpk(o23) >> 16));
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 11; j++) f[j] = fmul((float)byte_of(mw, j), INV255);  // (a row outside the image: mw = 0)
+#pragma unroll
+        for (int o = 0; o < 4; o++) hw[o] = h5f(f[2 * o], f[2 * o + 1], f[2 * o + 2], f[2 * o + 3], f[2 * o + 4]);
+        return;
     } else {
         // an 11-pixel run that meets a border: every load unconditional and from a position inside the image (so that all 44 of them
         // are in flight together), the CONSTANT-0 border of the weight as a select afterwards

@@ -211,6 +211,9 @@ int stx_launch_resize_exact(stx_ctx* ctx, const stx_buf* src, stx_buf* dst, cons
 
 int stx_launch_seam_resize_batch(stx_ctx* ctx, int n, const stx_buf* const* seams, const stx_buf* const* masks, stx_buf* const* dsts,
                                  const int* const* d_xt, const int* const* d_yt, uint8_t* const* tmp, const size_t* tstride);
+// SeamFinder.resize of n images as ONE launch (coefficients made in the kernel, dilation in LDS); full_wh_xy0 as stx_seam_mask_resize_batch_sub
+int stx_launch_seam_resize_lds(stx_ctx* ctx, int n, const stx_buf* const* seams, const stx_buf* const* masks, stx_buf* const* dsts,
+                               const int* full_wh_xy0, bool* done);
 // image-strip sharding: pack the columns [x0, x0 + w) of n images + masks into n flat buffers (one launch per 16 strips)
 int stx_launch_strip_pack(stx_ctx* ctx, int n, const stx_buf* const* imgs, const stx_buf* const* masks, const int* x0, const int* w,
                           stx_buf* const* dsts, const size_t* si, const size_t* sm, bool mask_bits);

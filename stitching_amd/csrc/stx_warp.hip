@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include <hip/hip_ext.h>
 
@@ -1526,10 +1527,23 @@ int stx_launch_roi_minmax(stx_ctx* ctx, int n, const StxProjector* projs, const 
                 while (done < nst && __atomic_load_n(stamps + done, __ATOMIC_ACQUIRE) == seq) done++;
                 if (done == nst) { seen = true; break; }
                 if ((spins & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(ROI_SPIN_US)) break;
+                // a polite spin: the x86 pause hint where it exists, a scheduler yield elsewhere (the library is host-portable)
+#if defined(__x86_64__) || defined(__i386__)
                 __builtin_ia32_pause();
+#elif defined(__aarch64__)
+                __asm__ __volatile__("yield");
+#else
+                std::this_thread::yield();
+#endif
             }
         }
         if (!seen) STX_HIP(hipStreamSynchronize(ctx->aux_stream));
+        else {
+            // every stamp was seen, so the kernel ran to its last block; a sticky asynchronous error (of it or of anything before it on
+            // this device) is still reported HERE, by the call that caused it, and not by some later, unrelated one
+            hipError_t qe = hipStreamQuery(ctx->aux_stream);
+            if (qe != hipSuccess && qe != hipErrorNotReady) STX_HIP(qe);
+        }
         for (int i = 0; i < cnt; i++) {
             // NaN-ignoring fold in the comparison form of the device loop
             float mnu = 3.402823466e+38f, mnv = mnu, mxu = -mnu, mxv = -mnu;

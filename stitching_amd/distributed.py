@@ -507,6 +507,8 @@ class ShardedStitchJob:
         self._local_comp = {}
         self.seam_masks = None if seam_masks is None else list(seam_masks)
         self._seam_dev = {}
+        self._seam_version = 0
+        self._agreed_inputs = None  # (gains version, seam-mask version) the ranks last compared digests under
         self.dist = group if group is not None else dist  # `dist`: the older name of the same argument
         if self.dist is not None:
             missing = [m for m in ("all_gather", "gather", "broadcast", "barrier", "all_reduce_min", "exchange_bytes") if not hasattr(self.dist, m)]
@@ -562,9 +564,38 @@ class ShardedStitchJob:
             self.plan_ = ShardPlan(corners, wsizes, self.owners, self.world, probe, self.exchange, self.mask_bits, balance=self.balance)
         self.last_num_bands = self.plan_.num_bands
         self._check_plan_agreement(refusal)
+        self._local_comp, self._seam_dev = {}, {}
+        self._agreed_inputs = self._inputs_version()
         if self.transport is None:
             self.transport = default_transport(self.ctx, self.rank, self.world, self.dist)
         return self.plan_
+
+    def set_seam_masks(self, seam_masks):
+        """New low-resolution seam masks (by global image order) for the following run()s: call it on EVERY rank between the same two
+        runs — the next run() compares digests again before a strip moves."""
+        self.seam_masks = None if seam_masks is None else list(seam_masks)
+        self._seam_dev = {}
+        self._seam_version += 1
+
+    def _inputs_version(self):
+        gv = getattr(self.compensator, "gains_version", 0) if self.compensator is not None else 0
+        # the gains and seam masks are also compared by identity: a caller that assigned `.gains` / `.seam_masks` directly is still noticed
+        ids = (id(getattr(self.compensator, "gains", None)), tuple(id(m) for m in self.seam_masks) if self.seam_masks is not None else None)
+        return (gv, self._seam_version, ids)
+
+    def _refresh_inputs(self):
+        """Gains (compensator.set_gains, e.g. re-estimated while a stream runs) or seam masks (set_seam_masks) changed since the ranks
+        last agreed: drop everything derived from the old ones — this rank's per-image compensators, the uploaded seam masks — and
+        compare digests again.  The agreement is a collective: set_gains / set_seam_masks must be called on every rank between the same
+        two run()s (SPMD); a rank that was left out keeps its peers in the all_gather until the group's timeout names it."""
+        v = self._inputs_version()
+        if v == self._agreed_inputs:
+            return
+        self._local_comp = {}
+        self._seam_dev = {}
+        if self._agreed_inputs is not None:
+            self._check_plan_agreement()
+        self._agreed_inputs = v
 
     def plan_digest(self):
         """What every rank must agree on before the first strip moves: the geometry (edges, messages) and everything process-wide that
@@ -612,6 +643,7 @@ class ShardedStitchJob:
         """warp + feed local images, exchange contribution strips, blend this rank's band.
         Returns device-resident (band u8x3, band mask u8)."""
         p = self.plan_ or self.plan()
+        self._refresh_inputs()
         # this rank's share of the ROI pass belongs to every panorama (as in StitchJob.run)
         local = {k: i for i, k in enumerate(self.my_orders)}
         corners, _ = self.warper.warp_rois([self.all_sizes[k] for k in self.my_orders], self.cameras, camera_arrays=self._cam_arrays)

@@ -43,6 +43,9 @@ class ExposureErrorCompensator:
         self.compensator_type = compensator
         self.nr_feeds, self.block_size = nr_feeds, block_size
         self.gains = None
+        # bumped by every set_gains(): whoever keeps something derived from the gains (ShardedStitchJob's per-run copies and its plan
+        # agreement) compares it with the version it derived from
+        self.gains_version = 0
         self._dev_gains = {}  # (context, image index) -> (DeviceImage of the gain map, STX_GAIN_MAP_BOUNDED flag): uploaded once
         self.compensator = estimator if estimator is not None else self._cv_estimator(compensator, nr_feeds, block_size)
 
@@ -63,6 +66,7 @@ class ExposureErrorCompensator:
         """gains[i]: scalar ("gain"), 3 per-channel BGR values ("channel") or the fp32 gain map ("gain_blocks":
         cv2's compensator.getMatGains()[i]) for image i."""
         self._dev_gains = {}
+        self.gains_version += 1
         if self.compensator_type == "gain_blocks":
             self.gains = [np.ascontiguousarray(np.asarray(g, np.float32).reshape(np.asarray(g).shape[:2])) for g in gains]
         elif self.compensator_type == "channel_blocks":  # CV_32FC3 gain maps (one BGR triple per block)

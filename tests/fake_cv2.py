@@ -94,7 +94,13 @@ class detail:
     Blender_NO = 0
 
     class CameraParams:
-        pass
+        """cv.detail.CameraParams(): attributes set by the caller; K() as cv2 computes it"""
+        focal, aspect, ppx, ppy = 1.0, 1.0, 0.0, 0.0
+
+        def K(self):
+            k = np.eye(3, dtype=np.float64)
+            k[0, 0], k[0, 2], k[1, 1], k[1, 2] = self.focal, self.ppx, self.focal * self.aspect, self.ppy
+            return k
 
     @staticmethod
     def resultRoi(corners, sizes):

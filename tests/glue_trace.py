@@ -275,7 +275,7 @@ class Replayer:
     NOT in `classes` are served by `fallback[label]` — a CPU stand-in of the reference's class (the oracle) for the partial switch of
     INTEGRATION.md §1 — and compared all the same.  `imwrite_log`: the list the test's cv2.imwrite stand-in appends (name, array) to."""
 
-    def __init__(self, trace, classes, frames, cameras, fallback=None, imwrite_log=None, umat=_UMatLike):
+    def __init__(self, trace, classes, frames, cameras, fallback=None, imwrite_log=None, umat=_UMatLike, compare=True):
         self.events = trace["events"]
         self.classes, self.fallback = classes, fallback or {}
         self.frames, self.cameras = frames, cameras
@@ -284,6 +284,9 @@ class Replayer:
         self.imwrite_log = imwrite_log if imwrite_log is not None else []
         self.umat = umat
         self.checked = 0
+        # compare=False: the calls are made, the results kept (self.tab), no array is compared — for a back end switched to another
+        # arithmetic model than the recording's (tests/test_gpu_opencv_golden.py compares the panorama with OpenCV's instead)
+        self.compare = compare
 
     def _cls(self, label):
         return self.classes[label] if label in self.classes else self.fallback[label]
@@ -339,7 +342,7 @@ class Replayer:
             a = np.asarray(got.get() if hasattr(got, "get") and not isinstance(got, np.ndarray) else got)
             if list(a.shape) != exp["shape"] or str(a.dtype) != exp["dtype"]:
                 raise ReplayMismatch(f"{where}: {a.shape} {a.dtype}, recorded {exp['shape']} {exp['dtype']}")
-            if sha(a) != exp["sha"]:
+            if self.compare and sha(a) != exp["sha"]:
                 raise ReplayMismatch(f"{where}: contents differ from the recording ({a.shape} {a.dtype})")
             if "ref" in exp:
                 self.tab[exp["ref"]] = got

@@ -27,6 +27,8 @@ SCENARIOS = {
     "stitcher_defaults": dict(cls="Stitcher", kwargs=dict(crop=False), cameras="ring"),
     # + the cropper (crop=True is the default): Blender.create_panorama for the mask, rectangles through cropper.py:64-88,150-151
     "stitcher_crop": dict(cls="Stitcher", kwargs=dict(), cameras="ring"),
+    # nothing estimated: no compensator, no seam finder — the scenario tools/write_opencv_golden.py records with REAL cv2 (GLUE there)
+    "stitcher_plain": dict(cls="Stitcher", kwargs=dict(crop=False, compensator="no", finder="no"), cameras="ring"),
     # AffineStitcher defaults (stitcher.py:267-275): affine warper, compensator "no", crop=True, multiband
     "affine_defaults": dict(cls="AffineStitcher", kwargs=dict(), cameras="affine"),
     # the other sink of the composition: timelapser.initialize / process_and_save_frame (stitcher.py:241-252)

@@ -52,7 +52,37 @@ def check_product_against(path, oracle):
         S.set_trig_mode(prev[0]); S.set_remap_mode(prev[1]); S.set_pyrdown_mode(*prev[2])
     assert warp_diff == pm["warp_differing_bytes"], (warp_diff, pm)
     assert blend_max <= 1, blend_max
+    if "glue/stitcher_plain/pano" in z.files:
+        rep["reference_glue_max_abs"] = glue_against(z, pm)
+        assert rep["reference_glue_max_abs"] <= 1, rep["reference_glue_max_abs"]  # the north star's bar on the final panorama
     return rep
+
+
+def glue_against(z, pm):
+    """The panorama the reference's own Stitcher.stitch composed over REAL cv2 (tools/write_opencv_golden.py: record_reference_glue)
+    against the product driven through the same calls (the recording `stitcher_plain`, replayed without digest comparison: the
+    product runs under the arithmetic modes the sweep named, the recording was made under the default ones)."""
+    from tests import fake_cv2_glue, glue_trace as GT, reference_glue as RG
+
+    frames, cams = RG.inputs("stitcher_plain")
+    fake_cv2_glue.install(cams)
+    pyr = pm["STITCHING_AMD_PYRDOWN"].split(":")
+    prev = (S.set_trig_mode(pm["STITCHING_AMD_TRIG"]), S.set_remap_mode(pm["STITCHING_AMD_REMAP"]),
+            S.set_pyrdown_mode(pyr[0], int(pyr[1]) if len(pyr) > 1 else 4))
+    try:
+        classes = {"Warper": S.Warper, "Blender": S.Blender, "ExposureErrorCompensator": S.ExposureErrorCompensator, "SeamFinder": S.SeamFinder,
+                   "Timelapser": S.Timelapser, "Images": S.Images}
+        tr = GT.load(RG.golden_path("stitcher_plain"))
+        rp = GT.Replayer(tr, classes, frames, cams, imwrite_log=fake_cv2_glue.WRITTEN, umat=fake_cv2_glue.UMat, compare=False)
+        rp.run()
+        blend = next(e for e in tr["events"] if e.get("name") == "blend")
+        pano = np.asarray(rp.tab[blend["ret"]["tuple"][0]["ref"]])
+    finally:
+        S.set_trig_mode(prev[0]); S.set_remap_mode(prev[1]); S.set_pyrdown_mode(*prev[2])
+        fake_cv2_glue.uninstall()
+    want = z["glue/stitcher_plain/pano"]
+    assert pano.shape == want.shape, (pano.shape, want.shape)
+    return int(np.abs(pano.astype(np.int16) - want.astype(np.int16)).max())
 
 
 @pytest.mark.skipif(not os.path.exists(G.GOLDEN), reason="no OpenCV-generated golden file committed: parity vs OpenCV is unpinned")

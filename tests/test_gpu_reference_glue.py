@@ -75,8 +75,15 @@ def test_resident_crop_slices_stay_on_the_device(oracle, gpu_ctx):
     tr = GT.load(RG.golden_path("stitcher_crop"))
     views = [a for e in tr["events"] for a in e.get("args", []) if isinstance(a, dict) and "view" in a]
     assert len(views) >= 6  # 3 final images + 3 final masks (and the low-resolution ones)
-    fed = [e for e in tr["events"] if e.get("name") == "feed"]
-    assert len(fed) == 3
+    blender = next(e["obj"] for e in tr["events"] if e["op"] == "new" and e["cls"] == "Blender")
+    fed = [e for e in tr["events"] if e.get("name") == "feed" and e.get("obj") == blender]
+    assert len(fed) == 3 and all("view" in e["args"][0] for e in fed) is False  # the fed images are COMPENSATED crops (new arrays), not views
+    applied = [e for e in tr["events"] if e.get("name") == "apply"]
+    assert len(applied) == 3 and all("view" in e["args"][2] and "view" in e["args"][3] for e in applied)  # crops of image and mask go in
+    for e in applied:  # and on the product they are device views of the warped images
+        v = e["args"][2]
+        base = rp.tab[v["view"]]
+        assert isinstance(base, S.DeviceImage) and base.shape[0] >= v["y"][1] and base.shape[1] >= v["x"][1]
 
 
 @pytest.mark.gpu

@@ -177,3 +177,68 @@ def test_sharded_default_composition_equals_oracle(oracle, gpu_ctx, btype):
     assert not jobs[0].plan_.mask_bits  # grey masks travel as bytes
     assert pano.shape == o_pano.shape
     assert np.array_equal(mask, o_mask) and np.array_equal(pano, o_pano), int(np.count_nonzero(pano != o_pano))
+
+
+def test_new_gains_and_seam_masks_between_runs_reach_every_rank(oracle, gpu_ctx):
+    """gains re-estimated while a stream runs (`compensator.set_gains`) and new seam masks (`set_seam_masks`) must reach
+    the sharded job's next run() — its per-rank compensator copies and uploaded seam masks are derived state — exactly as StitchJob picks
+    them up.  3 ranks x 2 frames, executed rank after rank with recorded strips; both panoramas against the oracle chain."""
+    from stitching_amd.distributed import ShardedStitchJob
+
+    w, h, world, per = 803, 601, 3, 2
+    cams = synthetic.ring_cameras(world * per, w, h, span_deg=200.0)
+    frames = [synthetic.make_frame(90 + i, w, h) for i in range(world * per)]
+    ow = oracle.Warper("spherical")
+    ow.set_scale(cams)
+    corners, sizes = ow.warp_rois([(w, h)] * len(cams), cams)
+    wm = [ow.create_and_warp_mask((w, h), c) for c in cams]
+    full = synthetic.voronoi_seam_masks(wm, corners, sizes)
+    rng = np.random.default_rng(29)
+
+    def inputs(step):
+        low = [np.ascontiguousarray(m[::step, ::step]) for m in full]
+        gains = [(0.8 + 0.4 * rng.random(((s[1] + 31) // 32, (s[0] + 31) // 32))).astype(np.float32) for s in sizes]
+        return low, gains
+
+    def oracle_pano(low, gains):
+        ob = oracle.Blender("multiband", 6)
+        ob.prepare(corners, sizes)
+        for f, c, g, l, m, corner in zip(frames, cams, gains, low, wm, corners):
+            ob.feed(oracle.block_gain_apply(ow.warp_image(f, c), g), oracle.seam_resize(l, m), corner)
+        return tuple(np.asarray(a) for a in ob.blend())
+
+    low1, gains1 = inputs(7)
+    comp = S.ExposureErrorCompensator("gain_blocks")
+    comp.set_gains(gains1)
+    jobs = []
+    for r in range(world):
+        job = ShardedStitchJob(frames[r * per:(r + 1) * per], cams[r * per:(r + 1) * per], cams, r, world, ctx=gpu_ctx,
+                               transport=helpers.StripRecorder(gpu_ctx), blend_strength=6, num_bands=None, compensator=comp, seam_masks=low1)
+        job.plan()
+        jobs.append(job)
+
+    def run_all():
+        recs = []
+        for job in jobs:
+            job.transport = helpers.StripRecorder(gpu_ctx)
+            del_ = job.run()
+            del del_
+            recs.append(job.transport)
+        bands = []
+        for r, job in enumerate(jobs):
+            inbox = {src: [a for dst, a in recs[src].sent if dst == r] for src in range(world) if src != r}
+            job.transport = helpers.StripReplay(gpu_ctx, inbox)
+            bands.append(tuple(np.asarray(a) for a in job.run()))
+        return np.concatenate([b[0] for b in bands], axis=1), np.concatenate([b[1] for b in bands], axis=1)
+
+    p1, m1 = run_all()
+    o1 = oracle_pano(low1, gains1)
+    assert np.array_equal(m1, o1[1]) and np.array_equal(p1, o1[0])
+    low2, gains2 = inputs(9)
+    comp.set_gains(gains2)
+    for job in jobs:
+        job.set_seam_masks(low2)
+    p2, m2 = run_all()
+    o2 = oracle_pano(low2, gains2)
+    assert not np.array_equal(o1[0], o2[0])
+    assert np.array_equal(m2, o2[1]) and np.array_equal(p2, o2[0]), int(np.count_nonzero(p2 != o2[0]))

@@ -483,3 +483,37 @@ def test_rccl_test_double_protocol():
     assert all(r["ok"] for r in res), res
     assert res[0]["rc"] != 0 and "receives 5 bytes from rank 1 which sends 6" in res[0]["err"]
     assert res[1]["rc"] == 0 and res[2]["rc"] == 0
+
+
+def test_sharded_job_notices_new_gains_and_seam_masks():
+    """ShardedStitchJob keeps per-rank compensator copies and uploaded seam masks; both are dropped, and the ranks
+    compare digests again, when the gains (set_gains bumps a version) or the seam masks (set_seam_masks, or a plain assignment) change
+    between two run()s — and only then."""
+    import stitching_amd as S
+    from stitching_amd.distributed import ShardedStitchJob
+
+    comp = S.ExposureErrorCompensator("gain")
+    assert comp.gains_version == 0
+    comp.set_gains([1.0, 1.1])
+    assert comp.gains_version == 1
+    job = object.__new__(ShardedStitchJob)  # the bookkeeping alone: no device behind it
+    job.compensator, job.seam_masks, job._seam_version = comp, [np.zeros((2, 2), np.uint8)], 0
+    job._local_comp, job._seam_dev, job._agreed_inputs = {"stale": 1}, {"stale": 1}, None
+    calls = []
+    job._check_plan_agreement = lambda refusal=None: calls.append(1)
+    job._agreed_inputs = job._inputs_version()  # what plan() does after its own agreement round
+    job._refresh_inputs()
+    assert calls == [] and job._local_comp == {"stale": 1}
+    comp.set_gains([1.2, 1.3])
+    job._refresh_inputs()
+    assert calls == [1] and job._local_comp == {} and job._seam_dev == {}
+    job._refresh_inputs()
+    assert calls == [1]
+    job._seam_dev = {"stale": 1}
+    job.set_seam_masks([np.ones((2, 2), np.uint8)])
+    assert job._seam_dev == {}
+    job._refresh_inputs()
+    assert calls == [1, 1]
+    job.seam_masks = [np.ones((3, 3), np.uint8)]  # assigned behind the setter's back: noticed by identity
+    job._refresh_inputs()
+    assert calls == [1, 1, 1]

@@ -405,3 +405,48 @@ def test_gains_fused_into_the_warp_equal_the_separate_pass(oracle, gpu_ctx, wtyp
     cs.set_gains([1.1, 0.9, 1.05, 1.2][:len(cams)])
     si, _, _ = g.warp_images_and_masks(imgs, cams, compensator=cs)
     assert np.array_equal(np.asarray(si[2]), oracle.gain_apply(o.warp_image(imgs[2], cams[2]), 1.05))
+
+
+@pytest.mark.gpu
+def test_seam_mask_resize_one_launch_sweep(oracle, gpu_ctx):
+    """The one-launch SeamFinder.resize (coefficients made in the kernel in double precision, dilation in LDS: round 6) against the CPU
+    checker over enlargement factors from 1 to 40, widths and heights that are no multiple of the 8 x 16 lane footprint or of the 512 x 64
+    tile, one-pixel-wide sources, grey final masks (the AND is bitwise), rectangles of a larger mask — singly and batched (mixed sizes
+    in one launch)."""
+    from stitching_amd.seam_finder import SeamFinder
+
+    rng = np.random.default_rng(77)
+    cases = [((37, 23), (407, 259)), ((64, 48), (64, 48)), ((9, 7), (1031, 517)), ((1, 5), (19, 333)), ((300, 2), (901, 65)),
+             ((50, 40), (520, 70)), ((121, 93), (3001, 771)), ((2, 2), (513, 65)), ((33, 77), (50, 100)), ((16, 16), (8, 8))]
+    lows, finals = [], []
+    for (sw, sh), (dw, dh) in cases:
+        low = (rng.random((sh, sw)) < 0.45).astype(np.uint8) * 255
+        low[rng.random((sh, sw)) < 0.05] = 77  # seam finders return 0 / 255; anything else must survive the same arithmetic
+        fin = np.where(rng.random((dh, dw)) < 0.8, 255, 0).astype(np.uint8)
+        fin[rng.random((dh, dw)) < 0.1] = 0x5a
+        lows.append(low)
+        finals.append(fin)
+    for low, fin in zip(lows, finals):
+        assert np.array_equal(np.asarray(SeamFinder.resize(low, fin)), oracle.seam_resize(low, fin)), (low.shape, fin.shape)
+    S.set_device_resident(True)
+    try:
+        dev = [S.DeviceImage.from_numpy(f, gpu_ctx) for f in finals]
+        out = SeamFinder.resize_all(lows, dev)
+        for o, low, fin in zip(out, lows, finals):
+            assert np.array_equal(np.asarray(o), oracle.seam_resize(low, fin)), (low.shape, fin.shape)
+        # rectangles (x0 a multiple of 4) of the full results
+        subs, rect_masks, want = [], [], []
+        for low, fin in zip(lows, finals):
+            dh, dw = fin.shape
+            if dw < 24 or dh < 8:
+                continue
+            x0, y0 = 4 * int(rng.integers(0, dw // 8)), int(rng.integers(0, dh // 2))
+            w, h = int(rng.integers(8, dw - x0 + 1)), int(rng.integers(4, dh - y0 + 1))
+            subs.append((low, (dw, dh, x0, y0)))
+            rect_masks.append(S.DeviceImage.from_numpy(np.ascontiguousarray(fin[y0:y0 + h, x0:x0 + w]), gpu_ctx))
+            want.append(oracle.seam_resize(low, fin)[y0:y0 + h, x0:x0 + w])
+        part = SeamFinder.resize_all([s[0] for s in subs], rect_masks, sub=[s[1] for s in subs])
+        for p, w_ in zip(part, want):
+            assert np.array_equal(np.asarray(p), w_)
+    finally:
+        S.set_device_resident(False)

@@ -21,7 +21,7 @@ def test_writer_imports_only_stdlib_numpy_cv2():
         elif isinstance(node, ast.ImportFrom):
             assert node.level == 0, "relative import"
             mods.add(node.module.split(".")[0])
-    assert mods <= {"json", "math", "platform", "sys", "numpy", "cv2"}, mods
+    assert mods <= {"json", "math", "platform", "sys", "numpy", "cv2", "stitching"}, mods  # `stitching`: the reference itself, optional
 
 
 def test_writer_inputs_equal_the_repositorys():
@@ -73,3 +73,31 @@ def test_writer_roundtrip_against_the_stand_in(oracle, tmp_path, monkeypatch):
     assert rp["plane_roi_corners"]["opencv_is"] == "size-1" and rp["plane_roi_corners"]["rois_equal_of_3"]["size-1"] == 3
     assert rp["affine_uses_K"]["opencv_is"] is True and rp["affine_uses_K"]["rois_equal_of_4"] == {"True": 4, "False": 0}
     assert max(rep["next_rows_max_abs"].values()) == 0
+
+
+def test_writer_records_the_reference_glue_against_the_stand_in(oracle):
+    """record_reference_glue — the reference's own Stitcher.stitch, registration taken out — against the cv2 stand-in where the
+    reference is importable: its panorama is the one the recording `stitcher_plain` ends with (tests/golden/reference_glue), so one
+    OpenCV-generated file pins the oracle AND the glue."""
+    import pytest
+
+    from tests import fake_cv2_glue, glue_trace, reference_glue as RG
+    from tools import write_opencv_golden as W
+
+    frames, cams = RG.inputs("stitcher_plain")
+    wf, wc = W.glue_inputs()
+    assert all(np.array_equal(a, b) for a, b in zip(frames, wf)) and W.GLUE["kwargs"] == RG.SCENARIOS["stitcher_plain"]["kwargs"]
+    for a, b in zip(wc, cams):
+        assert (a.focal, a.ppx, a.ppy) == (b.focal, b.ppx, b.ppy) and np.array_equal(a.R, np.asarray(b.R, np.float32))
+    if not RG.available():
+        pytest.skip("/root/reference is not present")
+    RG.load_reference(cams)
+    try:
+        out = {}
+        note = W.record_reference_glue(fake_cv2_glue, out)
+        assert note.startswith("stitching ")
+    finally:
+        RG.unload()
+    tr = glue_trace.load(RG.golden_path("stitcher_plain"))
+    blend = next(e for e in tr["events"] if e.get("name") == "blend")
+    assert glue_trace.sha(out["glue/stitcher_plain/pano"]) == blend["ret"]["tuple"][0]["sha"]

@@ -20,7 +20,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o kt
 cat "$OUT/kt_kernel_stats.csv"
 # PMC bytes per launch + rocprofv3's average durations, keyed by the kernel source hash: what bench.py quotes as `traffic` / `frac_rocprofv3`
 python tools/make_traffic_json.py "$OUT" "$OUT/traffic.json" "$OUT/kt_kernel_stats.csv"
-cp "$OUT/traffic.json" profiles/r05_traffic.json
+cp "$OUT/traffic.json" profiles/r06_traffic.json
 bash tools/prof_pmc_lite.sh ${TAG}_sq --streams 1 > /dev/null 2>&1; cp gpurun_out/${TAG}_sq/summary.txt "$OUT/sq_summary.txt"
 timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
 cat "$OUT/bench.json"

@@ -135,6 +135,13 @@ def main():
         tot_us += us
         print(f"  {i:3d} {yaw:7.1f} {pitch:7.1f}  {sizes[i][0]:6d} x {sizes[i][1]:5d}  {pw / (W * H):7.2f} {us:8.1f} {by / us / 1e3:8.1f} {us / (pw / 1e6):8.2f}   "
               f"| {st['tiles']:6d}  {st['interior']:6.3f} {st['mirror']:6.3f} {st['other']:6.3f} | {st['row_span']:10.1f} {st['x_span']:10.1f} {st['lines_per_load']:10.1f}")
+    # the same single launches with the images ALTERNATING (0, 1, 2, ..., 0, 1, ...): a launch that repeats one image finds its source
+    # (36 MB) and much of what it wrote last time in the 256 MB Infinity Cache; a round over all images has the batch's working set
+    def one_round():
+        for f, c in zip(frames, cams):
+            warper.warp_images_and_masks([f], [c])
+    us_rr, _ = timed(ctx, one_round, steps)
+    print(f"  one launch per image, images alternating: {us_rr * len(frames):.1f} us per round of {len(frames)} launches")
     us, by = timed(ctx, lambda: warper.warp_images_and_masks(frames, cams), steps)
     pw = sum(w * h for w, h in sizes)
     print(f"  all in one launch: {us:.1f} us, {by / us / 1e3:.1f} GB/s = {by / us / 1e3 / 8000:.3f} of 8 TB/s, {us / (pw / 1e6):.2f} us per dest Mpx "

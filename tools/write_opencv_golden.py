@@ -15,7 +15,8 @@ for byte).  The script only RECORDS: for every case the calls stitching/warper.p
     + setSharpness;  prepare / feed(UMat(int16)) / blend;  cv.convertScaleAbs
 
 — plus the probe inputs behind the four "recollection" questions of DESIGN.md section 2 (plane / affine warps of a noise image: no
-trig involved, every byte counts) and the next-row routines (resize INTER_LINEAR_EXACT, dilate + resize + AND, multiply, block gains).
+trig involved, every byte counts), the next-row routines (resize INTER_LINEAR_EXACT, dilate + resize + AND, multiply, block gains) and —
+when the reference itself is importable too (pip install stitching) — the panorama its own Stitcher.stitch composes (record_reference_glue).
 All analysis — which arithmetic model of the oracle this build follows, whether the product matches within the north-star bar — is
 done by the consumers of the file: tests/test_opencv_golden.py (CPU, the oracle) and tests/test_gpu_opencv_golden.py (the HIP path).
 """
@@ -253,6 +254,47 @@ def record_next_rows(cv, out):
     out["next/block_gain"] = _np(cv.multiply(img, cv.merge([full, full, full]), dtype=cv.CV_8UC3))
 
 
+# BASELINE config 1, "reference plumbing": the reference's OWN Stitcher.stitch over real cv2 on three weir-sized frames — when the
+# `stitching` package is importable next to cv2 (pip install stitching).  Registration is taken out (its six methods are replaced on the
+# instance: cameras are given), the composition half (stitching/stitcher.py:108-128: low-resolution warps, seam masks, final warps,
+# SeamFinder.resize, Blender) runs as the reference wrote it.  compensator "no" and finder "no" keep the estimation stages — whose
+# arithmetic nobody restates — out of the bytes.  The same scenario is `stitcher_plain` of tests/reference_glue.py.
+GLUE = {"frames": [3, 1000, 750, 40], "span": 172.0, "kwargs": {"crop": False, "compensator": "no", "finder": "no"}}
+
+
+def glue_inputs():
+    n, w, h, seed0 = GLUE["frames"]
+    s = min(1.0, math.sqrt(0.6e6 / (w * h)))  # Images.Resolution.MEDIUM (stitching/megapix_scaler.py): where the cameras live
+    wm, hm = int(round(w * s)), int(round(h * s))
+    return [make_frame(seed0 + i, w, h) for i in range(n)], ring_cameras(n, wm, hm, span_deg=GLUE["span"])
+
+
+def record_reference_glue(cv, out):
+    try:
+        import stitching
+    except ImportError:
+        return "the `stitching` package is not importable (pip install stitching): no reference-glue panorama recorded"
+    frames, cams = glue_inputs()
+
+    def camera_params(c):
+        p = cv.detail.CameraParams()
+        p.focal, p.aspect, p.ppx, p.ppy = c.focal, c.aspect, c.ppx, c.ppy
+        p.R = np.asarray(c.R, np.float32)
+        p.t = np.zeros((3, 1), np.float64)
+        return p
+
+    cameras = [camera_params(c) for c in cams]
+    s = stitching.Stitcher(**GLUE["kwargs"])
+    s.find_features = lambda imgs, feature_masks=[]: [None] * len(imgs)
+    s.match_features = lambda features: None
+    s.subset = lambda imgs, features, matches: (imgs, features, matches)
+    s.estimate_camera_parameters = lambda features, matches: cameras
+    s.refine_camera_parameters = lambda features, matches, cams_: cams_
+    s.perform_wave_correction = lambda cams_: cams_
+    out["glue/stitcher_plain/pano"] = _np(s.stitch(frames))
+    return "stitching " + str(getattr(stitching, "__version__", "?"))
+
+
 def main(argv):
     path = argv[1] if len(argv) > 1 else "opencv_golden.npz"
     import cv2 as cv
@@ -263,9 +305,12 @@ def main(argv):
         print(f"{name:32s} pano {out[name + '/pano'].shape}", flush=True)
     record_probes(cv, out)
     record_next_rows(cv, out)
+    glue = record_reference_glue(cv, out)
+    print("reference glue:", glue, flush=True)
     build = cv.getBuildInformation() if hasattr(cv, "getBuildInformation") else ""
     meta = {"format": FORMAT, "cv2": cv.__version__, "numpy": np.__version__, "python": platform.python_version(),
-            "machine": platform.machine(), "platform": platform.platform(), "build_information": build, "cases": CASES}
+            "machine": platform.machine(), "platform": platform.platform(), "build_information": build, "cases": CASES,
+            "reference_glue": {"recorded": glue, "scenario": GLUE}}
     out["__meta__"] = np.frombuffer(json.dumps(meta).encode(), np.uint8)
     np.savez_compressed(path, **out)
     print("OpenCV", cv.__version__, "->", path, f"({len(out)} arrays)")
