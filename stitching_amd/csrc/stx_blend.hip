@@ -1420,18 +1420,23 @@ int stx_launch_seam_resize_batch(stx_ctx* ctx, int n, const stx_buf* const* seam
 // SeamFinder.resize as ONE launch (round 6; stitching/seam_finder.py:37-43, stitching/stitcher.py:124,223-225).
 // Until round 5 a panorama's seam masks took a table upload (448 KB of coefficients made by the host in double precision), a dilate
 // launch into a global scratch and the resize launch with byte gathers from that scratch (81.6 us for config 2's eight masks, 0.24 of
-// the HBM peak).  Here a workgroup owns a 512 x 64 tile of the destination:
-//   * the coefficients of its 512 columns and 64 rows are made IN the kernel with the same IEEE double operations the host table used
+// the HBM peak).  Here a workgroup owns a 512 x 32 tile of the destination:
+//   * the coefficients of its 512 columns and 32 rows are made IN the kernel with the same IEEE double operations the host table used
 //     (scale * (v + 0.5) - 0.5, floor, rint of the fraction * 256 — interpolationLinear<ufixedpoint16>::getCoeffs; this file is built
 //     with -ffp-contract=off) and kept in LDS: nothing is uploaded;
 //   * the low-resolution source window under the tile (+ 1 px) goes to LDS, is dilated 3 x 3 there, and every tap is an LDS byte;
-//   * a lane makes 8 adjacent pixels of 16 rows: the final-mask dwords of all its rows are requested before the window is prepared,
+//   * a lane makes 8 adjacent pixels of 8 rows (rows per lane, one box, interleaved: 4: 48.4-50.0 us, 6: 48.6-49.4, 8: 47.7-49.1,
+//     16: 52.2-55.4, 32: 69.7-73.3 for config 2's eight masks): the final-mask dwords of all its rows are requested before the window is prepared,
 //     the horizontal 8.8 sums live in registers and are redone only when the source row changes, a pixel costs two 24-bit
 //     multiply-adds and 3/4 of a byte permute, a row leaves as one 8-byte store.
 // Same integers as resize_exact_kernel<1, true> (the tests compare both with the CPU checker).
 // ---------------------------------------------------------------------------------------------
 namespace {
-constexpr int SEAM1_COLS = 8, SEAM1_ROWS = 16;
+// rows per lane: -DSTX_SEAM1_ROWS=4 / 6 / 16 / 32 build the variants of the A/B (tools/gpu_r6g.sh)
+#ifndef STX_SEAM1_ROWS
+#define STX_SEAM1_ROWS 8
+#endif
+constexpr int SEAM1_COLS = 8, SEAM1_ROWS = STX_SEAM1_ROWS;
 constexpr int SEAM1_TW = 64 * SEAM1_COLS, SEAM1_TH = 4 * SEAM1_ROWS;
 struct Seam1K {
     const uint8_t* src; long long sstride; int sw, sh;  // the low-resolution seam mask as the seam finder made it

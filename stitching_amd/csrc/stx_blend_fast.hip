@@ -293,6 +293,42 @@ constexpr int LV_WAVES = STX_LV_WG_WAVES, LV_TH = 2 * LV_WAVES, LV_THREADS = 64 
 #endif
 constexpr int LV_BAND = STX_LV_BAND_ROWS / LV_TH;  // tile rows per XCD band
 
+// 36 bytes of an image row from byte offset `off` on (any alignment) as a little-endian byte stream w[0..8]
+STX_DEV void dn_load36(const STX_GAS uint8_t* img, uint32_t off, uint32_t (&w)[9])
+{
+    const STX_GAS uint8_t* q = img + (off & ~3u);
+    const uint32_t s = off & 3u;
+    const v4u d0 = *reinterpret_cast<const STX_GAS v4u_a4*>(q);
+    const v4u d1 = *reinterpret_cast<const STX_GAS v4u_a4*>(q + 16);
+    const v2u d2 = *reinterpret_cast<const STX_GAS v2u_a4*>(q + 32);
+    w[0] = __builtin_amdgcn_alignbyte(d0.y, d0.x, s);
+    w[1] = __builtin_amdgcn_alignbyte(d0.z, d0.y, s);
+    w[2] = __builtin_amdgcn_alignbyte(d0.w, d0.z, s);
+    w[3] = __builtin_amdgcn_alignbyte(d1.x, d0.w, s);
+    w[4] = __builtin_amdgcn_alignbyte(d1.y, d1.x, s);
+    w[5] = __builtin_amdgcn_alignbyte(d1.z, d1.y, s);
+    w[6] = __builtin_amdgcn_alignbyte(d1.w, d1.z, s);
+    w[7] = __builtin_amdgcn_alignbyte(d2.x, d1.w, s);
+    w[8] = __builtin_amdgcn_alignbyte(d2.y, d2.x, s);
+}
+// Packed horizontal 1-4-6-4-1 sums of channel C of the 11 BGR pixels in w[] (a u8 image): outputs o = 0..3 use pixels 2o .. 2o + 4; as
+// pairs (out0, out1) = (p0, p2) + 4 (p1, p3) + 6 (p2, p4) + 4 (p3, p5) + (p4, p6), (out2, out3) likewise from p4 .. p10.
+// MIRROR: the run was loaded in the opposite order (pixel k of the task is pixel 10 - k of w[]): the same sums from mirrored byte picks.
+template <bool MIRROR, int C>
+STX_DEV void dn_pack5_channel(const uint32_t* w, short* hs)
+{
+#define STX_PXB(k) (MIRROR ? 30 - 3 * (k) + C : 3 * (k) + C)
+    const pk16 A = pk(pair_u8<STX_PXB(0), STX_PXB(2)>(w)), Bp = pk(pair_u8<STX_PXB(1), STX_PXB(3)>(w));
+    const pk16 Cp = pk(pair_u8<STX_PXB(2), STX_PXB(4)>(w)), D = pk(pair_u8<STX_PXB(3), STX_PXB(5)>(w));
+    const pk16 E = pk(pair_u8<STX_PXB(4), STX_PXB(6)>(w)), F = pk(pair_u8<STX_PXB(5), STX_PXB(7)>(w));
+    const pk16 G = pk(pair_u8<STX_PXB(6), STX_PXB(8)>(w)), H = pk(pair_u8<STX_PXB(7), STX_PXB(9)>(w));
+    const pk16 I = pk(pair_u8<STX_PXB(8), STX_PXB(10)>(w));
+#undef STX_PXB
+    const pk16 o01 = A + E + Cp * pk_splat(6) + (Bp + D) * pk_splat(4);
+    const pk16 o23 = E + I + G * pk_splat(6) + (F + H) * pk_splat(4);
+    *reinterpret_cast<uint2*>(hs) = make_uint2(unpk(o01), unpk(o23));
+}
+
 // level 0 (u8 BGR + u8 mask): 4 outputs from 11 input pixels
 // PK: every image of the launch is u8 with a 0 / 255 mask (decided on the host: no per-task branch in the kernel)
 // NEAR: the border of the image inside its feed rectangle is narrower than the image (left, right <= iw, top, bottom <= ih: every
@@ -312,42 +348,11 @@ STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, s
     int px[11][3];
     float f[11];
     if (c0 >= 0 && c0 + 10 < im.fw && a0 >= 0 && a0 + 10 < im.iw) {
-        const uint32_t off = rowoff + (uint32_t)a0 * 3u;  // 33 bytes
-        const STX_GAS uint8_t* q = img + (off & ~3u);
-        const uint32_t s = off & 3u;
-        const v4u d0 = *reinterpret_cast<const STX_GAS v4u_a4*>(q);
-        const v4u d1 = *reinterpret_cast<const STX_GAS v4u_a4*>(q + 16);
-        const v2u d2 = *reinterpret_cast<const STX_GAS v2u_a4*>(q + 32);
         uint32_t w[9];
-        w[0] = __builtin_amdgcn_alignbyte(d0.y, d0.x, s);
-        w[1] = __builtin_amdgcn_alignbyte(d0.z, d0.y, s);
-        w[2] = __builtin_amdgcn_alignbyte(d0.w, d0.z, s);
-        w[3] = __builtin_amdgcn_alignbyte(d1.x, d0.w, s);
-        w[4] = __builtin_amdgcn_alignbyte(d1.y, d1.x, s);
-        w[5] = __builtin_amdgcn_alignbyte(d1.z, d1.y, s);
-        w[6] = __builtin_amdgcn_alignbyte(d1.w, d1.z, s);
-        w[7] = __builtin_amdgcn_alignbyte(d2.x, d1.w, s);
-        w[8] = __builtin_amdgcn_alignbyte(d2.y, d2.x, s);
-        {
-            // packed image sums (the image is u8 in this kernel whatever its mask is): outputs o = 0..3 use pixels 2o .. 2o+4 with weights
-            // 1 4 6 4 1; as pairs (out0,out1) = (p0,p2) + 4(p1,p3) + 6(p2,p4) + 4(p3,p5) + (p4,p6), (out2,out3) likewise from p4..p10
-            short* hs[3] = {hs0, hs1, hs2};
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const pk16 A = pk(c == 0 ? pair_u8<0, 6>(w) : c == 1 ? pair_u8<1, 7>(w) : pair_u8<2, 8>(w));
-                const pk16 Bp = pk(c == 0 ? pair_u8<3, 9>(w) : c == 1 ? pair_u8<4, 10>(w) : pair_u8<5, 11>(w));
-                const pk16 Cp = pk(c == 0 ? pair_u8<6, 12>(w) : c == 1 ? pair_u8<7, 13>(w) : pair_u8<8, 14>(w));
-                const pk16 D = pk(c == 0 ? pair_u8<9, 15>(w) : c == 1 ? pair_u8<10, 16>(w) : pair_u8<11, 17>(w));
-                const pk16 E = pk(c == 0 ? pair_u8<12, 18>(w) : c == 1 ? pair_u8<13, 19>(w) : pair_u8<14, 20>(w));
-                const pk16 F = pk(c == 0 ? pair_u8<15, 21>(w) : c == 1 ? pair_u8<16, 22>(w) : pair_u8<17, 23>(w));
-                const pk16 G = pk(c == 0 ? pair_u8<18, 24>(w) : c == 1 ? pair_u8<19, 25>(w) : pair_u8<20, 26>(w));
-                const pk16 H = pk(c == 0 ? pair_u8<21, 27>(w) : c == 1 ? pair_u8<22, 28>(w) : pair_u8<23, 29>(w));
-                const pk16 I = pk(c == 0 ? pair_u8<24, 30>(w) : c == 1 ? pair_u8<25, 31>(w) : pair_u8<26, 32>(w));
-                const pk16 o01 = A + E + Cp * pk_splat(6) + (Bp + D) * pk_splat(4);
-                const pk16 o23 = E + I + G * pk_splat(6) + (F + H) * pk_splat(4);
-                *reinterpret_cast<uint2*>(hs[c]) = make_uint2(unpk(o01), unpk(o23));
-            }
-        }
+        dn_load36(img, rowoff + (uint32_t)a0 * 3u, w);  // 33 bytes
+        dn_pack5_channel<false, 0>(w, hs0);  // packed image sums: the image is u8 in this kernel whatever its mask is
+        dn_pack5_channel<false, 1>(w, hs1);
+        dn_pack5_channel<false, 2>(w, hs2);
         // the mask's 11 bytes.  PK (host: every mask of the launch is 0 / 255): packed counts.  Otherwise (round 6) the SAME packed counts
         // whenever every lane of the wavefront reads nothing but 0 and 255 — a resized seam mask (SeamFinder.resize) is grey only along
         // its seams, a strip a dozen pixels wide — and the fp32 form (m / 255, row sums in pyrDown's order) for the wavefronts on a seam:
@@ -387,7 +392,24 @@ STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, s
 #pragma unroll
         for (int o = 0; o < 4; o++) hw[o] = h5f(f[2 * o], f[2 * o + 1], f[2 * o + 2], f[2 * o + 3], f[2 * o + 4]);
         return;
-    } else {
+    }
+    // Round 6.  An 11-pixel run that lies WHOLLY in the left or right border of the feed rectangle (copyMakeBorder's frame: 3 * 2^B
+    // columns either side, a fifth to a quarter of all runs at 7 bands or for seam-cell crops): BORDER_REFLECT maps it onto 11 ADJACENT
+    // pixels inside the image, in the opposite order — the same four vector loads and packed sums as an interior run with the byte
+    // picks mirrored, instead of 44 byte loads; the weight's border is CONSTANT 0.
+    if (c0 >= 0 && c0 + 10 < im.fw && (a0 + 10 < 0 || a0 >= im.iw)) {
+        const int s_low = a0 + 10 < 0 ? -(a0 + 10) - 1 : 2 * im.iw - 1 - (a0 + 10);  // source column of the run's LAST pixel = the lowest
+        if (s_low >= 0 && s_low + 10 < im.iw) {  // one mirror image away, all of it
+            uint32_t w[9];
+            dn_load36(img, rowoff + (uint32_t)s_low * 3u, w);
+            dn_pack5_channel<true, 0>(w, hs0);
+            dn_pack5_channel<true, 1>(w, hs1);
+            dn_pack5_channel<true, 2>(w, hs2);
+            *reinterpret_cast<float4*>(hw) = make_float4(0.f, 0.f, 0.f, 0.f);
+            return;
+        }
+    }
+    {
         // an 11-pixel run that meets a border: every load unconditional and from a position inside the image (so that all 44 of them
         // are in flight together), the CONSTANT-0 border of the weight as a select afterwards
         const STX_GAS uint8_t* mrow = gp(im.mask0) + (uint32_t)min(max(by, 0), im.ih - 1) * (uint32_t)im.mask0_stride;
