@@ -86,6 +86,57 @@ class SeamFinder:
         res = [DeviceImage(ctx, C.c_void_p(outs[i])) for i in range(n)]
         return res if config.device_resident() else [r.numpy() for r in res]
 
+    # the colours of stitching/seam_finder.py:81-91 (blend_seam_masks' default)
+    SEAM_COLORS = ((255, 0, 0), (0, 0, 255), (0, 255, 0), (0, 255, 255), (255, 0, 255), (128, 128, 255), (128, 128, 128), (0, 0, 128), (0, 128, 255))
+
+    @staticmethod
+    def blend_seam_masks(seam_masks, corners, sizes, colors=SEAM_COLORS):
+        """stitching/seam_finder.py:77-95: every image's seam cell in one colour, composed with the plain blender
+        (`Blender.create_panorama`: one gather on the device) — verbose mode's picture of who owns which panorama pixel."""
+        import warnings
+
+        from .blender import Blender
+
+        sizes = list(sizes)
+        if len(sizes) + 1 > len(colors):
+            warnings.warn("Without additional colors, there will be seam masks with identical colors", UserWarning)
+        imgs = (np.full((int(h), int(w), 3), colors[i % len(colors)], np.uint8) for i, (w, h) in enumerate(sizes))
+        blended, _ = Blender.create_panorama(imgs, seam_masks, corners, sizes)
+        return blended
+
+    @staticmethod
+    def _reference_plots():
+        """draw_seam_mask / draw_seam_polygons / draw_seam_lines / extract_seam_lines (stitching/seam_finder.py:45-75) are cv2 drawing code
+        for verbose mode (out of scope): they stay the reference's own — this back end sits behind that package."""
+        try:
+            from stitching.seam_finder import SeamFinder as Reference
+        except ImportError as e:
+            raise StitchingError("SeamFinder's plot helpers are the reference's (stitching.seam_finder), which is not importable here") from e
+        return Reference
+
+    @staticmethod
+    def _host_umat(mask):
+        """the reference's draw_seam_mask reads its mask through cv.UMat.get"""
+        import cv2 as cv
+
+        return mask if isinstance(mask, cv.UMat) else cv.UMat(np.ascontiguousarray(np.asarray(mask)))
+
+    @staticmethod
+    def draw_seam_mask(img, seam_mask, color=(0, 0, 0)):
+        return SeamFinder._reference_plots().draw_seam_mask(np.asarray(img), SeamFinder._host_umat(seam_mask), color)
+
+    @staticmethod
+    def draw_seam_polygons(panorama, blended_seam_masks, alpha=0.5):
+        return SeamFinder._reference_plots().draw_seam_polygons(np.asarray(panorama), np.asarray(blended_seam_masks), alpha)
+
+    @staticmethod
+    def draw_seam_lines(panorama, blended_seam_masks, linesize=1, color=(0, 0, 255)):
+        return SeamFinder._reference_plots().draw_seam_lines(np.asarray(panorama), np.asarray(blended_seam_masks), linesize, color)
+
+    @staticmethod
+    def extract_seam_lines(blended_seam_masks, linesize=1):
+        return SeamFinder._reference_plots().extract_seam_lines(np.asarray(blended_seam_masks), linesize)
+
     @staticmethod
     def resize(seam_mask, mask):
         """stitching/seam_finder.py:37-43 — returns the final-resolution seam mask for Blender.feed.  `seam_mask` may be

@@ -193,7 +193,10 @@ class Recorder:
         return v
 
     def io(self, name, arr):
-        """an image the back end wrote through cv.imwrite (the timelapser's frames): observed, attached to the running call"""
+        """an image the back end wrote through cv.imwrite (the timelapser's frames): observed, attached to the running call.  What the
+        GLUE writes itself (verbose.py's write_verbose_result) is not the back end's doing and is not recorded."""
+        if self.depth == 0:
+            return
         self._pending_io.append({"op": "io", "name": name, "shape": list(arr.shape), "dtype": str(arr.dtype), "sha": sha(arr)})
 
     # ------------------------------------------------------------------ proxies
@@ -268,6 +271,11 @@ class _UMatLike:
 
     def get(self):
         return self._a
+
+
+# SeamFinder's plot helpers (verbose mode: seam_finder.py:45-75): cv2 drawing code of the reference's own, whatever is switched — the
+# product hands them to the reference's class, which does not exist on the GPU box.  Never replayed; nothing later refers to their results.
+PLOT_HELPERS = ("draw_seam_mask", "draw_seam_polygons", "draw_seam_lines", "extract_seam_lines")
 
 
 class Replayer:
@@ -386,6 +394,9 @@ class Replayer:
             a = [self.dec(x) for x in ev.get("args", [])]
             kw = {k: self.dec(x) for k, x in ev.get("kwargs", {}).items()}
             io_before = len(self.imwrite_log)
+            if ev.get("name") in PLOT_HELPERS:
+                i += 1
+                continue
             try:
                 if ev["op"] == "new":
                     got = self._cls(ev["cls"])(*a, **kw)

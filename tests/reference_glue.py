@@ -29,6 +29,11 @@ SCENARIOS = {
     "stitcher_crop": dict(cls="Stitcher", kwargs=dict(), cameras="ring"),
     # nothing estimated: no compensator, no seam finder — the scenario tools/write_opencv_golden.py records with REAL cv2 (GLUE there)
     "stitcher_plain": dict(cls="Stitcher", kwargs=dict(crop=False, compensator="no", finder="no"), cameras="ring"),
+    # stitch_verbose (verbose.py:7-204): eager lists instead of generators, a Timelapser("as_is") of its own fed every final image,
+    # compensator.apply / seam_finder.resize through the instances, SeamFinder.blend_seam_masks (Blender.create_panorama of coloured
+    # images) and the plot helpers.  crop=False: with a cropper, blend_seam_masks asserts in the reference itself as soon as rounding clips
+    # a cropped mask (880 columns) below its scaled rectangle (882) — OpenCV's feed checks the same sizes
+    "stitcher_verbose": dict(cls="Stitcher", kwargs=dict(crop=False), cameras="ring", verbose=True),
     # AffineStitcher defaults (stitcher.py:267-275): affine warper, compensator "no", crop=True, multiband
     "affine_defaults": dict(cls="AffineStitcher", kwargs=dict(), cameras="affine"),
     # the other sink of the composition: timelapser.initialize / process_and_save_frame (stitcher.py:241-252)
@@ -117,13 +122,19 @@ def run(name, classes=None, recorder=None):
             fake_cv2_glue.IMWRITE_HOOK = recorder.io
         switch(use)
         stitcher = getattr(st, sc["cls"])(**sc["kwargs"])
-        pano = stitcher.stitch(frames)
+        if sc.get("verbose"):
+            import tempfile
+
+            with tempfile.TemporaryDirectory() as d:  # 00_stitcher.txt and 03_matches_graph.txt are real files; the images go to cv.imwrite
+                pano = stitcher.stitch_verbose(frames, verbose_dir=d)
+        else:
+            pano = stitcher.stitch(frames)
         return (None if pano is None else np.asarray(pano)), stitcher, list(fake_cv2_glue.WRITTEN)
     finally:
         unload()
 
 
-def cpu_reference_like():
+def cpu_reference_like(blender_cls=None):
     """{label: class} for the classes that are NOT switched in INTEGRATION.md §1's two-line form (ExposureErrorCompensator, SeamFinder,
     Timelapser stay the reference's): on the GPU box the reference's own classes do not exist, so their recorded calls are served by
     these few lines over the cv2 stand-in — the same cv2 calls the reference's classes make (exposure_error_compensator.py:22-45,
@@ -162,6 +173,13 @@ def cpu_reference_like():
             resized = cv.resize(dilated, (mask.shape[1], mask.shape[0]), 0, 0, cv.INTER_LINEAR_EXACT)
             return cv.bitwise_and(resized, mask)
 
+        @staticmethod
+        def blend_seam_masks(seam_masks, corners, sizes):
+            # seam_finder.py:77-95 with its default colours; `Blender` there is whatever the switch bound (blender_cls)
+            colors = ((255, 0, 0), (0, 0, 255), (0, 255, 0), (0, 255, 255), (255, 0, 255), (128, 128, 255), (128, 128, 128), (0, 0, 128), (0, 128, 255))
+            imgs = (np.full((h, w, 3), colors[i % len(colors)], np.uint8) for i, (w, h) in enumerate(sizes))
+            return blender_cls.create_panorama(imgs, seam_masks, corners, sizes)[0]
+
     class Timelapser:
         def __init__(self, timelapse="no", timelapse_prefix="fixed_"):
             self.do_timelapse = timelapse in ("as_is", "crop")
@@ -173,12 +191,17 @@ def cpu_reference_like():
         def initialize(self, *args):
             self.timelapser.initialize(*args)
 
-        def process_and_save_frame(self, img_name, img, corner):
+        def process_frame(self, img, corner):
             img = np.asarray(img)
             self.timelapser.process(img.astype(np.int16), np.ones(img.shape[:2], np.uint8), corner)
-            frame = cv.convertScaleAbs(np.float32(cv.UMat.get(self.timelapser.getDst())))
+
+        def get_frame(self):
+            return cv.convertScaleAbs(np.float32(cv.UMat.get(self.timelapser.getDst())))
+
+        def process_and_save_frame(self, img_name, img, corner):
+            self.process_frame(img, corner)
             d, f = os.path.split(img_name)
-            cv.imwrite(os.path.join(d, self.timelapse_prefix + f), frame)
+            cv.imwrite(os.path.join(d, self.timelapse_prefix + f), self.get_frame())
 
     return {"ExposureErrorCompensator": ExposureErrorCompensator, "SeamFinder": SeamFinder, "Timelapser": Timelapser}
 

@@ -21,12 +21,12 @@ def test_recordings_are_committed_and_well_formed(name):
     sc = RG.SCENARIOS[name]
     assert tr["meta"]["stitcher"] == sc["cls"] and tr["meta"]["kwargs"] == sc["kwargs"]
     ops = [e["op"] for e in tr["events"]]
-    assert ops.count("new") == 5 and {"call", "next", "static"} <= set(ops)
+    assert ops.count("new") == (6 if sc.get("verbose") else 5) and {"call", "next", "static"} <= set(ops)  # verbose: a Timelapser of its own
     # every class of INTEGRATION.md §1 takes part
     assert {e["cls"] for e in tr["events"] if e["op"] in ("new", "static")} == set(RG.LABELS)
     # lazy composition (stitcher.py:119-127): Blender.prepare runs BEFORE the first final-resolution image is warped
     names = [(e.get("name"), e["op"]) for e in tr["events"]]
-    if not tr["meta"]["kwargs"].get("timelapse"):
+    if not tr["meta"]["kwargs"].get("timelapse") and not sc.get("verbose"):  # (verbose mode builds lists: nothing lazy)
         prep = names.index(("prepare", "call"))
         final_warp = max(i for i, e in enumerate(tr["events"]) if e.get("name") == "warp_images")
         first_next_after = next(i for i, e in enumerate(tr["events"]) if i > final_warp and e["op"] == "next")
@@ -49,7 +49,7 @@ def test_recording_is_what_the_reference_does_today(oracle, name):
 
 
 @needs_reference
-@pytest.mark.parametrize("name", ["stitcher_defaults", "stitcher_crop", "stitcher_timelapse"])
+@pytest.mark.parametrize("name", ["stitcher_defaults", "stitcher_crop", "stitcher_timelapse", "stitcher_verbose"])
 def test_replayer_reproduces_the_recording_on_the_reference_classes(oracle, name):
     """the replayer itself, validated where the reference's classes exist: replaying the file over them must reproduce every digest"""
     from tests import fake_cv2_glue
@@ -86,12 +86,12 @@ def test_cpu_reference_like_classes_reproduce_the_recording(oracle):
     """the three classes that stay the reference's in the two-line switch, as the GPU box has to re-create them: same digests"""
     from tests import fake_cv2_glue
 
-    for name in ("stitcher_defaults", "stitcher_timelapse", "stitcher_no_channel_blocks"):
+    for name in ("stitcher_defaults", "stitcher_timelapse", "stitcher_no_channel_blocks", "stitcher_verbose"):
         frames, cams = RG.inputs(name)
         RG.load_reference(cams)
         try:
             classes = RG.reference_classes()
-            classes.update(RG.cpu_reference_like())
+            classes.update(RG.cpu_reference_like(classes["Blender"]))
             GT.Replayer(GT.load(RG.golden_path(name)), classes, frames, cams, imwrite_log=fake_cv2_glue.WRITTEN, umat=fake_cv2_glue.UMat).run()
         finally:
             RG.unload()
@@ -128,3 +128,29 @@ def test_the_stand_in_is_gone_afterwards():
 
     assert "stitching" not in sys.modules
     assert getattr(sys.modules.get("cv2"), "__version__", "") != "0.0-fake-oracle-glue"
+
+
+@needs_reference
+def test_product_seam_finder_hands_its_plot_helpers_to_the_reference(oracle):
+    """verbose mode's drawing code (seam_finder.py:45-75) stays the reference's: the product's SeamFinder delegates, converting what it
+    holds (arrays) into what that code reads (cv.UMat) — no GPU involved"""
+    import stitching_amd as S
+    from tests import fake_cv2_glue
+
+    frames, cams = RG.inputs("stitcher_defaults")
+    RG.load_reference(cams)
+    try:
+        ref = RG.reference_classes()["SeamFinder"]
+        img = frames[0][:40, :60].copy()
+        m = np.zeros((40, 60), np.uint8)
+        m[:, 20:] = 255
+        a = S.SeamFinder.draw_seam_mask(img, m)
+        assert np.array_equal(a, ref.draw_seam_mask(img, fake_cv2_glue.UMat(m))) and (a[:, :20] == 0).all()
+        blended = np.zeros((40, 60, 3), np.uint8)
+        blended[:, 30:] = (255, 0, 0)
+        assert np.array_equal(S.SeamFinder.draw_seam_lines(img, blended, linesize=3), ref.draw_seam_lines(img, blended, linesize=3))
+        assert np.array_equal(S.SeamFinder.draw_seam_polygons(img, blended), ref.draw_seam_polygons(img, blended))
+    finally:
+        RG.unload()
+    with pytest.raises(S.StitchingError, match="not importable"):
+        S.SeamFinder.draw_seam_polygons(img, blended)
