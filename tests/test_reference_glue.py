@@ -3,7 +3,6 @@ the cv2 stand-in tests/fake_cv2_glue.py) runs `Stitcher(...).stitch(frames)` end
 committed recording tests/golden/reference_glue/*.json.  The GPU half (tests/test_gpu_reference_glue.py) replays those files over the
 product.  Tests that need the reference skip where it does not exist (the GPU box); the files themselves are checked everywhere."""
 import json
-import os
 import warnings
 
 import numpy as np
