@@ -605,8 +605,16 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     unsigned long long src_a = (unsigned long long)P.src, dimg_a = (unsigned long long)P.dimg, dmask_a = (unsigned long long)P.dmask;
     long long dimg_stride = P.dimg_stride, dmask_stride = P.dmask_stride;
     uint32_t sstride = (uint32_t)P.sstride;
+    // Round 6: the scalars of the wavefronts that are NOT interior ride in the same batch.  Left in their branch they were four dependent
+    // scalar-cache round trips (the range test of the mirror zone compiled into a chain of short-circuit branches, one s_load + wait
+    // each) in front of a third of the wavefronts of a pitched frame: measured in column slices of the +-55 degree frames of config 3, a
+    // wavefront off the interior path cost 2.7 x an interior one (profiles/r06_warp_split.md section 6).
+    int sw_s = P.sw, sh_s = P.sh;
+    uint32_t mxhi_b = __float_as_uint(P.mx32_hi), myhi_b = __float_as_uint(P.my32_hi);
+    uint32_t ux_zlo = P.ux_zlo, ux_zhi = P.ux_zhi, uy_zlo = P.uy_zlo, uy_zhi = P.uy_zhi;
     asm volatile("" : "+s"(tiles_x), "+s"(tiles_y), "+s"(band_tiles), "+s"(band_rows), "+s"(magic_tx), "+s"(magic_band), "+s"(dw),
-                 "+s"(dh), "+s"(ux_int), "+s"(uy_int), "+s"(num_ok));
+                 "+s"(dh), "+s"(ux_int), "+s"(uy_int), "+s"(num_ok), "+s"(sw_s), "+s"(sh_s), "+s"(mxhi_b), "+s"(myhi_b), "+s"(ux_zlo),
+                 "+s"(ux_zhi), "+s"(uy_zlo), "+s"(uy_zhi));
     asm volatile("" : "+s"(src_a), "+s"(dimg_a), "+s"(dmask_a), "+s"(dimg_stride), "+s"(dmask_stride), "+s"(sstride), "+s"(colT_a),
                  "+s"(rowT_a));
     const STX_GAS v2f* colT = (const STX_GAS v2f*)colT_a;   // scalar base + 32-bit lane offset
@@ -784,9 +792,9 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
             }
         }
     } else if (RM != STX_REMAP_Q15) {
-        const int sw = P.sw, sh = P.sh;
+        const int sw = sw_s, sh = sh_s;
         if (MASK) {
-            const float mx32_hi = P.mx32_hi, my32_hi = P.my32_hi;
+            const float mx32_hi = __uint_as_float(mxhi_b), my32_hi = __uint_as_float(myhi_b);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const bool in = xs[j] >= -16.f && xs[j] < mx32_hi && ys[j] >= -16.f && ys[j] < my32_hi;
@@ -804,8 +812,8 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
             }
         }
     } else {
-        const int sw = P.sw, sh = P.sh;
-        const float mx32_hi = P.mx32_hi, my32_hi = P.my32_hi;
+        const int sw = sw_s, sh = sh_s;
+        const float mx32_hi = __uint_as_float(mxhi_b), my32_hi = __uint_as_float(myhi_b);
         if (MASK) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -814,7 +822,7 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
             }
         }
         if (IMG) {
-            const bool lane_zone = uxmn >= P.ux_zlo && uxmx <= P.ux_zhi && uymn >= P.uy_zlo && uymx <= P.uy_zhi;
+            const bool lane_zone = (uxmn >= ux_zlo) & (uxmx <= ux_zhi) & (uymn >= uy_zlo) & (uymx <= uy_zhi);  // (no short circuit: see the prologue)
             if (__builtin_amdgcn_ballot_w64(!lane_zone) == 0) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {

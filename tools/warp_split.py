@@ -116,7 +116,7 @@ def timed(ctx, fn, steps):
 
 def main():
     leg = sys.argv[1] if len(sys.argv) > 1 else "config3"
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith('-') else 10
     W, H, wt, cams, seeds = leg_setup(leg)
     ctx = S.get_context()
     warper = S.Warper(wt, ctx=ctx)
@@ -135,6 +135,18 @@ def main():
         tot_us += us
         print(f"  {i:3d} {yaw:7.1f} {pitch:7.1f}  {sizes[i][0]:6d} x {sizes[i][1]:5d}  {pw / (W * H):7.2f} {us:8.1f} {by / us / 1e3:8.1f} {us / (pw / 1e6):8.2f}   "
               f"| {st['tiles']:6d}  {st['interior']:6.3f} {st['mirror']:6.3f} {st['other']:6.3f} | {st['row_span']:10.1f} {st['x_span']:10.1f} {st['lines_per_load']:10.1f}")
+    if "--slices" in sys.argv:
+        # one image in 6 column slices (rects of the full ROI height): the slope of a destination row through the source — and with it the
+        # number of cache lines a load touches — grows from the middle of a pitched frame's ROI towards its ends, the arithmetic does not
+        print("  slices of 1/6 of the ROI width: img slice  us/Mpx_dst | interior mirror | src rows/64 lanes  128B lines/load")
+        for i, (f, c) in enumerate(zip(frames, cams)):
+            w, h = sizes[i]
+            for k in range(6):
+                x0, x1 = (w * k // 6) & ~63, (w * (k + 1) // 6) & ~63
+                rect = (corners[i][0] + x0, corners[i][1], x1 - x0, h)
+                us, _ = timed(ctx, lambda: warper.warp_images_and_masks([f], [c], rects=[rect]), steps)
+                st = tile_stats(wt, float(warper.scale), c, rect, W, H)
+                print(f"    {i} {k}  {us / ((x1 - x0) * h / 1e6):6.2f} | {st['interior']:5.3f} {st['mirror']:5.3f} | {st['row_span']:6.1f} {st['lines_per_load']:6.1f}")
     # the same single launches with the images ALTERNATING (0, 1, 2, ..., 0, 1, ...): a launch that repeats one image finds its source
     # (36 MB) and much of what it wrote last time in the 256 MB Infinity Cache; a round over all images has the batch's working set
     def one_round():
