@@ -406,15 +406,125 @@ struct MbCoarseK {
     int pw, ph;              // padded panorama size at level B-2 (a multiple of 4)
 };
 
+// ---- round 6: one memory round trip per covering image instead of four ------------------------------------------------------------
+// The general path below walks, per sample, all images of the table one after the other: a scalar round trip for the descriptor, a
+// branch, then the loads of that ONE image (weight, 3 values, 27 pyrUp taps) and their wait — for every covering image again, in three
+// phases of one, one and two samples per lane: (1 + 1 + 2) x (covering images) dependent memory round trips per wavefront, 30 us of
+// nothing but latency on config 2 (profiles/r05_latency.md).  The fast path
+//   * lists the images that reach the workgroup's three windows ONCE (a ballot per 64 images, feed order kept) and parks the
+//     descriptors of their three levels in LDS (scalar registers again by v_readfirstlane: no scalar-cache round trip per image);
+//   * gives every lane samples that share ONE parent sample — wavefronts 0, 1: a 2 x 2 block of level B-2; wavefronts 2, 3: a horizontal
+//     pair of level B-1 and one sample of level B — so that the pyrUp taps of a lane are one 3 x 3 window, read as ONE unaligned dword per
+//     row and plane (a byte pyramid): 17 loads per lane and image where the general path issues up to 124;
+//   * gathers inside one loop over the list, branch-free: addresses clamped into the image's rectangle, the contribution of a sample
+//     outside it multiplied out (weight 0.f, Laplacian 0: acc += 0, ws + 0.f = ws exactly), every load of an image issued before the
+//     first is waited for (__builtin_amdgcn_sched_barrier: left alone, the scheduler interleaves loads and uses to save registers).
+// Only the two pyrUp additions still wait for each other (levels B and B-1 finished in LDS, as before).  Integers and fp32 operations
+// per sample are those of mb_gather_norm, in the same order; taken whenever every listed image is a u8 image fed on this rank whose
+// level B is at least 4 samples wide (anything else — int16 images, received contribution strips, tiny levels, more than CO_MAXC
+// images over one tile — takes the general path, uniformly per workgroup).
+constexpr int CO_MAXC = 16;
+
+struct __attribute__((aligned(16))) CoLevel {  // level lv of one listed image, wave-uniform (12 dwords: three 16-byte LDS reads)
+    int ox, oy, lw, lh;                 // its rectangle at this level (panorama coordinates of the level)
+    uint32_t gs, gpl, ws, pad;          // sample pitch of a row / of a plane of G, of a row of W
+    const STX_GAS uint8_t* g;           // G_lv, byte planes
+    const STX_GAS float* w;             // W_lv
+};
+STX_DEV CoLevel co_level(const StxMbImage& im, int lv)
+{
+    CoLevel L;
+    L.ox = im.fx >> lv; L.oy = im.fy >> lv; L.lw = im.fw >> lv; L.lh = im.fh >> lv;
+    L.gs = (uint32_t)im.g_stride[lv]; L.gpl = (uint32_t)im.g_plane[lv]; L.ws = (uint32_t)im.wt_stride[lv]; L.pad = 0u;
+    L.g = (const STX_GAS uint8_t*)reinterpret_cast<const uint8_t*>(im.g[lv]);
+    L.w = (const STX_GAS float*)im.wt[lv];
+    return L;
+}
+// a listed level out of LDS into scalar registers (the address is wave-uniform; the compiler does not know the values are)
+STX_DEV CoLevel co_level_lds(const CoLevel* p)
+{
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+    uint32_t d[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) d[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q[i]);
+    CoLevel L;
+    L.ox = (int)d[0]; L.oy = (int)d[1]; L.lw = (int)d[2]; L.lh = (int)d[3];
+    L.gs = d[4]; L.gpl = d[5]; L.ws = d[6]; L.pad = 0u;
+    L.g = (const STX_GAS uint8_t*)(uintptr_t)((unsigned long long)d[8] | ((unsigned long long)d[9] << 32));
+    L.w = (const STX_GAS float*)(uintptr_t)((unsigned long long)d[10] | ((unsigned long long)d[11] << 32));
+    return L;
+}
+typedef uint32_t co_u32_u __attribute__((aligned(1)));
+typedef uint16_t co_u16_u __attribute__((aligned(1)));
+typedef float co_f2_u __attribute__((ext_vector_type(2), aligned(4)));
+// the three pyrUp tap rows of the samples whose parent is (px, py) of level U: one unaligned dword per row and plane, 4 bytes from column s
+struct CoTaps { uint32_t t[3][3]; };
+STX_DEV int co_tap_col(int px, int cw) { return min(max(px - 1, 0), cw - 4); }  // cw >= 4: the workgroup's test of the path
+STX_DEV void co_issue_taps(const CoLevel& U, int px, int py, CoTaps& T)
+{
+    const uint32_t s = (uint32_t)co_tap_col(px, U.lw);
+    const uint32_t r0 = (uint32_t)up_idx(py - 1, U.lh) * U.gs + s, r1 = (uint32_t)py * U.gs + s, r2 = (uint32_t)up_idx(py + 1, U.lh) * U.gs + s;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const STX_GAS uint8_t* pl = U.g + (uint32_t)c * U.gpl;
+        T.t[c][0] = *reinterpret_cast<const STX_GAS co_u32_u*>(pl + r0);
+        T.t[c][1] = *reinterpret_cast<const STX_GAS co_u32_u*>(pl + r1);
+        T.t[c][2] = *reinterpret_cast<const STX_GAS co_u32_u*>(pl + r2);
+    }
+}
+// (32-bit BYTE offsets from the scalar bases: an element index would be widened to a 64-bit lane address)
+STX_DEV float co_w1(const CoLevel& L, int cx, int cy)
+{
+    return *reinterpret_cast<const STX_GAS float*>(reinterpret_cast<const STX_GAS uint8_t*>(L.w) + (((uint32_t)cy * L.ws + (uint32_t)cx) << 2));
+}
+STX_DEV co_f2_u co_w2(const CoLevel& L, int cx, int cy)  // W at (cx, cy), (cx + 1, cy)
+{
+    return *reinterpret_cast<const STX_GAS co_f2_u*>(reinterpret_cast<const STX_GAS uint8_t*>(L.w) + (((uint32_t)cy * L.ws + (uint32_t)cx) << 2));
+}
+STX_DEV uint32_t co_g1(const CoLevel& L, int c, int cx, int cy) { return L.g[(uint32_t)c * L.gpl + (uint32_t)cy * L.gs + (uint32_t)cx]; }
+STX_DEV uint32_t co_g2(const CoLevel& L, int c, int cx, int cy)  // G_c at (cx, cy) in byte 0, at (cx + 1, cy) in byte 1
+{
+    return *reinterpret_cast<const STX_GAS co_u16_u*>(L.g + ((uint32_t)c * L.gpl + (uint32_t)cy * L.gs + (uint32_t)cx));
+}
+// pyrUp_ (pyr_up_at's integers) of channel c at a sample of column parity ox and row parity oy whose parent column is px
+STX_DEV int co_up(const CoTaps& T, int c, int px, int ox, int oy, int cw)
+{
+    const int s = co_tap_col(px, cw);
+    // byte positions of the three taps inside the window (pyrUp's border rule: -1 -> 1, cw -> cw - 1)
+    const uint32_t bl = 8u * (uint32_t)(up_idx(px - 1, cw) - s), bc = 8u * (uint32_t)(px - s), br = 8u * (uint32_t)(up_idx(px + 1, cw) - s);
+    const int wl = 1 - ox, wc = 6 - 2 * ox, wr = 1 + 3 * ox;
+    int h[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+        h[r] = __mul24((int)__builtin_amdgcn_ubfe(T.t[c][r], bl, 8u), wl) + __mul24((int)__builtin_amdgcn_ubfe(T.t[c][r], bc, 8u), wc) +
+               __mul24((int)__builtin_amdgcn_ubfe(T.t[c][r], br, 8u), wr);
+    const int v = __mul24(h[0], 1 - oy) + __mul24(h[1], 6 - 2 * oy) + __mul24(h[2], 1 + 3 * oy);
+    return (int)(short)((v + 32) >> 6);
+}
+// the accumulation step of mb_gather_norm for one sample of one image: Lp = its Laplacian (its value at the top level), w its weight;
+// a sample outside the image adds 0 / 0.f (acc + 0, ws + 0.f = ws exactly)
+STX_DEV void co_acc(int Lp, float wv, bool in, int& acc) { acc += trunc_s16(fmul((float)(in ? Lp : 0), in ? wv : 0.f)); }
+STX_DEV void co_normalise(const int (&acc)[3], float ws, int (&v)[3])
+{
+    const float den = fadd(ws, WEIGHT_EPS);
+#pragma unroll
+    for (int c = 0; c < 3; c++) v[c] = trunc_s16(fdiv((float)(short)acc[c], den));
+}
+
 // 7 wavefronts per SIMD (72 registers; the unconstrained build takes 78 -> 6): config 2's 1 680 workgroups are one resident set on
 // 256 CUs x 7, and a second round of a latency-bound kernel doubles its time
 #ifndef STX_COARSE_WAVES
 #define STX_COARSE_WAVES 7
 #endif
+#ifndef STX_COARSE_FAST
+#define STX_COARSE_FAST 1
+#endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_COARSE_WAVES, 8))) void mb_coarse_kernel(MbCoarseK P)
 {
     __shared__ short s0[3][CO_H0 * CO_W0];  // finished level B
     __shared__ short s1[3][CO_H1 * CO_W1];  // finished level B-1
+    __shared__ CoLevel s_ent[CO_MAXC][3];  // [listed image][B, B-1, B-2]
+    __shared__ int s_cnt;
     const int tid = threadIdx.x;
     const int B = P.num_bands;
     const int tx0 = P.x0 + blockIdx.x * CO_TW, ty0 = blockIdx.y * CO_TH;       // tile origin, level B-2
@@ -429,6 +539,153 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_COARSE_
     const int bx0 = max((ax0 >> 1) - 1, 0), bx1 = min((ax1 >> 1) + 1, pw0 - 1);
     const int by0 = max((ay0 >> 1) - 1, 0), by1 = min((ay1 >> 1) + 1, ph0 - 1);
     const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+#if STX_COARSE_FAST
+    // the images that reach any of the three windows, in feed order, their three levels' descriptors in LDS; s_cnt = -1: the general path
+    if (tid < 64) {
+        int cnt = 0;
+        bool slow = false;
+        for (int base = 0; base < P.n_images; base += 64) {
+            const int k = min(base + tid, P.n_images - 1);
+            const StxMbImage& im = P.images[k];
+            const int kind = im.kind, g_u8 = im.g_u8;  // every field is loaded, whatever the tests below say (no load behind a branch)
+            const int fxB = im.fx >> B, fyB = im.fy >> B, fwB = im.fw >> B, fhB = im.fh >> B;
+            const CoLevel L0 = co_level(im, B), L1 = co_level(im, B - 1), L2 = co_level(im, B - 2);
+            const bool hitB = fxB <= bx1 && fxB + fwB > bx0 && fyB <= by1 && fyB + fhB > by0;
+            const bool hitA = 2 * fxB <= ax1 && 2 * (fxB + fwB) > ax0 && 2 * fyB <= ay1 && 2 * (fyB + fhB) > ay0;
+            const bool hitT = 4 * fxB < tx1 && 4 * (fxB + fwB) > tx0 && 4 * fyB < ty1 && 4 * (fyB + fhB) > ty0;
+            const bool rel = base + tid < P.n_images && (hitB || hitA || hitT);
+            const bool odd = rel && (kind != 0 || !g_u8 || fwB < 4 || fhB < 1);
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(rel);
+            slow = slow || __builtin_amdgcn_ballot_w64(odd) != 0ull;
+            const int pos = cnt + __builtin_popcountll(bal & ((1ull << tid) - 1ull));
+            if (rel && pos < CO_MAXC) { s_ent[pos][0] = L0; s_ent[pos][1] = L1; s_ent[pos][2] = L2; }
+            cnt += __builtin_popcountll(bal);
+        }
+        if (tid == 0) s_cnt = (slow || cnt > CO_MAXC || (P.x0 & 1)) ? -1 : cnt;
+    }
+    __syncthreads();
+    const int cnt = __builtin_amdgcn_readfirstlane(s_cnt);
+    if (cnt >= 0) {
+        // Two roles, 17 loads per lane and listed image each, all in flight before the first is used:
+        //   wavefronts 0, 1: lane t owns the 2 x 2 block of level B-2 at (tx0 + 2 (t & 15), ty0 + 2 (t >> 4)) — one parent sample, so its four
+        //                    samples share nine tap dwords; their values are two bytes per plane and row, their weights one 8-byte load per row;
+        //   wavefronts 2, 3: lane u owns a horizontal pair of level B-1 (again one parent: nine tap dwords) and one sample of level B.
+        // Even coordinates stay even inside every image: feed rectangles start and end on multiples of 2^B.
+        const int role = __builtin_amdgcn_readfirstlane(tid >> 7);
+        int accT[2][2][3] = {{{0, 0, 0}, {0, 0, 0}}, {{0, 0, 0}, {0, 0, 0}}};
+        float wsT[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+        int accA[2][3] = {{0, 0, 0}, {0, 0, 0}}, accB[3] = {0, 0, 0};
+        float wsA[2] = {0.f, 0.f}, wsB = 0.f;
+        const int t = tid & 127;
+        // role 0
+        const int xT = tx0 + 2 * (t & 15), yT = ty0 + 2 * (t >> 4);
+        const bool hasT = xT < tx1 && yT < ty1;
+        // role 1
+        const int pc0 = ax0 >> 1, npc = (ax1 >> 1) - pc0 + 1;  // pair columns of the level B-1 window
+        const bool hasP = t < npc * ah;
+        const int rowA = hasP ? t / npc : 0, pcA = hasP ? t - rowA * npc : 0;
+        const int xA = 2 * (pc0 + pcA), yA = ay0 + rowA;  // samples (xA, yA), (xA + 1, yA); inside the window iff ax0 <= x <= ax1
+        const bool hasB = t < bw * bh;
+        const int yyB = hasB ? t / bw : 0, xxB = hasB ? t - yyB * bw : 0;
+        const int xB = bx0 + xxB, yB = by0 + yyB;
+        if (role == 0) {
+            for (int e = 0; e < cnt; e++) {
+                const CoLevel LA = co_level_lds(&s_ent[e][1]), LT = co_level_lds(&s_ent[e][2]);
+                const int lx = xT - LT.ox, ly = yT - LT.oy;
+                const bool in = hasT && (unsigned)lx < (unsigned)LT.lw && (unsigned)ly < (unsigned)LT.lh;
+                const int cx = min(max(lx, 0), LT.lw - 2), cy = min(max(ly, 0), LT.lh - 2);  // even, the block inside the rectangle
+                co_f2_u w[2];
+                uint32_t g[3][2];
+                CoTaps T;
+                w[0] = co_w2(LT, cx, cy); w[1] = co_w2(LT, cx, cy + 1);
+#pragma unroll
+                for (int c = 0; c < 3; c++) { g[c][0] = co_g2(LT, c, cx, cy); g[c][1] = co_g2(LT, c, cx, cy + 1); }
+                co_issue_taps(LA, cx >> 1, cy >> 1, T);
+                __builtin_amdgcn_sched_barrier(0);  // every load of the image has left before the first is waited for
+#pragma unroll
+                for (int dy = 0; dy < 2; dy++) {
+#pragma unroll
+                    for (int dx = 0; dx < 2; dx++) {
+                        const float wv = dx ? w[dy].y : w[dy].x;
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            const int gv = (int)((g[c][dy] >> (8 * dx)) & 255u);
+                            co_acc(sat_s16(gv - co_up(T, c, cx >> 1, dx, dy, LA.lw)), wv, in, accT[dy][dx][c]);
+                        }
+                        wsT[dy][dx] = fadd(wsT[dy][dx], in ? wv : 0.f);
+                    }
+                }
+            }
+        } else {
+            for (int e = 0; e < cnt; e++) {
+                const CoLevel LB = co_level_lds(&s_ent[e][0]), LA = co_level_lds(&s_ent[e][1]);
+                const int lx = xA - LA.ox, ly = yA - LA.oy;
+                const bool inA = hasP && (unsigned)lx < (unsigned)LA.lw && (unsigned)ly < (unsigned)LA.lh;
+                const int cx = min(max(lx, 0), LA.lw - 2), cy = min(max(ly, 0), LA.lh - 1);  // cx even
+                const int lxB = xB - LB.ox, lyB = yB - LB.oy;
+                const bool inB = hasB && (unsigned)lxB < (unsigned)LB.lw && (unsigned)lyB < (unsigned)LB.lh;
+                const int cxB = min(max(lxB, 0), LB.lw - 1), cyB = min(max(lyB, 0), LB.lh - 1);
+                uint32_t g[3], gB[3];
+                CoTaps T;
+                const co_f2_u w = co_w2(LA, cx, cy);
+#pragma unroll
+                for (int c = 0; c < 3; c++) g[c] = co_g2(LA, c, cx, cy);
+                co_issue_taps(LB, cx >> 1, cy >> 1, T);
+                const float wB = co_w1(LB, cxB, cyB);
+#pragma unroll
+                for (int c = 0; c < 3; c++) gB[c] = co_g1(LB, c, cxB, cyB);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dx = 0; dx < 2; dx++) {
+                    const float wv = dx ? w.y : w.x;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const int gv = (int)((g[c] >> (8 * dx)) & 255u);
+                        co_acc(sat_s16(gv - co_up(T, c, cx >> 1, dx, cy & 1, LB.lw)), wv, inA, accA[dx][c]);
+                    }
+                    wsA[dx] = fadd(wsA[dx], inA ? wv : 0.f);
+                }
+#pragma unroll
+                for (int c = 0; c < 3; c++) co_acc((int)gB[c], wB, inB, accB[c]);  // the top level: L_B = G_B
+                wsB = fadd(wsB, inB ? wB : 0.f);
+            }
+        }
+        int v[3];
+        if (role == 1 && hasB) {
+            co_normalise(accB, wsB, v);
+#pragma unroll
+            for (int c = 0; c < 3; c++) s0[c][yyB * CO_W0 + xxB] = (short)v[c];
+        }
+        __syncthreads();
+        if (role == 1 && hasP) {
+#pragma unroll
+            for (int dx = 0; dx < 2; dx++) {
+                const int x = xA + dx;
+                if (x < ax0 || x > ax1) continue;
+                co_normalise(accA[dx], wsA[dx], v);
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                    s1[c][rowA * CO_W1 + (x - ax0)] = (short)sat_s16(pyr_up_at_lds(s0[c], CO_W0, bx0, by0, pw0, ph0, x, yA) + v[c]);
+            }
+        }
+        __syncthreads();
+        if (role == 0 && hasT) {
+#pragma unroll
+            for (int dy = 0; dy < 2; dy++) {
+#pragma unroll
+                for (int dx = 0; dx < 2; dx++) {
+                    const int x = xT + dx, y = yT + dy;
+                    if (x >= tx1 || y >= ty1) continue;
+                    co_normalise(accT[dy][dx], wsT[dy][dx], v);
+                    short* O = P.out + (long long)y * P.out_stride + (x - P.out_x0);
+#pragma unroll
+                    for (int c = 0; c < 3; c++) O[c * P.out_plane] = (short)sat_s16(pyr_up_at_lds(s1[c], CO_W1, ax0, ay0, pw1, ph1, x, y) + v[c]);
+                }
+            }
+        }
+        return;
+    }
+#endif
     for (int i = tid; i < bw * bh; i += 256) {  // level B: L_B = G_B, nothing above it
         const int yy = i / bw, xx = i - yy * bw;
         int v[3];
