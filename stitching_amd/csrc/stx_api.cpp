@@ -1689,6 +1689,9 @@ static int mb_feed(stx_blender* b, const stx_buf* img, const stx_buf* mask, int 
     im.left = im.ix - im.fx; im.top = im.iy - im.fy;
     // the Gaussian levels of a u8 image are 0..255: stored as bytes (3 instead of 6 bytes per sample on every pyramid pass)
     im.g_u8 = img->elem == STX_U8 ? 1 : 0;
+    // W_1 of a 0 / 255 mask is k / 256, k <= 256: stored as halves, exactly (StxMbImage::w1_f16).  STITCHING_AMD_W1_F32: diagnostic (fp32 as before)
+    static const bool w1_f32 = getenv("STITCHING_AMD_W1_F32") != nullptr;
+    im.w1_f16 = (mask->mask_binary && !w1_f32) ? 1 : 0;
     for (int i = 1; i <= nb; i++) {
         const int lw = im.fw >> i, lh = im.fh >> i;
         // rows of 64 bytes either way
@@ -1698,7 +1701,7 @@ static int mb_feed(stx_blender* b, const stx_buf* img, const stx_buf* mask, int 
         // and end up to 8 bytes behind its last sample (up_row_window / up_row_window_u8)
         STX_TRY(stx_dev_alloc(ctx, MB_FRONT_PAD + (size_t)gs * lh * 3 * (im.g_u8 ? 1 : sizeof(short)) + 64, &g));
         b->pyr_allocs.push_back(g);
-        STX_TRY(stx_dev_alloc(ctx, (size_t)ws * lh * sizeof(float), &wt));
+        STX_TRY(stx_dev_alloc(ctx, (size_t)ws * lh * ((i == 1 && im.w1_f16) ? sizeof(uint16_t) : sizeof(float)), &wt));
         b->pyr_allocs.push_back(wt);
         im.g[i] = (short*)((uint8_t*)g + MB_FRONT_PAD); im.g_stride[i] = gs; im.g_plane[i] = gs * lh;
         im.wt[i] = (float*)wt; im.wt_stride[i] = ws;
@@ -1785,7 +1788,7 @@ static double mb_level_bytes(const stx_blender* b, const std::vector<StxMbImage>
         const double g3 = im.g_u8 ? 3.0 : 6.0;  // the three Gaussian planes of a sample: bytes (u8 image) or int16
         if (im.kind == 1) bytes += cols * rows * 10.0;
         else if (lv == 0) bytes += cols * rows * ((im.img0_is_s16 ? 6 : 3) + 1) + (nb > 0 ? cols * rows * g3 / 4.0 : 0.0);
-        else bytes += cols * rows * (g3 + 4.0) + (lv < nb ? cols * rows * g3 / 4.0 : 0.0);
+        else bytes += cols * rows * (g3 + ((lv == 1 && im.w1_f16) ? 2.0 : 4.0)) + (lv < nb ? cols * rows * g3 / 4.0 : 0.0);
     }
     const double area = (double)(x1 - x0) * ph;
     if (emit) return bytes + area * 10.0;

@@ -91,6 +91,18 @@ STX_DEV void st_g(const StxMbImage& im, int lv, long long idx, int v)
     if (im.g_u8) reinterpret_cast<uint8_t*>(im.g[lv])[idx] = (uint8_t)v;
     else im.g[lv][idx] = (short)v;
 }
+// sample `idx` of level lv of an image's weight pyramid: fp32, or the halves of level 1 of an image with a 0 / 255 mask (StxMbImage::w1_f16:
+// k / 256, exact either way)
+STX_DEV float ld_w(const StxMbImage& im, int lv, long long idx)
+{
+    if (lv == 1 && im.w1_f16) return (float)((const STX_GAS _Float16*)reinterpret_cast<const _Float16*>(im.wt[1]))[idx];
+    return ((const STX_GAS float*)im.wt[lv])[idx];
+}
+STX_DEV void st_w(const StxMbImage& im, int lv, long long idx, float v)
+{
+    if (lv == 1 && im.w1_f16) reinterpret_cast<_Float16*>(im.wt[1])[idx] = (_Float16)v;
+    else im.wt[lv][idx] = v;
+}
 
 // pyrDown of (bordered level 0) -> level 1: G_1 planar (u8 / int16), W_1 fp32
 template <bool S16>
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(256) void mb_down0_kernel(StxMbImage im, int pyr_mo
     st_g(im, 1, o + im.g_plane[1], (vg[2] * 6 + (vg[1] + vg[3]) * 4 + vg[0] + vg[4] + 128) >> 8);
     st_g(im, 1, o + 2 * im.g_plane[1], (vr[2] * 6 + (vr[1] + vr[3]) * 4 + vr[0] + vr[4] + 128) >> 8);
     const float col = x < po.vx1 ? v5f_simd(vw[0], vw[1], vw[2], vw[3], vw[4], po.fused) : h5f(vw[0], vw[1], vw[2], vw[3], vw[4]);
-    im.wt[1][(long long)y * im.wt_stride[1] + x] = fmul(col, INV256);
+    st_w(im, 1, (long long)y * im.wt_stride[1] + x, fmul(col, INV256));
 }
 
 // pyrDown level i -> i+1 (i >= 1), planar int16 x3 + fp32
@@ -148,7 +160,6 @@ __global__ __launch_bounds__(256) void mb_down_kernel(StxMbImage im, int lv, int
 #pragma unroll
     for (int j = 0; j < 5; j++) cx[j] = reflect101(2 * x - 2 + j, iw);
     const long long gs = im.g_stride[lv], gp = im.g_plane[lv];
-    const float* W = im.wt[lv];
     const long long ws = im.wt_stride[lv];
     int v[3][5];
     float vw[5];
@@ -161,16 +172,17 @@ __global__ __launch_bounds__(256) void mb_down_kernel(StxMbImage im, int lv, int
             v[c][k] = ld_g(im, lv, row + cx[2]) * 6 + (ld_g(im, lv, row + cx[1]) + ld_g(im, lv, row + cx[3])) * 4 + ld_g(im, lv, row + cx[0]) +
                       ld_g(im, lv, row + cx[4]);
         }
-        const float* wr = W + (long long)sy * ws;
-        vw[k] = (x >= 1 && x < po.hx1) ? h5f_simd(wr[cx[0]], wr[cx[1]], wr[cx[2]], wr[cx[3]], wr[cx[4]], po.fused)
-                                       : h5f(wr[cx[0]], wr[cx[1]], wr[cx[2]], wr[cx[3]], wr[cx[4]]);
+        const long long wrow = (long long)sy * ws;
+        const float w0 = ld_w(im, lv, wrow + cx[0]), w1 = ld_w(im, lv, wrow + cx[1]), w2 = ld_w(im, lv, wrow + cx[2]), w3 = ld_w(im, lv, wrow + cx[3]),
+                    w4 = ld_w(im, lv, wrow + cx[4]);
+        vw[k] = (x >= 1 && x < po.hx1) ? h5f_simd(w0, w1, w2, w3, w4, po.fused) : h5f(w0, w1, w2, w3, w4);
     }
 #pragma unroll
     for (int c = 0; c < 3; c++)
         st_g(im, lv + 1, c * im.g_plane[lv + 1] + (long long)y * im.g_stride[lv + 1] + x,
              (v[c][2] * 6 + (v[c][1] + v[c][3]) * 4 + v[c][0] + v[c][4] + 128) >> 8);
     const float col = x < po.vx1 ? v5f_simd(vw[0], vw[1], vw[2], vw[3], vw[4], po.fused) : h5f(vw[0], vw[1], vw[2], vw[3], vw[4]);
-    im.wt[lv + 1][(long long)y * im.wt_stride[lv + 1] + x] = fmul(col, INV256);
+    st_w(im, lv + 1, (long long)y * im.wt_stride[lv + 1] + x, fmul(col, INV256));
 }
 
 // pyrUp_<FixPtCast<short,6>> sampled at one destination pixel (X, Y) of a planar image (int16, or the bytes of a u8 pyramid)
@@ -233,7 +245,7 @@ STX_DEV void mb_level_pixel(const MbLevelK& P, const int x, const int y)
             const int lx = x - (im.fx >> lv), ly = y - (im.fy >> lv);
             const int lw = im.fw >> lv, lh = im.fh >> lv;
             if ((unsigned)lx >= (unsigned)lw || (unsigned)ly >= (unsigned)lh) continue;
-            const float w = im.wt[lv][(long long)ly * im.wt_stride[lv] + lx];
+            const float w = ld_w(im, lv, (long long)ly * im.wt_stride[lv] + lx);
             const long long gi = (long long)ly * im.g_stride[lv] + lx;
             int L[3];
 #pragma unroll
@@ -353,7 +365,7 @@ STX_DEV void mb_gather_norm(const StxMbImage* __restrict__ images, int n_images,
         const int lx = x - (im.fx >> lv), ly = y - (im.fy >> lv);
         const int lw = im.fw >> lv, lh = im.fh >> lv;
         if ((unsigned)lx >= (unsigned)lw || (unsigned)ly >= (unsigned)lh) continue;
-        const float w = ((const STX_GAS float*)im.wt[lv])[(long long)ly * im.wt_stride[lv] + lx];
+        const float w = ld_w(im, lv, (long long)ly * im.wt_stride[lv] + lx);
         const bool lap = im.kind == 0 && lv < num_bands;
         int L[3];
         if (im.g_u8) mb_sample_of<uint8_t>(im, lap, lv, lx, ly, lw, lh, L);
@@ -547,14 +559,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STX_COARSE_
         for (int base = 0; base < P.n_images; base += 64) {
             const int k = min(base + tid, P.n_images - 1);
             const StxMbImage& im = P.images[k];
-            const int kind = im.kind, g_u8 = im.g_u8;  // every field is loaded, whatever the tests below say (no load behind a branch)
+            const int kind = im.kind, g_u8 = im.g_u8, w1h = im.w1_f16;  // every field is loaded, whatever the tests below say (no load behind a branch)
             const int fxB = im.fx >> B, fyB = im.fy >> B, fwB = im.fw >> B, fhB = im.fh >> B;
             const CoLevel L0 = co_level(im, B), L1 = co_level(im, B - 1), L2 = co_level(im, B - 2);
             const bool hitB = fxB <= bx1 && fxB + fwB > bx0 && fyB <= by1 && fyB + fhB > by0;
             const bool hitA = 2 * fxB <= ax1 && 2 * (fxB + fwB) > ax0 && 2 * fyB <= ay1 && 2 * (fyB + fhB) > ay0;
             const bool hitT = 4 * fxB < tx1 && 4 * (fxB + fwB) > tx0 && 4 * fyB < ty1 && 4 * (fyB + fhB) > ty0;
             const bool rel = base + tid < P.n_images && (hitB || hitA || hitT);
-            const bool odd = rel && (kind != 0 || !g_u8 || fwB < 4 || fhB < 1);
+            const bool odd = rel && (kind != 0 || !g_u8 || fwB < 4 || fhB < 1 || (w1h && B <= 3));  // (level 1 as halves: the general path reads them)
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(rel);
             slow = slow || __builtin_amdgcn_ballot_w64(odd) != 0ull;
             const int pos = cnt + __builtin_popcountll(bal & ((1ull << tid) - 1ull));
@@ -793,8 +805,9 @@ int stx_launch_mb_pyramids(stx_ctx* ctx, const StxMbImage* d_images, const StxMb
             const StxMbImage& im = h_images[i];
             const double ip = (double)(im.fw >> lv) * (im.fh >> lv), op = ip / 4.0;
             const double gw = (im.g_u8 ? 3.0 : 6.0) + 4.0;  // bytes per pyramid sample: 3 Gaussian planes (bytes / int16) + the fp32 weight
-            if (lv == 0) bytes += ((im.img0_is_s16 ? 6.0 : 3.0) + 1.0) * im.iw * im.ih + gw * op;
-            else bytes += gw * ip + gw * op;
+            const double gw1 = gw - (im.w1_f16 ? 2.0 : 0.0);  // ... of level 1: its weight may be a half (StxMbImage::w1_f16)
+            if (lv == 0) bytes += ((im.img0_is_s16 ? 6.0 : 3.0) + 1.0) * im.iw * im.ih + gw1 * op;
+            else bytes += (lv == 1 ? gw1 : gw) * ip + gw * op;
             any_s16 = any_s16 || im.img0_is_s16;
         }
         StxProfScope prof(ctx, lv == 0 ? "mb_down0" : "mb_down", bytes);

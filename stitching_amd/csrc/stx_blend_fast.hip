@@ -460,6 +460,7 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
     const int X0 = tile_tx * DN_TOW, Y0 = tile_ty * DN_TOH;
     if (im.img0_is_s16 || X0 >= ow || Y0 >= oh) return;  // int16 sources take the generic kernel
     uint8_t* const occ = im.occ[1];
+    const bool w1h = im.w1_f16 != 0;
     asm volatile("" ::"s"(occ));  // fetched with the other descriptor fields, not at the tail where nothing hides the round trip
     // rows / columns of the tile past the image's last output feed nothing (narrow exchange strips and the right / bottom
     // edge tiles would otherwise run the reflecting slow path for them)
@@ -511,10 +512,17 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
         }
         const float wa = fmul(h5f(fa[0], fa[1], fa[2], fa[3], fa[4]), INV256);
         const float wb = fmul(h5f(fb[0], fb[1], fb[2], fb[3], fb[4]), INV256);
-        STX_GAS float* o = gp(im.wt[1]) + ((uint32_t)y * (uint32_t)im.wt_stride[1] + (uint32_t)xo);
-        typedef float v2fl __attribute__((ext_vector_type(2)));
-        if (two) { const v2fl wab = {wa, wb}; *reinterpret_cast<STX_GAS v2fl*>(o) = wab; }
-        else o[0] = wa;
+        if (w1h) {  // StxMbImage::w1_f16: k / 256 as halves (exact: a 9-bit significand)
+            STX_GAS _Float16* o = reinterpret_cast<STX_GAS _Float16*>(gp(im.wt[1])) + ((uint32_t)y * (uint32_t)im.wt_stride[1] + (uint32_t)xo);
+            typedef _Float16 v2h16 __attribute__((ext_vector_type(2)));
+            if (two) { const v2h16 wab = {(_Float16)wa, (_Float16)wb}; *reinterpret_cast<STX_GAS v2h16*>(o) = wab; }
+            else o[0] = (_Float16)wa;
+        } else {
+            STX_GAS float* o = gp(im.wt[1]) + ((uint32_t)y * (uint32_t)im.wt_stride[1] + (uint32_t)xo);
+            typedef float v2fl __attribute__((ext_vector_type(2)));
+            if (two) { const v2fl wab = {wa, wb}; *reinterpret_cast<STX_GAS v2fl*>(o) = wab; }
+            else o[0] = wa;
+        }
         nz |= __float_as_uint(wa) | (two ? __float_as_uint(wb) : 0u);
     }
     dn_note_occ(occ, nz, tid, X0, Y0, ow, oh);
@@ -574,6 +582,7 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
     const bool g8b = im.g_u8 != 0;  // byte planes (u8 image) or int16 planes: uniform for the workgroup
     const uint32_t gs = (uint32_t)im.g_stride[lv], gpl = (uint32_t)im.g_plane[lv];
     uint8_t* const occ = im.occ[lv + 1];
+    const bool w_half = lv == 1 && im.w1_f16 != 0;
     asm volatile("" ::"s"(occ));  // as in the level-0 kernel
     const int r_end = 2 * min(DN_TOH, oh - Y0) + 3;  // as in the level-0 kernel
     for (int task = tid; task < DN_ROWS * (DN_TOW / 8); task += 256) {
@@ -606,7 +615,22 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
         }
         const STX_GAS float* wq = gp(im.wt[lv]) + (uint32_t)sy * (uint32_t)im.wt_stride[lv];
         float f[19];
-        if (fast) {
+        if (w_half) {  // level 1 as halves (StxMbImage::w1_f16): the same 19 samples from half the bytes
+            const STX_GAS _Float16* hq = reinterpret_cast<const STX_GAS _Float16*>(gp(im.wt[1])) + (uint32_t)sy * (uint32_t)im.wt_stride[1];
+            if (fast) {
+                typedef _Float16 v2h16 __attribute__((ext_vector_type(2)));
+                typedef _Float16 v8h16 __attribute__((ext_vector_type(8)));
+                const v2h16 a = *reinterpret_cast<const STX_GAS v2h16*>(hq + c0);
+                const v8h16 b = *reinterpret_cast<const STX_GAS v8h16*>(hq + c0 + 2), c = *reinterpret_cast<const STX_GAS v8h16*>(hq + c0 + 10);
+                f[0] = (float)a.x; f[1] = (float)a.y;
+#pragma unroll
+                for (int k = 0; k < 8; k++) { f[2 + k] = (float)b[k]; f[10 + k] = (float)c[k]; }
+                f[18] = (float)hq[c0 + 18];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 19; j++) f[j] = (float)hq[reflect101_near(c0 + j, iw)];
+            }
+        } else if (fast) {
             const v2u a = *reinterpret_cast<const STX_GAS v2u*>(wq + c0);
             f[0] = __uint_as_float(a.x); f[1] = __uint_as_float(a.y);
 #pragma unroll
@@ -928,6 +952,13 @@ STX_DEV void mb_level_fast_body(const MbLevelK& P)
                 float w[2][8];
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
+                    if (lv == 1 && im.w1_f16) {  // level 1 as halves (StxMbImage::w1_f16)
+                        typedef _Float16 v8h16 __attribute__((ext_vector_type(8)));
+                        const v8h16 a = *reinterpret_cast<const v8h16*>(reinterpret_cast<const _Float16*>(im.wt[1]) + (long long)(ly0 + r) * im.wt_stride[1] + lx0);
+#pragma unroll
+                        for (int j = 0; j < 8; j++) w[r][j] = (float)a[j];
+                        continue;
+                    }
                     const float* q = im.wt[lv] + (long long)(ly0 + r) * im.wt_stride[lv] + lx0;
                     float4 a = *reinterpret_cast<const float4*>(q), b = *reinterpret_cast<const float4*>(q + 4);
                     w[r][0] = a.x; w[r][1] = a.y; w[r][2] = a.z; w[r][3] = a.w;
@@ -1710,9 +1741,18 @@ __global__ __launch_bounds__(LV_THREADS) void mb_level_pk_kernel(MbLevelK P)
             const int lw = im.fw >> lv, lh = im.fh >> lv;
             if ((unsigned)lx0 >= (unsigned)lw || (unsigned)ly0 >= (unsigned)lh) continue;
             // the 16 weights (bit patterns; all in [0, 1], so unsigned order = float order)
+            const bool w_half = lv == 1 && im.w1_f16 != 0;
             uint32_t wb[2][8];
 #pragma unroll
             for (int r = 0; r < 2; r++) {
+                if (w_half) {  // level 1 as halves (StxMbImage::w1_f16): one 16-byte load per row, converted (exactly) to the fp32 patterns
+                    typedef _Float16 v8h16 __attribute__((ext_vector_type(8)));
+                    const v8h16 a = *reinterpret_cast<const STX_GAS v8h16*>(reinterpret_cast<const STX_GAS _Float16*>(gp(im.wt[1])) +
+                                                                            ((uint32_t)(ly0 + r) * (uint32_t)im.wt_stride[1] + (uint32_t)lx0));
+#pragma unroll
+                    for (int j = 0; j < 8; j++) wb[r][j] = __float_as_uint((float)a[j]);
+                    continue;
+                }
                 const STX_GAS float* q = gp(im.wt[lv]) + ((uint32_t)(ly0 + r) * (uint32_t)im.wt_stride[lv] + (uint32_t)lx0);
                 const v4u a = *reinterpret_cast<const STX_GAS v4u*>(q), b = *reinterpret_cast<const STX_GAS v4u*>(q + 4);
                 wb[r][0] = a.x; wb[r][1] = a.y; wb[r][2] = a.z; wb[r][3] = a.w;

@@ -182,6 +182,12 @@ struct StxMbImage {  // device-visible descriptor of one fed image (all levels)
     int g_u8;
     short* g[STX_MAX_BANDS + 1]; long long g_stride[STX_MAX_BANDS + 1]; long long g_plane[STX_MAX_BANDS + 1];
     float* wt[STX_MAX_BANDS + 1]; long long wt_stride[STX_MAX_BANDS + 1];
+    // w1_f16 = 1 (round 6: an image fed on this rank whose mask holds only 0 / 255): wt[1] points to IEEE HALF values (wt_stride[1] still counts
+    // samples).  W_0 is then exactly 0.f / 1.f, pyrDown's 25-tap sum a small integer k <= 256 in whatever order it is taken, and
+    // W_1 = k / 256 has a 9-bit significand: the half holds it exactly, the conversion back is exact, every consumer sees the same
+    // fp32 value as before — at 2 instead of 4 of the 7 bytes a level-1 sample costs (written once, read by the level-1 pyrDown and by
+    // the level-1 gather).  Levels >= 2 need 17 and more bits and stay fp32.
+    int w1_f16;
     // occupancy of the weight pyramid (null: not recorded): occ[i][p * nt + t] != 0 iff W_i has a non-zero value in the rows
     // 2 p, 2 p + 1 and the columns 64 t .. 64 t + 63 of level i (frame coordinates), nt = ((fw >> i) + 63) / 64 rounded up to 4.  Every entry is
     // written by the pyramid kernel that produces the level (one byte store per half-wavefront: no atomics, no clearing);
