@@ -153,14 +153,31 @@ STX_DEV const STX_GAS uint8_t* row_ptr_s(const STX_GAS uint8_t* plane, int r, ui
 
 // pyrUp_<FixPtCast<short,6>> of one byte plane (values 0..255) for the 8x2 patch with coarse origin (cx, cy).
 // cy (and with it the three row pointers) is wave-uniform: a wavefront owns two panorama rows.  boff = cx, sel = up_sel_u8(...).
-STX_DEV void up_patch_pk(const STX_GAS uint8_t* __restrict__ plane, uint32_t stride, int ch, uint32_t boff, int cy, UpSel sel, pk16 up[2][4])
+// In two halves (round 6): the three 12-byte window loads, and the arithmetic on what they returned — a caller with several planes
+// in front of it issues all their loads before the first use (one memory round trip per image instead of one per plane).
+STX_DEV void up_patch_pk_load(const STX_GAS uint8_t* __restrict__ plane, uint32_t stride, int ch, uint32_t boff, int cy, v3u (&w)[3])
 {
     const int rr[3] = {up_idx_s(cy - 1, ch), cy, up_idx_s(cy + 1, ch)};
-    pk16 HE[3][2], HO[3][2];
     asm("" : "+v"(boff));  // the zero-extension of the lane offset stays in this block: scalar base + 32-bit lane offset loads
 #pragma unroll
+    for (int r = 0; r < 3; r++) w[r] = *reinterpret_cast<const STX_GAS v3u_a4*>(row_ptr_s(plane, rr[r], stride) + (size_t)boff - 4);
+}
+STX_DEV UpRow up_row_of_u8(v3u w, UpSel sel)
+{
+    UpRow r;
+    r.A0 = __builtin_amdgcn_perm(w.y, w.x, sel.a0);
+    r.B0 = __builtin_amdgcn_perm(w.y, w.y, 0x0c010c00u);
+    r.A1 = __builtin_amdgcn_perm(w.y, w.y, 0x0c020c01u);
+    r.B1 = __builtin_amdgcn_perm(w.y, w.y, 0x0c030c02u);
+    r.A2 = __builtin_amdgcn_perm(w.z, w.y, sel.a2);
+    return r;
+}
+STX_DEV void up_patch_pk_math(const v3u (&w)[3], UpSel sel, pk16 up[2][4])
+{
+    pk16 HE[3][2], HO[3][2];
+#pragma unroll
     for (int r = 0; r < 3; r++) {
-        const UpRow t = up_row_window_u8(row_ptr_s(plane, rr[r], stride), boff, sel);
+        const UpRow t = up_row_of_u8(w[r], sel);
         HE[r][0] = pk(t.A0) + pk(t.B0) * pk_splat(6) + pk(t.A1);            // c[j] + 6 c[j+1] + c[j+2], j = 0,1
         HE[r][1] = pk(t.A1) + pk(t.B1) * pk_splat(6) + pk(t.A2);            // j = 2,3
         HO[r][0] = pk(t.B0) + pk(t.A1);                                     // c[j+1] + c[j+2] (the factor 4 is folded below)
@@ -174,19 +191,32 @@ STX_DEV void up_patch_pk(const STX_GAS uint8_t* __restrict__ plane, uint32_t str
         up[1][2 + k] = (HO[1][k] + HO[2][k] + pk_splat(2)) >> pk_splat(2);
     }
 }
+STX_DEV void up_patch_pk(const STX_GAS uint8_t* __restrict__ plane, uint32_t stride, int ch, uint32_t boff, int cy, UpSel sel, pk16 up[2][4])
+{
+    v3u w[3];
+    up_patch_pk_load(plane, stride, ch, boff, cy, w);
+    up_patch_pk_math(w, sel, up);
+}
 // byte plane c of level lv of a u8 pyramid
 STX_DEV const STX_GAS uint8_t* g8(const StxMbImage& im, int lv, int c)
 {
     return gp(reinterpret_cast<const uint8_t*>(im.g[lv])) + c * im.g_plane[lv];
 }
 // the 8 samples at (row r, column x0) of a byte plane as the pyrUp pair order (0,2)(4,6)(1,3)(5,7), zero-extended to 16 bits
-STX_DEV void g8_row_pairs(const STX_GAS uint8_t* plane, int r, uint32_t stride, uint32_t x0, uint32_t (&q)[4])
+STX_DEV v2u g8_row_load(const STX_GAS uint8_t* plane, int r, uint32_t stride, uint32_t x0)
 {
-    const v2u gv = *reinterpret_cast<const STX_GAS v2u*>(row_ptr_s(plane, r, stride) + (size_t)x0);
+    return *reinterpret_cast<const STX_GAS v2u*>(row_ptr_s(plane, r, stride) + (size_t)x0);
+}
+STX_DEV void g8_pairs_of(v2u gv, uint32_t (&q)[4])
+{
     q[0] = __builtin_amdgcn_perm(gv.x, gv.x, 0x0c020c00u);
     q[1] = __builtin_amdgcn_perm(gv.y, gv.y, 0x0c020c00u);
     q[2] = __builtin_amdgcn_perm(gv.x, gv.x, 0x0c030c01u);
     q[3] = __builtin_amdgcn_perm(gv.y, gv.y, 0x0c030c01u);
+}
+STX_DEV void g8_row_pairs(const STX_GAS uint8_t* plane, int r, uint32_t stride, uint32_t x0, uint32_t (&q)[4])
+{
+    g8_pairs_of(g8_row_load(plane, r, stride, x0), q);
 }
 
 
@@ -877,7 +907,7 @@ STX_DEV bool occ_hit(const StxMbImage& im, int lv, int tile_x, int Y0)
     return ((w0 & m0) | (w1 & m1) | (n > 8 ? w2 & 0xffu : 0u)) != 0u;
 }
 
-template <bool WF>
+template <bool WF, bool AHEAD = true>
 STX_DEV void level0_epilogue_pk(const MbLevelK& P, int X0, int Y0, uint32_t (&acc)[2][3][4], uint32_t (&cnt)[2][4], const float (*ws)[8]);
 
 // CONTRIB: the image table may hold received contribution strips (kind 1); EMIT: write un-normalised sums.
@@ -1264,16 +1294,28 @@ STX_DEV pk16s pks(uint32_t v) { return __builtin_bit_cast(pk16s, v); }
 STX_DEV uint32_t unpks(pk16s v) { return __builtin_bit_cast(uint32_t, v); }
 STX_DEV pk16s pks_splat(short v) { pk16s r = {v, v}; return r; }
 
-// returns false (and leaves `up` untouched) when a tap is outside [-500, 500]
-STX_DEV bool up_patch_pks(const STX_GAS short* __restrict__ plane, uint32_t stride, int ch, uint32_t boff, int cy, UpSel sel, pk16s up[2][4])
+// returns false (and leaves `up` untouched) when a tap is outside [-500, 500].  In two halves like up_patch_pk: the three 16-byte
+// window loads, then the arithmetic.
+STX_DEV void up_patch_pks_load(const STX_GAS short* __restrict__ plane, uint32_t stride, int ch, uint32_t boff, int cy, v4u (&w)[3])
 {
     const int rr[3] = {up_idx_s(cy - 1, ch), cy, up_idx_s(cy + 1, ch)};
-    pk16s HE[3][2], HO[3][2];
-    pk16 worst = pk_splat(0);
     asm("" : "+v"(boff));  // as in up_patch_pk
 #pragma unroll
+    for (int r = 0; r < 3; r++)
+        w[r] = *reinterpret_cast<const STX_GAS v4u_a4*>(reinterpret_cast<const STX_GAS char*>(row_ptr_s(plane, rr[r], stride)) + (size_t)boff - 4);
+}
+STX_DEV bool up_patch_pks_math(const v4u (&w)[3], UpSel sel, pk16s up[2][4])
+{
+    pk16s HE[3][2], HO[3][2];
+    pk16 worst = pk_splat(0);
+#pragma unroll
     for (int r = 0; r < 3; r++) {
-        const UpRow t = up_row_window(row_ptr_s(plane, rr[r], stride), boff, sel);
+        UpRow t;  // up_row_window's five registers from the window (x,c0) (c1,c2) (c3,c4) (c5,x)
+        t.B0 = w[r].y;
+        t.B1 = w[r].z;
+        t.A1 = __builtin_amdgcn_alignbit(w[r].z, w[r].y, 16);
+        t.A0 = __builtin_amdgcn_perm(w[r].y, w[r].x, sel.a0);
+        t.A2 = __builtin_amdgcn_perm(w[r].w, w[r].z, sel.a2);
         worst = __builtin_elementwise_max(worst, pk(t.A0) + pk_splat(500));
         worst = __builtin_elementwise_max(worst, pk(t.A1) + pk_splat(500));
         worst = __builtin_elementwise_max(worst, pk(t.A2) + pk_splat(500));
@@ -1291,6 +1333,12 @@ STX_DEV bool up_patch_pks(const STX_GAS short* __restrict__ plane, uint32_t stri
         up[1][2 + k] = (HO[1][k] + HO[2][k] + pks_splat(2)) >> pks_splat(2);
     }
     return true;
+}
+STX_DEV bool up_patch_pks(const STX_GAS short* __restrict__ plane, uint32_t stride, int ch, uint32_t boff, int cy, UpSel sel, pk16s up[2][4])
+{
+    v4u w[3];
+    up_patch_pks_load(plane, stride, ch, boff, cy, w);
+    return up_patch_pks_math(w, sel, up);
 }
 
 // pair register / half that hold pixel j of a lane's 8-pixel strip
@@ -1311,7 +1359,8 @@ STX_DEV uint32_t bgr_dword(const uint32_t (&U)[3][4])
 
 // WF: the weight sums are fp32 values `ws` (grey masks somewhere under the wavefront): every pixel takes the division, and `cnt` holds
 // 1 / 0 per pixel for "weight sum > WEIGHT_EPS" (only the final mask and the zeroing look at it)
-template <bool WF>
+// AHEAD: the pyrUp windows of the finished level 1 are loaded ahead of their use (see below); costs registers
+template <bool WF, bool AHEAD>
 STX_DEV void level0_epilogue_pk(const MbLevelK& P, int X0, int Y0, uint32_t (&acc)[2][3][4], uint32_t (&cnt)[2][4], const float (*ws)[8])
 {
     // The constants (1, 1) and (-1, -1) as values the compiler cannot see through: against literal constants LLVM rewrites
@@ -1355,12 +1404,31 @@ STX_DEV void level0_epilogue_pk(const MbLevelK& P, int X0, int Y0, uint32_t (&ac
     }
     // ---- + pyrUp(finished level 1), saturating
     if (P.up) {
+        // (round 6) AHEAD: the windows of the planes of the finished level 1 are loaded ahead of their use — planes 0 and 1 together,
+        // plane 2 while plane 0 is worked on: two memory round trips at the end of every wavefront where a branch between the planes
+        // made three.  It costs 12 registers: free for the instantiations that hold 88 anyway (grey-mask deferral, contribution strips:
+        // the reference-default leg's level 0 193 -> 179 us together with the batched image search), one wavefront per SIMD less for the
+        // binary-mask instantiation at 80 (measured: +1.4 us) — which therefore keeps the plane-by-plane form.
+        v4u uw[3][3];
+        const short* const plane0 = P.up - ((long long)P.up_y0 * P.up_stride + P.up_x0);
+        if (AHEAD) {
+            up_patch_pks_load(gp(plane0), (uint32_t)P.up_stride, P.ph >> 1, (uint32_t)(X0 >> 1) * 2u, Y0 >> 1, uw[0]);
+            up_patch_pks_load(gp(plane0 + P.up_plane), (uint32_t)P.up_stride, P.ph >> 1, (uint32_t)(X0 >> 1) * 2u, Y0 >> 1, uw[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const short* plane = P.up + c * P.up_plane - ((long long)P.up_y0 * P.up_stride + P.up_x0);
+            if (AHEAD) {
+                if (c == 0) {
+                    up_patch_pks_load(gp(plane0 + 2 * P.up_plane), (uint32_t)P.up_stride, P.ph >> 1, (uint32_t)(X0 >> 1) * 2u, Y0 >> 1, uw[2]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                up_patch_pks_load(gp(plane), (uint32_t)P.up_stride, P.ph >> 1, (uint32_t)(X0 >> 1) * 2u, Y0 >> 1, uw[c]);
+            }
             pk16s up[2][4];
-            if (!up_patch_pks(gp(plane), (uint32_t)P.up_stride, P.ph >> 1, (uint32_t)(X0 >> 1) * 2u, Y0 >> 1,
-                              up_sel(X0 == 0, (X0 >> 1) + 4 >= (P.pw >> 1)), up)) {
+            if (!up_patch_pks_math(uw[c], up_sel(X0 == 0, (X0 >> 1) + 4 >= (P.pw >> 1)), up)) {
                 int u32[2][8];
                 up_patch(plane, P.up_stride, P.pw >> 1, P.ph >> 1, X0 >> 1, Y0 >> 1, u32);
 #pragma unroll
@@ -1453,10 +1521,20 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(STX_
         bool hit = false;
         {
             const int kk = base + (tid & 63);
-            if (kk < P.n_images) {
-                const StxMbImage& im = P.images[kk];
-                int rx = im.ix, ry = im.iy, rw = im.iw, rh = im.ih;
+            // (round 6) size and corner of the lane's image as ONE 16-byte load and tests without short circuits: `&&` had become three
+            // dependent loads, each behind its own branch (see mb_level_pk_kernel)
+            // (round 6) size and corner of the lane's image as ONE 16-byte load and tests without short circuits (`&&` had become three
+            // dependent loads, each behind its own branch: see mb_level_pk_kernel) — where its 8 registers are free (see level0_epilogue_pk)
+            if (DEFER || CONTRIB) {
+                const StxMbImage& im = P.images[min(kk, P.n_images - 1)];
+                const v4u f = *reinterpret_cast<const v4u_a4*>(&im.iw);  // iw, ih, ix, iy
+                int rx = (int)f.z, ry = (int)f.w, rw = (int)f.x, rh = (int)f.y;
                 if (CONTRIB && im.kind == 1) { rx = im.fx; ry = im.fy; rw = im.fw; rh = im.fh; }
+                hit = (kk < P.n_images) & (rx < tile_x + 512) & (rx + rw > tile_x) & (ry < Y0 + 2) & (ry + rh > Y0);
+                if (hit) hit = occ_hit<true>(im, 0, tile_x, Y0);
+            } else if (kk < P.n_images) {
+                const StxMbImage& im = P.images[kk];
+                const int rx = im.ix, ry = im.iy, rw = im.iw, rh = im.ih;
                 hit = rx < tile_x + 512 && rx + rw > tile_x && ry < Y0 + 2 && ry + rh > Y0;
                 if (hit) hit = occ_hit<true>(im, 0, tile_x, Y0);
             }
@@ -1588,7 +1666,7 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(STX_
         cnt[r][2] = pair_u8<1, 3>(cntb[r]);
         cnt[r][3] = pair_u8<5, 7>(cntb[r]);
     }
-    level0_epilogue_pk<false>(P, X0, Y0, acc, cnt, nullptr);
+    level0_epilogue_pk<false, DEFER || CONTRIB>(P, X0, Y0, acc, cnt, nullptr);
 }
 
 
@@ -1698,7 +1776,21 @@ __global__ __launch_bounds__(256) void mb_level0_deferred_kernel(MbLevelK P)
 STX_DEV uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) { return min(min(a, b), c); }
 STX_DEV uint32_t max3u(uint32_t a, uint32_t b, uint32_t c) { return max(max(a, b), c); }
 
-__global__ __launch_bounds__(LV_THREADS) void mb_level_pk_kernel(MbLevelK P)
+// at least 3 wavefronts per SIMD (168 registers): the batched loads of round 6 would otherwise take 174 and leave two.
+// Measured forms (one box, interleaved, tools/gpu_r6o.sh / gpu_r6p.sh; mb_level of config 2 = levels 1 + 2 / the four launches of the
+// reference-default leg / of config 4's share):  HEAD (loads plane by plane, 103 registers, 4 per SIMD): 84.8 / 128.0 / 332.4 us;
+// STX_LVPK_LOOP = 1 (all loads of an image in one batch, 3 per SIMD: shipped): 79.1 / 116.3 / 308.7;  STX_LVPK_LOOP = 0 with the batched
+// image search and the windows of the epilogue ahead, held to 4 per SIMD (128 registers, 19 spill instructions): 89.5 / 146.5 / 376.6.
+#ifndef STX_LVPK_WAVES
+#define STX_LVPK_WAVES 3
+#endif
+#ifndef STX_LVPK_EPI
+#define STX_LVPK_EPI 3
+#endif
+#ifndef STX_LVPK_LOOP
+#define STX_LVPK_LOOP 1
+#endif
+__global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(STX_LVPK_WAVES, 8))) void mb_level_pk_kernel(MbLevelK P)
 {
     const int tid = threadIdx.x;
     const int lv = P.level;
@@ -1721,15 +1813,16 @@ __global__ __launch_bounds__(LV_THREADS) void mb_level_pk_kernel(MbLevelK P)
     uint32_t mixed = 0;    // != 0: some image had a weight here that is neither covered by `ones` nor 0.f
 
     for (int base = 0; base < P.n_images; base += 64) {
+        // (round 6) the rectangle of the lane's image as ONE 16-byte load, the tests without short circuits: left to `&&` the compiler
+        // made three dependent loads of it, each behind its own branch — three memory round trips before a wavefront knew its images
         bool hit = false;
         {
             const int kk = base + (tid & 63);
-            if (kk < P.n_images) {
-                const StxMbImage& im = P.images[kk];
-                const int rx = im.fx >> lv, ry = im.fy >> lv, rw = im.fw >> lv, rh = im.fh >> lv;
-                hit = rx < tile_x + 512 && rx + rw > tile_x && ry < Y0 + 2 && ry + rh > Y0;
-                if (hit) hit = occ_hit<false>(im, lv, tile_x, Y0);
-            }
+            const StxMbImage& im = P.images[min(kk, P.n_images - 1)];
+            const v4u f = *reinterpret_cast<const v4u_a4*>(&im.fx);  // fx, fy, fw, fh
+            const int rx = (int)f.x >> lv, ry = (int)f.y >> lv, rw = (int)f.z >> lv, rh = (int)f.w >> lv;
+            hit = (kk < P.n_images) & (rx < tile_x + 512) & (rx + rw > tile_x) & (ry < Y0 + 2) & (ry + rh > Y0);
+            if (hit) hit = occ_hit<false>(im, lv, tile_x, Y0);
         }
         unsigned long long todo = __ballot(hit);
         while (todo) {
@@ -1743,39 +1836,68 @@ __global__ __launch_bounds__(LV_THREADS) void mb_level_pk_kernel(MbLevelK P)
             // the 16 weights (bit patterns; all in [0, 1], so unsigned order = float order)
             const bool w_half = lv == 1 && im.w1_f16 != 0;
             uint32_t wb[2][8];
+            typedef _Float16 v8h16 __attribute__((ext_vector_type(8)));
+            v8h16 hw[2];
+            // (round 6) every load of the image — its weights, the three pyrUp windows and the two value rows of each plane — leaves before
+            // the first is used: one memory round trip per image where the plane-by-plane form made four (a wavefront of this kernel is a
+            // chain of round trips and little else: 3 wavefronts per SIMD, 13 k wavefronts at level 1 of config 2)
+            if (w_half) {  // level 1 as halves (StxMbImage::w1_f16): one 16-byte load per row
 #pragma unroll
-            for (int r = 0; r < 2; r++) {
-                if (w_half) {  // level 1 as halves (StxMbImage::w1_f16): one 16-byte load per row, converted (exactly) to the fp32 patterns
-                    typedef _Float16 v8h16 __attribute__((ext_vector_type(8)));
-                    const v8h16 a = *reinterpret_cast<const STX_GAS v8h16*>(reinterpret_cast<const STX_GAS _Float16*>(gp(im.wt[1])) +
-                                                                            ((uint32_t)(ly0 + r) * (uint32_t)im.wt_stride[1] + (uint32_t)lx0));
+                for (int r = 0; r < 2; r++)
+                    hw[r] = *reinterpret_cast<const STX_GAS v8h16*>(reinterpret_cast<const STX_GAS _Float16*>(gp(im.wt[1])) +
+                                                                   ((uint32_t)(ly0 + r) * (uint32_t)im.wt_stride[1] + (uint32_t)lx0));
+            } else {
 #pragma unroll
-                    for (int j = 0; j < 8; j++) wb[r][j] = __float_as_uint((float)a[j]);
-                    continue;
+                for (int r = 0; r < 2; r++) {
+                    const STX_GAS float* q = gp(im.wt[lv]) + ((uint32_t)(ly0 + r) * (uint32_t)im.wt_stride[lv] + (uint32_t)lx0);
+                    const v4u a = *reinterpret_cast<const STX_GAS v4u*>(q), b = *reinterpret_cast<const STX_GAS v4u*>(q + 4);
+                    wb[r][0] = a.x; wb[r][1] = a.y; wb[r][2] = a.z; wb[r][3] = a.w;
+                    wb[r][4] = b.x; wb[r][5] = b.y; wb[r][6] = b.z; wb[r][7] = b.w;
                 }
-                const STX_GAS float* q = gp(im.wt[lv]) + ((uint32_t)(ly0 + r) * (uint32_t)im.wt_stride[lv] + (uint32_t)lx0);
-                const v4u a = *reinterpret_cast<const STX_GAS v4u*>(q), b = *reinterpret_cast<const STX_GAS v4u*>(q + 4);
-                wb[r][0] = a.x; wb[r][1] = a.y; wb[r][2] = a.z; wb[r][3] = a.w;
-                wb[r][4] = b.x; wb[r][5] = b.y; wb[r][6] = b.z; wb[r][7] = b.w;
             }
-            uint32_t lo = min3u(wb[0][0], wb[0][1], wb[0][2]);
-            lo = min3u(lo, wb[0][3], wb[0][4]); lo = min3u(lo, wb[0][5], wb[0][6]); lo = min3u(lo, wb[0][7], wb[1][0]);
-            lo = min3u(lo, wb[1][1], wb[1][2]); lo = min3u(lo, wb[1][3], wb[1][4]); lo = min3u(lo, wb[1][5], wb[1][6]);
-            lo = min(lo, wb[1][7]);
-            const bool all1 = lo == 0x3f800000u;
-            const bool wave_all1 = __ballot(!all1) == 0ull;  // over the lanes that reached this point
             const uint32_t g1_boff = (uint32_t)(lx0 >> 1);
             const UpSel g1_sel = up_sel_u8(lx0 == 0, (lx0 >> 1) + 4 >= (lw >> 1));
+            v3u win[3][3];
+            v2u grow[3][2];
+#define STX_LVPK_LOAD(c)                                                                                                            \
+    {                                                                                                                              \
+        up_patch_pk_load(g8(im, lv + 1, c), (uint32_t)im.g_stride[lv + 1], lh >> 1, g1_boff, ly0 >> 1, win[c]);                    \
+        _Pragma("unroll") for (int r = 0; r < 2; r++) grow[c][r] = g8_row_load(g8(im, lv, c), ly0 + r, (uint32_t)im.g_stride[lv], (uint32_t)lx0); \
+    }
+#if STX_LVPK_LOOP
+#pragma unroll
+            for (int c = 0; c < 3; c++) STX_LVPK_LOAD(c)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            bool all1;
+            if (w_half) {
+                // "all sixteen are 1" is decided on the half patterns themselves (weights are in [0, 1]: unsigned order = float order;
+                // 1.0 = 0x3c00): seven packed minima instead of sixteen conversions in front of the path almost every wavefront takes
+                const v4u h0 = __builtin_bit_cast(v4u, hw[0]), h1 = __builtin_bit_cast(v4u, hw[1]);
+                const pk16 m = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_min(pk(h0.x), pk(h0.y)), __builtin_elementwise_min(pk(h0.z), pk(h0.w))),
+                                                         __builtin_elementwise_min(__builtin_elementwise_min(pk(h1.x), pk(h1.y)), __builtin_elementwise_min(pk(h1.z), pk(h1.w))));
+                all1 = unpk(m) == 0x3c003c00u;
+            } else {
+                uint32_t lo = min3u(wb[0][0], wb[0][1], wb[0][2]);
+                lo = min3u(lo, wb[0][3], wb[0][4]); lo = min3u(lo, wb[0][5], wb[0][6]); lo = min3u(lo, wb[0][7], wb[1][0]);
+                lo = min3u(lo, wb[1][1], wb[1][2]); lo = min3u(lo, wb[1][3], wb[1][4]); lo = min3u(lo, wb[1][5], wb[1][6]);
+                lo = min(lo, wb[1][7]);
+                all1 = lo == 0x3f800000u;
+            }
+            const bool wave_all1 = __ballot(!all1) == 0ull;  // over the lanes that reached this point
             if (wave_all1) {
                 ones += 1u;
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     pk16 upk[2][4];
-                    up_patch_pk(g8(im, lv + 1, c), (uint32_t)im.g_stride[lv + 1], lh >> 1, g1_boff, ly0 >> 1, g1_sel, upk);
+#if !STX_LVPK_LOOP
+                    STX_LVPK_LOAD(c)
+#endif
+                    up_patch_pk_math(win[c], g1_sel, upk);
 #pragma unroll
                     for (int r = 0; r < 2; r++) {
                         uint32_t gq[4];  // the pyrUp pair order (0,2)(4,6)(1,3)(5,7); L in [-255, 255]
-                        g8_row_pairs(g8(im, lv, c), ly0 + r, (uint32_t)im.g_stride[lv], (uint32_t)lx0, gq);
+                        g8_pairs_of(grow[c][r], gq);
 #pragma unroll
                         for (int q = 0; q < 4; q++) acc[r][c][q] = unpk(pk(acc[r][c][q]) + (pk(gq[q]) - upk[r][q]));
                     }
@@ -1785,6 +1907,12 @@ __global__ __launch_bounds__(LV_THREADS) void mb_level_pk_kernel(MbLevelK P)
 #pragma unroll
                     for (int j = 0; j < 8; j++) ws[r][j] = fadd(ws[r][j], 1.0f);
                 continue;
+            }
+            if (w_half) {  // the fp32 patterns of the halves (exact) for the weighted path
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) wb[r][j] = __float_as_uint((float)hw[r][j]);
             }
             {   // book-keeping for the epilogue's short cut
                 uint32_t hi = max3u(wb[0][0], wb[0][1], wb[0][2]);
@@ -1797,11 +1925,14 @@ __global__ __launch_bounds__(LV_THREADS) void mb_level_pk_kernel(MbLevelK P)
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 pk16 upk[2][4];
-                up_patch_pk(g8(im, lv + 1, c), (uint32_t)im.g_stride[lv + 1], lh >> 1, g1_boff, ly0 >> 1, g1_sel, upk);
+#if !STX_LVPK_LOOP
+                STX_LVPK_LOAD(c)
+#endif
+                up_patch_pk_math(win[c], g1_sel, upk);
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
                     uint32_t gq[4];
-                    g8_row_pairs(g8(im, lv, c), ly0 + r, (uint32_t)im.g_stride[lv], (uint32_t)lx0, gq);
+                    g8_pairs_of(grow[c][r], gq);
                     const uint32_t Lq[4] = {unpk(pk(gq[0]) - upk[r][0]), unpk(pk(gq[1]) - upk[r][1]), unpk(pk(gq[2]) - upk[r][2]),
                                             unpk(pk(gq[3]) - upk[r][3])};
 #pragma unroll
@@ -1859,11 +1990,31 @@ __global__ __launch_bounds__(LV_THREADS) void mb_level_pk_kernel(MbLevelK P)
     // ---- + pyrUp(finished coarser level), saturating
     if (P.up) {
         const UpSel usel = up_sel(X0 == 0, (X0 >> 1) + 4 >= (P.pw >> 1));
+        // (round 6) the windows of the planes are loaded ahead of their use (they were three round trips: a branch sat between the planes)
+        v4u uw[3][3];
+        const short* const plane0 = P.up - ((long long)P.up_y0 * P.up_stride + P.up_x0);
+#if STX_LVPK_EPI == 3
+#pragma unroll
+        for (int c = 0; c < 3; c++) up_patch_pks_load(gp(plane0 + c * P.up_plane), (uint32_t)P.up_stride, P.ph >> 1, (uint32_t)(X0 >> 1) * 2u, Y0 >> 1, uw[c]);
+        __builtin_amdgcn_sched_barrier(0);
+#elif STX_LVPK_EPI == 2
+        up_patch_pks_load(gp(plane0), (uint32_t)P.up_stride, P.ph >> 1, (uint32_t)(X0 >> 1) * 2u, Y0 >> 1, uw[0]);
+        up_patch_pks_load(gp(plane0 + P.up_plane), (uint32_t)P.up_stride, P.ph >> 1, (uint32_t)(X0 >> 1) * 2u, Y0 >> 1, uw[1]);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const short* plane = P.up + c * P.up_plane - ((long long)P.up_y0 * P.up_stride + P.up_x0);
+#if STX_LVPK_EPI == 2
+            if (c == 0) {
+                up_patch_pks_load(gp(plane0 + 2 * P.up_plane), (uint32_t)P.up_stride, P.ph >> 1, (uint32_t)(X0 >> 1) * 2u, Y0 >> 1, uw[2]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#elif STX_LVPK_EPI < 2
+            up_patch_pks_load(gp(plane), (uint32_t)P.up_stride, P.ph >> 1, (uint32_t)(X0 >> 1) * 2u, Y0 >> 1, uw[c]);
+#endif
             pk16s up[2][4];
-            if (!up_patch_pks(gp(plane), (uint32_t)P.up_stride, P.ph >> 1, (uint32_t)(X0 >> 1) * 2u, Y0 >> 1, usel, up)) {
+            if (!up_patch_pks_math(uw[c], usel, up)) {
                 int u32[2][8];
                 up_patch(plane, P.up_stride, P.pw >> 1, P.ph >> 1, X0 >> 1, Y0 >> 1, u32);
 #pragma unroll
