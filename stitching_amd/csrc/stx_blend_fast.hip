@@ -257,10 +257,11 @@ STX_DEV void lane_valid_bytes(int lx0, int iw, uint32_t& vm0, uint32_t& vm1)
 // bytes in front of the image so that they stay non-negative.  (Round 2 fetched the inside pixels of such a lane byte by byte
 // behind per-pixel branches: 16 dependent round trips for every wavefront that holds one — two lanes per image and row pair, a
 // quarter of all wavefront visits.)
-STX_DEV void load_px8_u8(const StxMbImage& im, int lx0, int ly, uint32_t vm0, uint32_t vm1, uint32_t (&pw)[6], uint32_t (&mw)[2])
+STX_DEV void load_px8_u8(const uint8_t* img0, uint32_t img0_stride, const uint8_t* mask0, uint32_t mask0_stride, int lx0, int ly, uint32_t vm0,
+                         uint32_t vm1, uint32_t (&pw)[6], uint32_t (&mw)[2])
 {
-    const uint32_t off = (uint32_t)ly * (uint32_t)im.img0_stride + (uint32_t)(lx0 * 3 + 64);
-    const STX_GAS uint8_t* q = gp(im.img0) - 64 + (off & ~3u);
+    const uint32_t off = (uint32_t)ly * img0_stride + (uint32_t)(lx0 * 3 + 64);
+    const STX_GAS uint8_t* q = gp(img0) - 64 + (off & ~3u);
     const uint32_t s = off & 3u;
     const v4u d0 = *reinterpret_cast<const STX_GAS v4u_a4*>(q);
     const v4u d1 = *reinterpret_cast<const STX_GAS v4u_a4*>(q + 16);
@@ -270,13 +271,17 @@ STX_DEV void load_px8_u8(const StxMbImage& im, int lx0, int ly, uint32_t vm0, ui
     pw[3] = __builtin_amdgcn_alignbyte(d1.x, d0.w, s);
     pw[4] = __builtin_amdgcn_alignbyte(d1.y, d1.x, s);
     pw[5] = __builtin_amdgcn_alignbyte(d1.z, d1.y, s);
-    const uint32_t moff = (uint32_t)ly * (uint32_t)im.mask0_stride + (uint32_t)(lx0 + 64);
-    const STX_GAS uint8_t* mq = gp(im.mask0) - 64 + (moff & ~3u);
+    const uint32_t moff = (uint32_t)ly * mask0_stride + (uint32_t)(lx0 + 64);
+    const STX_GAS uint8_t* mq = gp(mask0) - 64 + (moff & ~3u);
     const uint32_t ms = moff & 3u;
     const uint32_t m0 = *reinterpret_cast<const STX_GAS uint32_t*>(mq), m1 = *reinterpret_cast<const STX_GAS uint32_t*>(mq + 4),
                    m2 = *reinterpret_cast<const STX_GAS uint32_t*>(mq + 8);
     mw[0] = __builtin_amdgcn_alignbyte(m1, m0, ms) & vm0;
     mw[1] = __builtin_amdgcn_alignbyte(m2, m1, ms) & vm1;
+}
+STX_DEV void load_px8_u8(const StxMbImage& im, int lx0, int ly, uint32_t vm0, uint32_t vm1, uint32_t (&pw)[6], uint32_t (&mw)[2])
+{
+    load_px8_u8(im.img0, (uint32_t)im.img0_stride, im.mask0, (uint32_t)im.mask0_stride, lx0, ly, vm0, vm1, pw, mw);
 }
 
 STX_DEV int s16lo(uint32_t v) { return (int)(short)(v & 0xffffu); }
@@ -364,8 +369,17 @@ STX_DEV void dn_pack5_channel(const uint32_t* w, short* hs)
 // NEAR: the border of the image inside its feed rectangle is narrower than the image (left, right <= iw, top, bottom <= ih: every
 // position is at most one mirror image away: branch-free index maps, no division); !NEAR (an exchange strip a few columns wide inside
 // a 96-column border): cv::borderInterpolate's general form
-template <bool PK, bool NEAR>
-STX_DEV void dn_task_level0(const StxMbImage& im, int row, int xo, short* hs0, short* hs1, short* hs2, float* hw)
+// What the level-0 pyrDown reads of an image's descriptor, fetched ONCE per workgroup as one batch of scalar loads and pinned in scalar
+// registers (round 6): read through the descriptor inside the task loop, the fields came back as dependent scalar-cache round trips
+// in every iteration (the compiler sinks a kernel-argument load to its first use: three s_load + wait pairs per task).
+struct DnImage0 {
+    int fw, fh, iw, ih, left, top;
+    uint32_t img0_stride, mask0_stride;
+    const uint8_t* img0;
+    const uint8_t* mask0;
+};
+template <bool PK, bool NEAR, class IM>
+STX_DEV void dn_task_level0(const IM& im, int row, int xo, short* hs0, short* hs1, short* hs2, float* hw)
 {
     const int by = reflect101_near(row, im.fh) - im.top;  // bordered row -> image row
     const bool yin = (unsigned)by < (unsigned)im.ih;
@@ -492,16 +506,41 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
     uint8_t* const occ = im.occ[1];
     const bool w1h = im.w1_f16 != 0;
     asm volatile("" ::"s"(occ));  // fetched with the other descriptor fields, not at the tail where nothing hides the round trip
+    DnImage0 D;
+    {
+        int fw = im.fw, fh = im.fh, iw_ = im.iw, ih_ = im.ih, left = im.left, top = im.top;
+        uint32_t is = (uint32_t)im.img0_stride, ms = (uint32_t)im.mask0_stride;
+        unsigned long long ia = (unsigned long long)im.img0, ma = (unsigned long long)im.mask0;
+        // (the binary-mask instantiation only: the grey-mask one measured 148 -> 155 us with its fields pinned, three interleaved runs of the
+        // reference-default leg, tools/gpu_r6r.sh; the binary one 121.7 -> 120.1)
+        if (PK) asm volatile("" : "+s"(fw), "+s"(fh), "+s"(iw_), "+s"(ih_), "+s"(left), "+s"(top), "+s"(is), "+s"(ms), "+s"(ia), "+s"(ma));
+        D.fw = fw; D.fh = fh; D.iw = iw_; D.ih = ih_; D.left = left; D.top = top; D.img0_stride = is; D.mask0_stride = ms;
+        D.img0 = (const uint8_t*)ia; D.mask0 = (const uint8_t*)ma;
+    }
+    // ... and what the second phase stores through (they came back as five more scalar round trips behind the barrier, once per row)
+    uint32_t g1_plane = 0, g1_stride = 0, w1_stride = 0;
+    unsigned long long g1_a = 0, w1_a = 0;
+    if (PK) {
+        g1_plane = (uint32_t)im.g_plane[1]; g1_stride = (uint32_t)im.g_stride[1]; w1_stride = (uint32_t)im.wt_stride[1];
+        g1_a = (unsigned long long)im.g[1]; w1_a = (unsigned long long)im.wt[1];
+        asm volatile("" : "+s"(g1_plane), "+s"(g1_stride), "+s"(w1_stride), "+s"(g1_a), "+s"(w1_a));
+    }
     // rows / columns of the tile past the image's last output feed nothing (narrow exchange strips and the right / bottom
     // edge tiles would otherwise run the reflecting slow path for them)
     const int r_end = 2 * min(DN_TOH, oh - Y0) + 3;
     // uniform for the workgroup: which form of the border index maps this image needs (dn_task_level0)
-    const bool near = im.left <= im.iw && im.fw - im.left - im.iw <= im.iw && im.top <= im.ih && im.fh - im.top - im.ih <= im.ih;
+    const bool near = PK ? (D.left <= D.iw && D.fw - D.left - D.iw <= D.iw && D.top <= D.ih && D.fh - D.top - D.ih <= D.ih)
+                         : (im.left <= im.iw && im.fw - im.left - im.iw <= im.iw && im.top <= im.ih && im.fh - im.top - im.ih <= im.ih);
     for (int task = tid; task < DN_ROWS * (DN_TOW / 4); task += 256) {
         const int r = task / (DN_TOW / 4), q = task % (DN_TOW / 4);
         if (X0 + 4 * q >= ow || r >= r_end) continue;
-        if (near) dn_task_level0<PK, true>(im, 2 * Y0 - 2 + r, X0 + 4 * q, &s_h[0][r][4 * q], &s_h[1][r][4 * q], &s_h[2][r][4 * q], &s_w[r][4 * q]);
-        else dn_task_level0<PK, false>(im, 2 * Y0 - 2 + r, X0 + 4 * q, &s_h[0][r][4 * q], &s_h[1][r][4 * q], &s_h[2][r][4 * q], &s_w[r][4 * q]);
+        if (PK) {  // the pinned copy of the descriptor
+            if (near) dn_task_level0<PK, true>(D, 2 * Y0 - 2 + r, X0 + 4 * q, &s_h[0][r][4 * q], &s_h[1][r][4 * q], &s_h[2][r][4 * q], &s_w[r][4 * q]);
+            else dn_task_level0<PK, false>(D, 2 * Y0 - 2 + r, X0 + 4 * q, &s_h[0][r][4 * q], &s_h[1][r][4 * q], &s_h[2][r][4 * q], &s_w[r][4 * q]);
+        } else {   // the descriptor itself, as rounds 1 - 5 read it
+            if (near) dn_task_level0<PK, true>(im, 2 * Y0 - 2 + r, X0 + 4 * q, &s_h[0][r][4 * q], &s_h[1][r][4 * q], &s_h[2][r][4 * q], &s_w[r][4 * q]);
+            else dn_task_level0<PK, false>(im, 2 * Y0 - 2 + r, X0 + 4 * q, &s_h[0][r][4 * q], &s_h[1][r][4 * q], &s_h[2][r][4 * q], &s_w[r][4 * q]);
+        }
     }
     __syncthreads();
     const int p = tid & 31, rg = tid >> 5;  // output pair, row group (2 rows)
@@ -521,7 +560,8 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
             for (int k = 0; k < 5; k++) a[k] = pk(*reinterpret_cast<const uint32_t*>(&s_h[c][2 * yl + k][2 * p]));
             const pk16 v = (a[0] + a[4] + a[2] * pk_splat(6) + (a[1] + a[3]) * pk_splat(4) + pk_splat(128)) >> pk_splat(8);
             // G_1 of a u8 image is <= 255: one byte per sample (StxMbImage::g_u8)
-            STX_GAS uint8_t* o = gp(reinterpret_cast<uint8_t*>(im.g[1])) + ((uint32_t)c * (uint32_t)im.g_plane[1] + (uint32_t)y * (uint32_t)im.g_stride[1] + (uint32_t)xo);
+            STX_GAS uint8_t* o = PK ? gp(reinterpret_cast<uint8_t*>(g1_a)) + ((uint32_t)c * g1_plane + (uint32_t)y * g1_stride + (uint32_t)xo)
+                                    : gp(reinterpret_cast<uint8_t*>(im.g[1])) + ((uint32_t)c * (uint32_t)im.g_plane[1] + (uint32_t)y * (uint32_t)im.g_stride[1] + (uint32_t)xo);
             const uint32_t b2 = __builtin_amdgcn_perm(0u, unpk(v), 0x0c0c0200u);
             if (two) *reinterpret_cast<STX_GAS uint16_t*>(o) = (uint16_t)b2;
             else o[0] = (uint8_t)b2;
@@ -543,12 +583,14 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
         const float wa = fmul(h5f(fa[0], fa[1], fa[2], fa[3], fa[4]), INV256);
         const float wb = fmul(h5f(fb[0], fb[1], fb[2], fb[3], fb[4]), INV256);
         if (w1h) {  // StxMbImage::w1_f16: k / 256 as halves (exact: a 9-bit significand)
-            STX_GAS _Float16* o = reinterpret_cast<STX_GAS _Float16*>(gp(im.wt[1])) + ((uint32_t)y * (uint32_t)im.wt_stride[1] + (uint32_t)xo);
+            STX_GAS _Float16* o = PK ? gp(reinterpret_cast<_Float16*>(w1_a)) + ((uint32_t)y * w1_stride + (uint32_t)xo)
+                                     : reinterpret_cast<STX_GAS _Float16*>(gp(im.wt[1])) + ((uint32_t)y * (uint32_t)im.wt_stride[1] + (uint32_t)xo);
             typedef _Float16 v2h16 __attribute__((ext_vector_type(2)));
             if (two) { const v2h16 wab = {(_Float16)wa, (_Float16)wb}; *reinterpret_cast<STX_GAS v2h16*>(o) = wab; }
             else o[0] = (_Float16)wa;
         } else {
-            STX_GAS float* o = gp(im.wt[1]) + ((uint32_t)y * (uint32_t)im.wt_stride[1] + (uint32_t)xo);
+            STX_GAS float* o = PK ? gp(reinterpret_cast<float*>(w1_a)) + ((uint32_t)y * w1_stride + (uint32_t)xo)
+                                  : gp(im.wt[1]) + ((uint32_t)y * (uint32_t)im.wt_stride[1] + (uint32_t)xo);
             typedef float v2fl __attribute__((ext_vector_type(2)));
             if (two) { const v2fl wab = {wa, wb}; *reinterpret_cast<STX_GAS v2fl*>(o) = wab; }
             else o[0] = wa;
@@ -608,9 +650,15 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
     if (!xcd_tile(M, blockIdx.x, tile_tx, tile_ty)) return;
     const int X0 = tile_tx * DN_TOW, Y0 = tile_ty * DN_TOH;
     if (X0 >= ow || Y0 >= oh) return;
-    const short* G = im.g[lv];
     const bool g8b = im.g_u8 != 0;  // byte planes (u8 image) or int16 planes: uniform for the workgroup
-    const uint32_t gs = (uint32_t)im.g_stride[lv], gpl = (uint32_t)im.g_plane[lv];
+    // every descriptor field of both phases in ONE batch of scalar loads, pinned (round 6: as in the level-0 kernel — the weight pointer
+    // came back inside the task loop, the output pointers behind the barrier, once per row: seven dependent scalar round trips)
+    unsigned long long G_a = (unsigned long long)im.g[lv], W_a = (unsigned long long)im.wt[lv];
+    unsigned long long Go_a = (unsigned long long)im.g[lv + 1], Wo_a = (unsigned long long)im.wt[lv + 1];
+    uint32_t gs = (uint32_t)im.g_stride[lv], gpl = (uint32_t)im.g_plane[lv], wst = (uint32_t)im.wt_stride[lv];
+    uint32_t gos = (uint32_t)im.g_stride[lv + 1], gopl = (uint32_t)im.g_plane[lv + 1], wost = (uint32_t)im.wt_stride[lv + 1];
+    asm volatile("" : "+s"(G_a), "+s"(W_a), "+s"(Go_a), "+s"(Wo_a), "+s"(gs), "+s"(gpl), "+s"(wst), "+s"(gos), "+s"(gopl), "+s"(wost));
+    const short* G = (const short*)G_a;
     uint8_t* const occ = im.occ[lv + 1];
     const bool w_half = lv == 1 && im.w1_f16 != 0;
     asm volatile("" ::"s"(occ));  // as in the level-0 kernel
@@ -643,10 +691,10 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
             *reinterpret_cast<int4*>(&s_h[c][r][4 * q]) = make_int4(lo.x, lo.z, hi.x, hi.z);
             *reinterpret_cast<int4*>(&s_h[c][r][32 + 4 * q]) = make_int4(lo.y, lo.w, hi.y, hi.w);
         }
-        const STX_GAS float* wq = gp(im.wt[lv]) + (uint32_t)sy * (uint32_t)im.wt_stride[lv];
+        const STX_GAS float* wq = gp(reinterpret_cast<const float*>(W_a)) + (uint32_t)sy * wst;
         float f[19];
         if (w_half) {  // level 1 as halves (StxMbImage::w1_f16): the same 19 samples from half the bytes
-            const STX_GAS _Float16* hq = reinterpret_cast<const STX_GAS _Float16*>(gp(im.wt[1])) + (uint32_t)sy * (uint32_t)im.wt_stride[1];
+            const STX_GAS _Float16* hq = gp(reinterpret_cast<const _Float16*>(W_a)) + (uint32_t)sy * wst;
             if (fast) {
                 typedef _Float16 v2h16 __attribute__((ext_vector_type(2)));
                 typedef _Float16 v8h16 __attribute__((ext_vector_type(8)));
@@ -706,13 +754,13 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
             }
             const int va = (h5i(a[0], a[1], a[2], a[3], a[4]) + 128) >> 8;
             const int vb = (h5i(b[0], b[1], b[2], b[3], b[4]) + 128) >> 8;
-            const uint32_t oo = (uint32_t)c * (uint32_t)im.g_plane[lv + 1] + (uint32_t)y * (uint32_t)im.g_stride[lv + 1] + (uint32_t)xo;
+            const uint32_t oo = (uint32_t)c * gopl + (uint32_t)y * gos + (uint32_t)xo;
             if (g8b) {
-                STX_GAS uint8_t* o = gp(reinterpret_cast<uint8_t*>(im.g[lv + 1])) + oo;
+                STX_GAS uint8_t* o = gp(reinterpret_cast<uint8_t*>(Go_a)) + oo;
                 if (two) *reinterpret_cast<STX_GAS uint16_t*>(o) = (uint16_t)((uint32_t)va | ((uint32_t)vb << 8));
                 else o[0] = (uint8_t)va;
             } else {
-                STX_GAS short* o = gp(im.g[lv + 1]) + oo;
+                STX_GAS short* o = gp(reinterpret_cast<short*>(Go_a)) + oo;
                 if (two) *reinterpret_cast<STX_GAS uint32_t*>(o) = pack16(va, vb);
                 else o[0] = (short)va;
             }
@@ -725,7 +773,7 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
         }
         const float wa = fmul(h5f(fa[0], fa[1], fa[2], fa[3], fa[4]), INV256);
         const float wb = fmul(h5f(fb[0], fb[1], fb[2], fb[3], fb[4]), INV256);
-        STX_GAS float* o = gp(im.wt[lv + 1]) + ((uint32_t)y * (uint32_t)im.wt_stride[lv + 1] + (uint32_t)xo);
+        STX_GAS float* o = gp(reinterpret_cast<float*>(Wo_a)) + ((uint32_t)y * wost + (uint32_t)xo);
         typedef float v2fl __attribute__((ext_vector_type(2)));
         if (two) { const v2fl wab = {wa, wb}; *reinterpret_cast<STX_GAS v2fl*>(o) = wab; }
         else o[0] = wa;
@@ -878,16 +926,17 @@ STX_DEV void level_epilogue(const MbLevelK& P, int X0, int Y0, int (&acc)[2][8][
 // frame position (x, y) makes W_1(x >> 1, y >> 1) non-zero (the taps 2 x', 2 x' + 1 of the 5-tap kernel are direct, the weights
 // are non-negative and far above underflow), so the level-1 entries over (x >> 1, y >> 1) bound it.  Passing over an image whose
 // weights are all exactly 0 changes nothing: (short)(L * 0.f) = 0 and w + 0.f = w.
+// (the fields as values: a caller that has them in registers — loaded in one batch with the rest of its image search — spares the
+// dependent loads of the pointer and of the rectangle)
 template <bool L0>
-STX_DEV bool occ_hit(const StxMbImage& im, int lv, int tile_x, int Y0)
+STX_DEV bool occ_hit_f(const uint8_t* occ, int fx, int fy, int fw, int fh, int lv, int tile_x, int Y0)
 {
     const int sl = L0 ? 1 : lv;
-    const uint8_t* occ = im.occ[sl];
     if (occ == nullptr) return true;
-    const int lw = im.fw >> sl, lh = im.fh >> sl;
-    const int fr = L0 ? (Y0 - im.fy) >> 1 : Y0 - (im.fy >> lv);  // row of level sl, frame coordinates
-    int x0 = L0 ? (tile_x - im.fx) >> 1 : tile_x - (im.fx >> lv);
-    int x1 = L0 ? (tile_x + 511 - im.fx) >> 1 : x0 + 511;
+    const int lw = fw >> sl, lh = fh >> sl;
+    const int fr = L0 ? (Y0 - fy) >> 1 : Y0 - (fy >> lv);  // row of level sl, frame coordinates
+    int x0 = L0 ? (tile_x - fx) >> 1 : tile_x - (fx >> lv);
+    int x1 = L0 ? (tile_x + 511 - fx) >> 1 : x0 + 511;
     x0 = max(x0, 0); x1 = min(x1, lw - 1);
     if (fr < 0 || fr >= lh || x0 > x1) return true;
     // entries t0 .. t1 (at most 5 at level 0: 256 columns of level 1; 9 otherwise) from one dword-aligned 8 / 12-byte load (rows
@@ -905,6 +954,11 @@ STX_DEV bool occ_hit(const StxMbImage& im, int lv, int tile_x, int Y0)
     const uint32_t m0 = n >= 4 ? 0xffffffffu : (1u << (8 * n)) - 1u;
     const uint32_t m1 = n >= 8 ? 0xffffffffu : (n > 4 ? (1u << (8 * (n - 4))) - 1u : 0u);
     return ((w0 & m0) | (w1 & m1) | (n > 8 ? w2 & 0xffu : 0u)) != 0u;
+}
+template <bool L0>
+STX_DEV bool occ_hit(const StxMbImage& im, int lv, int tile_x, int Y0)
+{
+    return occ_hit_f<L0>(im.occ[L0 ? 1 : lv], im.fx, im.fy, im.fw, im.fh, lv, tile_x, Y0);
 }
 
 template <bool WF, bool AHEAD = true>
@@ -1528,10 +1582,13 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(STX_
             if (DEFER || CONTRIB) {
                 const StxMbImage& im = P.images[min(kk, P.n_images - 1)];
                 const v4u f = *reinterpret_cast<const v4u_a4*>(&im.iw);  // iw, ih, ix, iy
+                const v4u ff = *reinterpret_cast<const v4u_a4*>(&im.fx);  // fx, fy, fw, fh
+                const uint8_t* const occp = im.occ[1];
+                const int kind = CONTRIB ? im.kind : 0;
                 int rx = (int)f.z, ry = (int)f.w, rw = (int)f.x, rh = (int)f.y;
-                if (CONTRIB && im.kind == 1) { rx = im.fx; ry = im.fy; rw = im.fw; rh = im.fh; }
+                if (CONTRIB && kind == 1) { rx = (int)ff.x; ry = (int)ff.y; rw = (int)ff.z; rh = (int)ff.w; }
                 hit = (kk < P.n_images) & (rx < tile_x + 512) & (rx + rw > tile_x) & (ry < Y0 + 2) & (ry + rh > Y0);
-                if (hit) hit = occ_hit<true>(im, 0, tile_x, Y0);
+                if (hit) hit = occ_hit_f<true>(occp, (int)ff.x, (int)ff.y, (int)ff.z, (int)ff.w, 0, tile_x, Y0);
             } else if (kk < P.n_images) {
                 const StxMbImage& im = P.images[kk];
                 const int rx = im.ix, ry = im.iy, rw = im.iw, rh = im.ih;
@@ -1570,8 +1627,14 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(STX_
                 }
                 continue;
             }
-            const int lx0 = X0 - im.ix, ly0 = Y0 - im.iy;
-            if (lx0 + 8 <= 0 || lx0 >= im.iw || ly0 + 2 <= 0 || ly0 >= im.ih) continue;
+            // every field of the image's descriptor this iteration reads, as ONE batch of scalar loads (round 6, as in mb_level_pk_kernel)
+            int i_ix = im.ix, i_iy = im.iy, i_iw = im.iw, i_ih = im.ih, i_fx = im.fx, i_fy = im.fy, i_fw = im.fw, i_fh = im.fh;
+            unsigned long long I_a = (unsigned long long)im.img0, M_a = (unsigned long long)im.mask0, G1_a = (unsigned long long)im.g[1];
+            uint32_t ist = (uint32_t)im.img0_stride, mst = (uint32_t)im.mask0_stride, g1s = (uint32_t)im.g_stride[1], g1p = (uint32_t)im.g_plane[1];
+            asm("" : "+s"(i_ix), "+s"(i_iy), "+s"(i_iw), "+s"(i_ih), "+s"(i_fx), "+s"(i_fy), "+s"(i_fw), "+s"(i_fh), "+s"(I_a), "+s"(M_a), "+s"(G1_a),
+                "+s"(ist), "+s"(mst), "+s"(g1s), "+s"(g1p));
+            const int lx0 = X0 - i_ix, ly0 = Y0 - i_iy;
+            if (lx0 + 8 <= 0 || lx0 >= i_iw || ly0 + 2 <= 0 || ly0 >= i_ih) continue;
             // lanes partly left / right of the image take the same aligned loads (load_px8_u8): no per-pixel path
             uint32_t pw_[2][6], mw[2][2];
 #pragma unroll
@@ -1580,12 +1643,12 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(STX_
 #pragma unroll
                 for (int q = 0; q < 6; q++) pw_[r][q] = 0;
                 mw[r][0] = mw[r][1] = 0;
-                if ((unsigned)ly >= (unsigned)im.ih) continue;
-                load_px8_u8(im, lx0, ly, 0xffffffffu, 0xffffffffu, pw_[r], mw[r]);
+                if ((unsigned)ly >= (unsigned)i_ih) continue;
+                load_px8_u8((const uint8_t*)I_a, ist, (const uint8_t*)M_a, mst, lx0, ly, 0xffffffffu, 0xffffffffu, pw_[r], mw[r]);
             }
             {   // mask bytes of the pixels outside the image: cleared (after the loads: two registers less while they are in flight)
                 uint32_t vm0, vm1;
-                lane_valid_bytes(lx0, im.iw, vm0, vm1);
+                lane_valid_bytes(lx0, i_iw, vm0, vm1);
                 mw[0][0] &= vm0; mw[0][1] &= vm1; mw[1][0] &= vm0; mw[1][1] &= vm1;
             }
             if (DEFER) {
@@ -1598,8 +1661,8 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(STX_
                     }
             }
             // (no early-out on an all-zero mask: it would put the G_1 loads behind the mask loads' round trip)
-            const uint32_t g1_boff = (uint32_t)((X0 - im.fx) >> 1);  // this lane's samples of G_1 (bytes): offset in a row
-            const UpSel g1_sel = up_sel_u8(X0 == im.fx, ((X0 - im.fx) >> 1) + 4 >= (im.fw >> 1));
+            const uint32_t g1_boff = (uint32_t)((X0 - i_fx) >> 1);  // this lane's samples of G_1 (bytes): offset in a row
+            const UpSel g1_sel = up_sel_u8(X0 == i_fx, ((X0 - i_fx) >> 1) + 4 >= (i_fw >> 1));
             uint32_t M[2][4];
 #pragma unroll
             for (int r = 0; r < 2; r++) {
@@ -1616,7 +1679,7 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(STX_
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 pk16 up[2][4];
-                up_patch_pk(g8(im, 1, c), (uint32_t)im.g_stride[1], im.fh >> 1, g1_boff, (Y0 - im.fy) >> 1, g1_sel, up);
+                up_patch_pk(gp(reinterpret_cast<const uint8_t*>(G1_a)) + (uint32_t)c * g1p, g1s, i_fh >> 1, g1_boff, (Y0 - i_fy) >> 1, g1_sel, up);
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
                     uint32_t px[4];
@@ -1820,9 +1883,10 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(STX_
             const int kk = base + (tid & 63);
             const StxMbImage& im = P.images[min(kk, P.n_images - 1)];
             const v4u f = *reinterpret_cast<const v4u_a4*>(&im.fx);  // fx, fy, fw, fh
+            const uint8_t* const occp = im.occ[lv];                  // (in the same batch: the occupancy test then costs one round trip, not two)
             const int rx = (int)f.x >> lv, ry = (int)f.y >> lv, rw = (int)f.z >> lv, rh = (int)f.w >> lv;
             hit = (kk < P.n_images) & (rx < tile_x + 512) & (rx + rw > tile_x) & (ry < Y0 + 2) & (ry + rh > Y0);
-            if (hit) hit = occ_hit<false>(im, lv, tile_x, Y0);
+            if (hit) hit = occ_hit_f<false>(occp, (int)f.x, (int)f.y, (int)f.z, (int)f.w, lv, tile_x, Y0);
         }
         unsigned long long todo = __ballot(hit);
         while (todo) {
@@ -1830,11 +1894,21 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(STX_
             todo &= todo - 1;
             const StxMbImage& im = P.images[k];
             if (!active) continue;
-            const int lx0 = X0 - (im.fx >> lv), ly0 = Y0 - (im.fy >> lv);
-            const int lw = im.fw >> lv, lh = im.fh >> lv;
+            // every field of the image's descriptor this iteration reads, as ONE batch of scalar loads (round 6: left to the compiler
+            // they came back one dependent scalar-cache round trip after the other — rectangle, weight pointer, value pointers — in
+            // front of the vector loads they address)
+            int i_fx = im.fx, i_fy = im.fy, i_fw = im.fw, i_fh = im.fh, i_w1h = im.w1_f16;
+            unsigned long long W_a = (unsigned long long)im.wt[lv], G0_a = (unsigned long long)im.g[lv], G1_a = (unsigned long long)im.g[lv + 1];
+            uint32_t wst = (uint32_t)im.wt_stride[lv], g0s = (uint32_t)im.g_stride[lv], g1s = (uint32_t)im.g_stride[lv + 1];
+            uint32_t g0p = (uint32_t)im.g_plane[lv], g1p = (uint32_t)im.g_plane[lv + 1];
+            // (not volatile: a side-effecting asm counts as a memory clobber and would turn the NEXT iteration's descriptor loads into vector loads)
+            asm("" : "+s"(i_fx), "+s"(i_fy), "+s"(i_fw), "+s"(i_fh), "+s"(i_w1h), "+s"(W_a), "+s"(G0_a), "+s"(G1_a), "+s"(wst), "+s"(g0s),
+                "+s"(g1s), "+s"(g0p), "+s"(g1p));
+            const int lx0 = X0 - (i_fx >> lv), ly0 = Y0 - (i_fy >> lv);
+            const int lw = i_fw >> lv, lh = i_fh >> lv;
             if ((unsigned)lx0 >= (unsigned)lw || (unsigned)ly0 >= (unsigned)lh) continue;
             // the 16 weights (bit patterns; all in [0, 1], so unsigned order = float order)
-            const bool w_half = lv == 1 && im.w1_f16 != 0;
+            const bool w_half = lv == 1 && i_w1h != 0;
             uint32_t wb[2][8];
             typedef _Float16 v8h16 __attribute__((ext_vector_type(8)));
             v8h16 hw[2];
@@ -1844,12 +1918,11 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(STX_
             if (w_half) {  // level 1 as halves (StxMbImage::w1_f16): one 16-byte load per row
 #pragma unroll
                 for (int r = 0; r < 2; r++)
-                    hw[r] = *reinterpret_cast<const STX_GAS v8h16*>(reinterpret_cast<const STX_GAS _Float16*>(gp(im.wt[1])) +
-                                                                   ((uint32_t)(ly0 + r) * (uint32_t)im.wt_stride[1] + (uint32_t)lx0));
+                    hw[r] = *reinterpret_cast<const STX_GAS v8h16*>(gp(reinterpret_cast<const _Float16*>(W_a)) + ((uint32_t)(ly0 + r) * wst + (uint32_t)lx0));
             } else {
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
-                    const STX_GAS float* q = gp(im.wt[lv]) + ((uint32_t)(ly0 + r) * (uint32_t)im.wt_stride[lv] + (uint32_t)lx0);
+                    const STX_GAS float* q = gp(reinterpret_cast<const float*>(W_a)) + ((uint32_t)(ly0 + r) * wst + (uint32_t)lx0);
                     const v4u a = *reinterpret_cast<const STX_GAS v4u*>(q), b = *reinterpret_cast<const STX_GAS v4u*>(q + 4);
                     wb[r][0] = a.x; wb[r][1] = a.y; wb[r][2] = a.z; wb[r][3] = a.w;
                     wb[r][4] = b.x; wb[r][5] = b.y; wb[r][6] = b.z; wb[r][7] = b.w;
@@ -1861,8 +1934,9 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(STX_
             v2u grow[3][2];
 #define STX_LVPK_LOAD(c)                                                                                                            \
     {                                                                                                                              \
-        up_patch_pk_load(g8(im, lv + 1, c), (uint32_t)im.g_stride[lv + 1], lh >> 1, g1_boff, ly0 >> 1, win[c]);                    \
-        _Pragma("unroll") for (int r = 0; r < 2; r++) grow[c][r] = g8_row_load(g8(im, lv, c), ly0 + r, (uint32_t)im.g_stride[lv], (uint32_t)lx0); \
+        up_patch_pk_load(gp(reinterpret_cast<const uint8_t*>(G1_a)) + (uint32_t)(c) * g1p, g1s, lh >> 1, g1_boff, ly0 >> 1, win[c]);    \
+        _Pragma("unroll") for (int r = 0; r < 2; r++)                                                                              \
+            grow[c][r] = g8_row_load(gp(reinterpret_cast<const uint8_t*>(G0_a)) + (uint32_t)(c) * g0p, ly0 + r, g0s, (uint32_t)lx0);   \
     }
 #if STX_LVPK_LOOP
 #pragma unroll
