@@ -531,7 +531,72 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
     // uniform for the workgroup: which form of the border index maps this image needs (dn_task_level0)
     const bool near = PK ? (D.left <= D.iw && D.fw - D.left - D.iw <= D.iw && D.top <= D.ih && D.fh - D.top - D.ih <= D.ih)
                          : (im.left <= im.iw && im.fw - im.left - im.iw <= im.iw && im.top <= im.ih && im.fh - im.top - im.ih <= im.ih);
-    for (int task = tid; task < DN_ROWS * (DN_TOW / 4); task += 256) {
+    // (round 6) Binary masks, every 11-pixel run of the wavefront inside the image: a lane's TWO tasks — the same column group q in the
+    // rows r and r + 16 — take their seven image loads and two mask loads in ONE batch.  The task loop below makes four dependent memory
+    // round trips of them (image, then the mask behind its row test; twice) in front of the workgroup's barrier.
+    bool batched = false;
+    if (PK && near) {
+        const int q = tid & 15, rA = tid >> 4;
+        const int xo = X0 + 4 * q, c0 = 2 * xo - 2, a0 = c0 - D.left;
+        const bool col_ok = xo < ow;
+        const bool interior = c0 >= 0 && c0 + 10 < D.fw && a0 >= 0 && a0 + 10 < D.iw;
+        batched = __builtin_amdgcn_ballot_w64(col_ok && !interior) == 0ull;  // wave-uniform; the four wavefronts decide for themselves
+        if (batched && col_ok) {
+            v4u d0[2], d1[2], mq4[2];
+            v2u d2[2];
+            uint32_t sh[2], msh[2];
+            bool yin[2], live[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int r = rA + 16 * t;
+                live[t] = r < r_end && r < DN_ROWS;
+                const int row = 2 * Y0 - 2 + min(r, r_end - 1);  // (a row past the tile's last is loaded from the last and not stored)
+                const int by = reflect101_near(row, D.fh) - D.top;
+                yin[t] = (unsigned)by < (unsigned)D.ih;
+                const int sy = reflect_near(by, D.ih);
+                const uint32_t off = (uint32_t)sy * D.img0_stride + (uint32_t)a0 * 3u;
+                const STX_GAS uint8_t* p = gp(D.img0) + (off & ~3u);
+                sh[t] = off & 3u;
+                d0[t] = *reinterpret_cast<const STX_GAS v4u_a4*>(p);
+                d1[t] = *reinterpret_cast<const STX_GAS v4u_a4*>(p + 16);
+                d2[t] = *reinterpret_cast<const STX_GAS v2u_a4*>(p + 32);
+                const uint32_t moff = (uint32_t)min(max(by, 0), D.ih - 1) * D.mask0_stride + (uint32_t)a0;  // 11 bytes (cleared below when !yin)
+                msh[t] = moff & 3u;
+                mq4[t] = *reinterpret_cast<const STX_GAS v4u_a4*>(gp(D.mask0) + (moff & ~3u));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                if (!live[t]) continue;
+                const int r = rA + 16 * t;
+                uint32_t w[9];
+                w[0] = __builtin_amdgcn_alignbyte(d0[t].y, d0[t].x, sh[t]);
+                w[1] = __builtin_amdgcn_alignbyte(d0[t].z, d0[t].y, sh[t]);
+                w[2] = __builtin_amdgcn_alignbyte(d0[t].w, d0[t].z, sh[t]);
+                w[3] = __builtin_amdgcn_alignbyte(d1[t].x, d0[t].w, sh[t]);
+                w[4] = __builtin_amdgcn_alignbyte(d1[t].y, d1[t].x, sh[t]);
+                w[5] = __builtin_amdgcn_alignbyte(d1[t].z, d1[t].y, sh[t]);
+                w[6] = __builtin_amdgcn_alignbyte(d1[t].w, d1[t].z, sh[t]);
+                w[7] = __builtin_amdgcn_alignbyte(d2[t].x, d1[t].w, sh[t]);
+                w[8] = __builtin_amdgcn_alignbyte(d2[t].y, d2[t].x, sh[t]);
+                dn_pack5_channel<false, 0>(w, &s_h[0][r][4 * q]);
+                dn_pack5_channel<false, 1>(w, &s_h[1][r][4 * q]);
+                dn_pack5_channel<false, 2>(w, &s_h[2][r][4 * q]);
+                const uint32_t keep = yin[t] ? 0x01010101u : 0u;  // 0 / 255 -> 0 / 1; a row outside the image: the weight's border is CONSTANT 0
+                uint32_t mb[3];
+                mb[0] = __builtin_amdgcn_alignbyte(mq4[t].y, mq4[t].x, msh[t]) & keep;
+                mb[1] = __builtin_amdgcn_alignbyte(mq4[t].z, mq4[t].y, msh[t]) & keep;
+                mb[2] = __builtin_amdgcn_alignbyte(mq4[t].w, mq4[t].z, msh[t]) & keep & 0x00ffffffu;
+                const pk16 o01 = pk(pair_u8<0, 2>(mb)) + pk(pair_u8<4, 6>(mb)) + pk(pair_u8<2, 4>(mb)) * pk_splat(6) +
+                                 (pk(pair_u8<1, 3>(mb)) + pk(pair_u8<3, 5>(mb))) * pk_splat(4);
+                const pk16 o23 = pk(pair_u8<4, 6>(mb)) + pk(pair_u8<8, 10>(mb)) + pk(pair_u8<6, 8>(mb)) * pk_splat(6) +
+                                 (pk(pair_u8<5, 7>(mb)) + pk(pair_u8<7, 9>(mb))) * pk_splat(4);
+                *reinterpret_cast<float4*>(&s_w[r][4 * q]) = make_float4((float)(unpk(o01) & 0xffffu), (float)(unpk(o01) >> 16),
+                                                                        (float)(unpk(o23) & 0xffffu), (float)(unpk(o23) >> 16));
+            }
+        }
+    }
+    for (int task = tid; task < DN_ROWS * (DN_TOW / 4) && !batched; task += 256) {
         const int r = task / (DN_TOW / 4), q = task % (DN_TOW / 4);
         if (X0 + 4 * q >= ow || r >= r_end) continue;
         if (PK) {  // the pinned copy of the descriptor
@@ -638,6 +703,37 @@ STX_DEV void dn_load19_s16(const STX_GAS short* __restrict__ base, uint32_t off,
     }
 }
 
+// horizontal 1-4-6-4-1 sums of 19 samples -> 8 outputs, parked in the LDS column order of mb_down_lds_kernel (even output columns
+// in the first half of the row, odd ones in the second: see the kernel)
+STX_DEV void dn_hsum_store_i(const int (&s)[19], int* row_q)
+{
+    int4 lo, hi;
+    lo.x = h5i(s[0], s[1], s[2], s[3], s[4]);
+    lo.y = h5i(s[2], s[3], s[4], s[5], s[6]);
+    lo.z = h5i(s[4], s[5], s[6], s[7], s[8]);
+    lo.w = h5i(s[6], s[7], s[8], s[9], s[10]);
+    hi.x = h5i(s[8], s[9], s[10], s[11], s[12]);
+    hi.y = h5i(s[10], s[11], s[12], s[13], s[14]);
+    hi.z = h5i(s[12], s[13], s[14], s[15], s[16]);
+    hi.w = h5i(s[14], s[15], s[16], s[17], s[18]);
+    *reinterpret_cast<int4*>(row_q) = make_int4(lo.x, lo.z, hi.x, hi.z);
+    *reinterpret_cast<int4*>(row_q + 32) = make_int4(lo.y, lo.w, hi.y, hi.w);
+}
+STX_DEV void dn_hsum_store_f(const float (&f)[19], float* row_q)
+{
+    float4 lo, hi;
+    lo.x = h5f(f[0], f[1], f[2], f[3], f[4]);
+    lo.y = h5f(f[2], f[3], f[4], f[5], f[6]);
+    lo.z = h5f(f[4], f[5], f[6], f[7], f[8]);
+    lo.w = h5f(f[6], f[7], f[8], f[9], f[10]);
+    hi.x = h5f(f[8], f[9], f[10], f[11], f[12]);
+    hi.y = h5f(f[10], f[11], f[12], f[13], f[14]);
+    hi.z = h5f(f[12], f[13], f[14], f[15], f[16]);
+    hi.w = h5f(f[14], f[15], f[16], f[17], f[18]);
+    *reinterpret_cast<float4*>(row_q) = make_float4(lo.x, lo.z, hi.x, hi.z);
+    *reinterpret_cast<float4*>(row_q + 32) = make_float4(lo.y, lo.w, hi.y, hi.w);
+}
+
 __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __restrict__ images, int lv, StxTileMap M)
 {
     __shared__ __attribute__((aligned(16))) int s_h[3][DN_ROWS][DN_TOW];
@@ -669,35 +765,76 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
         const int sy = reflect101_near(2 * Y0 - 2 + r, ih);
         const int c0 = 2 * (X0 + 8 * q) - 2;
         const bool fast = c0 >= 0 && c0 + 18 < iw;
+        typedef _Float16 v2h16 __attribute__((ext_vector_type(2)));
+        typedef _Float16 v8h16 __attribute__((ext_vector_type(8)));
+        // (round 6) a wavefront of a byte pyramid whose lanes are all clear of the border: the loads of the three planes and of the weights
+        // leave in ONE batch.  Plane by plane — a branch on `fast` sits in front of every plane's loads — a task was four dependent memory
+        // round trips, and a workgroup of this kernel is its tasks' round trips + a barrier.
+        if (g8b && __builtin_amdgcn_ballot_w64(!fast) == 0ull) {
+            uint32_t ra[3], rc[3];
+            v4u rb[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const STX_GAS uint8_t* pp = gp(reinterpret_cast<const uint8_t*>(G)) + ((uint32_t)c * gpl + (uint32_t)sy * gs + (uint32_t)c0);
+                ra[c] = *reinterpret_cast<const STX_GAS uint32_t*>(pp - 2);
+                rb[c] = *reinterpret_cast<const STX_GAS v4u*>(pp + 2);
+                rc[c] = *reinterpret_cast<const STX_GAS uint32_t*>(pp + 18);
+            }
+            float f[19];
+            if (w_half) {  // wave-uniform
+                const STX_GAS _Float16* hq = gp(reinterpret_cast<const _Float16*>(W_a)) + (uint32_t)sy * wst;
+                const v2h16 ha = *reinterpret_cast<const STX_GAS v2h16*>(hq + c0);
+                const v8h16 hb = *reinterpret_cast<const STX_GAS v8h16*>(hq + c0 + 2), hc = *reinterpret_cast<const STX_GAS v8h16*>(hq + c0 + 10);
+                const _Float16 hl = hq[c0 + 18];
+                __builtin_amdgcn_sched_barrier(0);
+                f[0] = (float)ha.x; f[1] = (float)ha.y;
+#pragma unroll
+                for (int k = 0; k < 8; k++) { f[2 + k] = (float)hb[k]; f[10 + k] = (float)hc[k]; }
+                f[18] = (float)hl;
+            } else {
+                const STX_GAS float* wq0 = gp(reinterpret_cast<const float*>(W_a)) + (uint32_t)sy * wst;
+                const v2u wa = *reinterpret_cast<const STX_GAS v2u*>(wq0 + c0);
+                v4u wb4[4];
+#pragma unroll
+                for (int k4 = 0; k4 < 4; k4++) wb4[k4] = *reinterpret_cast<const STX_GAS v4u*>(wq0 + c0 + 2 + 4 * k4);
+                const float wl = wq0[c0 + 18];
+                __builtin_amdgcn_sched_barrier(0);
+                f[0] = __uint_as_float(wa.x); f[1] = __uint_as_float(wa.y);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    f[2 + 4 * k] = __uint_as_float(wb4[k].x); f[3 + 4 * k] = __uint_as_float(wb4[k].y); f[4 + 4 * k] = __uint_as_float(wb4[k].z);
+                    f[5 + 4 * k] = __uint_as_float(wb4[k].w);
+                }
+                f[18] = wl;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const uint32_t w6[6] = {ra[c], rb[c].x, rb[c].y, rb[c].z, rb[c].w, rc[c]};
+                int s[19];
+#pragma unroll
+                for (int j = 0; j < 19; j++) s[j] = (int)byte_of(w6, j + 2);
+                dn_hsum_store_i(s, &s_h[c][r][4 * q]);
+            }
+            dn_hsum_store_f(f, &s_w[r][4 * q]);
+            continue;
+        }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             int s[19];
             if (g8b) dn_load19_u8(gp(reinterpret_cast<const uint8_t*>(G)), (uint32_t)c * gpl + (uint32_t)sy * gs, c0, iw, fast, s);
             else dn_load19_s16(gp(G), (uint32_t)c * gpl + (uint32_t)sy * gs, c0, iw, fast, s);
-            int4 lo, hi;
-            lo.x = h5i(s[0], s[1], s[2], s[3], s[4]);
-            lo.y = h5i(s[2], s[3], s[4], s[5], s[6]);
-            lo.z = h5i(s[4], s[5], s[6], s[7], s[8]);
-            lo.w = h5i(s[6], s[7], s[8], s[9], s[10]);
-            hi.x = h5i(s[8], s[9], s[10], s[11], s[12]);
-            hi.y = h5i(s[10], s[11], s[12], s[13], s[14]);
-            hi.z = h5i(s[12], s[13], s[14], s[15], s[16]);
-            hi.w = h5i(s[14], s[15], s[16], s[17], s[18]);
             // LDS column order: even output columns in the first half of the row, odd ones in the second (column c at
             // (c & 1) * 32 + (c >> 1)).  Stores: the eight lanes of a 16-byte store group write 128 contiguous bytes (natural
             // order: 32-byte lane pitch, lanes q and q + 4 on the same banks); loads: the pair (2p, 2p+1) is two dword
             // reads of 32 consecutive banks each (natural order: every other bank, twice).  3.5 conflict cycles per LDS
             // instruction measured with the natural order.
-            *reinterpret_cast<int4*>(&s_h[c][r][4 * q]) = make_int4(lo.x, lo.z, hi.x, hi.z);
-            *reinterpret_cast<int4*>(&s_h[c][r][32 + 4 * q]) = make_int4(lo.y, lo.w, hi.y, hi.w);
+            dn_hsum_store_i(s, &s_h[c][r][4 * q]);
         }
         const STX_GAS float* wq = gp(reinterpret_cast<const float*>(W_a)) + (uint32_t)sy * wst;
         float f[19];
         if (w_half) {  // level 1 as halves (StxMbImage::w1_f16): the same 19 samples from half the bytes
             const STX_GAS _Float16* hq = gp(reinterpret_cast<const _Float16*>(W_a)) + (uint32_t)sy * wst;
             if (fast) {
-                typedef _Float16 v2h16 __attribute__((ext_vector_type(2)));
-                typedef _Float16 v8h16 __attribute__((ext_vector_type(8)));
                 const v2h16 a = *reinterpret_cast<const STX_GAS v2h16*>(hq + c0);
                 const v8h16 b = *reinterpret_cast<const STX_GAS v8h16*>(hq + c0 + 2), c = *reinterpret_cast<const STX_GAS v8h16*>(hq + c0 + 10);
                 f[0] = (float)a.x; f[1] = (float)a.y;
@@ -722,17 +859,7 @@ __global__ __launch_bounds__(256) void mb_down_lds_kernel(const StxMbImage* __re
 #pragma unroll
             for (int j = 0; j < 19; j++) f[j] = wq[reflect101_near(c0 + j, iw)];
         }
-        float4 lo, hi;
-        lo.x = h5f(f[0], f[1], f[2], f[3], f[4]);
-        lo.y = h5f(f[2], f[3], f[4], f[5], f[6]);
-        lo.z = h5f(f[4], f[5], f[6], f[7], f[8]);
-        lo.w = h5f(f[6], f[7], f[8], f[9], f[10]);
-        hi.x = h5f(f[8], f[9], f[10], f[11], f[12]);
-        hi.y = h5f(f[10], f[11], f[12], f[13], f[14]);
-        hi.z = h5f(f[12], f[13], f[14], f[15], f[16]);
-        hi.w = h5f(f[14], f[15], f[16], f[17], f[18]);
-        *reinterpret_cast<float4*>(&s_w[r][4 * q]) = make_float4(lo.x, lo.z, hi.x, hi.z);
-        *reinterpret_cast<float4*>(&s_w[r][32 + 4 * q]) = make_float4(lo.y, lo.w, hi.y, hi.w);
+        dn_hsum_store_f(f, &s_w[r][4 * q]);
     }
     __syncthreads();
     const int p = tid & 31, rg = tid >> 5;
