@@ -490,6 +490,9 @@ STX_DEV void dn_note_occ(uint8_t* __restrict__ occ, uint32_t nzbits, int tid, in
     occ[(long long)((Y0 >> 1) + rg) * occ_pitch(ow) + (X0 >> 6)] = half != 0u ? 1 : 0;
 }
 
+#ifndef STX_DN0_BATCH
+#define STX_DN0_BATCH 1
+#endif
 // blockIdx.z = image: all fed images are processed by one launch (deferred pyramid build)
 template <bool PK>
 __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __restrict__ images, StxTileMap M)
@@ -535,7 +538,7 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
     // rows r and r + 16 — take their seven image loads and two mask loads in ONE batch.  The task loop below makes four dependent memory
     // round trips of them (image, then the mask behind its row test; twice) in front of the workgroup's barrier.
     bool batched = false;
-    if (PK && near) {
+    if (STX_DN0_BATCH && PK && near) {
         const int q = tid & 15, rA = tid >> 4;
         const int xo = X0 + 4 * q, c0 = 2 * xo - 2, a0 = c0 - D.left;
         const bool col_ok = xo < ow;
