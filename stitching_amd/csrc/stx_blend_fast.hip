@@ -490,8 +490,9 @@ STX_DEV void dn_note_occ(uint8_t* __restrict__ occ, uint32_t nzbits, int tid, in
     occ[(long long)((Y0 >> 1) + rg) * occ_pitch(ow) + (X0 >> 6)] = half != 0u ? 1 : 0;
 }
 
+// bit 0: the binary-mask instantiation, bit 1: the grey-mask one
 #ifndef STX_DN0_BATCH
-#define STX_DN0_BATCH 1
+#define STX_DN0_BATCH 3
 #endif
 // blockIdx.z = image: all fed images are processed by one launch (deferred pyramid build)
 template <bool PK>
@@ -534,17 +535,22 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
     // uniform for the workgroup: which form of the border index maps this image needs (dn_task_level0)
     const bool near = PK ? (D.left <= D.iw && D.fw - D.left - D.iw <= D.iw && D.top <= D.ih && D.fh - D.top - D.ih <= D.ih)
                          : (im.left <= im.iw && im.fw - im.left - im.iw <= im.iw && im.top <= im.ih && im.fh - im.top - im.ih <= im.ih);
-    // (round 6) Binary masks, every 11-pixel run of the wavefront inside the image: a lane's TWO tasks — the same column group q in the
-    // rows r and r + 16 — take their seven image loads and two mask loads in ONE batch.  The task loop below makes four dependent memory
-    // round trips of them (image, then the mask behind its row test; twice) in front of the workgroup's barrier.
+    // (round 6) Every 11-pixel run of the wavefront either inside the image or wholly inside the left / right frame one mirror image away
+    // (the two forms dn_task_level0 serves with four vector loads): a lane's TWO tasks — the same column group q in the rows r and r + 16 —
+    // take their six image loads and two mask loads in ONE batch.  The task loop below makes four dependent memory round trips of them
+    // (image, then the mask behind its row test; twice) in front of the workgroup's barrier.
     bool batched = false;
-    if (STX_DN0_BATCH && PK && near) {
+    if ((STX_DN0_BATCH & (PK ? 1 : 2)) && near) {
         const int q = tid & 15, rA = tid >> 4;
         const int xo = X0 + 4 * q, c0 = 2 * xo - 2, a0 = c0 - D.left;
         const bool col_ok = xo < ow;
-        const bool interior = c0 >= 0 && c0 + 10 < D.fw && a0 >= 0 && a0 + 10 < D.iw;
-        batched = __builtin_amdgcn_ballot_w64(col_ok && !interior) == 0ull;  // wave-uniform; the four wavefronts decide for themselves
+        const bool in_frame = c0 >= 0 && c0 + 10 < D.fw;
+        const bool interior = in_frame && a0 >= 0 && a0 + 10 < D.iw;
+        const int s_low = a0 + 10 < 0 ? -(a0 + 10) - 1 : 2 * D.iw - 1 - (a0 + 10);  // a run in the frame: the source column of its LAST pixel = the lowest
+        const bool mirrored = in_frame && (a0 + 10 < 0 || a0 >= D.iw) && s_low >= 0 && s_low + 10 < D.iw;
+        batched = __builtin_amdgcn_ballot_w64(col_ok && !(interior || mirrored)) == 0ull;  // wave-uniform; the four wavefronts decide for themselves
         if (batched && col_ok) {
+            const int acol = interior ? a0 : s_low;  // first image column of the 11 that are loaded
             v4u d0[2], d1[2], mq4[2];
             v2u d2[2];
             uint32_t sh[2], msh[2];
@@ -557,13 +563,14 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
                 const int by = reflect101_near(row, D.fh) - D.top;
                 yin[t] = (unsigned)by < (unsigned)D.ih;
                 const int sy = reflect_near(by, D.ih);
-                const uint32_t off = (uint32_t)sy * D.img0_stride + (uint32_t)a0 * 3u;
+                const uint32_t off = (uint32_t)sy * (uint32_t)D.img0_stride + (uint32_t)acol * 3u;
                 const STX_GAS uint8_t* p = gp(D.img0) + (off & ~3u);
                 sh[t] = off & 3u;
                 d0[t] = *reinterpret_cast<const STX_GAS v4u_a4*>(p);
                 d1[t] = *reinterpret_cast<const STX_GAS v4u_a4*>(p + 16);
                 d2[t] = *reinterpret_cast<const STX_GAS v2u_a4*>(p + 32);
-                const uint32_t moff = (uint32_t)min(max(by, 0), D.ih - 1) * D.mask0_stride + (uint32_t)a0;  // 11 bytes (cleared below when !yin)
+                // the mask's 11 bytes (cleared below for a row outside the image and for a run in the frame: the weight's border is CONSTANT 0)
+                const uint32_t moff = (uint32_t)min(max(by, 0), D.ih - 1) * (uint32_t)D.mask0_stride + (uint32_t)acol;
                 msh[t] = moff & 3u;
                 mq4[t] = *reinterpret_cast<const STX_GAS v4u_a4*>(gp(D.mask0) + (moff & ~3u));
             }
@@ -582,20 +589,44 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
                 w[6] = __builtin_amdgcn_alignbyte(d1[t].w, d1[t].z, sh[t]);
                 w[7] = __builtin_amdgcn_alignbyte(d2[t].x, d1[t].w, sh[t]);
                 w[8] = __builtin_amdgcn_alignbyte(d2[t].y, d2[t].x, sh[t]);
-                dn_pack5_channel<false, 0>(w, &s_h[0][r][4 * q]);
-                dn_pack5_channel<false, 1>(w, &s_h[1][r][4 * q]);
-                dn_pack5_channel<false, 2>(w, &s_h[2][r][4 * q]);
-                const uint32_t keep = yin[t] ? 0x01010101u : 0u;  // 0 / 255 -> 0 / 1; a row outside the image: the weight's border is CONSTANT 0
-                uint32_t mb[3];
-                mb[0] = __builtin_amdgcn_alignbyte(mq4[t].y, mq4[t].x, msh[t]) & keep;
-                mb[1] = __builtin_amdgcn_alignbyte(mq4[t].z, mq4[t].y, msh[t]) & keep;
-                mb[2] = __builtin_amdgcn_alignbyte(mq4[t].w, mq4[t].z, msh[t]) & keep & 0x00ffffffu;
-                const pk16 o01 = pk(pair_u8<0, 2>(mb)) + pk(pair_u8<4, 6>(mb)) + pk(pair_u8<2, 4>(mb)) * pk_splat(6) +
-                                 (pk(pair_u8<1, 3>(mb)) + pk(pair_u8<3, 5>(mb))) * pk_splat(4);
-                const pk16 o23 = pk(pair_u8<4, 6>(mb)) + pk(pair_u8<8, 10>(mb)) + pk(pair_u8<6, 8>(mb)) * pk_splat(6) +
-                                 (pk(pair_u8<5, 7>(mb)) + pk(pair_u8<7, 9>(mb))) * pk_splat(4);
-                *reinterpret_cast<float4*>(&s_w[r][4 * q]) = make_float4((float)(unpk(o01) & 0xffffu), (float)(unpk(o01) >> 16),
-                                                                        (float)(unpk(o23) & 0xffffu), (float)(unpk(o23) >> 16));
+                if (interior) {
+                    dn_pack5_channel<false, 0>(w, &s_h[0][r][4 * q]);
+                    dn_pack5_channel<false, 1>(w, &s_h[1][r][4 * q]);
+                    dn_pack5_channel<false, 2>(w, &s_h[2][r][4 * q]);
+                } else {
+                    dn_pack5_channel<true, 0>(w, &s_h[0][r][4 * q]);
+                    dn_pack5_channel<true, 1>(w, &s_h[1][r][4 * q]);
+                    dn_pack5_channel<true, 2>(w, &s_h[2][r][4 * q]);
+                }
+                const uint32_t keep = (yin[t] && interior) ? 0xffffffffu : 0u;
+                uint32_t mw[3];
+                mw[0] = __builtin_amdgcn_alignbyte(mq4[t].y, mq4[t].x, msh[t]) & keep;
+                mw[1] = __builtin_amdgcn_alignbyte(mq4[t].z, mq4[t].y, msh[t]) & keep;
+                mw[2] = __builtin_amdgcn_alignbyte(mq4[t].w, mq4[t].z, msh[t]) & keep & 0x00ffffffu;
+                bool packed = PK;
+                if (!PK) {  // byte b is 0 or 255  <=>  b == 255 * (b >> 7); over the lanes of this task (see dn_task_level0)
+                    const uint32_t odd = (mw[0] ^ (((mw[0] >> 7) & 0x01010101u) * 255u)) | (mw[1] ^ (((mw[1] >> 7) & 0x01010101u) * 255u)) |
+                                         (mw[2] ^ (((mw[2] >> 7) & 0x01010101u) * 255u));
+                    packed = __builtin_amdgcn_ballot_w64(odd != 0u) == 0ull;
+                }
+                if (packed) {
+                    uint32_t mb[3];  // 0 / 255 -> 0 / 1: W_0 is exactly 0.f or 1.f, the fp32 row sums are small integers
+                    mb[0] = mw[0] & 0x01010101u;
+                    mb[1] = mw[1] & 0x01010101u;
+                    mb[2] = mw[2] & 0x01010101u;
+                    const pk16 o01 = pk(pair_u8<0, 2>(mb)) + pk(pair_u8<4, 6>(mb)) + pk(pair_u8<2, 4>(mb)) * pk_splat(6) +
+                                     (pk(pair_u8<1, 3>(mb)) + pk(pair_u8<3, 5>(mb))) * pk_splat(4);
+                    const pk16 o23 = pk(pair_u8<4, 6>(mb)) + pk(pair_u8<8, 10>(mb)) + pk(pair_u8<6, 8>(mb)) * pk_splat(6) +
+                                     (pk(pair_u8<5, 7>(mb)) + pk(pair_u8<7, 9>(mb))) * pk_splat(4);
+                    *reinterpret_cast<float4*>(&s_w[r][4 * q]) = make_float4((float)(unpk(o01) & 0xffffu), (float)(unpk(o01) >> 16),
+                                                                            (float)(unpk(o23) & 0xffffu), (float)(unpk(o23) >> 16));
+                } else {
+                    float f[11];
+#pragma unroll
+                    for (int j = 0; j < 11; j++) f[j] = fmul((float)byte_of(mw, j), INV255);
+#pragma unroll
+                    for (int o = 0; o < 4; o++) s_w[r][4 * q + o] = h5f(f[2 * o], f[2 * o + 1], f[2 * o + 2], f[2 * o + 3], f[2 * o + 4]);
+                }
             }
         }
     }
