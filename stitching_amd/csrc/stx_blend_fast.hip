@@ -27,6 +27,14 @@ namespace {
 #ifndef STX_L0_WAVES
 #define STX_L0_WAVES 5
 #endif
+// STX_L0_FULL = 1 (round 6, shipped): the level-0 gather issues EVERY load of an image in one batch — both pixel rows (a row outside the
+// image from the clamped row, its mask cleared), the pyrUp windows of the three planes — with the batched image search and the epilogue's
+// windows ahead in every instantiation: 92 registers = 5 wavefronts per SIMD instead of 80 = 6, and still 159.2 -> 147.9 us on config 2
+// (four interleaved runs, tools/gpu_r6w.sh), 176.7 -> 167.0 on the reference-default leg.  Each of the three alone, at 88-92 registers,
+// had measured slower than the plane-by-plane form at 80 (profiles/r06_round_trips.md): it is the whole chain that pays for the wavefront.
+#ifndef STX_L0_FULL
+#define STX_L0_FULL 1
+#endif
 constexpr float WEIGHT_EPS = 1e-5f;
 constexpr float INV255 = 0.0039215688593685627f;  // (float)(1./255.)
 constexpr float INV256 = 0.00390625f;
@@ -1740,7 +1748,7 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(STX_
             // dependent loads, each behind its own branch (see mb_level_pk_kernel)
             // (round 6) size and corner of the lane's image as ONE 16-byte load and tests without short circuits (`&&` had become three
             // dependent loads, each behind its own branch: see mb_level_pk_kernel) — where its 8 registers are free (see level0_epilogue_pk)
-            if (DEFER || CONTRIB) {
+            if (DEFER || CONTRIB || STX_L0_FULL) {
                 const StxMbImage& im = P.images[min(kk, P.n_images - 1)];
                 const v4u f = *reinterpret_cast<const v4u_a4*>(&im.iw);  // iw, ih, ix, iy
                 const v4u ff = *reinterpret_cast<const v4u_a4*>(&im.fx);  // fx, fy, fw, fh
@@ -1798,6 +1806,21 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(STX_
             if (lx0 + 8 <= 0 || lx0 >= i_iw || ly0 + 2 <= 0 || ly0 >= i_ih) continue;
             // lanes partly left / right of the image take the same aligned loads (load_px8_u8): no per-pixel path
             uint32_t pw_[2][6], mw[2][2];
+#if STX_L0_FULL
+            // every load of the image in one batch: both pixel rows (clamped row, mask cleared when outside) and the pyrUp windows of the planes
+            const uint32_t g1_boff_f = (uint32_t)((X0 - i_fx) >> 1);
+            v3u win[3][3];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int ly = ly0 + r;
+                const uint32_t rm = (unsigned)ly < (unsigned)i_ih ? 0xffffffffu : 0u;
+                load_px8_u8((const uint8_t*)I_a, ist, (const uint8_t*)M_a, mst, lx0, min(max(ly, 0), i_ih - 1), rm, rm, pw_[r], mw[r]);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                up_patch_pk_load(gp(reinterpret_cast<const uint8_t*>(G1_a)) + (uint32_t)c * g1p, g1s, i_fh >> 1, g1_boff_f, (Y0 - i_fy) >> 1, win[c]);
+            __builtin_amdgcn_sched_barrier(0);
+#else
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 const int ly = ly0 + r;
@@ -1807,6 +1830,7 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(STX_
                 if ((unsigned)ly >= (unsigned)i_ih) continue;
                 load_px8_u8((const uint8_t*)I_a, ist, (const uint8_t*)M_a, mst, lx0, ly, 0xffffffffu, 0xffffffffu, pw_[r], mw[r]);
             }
+#endif
             {   // mask bytes of the pixels outside the image: cleared (after the loads: two registers less while they are in flight)
                 uint32_t vm0, vm1;
                 lane_valid_bytes(lx0, i_iw, vm0, vm1);
@@ -1840,7 +1864,11 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(STX_
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 pk16 up[2][4];
+#if STX_L0_FULL
+                up_patch_pk_math(win[c], g1_sel, up);
+#else
                 up_patch_pk(gp(reinterpret_cast<const uint8_t*>(G1_a)) + (uint32_t)c * g1p, g1s, i_fh >> 1, g1_boff, (Y0 - i_fy) >> 1, g1_sel, up);
+#endif
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
                     uint32_t px[4];
@@ -1890,7 +1918,7 @@ __global__ __launch_bounds__(LV_THREADS) __attribute__((amdgpu_waves_per_eu(STX_
         cnt[r][2] = pair_u8<1, 3>(cntb[r]);
         cnt[r][3] = pair_u8<5, 7>(cntb[r]);
     }
-    level0_epilogue_pk<false, DEFER || CONTRIB>(P, X0, Y0, acc, cnt, nullptr);
+    level0_epilogue_pk<false, DEFER || CONTRIB || STX_L0_FULL>(P, X0, Y0, acc, cnt, nullptr);
 }
 
 
