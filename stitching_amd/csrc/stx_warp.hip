@@ -35,6 +35,9 @@ constexpr int WARP_TH = 4;    // tile height (4 waves x 1 row)
 // sample loads could not be waited for without also waiting for the first block's stores.  Round 4 samples every block before the first
 // result leaves (the stores follow the loop): 179.4 / 182.8 us with 2 blocks against 177.5 / 178.1 with 1 — the diagnosis was right and
 // the prologue it saves is worth nothing measurable.  1 it stays (-DSTX_WARP_IT=2 builds the other).
+#ifndef STX_WARP_GAIN_EARLY
+#define STX_WARP_GAIN_EARLY 1
+#endif
 #ifndef STX_WARP_IT
 #define STX_WARP_IT 1
 #endif
@@ -654,6 +657,21 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
         if (TYPE == STX_WARP_CYLINDRICAL) { r2 = fmul(P.kr[2], ct.y); r5 = fmul(P.kr[5], ct.y); r8 = fmul(P.kr[8], ct.y); }
         else { r2 = P.c2; r5 = P.c5; r8 = P.c8; }
     }
+    // GAIN (round 6): the two gain rows of the position this lane STORES in the epilogue (row y0 + (lane >> 4), columns xw + 4 (lane & 15) ..)
+    // are fetched here, behind the tables, and wait under the projector and the gathers.  Fetched in the epilogue — row table entry, then
+    // the two rows it names — they were two more dependent memory round trips at the end of every wavefront: the fused gain cost +58 us
+    // on a 170 us kernel for arithmetic worth a fifth of that (STX_WARP_GAIN_EARLY=0 builds that form).
+    float4 g_u = make_float4(0.f, 0.f, 0.f, 0.f), g_v = g_u;
+    float g_b1 = 0.f;
+    if (GAIN && WARP_IT == 1 && STX_WARP_GAIN_EARLY) {
+        const int er = lane >> 4, ec = lane & 15;
+        const int2 ty = P.g_yt[min(tile_y * WARP_TH + er, dh - 1)];
+        g_b1 = __int_as_float(ty.y);
+        const int r0 = min(max(ty.x, 0), P.g_gh - 1), r1 = min(max(ty.x + 1, 0), P.g_gh - 1);
+        const int colq = min(xw + 4 * ec, (int)P.g_hstride - 4);  // (columns in the row pitch beyond the image: any gain will do)
+        g_u = *reinterpret_cast<const float4*>(P.g_H + (long long)r0 * P.g_hstride + colq);
+        g_v = *reinterpret_cast<const float4*>(P.g_H + (long long)r1 * P.g_hstride + colq);
+    }
     const STX_GAS uint8_t* src = (const STX_GAS uint8_t*)src_a;
     uint8_t* const lpx0 = reinterpret_cast<uint8_t*>(&s_px[wv][0][0]) + lane * 3;  // + 192 per row, + channel
     uint8_t* const lmk0 = reinterpret_cast<uint8_t*>(&s_mk[wv][0][0]) + lane;      // + 64 per row
@@ -880,12 +898,19 @@ __global__ __launch_bounds__(WARP_FW) __attribute__((amdgpu_waves_per_eu(8, 8)))
             uint32_t a0 = sp[0], a1 = sp[1], a2 = sp[2];
             if (GAIN) {
                 // this lane's 4 pixels: columns xw + 4 c .. + 3 of row y0 + r.  g = H[r0][x] b0 + H[r1][x] b1 as cv::resize(INTER_LINEAR) rounds it
-                const int2 ty = P.g_yt[y0 + r];
-                const float b1 = __int_as_float(ty.y), b0 = fsub(1.f, b1);
-                const int r0 = min(max(ty.x, 0), P.g_gh - 1), r1 = min(max(ty.x + 1, 0), P.g_gh - 1);
-                const int colq = min(xw + 4 * c, (int)P.g_hstride - 4);  // (columns in the row pitch beyond the image: any gain will do)
-                const float4 u = *reinterpret_cast<const float4*>(P.g_H + (long long)r0 * P.g_hstride + colq);
-                const float4 v = *reinterpret_cast<const float4*>(P.g_H + (long long)r1 * P.g_hstride + colq);
+                float4 u, v;
+                float b1;
+                if (WARP_IT == 1 && STX_WARP_GAIN_EARLY) {  // fetched behind the tables (see there)
+                    u = g_u; v = g_v; b1 = g_b1;
+                } else {
+                    const int2 ty = P.g_yt[y0 + r];
+                    b1 = __int_as_float(ty.y);
+                    const int r0 = min(max(ty.x, 0), P.g_gh - 1), r1 = min(max(ty.x + 1, 0), P.g_gh - 1);
+                    const int colq = min(xw + 4 * c, (int)P.g_hstride - 4);  // (columns in the row pitch beyond the image: any gain will do)
+                    u = *reinterpret_cast<const float4*>(P.g_H + (long long)r0 * P.g_hstride + colq);
+                    v = *reinterpret_cast<const float4*>(P.g_H + (long long)r1 * P.g_hstride + colq);
+                }
+                const float b0 = fsub(1.f, b1);
                 const float g[4] = {fadd(fmul(u.x, b0), fmul(v.x, b1)), fadd(fmul(u.y, b0), fmul(v.y, b1)), fadd(fmul(u.z, b0), fmul(v.z, b1)),
                                     fadd(fmul(u.w, b0), fmul(v.w, b1))};
                 const uint32_t in[3] = {a0, a1, a2};
