@@ -32,6 +32,11 @@ namespace {
 // windows ahead in every instantiation: 92 registers = 5 wavefronts per SIMD instead of 80 = 6, and still 159.2 -> 147.9 us on config 2
 // (four interleaved runs, tools/gpu_r6w.sh), 176.7 -> 167.0 on the reference-default leg.  Each of the three alone, at 88-92 registers,
 // had measured slower than the plane-by-plane form at 80 (profiles/r06_round_trips.md): it is the whole chain that pays for the wavefront.
+// normalisation of the level-0 gather on integer counts (binary masks): bit 0 the packed shift form for counts <= 2, bit 1 the
+// one-multiplication form for counts < 16 (level0_epilogue_pk); 0 builds the shared-reciprocal IEEE division for every count above 1
+#ifndef STX_L0_NORM
+#define STX_L0_NORM 3
+#endif
 #ifndef STX_L0_FULL
 #define STX_L0_FULL 1
 #endif
@@ -372,6 +377,30 @@ STX_DEV void dn_pack5_channel(const uint32_t* w, short* hs)
     *reinterpret_cast<uint2*>(hs) = make_uint2(unpk(o01), unpk(o23));
 }
 
+// The four 1-4-6-4-1 row sums (stride 2) of 11 mask bits held as bytes 0 / 1 in mb[0..2] (byte 11 may hold anything); sums <= 16: exact
+// as floats.  STX_DN0_DOT4 = 1 (round 6, visit ab): bytes are what v_dot4_u32_u8 multiplies — 8 dot products against constant weight
+// dwords where the packed 16-bit form takes 9 v_perm + 10 v_pk_*; measured SLOWER (mb_down0 108.1 / 109.7 / 110.1 -> 110.5 / 111.3 /
+// 113.7 us, three interleaved runs of config 2): the dot product does not issue at the rate of the packed instructions.  Default 0.
+#ifndef STX_DN0_DOT4
+#define STX_DN0_DOT4 0
+#endif
+STX_DEV float4 dn_mask_sums4(const uint32_t (&mb)[3])
+{
+#if STX_DN0_DOT4
+    const uint32_t o0 = __builtin_amdgcn_udot4(mb[0], 0x04060401u, mb[1] & 1u, false);                                      // bytes 0 .. 4
+    const uint32_t o1 = __builtin_amdgcn_udot4(mb[1], 0x00010406u, __builtin_amdgcn_udot4(mb[0], 0x04010000u, 0u, false), false);  // 2 .. 6
+    const uint32_t o2 = __builtin_amdgcn_udot4(mb[1], 0x04060401u, mb[2] & 1u, false);                                      // 4 .. 8
+    const uint32_t o3 = __builtin_amdgcn_udot4(mb[2], 0x00010406u, __builtin_amdgcn_udot4(mb[1], 0x04010000u, 0u, false), false);  // 6 .. 10
+    return make_float4((float)o0, (float)o1, (float)o2, (float)o3);
+#else
+    const pk16 o01 = pk(pair_u8<0, 2>(mb)) + pk(pair_u8<4, 6>(mb)) + pk(pair_u8<2, 4>(mb)) * pk_splat(6) +
+                     (pk(pair_u8<1, 3>(mb)) + pk(pair_u8<3, 5>(mb))) * pk_splat(4);
+    const pk16 o23 = pk(pair_u8<4, 6>(mb)) + pk(pair_u8<8, 10>(mb)) + pk(pair_u8<6, 8>(mb)) * pk_splat(6) +
+                     (pk(pair_u8<5, 7>(mb)) + pk(pair_u8<7, 9>(mb))) * pk_splat(4);
+    return make_float4((float)(unpk(o01) & 0xffffu), (float)(unpk(o01) >> 16), (float)(unpk(o23) & 0xffffu), (float)(unpk(o23) >> 16));
+#endif
+}
+
 // level 0 (u8 BGR + u8 mask): 4 outputs from 11 input pixels
 // PK: every image of the launch is u8 with a 0 / 255 mask (decided on the host: no per-task branch in the kernel)
 // NEAR: the border of the image inside its feed rectangle is narrower than the image (left, right <= iw, top, bottom <= ih: every
@@ -431,12 +460,7 @@ STX_DEV void dn_task_level0(const IM& im, int row, int xo, short* hs0, short* hs
             mb[0] = mw[0] & 0x01010101u;
             mb[1] = mw[1] & 0x01010101u;
             mb[2] = mw[2] & 0x01010101u;
-            const pk16 o01 = pk(pair_u8<0, 2>(mb)) + pk(pair_u8<4, 6>(mb)) + pk(pair_u8<2, 4>(mb)) * pk_splat(6) +
-                             (pk(pair_u8<1, 3>(mb)) + pk(pair_u8<3, 5>(mb))) * pk_splat(4);
-            const pk16 o23 = pk(pair_u8<4, 6>(mb)) + pk(pair_u8<8, 10>(mb)) + pk(pair_u8<6, 8>(mb)) * pk_splat(6) +
-                             (pk(pair_u8<5, 7>(mb)) + pk(pair_u8<7, 9>(mb))) * pk_splat(4);
-            *reinterpret_cast<float4*>(hw) = make_float4((float)(unpk(o01) & 0xffffu), (float)(unpk(o01) >> 16),
-                                                         (float)(unpk(o23) & 0xffffu), (float)(unpk(o23) >> 16));
+            *reinterpret_cast<float4*>(hw) = dn_mask_sums4(mb);
             return;
         }
 #pragma unroll
@@ -622,12 +646,7 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
                     mb[0] = mw[0] & 0x01010101u;
                     mb[1] = mw[1] & 0x01010101u;
                     mb[2] = mw[2] & 0x01010101u;
-                    const pk16 o01 = pk(pair_u8<0, 2>(mb)) + pk(pair_u8<4, 6>(mb)) + pk(pair_u8<2, 4>(mb)) * pk_splat(6) +
-                                     (pk(pair_u8<1, 3>(mb)) + pk(pair_u8<3, 5>(mb))) * pk_splat(4);
-                    const pk16 o23 = pk(pair_u8<4, 6>(mb)) + pk(pair_u8<8, 10>(mb)) + pk(pair_u8<6, 8>(mb)) * pk_splat(6) +
-                                     (pk(pair_u8<5, 7>(mb)) + pk(pair_u8<7, 9>(mb))) * pk_splat(4);
-                    *reinterpret_cast<float4*>(&s_w[r][4 * q]) = make_float4((float)(unpk(o01) & 0xffffu), (float)(unpk(o01) >> 16),
-                                                                            (float)(unpk(o23) & 0xffffu), (float)(unpk(o23) >> 16));
+                    *reinterpret_cast<float4*>(&s_w[r][4 * q]) = dn_mask_sums4(mb);
                 } else {
                     float f[11];
 #pragma unroll
@@ -1594,6 +1613,10 @@ STX_DEV void level0_epilogue_pk(const MbLevelK& P, int X0, int Y0, uint32_t (&ac
     // ---- normalizeUsingWeightMap
     uint32_t v[2][3][4];
     const uint32_t anyc = (cnt[0][0] | cnt[0][1] | cnt[0][2] | cnt[0][3]) | (cnt[1][0] | cnt[1][1] | cnt[1][2] | cnt[1][3]);
+    // every count + 1 ORed: no bit above 2 set <=> every count <= 2 (the counts are below 256: no carry between the halves)
+    const uint32_t k11 = 0x00010001u;
+    const uint32_t cnt3 = ((cnt[0][0] + k11) | (cnt[0][1] + k11) | (cnt[0][2] + k11) | (cnt[0][3] + k11)) |
+                          ((cnt[1][0] + k11) | (cnt[1][1] + k11) | (cnt[1][2] + k11) | (cnt[1][3] + k11));
     if (!WF && (anyc & 0xfffefffeu) == 0u) {
 #pragma unroll
         for (int r = 0; r < 2; r++)
@@ -1604,7 +1627,28 @@ STX_DEV void level0_epilogue_pk(const MbLevelK& P, int X0, int Y0, uint32_t (&ac
                     const pk16s a = pks(acc[r][c][q]);
                     v[r][c][q] = unpks(a - __builtin_elementwise_min(__builtin_elementwise_max(a, pks(k_m1)), pks(k_p1)));  // a - sign(a)
                 }
+    } else if (!WF && (STX_L0_NORM & 1) && (cnt3 & 0xfffcfffcu) == 0u) {
+        // (round 6) at most TWO images over every pixel of the lane — all an un-pitched ring ever has.  For an integer count n <= 16 and
+        // |a| <= 32768, (int)(a / (n + 1e-5f)) = trunc((a - sign(a)) / n): the quotient falls short of a / n by a * 1e-5 / n^2 < 1 / n,
+        // 40+ ulps when a / n is an integer (tests/test_host_logic.py checks every a and n against IEEE division).  For n = 1, 2 that
+        // is a shift in the packed lanes: 7 VALU per pixel pair and channel where the shared-reciprocal division takes ~18.
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const pk16 h = pk(cnt[r][q]) >> pk_splat(1);  // 1 where two images cover the pixel (a is 0 where none does)
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const pk16s a0 = pks(acc[r][c][q]);
+                    const pk16s a = a0 - __builtin_elementwise_min(__builtin_elementwise_max(a0, pks(k_m1)), pks(k_p1));
+                    const pk16 neg = pk(unpks(a)) >> pk_splat(15);
+                    v[r][c][q] = unpks(pks(unpk(pk(unpks(a)) + (neg & h))) >> pks(unpk(h)));  // towards zero
+                }
+            }
     } else {
+        // (round 6) integer counts below 16: the same quotients from ONE multiplication by v_rcp_f32's reciprocal (1 ulp) — the distance
+        // of a / (n + 1e-5f) to the next integer is 1000 x the error of the product (checked for every a, n <= 30 and reciprocals 2 ulps off)
+        const bool small = !WF && (STX_L0_NORM & 2) && (anyc & 0xfff0fff0u) == 0u;
 #pragma unroll
         for (int r = 0; r < 2; r++)
 #pragma unroll
@@ -1615,10 +1659,15 @@ STX_DEV void level0_epilogue_pk(const MbLevelK& P, int X0, int Y0, uint32_t (&ac
                     // pair q = pixels (j0, j0 + 2), j0 = 0, 4, 1, 5
                     const float den = WF ? fadd(ws[r][(q & 1) * 4 + (q >> 1) + 2 * hf], WEIGHT_EPS)
                                          : fadd((float)(hf ? (cnt[r][q] >> 16) : (cnt[r][q] & 0xffffu)), WEIGHT_EPS);
+                    const float n0 = (float)(hf ? s16hi(acc[r][0][q]) : s16lo(acc[r][0][q])), n1 = (float)(hf ? s16hi(acc[r][1][q]) : s16lo(acc[r][1][q])),
+                                n2 = (float)(hf ? s16hi(acc[r][2][q]) : s16lo(acc[r][2][q]));
                     float q0, q1, q2;
-                    div3_shared(den, (float)(hf ? s16hi(acc[r][0][q]) : s16lo(acc[r][0][q])),
-                                (float)(hf ? s16hi(acc[r][1][q]) : s16lo(acc[r][1][q])),
-                                (float)(hf ? s16hi(acc[r][2][q]) : s16lo(acc[r][2][q])), q0, q1, q2);
+                    if (small) {
+                        const float rr = __builtin_amdgcn_rcpf(den);
+                        q0 = fmul(n0, rr); q1 = fmul(n1, rr); q2 = fmul(n2, rr);
+                    } else {
+                        div3_shared(den, n0, n1, n2, q0, q1, q2);
+                    }
                     o[hf][0] = trunc_small(q0); o[hf][1] = trunc_small(q1); o[hf][2] = trunc_small(q2);
                 }
 #pragma unroll

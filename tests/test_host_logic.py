@@ -517,3 +517,40 @@ def test_sharded_job_notices_new_gains_and_seam_masks():
     job.seam_masks = [np.ones((3, 3), np.uint8)]  # assigned behind the setter's back: noticed by identity
     job._refresh_inputs()
     assert calls == [1, 1, 1]
+
+
+def test_level0_normalisation_closed_forms_equal_ieee_division():
+    """csrc/stx_blend_fast.hip level0_epilogue_pk (round 6): with binary masks the weight sum of a level-0 sample is an integer count n,
+    and normalizeUsingWeightMap's (short)(a / (n + 1e-5f)) is (a) trunc((a - sign(a)) / n) — a shift in packed 16-bit lanes for n <= 2 —
+    and (b) the truncated product with v_rcp_f32's reciprocal (1 ulp; 2 ulps allowed here) for n < 16.  Every int16 a, every n."""
+    a = np.arange(-32768, 32768, dtype=np.int32)
+    eps = np.float32(1e-5)
+    for n in range(1, 17):
+        den = np.float32(n) + eps
+        want = np.trunc(a.astype(np.float32) / den).astype(np.int32)  # IEEE fp32 division, (int) truncates
+        b = a - np.sign(a)
+        assert np.array_equal(want, np.sign(b) * (np.abs(b) // n)), n
+        if n <= 2:  # the packed form: (b + (b < 0 and n == 2)) >> (n >> 1), arithmetic
+            h = n >> 1
+            assert np.array_equal(want, (b + ((b < 0) & (h == 1))) >> h), n
+        r0 = np.float32(1) / den
+        for r in (r0, np.nextafter(r0, np.float32(9)), np.nextafter(r0, np.float32(-9)),
+                  np.nextafter(np.nextafter(r0, np.float32(9)), np.float32(9)), np.nextafter(np.nextafter(r0, np.float32(-9)), np.float32(-9))):
+            assert np.array_equal(want, np.trunc(a.astype(np.float32) * np.float32(r)).astype(np.int32)), (n, r)
+
+
+def test_pyrdown_mask_row_sums_as_byte_dot_products():
+    """csrc/stx_blend_fast.hip dn_mask_sums4 (round 6): the four stride-2 1-4-6-4-1 sums of 11 mask bits as eight 4-byte dot products
+    against constant weight dwords — the weight dwords below are the kernel's."""
+    rng = np.random.default_rng(5)
+    w_a, w_b, w_c = 0x04060401, 0x00010406, 0x04010000
+
+    def dot4(x, w, c):
+        return sum(((x >> (8 * k)) & 255) * ((w >> (8 * k)) & 255) for k in range(4)) + c
+
+    for _ in range(2000):
+        bits = rng.integers(0, 2, 12)
+        mb = [int(sum(int(bits[4 * i + k]) << (8 * k) for k in range(4))) for i in range(3)]
+        got = [dot4(mb[0], w_a, mb[1] & 1), dot4(mb[1], w_b, dot4(mb[0], w_c, 0)), dot4(mb[1], w_a, mb[2] & 1), dot4(mb[2], w_b, dot4(mb[1], w_c, 0))]
+        want = [int(bits[2 * o] + 4 * bits[2 * o + 1] + 6 * bits[2 * o + 2] + 4 * bits[2 * o + 3] + bits[2 * o + 4]) for o in range(4)]
+        assert got == want
