@@ -522,6 +522,9 @@ STX_DEV void dn_note_occ(uint8_t* __restrict__ occ, uint32_t nzbits, int tid, in
     occ[(long long)((Y0 >> 1) + rg) * occ_pitch(ow) + (X0 >> 6)] = half != 0u ? 1 : 0;
 }
 
+#ifndef STX_DN0_REV
+#define STX_DN0_REV 1
+#endif
 // bit 0: the binary-mask instantiation, bit 1: the grey-mask one
 #ifndef STX_DN0_BATCH
 #define STX_DN0_BATCH 3
@@ -532,11 +535,16 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
 {
     __shared__ __attribute__((aligned(16))) short s_h[3][DN_ROWS][DN_TOW];  // horizontal sums, <= 255*16
     __shared__ __attribute__((aligned(16))) float s_w[DN_ROWS][DN_TOW];
-    const StxMbImage& im = images[blockIdx.z];
+    // (round 6, STX_DN0_REV) The launch walks the images and their tiles in the REVERSE of the order the batched warp wrote them: the
+    // warped images of a panorama (317 MB on config 2) are a little more than the 256 MB Infinity Cache holds, so a second pass in the
+    // same order finds every line evicted just before it asks for it, while the reverse pass starts on what was written last.
+    // (gridDim.x - 1 - b keeps b mod 8: the tiles of a band still meet on one XCD.)
+    const uint32_t zz = STX_DN0_REV ? gridDim.z - 1u - blockIdx.z : blockIdx.z, bb = STX_DN0_REV ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+    const StxMbImage& im = images[zz];
     const int tid = threadIdx.x;
     const int ow = im.fw >> 1, oh = im.fh >> 1;
     int tile_tx, tile_ty;
-    if (!xcd_tile(M, blockIdx.x, tile_tx, tile_ty)) return;
+    if (!xcd_tile(M, bb, tile_tx, tile_ty)) return;
     const int X0 = tile_tx * DN_TOW, Y0 = tile_ty * DN_TOH;
     if (im.img0_is_s16 || X0 >= ow || Y0 >= oh) return;  // int16 sources take the generic kernel
     uint8_t* const occ = im.occ[1];
