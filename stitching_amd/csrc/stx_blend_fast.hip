@@ -37,6 +37,9 @@ namespace {
 #ifndef STX_L0_NORM
 #define STX_L0_NORM 3
 #endif
+#ifndef STX_ABLATE_MASK
+#define STX_ABLATE_MASK 0
+#endif
 #ifndef STX_L0_FULL
 #define STX_L0_FULL 1
 #endif
@@ -284,6 +287,10 @@ STX_DEV void load_px8_u8(const uint8_t* img0, uint32_t img0_stride, const uint8_
     pw[3] = __builtin_amdgcn_alignbyte(d1.x, d0.w, s);
     pw[4] = __builtin_amdgcn_alignbyte(d1.y, d1.x, s);
     pw[5] = __builtin_amdgcn_alignbyte(d1.z, d1.y, s);
+#if STX_ABLATE_MASK
+    mw[0] = vm0; mw[1] = vm1;  // timing experiment only: every mask byte taken as 255
+    return;
+#endif
     const uint32_t moff = (uint32_t)ly * mask0_stride + (uint32_t)(lx0 + 64);
     const STX_GAS uint8_t* mq = gp(mask0) - 64 + (moff & ~3u);
     const uint32_t ms = moff & 3u;
@@ -612,7 +619,11 @@ __global__ __launch_bounds__(256) void mb_down0_lds_kernel(const StxMbImage* __r
                 // the mask's 11 bytes (cleared below for a row outside the image and for a run in the frame: the weight's border is CONSTANT 0)
                 const uint32_t moff = (uint32_t)min(max(by, 0), D.ih - 1) * (uint32_t)D.mask0_stride + (uint32_t)acol;
                 msh[t] = moff & 3u;
+#if STX_ABLATE_MASK
+                mq4[t] = v4u{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};  // timing experiment only
+#else
                 mq4[t] = *reinterpret_cast<const STX_GAS v4u_a4*>(gp(D.mask0) + (moff & ~3u));
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
