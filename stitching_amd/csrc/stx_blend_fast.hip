@@ -2395,7 +2395,14 @@ bool stx_fast_mb_down_batch(stx_ctx* ctx, const StxMbImage* d_images, const StxM
     // kernel time and equal end-to-end throughput (A/B on one box, two panoramas in flight: 116.1 / 116.9 against
     // 116.5 / 116.9 Gpix/s) — kept for the HBM traffic they leave to the co-running kernels.
     StxTileMap M = stx_tile_map((mw + DN_TOW - 1) / DN_TOW, (mh + DN_TOH - 1) / DN_TOH, DN_BAND);
-    M.plain = level >= 1;  // the bands save little on the small levels and cost level 1 -> 2 ~15 % (103 against 88 us)
+    // Levels 1 and 2 in XCD bands too (round 6, visits af / ag).  Round 4 had measured the bands 15 % SLOWER on level 1 -> 2 (103 against
+    // 88 us) and kept the plain row-major order from level 1 on, at 1.8 x the algorithmic bytes fetched; on the batched-load kernel of round 6
+    // the bands win: mb_down x 4 88.7 -> 80 us, value +1.0 %, latency 0.683 -> 0.66 ms (three interleaved runs; bands on the levels >= 3 as well
+    // change nothing more).  STX_DN_PLAIN_FROM = first level in plain order.
+#ifndef STX_DN_PLAIN_FROM
+#define STX_DN_PLAIN_FROM 3
+#endif
+    M.plain = level >= STX_DN_PLAIN_FROM;
     bool pk_ok = true;  // packed 16-bit row sums need u8 images with 0 / 255 masks
     for (int i = 0; i < n; i++) pk_ok = pk_ok && !h_images[i].img0_is_s16 && h_images[i].mask_binary;
     dim3 grid(stx_tile_grid(M), 1, n);
