@@ -484,3 +484,48 @@ def test_blend_sparse_masks_bit_exact(oracle, gpu_ctx, kind):
     g = helpers.run_pipeline(S.Warper, S.Blender, imgs, cams, blend_strength=6, masks_fn=fn)
     assert np.array_equal(g["pmask"], o["pmask"])
     assert np.array_equal(g["pano"], o["pano"]), int(np.count_nonzero(g["pano"] != o["pano"]))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 15, 16, 17, 40])
+def test_blend_many_images_over_the_same_pixels(oracle, gpu_ctx, n):
+    """n images stacked over the same panorama pixels with binary masks: the weight sum under a level-0 sample is an integer count up
+    to n, and level0_epilogue_pk (csrc/stx_blend_fast.hip, round 6) normalises without a division — a packed shift for counts <= 2, one
+    multiplication by v_rcp_f32's reciprocal below 16, the shared-reciprocal IEEE expansion from 16 on.  Extreme pixel values (0 / 255
+    checkerboards against flat images) drive the int16 Laplacian sums to both ends of their range; every tier against the oracle's
+    plain fp32 division, with counts that change inside a lane's 8 x 2 patch (ragged mask edges)."""
+    rng = np.random.default_rng(1000 + n)
+    w, h = 1100, 96
+    yy, xx = np.mgrid[0:h, 0:w]
+    imgs, masks, corners = [], [], []
+    for k in range(n):
+        kind = k % 4
+        if kind == 0:
+            im = np.where(((xx + yy + k) & 1)[..., None] == 1, 255, 0).astype(np.uint8).repeat(3, axis=2)
+        elif kind == 1:
+            im = np.full((h, w, 3), 255 if k % 8 == 1 else 0, np.uint8)
+        else:
+            im = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        m = np.full((h, w), 255, np.uint8)
+        x0, x1 = int(rng.integers(0, 200)), int(rng.integers(w - 200, w + 1))
+        m[:, :x0] = 0
+        m[:, x1:] = 0
+        ragged = rng.integers(0, 12, h)
+        for y in range(h):  # ragged left edge: the count changes from pixel to pixel within a lane's patch
+            m[y, x0:x0 + int(ragged[y])] = 0
+        if k % 5 == 4:
+            m[rng.integers(0, 2, (h, w)) == 0] = 0  # a salt-and-pepper mask
+        imgs.append(im)
+        masks.append(m)
+        corners.append((int(rng.integers(0, 9)) if k else 0, int(rng.integers(0, 5)) if k else 0))
+    sizes = [(w, h)] * n
+    ob, gb = oracle.Blender("multiband", 10), S.Blender("multiband", 10)  # 5 bands
+    ob.prepare(corners, sizes)
+    gb.prepare(corners, sizes)
+    for im, m, c in zip(imgs, masks, corners):
+        ob.blender.feed(im.astype(np.int16), m, c)
+        gb.feed(im, m, c)
+    o16, omask = ob.blender.blend()
+    pano, mask, p16 = gb.blender.blend(want_s16=True)
+    assert np.array_equal(np.asarray(mask), omask)
+    assert np.array_equal(np.asarray(p16), o16), int(np.count_nonzero(np.asarray(p16) != o16))
+    assert np.array_equal(np.asarray(pano), oracle.convert_scale_abs(o16))
